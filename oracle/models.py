@@ -1,0 +1,496 @@
+"""Oracle (TEST INFRASTRUCTURE): VAE / GMVAE forward, loss, gradients, Adam.
+
+PARITY UNPINNED (see ``oracle/__init__.py``): the reference graph cannot be
+executed in the build container, so this restatement follows the reference
+source line by line but is not checked against reference outputs.
+
+Restates, dtype-generically in torch on the CPU (float64 for parity/fixtures,
+float32 for ``bench.py``'s ``cpu_baseline``):
+
+* ``dense_layer`` / ``dense_layers``      scvae/models/utilities.py:38-126
+  (``tf.contrib.layers.fully_connected`` + ``batch_norm(center=True,
+  scale=False)``: epsilon 1e-3, decay 0.999, fused kernel => normalise with
+  the biased batch variance, update moving_variance with the unbiased one)
+* VAE graph                               scvae/models/variational_autoencoder.py:2219-2558
+* VAE loss                                scvae/models/variational_autoencoder.py:2560-2734
+* GMVAE graph                             scvae/models/gaussian_mixture_variational_autoencoder.py:2788-3221
+* GMVAE loss                              scvae/models/gaussian_mixture_variational_autoencoder.py:3223-3434
+* optimiser (clip-by-value +-1, TF Adam)  scvae/models/variational_autoencoder.py:2736-2770
+* ``log_reduce_exp``                      scvae/models/utilities.py:129-137
+
+Gradients come from torch autograd over these same formulas.
+"""
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Tuple
+
+import torch
+import torch.nn.functional as F
+
+from oracle import likelihoods as lk
+
+BN_EPSILON = 1e-3
+BN_DECAY = 0.999
+ADAM_BETA1 = 0.9
+ADAM_BETA2 = 0.999
+ADAM_EPSILON = 1e-8
+HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
+FLOAT32_MAX_HALF = 3.4028234663852886e38 / 2
+
+
+@dataclass
+class ModelConfig:
+    feature_size: int
+    latent_size: int = 2
+    hidden_sizes: Tuple[int, ...] = (100,)
+    likelihood: str = "poisson"
+    minibatch_normalisation: bool = True
+    n_iw: int = 1
+    n_mc: int = 1
+    kl_weight: float = 1.0
+    # GMVAE only
+    n_clusters: int = 1
+    free_nats_proportion: float = 0.0
+
+    @property
+    def heads(self):
+        return lk.LIKELIHOOD_PARAMETERS[self.likelihood]
+
+
+# --------------------------------------------------------------------------
+# parameter tables (names follow the reference's variable scopes,
+# SURVEY.md appendix B)
+# --------------------------------------------------------------------------
+
+def _dense_entries(scope, n_in, n_out, bn):
+    e = [(scope + "/DENSE/weights", (n_in, n_out)),
+         (scope + "/DENSE/biases", (n_out,))]
+    if bn:
+        e.append((scope + "/BATCH_NORM/beta", (n_out,)))
+    return e
+
+
+def vae_parameter_shapes(cfg):
+    bn = cfg.minibatch_normalisation
+    H = list(cfg.hidden_sizes)
+    n = len(H)
+    shapes = []
+    n_in = cfg.feature_size
+    for i, h in enumerate(H):
+        shapes += _dense_entries("ENCODER/{}".format(i + 1), n_in, h, bn)
+        n_in = h
+    shapes += _dense_entries("POSTERIOR/MU", n_in, cfg.latent_size, False)
+    shapes += _dense_entries("POSTERIOR/LOG_SIGMA", n_in, cfg.latent_size,
+                             False)
+    n_in = cfg.latent_size
+    # reverse_order=True: sizes reversed, scopes numbered n..1
+    for i, h in enumerate(H[::-1]):
+        shapes += _dense_entries("DECODER/{}".format(n - i), n_in, h, bn)
+        n_in = h
+    for p in cfg.heads:
+        shapes += _dense_entries("X_TILDE/" + p.upper(), n_in,
+                                 cfg.feature_size, False)
+    return OrderedDict(shapes)
+
+
+def gmvae_parameter_shapes(cfg):
+    bn = cfg.minibatch_normalisation
+    H = list(cfg.hidden_sizes)
+    K, L, Fs = cfg.n_clusters, cfg.latent_size, cfg.feature_size
+    shapes = []
+    n_in = Fs
+    for i, h in enumerate(H):
+        shapes += _dense_entries(
+            "Y/CATEGORICAL/ENCODER/LAYER_{}".format(i + 1), n_in, h, bn)
+        n_in = h
+    shapes += _dense_entries("Y/CATEGORICAL/LOGITS", n_in, K, False)
+    n_in = Fs + K
+    for i, h in enumerate(H):
+        shapes += _dense_entries(
+            "Z/Q/ENCODER/LAYER_{}".format(i + 1), n_in, h, bn)
+        n_in = h
+    shapes += _dense_entries("Z/Q/SOFTPLUS_GAUSSIAN/MEAN", n_in, L, False)
+    shapes += _dense_entries("Z/Q/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE", n_in, L,
+                             False)
+    shapes += _dense_entries("Z/P/SOFTPLUS_GAUSSIAN/MEAN", K, L, False)
+    shapes += _dense_entries("Z/P/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE", K, L,
+                             False)
+    n_in = L
+    for i, h in enumerate(H[::-1]):
+        shapes += _dense_entries(
+            "X/DECODER/LAYER_{}".format(i + 1), n_in, h, bn)
+        n_in = h
+    for p in cfg.heads:
+        shapes += _dense_entries("X/DISTRIBUTION/" + p.upper(), n_in, Fs,
+                                 False)
+    return OrderedDict(shapes)
+
+
+def init_parameters(shapes, seed=0, dtype=torch.float64):
+    """Glorot-uniform weights, zero biases/beta (tf.contrib defaults)."""
+    g = torch.Generator().manual_seed(seed)
+    params = OrderedDict()
+    for name, shape in shapes.items():
+        if name.endswith("weights"):
+            limit = math.sqrt(6.0 / (shape[0] + shape[1]))
+            w = (torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1)
+            params[name] = (w * limit).to(dtype)
+        else:
+            params[name] = torch.zeros(shape, dtype=dtype)
+    return params
+
+
+def init_moving_statistics(shapes, dtype=torch.float64):
+    stats = OrderedDict()
+    for name, shape in shapes.items():
+        if name.endswith("BATCH_NORM/beta"):
+            base = name[:-len("beta")]
+            stats[base + "moving_mean"] = torch.zeros(shape, dtype=dtype)
+            stats[base + "moving_variance"] = torch.ones(shape, dtype=dtype)
+    return stats
+
+
+# --------------------------------------------------------------------------
+# layers
+# --------------------------------------------------------------------------
+
+def dense_layer(x, params, scope, bn, training, moving, new_moving,
+                activation=True, extra_row=None):
+    """utilities.py:38-76.  ``extra_row`` adds one weight row (GMVAE one-hot
+    input column) to the affine map."""
+    W = params[scope + "/DENSE/weights"]
+    b = params[scope + "/DENSE/biases"]
+    if extra_row is None:
+        a = x @ W + b
+    else:
+        n_x = x.shape[1]
+        a = x @ W[:n_x] + W[n_x + extra_row] + b
+    if bn:
+        beta = params[scope + "/BATCH_NORM/beta"]
+        mkey = scope + "/BATCH_NORM/moving_mean"
+        vkey = scope + "/BATCH_NORM/moving_variance"
+        if training:
+            n = a.shape[0]
+            mean = a.mean(dim=0)
+            centred = a - mean
+            var = (centred * centred).mean(dim=0)
+            a = centred * torch.rsqrt(var + BN_EPSILON) + beta
+            if new_moving is not None:
+                mm = new_moving.get(mkey, moving[mkey])
+                mv = new_moving.get(vkey, moving[vkey])
+                unbiased = var.detach() * (n / max(n - 1, 1))
+                new_moving[mkey] = mm - (mm - mean.detach()) * (1 - BN_DECAY)
+                new_moving[vkey] = mv - (mv - unbiased) * (1 - BN_DECAY)
+        else:
+            a = ((a - moving[mkey])
+                 * torch.rsqrt(moving[vkey] + BN_EPSILON) + beta)
+    if activation:
+        a = torch.relu(a)
+    return a
+
+
+def log_reduce_exp_mean(x, dim):
+    """utilities.py:129-137 with reduction_function = mean."""
+    m = x.max(dim=dim, keepdim=True).values
+    return (torch.log(torch.exp(x - m).mean(dim=dim, keepdim=True))
+            + m).squeeze(dim)
+
+
+def _normal_log_prob(z, mean, sigma):
+    return (-0.5 * ((z - mean) / sigma) ** 2 - torch.log(sigma)
+            - HALF_LOG_2PI)
+
+
+# --------------------------------------------------------------------------
+# VAE
+# --------------------------------------------------------------------------
+
+def vae_forward(cfg, params, moving, x, t, eps, training, warm_up_weight=1.0,
+                new_moving=None, deterministic_z=False, analytical_kl=True,
+                evaluation_statistics=False):
+    """One graph execution.  ``eps``: [S, B, L] standard-normal draws
+    (S = n_iw * n_mc, IW-major) or None with ``deterministic_z``."""
+    bn = cfg.minibatch_normalisation
+    H = list(cfg.hidden_sizes)
+    n = len(H)
+    B = x.shape[0]
+    L = cfg.latent_size
+
+    h = x
+    for i in range(n):
+        h = dense_layer(h, params, "ENCODER/{}".format(i + 1), bn, training,
+                        moving, new_moving)
+    mu = dense_layer(h, params, "POSTERIOR/MU", False, training, moving,
+                     None, activation=False)
+    mu = torch.clamp(mu, -FLOAT32_MAX_HALF, FLOAT32_MAX_HALF)
+    log_sigma = dense_layer(h, params, "POSTERIOR/LOG_SIGMA", False, training,
+                            moving, None, activation=False)
+    log_sigma = torch.clamp(log_sigma, -3.0, 3.0)
+    sigma = torch.exp(log_sigma)
+
+    if deterministic_z:
+        n_iw, n_mc = 1, 1
+        z = mu.unsqueeze(0)
+    else:
+        n_iw, n_mc = cfg.n_iw, cfg.n_mc
+        z = mu.unsqueeze(0) + sigma.unsqueeze(0) * eps  # [S, B, L]
+    S = z.shape[0]
+
+    d = z.reshape(S * B, L)
+    for i in range(n):
+        d = dense_layer(d, params, "DECODER/{}".format(n - i), bn, training,
+                        moving, new_moving)
+    pre = tuple(
+        dense_layer(d, params, "X_TILDE/" + p.upper(), False, training,
+                    moving, None, activation=False)
+        for p in cfg.heads)
+
+    t_tiled = t.repeat(S, 1)
+    log_p = lk.log_prob(cfg.likelihood, t_tiled, pre).sum(dim=-1)
+    log_p = log_p.reshape(n_iw, n_mc, B)
+
+    if analytical_kl:
+        kl = 0.5 * (mu * mu + sigma * sigma - 1.0) - log_sigma  # [B, L]
+        kl_neurons = kl.mean(dim=0)
+        kl_cell = kl.sum(dim=-1).reshape(1, 1, B)
+    else:
+        zr = z.reshape(n_iw, n_mc, B, L)
+        log_q = _normal_log_prob(zr, mu, sigma)
+        log_pz = _normal_log_prob(zr, torch.zeros_like(mu),
+                                  torch.ones_like(sigma))
+        kl = log_q - log_pz
+        kl_neurons = kl.reshape(-1, L).mean(dim=0)
+        kl_cell = kl.sum(dim=-1)
+    out = {
+        "reconstruction_error": log_p.mean(),
+        "kl_divergence": kl_neurons.sum(),
+        "kl_divergence_neurons": kl_neurons,
+        "log_p_x_given_z": log_p,            # [IW, MC, B] per-cell log-lik
+        "q_z_mean": mu,
+        "q_z_log_sigma": log_sigma,
+        "z": z,
+    }
+    out["lower_bound"] = log_reduce_exp_mean(log_p - kl_cell, 0).mean()
+    w = warm_up_weight * cfg.kl_weight
+    out["lower_bound_weighted"] = log_reduce_exp_mean(
+        log_p - w * kl_cell, 0).mean()
+
+    if evaluation_statistics:
+        m, v = lk.mean_variance(cfg.likelihood, pre)
+        m = m.reshape(n_iw, n_mc, B, -1)
+        v = v.reshape(n_iw, n_mc, B, -1)
+        p_x_mean = m.mean(dim=1).mean(dim=0)
+        var_of_mean = ((m - p_x_mean) ** 2).mean(dim=1).mean(dim=0)
+        out["p_x_mean"] = p_x_mean
+        out["stddev_of_p_x_given_z_mean"] = torch.sqrt(var_of_mean)
+        out["p_x_stddev"] = torch.sqrt(
+            var_of_mean + v.mean(dim=1).mean(dim=0))
+    return out
+
+
+# --------------------------------------------------------------------------
+# GMVAE
+# --------------------------------------------------------------------------
+
+def _layers(x, params, prefix, sizes, bn, training, moving, new_moving,
+            extra_row=None):
+    h = x
+    for i in range(len(sizes)):
+        h = dense_layer(h, params, "{}/LAYER_{}".format(prefix, i + 1), bn,
+                        training, moving, new_moving,
+                        extra_row=extra_row if i == 0 else None)
+    return h
+
+
+def _clip_big(a):
+    return torch.clamp(a, -FLOAT32_MAX_HALF, FLOAT32_MAX_HALF)
+
+
+def gmvae_forward(cfg, params, moving, x, t, eps, training,
+                  warm_up_weight=1.0, new_moving=None,
+                  evaluation_statistics=False):
+    """``eps``: [K, S, B, L].  Uniform p(y) (the default
+    ``prior_probabilities_method``)."""
+    bn = cfg.minibatch_normalisation
+    H = list(cfg.hidden_sizes)
+    K, L = cfg.n_clusters, cfg.latent_size
+    B = x.shape[0]
+    S = cfg.n_iw * cfg.n_mc
+
+    # q(y|x)
+    hy = _layers(x, params, "Y/CATEGORICAL/ENCODER", H, bn, training, moving,
+                 new_moving)
+    logits = dense_layer(hy, params, "Y/CATEGORICAL/LOGITS", False, training,
+                         moving, None, activation=False)
+    log_y = torch.log_softmax(logits, dim=-1)
+    y = torch.exp(log_y)
+    entropy = -(y * log_y).sum(dim=-1)
+    p_y_entropy = math.log(K)
+    kl_y_cell = p_y_entropy - entropy
+
+    Wpm = params["Z/P/SOFTPLUS_GAUSSIAN/MEAN/DENSE/weights"]
+    bpm = params["Z/P/SOFTPLUS_GAUSSIAN/MEAN/DENSE/biases"]
+    Wps = params["Z/P/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE/DENSE/weights"]
+    bps = params["Z/P/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE/DENSE/biases"]
+
+    t_tiled = t.repeat(S, 1)
+    kl_z_cell = 0.0
+    rec_cell = 0.0
+    kl_z_neurons = 0.0
+    z_mean = 0.0
+    log_p_all = []
+    p_z_means, p_z_variances, q_z_means, q_z_variances = [], [], [], []
+    p_x_means, mean_of_var, var_of_mean = [], [], []
+    for k in range(K):
+        h = _layers(x, params, "Z/Q/ENCODER", H, bn, training, moving,
+                    new_moving, extra_row=k)
+        q_mean = _clip_big(dense_layer(
+            h, params, "Z/Q/SOFTPLUS_GAUSSIAN/MEAN", False, training, moving,
+            None, activation=False))
+        q_s = _clip_big(dense_layer(
+            h, params, "Z/Q/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE", False,
+            training, moving, None, activation=False))
+        q_sigma = torch.sqrt(F.softplus(q_s))
+        z = q_mean.unsqueeze(0) + q_sigma.unsqueeze(0) * eps[k]   # [S,B,L]
+        p_mean = _clip_big(Wpm[k] + bpm)
+        p_sigma = torch.sqrt(F.softplus(_clip_big(Wps[k] + bps)))
+
+        d = _layers(z.reshape(S * B, L), params, "X/DECODER", H[::-1], bn,
+                    training, moving, new_moving)
+        pre = tuple(
+            dense_layer(d, params, "X/DISTRIBUTION/" + p.upper(), False,
+                        training, moving, None, activation=False)
+            for p in cfg.heads)
+        log_p = lk.log_prob(cfg.likelihood, t_tiled, pre).sum(dim=-1)
+        log_p = log_p.reshape(S, B)
+        log_p_all.append(log_p)
+
+        kl_dims = (_normal_log_prob(z, q_mean, q_sigma)
+                   - _normal_log_prob(z, p_mean, p_sigma))     # [S,B,L]
+        yk = y[:, k]
+        kl_z_cell = kl_z_cell + kl_dims.sum(dim=-1).mean(dim=0) * yk
+        rec_cell = rec_cell + log_p.mean(dim=0) * yk
+        kl_z_neurons = kl_z_neurons + kl_dims.mean(dim=0) * yk.unsqueeze(-1)
+        z_mean = z_mean + q_mean * yk.unsqueeze(-1)
+
+        p_z_means.append(p_mean)
+        p_z_variances.append(p_sigma ** 2)
+        q_z_means.append(q_mean.mean(dim=0))
+        q_z_variances.append((q_sigma ** 2).mean(dim=0))
+
+        if evaluation_statistics:
+            m, v = lk.mean_variance(cfg.likelihood, pre)
+            m = m.reshape(S, B, -1)
+            v = v.reshape(S, B, -1)
+            pxm = m.mean(dim=0) * yk.unsqueeze(-1)
+            p_x_means.append(pxm)
+            mean_of_var.append(v.mean(dim=0) * yk.unsqueeze(-1))
+            # gm:3338-3351 subtracts the already y-weighted mean (quirk)
+            var_of_mean.append(((m - pxm) ** 2).mean(dim=0)
+                               * yk.unsqueeze(-1))
+
+    kl_z = kl_z_cell.mean()
+    kl_y = kl_y_cell.mean()
+    rec = rec_cell.mean()
+    if cfg.free_nats_proportion:
+        thr = cfg.free_nats_proportion * p_y_entropy
+        kl_y_mod = torch.where(kl_y > thr, kl_y, torch.full_like(kl_y, thr))
+    else:
+        kl_y_mod = kl_y
+    w = warm_up_weight * cfg.kl_weight
+    out = {
+        "reconstruction_error": rec,
+        "kl_divergence_z": kl_z,
+        "kl_divergence_y": kl_y,
+        "kl_divergence": kl_z + kl_y,
+        "lower_bound": rec - (kl_z + kl_y),
+        "lower_bound_weighted": rec - w * (kl_z + kl_y_mod),
+        "kl_divergence_z_neurons": kl_z_neurons.mean(dim=0),
+        "log_p_x_given_z": torch.stack(log_p_all),      # [K, S, B]
+        "reconstruction_cell": rec_cell,                # [B]
+        "q_y_logits": logits,
+        "q_y_probabilities": y.mean(dim=0),
+        "y": y,
+        "z_mean": z_mean,
+        "p_z_means": torch.stack(p_z_means),
+        "p_z_variances": torch.stack(p_z_variances),
+        "q_z_means": torch.stack(q_z_means),
+        "q_z_variances": torch.stack(q_z_variances),
+    }
+    if evaluation_statistics:
+        vm = sum(var_of_mean)
+        out["p_x_mean"] = sum(p_x_means)
+        out["stddev_of_p_x_given_z_mean"] = torch.sqrt(vm)
+        out["p_x_stddev"] = torch.sqrt(sum(mean_of_var) + vm)
+    return out
+
+
+# --------------------------------------------------------------------------
+# optimiser
+# --------------------------------------------------------------------------
+
+def adam_state(params):
+    return {
+        "m": OrderedDict((k, torch.zeros_like(v)) for k, v in params.items()),
+        "v": OrderedDict((k, torch.zeros_like(v)) for k, v in params.items()),
+        "t": 0,
+    }
+
+
+def clip_and_adam(params, grads, state, learning_rate):
+    """va:2742-2759: clip every gradient element to [-1, 1], then
+    ``tf.train.AdamOptimizer`` (beta1 .9, beta2 .999, epsilon 1e-8):
+    ``lr_t = lr*sqrt(1-b2^t)/(1-b1^t)``; ``theta -= lr_t*m/(sqrt(v)+eps)``."""
+    state["t"] += 1
+    t = state["t"]
+    lr_t = (learning_rate * math.sqrt(1.0 - ADAM_BETA2 ** t)
+            / (1.0 - ADAM_BETA1 ** t))
+    for k in params:
+        g = torch.clamp(grads[k], -1.0, 1.0)
+        m = state["m"][k]
+        v = state["v"][k]
+        m.mul_(ADAM_BETA1).add_(g, alpha=1.0 - ADAM_BETA1)
+        v.mul_(ADAM_BETA2).addcmul_(g, g, value=1.0 - ADAM_BETA2)
+        params[k] = params[k] - lr_t * m / (torch.sqrt(v) + ADAM_EPSILON)
+    return params
+
+
+def gradients(forward, params, *args, **kwargs):
+    """Gradients of ``-lower_bound_weighted`` w.r.t. every parameter."""
+    leaves = OrderedDict(
+        (k, v.detach().clone().requires_grad_(True))
+        for k, v in params.items())
+    out = forward(leaves, *args, **kwargs)
+    loss = -out["lower_bound_weighted"]
+    grads = torch.autograd.grad(loss, list(leaves.values()),
+                                allow_unused=True)
+    grads = OrderedDict(
+        (k, g if g is not None else torch.zeros_like(v))
+        for (k, v), g in zip(leaves.items(), grads))
+    out = {k: (v.detach() if torch.is_tensor(v) else v)
+           for k, v in out.items()}
+    return out, grads
+
+
+def vae_train_step(cfg, params, moving, state, x, t, eps, learning_rate,
+                   warm_up_weight=1.0):
+    new_moving = {}
+    out, grads = gradients(
+        lambda p: vae_forward(cfg, p, moving, x, t, eps, True,
+                              warm_up_weight, new_moving), params)
+    params = clip_and_adam(params, grads, state, learning_rate)
+    moving = OrderedDict((k, new_moving.get(k, v)) for k, v in moving.items())
+    return params, moving, out, grads
+
+
+def gmvae_train_step(cfg, params, moving, state, x, t, eps, learning_rate,
+                     warm_up_weight=1.0):
+    new_moving = {}
+    out, grads = gradients(
+        lambda p: gmvae_forward(cfg, p, moving, x, t, eps, True,
+                                warm_up_weight, new_moving), params)
+    params = clip_and_adam(params, grads, state, learning_rate)
+    moving = OrderedDict((k, new_moving.get(k, v)) for k, v in moving.items())
+    return params, moving, out, grads
