@@ -1,0 +1,166 @@
+/* C ABI of libscvae_hip.so -- the MI355X (gfx950) execution engine underneath
+ * the Python model classes of scvae_amd (the drop-in for scvae.models).
+ *
+ * The reference (scvae/scvae v2.1.4) has no FFI: its hot path is a TensorFlow
+ * graph executed by session.run().  Each entry point below names the piece of
+ * the reference graph / loop it replaces (paths relative to /root/reference).
+ *
+ * Conventions:
+ *  - plain pointers and sizes only; every buffer is a DEVICE pointer owned by
+ *    the caller (the library never allocates device memory), row-major fp32
+ *    unless stated otherwise;
+ *  - asynchronous on the given hipStream_t (as void*), no internal sync;
+ *  - return 0 on success, -1 bad argument, -2 HIP error; the text is returned
+ *    by scvae_last_error() (per host thread);
+ *  - one host thread per plan.
+ */
+#ifndef SCVAE_HIP_H
+#define SCVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCVAE_MAX_HIDDEN 8
+#define SCVAE_NAME_MAX 96
+
+/* likelihood kinds; head order = parameter order of the DISTRIBUTIONS registry
+ * (scvae/distributions/utilities.py:206-305) */
+enum {
+  SCVAE_POISSON = 0, /* log_lambda            */
+  SCVAE_NB = 1,      /* p, log_r              */
+  SCVAE_ZIP = 2,     /* pi, log_lambda        */
+  SCVAE_ZINB = 3     /* pi, p, log_r          */
+};
+
+enum { SCVAE_MODEL_VAE = 0, SCVAE_MODEL_GMVAE = 1 };
+
+/* Constructor arguments of VariationalAutoencoder /
+ * GaussianMixtureVariationalAutoencoder that shape the graph
+ * (scvae/models/variational_autoencoder.py:114-292,
+ *  scvae/models/gaussian_mixture_variational_autoencoder.py:136-326). */
+typedef struct scvae_model_config {
+  int32_t model_type;         /* SCVAE_MODEL_* */
+  int32_t feature_size;       /* F */
+  int32_t latent_size;        /* L */
+  int32_t n_hidden;           /* len(hidden_sizes) */
+  int32_t hidden[SCVAE_MAX_HIDDEN];
+  int32_t likelihood;         /* SCVAE_POISSON ... */
+  int32_t batch_norm;         /* minibatch_normalisation */
+  int32_t n_clusters;         /* K (GMVAE), 1 for the VAE */
+  float kl_weight;
+  float free_nats_proportion; /* proportion_of_free_nats_for_y_kl_divergence */
+} scvae_model_config;
+
+typedef struct scvae_plan scvae_plan; /* opaque */
+
+/* Collective hook used by data-parallel training (one process per GPU).
+ * kind 0: all-reduce(sum) `count` floats in place at `buf`;
+ * kind 1: merge batch-norm statistics: buf = [mean(n) | var(n)] of `local_rows`
+ *         rows -> global mean/var over all ranks, in place (count = 2n).
+ * Must enqueue on the plan's stream.  NULL = single process. */
+typedef int (*scvae_sync_fn)(void* user, float* buf, int64_t count, int32_t kind,
+                             int64_t local_rows);
+
+const char* scvae_last_error(void);
+int scvae_version(void);
+
+/* ---- graph build: _setup_model_graph (va:2219-2558, gm:2788-3221) ---- */
+int scvae_plan_create(const scvae_model_config* cfg, scvae_plan** out);
+void scvae_plan_destroy(scvae_plan* plan);
+/* trainable variables in reference creation order */
+int64_t scvae_plan_param_count(const scvae_plan* plan);
+int64_t scvae_plan_param_floats(const scvae_plan* plan);   /* flat buffer length  */
+int64_t scvae_plan_moving_floats(const scvae_plan* plan);  /* BN moving mean/var  */
+int scvae_plan_param_info(const scvae_plan* plan, int64_t index, char* name /*SCVAE_NAME_MAX*/,
+                          int64_t* offset, int64_t* rows, int64_t* cols);
+int64_t scvae_plan_moving_count(const scvae_plan* plan);
+int scvae_plan_moving_info(const scvae_plan* plan, int64_t index, char* name, int64_t* offset,
+                           int64_t* size);
+int64_t scvae_plan_workspace_bytes(const scvae_plan* plan, int64_t max_cells, int64_t max_samples);
+int scvae_plan_bind(scvae_plan* plan, float* params, float* grads, float* moving, void* workspace,
+                    int64_t workspace_bytes, int64_t max_cells, int64_t max_samples);
+int scvae_plan_set_sync(scvae_plan* plan, scvae_sync_fn fn, void* user);
+
+/* One graph execution = session.run(...) in the reference loops
+ * (train step va:1026-1029 / gm:1094-1097; evaluation va:1124-1135, 1983-2014).
+ * x, t: [cells, F]; row_const: [cells] sum_f lgamma(1+t) (or NULL);
+ * eps: VAE [S, cells, L], GMVAE [K, S, cells, L] standard normal draws
+ * (S = n_iw*n_mc; may be NULL when deterministic_z);
+ * global_cells: minibatch size over all data-parallel ranks (= cells if single).
+ * training!=0: is_training=True and gradients of -lower_bound_weighted are
+ * written to the bound grads buffer (and BN moving statistics are updated).
+ * scalars (device, 8 floats): [0] lower_bound [1] lower_bound_weighted
+ * [2] reconstruction_error [3] kl_divergence (VAE) / kl_divergence_z (GMVAE)
+ * [4] kl_divergence_y (GMVAE) ; each is this rank's share of the global mean. */
+typedef struct scvae_step_args {
+  const float* x;
+  const float* t;
+  const float* row_const;
+  const float* eps;
+  int64_t cells;
+  int64_t global_cells;
+  int32_t n_iw;
+  int32_t n_mc;
+  int32_t training;
+  int32_t deterministic_z;
+  float warm_up_weight;
+  float* scalars;
+  /* optional outputs (NULL to skip) */
+  float* log_p_x_given_z;  /* VAE [S*cells]; GMVAE [K*S*cells]: per-cell sum_F log p(t|z) */
+  float* q_z_mean;         /* [cells, L]  (GMVAE: z_mean = sum_k y_k mean_k) */
+  float* kl_neurons;       /* [L] share of kl_divergence_neurons */
+  float* q_y_logits;       /* GMVAE [cells, K] */
+  float* p_x_mean;         /* [cells, F] */
+  float* p_x_stddev;       /* [cells, F] */
+  float* stddev_of_p_x_given_z_mean; /* [cells, F] */
+  float* cluster_stats;    /* GMVAE: [4, K, L] p_z_means, p_z_variances, q_z_means(sum share),
+                              q_z_variances(sum share) */
+} scvae_step_args;
+int scvae_plan_step(scvae_plan* plan, const scvae_step_args* args, void* stream);
+
+/* _setup_optimiser (va:2736-2770): g <- clip(g*grad_scale, +-1); tf.train.AdamOptimizer
+ * with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller. */
+int scvae_adam_clip_step(float* theta, float* grad, float* m, float* v, int64_t n,
+                         float grad_scale, float lr_t, float beta1, float beta2, float epsilon,
+                         void* stream);
+
+/* ---- individual ops (also used by the tests) ---- */
+/* dense_layer (scvae/models/utilities.py:38-76): C (+)= act(op(A) op(B) + bias) */
+int scvae_gemm(int32_t trans_a, int32_t trans_b, const float* A, const float* B,
+               const float* bias, float* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+               int64_t ldb, int64_t ldc, int32_t relu, int32_t accumulate, void* workspace,
+               int64_t workspace_bytes, void* stream);
+int64_t scvae_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+/* p(x|z).log_prob(t) summed over F (va:2583-2590); pre = heads' pre-activations [rows,F] */
+int scvae_loglik_fwd(int32_t kind, const float* t, const float* const* pre, const float* row_const,
+                     float* ll, int64_t rows, int64_t cells, int64_t F, void* stream);
+/* in place: pre_j <- gw[r] * d log p / d pre_j; ll (optional) as above */
+int scvae_loglik_bwd(int32_t kind, const float* t, float* const* pre, const float* gw,
+                     const float* row_const, float* ll, int64_t rows, int64_t cells, int64_t F,
+                     void* stream);
+/* q(z|x) sample + analytic KL (va:2346-2369, 2624-2656) */
+int scvae_gauss_latent_fwd(const float* mu_pre, const float* ls_pre, const float* eps, float* z,
+                           float* kl_elem, float* kl_cell, int64_t S, int64_t cells, int64_t L,
+                           int32_t deterministic, void* stream);
+/* minibatch fetch x_train[idx].toarray() (va:985-998) from a device-resident CSR matrix */
+int scvae_csr_densify(const int64_t* indptr, const int32_t* indices, const float* values,
+                      const int64_t* rows, int64_t n, int64_t F, float* out, void* stream);
+int scvae_csr_row_lgamma1p(const int64_t* indptr, const float* values, int64_t n_rows, float* out,
+                           void* stream);
+int scvae_gather_rows(const float* src, const int64_t* rows, int64_t n, float* out, void* stream);
+/* q.sample() noise: Philox4x32-10 + Box-Muller keyed by (seed, stream_id, row_offset+row, col) */
+int scvae_philox_normal(float* out, int64_t rows, int64_t cols, int64_t row_offset, uint64_t seed,
+                        uint64_t stream_id, void* stream);
+/* batch-norm statistic merge for the data-parallel hook: gathered = [ranks][mean(n)|var(n)],
+ * counts = rows per rank (DEVICE int64 array) -> out [mean(n)|var(n)] */
+int scvae_bn_merge(const float* gathered, const int64_t* counts, int64_t ranks, int64_t n,
+                   float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCVAE_HIP_H */

@@ -1,0 +1,154 @@
+"""ctypes binding of ``libscvae_hip.so`` (C ABI declared in ``include/scvae_hip.h``).
+
+The library is the only compute path of this package: loading fails loudly
+when it has not been built (``python __graft_entry__.py`` or
+``scvae_amd/csrc/build.sh``), and there is no CPU fallback.
+"""
+
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int32, c_int64,
+                    c_uint64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBRARY_PATH = os.path.join(_HERE, "csrc", "libscvae_hip.so")
+
+MAX_HIDDEN = 8
+NAME_MAX = 96
+
+POISSON, NB, ZIP, ZINB = 0, 1, 2, 3
+MODEL_VAE, MODEL_GMVAE = 0, 1
+
+#: registry name -> (kind, head parameter names in registry order)
+LIKELIHOOD_KINDS = {
+    "poisson": (POISSON, ("log_lambda",)),
+    "negative binomial": (NB, ("p", "log_r")),
+    "zero-inflated poisson": (ZIP, ("pi", "log_lambda")),
+    "zero-inflated negative binomial": (ZINB, ("pi", "p", "log_r")),
+}
+
+
+class ModelConfig(Structure):
+    _fields_ = [
+        ("model_type", c_int32),
+        ("feature_size", c_int32),
+        ("latent_size", c_int32),
+        ("n_hidden", c_int32),
+        ("hidden", c_int32 * MAX_HIDDEN),
+        ("likelihood", c_int32),
+        ("batch_norm", c_int32),
+        ("n_clusters", c_int32),
+        ("kl_weight", c_float),
+        ("free_nats_proportion", c_float),
+    ]
+
+
+class StepArgs(Structure):
+    _fields_ = [
+        ("x", c_void_p),
+        ("t", c_void_p),
+        ("row_const", c_void_p),
+        ("eps", c_void_p),
+        ("cells", c_int64),
+        ("global_cells", c_int64),
+        ("n_iw", c_int32),
+        ("n_mc", c_int32),
+        ("training", c_int32),
+        ("deterministic_z", c_int32),
+        ("warm_up_weight", c_float),
+        ("scalars", c_void_p),
+        ("log_p_x_given_z", c_void_p),
+        ("q_z_mean", c_void_p),
+        ("kl_neurons", c_void_p),
+        ("q_y_logits", c_void_p),
+        ("p_x_mean", c_void_p),
+        ("p_x_stddev", c_void_p),
+        ("stddev_of_p_x_given_z_mean", c_void_p),
+        ("cluster_stats", c_void_p),
+    ]
+
+
+SYNC_FN = ctypes.CFUNCTYPE(c_int32, c_void_p, c_void_p, c_int64, c_int32,
+                           c_int64)
+
+#: every symbol declared in include/scvae_hip.h: name -> (restype, argtypes)
+SIGNATURES = {
+    "scvae_last_error": (c_char_p, []),
+    "scvae_version": (c_int32, []),
+    "scvae_plan_create": (c_int32, [POINTER(ModelConfig), POINTER(c_void_p)]),
+    "scvae_plan_destroy": (None, [c_void_p]),
+    "scvae_plan_param_count": (c_int64, [c_void_p]),
+    "scvae_plan_param_floats": (c_int64, [c_void_p]),
+    "scvae_plan_moving_floats": (c_int64, [c_void_p]),
+    "scvae_plan_param_info": (c_int32, [
+        c_void_p, c_int64, c_char_p, POINTER(c_int64), POINTER(c_int64),
+        POINTER(c_int64)]),
+    "scvae_plan_moving_count": (c_int64, [c_void_p]),
+    "scvae_plan_moving_info": (c_int32, [
+        c_void_p, c_int64, c_char_p, POINTER(c_int64), POINTER(c_int64)]),
+    "scvae_plan_workspace_bytes": (c_int64, [c_void_p, c_int64, c_int64]),
+    "scvae_plan_bind": (c_int32, [
+        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+        c_int64]),
+    "scvae_plan_set_sync": (c_int32, [c_void_p, SYNC_FN, c_void_p]),
+    "scvae_plan_step": (c_int32, [c_void_p, POINTER(StepArgs), c_void_p]),
+    "scvae_adam_clip_step": (c_int32, [
+        c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float,
+        c_float, c_float, c_float, c_void_p]),
+    "scvae_gemm": (c_int32, [
+        c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+        c_int64, c_int64, c_int64, c_int64, c_int64, c_int32, c_int32,
+        c_void_p, c_int64, c_void_p]),
+    "scvae_gemm_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "scvae_loglik_fwd": (c_int32, [
+        c_int32, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_int64,
+        c_int64, c_int64, c_void_p]),
+    "scvae_loglik_bwd": (c_int32, [
+        c_int32, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p,
+        c_int64, c_int64, c_int64, c_void_p]),
+    "scvae_gauss_latent_fwd": (c_int32, [
+        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+        c_int64, c_int64, c_int32, c_void_p]),
+    "scvae_csr_densify": (c_int32, [
+        c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
+        c_void_p]),
+    "scvae_csr_row_lgamma1p": (c_int32, [
+        c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "scvae_gather_rows": (c_int32, [
+        c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "scvae_philox_normal": (c_int32, [
+        c_void_p, c_int64, c_int64, c_int64, c_uint64, c_uint64, c_void_p]),
+    "scvae_bn_merge": (c_int32, [
+        c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once) and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBRARY_PATH):
+        raise HipLibraryError(
+            "{} has not been built; run `python __graft_entry__.py` or "
+            "scvae_amd/csrc/build.sh (there is no CPU fallback).".format(
+                LIBRARY_PATH))
+    lib = ctypes.CDLL(LIBRARY_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        message = load().scvae_last_error().decode("utf-8", "replace")
+        raise HipLibraryError("{} failed ({}): {}".format(what, rc, message))

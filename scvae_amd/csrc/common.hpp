@@ -1,0 +1,147 @@
+// Shared device/host helpers for the scVAE gfx950 kernels.
+// Wave = 64 lanes everywhere in this file (CDNA4); no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+namespace scvae {
+
+constexpr int WAVE = 64;
+constexpr float F32_TINY = 1.1754943508222875e-38f;
+constexpr float LOGIT_OF_TINY = -87.33654475055310898657f;  // log(float32.tiny)
+constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
+constexpr float F32_MAX_HALF = 1.7014117331926443e38f;
+constexpr float BN_EPSILON = 1e-3f;
+constexpr float BN_DECAY = 0.999f;
+
+// ---- error reporting (per-thread string, returned by scvae_last_error) ----
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+#define SCVAE_HIP(call)                                            \
+  do {                                                             \
+    int _rc = ::scvae::check_hip((call), #call);                   \
+    if (_rc) return _rc;                                           \
+  } while (0)
+#define SCVAE_LAUNCH_CHECK(name)                                   \
+  do {                                                             \
+    int _rc = ::scvae::check_hip(hipGetLastError(), name);         \
+    if (_rc) return _rc;                                           \
+  } while (0)
+#define SCVAE_ARG(cond)                                            \
+  do {                                                             \
+    if (!(cond)) {                                                 \
+      ::scvae::set_error("bad argument: %s (%s:%d)", #cond, __FILE__, __LINE__); \
+      return -1;                                                   \
+    }                                                              \
+  } while (0)
+
+// likelihood kinds (order of heads follows the DISTRIBUTIONS registry,
+// scvae/distributions/utilities.py:206-305)
+enum Likelihood : int {
+  LK_POISSON = 0,  // heads: log_lambda
+  LK_NB = 1,       // heads: p, log_r
+  LK_ZIP = 2,      // heads: pi, log_lambda
+  LK_ZINB = 3      // heads: pi, p, log_r
+};
+__host__ __device__ inline int likelihood_heads(int kind) {
+  return kind == LK_POISSON ? 1 : (kind == LK_ZINB ? 3 : 2);
+}
+
+#ifdef __HIPCC__
+// ---- wave / block reductions ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, WAVE));
+  return v;
+}
+// Sum over a block of NT threads (NT multiple of 64, <= 1024). `red` is an LDS
+// array of NT/64 floats. Result valid in every thread.
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) s += red[i];
+  return s;
+}
+
+// ---- scalar math used by the likelihood kernels ----
+// log(sigmoid(a)) = -softplus(-a), stable for any a
+__device__ __forceinline__ float log_sigmoid(float a) {
+  return fminf(a, 0.f) - log1pf(__expf(-fabsf(a)));
+}
+__device__ __forceinline__ float softplusf(float a) {
+  return fmaxf(a, 0.f) + log1pf(__expf(-fabsf(a)));
+}
+__device__ __forceinline__ float sigmoidf(float a) {
+  const float e = __expf(-fabsf(a));
+  const float s = 1.f / (1.f + e);
+  return a >= 0.f ? s : e * s;
+}
+
+// Stirling tail s(y) = 1/(12y) - 1/(360y^3) + 1/(1260y^5), y >= 8
+__device__ __forceinline__ float stirling_tail(float y) {
+  const float iy = 1.f / y, iy2 = iy * iy;
+  return iy * (8.3333333333e-2f + iy2 * (-2.7777777778e-3f + iy2 * 7.9365079365e-4f));
+}
+// digamma tail u(y) = 1/(2y) + 1/(12y^2) - 1/(120y^4) + 1/(252y^6), psi(y) = log y - u(y)
+__device__ __forceinline__ float digamma_tail(float y) {
+  const float iy = 1.f / y, iy2 = iy * iy;
+  return 0.5f * iy + iy2 * (8.3333333333e-2f + iy2 * (-8.3333333333e-3f + iy2 * 3.9682539683e-3f));
+}
+
+// A = lgamma(r+t) - lgamma(r) and D = digamma(r+t) - digamma(r) for r > 0,
+// t >= 0 (t need not be an integer).  Both arguments are shifted up by 8 with
+// the recurrence, and the shifted difference is taken analytically
+//   lgamma(b+t)-lgamma(b) = t*log(b+t) + (b-1/2)*log1p(t/b) - t + s(b+t)-s(b)
+// so there is no cancellation of two large lgamma values.  Exactly 0 at t == 0.
+template <bool WITH_D>
+__device__ __forceinline__ void lgamma_digamma_diff(float r, float t, float& A, float& D) {
+  const float x = r + t;
+  const float b = r + 8.f, a = x + 8.f;
+  const float q = t / b;
+  const float l1 = log1pf(q);
+  float A8 = t * __logf(a) + (b - 0.5f) * l1 - t + (stirling_tail(a) - stirling_tail(b));
+  // products of the 8 shift factors, in two groups of 4 (no overflow for t < 1e7)
+  float n1 = x, n2 = x + 4.f, d1 = r, d2 = r + 4.f;
+  float n1p = 1.f, n2p = 1.f, d1p = 1.f, d2p = 1.f;  // derivatives of the products
+#pragma unroll
+  for (int i = 1; i < 4; ++i) {
+    const float fx1 = x + (float)i, fx2 = x + (float)(4 + i);
+    const float fr1 = r + (float)i, fr2 = r + (float)(4 + i);
+    if (WITH_D) {
+      n1p = fmaf(n1p, fx1, n1); n2p = fmaf(n2p, fx2, n2);
+      d1p = fmaf(d1p, fr1, d1); d2p = fmaf(d2p, fr2, d2);
+    }
+    n1 *= fx1; n2 *= fx2; d1 *= fr1; d2 *= fr2;
+  }
+  // log(n1*n2/(d1*d2)) as log(n1/d1) + log(n2/d2): each ratio is >= 1 and finite
+  A = A8 - (__logf(n1 / d1) + __logf(n2 / d2));
+  if (WITH_D) {
+    const float D8 = l1 - (digamma_tail(a) - digamma_tail(b));
+    // sum_{i<8} 1/(r+i) - 1/(x+i)
+    const float sr = d1p / d1 + d2p / d2;
+    const float sx = n1p / n1 + n2p / n2;
+    D = D8 + (sr - sx);
+  } else {
+    D = 0.f;
+  }
+}
+
+// lgamma(1+t) for t >= 0 (data-only term of the count likelihoods)
+__device__ __forceinline__ float lgamma1p(float t) {
+  return t == 0.f ? 0.f : lgammaf(1.f + t);
+}
+#endif  // __HIPCC__
+
+}  // namespace scvae

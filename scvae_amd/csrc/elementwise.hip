@@ -1,0 +1,785 @@
+// Coalesced elementwise / row-reduction kernels of the scVAE step (HBM-bound):
+// count log-likelihoods, Gaussian reparameterisation + KL, ELBO, batch norm,
+// clip + Adam, CSR densify, Philox normals.  One wavefront = 64 lanes.
+#include "common.hpp"
+#include "kernels.hpp"
+#include "likelihood.hpp"
+
+namespace scvae {
+
+// ============================ log-likelihood ==============================
+
+// One workgroup per row r of the [rows, F] head pre-activations; target row r % B.
+// GRAD: overwrite pre_j with gw[r] * dlp/dpre_j.
+template <int KIND, bool GRAD>
+__global__ __launch_bounds__(256) void loglik_rows_kernel(const float* __restrict__ t, int ldt,
+                                                          HeadPtrs pre, int ldp,
+                                                          const float* __restrict__ gw,
+                                                          const float* __restrict__ row_const,
+                                                          float* __restrict__ ll, int B, int F) {
+  constexpr int P = (KIND == LK_POISSON) ? 1 : (KIND == LK_ZINB ? 3 : 2);
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  const int b = r % B;
+  const float* trow = t + (size_t)b * ldt;
+  const float g_up = GRAD ? gw[r] : 0.f;
+  float acc = 0.f;
+  for (int f = threadIdx.x; f < F; f += 256) {
+    const float tv = trow[f];
+    float a[P], g[P], lp;
+#pragma unroll
+    for (int j = 0; j < P; ++j) a[j] = pre.p[j][(size_t)r * ldp + f];
+    lik_elem<KIND, GRAD>(tv, a, lp, g);
+    acc += lp;
+    if (row_const == nullptr) acc -= lgamma1p(tv);
+    if (GRAD) {
+#pragma unroll
+      for (int j = 0; j < P; ++j) pre.p[j][(size_t)r * ldp + f] = g_up * g[j];
+    }
+  }
+  acc = block_sum<256>(acc, red);
+  if (threadIdx.x == 0 && ll != nullptr) ll[r] = acc - (row_const ? row_const[b] : 0.f);
+}
+
+template <bool GRAD>
+static int launch_loglik(hipStream_t stream, int kind, const float* t, int ldt, HeadPtrs pre,
+                         int ldp, const float* gw, const float* row_const, float* ll, int rows,
+                         int B, int F) {
+  SCVAE_ARG(t && pre.p[0] && rows >= 0 && B > 0 && F > 0);
+  if (rows == 0) return 0;
+  dim3 grid(rows), block(256);
+  switch (kind) {
+    case LK_POISSON:
+      hipLaunchKernelGGL((loglik_rows_kernel<LK_POISSON, GRAD>), grid, block, 0, stream, t, ldt,
+                         pre, ldp, gw, row_const, ll, B, F);
+      break;
+    case LK_NB:
+      hipLaunchKernelGGL((loglik_rows_kernel<LK_NB, GRAD>), grid, block, 0, stream, t, ldt, pre,
+                         ldp, gw, row_const, ll, B, F);
+      break;
+    case LK_ZIP:
+      hipLaunchKernelGGL((loglik_rows_kernel<LK_ZIP, GRAD>), grid, block, 0, stream, t, ldt, pre,
+                         ldp, gw, row_const, ll, B, F);
+      break;
+    case LK_ZINB:
+      hipLaunchKernelGGL((loglik_rows_kernel<LK_ZINB, GRAD>), grid, block, 0, stream, t, ldt, pre,
+                         ldp, gw, row_const, ll, B, F);
+      break;
+    default:
+      set_error("unknown likelihood kind %d", kind);
+      return -1;
+  }
+  SCVAE_LAUNCH_CHECK("loglik_rows_kernel");
+  return 0;
+}
+
+int loglik_fwd(hipStream_t stream, int kind, const float* t, int ldt, HeadPtrs pre, int ldp,
+               const float* row_const, float* ll, int rows, int B, int F) {
+  SCVAE_ARG(ll);
+  return launch_loglik<false>(stream, kind, t, ldt, pre, ldp, nullptr, row_const, ll, rows, B, F);
+}
+
+int loglik_bwd(hipStream_t stream, int kind, const float* t, int ldt, HeadPtrs pre, int ldp,
+               const float* gw, const float* row_const, float* ll, int rows, int B, int F) {
+  SCVAE_ARG(gw);
+  return launch_loglik<true>(stream, kind, t, ldt, pre, ldp, gw, row_const, ll, rows, B, F);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void px_statistics_kernel(HeadPtrs pre, int ldp, int S, int B,
+                                                            int F, const float* __restrict__ weight,
+                                                            int ldw, int accumulate,
+                                                            float* __restrict__ p_x_mean,
+                                                            float* __restrict__ mean_of_var,
+                                                            float* __restrict__ var_of_mean) {
+  constexpr int P = (KIND == LK_POISSON) ? 1 : (KIND == LK_ZINB ? 3 : 2);
+  const int b = blockIdx.y;
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  const float wgt = weight ? weight[(size_t)b * ldw] : 1.f;
+  const float inv_s = 1.f / (float)S;
+  float ms = 0.f, vs = 0.f;
+  for (int s = 0; s < S; ++s) {
+    float a[P], m, v;
+#pragma unroll
+    for (int j = 0; j < P; ++j) a[j] = pre.p[j][((size_t)s * B + b) * ldp + f];
+    lik_mean_var<KIND>(a, m, v);
+    ms += m; vs += v;
+  }
+  const float pm = ms * inv_s * wgt;
+  float vom = 0.f;
+  for (int s = 0; s < S; ++s) {
+    float a[P], m, v;
+#pragma unroll
+    for (int j = 0; j < P; ++j) a[j] = pre.p[j][((size_t)s * B + b) * ldp + f];
+    lik_mean_var<KIND>(a, m, v);
+    vom += (m - pm) * (m - pm);
+  }
+  vom *= inv_s * wgt;
+  const float mov = vs * inv_s * wgt;
+  const size_t o = (size_t)b * F + f;
+  if (accumulate) { p_x_mean[o] += pm; mean_of_var[o] += mov; var_of_mean[o] += vom; }
+  else { p_x_mean[o] = pm; mean_of_var[o] = mov; var_of_mean[o] = vom; }
+}
+
+int px_statistics(hipStream_t stream, int kind, HeadPtrs pre, int ldp, int S, int B, int F,
+                  const float* weight, int ldw, int accumulate, float* p_x_mean,
+                  float* mean_of_var, float* var_of_mean) {
+  SCVAE_ARG(pre.p[0] && p_x_mean && mean_of_var && var_of_mean && S > 0 && F > 0);
+  if (B == 0) return 0;
+  dim3 grid((F + 255) / 256, B), block(256);
+#define SCVAE_PX(K_)                                                                             \
+  hipLaunchKernelGGL((px_statistics_kernel<K_>), grid, block, 0, stream, pre, ldp, S, B, F, weight, \
+                     ldw, accumulate, p_x_mean, mean_of_var, var_of_mean)
+  switch (kind) {
+    case LK_POISSON: SCVAE_PX(LK_POISSON); break;
+    case LK_NB: SCVAE_PX(LK_NB); break;
+    case LK_ZIP: SCVAE_PX(LK_ZIP); break;
+    case LK_ZINB: SCVAE_PX(LK_ZINB); break;
+    default: set_error("unknown likelihood kind %d", kind); return -1;
+  }
+#undef SCVAE_PX
+  SCVAE_LAUNCH_CHECK("px_statistics_kernel");
+  return 0;
+}
+
+__global__ void sqrt_sum_kernel(const float* a, const float* b, float* out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    out[i] = sqrtf(a[i] + (b ? b[i] : 0.f));
+}
+int sqrt_sum(hipStream_t stream, const float* a, const float* b, float* out, size_t n) {
+  SCVAE_ARG(a && out);
+  if (n == 0) return 0;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sqrt_sum_kernel, dim3(blocks), dim3(256), 0, stream, a, b, out, n);
+  SCVAE_LAUNCH_CHECK("sqrt_sum_kernel");
+  return 0;
+}
+
+// ============================ Gaussian latent =============================
+
+// one workgroup (64*ceil(L/64) threads) per cell b
+__global__ void gauss_latent_fwd_kernel(const float* __restrict__ mu_pre,
+                                        const float* __restrict__ ls_pre,
+                                        const float* __restrict__ eps, float* __restrict__ z,
+                                        float* __restrict__ kl_elem, float* __restrict__ kl_cell,
+                                        int S, int B, int L, int deterministic) {
+  __shared__ float red[16];
+  const int b = blockIdx.x, l = threadIdx.x;
+  float kl = 0.f;
+  if (l < L) {
+    const size_t i = (size_t)b * L + l;
+    const float mu = fminf(fmaxf(mu_pre[i], -F32_MAX_HALF), F32_MAX_HALF);
+    const float ls = fminf(fmaxf(ls_pre[i], -3.f), 3.f);
+    const float sigma = __expf(ls);
+    if (deterministic) {
+      z[i] = mu;
+    } else {
+      for (int s = 0; s < S; ++s) {
+        const size_t o = ((size_t)s * B + b) * L + l;
+        z[o] = fmaf(sigma, eps[o], mu);
+      }
+    }
+    kl = 0.5f * (mu * mu + sigma * sigma - 1.f) - ls;
+    kl_elem[i] = kl;
+  }
+  // block reduction over L (blockDim.x is a multiple of 64, <= 1024)
+  kl = wave_sum(kl);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0) red[w] = kl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    kl_cell[b] = s;
+  }
+}
+
+int gauss_latent_fwd(hipStream_t stream, const float* mu_pre, const float* ls_pre,
+                     const float* eps, float* z, float* kl_elem, float* kl_cell, int S, int B,
+                     int L, int deterministic) {
+  SCVAE_ARG(mu_pre && ls_pre && z && kl_elem && kl_cell);
+  SCVAE_ARG(deterministic || eps);
+  SCVAE_ARG(L > 0 && L <= 1024 && S > 0);
+  if (B == 0) return 0;
+  const int threads = (L + 63) / 64 * 64;
+  hipLaunchKernelGGL(gauss_latent_fwd_kernel, dim3(B), dim3(threads), 0, stream, mu_pre, ls_pre,
+                     eps, z, kl_elem, kl_cell, S, B, L, deterministic);
+  SCVAE_LAUNCH_CHECK("gauss_latent_fwd_kernel");
+  return 0;
+}
+
+__global__ void gauss_latent_bwd_kernel(const float* __restrict__ mu_pre,
+                                        const float* __restrict__ ls_pre,
+                                        const float* __restrict__ eps,
+                                        const float* __restrict__ dz, float kl_coeff,
+                                        float* __restrict__ dmu_pre, float* __restrict__ dls_pre,
+                                        int S, int B, int L) {
+  const size_t n = (size_t)B * L;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const float mp = mu_pre[i], lp = ls_pre[i];
+    const float mu = fminf(fmaxf(mp, -F32_MAX_HALF), F32_MAX_HALF);
+    const float ls = fminf(fmaxf(lp, -3.f), 3.f);
+    const float sigma = __expf(ls);
+    float gz = 0.f, gze = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const size_t o = (size_t)s * n + i;
+      const float d = dz[o];
+      gz += d;
+      gze += d * eps[o];
+    }
+    const float gmu = gz + kl_coeff * mu;
+    const float gls = gze * sigma + kl_coeff * (sigma * sigma - 1.f);
+    dmu_pre[i] = (mp >= -F32_MAX_HALF && mp <= F32_MAX_HALF) ? gmu : 0.f;
+    dls_pre[i] = (lp >= -3.f && lp <= 3.f) ? gls : 0.f;
+  }
+}
+
+int gauss_latent_bwd(hipStream_t stream, const float* mu_pre, const float* ls_pre,
+                     const float* eps, const float* dz, float kl_coeff, float* dmu_pre,
+                     float* dls_pre, int S, int B, int L) {
+  SCVAE_ARG(mu_pre && ls_pre && eps && dz && dmu_pre && dls_pre);
+  if (B == 0) return 0;
+  const size_t n = (size_t)B * L;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gauss_latent_bwd_kernel, dim3(blocks), dim3(256), 0, stream, mu_pre, ls_pre,
+                     eps, dz, kl_coeff, dmu_pre, dls_pre, S, B, L);
+  SCVAE_LAUNCH_CHECK("gauss_latent_bwd_kernel");
+  return 0;
+}
+
+// ================================= ELBO ===================================
+
+// single workgroup; ll index = (r*n_mc + m)*B + b.  row_scale = 1/(n_mc*B_global)
+// lets a data-parallel rank emit its share of the global means (summed by all-reduce).
+__global__ __launch_bounds__(256) void vae_elbo_kernel(const float* __restrict__ ll,
+                                                       const float* __restrict__ kl_cell, int n_iw,
+                                                       int n_mc, int B, float w, float row_scale,
+                                                       float* __restrict__ scalars,
+                                                       float* __restrict__ gw) {
+  __shared__ float red[4];
+  float lb = 0.f, lbw = 0.f, rec = 0.f, klsum = 0.f;
+  const int pairs = n_mc * B;
+  for (int i = threadIdx.x; i < pairs; i += 256) {
+    const int m = i / B, b = i % B;
+    const float kl = kl_cell[b];
+    if (m == 0) klsum += kl;
+    float mx = -INFINITY, mxw = -INFINITY;
+    for (int r = 0; r < n_iw; ++r) {
+      const float v = ll[((size_t)r * n_mc + m) * B + b];
+      rec += v;
+      mx = fmaxf(mx, v - kl);
+      mxw = fmaxf(mxw, v - w * kl);
+    }
+    float se = 0.f, sew = 0.f;
+    for (int r = 0; r < n_iw; ++r) {
+      const float v = ll[((size_t)r * n_mc + m) * B + b];
+      se += __expf(v - kl - mx);
+      sew += __expf(v - w * kl - mxw);
+    }
+    const float inv = 1.f / (float)n_iw;
+    lb += __logf(se * inv) + mx;
+    lbw += __logf(sew * inv) + mxw;
+    if (gw != nullptr) {
+      for (int r = 0; r < n_iw; ++r) {
+        const size_t o = ((size_t)r * n_mc + m) * B + b;
+        gw[o] = -__expf(ll[o] - w * kl - mxw) / sew * row_scale;
+      }
+    }
+  }
+  lb = block_sum<256>(lb, red);
+  lbw = block_sum<256>(lbw, red);
+  rec = block_sum<256>(rec, red);
+  klsum = block_sum<256>(klsum, red);
+  if (threadIdx.x == 0) {
+    scalars[0] = lb * row_scale;
+    scalars[1] = lbw * row_scale;
+    scalars[2] = rec * row_scale / (float)n_iw;
+    scalars[3] = klsum * row_scale * (float)n_mc;
+  }
+}
+
+int vae_elbo(hipStream_t stream, const float* ll, const float* kl_cell, int n_iw, int n_mc, int B,
+             float kl_weight_total, float row_scale, float* scalars, float* gw) {
+  SCVAE_ARG(ll && kl_cell && scalars && n_iw > 0 && n_mc > 0 && B > 0);
+  hipLaunchKernelGGL(vae_elbo_kernel, dim3(1), dim3(256), 0, stream, ll, kl_cell, n_iw, n_mc, B,
+                     kl_weight_total, row_scale, scalars, gw);
+  SCVAE_LAUNCH_CHECK("vae_elbo_kernel");
+  return 0;
+}
+
+// ============================ batch normalisation =========================
+
+// grid (ceil(N/64), groups); 64 columns x 16 row lanes per workgroup.
+// Two-pass (centred) variance like the fused TF kernel: mean, then mean((a-mean)^2).
+__global__ __launch_bounds__(1024) void bn_stats_kernel(const float* __restrict__ a, int lda,
+                                                        int R, int N, float* __restrict__ mean,
+                                                        float* __restrict__ var) {
+  __shared__ float red[16][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int g = blockIdx.y;
+  const float* base = a + (size_t)g * R * lda;
+  float s = 0.f;
+  if (c < N)
+    for (int r = rl; r < R; r += 16) s += base[(size_t)r * lda + c];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  float mu = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mu += red[i][threadIdx.x & 63];
+  mu /= (float)R;
+  __syncthreads();
+  float q = 0.f;
+  if (c < N)
+    for (int r = rl; r < R; r += 16) {
+      const float d = base[(size_t)r * lda + c] - mu;
+      q = fmaf(d, d, q);
+    }
+  red[rl][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v += red[i][threadIdx.x & 63];
+    mean[(size_t)g * N + c] = mu;
+    var[(size_t)g * N + c] = v / (float)R;
+  }
+}
+
+int bn_stats(hipStream_t stream, const float* a, int lda, int rows_per_group, int groups, int N,
+             float* mean, float* var) {
+  SCVAE_ARG(a && mean && var && rows_per_group > 0 && groups > 0 && N > 0);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3((N + 63) / 64, groups), dim3(1024), 0, stream, a, lda,
+                     rows_per_group, N, mean, var);
+  SCVAE_LAUNCH_CHECK("bn_stats_kernel");
+  return 0;
+}
+
+// h = [relu]((a - mean) * rsqrt(var + eps) + beta); stat_stride = N for per-group batch
+// statistics, 0 for the moving statistics shared by all groups (is_training=False).
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ a, int lda,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ var,
+                                                       int stat_stride,
+                                                       const float* __restrict__ beta,
+                                                       float* __restrict__ h, int ldh, int R,
+                                                       int groups, int N, int relu) {
+  const size_t total = (size_t)R * groups * N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % N);
+    const size_t row = i / N;
+    const int g = (int)(row / R);
+    const float mu = mean[(size_t)g * stat_stride + c];
+    const float istd = rsqrtf(var[(size_t)g * stat_stride + c] + BN_EPSILON);
+    float v = (a[row * lda + c] - mu) * istd + beta[c];
+    if (relu) v = fmaxf(v, 0.f);
+    h[row * ldh + c] = v;
+  }
+}
+
+int bn_apply(hipStream_t stream, const float* a, int lda, const float* mean, const float* var,
+             int stat_stride, const float* beta, float* h, int ldh, int rows_per_group, int groups,
+             int N, int relu) {
+  SCVAE_ARG(a && mean && var && beta && h);
+  const size_t total = (size_t)rows_per_group * groups * N;
+  if (total == 0) return 0;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, stream, a, lda, mean, var,
+                     stat_stride, beta, h, ldh, rows_per_group, groups, N, relu);
+  SCVAE_LAUNCH_CHECK("bn_apply_kernel");
+  return 0;
+}
+
+// moving <- moving - (moving - batch) * (1 - decay), applied group after group (the K
+// passes of the GMVAE share one pair of moving statistics); variance is Bessel-corrected.
+__global__ void bn_update_moving_kernel(const float* __restrict__ mean,
+                                        const float* __restrict__ var, int R, int groups, int N,
+                                        float* __restrict__ moving_mean,
+                                        float* __restrict__ moving_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float mm = moving_mean[c], mv = moving_var[c];
+  const float bessel = (float)R / (float)(R > 1 ? R - 1 : 1);
+  for (int g = 0; g < groups; ++g) {
+    mm -= (mm - mean[(size_t)g * N + c]) * (1.f - BN_DECAY);
+    mv -= (mv - var[(size_t)g * N + c] * bessel) * (1.f - BN_DECAY);
+  }
+  moving_mean[c] = mm;
+  moving_var[c] = mv;
+}
+
+int bn_update_moving(hipStream_t stream, const float* mean, const float* var, int rows_per_group,
+                     int groups, int N, float* moving_mean, float* moving_var) {
+  SCVAE_ARG(mean && var && moving_mean && moving_var && N > 0);
+  hipLaunchKernelGGL(bn_update_moving_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, mean, var,
+                     rows_per_group, groups, N, moving_mean, moving_var);
+  SCVAE_LAUNCH_CHECK("bn_update_moving_kernel");
+  return 0;
+}
+
+// s1[g,c] = sum_r dA, s2[g,c] = sum_r dA * xhat with dA = dh * (h > 0) [relu]
+__global__ __launch_bounds__(1024) void bn_bwd_stats_kernel(
+    const float* __restrict__ dh, int lddh, const float* __restrict__ h, int ldh,
+    const float* __restrict__ a, int lda, const float* __restrict__ mean,
+    const float* __restrict__ var, int R, int N, int relu, float* __restrict__ s1,
+    float* __restrict__ s2) {
+  __shared__ float red1[16][64];
+  __shared__ float red2[16][64];
+  const int cl = threadIdx.x & 63;
+  const int c = blockIdx.x * 64 + cl;
+  const int rl = threadIdx.x >> 6;
+  const int g = blockIdx.y;
+  float a1 = 0.f, a2 = 0.f;
+  if (c < N) {
+    const float mu = mean[(size_t)g * N + c];
+    const float istd = rsqrtf(var[(size_t)g * N + c] + BN_EPSILON);
+    for (int r = rl; r < R; r += 16) {
+      const size_t row = (size_t)g * R + r;
+      float d = dh[row * lddh + c];
+      if (relu && !(h[row * ldh + c] > 0.f)) d = 0.f;
+      const float xh = (a[row * lda + c] - mu) * istd;
+      a1 += d;
+      a2 = fmaf(d, xh, a2);
+    }
+  }
+  red1[rl][cl] = a1;
+  red2[rl][cl] = a2;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { t1 += red1[i][cl]; t2 += red2[i][cl]; }
+    s1[(size_t)g * N + c] = t1;
+    s2[(size_t)g * N + c] = t2;
+  }
+}
+
+int bn_bwd_stats(hipStream_t stream, const float* dh, int lddh, const float* h, int ldh,
+                 const float* a, int lda, const float* mean, const float* var, int rows_per_group,
+                 int groups, int N, int relu, float* s1, float* s2) {
+  SCVAE_ARG(dh && h && a && mean && var && s1 && s2);
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((N + 63) / 64, groups), dim3(1024), 0, stream, dh,
+                     lddh, h, ldh, a, lda, mean, var, rows_per_group, N, relu, s1, s2);
+  SCVAE_LAUNCH_CHECK("bn_bwd_stats_kernel");
+  return 0;
+}
+
+// da = istd * (dA - s1*inv_count - xhat * s2*inv_count); inv_count = 1 / (rows of the
+// whole (global) minibatch in the group), s1/s2 the matching global sums
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ dh, int lddh, const float* __restrict__ h, int ldh,
+    const float* __restrict__ a, int lda, const float* __restrict__ mean,
+    const float* __restrict__ var, const float* __restrict__ s1, const float* __restrict__ s2,
+    int R, int groups, int N, int relu, float inv_count, float* __restrict__ da, int ldda) {
+  const size_t total = (size_t)R * groups * N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % N);
+    const size_t row = i / N;
+    const int g = (int)(row / R);
+    const float mu = mean[(size_t)g * N + c];
+    const float istd = rsqrtf(var[(size_t)g * N + c] + BN_EPSILON);
+    float d = dh[row * lddh + c];
+    if (relu && !(h[row * ldh + c] > 0.f)) d = 0.f;
+    const float xh = (a[row * lda + c] - mu) * istd;
+    da[row * ldda + c] =
+        istd * (d - s1[(size_t)g * N + c] * inv_count - xh * s2[(size_t)g * N + c] * inv_count);
+  }
+}
+
+__global__ void bn_dbeta_kernel(const float* __restrict__ s1, int groups, int N,
+                                float* __restrict__ dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int g = 0; g < groups; ++g) s += s1[(size_t)g * N + c];
+  dbeta[c] = accumulate ? dbeta[c] + s : s;
+}
+
+int bn_bwd_apply(hipStream_t stream, const float* dh, int lddh, const float* h, int ldh,
+                 const float* a, int lda, const float* mean, const float* var, const float* s1,
+                 const float* s2, int rows_per_group, int groups, int N, int relu, float inv_count,
+                 float* da, int ldda) {
+  SCVAE_ARG(dh && h && a && mean && var && s1 && s2 && da);
+  const size_t total = (size_t)rows_per_group * groups * N;
+  if (total == 0) return 0;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, stream, dh, lddh, h, ldh, a,
+                     lda, mean, var, s1, s2, rows_per_group, groups, N, relu, inv_count, da, ldda);
+  SCVAE_LAUNCH_CHECK("bn_bwd_apply_kernel");
+  return 0;
+}
+
+int bn_dbeta(hipStream_t stream, const float* s1, int groups, int N, float* dbeta,
+             int accumulate) {
+  SCVAE_ARG(s1 && dbeta && N > 0);
+  hipLaunchKernelGGL(bn_dbeta_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, s1, groups, N,
+                     dbeta, accumulate);
+  SCVAE_LAUNCH_CHECK("bn_dbeta_kernel");
+  return 0;
+}
+
+// Chan et al. merge of per-rank (count, mean, biased var): gathered = [ranks][mean(n)|var(n)]
+__global__ void bn_merge_kernel(const float* __restrict__ gathered,
+                                const int64_t* __restrict__ counts, int ranks, int n,
+                                float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  double total = 0.0, mean = 0.0;
+  for (int r = 0; r < ranks; ++r) {
+    total += (double)counts[r];
+    mean += (double)counts[r] * (double)gathered[(size_t)r * 2 * n + c];
+  }
+  mean /= total;
+  double m2 = 0.0;
+  for (int r = 0; r < ranks; ++r) {
+    const double d = (double)gathered[(size_t)r * 2 * n + c] - mean;
+    m2 += (double)counts[r] * ((double)gathered[(size_t)r * 2 * n + n + c] + d * d);
+  }
+  out[c] = (float)mean;
+  out[n + c] = (float)(m2 / total);
+}
+
+int bn_merge(hipStream_t stream, const float* gathered, const int64_t* counts, int ranks, int n,
+             float* out) {
+  SCVAE_ARG(gathered && counts && out && ranks > 0 && n > 0);
+  hipLaunchKernelGGL(bn_merge_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, gathered, counts,
+                     ranks, n, out);
+  SCVAE_LAUNCH_CHECK("bn_merge_kernel");
+  return 0;
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ h,
+                                float* __restrict__ da, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    da[i] = h[i] > 0.f ? dh[i] : 0.f;
+}
+int relu_bwd(hipStream_t stream, const float* dh, const float* h, float* da, size_t n) {
+  SCVAE_ARG(dh && h && da);
+  if (n == 0) return 0;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, stream, dh, h, da, n);
+  SCVAE_LAUNCH_CHECK("relu_bwd_kernel");
+  return 0;
+}
+
+// out[c] (+)= scale * sum_r a[r,c]; grid ceil(N/64), 64 columns x 16 row lanes
+__global__ __launch_bounds__(1024) void col_sum_kernel(const float* __restrict__ a, int lda,
+                                                       int rows, int N, float* __restrict__ out,
+                                                       float scale, int accumulate) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63;
+  const int c = blockIdx.x * 64 + cl;
+  const int rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < N)
+    for (int r = rl; r < rows; r += 16) s += a[(size_t)r * lda + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][cl];
+    t *= scale;
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+
+int col_sum(hipStream_t stream, const float* a, int lda, int rows, int N, float* out, float scale,
+            int accumulate) {
+  SCVAE_ARG(a && out && N > 0 && rows >= 0);
+  hipLaunchKernelGGL(col_sum_kernel, dim3((N + 63) / 64), dim3(1024), 0, stream, a, lda, rows, N,
+                     out, scale, accumulate);
+  SCVAE_LAUNCH_CHECK("col_sum_kernel");
+  return 0;
+}
+
+// ================================ optimiser ================================
+
+// g <- clip(g * grad_scale, -1, 1); TF Adam: m,v update; theta -= lr_t * m / (sqrt(v) + eps)
+__global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ theta,
+                                                        float* __restrict__ grad,
+                                                        float* __restrict__ m,
+                                                        float* __restrict__ v, size_t n,
+                                                        float grad_scale, float lr_t, float beta1,
+                                                        float beta2, float epsilon) {
+  const size_t n4 = n / 4;
+  float4* th4 = reinterpret_cast<float4*>(theta);
+  const float4* g4 = reinterpret_cast<const float4*>(grad);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  auto upd = [&](float& th, float g, float& mm, float& vv) {
+    g = fminf(fmaxf(g * grad_scale, -1.f), 1.f);
+    mm = beta1 * mm + (1.f - beta1) * g;
+    vv = beta2 * vv + (1.f - beta2) * g * g;
+    th -= lr_t * mm / (sqrtf(vv) + epsilon);
+  };
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float4 th = th4[i], g = g4[i], mm = m4[i], vv = v4[i];
+    upd(th.x, g.x, mm.x, vv.x);
+    upd(th.y, g.y, mm.y, vv.y);
+    upd(th.z, g.z, mm.z, vv.z);
+    upd(th.w, g.w, mm.w, vv.w);
+    th4[i] = th; m4[i] = mm; v4[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    upd(theta[i], grad[i], m[i], v[i]);
+  }
+}
+
+int adam_clip_step(hipStream_t stream, float* theta, float* grad, float* m, float* v, size_t n,
+                   float grad_scale, float lr_t, float beta1, float beta2, float epsilon) {
+  SCVAE_ARG(theta && grad && m && v);
+  SCVAE_ARG(((uintptr_t)theta | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) % 16 == 0);
+  if (n == 0) return 0;
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(adam_clip_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, theta, grad,
+                     m, v, n, grad_scale, lr_t, beta1, beta2, epsilon);
+  SCVAE_LAUNCH_CHECK("adam_clip_kernel");
+  return 0;
+}
+
+// ============================== CSR minibatch ==============================
+
+// one workgroup per gathered row: scatter the row's nonzeros into the (pre-zeroed) dense row
+__global__ __launch_bounds__(256) void csr_scatter_kernel(const int64_t* __restrict__ indptr,
+                                                          const int32_t* __restrict__ indices,
+                                                          const float* __restrict__ values,
+                                                          const int64_t* __restrict__ rows, int F,
+                                                          float* __restrict__ out, int ldo) {
+  const int b = blockIdx.x;
+  const int64_t r = rows[b];
+  const int64_t lo = indptr[r], hi = indptr[r + 1];
+  float* orow = out + (size_t)b * ldo;
+  for (int64_t j = lo + threadIdx.x; j < hi; j += 256) {
+    const int32_t c = indices[j];
+    if (c >= 0 && c < F) orow[c] = values[j];
+  }
+}
+
+int csr_densify(hipStream_t stream, const int64_t* indptr, const int32_t* indices,
+                const float* values, const int64_t* rows, int B, int F, float* out, int ldo) {
+  SCVAE_ARG(indptr && indices && values && rows && out && F > 0 && ldo >= F);
+  if (B == 0) return 0;
+  SCVAE_HIP(hipMemsetAsync(out, 0, (size_t)B * ldo * sizeof(float), stream));
+  hipLaunchKernelGGL(csr_scatter_kernel, dim3(B), dim3(256), 0, stream, indptr, indices, values,
+                     rows, F, out, ldo);
+  SCVAE_LAUNCH_CHECK("csr_scatter_kernel");
+  return 0;
+}
+
+// out[r] = sum_j lgamma(1 + values[j]) over the nonzeros of row r (one wave per row)
+__global__ __launch_bounds__(256) void csr_row_lgamma1p_kernel(const int64_t* __restrict__ indptr,
+                                                               const float* __restrict__ values,
+                                                               int64_t n_rows,
+                                                               float* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int64_t j = indptr[r] + lane; j < indptr[r + 1]; j += 64) s += lgamma1p(values[j]);
+  s = wave_sum(s);
+  if (lane == 0) out[r] = s;
+}
+
+int csr_row_lgamma1p(hipStream_t stream, const int64_t* indptr, const float* values,
+                     int64_t n_rows, float* out) {
+  SCVAE_ARG(indptr && values && out);
+  if (n_rows == 0) return 0;
+  hipLaunchKernelGGL(csr_row_lgamma1p_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0,
+                     stream, indptr, values, n_rows, out);
+  SCVAE_LAUNCH_CHECK("csr_row_lgamma1p_kernel");
+  return 0;
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ rows,
+                                   int B, float* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) out[b] = src[rows[b]];
+}
+int gather_rows_f32(hipStream_t stream, const float* src, const int64_t* rows, int B, float* out) {
+  SCVAE_ARG(src && rows && out);
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, src, rows, B,
+                     out);
+  SCVAE_LAUNCH_CHECK("gather_rows_kernel");
+  return 0;
+}
+
+// ================================ Philox ===================================
+
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+// thread per (row, group of 4 columns): counter = (row_lo, row_hi, col_group, stream_id),
+// key = seed.  u = ((x >> 8) + 0.5) * 2^-24; Box-Muller on (u0,u1) and (u2,u3).
+__global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, int64_t rows,
+                                                            int cols, int64_t row_offset,
+                                                            uint32_t seed_lo, uint32_t seed_hi,
+                                                            uint32_t stream_id) {
+  const int groups = (cols + 3) / 4;
+  const int64_t total = rows * groups;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / groups;
+    const int cg = (int)(i % groups);
+    const uint64_t grow = (uint64_t)(row + row_offset);
+    uint32_t c[4] = {(uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)cg, stream_id};
+    uint32_t k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    float u[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[j] = ((float)(c[j] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    float n[4];
+    const float r0 = sqrtf(-2.f * logf(u[0])), r1 = sqrtf(-2.f * logf(u[2]));
+    const float th0 = 6.283185307179586f * u[1], th1 = 6.283185307179586f * u[3];
+    n[0] = r0 * cosf(th0); n[1] = r0 * sinf(th0);
+    n[2] = r1 * cosf(th1); n[3] = r1 * sinf(th1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = cg * 4 + j;
+      if (col < cols) out[row * cols + col] = n[j];
+    }
+  }
+}
+
+int philox_normal(hipStream_t stream, float* out, int64_t rows, int cols, int64_t row_offset,
+                  uint64_t seed, uint64_t stream_id) {
+  SCVAE_ARG(out && rows >= 0 && cols > 0);
+  if (rows == 0) return 0;
+  const int64_t total = rows * ((cols + 3) / 4);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, out, rows,
+                     cols, row_offset, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)stream_id);
+  SCVAE_LAUNCH_CHECK("philox_normal_kernel");
+  return 0;
+}
+
+}  // namespace scvae

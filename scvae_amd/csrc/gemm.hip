@@ -1,0 +1,192 @@
+// Generic fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32):
+//   C[M,N] (+)= act(op(A)[M,K] * op(B)[K,N] + bias[N])
+// This is the dense layer of scvae/models/utilities.py:38-76
+// (tf.contrib.layers.fully_connected: x*W + b, optional ReLU) and its two
+// backward contractions (dX = dY*W^T, dW = X^T*dY).  fp32 in, fp32 accumulate:
+// the MFMA result is bit-identical to a k-ordered fmaf chain.
+//
+// Tile: 64x64 per 256-thread workgroup (4 waves, one 32x32 accumulator each),
+// BK = 16, operands staged k-major in LDS so that the MFMA A/B fragment reads
+// (lane l: A[i=l&31][k=l>>5]) are bank-conflict free.  Optional split-K writes
+// fp32 partial slabs that a second kernel reduces in a fixed order
+// (deterministic; no atomics).
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace scvae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GT = 64;   // tile edge
+constexpr int GBK = 16;  // k-step staged per barrier
+constexpr int GLD = GT + 4;
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+    float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, int act, int accumulate,
+    int k_chunk, float* __restrict__ slabs) {
+  __shared__ float As[2][GBK][GLD];
+  __shared__ float Bs[2][GBK][GLD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  const int kz = blockIdx.z;
+  const int k_begin = kz * k_chunk;
+  const int k_end = min(K, k_begin + k_chunk);
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  float ra[4], rb[4];
+  auto load_tiles = [&](int kt) {
+    // A tile: 64 (m) x 16 (k)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int m, k;
+      if (TA) { m = tid & 63; k = (tid >> 6) + 4 * p; }
+      else    { k = tid & 15; m = (tid >> 4) + 16 * p; }
+      const int gm = m0 + m, gk = kt + k;
+      float v = 0.f;
+      if (gm < M && gk < k_end) v = TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
+      ra[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int n, k;
+      if (TB) { k = tid & 15; n = (tid >> 4) + 16 * p; }
+      else    { n = tid & 63; k = (tid >> 6) + 4 * p; }
+      const int gn = n0 + n, gk = kt + k;
+      float v = 0.f;
+      if (gn < N && gk < k_end) v = TB ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn];
+      rb[p] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int m, k;
+      if (TA) { m = tid & 63; k = (tid >> 6) + 4 * p; }
+      else    { k = tid & 15; m = (tid >> 4) + 16 * p; }
+      As[buf][k][m] = ra[p];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int n, k;
+      if (TB) { k = tid & 15; n = (tid >> 4) + 16 * p; }
+      else    { n = tid & 63; k = (tid >> 6) + 4 * p; }
+      Bs[buf][k][n] = rb[p];
+    }
+  };
+
+  int buf = 0;
+  if (k_begin < k_end) {
+    load_tiles(k_begin);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int kt = k_begin; kt < k_end; kt += GBK) {
+    const bool has_next = kt + GBK < k_end;
+    if (has_next) load_tiles(kt + GBK);  // global loads in flight under the MFMAs
+    const int kh = lane >> 5, li = lane & 31;
+#pragma unroll
+    for (int kk = 0; kk < GBK; kk += 2) {
+      const float a = As[buf][kk + kh][wm * 32 + li];
+      const float b = Bs[buf][kk + kh][wn * 32 + li];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (has_next) store_tiles(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int col = n0 + wn * 32 + (lane & 31);
+  if (col >= N) return;
+  const float bv = (bias != nullptr && slabs == nullptr) ? bias[col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row >= M) continue;
+    if (slabs != nullptr) {
+      slabs[((size_t)kz * M + row) * N + col] = acc[r];
+    } else {
+      float v = acc[r] + bv;
+      if (act == ACT_RELU) v = fmaxf(v, 0.f);
+      float* c = C + (size_t)row * ldc + col;
+      *c = accumulate ? (*c + v) : v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(
+    const float* __restrict__ slabs, const float* __restrict__ bias, float* __restrict__ C, int M,
+    int N, int ldc, int splits, int act, int accumulate) {
+  const size_t total = (size_t)M * N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / N), col = (int)(i % N);
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * total + i];
+    if (bias) s += bias[col];
+    if (act == ACT_RELU) s = fmaxf(s, 0.f);
+    float* c = C + (size_t)row * ldc + col;
+    *c = accumulate ? (*c + s) : s;
+  }
+}
+
+size_t gemm_workspace_bytes(int M, int N, int K) {
+  const int splits = gemm_choose_splits(M, N, K);
+  return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+}
+
+int gemm_choose_splits(int M, int N, int K) {
+  const long tiles = (long)((M + GT - 1) / GT) * ((N + GT - 1) / GT);
+  if (tiles >= 256 || K < 1024) return 1;
+  long want = (512 + tiles - 1) / tiles;          // aim for ~2 workgroups per CU
+  long max_by_k = K / 256;                        // keep >= 256 of K per split
+  long s = want < max_by_k ? want : max_by_k;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return (int)s;
+}
+
+int gemm(hipStream_t stream, bool ta, bool tb, const float* A, const float* B, const float* bias,
+         float* C, int M, int N, int K, int lda, int ldb, int ldc, int act, bool accumulate,
+         float* workspace, size_t workspace_bytes) {
+  SCVAE_ARG(A && B && C);
+  SCVAE_ARG(M >= 0 && N >= 0 && K >= 0);
+  if (M == 0 || N == 0) return 0;
+  int splits = gemm_choose_splits(M, N, K);
+  if (splits > 1 && (workspace == nullptr ||
+                     workspace_bytes < (size_t)splits * M * N * sizeof(float)))
+    splits = 1;
+  int k_chunk = K;
+  if (splits > 1) {
+    k_chunk = (K + splits - 1) / splits;
+    k_chunk = (k_chunk + GBK - 1) / GBK * GBK;
+    splits = (K + k_chunk - 1) / k_chunk;
+  }
+  dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, splits);
+  float* slabs = splits > 1 ? workspace : nullptr;
+  const int acc = accumulate ? 1 : 0;
+#define SCVAE_GEMM_LAUNCH(TA_, TB_)                                                              \
+  hipLaunchKernelGGL((gemm_kernel<TA_, TB_>), grid, dim3(256), 0, stream, A, B, bias, C, M, N, K, \
+                     lda, ldb, ldc, act, acc, k_chunk, slabs)
+  if (ta) { if (tb) SCVAE_GEMM_LAUNCH(true, true); else SCVAE_GEMM_LAUNCH(true, false); }
+  else    { if (tb) SCVAE_GEMM_LAUNCH(false, true); else SCVAE_GEMM_LAUNCH(false, false); }
+#undef SCVAE_GEMM_LAUNCH
+  SCVAE_LAUNCH_CHECK("gemm_kernel");
+  if (splits > 1) {
+    const size_t total = (size_t)M * N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slabs, bias, C, M,
+                       N, ldc, splits, act, acc);
+    SCVAE_LAUNCH_CHECK("splitk_reduce_kernel");
+  }
+  return 0;
+}
+
+}  // namespace scvae

@@ -1,0 +1,88 @@
+// Host-side launchers of the gfx950 kernels (internal C++ interface; the
+// exported C ABI is include/scvae_hip.h).  Every launcher is asynchronous on
+// `stream`, never allocates, and returns 0 / -1 (bad argument) / -2 (HIP error).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace scvae {
+
+enum Activation : int { ACT_NONE = 0, ACT_RELU = 1 };
+
+// ---- gemm.hip ----
+int gemm_choose_splits(int M, int N, int K);
+size_t gemm_workspace_bytes(int M, int N, int K);
+int gemm(hipStream_t stream, bool ta, bool tb, const float* A, const float* B, const float* bias,
+         float* C, int M, int N, int K, int lda, int ldb, int ldc, int act, bool accumulate,
+         float* workspace, size_t workspace_bytes);
+
+// ---- elementwise.hip ----
+struct HeadPtrs {
+  float* p[3];
+};
+// per-row log-likelihood sums; rows r = s*B + b use target row b
+int loglik_fwd(hipStream_t stream, int kind, const float* t, int ldt, HeadPtrs pre, int ldp,
+               const float* row_const, float* ll, int rows, int B, int F);
+// in place: pre_j <- gw[r] * d loglik / d pre_j ; also (re)computes ll if ll != null
+int loglik_bwd(hipStream_t stream, int kind, const float* t, int ldt, HeadPtrs pre, int ldp,
+               const float* gw, const float* row_const, float* ll, int rows, int B, int F);
+// evaluate-time statistics over the S samples of each cell (va:2665-2713):
+// p_x_mean, p_x_stddev, stddev_of_p_x_given_z_mean, each [B,F]. `weight` (optional, [B], stride
+// ldw) and `accumulate` implement the GMVAE mixture sums (gm:3311-3386).
+int px_statistics(hipStream_t stream, int kind, HeadPtrs pre, int ldp, int S, int B, int F,
+                  const float* weight, int ldw, int accumulate, float* p_x_mean,
+                  float* mean_of_var, float* var_of_mean);
+int sqrt_sum(hipStream_t stream, const float* a, const float* b, float* out, size_t n);
+
+// Gaussian posterior: clip, reparameterise, analytic KL (va:2266-2289, 2346-2369, 2624-2656)
+int gauss_latent_fwd(hipStream_t stream, const float* mu_pre, const float* ls_pre,
+                     const float* eps, float* z, float* kl_elem, float* kl_cell, int S, int B,
+                     int L, int deterministic);
+int gauss_latent_bwd(hipStream_t stream, const float* mu_pre, const float* ls_pre,
+                     const float* eps, const float* dz, float kl_coeff, float* dmu_pre,
+                     float* dls_pre, int S, int B, int L);
+// ELBO terms and d(-ELBO_weighted)/d loglik (va:2717-2734, mu:129-137)
+// scalars: [0] lower_bound [1] lower_bound_weighted [2] reconstruction_error [3] kl_divergence
+int vae_elbo(hipStream_t stream, const float* ll, const float* kl_cell, int n_iw, int n_mc, int B,
+             float kl_weight_total, float row_scale, float* scalars, float* gw);
+
+// batch normalisation (tf.contrib.layers.batch_norm(center=True, scale=False), fused semantics)
+int bn_stats(hipStream_t stream, const float* a, int lda, int rows_per_group, int groups, int N,
+             float* mean, float* var);
+int bn_apply(hipStream_t stream, const float* a, int lda, const float* mean, const float* var,
+             int stat_stride, const float* beta, float* h, int ldh, int rows_per_group, int groups,
+             int N, int relu);
+int bn_update_moving(hipStream_t stream, const float* mean, const float* var, int rows_per_group,
+                     int groups, int N, float* moving_mean, float* moving_var);
+int bn_bwd_stats(hipStream_t stream, const float* dh, int lddh, const float* h, int ldh,
+                 const float* a, int lda, const float* mean, const float* var, int rows_per_group,
+                 int groups, int N, int relu, float* s1, float* s2);
+int bn_bwd_apply(hipStream_t stream, const float* dh, int lddh, const float* h, int ldh,
+                 const float* a, int lda, const float* mean, const float* var, const float* s1,
+                 const float* s2, int rows_per_group, int groups, int N, int relu, float inv_count,
+                 float* da, int ldda);
+int bn_dbeta(hipStream_t stream, const float* s1, int groups, int N, float* dbeta, int accumulate);
+int bn_merge(hipStream_t stream, const float* gathered, const int64_t* counts, int ranks, int n,
+             float* out);
+int relu_bwd(hipStream_t stream, const float* dh, const float* h, float* da, size_t n);
+int col_sum(hipStream_t stream, const float* a, int lda, int rows, int N, float* out, float scale,
+            int accumulate);
+
+// clip-by-value(+-1) and TF Adam on a flat parameter buffer (va:2742-2759)
+int adam_clip_step(hipStream_t stream, float* theta, float* grad, float* m, float* v, size_t n,
+                   float grad_scale, float lr_t, float beta1, float beta2, float epsilon);
+
+// CSR row gather + densify (va:985-998)
+int csr_densify(hipStream_t stream, const int64_t* indptr, const int32_t* indices,
+                const float* values, const int64_t* rows, int B, int F, float* out, int ldo);
+int csr_row_lgamma1p(hipStream_t stream, const int64_t* indptr, const float* values, int64_t n_rows,
+                     float* out);
+int gather_rows_f32(hipStream_t stream, const float* src, const int64_t* rows, int B, float* out);
+
+// counter-based standard-normal draws (Philox4x32-10 + Box-Muller), keyed by
+// (seed, stream id, global row, column): identical for any sharding of the rows
+int philox_normal(hipStream_t stream, float* out, int64_t rows, int cols, int64_t row_offset,
+                  uint64_t seed, uint64_t stream_id);
+
+}  // namespace scvae

@@ -1,0 +1,102 @@
+// Per-element count likelihoods of the scVAE decoder, from head pre-activations.
+//
+// Replaces the TF/TFP op chain activation -> clip_by_value -> distribution
+// .log_prob/.mean/.variance built at
+//   scvae/models/variational_autoencoder.py:2466-2505, 2583
+//   scvae/distributions/utilities.py:206-216 (poisson), 247-264 (ZIP),
+//   266-281 (negative binomial), 283-305 (ZINB)
+//   scvae/distributions/zero_inflated.py:180-199
+// in the algebraically equal stable form (log p = log_sigmoid(a),
+// log(1-p) = log_sigmoid(-a)); see oracle/likelihoods.py for the formulas.
+//
+// The data-only term -lgamma(1+t) is NOT included here: callers add the
+// per-cell constant sum_f lgamma(1+t[b,f]) once per row (it has no gradient).
+#pragma once
+#include "common.hpp"
+
+namespace scvae {
+
+#ifdef __HIPCC__
+// lp  : log p(t | theta) + lgamma(1+t)
+// g[] : d lp / d pre-activation of each head (only if GRAD)
+template <int KIND, bool GRAD>
+__device__ __forceinline__ void lik_elem(float t, const float* a, float& lp, float* g) {
+  if constexpr (KIND == LK_POISSON) {
+    const float ll = fminf(fmaxf(a[0], -10.f), 10.f);
+    const float lam = __expf(ll);
+    lp = t * ll - lam;
+    if (GRAD) g[0] = (a[0] >= -10.f && a[0] <= 10.f) ? (t - lam) : 0.f;
+  } else if constexpr (KIND == LK_NB) {
+    const float ap = fmaxf(a[0], LOGIT_OF_TINY);
+    const float logp = log_sigmoid(ap), log1mp = log_sigmoid(-ap);
+    const float lr = fminf(fmaxf(a[1], -10.f), 10.f);
+    const float r = __expf(lr);
+    float A, D;
+    lgamma_digamma_diff<GRAD>(r, t, A, D);
+    lp = r * log1mp + t * logp + A;
+    if (GRAD) {
+      const float p = sigmoidf(ap);
+      g[0] = (a[0] >= LOGIT_OF_TINY) ? (t * (1.f - p) - r * p) : 0.f;
+      g[1] = (a[1] >= -10.f && a[1] <= 10.f) ? r * (log1mp + D) : 0.f;
+    }
+  } else {
+    // zero-inflated: head 0 is pi, the rest belong to the base distribution
+    float lpb;
+    float gb[2];
+    if constexpr (KIND == LK_ZIP) {
+      lik_elem<LK_POISSON, GRAD>(t, a + 1, lpb, gb);
+    } else {
+      lik_elem<LK_NB, GRAD>(t, a + 1, lpb, gb);
+    }
+    const float api = fmaxf(a[0], LOGIT_OF_TINY);
+    const float logpi = log_sigmoid(api), log1mpi = log_sigmoid(-api);
+    const float pi = sigmoidf(api);
+    const bool gate = a[0] >= LOGIT_OF_TINY;
+    constexpr int NB_HEADS = (KIND == LK_ZIP) ? 1 : 2;
+    if (t > 0.f) {
+      lp = log1mpi + lpb;
+      if (GRAD) {
+        g[0] = gate ? -pi : 0.f;
+#pragma unroll
+        for (int j = 0; j < NB_HEADS; ++j) g[1 + j] = gb[j];
+      }
+    } else {
+      const float u1 = logpi, u2 = log1mpi + lpb;
+      const float m = fmaxf(u1, u2);
+      const float y0 = m + log1pf(__expf(-fabsf(u1 - u2)));
+      lp = y0;
+      if (GRAD) {
+        const float u = __expf(u1 - y0);   // pi / (pi + (1-pi) e^lpb)
+        const float w = __expf(u2 - y0);   // 1 - u
+        g[0] = gate ? (u * (1.f - pi) - w * pi) : 0.f;
+#pragma unroll
+        for (int j = 0; j < NB_HEADS; ++j) g[1 + j] = w * gb[j];
+      }
+    }
+  }
+}
+
+// E[x|z] and Var[x|z] (TFP semantics; evaluate-time statistics, va:2665-2713)
+template <int KIND>
+__device__ __forceinline__ void lik_mean_var(const float* a, float& mean, float& var) {
+  if constexpr (KIND == LK_POISSON) {
+    const float lam = __expf(fminf(fmaxf(a[0], -10.f), 10.f));
+    mean = lam; var = lam;
+  } else if constexpr (KIND == LK_NB) {
+    const float ap = fmaxf(a[0], LOGIT_OF_TINY);
+    const float r = __expf(fminf(fmaxf(a[1], -10.f), 10.f));
+    mean = r * __expf(ap);               // r * p/(1-p)
+    var = mean * (1.f + __expf(ap));     // mean / (1-p)
+  } else {
+    float m, v;
+    if constexpr (KIND == LK_ZIP) lik_mean_var<LK_POISSON>(a + 1, m, v);
+    else lik_mean_var<LK_NB>(a + 1, m, v);
+    const float api = fmaxf(a[0], LOGIT_OF_TINY);
+    const float omp = sigmoidf(-api);
+    mean = omp * m;
+    var = omp * (v + m * m) - mean * mean;
+  }
+}
+#endif
+
+}  // namespace scvae

@@ -1,0 +1,676 @@
+// Host-side execution plan: the MI355X replacement of the reference's TF graph
+// (build: variational_autoencoder.py:2219-2770; run: session.run in the loops at
+// variational_autoencoder.py:987-1044, 1092-1150, 1969-2014).  A plan owns no device
+// memory: parameters, gradients, moving statistics and workspace are bound by the
+// caller.  scvae_plan_step enqueues the whole forward (+backward) kernel sequence on
+// one stream with no host synchronisation.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/scvae_hip.h"
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace scvae {
+
+// ------------------------------ errors ------------------------------------
+static thread_local char g_error[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+}
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+  return -2;
+}
+const char* last_error() { return g_error; }
+
+// ------------------------------ layout ------------------------------------
+constexpr size_t NPOS = (size_t)-1;
+constexpr size_t ALIGN_FLOATS = 64;  // every tensor starts on a 256-byte boundary
+
+struct ParamInfo {
+  std::string name;
+  size_t offset;
+  int rows, cols;  // cols == 0 for vectors
+};
+struct MovingInfo {
+  std::string name;
+  size_t offset;
+  int size;
+};
+struct Dense {
+  int n_in = 0, n_out = 0;
+  size_t w = NPOS, b = NPOS, beta = NPOS;      // offsets in the flat parameter buffer
+  size_t mov_mean = NPOS, mov_var = NPOS;      // offsets in the moving-statistics buffer
+  bool bn = false;
+  // workspace (assigned at bind)
+  float* a = nullptr;      // pre-normalisation output [rows, n_out] (BN only)
+  float* h = nullptr;      // layer output [rows, n_out]
+  float* stats = nullptr;  // [mean | var | s1 | s2], each groups*n_out
+};
+
+struct Layout {
+  std::vector<ParamInfo> params;
+  std::vector<MovingInfo> moving;
+  size_t n_params = 0, n_moving = 0;
+  size_t add(const std::string& name, int rows, int cols) {
+    const size_t off = n_params;
+    params.push_back({name, off, rows, cols});
+    const size_t n = (size_t)rows * (cols ? cols : 1);
+    n_params += (n + ALIGN_FLOATS - 1) / ALIGN_FLOATS * ALIGN_FLOATS;
+    return off;
+  }
+  size_t add_moving(const std::string& name, int size) {
+    const size_t off = n_moving;
+    moving.push_back({name, off, size});
+    n_moving += ((size_t)size + ALIGN_FLOATS - 1) / ALIGN_FLOATS * ALIGN_FLOATS;
+    return off;
+  }
+  Dense dense(const std::string& scope, int n_in, int n_out, bool bn) {
+    Dense d;
+    d.n_in = n_in; d.n_out = n_out; d.bn = bn;
+    d.w = add(scope + "/DENSE/weights", n_in, n_out);
+    d.b = add(scope + "/DENSE/biases", n_out, 0);
+    if (bn) {
+      d.beta = add(scope + "/BATCH_NORM/beta", n_out, 0);
+      d.mov_mean = add_moving(scope + "/BATCH_NORM/moving_mean", n_out);
+      d.mov_var = add_moving(scope + "/BATCH_NORM/moving_variance", n_out);
+    }
+    return d;
+  }
+};
+
+static const char* head_names(int kind, int j) {
+  static const char* P[] = {"LOG_LAMBDA"};
+  static const char* NB[] = {"P", "LOG_R"};
+  static const char* ZIP[] = {"PI", "LOG_LAMBDA"};
+  static const char* ZINB[] = {"PI", "P", "LOG_R"};
+  switch (kind) {
+    case LK_POISSON: return P[j];
+    case LK_NB: return NB[j];
+    case LK_ZIP: return ZIP[j];
+    default: return ZINB[j];
+  }
+}
+
+struct Bump {
+  char* base;
+  size_t used = 0, cap;
+  bool dry;  // dry run: only measure
+  Bump(void* b, size_t c, bool d) : base((char*)b), cap(c), dry(d) {}
+  float* floats(size_t n) {
+    const size_t bytes = (n * sizeof(float) + 255) / 256 * 256;
+    char* p = dry ? nullptr : base + used;
+    used += bytes;
+    return (float*)p;
+  }
+};
+
+}  // namespace scvae
+
+using namespace scvae;
+
+struct scvae_plan {
+  scvae_model_config cfg;
+  Layout layout;
+  int P = 1;  // likelihood heads
+  // VAE graph
+  std::vector<Dense> enc, dec;
+  Dense mu, ls;
+  Dense heads[3];
+  // bound buffers
+  float *params = nullptr, *grads = nullptr, *moving = nullptr;
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  int64_t max_cells = 0, max_samples = 0;
+  // workspace views
+  float *mu_pre = nullptr, *ls_pre = nullptr, *kl_elem = nullptr, *kl_cell = nullptr;
+  float *z = nullptr, *ll = nullptr, *gw = nullptr;
+  float* pre[3] = {nullptr, nullptr, nullptr};
+  float *dbuf[3] = {nullptr, nullptr, nullptr}, *dz = nullptr, *dmu = nullptr, *dls = nullptr;
+  float *mov = nullptr, *vom = nullptr;  // evaluate statistics scratch [cells, F]
+  float* gemm_ws = nullptr;
+  size_t gemm_ws_bytes = 0;
+  scvae_sync_fn sync = nullptr;
+  void* sync_user = nullptr;
+};
+
+namespace scvae {
+
+static int build_vae(scvae_plan* p) {
+  const scvae_model_config& c = p->cfg;
+  const bool bn = c.batch_norm != 0;
+  Layout& L = p->layout;
+  int n_in = c.feature_size;
+  char scope[64];
+  for (int i = 0; i < c.n_hidden; ++i) {
+    snprintf(scope, sizeof scope, "ENCODER/%d", i + 1);
+    p->enc.push_back(L.dense(scope, n_in, c.hidden[i], bn));
+    n_in = c.hidden[i];
+  }
+  p->mu = L.dense("POSTERIOR/MU", n_in, c.latent_size, false);
+  p->ls = L.dense("POSTERIOR/LOG_SIGMA", n_in, c.latent_size, false);
+  n_in = c.latent_size;
+  // dense_layers(reverse_order=True): sizes reversed, scopes numbered n..1 (mu:102-105)
+  for (int i = 0; i < c.n_hidden; ++i) {
+    const int h = c.hidden[c.n_hidden - 1 - i];
+    snprintf(scope, sizeof scope, "DECODER/%d", c.n_hidden - i);
+    p->dec.push_back(L.dense(scope, n_in, h, bn));
+    n_in = h;
+  }
+  for (int j = 0; j < p->P; ++j) {
+    snprintf(scope, sizeof scope, "X_TILDE/%s", head_names(c.likelihood, j));
+    p->heads[j] = L.dense(scope, n_in, c.feature_size, false);
+  }
+  return 0;
+}
+
+// carve (or measure) the workspace
+static size_t carve(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t samples,
+                    bool dry) {
+  const scvae_model_config& c = p->cfg;
+  Bump b(base, cap, dry);
+  const size_t B = (size_t)cells, R = (size_t)cells * samples;
+  const size_t Lz = c.latent_size, F = c.feature_size;
+  size_t hmax = Lz;
+  size_t gws = 0;
+  auto track = [&](size_t M, size_t N, size_t K) {
+    const size_t w = gemm_workspace_bytes((int)M, (int)N, (int)K);
+    if (w > gws) gws = w;
+  };
+  auto layer_ws = [&](Dense& d, size_t rows) {
+    float* a = d.bn ? b.floats(rows * d.n_out) : nullptr;
+    float* h = b.floats(rows * d.n_out);
+    float* st = d.bn ? b.floats(4 * (size_t)d.n_out) : nullptr;
+    if (!dry) { d.a = a; d.h = h; d.stats = st; }
+    if ((size_t)d.n_out > hmax) hmax = d.n_out;
+    if ((size_t)d.n_in > hmax && d.n_in != c.feature_size) hmax = d.n_in;
+    track(rows, d.n_out, d.n_in);  // forward
+    track(d.n_in, d.n_out, rows);  // dW
+    track(rows, d.n_in, d.n_out);  // dX
+  };
+  for (auto& d : p->enc) layer_ws(d, B);
+  for (auto& d : p->dec) layer_ws(d, R);
+  float* mu_pre = b.floats(B * Lz);
+  float* ls_pre = b.floats(B * Lz);
+  float* kl_elem = b.floats(B * Lz);
+  float* kl_cell = b.floats(B);
+  float* z = b.floats(R * Lz);
+  float* ll = b.floats(R);
+  float* gw = b.floats(R);
+  float* pre[3] = {nullptr, nullptr, nullptr};
+  for (int j = 0; j < p->P; ++j) pre[j] = b.floats(R * F);
+  float* d0 = b.floats(R * hmax);
+  float* d1 = b.floats(R * hmax);
+  float* d2 = b.floats(R * hmax);
+  float* dz = b.floats(R * Lz);
+  float* dmu = b.floats(B * Lz);
+  float* dls = b.floats(B * Lz);
+  float* mov = b.floats(B * F);
+  float* vom = b.floats(B * F);
+  const int hn = c.n_hidden ? c.hidden[c.n_hidden - 1] : c.feature_size;
+  const int h1 = c.n_hidden ? c.hidden[0] : c.latent_size;
+  track(B, Lz, hn); track(hn, Lz, B); track(B, hn, Lz);
+  track(R, F, h1); track(h1, F, R); track(R, h1, F);
+  float* gemm_ws = gws ? b.floats(gws / sizeof(float)) : nullptr;
+  if (!dry) {
+    p->mu_pre = mu_pre; p->ls_pre = ls_pre; p->kl_elem = kl_elem; p->kl_cell = kl_cell;
+    p->z = z; p->ll = ll; p->gw = gw;
+    for (int j = 0; j < 3; ++j) p->pre[j] = pre[j];
+    p->dbuf[0] = d0; p->dbuf[1] = d1; p->dbuf[2] = d2; p->dz = dz; p->dmu = dmu; p->dls = dls;
+    p->mov = mov; p->vom = vom;
+    p->gemm_ws = gemm_ws; p->gemm_ws_bytes = gws;
+  }
+  return b.used;
+}
+
+// ---- dense layer forward: fully_connected (+ batch_norm) (+ relu), mu:38-76 ----
+static int dense_forward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_in,
+                         int rows, int groups, bool relu, bool training) {
+  const float* W = p->params + d.w;
+  const float* bias = p->params + d.b;
+  if (!d.bn) {
+    return gemm(s, false, false, in, W, bias, d.h, rows, d.n_out, d.n_in, ld_in, d.n_out, d.n_out,
+                relu ? ACT_RELU : ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes);
+  }
+  int rc = gemm(s, false, false, in, W, bias, d.a, rows, d.n_out, d.n_in, ld_in, d.n_out, d.n_out,
+                ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes);
+  if (rc) return rc;
+  const int N = d.n_out;
+  if (training) {
+    const int rpg = rows / groups;
+    float* mean = d.stats;
+    float* var = d.stats + (size_t)groups * N;
+    if ((rc = bn_stats(s, d.a, N, rpg, groups, N, mean, var))) return rc;
+    if (p->sync) {
+      // statistics of the global minibatch (sync batch norm); groups == 1 on this path
+      if (p->sync(p->sync_user, d.stats, 2 * (int64_t)groups * N, 1, rpg)) {
+        set_error("batch-norm sync hook failed");
+        return -2;
+      }
+    }
+    if ((rc = bn_apply(s, d.a, N, mean, var, N, p->params + d.beta, d.h, N, rpg, groups, N,
+                       relu ? 1 : 0)))
+      return rc;
+    return 0;
+  }
+  return bn_apply(s, d.a, N, p->moving + d.mov_mean, p->moving + d.mov_var, 0, p->params + d.beta,
+                  d.h, N, rows, 1, N, relu ? 1 : 0);
+}
+
+// moving-average update (UPDATE_OPS, va:2763-2768); uses the (possibly synced) batch statistics
+static int dense_update_moving(scvae_plan* p, hipStream_t s, Dense& d, int64_t global_rows_per_group,
+                               int groups) {
+  if (!d.bn) return 0;
+  const int N = d.n_out;
+  return bn_update_moving(s, d.stats, d.stats + (size_t)groups * N, (int)global_rows_per_group,
+                          groups, N, p->moving + d.mov_mean, p->moving + d.mov_var);
+}
+
+// ---- dense layer backward.  dh: gradient w.r.t. the layer output h [rows, n_out];
+// scratch: [rows, n_out]; d_in (optional): gradient w.r.t. the layer input ----
+static int dense_backward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_in,
+                          int rows, int groups, bool relu, const float* dh, float* scratch,
+                          float* d_in, bool accumulate_d_in, int64_t global_rows_per_group) {
+  const int N = d.n_out;
+  int rc;
+  const float* da = dh;
+  if (d.bn) {
+    const int rpg = rows / groups;
+    float* mean = d.stats;
+    float* var = d.stats + (size_t)groups * N;
+    float* s1 = d.stats + 2 * (size_t)groups * N;
+    float* s2 = d.stats + 3 * (size_t)groups * N;
+    if ((rc = bn_bwd_stats(s, dh, N, d.h, N, d.a, N, mean, var, rpg, groups, N, relu ? 1 : 0, s1,
+                           s2)))
+      return rc;
+    // dbeta = sum over this rank's rows of dA (taken before s1 becomes a global sum)
+    if ((rc = bn_dbeta(s, s1, groups, N, p->grads + d.beta, 0))) return rc;
+    if (p->sync) {
+      if (p->sync(p->sync_user, s1, 2 * (int64_t)groups * N, 0, rpg)) {
+        set_error("batch-norm backward sync hook failed");
+        return -2;
+      }
+    }
+    if ((rc = bn_bwd_apply(s, dh, N, d.h, N, d.a, N, mean, var, s1, s2, rpg, groups, N,
+                           relu ? 1 : 0, 1.f / (float)global_rows_per_group, scratch, N)))
+      return rc;
+    da = scratch;
+  } else if (relu) {
+    if ((rc = relu_bwd(s, dh, d.h, scratch, (size_t)rows * N))) return rc;
+    da = scratch;
+  }
+  // dW = in^T da ; db = colsum(da)
+  if ((rc = gemm(s, true, false, in, da, nullptr, p->grads + d.w, d.n_in, N, rows, ld_in, N, N,
+                 ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+    return rc;
+  if ((rc = col_sum(s, da, N, rows, N, p->grads + d.b, 1.f, 0))) return rc;
+  if (d_in) {
+    if ((rc = gemm(s, false, true, da, p->params + d.w, nullptr, d_in, rows, d.n_in, N, N, N,
+                   d.n_in, ACT_NONE, accumulate_d_in, p->gemm_ws, p->gemm_ws_bytes)))
+      return rc;
+  }
+  return 0;
+}
+
+}  // namespace scvae
+
+namespace scvae {
+__global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+__global__ void fill_kernel(float* __restrict__ dst, float v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = v;
+}
+static int fill(hipStream_t s, float* dst, float v, size_t n) {
+  if (n == 0) return 0;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, dst, v, n);
+  SCVAE_LAUNCH_CHECK("fill_kernel");
+  return 0;
+}
+static int copy(hipStream_t s, const float* src, float* dst, size_t n) {
+  if (n == 0) return 0;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(copy_kernel, dim3(blocks), dim3(256), 0, s, src, dst, n);
+  SCVAE_LAUNCH_CHECK("copy_kernel");
+  return 0;
+}
+}  // namespace scvae
+
+namespace scvae {
+
+static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
+  const scvae_model_config& c = p->cfg;
+  const int B = (int)a->cells;
+  const int S = a->deterministic_z ? 1 : a->n_iw * a->n_mc;
+  const int n_iw = a->deterministic_z ? 1 : a->n_iw;
+  const int n_mc = a->deterministic_z ? 1 : a->n_mc;
+  const int R = B * S;
+  const int F = c.feature_size, L = c.latent_size;
+  const bool training = a->training != 0;
+  const int64_t GB = a->global_cells > 0 ? a->global_cells : a->cells;
+  const float w = a->warm_up_weight * c.kl_weight;
+  int rc;
+
+  // ---------------- forward ----------------
+  const float* h = a->x;
+  int ld = F;
+  for (auto& d : p->enc) {
+    if ((rc = dense_forward(p, s, d, h, ld, B, 1, true, training))) return rc;
+    h = d.h; ld = d.n_out;
+  }
+  Dense& mu = p->mu;
+  Dense& ls = p->ls;
+  if ((rc = gemm(s, false, false, h, p->params + mu.w, p->params + mu.b, p->mu_pre, B, L, mu.n_in,
+                 ld, L, L, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+    return rc;
+  if ((rc = gemm(s, false, false, h, p->params + ls.w, p->params + ls.b, p->ls_pre, B, L, ls.n_in,
+                 ld, L, L, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+    return rc;
+  if ((rc = gauss_latent_fwd(s, p->mu_pre, p->ls_pre, a->eps, p->z, p->kl_elem, p->kl_cell, S, B,
+                             L, a->deterministic_z)))
+    return rc;
+  if (a->kl_neurons)
+    if ((rc = col_sum(s, p->kl_elem, L, B, L, a->kl_neurons, 1.f / (float)GB, 0))) return rc;
+  if (a->q_z_mean)
+    if ((rc = copy(s, p->mu_pre, a->q_z_mean, (size_t)B * L))) return rc;
+
+  const float* dch = p->z;
+  ld = L;
+  for (auto& d : p->dec) {
+    if ((rc = dense_forward(p, s, d, dch, ld, R, 1, true, training))) return rc;
+    dch = d.h; ld = d.n_out;
+  }
+  HeadPtrs pre;
+  for (int j = 0; j < 3; ++j) pre.p[j] = p->pre[j];
+  for (int j = 0; j < p->P; ++j) {
+    Dense& hd = p->heads[j];
+    if ((rc = gemm(s, false, false, dch, p->params + hd.w, p->params + hd.b, p->pre[j], R, F,
+                   hd.n_in, ld, F, F, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+      return rc;
+  }
+  if (a->p_x_mean) {
+    if (!(a->p_x_stddev && a->stddev_of_p_x_given_z_mean)) {
+      set_error("p_x_mean requires p_x_stddev and stddev_of_p_x_given_z_mean");
+      return -1;
+    }
+    if ((rc = px_statistics(s, c.likelihood, pre, F, S, B, F, nullptr, 0, 0, a->p_x_mean, p->mov,
+                            p->vom)))
+      return rc;
+    if ((rc = sqrt_sum(s, p->vom, p->mov, a->p_x_stddev, (size_t)B * F))) return rc;
+    if ((rc = sqrt_sum(s, p->vom, nullptr, a->stddev_of_p_x_given_z_mean, (size_t)B * F)))
+      return rc;
+  }
+  const float row_scale = 1.f / ((float)n_mc * (float)GB);
+  if (!training) {
+    if ((rc = loglik_fwd(s, c.likelihood, a->t, F, pre, F, a->row_const, p->ll, R, B, F)))
+      return rc;
+    if ((rc = vae_elbo(s, p->ll, p->kl_cell, n_iw, n_mc, B, w, row_scale, a->scalars, nullptr)))
+      return rc;
+    if (a->log_p_x_given_z)
+      if ((rc = copy(s, p->ll, a->log_p_x_given_z, (size_t)R))) return rc;
+    return 0;
+  }
+
+  // ---------------- backward ----------------
+  if (n_iw == 1) {
+    // d(-ELBO_w)/d log p = -1/(MC*B) for every row: one fused likelihood pass
+    if ((rc = fill(s, p->gw, -row_scale, (size_t)R))) return rc;
+    if ((rc = loglik_bwd(s, c.likelihood, a->t, F, pre, F, p->gw, a->row_const, p->ll, R, B, F)))
+      return rc;
+    if ((rc = vae_elbo(s, p->ll, p->kl_cell, n_iw, n_mc, B, w, row_scale, a->scalars, nullptr)))
+      return rc;
+  } else {
+    if ((rc = loglik_fwd(s, c.likelihood, a->t, F, pre, F, a->row_const, p->ll, R, B, F)))
+      return rc;
+    if ((rc = vae_elbo(s, p->ll, p->kl_cell, n_iw, n_mc, B, w, row_scale, a->scalars, p->gw)))
+      return rc;
+    if ((rc = loglik_bwd(s, c.likelihood, a->t, F, pre, F, p->gw, a->row_const, nullptr, R, B,
+                         F)))
+      return rc;
+  }
+  if (a->log_p_x_given_z)
+    if ((rc = copy(s, p->ll, a->log_p_x_given_z, (size_t)R))) return rc;
+
+  // heads: dW_j = d^T G_j, db_j = colsum(G_j), dd (+)= G_j W_j^T
+  float* dcur = p->dbuf[0];
+  float* dalt = p->dbuf[1];
+  {
+    const int h1 = p->heads[0].n_in;
+    for (int j = 0; j < p->P; ++j) {
+      Dense& hd = p->heads[j];
+      if ((rc = gemm(s, true, false, dch, p->pre[j], nullptr, p->grads + hd.w, h1, F, R, ld, F, F,
+                     ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+        return rc;
+      if ((rc = col_sum(s, p->pre[j], F, R, F, p->grads + hd.b, 1.f, 0))) return rc;
+      if ((rc = gemm(s, false, true, p->pre[j], p->params + hd.w, nullptr, dcur, R, h1, F, F, F,
+                     h1, ACT_NONE, j > 0, p->gemm_ws, p->gemm_ws_bytes)))
+        return rc;
+    }
+  }
+  const int64_t GR = GB * S;  // global decoder rows
+  // decoder layers, last to first; the first decoder layer's input is z
+  for (int i = (int)p->dec.size() - 1; i >= 0; --i) {
+    Dense& d = p->dec[i];
+    const float* in = i > 0 ? p->dec[i - 1].h : p->z;
+    const int ld_in = d.n_in;
+    float* d_in = i > 0 ? dalt : p->dz;
+    float* scratch = p->dbuf[2];
+    if ((rc = dense_backward(p, s, d, in, ld_in, R, 1, true, dcur, scratch, d_in, false, GR)))
+      return rc;
+    if (i > 0) { float* t = dcur; dcur = dalt; dalt = t; }
+  }
+  // latent: dz -> dmu_pre, dls_pre  (d(-ELBO_w)/dKL_cell = w / B_global)
+  if ((rc = gauss_latent_bwd(s, p->mu_pre, p->ls_pre, a->eps, p->dz, w / (float)GB, p->dmu, p->dls,
+                             S, B, L)))
+    return rc;
+  const float* hn = p->enc.empty() ? a->x : p->enc.back().h;
+  const int ldn = p->enc.empty() ? F : p->enc.back().n_out;
+  float* dh = p->dbuf[0];
+  float* dh_alt = p->dbuf[1];
+  const bool need_dh = !p->enc.empty();
+  for (int q = 0; q < 2; ++q) {
+    Dense& hd = q == 0 ? mu : ls;
+    const float* dpre = q == 0 ? p->dmu : p->dls;
+    if ((rc = gemm(s, true, false, hn, dpre, nullptr, p->grads + hd.w, hd.n_in, L, B, ldn, L, L,
+                   ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+      return rc;
+    if ((rc = col_sum(s, dpre, L, B, L, p->grads + hd.b, 1.f, 0))) return rc;
+    if (need_dh)
+      if ((rc = gemm(s, false, true, dpre, p->params + hd.w, nullptr, dh, B, hd.n_in, L, L, L,
+                     hd.n_in, ACT_NONE, q > 0, p->gemm_ws, p->gemm_ws_bytes)))
+        return rc;
+  }
+  for (int i = (int)p->enc.size() - 1; i >= 0; --i) {
+    Dense& d = p->enc[i];
+    const float* in = i > 0 ? p->enc[i - 1].h : a->x;
+    const int ld_in = d.n_in;
+    float* d_in = i > 0 ? dh_alt : nullptr;
+    float* scratch = p->dbuf[2];
+    if ((rc = dense_backward(p, s, d, in, ld_in, B, 1, true, dh, scratch, d_in, false, GB)))
+      return rc;
+    if (i > 0) { float* t = dh; dh = dh_alt; dh_alt = t; }
+  }
+  // batch-norm moving averages
+  for (auto& d : p->enc)
+    if ((rc = dense_update_moving(p, s, d, GB, 1))) return rc;
+  for (auto& d : p->dec)
+    if ((rc = dense_update_moving(p, s, d, GR, 1))) return rc;
+  return 0;
+}
+
+}  // namespace scvae
+
+// =============================== C ABI =====================================
+extern "C" {
+
+const char* scvae_last_error(void) { return scvae::last_error(); }
+int scvae_version(void) { return 1; }
+
+int scvae_plan_create(const scvae_model_config* cfg, scvae_plan** out) {
+  SCVAE_ARG(cfg && out);
+  SCVAE_ARG(cfg->feature_size > 0 && cfg->latent_size > 0 && cfg->latent_size <= 1024);
+  SCVAE_ARG(cfg->n_hidden >= 0 && cfg->n_hidden <= SCVAE_MAX_HIDDEN);
+  SCVAE_ARG(cfg->likelihood >= 0 && cfg->likelihood <= 3);
+  for (int i = 0; i < cfg->n_hidden; ++i) SCVAE_ARG(cfg->hidden[i] > 0);
+  if (cfg->model_type != SCVAE_MODEL_VAE) {
+    scvae::set_error("model_type %d is not built in this library version", cfg->model_type);
+    return -1;
+  }
+  scvae_plan* p = new scvae_plan();
+  p->cfg = *cfg;
+  p->P = scvae::likelihood_heads(cfg->likelihood);
+  scvae::build_vae(p);
+  *out = p;
+  return 0;
+}
+
+void scvae_plan_destroy(scvae_plan* plan) { delete plan; }
+
+int64_t scvae_plan_param_count(const scvae_plan* p) { return p ? (int64_t)p->layout.params.size() : -1; }
+int64_t scvae_plan_param_floats(const scvae_plan* p) { return p ? (int64_t)p->layout.n_params : -1; }
+int64_t scvae_plan_moving_floats(const scvae_plan* p) { return p ? (int64_t)p->layout.n_moving : -1; }
+int64_t scvae_plan_moving_count(const scvae_plan* p) { return p ? (int64_t)p->layout.moving.size() : -1; }
+
+int scvae_plan_param_info(const scvae_plan* p, int64_t i, char* name, int64_t* offset,
+                          int64_t* rows, int64_t* cols) {
+  SCVAE_ARG(p && i >= 0 && i < (int64_t)p->layout.params.size());
+  const auto& q = p->layout.params[(size_t)i];
+  if (name) { strncpy(name, q.name.c_str(), SCVAE_NAME_MAX - 1); name[SCVAE_NAME_MAX - 1] = 0; }
+  if (offset) *offset = (int64_t)q.offset;
+  if (rows) *rows = q.rows;
+  if (cols) *cols = q.cols;
+  return 0;
+}
+
+int scvae_plan_moving_info(const scvae_plan* p, int64_t i, char* name, int64_t* offset,
+                           int64_t* size) {
+  SCVAE_ARG(p && i >= 0 && i < (int64_t)p->layout.moving.size());
+  const auto& q = p->layout.moving[(size_t)i];
+  if (name) { strncpy(name, q.name.c_str(), SCVAE_NAME_MAX - 1); name[SCVAE_NAME_MAX - 1] = 0; }
+  if (offset) *offset = (int64_t)q.offset;
+  if (size) *size = q.size;
+  return 0;
+}
+
+int64_t scvae_plan_workspace_bytes(const scvae_plan* p, int64_t max_cells, int64_t max_samples) {
+  if (!p || max_cells <= 0 || max_samples <= 0) return -1;
+  return (int64_t)scvae::carve(const_cast<scvae_plan*>(p), nullptr, 0, max_cells, max_samples, true);
+}
+
+int scvae_plan_bind(scvae_plan* p, float* params, float* grads, float* moving, void* workspace,
+                    int64_t workspace_bytes, int64_t max_cells, int64_t max_samples) {
+  SCVAE_ARG(p && params && workspace && max_cells > 0 && max_samples > 0);
+  SCVAE_ARG(p->layout.n_moving == 0 || moving);
+  const size_t need = scvae::carve(p, nullptr, 0, max_cells, max_samples, true);
+  if ((size_t)workspace_bytes < need) {
+    scvae::set_error("workspace too small: %lld < %zu bytes", (long long)workspace_bytes, need);
+    return -1;
+  }
+  SCVAE_ARG(((uintptr_t)workspace % 256) == 0 && ((uintptr_t)params % 256) == 0);
+  p->params = params; p->grads = grads; p->moving = moving;
+  p->ws = workspace; p->ws_bytes = (size_t)workspace_bytes;
+  p->max_cells = max_cells; p->max_samples = max_samples;
+  scvae::carve(p, workspace, (size_t)workspace_bytes, max_cells, max_samples, false);
+  return 0;
+}
+
+int scvae_plan_set_sync(scvae_plan* p, scvae_sync_fn fn, void* user) {
+  SCVAE_ARG(p);
+  p->sync = fn; p->sync_user = user;
+  return 0;
+}
+
+int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
+  SCVAE_ARG(p && a);
+  SCVAE_ARG(p->params && p->ws);
+  SCVAE_ARG(a->x && a->t && a->scalars);
+  SCVAE_ARG(a->cells > 0 && a->cells <= p->max_cells);
+  SCVAE_ARG(a->n_iw > 0 && a->n_mc > 0);
+  SCVAE_ARG(a->deterministic_z || (int64_t)a->n_iw * a->n_mc <= p->max_samples);
+  SCVAE_ARG(a->deterministic_z || a->eps);
+  SCVAE_ARG(!a->training || p->grads);
+  SCVAE_ARG(!(a->training && a->deterministic_z));
+  return scvae::vae_step(p, a, (hipStream_t)stream);
+}
+
+int scvae_adam_clip_step(float* theta, float* grad, float* m, float* v, int64_t n,
+                         float grad_scale, float lr_t, float beta1, float beta2, float epsilon,
+                         void* stream) {
+  SCVAE_ARG(n >= 0);
+  return scvae::adam_clip_step((hipStream_t)stream, theta, grad, m, v, (size_t)n, grad_scale, lr_t,
+                               beta1, beta2, epsilon);
+}
+
+int scvae_gemm(int32_t ta, int32_t tb, const float* A, const float* B, const float* bias, float* C,
+               int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t relu,
+               int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+  return scvae::gemm((hipStream_t)stream, ta != 0, tb != 0, A, B, bias, C, (int)M, (int)N, (int)K,
+                     (int)lda, (int)ldb, (int)ldc, relu ? scvae::ACT_RELU : scvae::ACT_NONE,
+                     accumulate != 0, (float*)workspace, (size_t)workspace_bytes);
+}
+int64_t scvae_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  return (int64_t)scvae::gemm_workspace_bytes((int)M, (int)N, (int)K);
+}
+
+int scvae_loglik_fwd(int32_t kind, const float* t, const float* const* pre, const float* row_const,
+                     float* ll, int64_t rows, int64_t cells, int64_t F, void* stream) {
+  SCVAE_ARG(pre && kind >= 0 && kind <= 3);
+  scvae::HeadPtrs hp = {{nullptr, nullptr, nullptr}};
+  for (int j = 0; j < scvae::likelihood_heads(kind); ++j) hp.p[j] = const_cast<float*>(pre[j]);
+  return scvae::loglik_fwd((hipStream_t)stream, kind, t, (int)F, hp, (int)F, row_const, ll,
+                           (int)rows, (int)cells, (int)F);
+}
+int scvae_loglik_bwd(int32_t kind, const float* t, float* const* pre, const float* gw,
+                     const float* row_const, float* ll, int64_t rows, int64_t cells, int64_t F,
+                     void* stream) {
+  SCVAE_ARG(pre && kind >= 0 && kind <= 3);
+  scvae::HeadPtrs hp = {{nullptr, nullptr, nullptr}};
+  for (int j = 0; j < scvae::likelihood_heads(kind); ++j) hp.p[j] = pre[j];
+  return scvae::loglik_bwd((hipStream_t)stream, kind, t, (int)F, hp, (int)F, gw, row_const, ll,
+                           (int)rows, (int)cells, (int)F);
+}
+int scvae_gauss_latent_fwd(const float* mu_pre, const float* ls_pre, const float* eps, float* z,
+                           float* kl_elem, float* kl_cell, int64_t S, int64_t cells, int64_t L,
+                           int32_t deterministic, void* stream) {
+  return scvae::gauss_latent_fwd((hipStream_t)stream, mu_pre, ls_pre, eps, z, kl_elem, kl_cell,
+                                 (int)S, (int)cells, (int)L, deterministic);
+}
+int scvae_csr_densify(const int64_t* indptr, const int32_t* indices, const float* values,
+                      const int64_t* rows, int64_t n, int64_t F, float* out, void* stream) {
+  return scvae::csr_densify((hipStream_t)stream, indptr, indices, values, rows, (int)n, (int)F, out,
+                            (int)F);
+}
+int scvae_csr_row_lgamma1p(const int64_t* indptr, const float* values, int64_t n_rows, float* out,
+                           void* stream) {
+  return scvae::csr_row_lgamma1p((hipStream_t)stream, indptr, values, n_rows, out);
+}
+int scvae_gather_rows(const float* src, const int64_t* rows, int64_t n, float* out, void* stream) {
+  return scvae::gather_rows_f32((hipStream_t)stream, src, rows, (int)n, out);
+}
+int scvae_bn_merge(const float* gathered, const int64_t* counts, int64_t ranks, int64_t n,
+                   float* out, void* stream) {
+  return scvae::bn_merge((hipStream_t)stream, gathered, counts, (int)ranks, (int)n, out);
+}
+int scvae_philox_normal(float* out, int64_t rows, int64_t cols, int64_t row_offset, uint64_t seed,
+                        uint64_t stream_id, void* stream) {
+  return scvae::philox_normal((hipStream_t)stream, out, rows, (int)cols, row_offset, seed,
+                              stream_id);
+}
+
+}  // extern "C"

@@ -1,0 +1,282 @@
+"""Device-side engine of a model: one ``scvae_plan`` plus the torch buffers it
+is bound to.
+
+This is the replacement of the reference's ``tf.Graph`` + ``tf.Session``
+(``scvae/models/variational_autoencoder.py:310-410, 887``): parameters, Adam
+slots, batch-norm moving statistics and the activation workspace live in flat
+fp32 device buffers allocated through torch (plumbing only); all arithmetic is
+done by the HIP kernels behind ``libscvae_hip.so``.
+"""
+
+import ctypes
+import math
+from collections import OrderedDict
+
+import torch
+
+from scvae_amd import _lib
+
+ADAM_BETA1 = 0.9
+ADAM_BETA2 = 0.999
+ADAM_EPSILON = 1e-8
+
+SCALAR_NAMES = ("lower_bound", "lower_bound_weighted", "reconstruction_error",
+                "kl_divergence", "kl_divergence_y")
+
+
+def _ptr(tensor):
+    return ctypes.c_void_p(tensor.data_ptr()) if tensor is not None else None
+
+
+def current_stream_handle(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Engine:
+    """Flat-buffer model state + kernel plan on one GPU."""
+
+    def __init__(self, feature_size, latent_size, hidden_sizes, likelihood,
+                 batch_norm=True, model_type="VAE", n_clusters=1,
+                 kl_weight=1.0, free_nats_proportion=0.0, device=None,
+                 seed=0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.HipLibraryError(
+                "No GPU visible: the scVAE engine has no CPU path.")
+        self.device = torch.device(device if device is not None else "cuda:0")
+        kind, head_names = _lib.LIKELIHOOD_KINDS[likelihood]
+        self.likelihood = likelihood
+        self.head_names = head_names
+        self.model_type = model_type
+        self.feature_size = int(feature_size)
+        self.latent_size = int(latent_size)
+        self.hidden_sizes = [int(h) for h in hidden_sizes]
+        self.n_clusters = int(n_clusters)
+        if len(self.hidden_sizes) > _lib.MAX_HIDDEN:
+            raise ValueError("At most {} hidden layers are supported.".format(
+                _lib.MAX_HIDDEN))
+
+        cfg = _lib.ModelConfig()
+        cfg.model_type = (_lib.MODEL_GMVAE if model_type == "GMVAE"
+                          else _lib.MODEL_VAE)
+        cfg.feature_size = self.feature_size
+        cfg.latent_size = self.latent_size
+        cfg.n_hidden = len(self.hidden_sizes)
+        for i, h in enumerate(self.hidden_sizes):
+            cfg.hidden[i] = h
+        cfg.likelihood = kind
+        cfg.batch_norm = 1 if batch_norm else 0
+        cfg.n_clusters = self.n_clusters
+        cfg.kl_weight = float(kl_weight)
+        cfg.free_nats_proportion = float(free_nats_proportion)
+        self.config = cfg
+
+        handle = ctypes.c_void_p()
+        _lib.check(self.lib.scvae_plan_create(ctypes.byref(cfg),
+                                              ctypes.byref(handle)),
+                   "scvae_plan_create")
+        self.handle = handle
+
+        n = self.lib.scvae_plan_param_floats(handle)
+        nm = self.lib.scvae_plan_moving_floats(handle)
+        dev = self.device
+        self.params = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.adam_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.moving = torch.zeros(max(nm, 1), dtype=torch.float32, device=dev)
+        self.adam_t = 0
+        self.workspace = None
+        self.max_cells = 0
+        self.max_samples = 0
+        self._sync_cb = None
+
+        # named views, reference creation order
+        self.param_table = OrderedDict()
+        name = ctypes.create_string_buffer(_lib.NAME_MAX)
+        off, rows, cols = (ctypes.c_int64(), ctypes.c_int64(),
+                           ctypes.c_int64())
+        for i in range(self.lib.scvae_plan_param_count(handle)):
+            _lib.check(self.lib.scvae_plan_param_info(
+                handle, i, name, ctypes.byref(off), ctypes.byref(rows),
+                ctypes.byref(cols)), "scvae_plan_param_info")
+            shape = ((rows.value, cols.value) if cols.value
+                     else (rows.value,))
+            self.param_table[name.value.decode()] = (off.value, shape)
+        self.moving_table = OrderedDict()
+        size = ctypes.c_int64()
+        for i in range(self.lib.scvae_plan_moving_count(handle)):
+            _lib.check(self.lib.scvae_plan_moving_info(
+                handle, i, name, ctypes.byref(off), ctypes.byref(size)),
+                "scvae_plan_moving_info")
+            self.moving_table[name.value.decode()] = (off.value,
+                                                      (size.value,))
+        self.initialise(seed)
+
+    def __del__(self):
+        handle = getattr(self, "handle", None)
+        if handle:
+            self.lib.scvae_plan_destroy(handle)
+            self.handle = None
+
+    # ---- named views ----------------------------------------------------
+    @staticmethod
+    def _view(flat, offset, shape):
+        n = 1
+        for s in shape:
+            n *= s
+        return flat[offset:offset + n].view(*shape)
+
+    def parameter(self, name):
+        off, shape = self.param_table[name]
+        return self._view(self.params, off, shape)
+
+    def gradient(self, name):
+        off, shape = self.param_table[name]
+        return self._view(self.grads, off, shape)
+
+    def moving_statistic(self, name):
+        off, shape = self.moving_table[name]
+        return self._view(self.moving, off, shape)
+
+    def named_parameters(self):
+        return OrderedDict((k, self.parameter(k)) for k in self.param_table)
+
+    def named_gradients(self):
+        return OrderedDict((k, self.gradient(k)) for k in self.param_table)
+
+    def named_moving_statistics(self):
+        return OrderedDict(
+            (k, self.moving_statistic(k)) for k in self.moving_table)
+
+    def number_of_parameters(self):
+        total = 0
+        for _, shape in self.param_table.values():
+            n = 1
+            for s in shape:
+                n *= s
+            total += n
+        return total
+
+    # ---- initialisation / state ------------------------------------------
+    def initialise(self, seed=0):
+        """``tf.global_variables_initializer`` with the tf.contrib defaults:
+        Glorot-uniform weights, zero biases and beta, moving mean 0 /
+        variance 1, Adam slots 0."""
+        g = torch.Generator(device="cpu").manual_seed(int(seed))
+        self.params.zero_()
+        for name, (off, shape) in self.param_table.items():
+            if name.endswith("weights"):
+                limit = math.sqrt(6.0 / (shape[0] + shape[1]))
+                w = (torch.rand(shape, generator=g, dtype=torch.float64)
+                     * 2 - 1) * limit
+                self._view(self.params, off, shape).copy_(
+                    w.to(torch.float32))
+        self.moving.zero_()
+        for name, (off, shape) in self.moving_table.items():
+            if name.endswith("moving_variance"):
+                self._view(self.moving, off, shape).fill_(1.0)
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        self.grads.zero_()
+        self.adam_t = 0
+
+    def load_parameters(self, named, moving=None):
+        for k, v in named.items():
+            self.parameter(k).copy_(torch.as_tensor(v).to(torch.float32))
+        if moving:
+            for k, v in moving.items():
+                self.moving_statistic(k).copy_(
+                    torch.as_tensor(v).to(torch.float32))
+
+    def state_dict(self):
+        return {
+            "params": self.params.detach().cpu(),
+            "adam_m": self.adam_m.detach().cpu(),
+            "adam_v": self.adam_v.detach().cpu(),
+            "moving": self.moving.detach().cpu(),
+            "adam_t": self.adam_t,
+        }
+
+    def load_state_dict(self, state):
+        self.params.copy_(state["params"])
+        self.adam_m.copy_(state["adam_m"])
+        self.adam_v.copy_(state["adam_v"])
+        self.moving.copy_(state["moving"])
+        self.adam_t = int(state["adam_t"])
+
+    # ---- binding -----------------------------------------------------------
+    def reserve(self, max_cells, max_samples=1):
+        """(Re)allocate the activation workspace for minibatches of up to
+        ``max_cells`` cells and ``max_samples`` latent samples per cell."""
+        max_cells, max_samples = int(max_cells), int(max_samples)
+        if (self.workspace is not None and max_cells <= self.max_cells
+                and max_samples <= self.max_samples):
+            return
+        max_cells = max(max_cells, self.max_cells)
+        max_samples = max(max_samples, self.max_samples)
+        nbytes = self.lib.scvae_plan_workspace_bytes(
+            self.handle, max_cells, max_samples)
+        if nbytes < 0:
+            raise _lib.HipLibraryError("scvae_plan_workspace_bytes failed")
+        self.workspace = None
+        self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8,
+                                     device=self.device)
+        _lib.check(self.lib.scvae_plan_bind(
+            self.handle, _ptr(self.params), _ptr(self.grads),
+            _ptr(self.moving), _ptr(self.workspace), nbytes, max_cells,
+            max_samples), "scvae_plan_bind")
+        self.max_cells, self.max_samples = max_cells, max_samples
+        self.scalars = torch.zeros(8, dtype=torch.float32, device=self.device)
+
+    def set_sync(self, callback):
+        """Install the data-parallel collective hook (see scvae_sync_fn)."""
+        if callback is None:
+            self._sync_cb = _lib.SYNC_FN(0)
+        else:
+            self._sync_cb = _lib.SYNC_FN(callback)
+        _lib.check(self.lib.scvae_plan_set_sync(self.handle, self._sync_cb,
+                                                None), "scvae_plan_set_sync")
+
+    # ---- execution -----------------------------------------------------------
+    def step(self, x, t, eps=None, row_const=None, training=False,
+             n_iw=1, n_mc=1, warm_up_weight=1.0, deterministic_z=False,
+             global_cells=None, outputs=None, scalars=None):
+        """One graph execution (no host synchronisation).  ``outputs`` maps
+        optional output names of ``scvae_step_args`` to preallocated tensors.
+        Returns the device tensor of scalars."""
+        cells = x.shape[0]
+        samples = 1 if deterministic_z else n_iw * n_mc
+        self.reserve(cells, samples)
+        a = _lib.StepArgs()
+        a.x = x.data_ptr()
+        a.t = t.data_ptr()
+        a.row_const = row_const.data_ptr() if row_const is not None else None
+        a.eps = eps.data_ptr() if eps is not None else None
+        a.cells = cells
+        a.global_cells = global_cells if global_cells else cells
+        a.n_iw, a.n_mc = n_iw, n_mc
+        a.training = 1 if training else 0
+        a.deterministic_z = 1 if deterministic_z else 0
+        a.warm_up_weight = float(warm_up_weight)
+        out_scalars = scalars if scalars is not None else self.scalars
+        a.scalars = out_scalars.data_ptr()
+        if outputs:
+            for key, tensor in outputs.items():
+                setattr(a, key, tensor.data_ptr())
+        _lib.check(self.lib.scvae_plan_step(
+            self.handle, ctypes.byref(a), current_stream_handle(self.device)),
+            "scvae_plan_step")
+        return out_scalars
+
+    def adam_step(self, learning_rate, grad_scale=1.0):
+        """clip-by-value(+-1) + ``tf.train.AdamOptimizer`` update (va:2742-2759)."""
+        self.adam_t += 1
+        t = self.adam_t
+        lr_t = (learning_rate * math.sqrt(1.0 - ADAM_BETA2 ** t)
+                / (1.0 - ADAM_BETA1 ** t))
+        _lib.check(self.lib.scvae_adam_clip_step(
+            _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m),
+            _ptr(self.adam_v), self.params.numel(), float(grad_scale),
+            float(lr_t), ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON,
+            current_stream_handle(self.device)), "scvae_adam_clip_step")

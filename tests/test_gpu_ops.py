@@ -1,0 +1,152 @@
+"""GPU unit tests of individual C-ABI ops against fp64 CPU references."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import likelihoods as lk
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [
+    (1, 1, 1), (37, 100, 203), (64, 64, 16), (100, 25, 100),
+    (130, 70, 5000),   # split-K
+    (300, 100, 33),
+])
+def test_gemm_matches_fp64(cuda_device, ta, tb, M, N, K):
+    from scvae_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    # asymmetric operands (catches transposed fragment layouts)
+    A = torch.randn((K, M) if ta else (M, K), generator=g, dtype=torch.float64)
+    Bm = torch.randn((N, K) if tb else (K, N), generator=g,
+                     dtype=torch.float64)
+    bias = torch.randn(N, generator=g, dtype=torch.float64)
+    ref = (A.T if ta else A) @ (Bm.T if tb else Bm) + bias
+    Ad, Bd, bd = (v.float().to(cuda_device) for v in (A, Bm, bias))
+    C = torch.full((M, N), 7.0, device=cuda_device)
+    ws_bytes = lib.scvae_gemm_workspace_bytes(M, N, K)
+    ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=cuda_device)
+    for relu, acc in ((0, 0), (1, 0), (0, 1)):
+        C.fill_(7.0)
+        _lib.check(lib.scvae_gemm(
+            ta, tb, _p(Ad), _p(Bd), _p(bd), _p(C), M, N, K, Ad.shape[1],
+            Bd.shape[1], N, relu, acc, _p(ws), ws_bytes, _stream()), "gemm")
+        torch.cuda.synchronize()
+        want = ref.clamp(min=0) if relu else ref
+        if acc:
+            want = want + 7.0
+        scale = (A.abs().max() * Bm.abs().max() * np.sqrt(K)).item() + 1.0
+        err = (C.cpu().double() - want).abs().max().item()
+        assert err < 2e-6 * scale * max(1.0, np.sqrt(K) / 8), (err, scale)
+
+
+@pytest.mark.parametrize("name", list(lk.LIKELIHOOD_PARAMETERS))
+def test_loglik_forward_backward(cuda_device, name):
+    from scvae_amd import _lib
+    lib = _lib.load()
+    kind, heads = _lib.LIKELIHOOD_KINDS[name]
+    P = len(heads)
+    cells, S, F = 9, 2, 517
+    rows = cells * S
+    rng = np.random.default_rng(3)
+    t = rng.poisson(2.0, size=(cells, F)).astype(np.float64)
+    t *= rng.random((cells, F)) > 0.6
+    t[0, :6] = [0, 1, 17, 250, 4000, 30000]
+    pre = [rng.normal(0, 3.0, size=(rows, F)) for _ in range(P)]
+    # exercise the clips
+    for j in range(P):
+        pre[j][1, :4] = [-95.0, 40.0, -11.0, 11.0]
+    gw = rng.normal(size=rows)
+    tt = torch.from_numpy(t)
+    pre_t = [torch.from_numpy(a).requires_grad_(True) for a in pre]
+    lp = lk.log_prob(name, tt.repeat(S, 1), tuple(pre_t)).sum(dim=-1)
+    (lp * torch.from_numpy(gw)).sum().backward()
+
+    td = tt.float().to(cuda_device)
+    pre_d = [torch.from_numpy(a).float().to(cuda_device) for a in pre]
+    arr = (ctypes.c_void_p * P)(*[a.data_ptr() for a in pre_d])
+    ll = torch.zeros(rows, device=cuda_device)
+    _lib.check(lib.scvae_loglik_fwd(kind, _p(td), arr, None, _p(ll), rows,
+                                    cells, F, _stream()), "loglik_fwd")
+    torch.cuda.synchronize()
+    want = lp.detach().numpy()
+    assert np.abs(ll.cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max()
+
+    # row constant variant
+    rc = torch.lgamma(tt + 1).sum(dim=1).float().to(cuda_device)
+    ll2 = torch.zeros(rows, device=cuda_device)
+    gwd = torch.from_numpy(gw).float().to(cuda_device)
+    _lib.check(lib.scvae_loglik_bwd(kind, _p(td), arr, _p(gwd), _p(rc),
+                                    _p(ll2), rows, cells, F, _stream()),
+               "loglik_bwd")
+    torch.cuda.synchronize()
+    assert np.abs(ll2.cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max()
+    for j in range(P):
+        g_ref = pre_t[j].grad.numpy()
+        g = pre_d[j].cpu().numpy()
+        # element-wise: relative to the element's scale + a small absolute floor
+        tol = 2e-5 * np.abs(g_ref) + 2e-5 * (1 + np.abs(t).repeat(S, 0).reshape(
+            S, cells, F).reshape(rows, F) * 0 + np.abs(gw)[:, None])
+        bad = np.abs(g - g_ref) > tol * 5
+        assert not bad.any(), (heads[j], np.argwhere(bad)[:5],
+                               g[bad][:5], g_ref[bad][:5])
+
+
+def test_philox_normal_is_sharding_invariant(cuda_device):
+    from scvae_amd import _lib
+    lib = _lib.load()
+    rows, cols = 1000, 25
+    full = torch.zeros(rows, cols, device=cuda_device)
+    _lib.check(lib.scvae_philox_normal(_p(full), rows, cols, 0, 1234, 7,
+                                       _stream()), "philox")
+    part = torch.zeros(400, cols, device=cuda_device)
+    _lib.check(lib.scvae_philox_normal(_p(part), 400, cols, 600, 1234, 7,
+                                       _stream()), "philox")
+    torch.cuda.synchronize()
+    assert torch.equal(full[600:], part)
+    z = full.cpu().double()
+    assert abs(z.mean().item()) < 0.03 and abs(z.std().item() - 1) < 0.03
+    other = torch.zeros(rows, cols, device=cuda_device)
+    _lib.check(lib.scvae_philox_normal(_p(other), rows, cols, 0, 1234, 8,
+                                       _stream()), "philox")
+    torch.cuda.synchronize()
+    assert not torch.equal(full, other)
+
+
+def test_csr_densify(cuda_device):
+    import scipy.sparse as sp
+    from scvae_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    N, F = 50, 333
+    dense = rng.poisson(0.3, size=(N, F)).astype(np.float32)
+    dense[7] = 0  # empty row
+    m = sp.csr_matrix(dense)
+    indptr = torch.from_numpy(m.indptr.astype(np.int64)).to(cuda_device)
+    indices = torch.from_numpy(m.indices.astype(np.int32)).to(cuda_device)
+    values = torch.from_numpy(m.data.astype(np.float32)).to(cuda_device)
+    rows = torch.tensor([49, 7, 0, 7, 13], dtype=torch.int64,
+                        device=cuda_device)
+    out = torch.full((5, F), -1.0, device=cuda_device)
+    _lib.check(lib.scvae_csr_densify(_p(indptr), _p(indices), _p(values),
+                                     _p(rows), 5, F, _p(out), _stream()),
+               "densify")
+    lg = torch.zeros(N, device=cuda_device)
+    _lib.check(lib.scvae_csr_row_lgamma1p(_p(indptr), _p(values), N, _p(lg),
+                                          _stream()), "lgamma1p")
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), dense[[49, 7, 0, 7, 13]])
+    want = torch.lgamma(torch.from_numpy(dense).double() + 1).sum(dim=1)
+    assert np.allclose(lg.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)

@@ -1,0 +1,158 @@
+"""GPU parity: one VAE graph execution through the C ABI vs the fp64 oracle.
+
+Tolerance: BASELINE.json asks for ELBO and per-cell reconstruction
+log-likelihood within 1e-4 relative in fp32; gradients / post-Adam weights are
+held to 2e-4 of the tensor's largest magnitude.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as om
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def _counts(rng, cells, features, scale=3.0, sparsity=0.7):
+    lam = rng.gamma(0.5, scale, size=(1, features))
+    x = rng.poisson(lam, size=(cells, features)).astype(np.float64)
+    x *= rng.random((cells, features)) > sparsity
+    x[0, 0] = 1000.0  # one large count
+    return x
+
+
+def _setup(cuda_device, likelihood, F, L, H, B, bn, seed=0, n_iw=1, n_mc=1):
+    from scvae_amd.engine import Engine
+    eng = Engine(F, L, H, likelihood, batch_norm=bn, device=cuda_device,
+                 seed=seed)
+    # perturb biases / beta so they are not all zero
+    g = torch.Generator().manual_seed(seed + 1)
+    for name, p in eng.named_parameters().items():
+        if not name.endswith("weights"):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    cfg = om.ModelConfig(feature_size=F, latent_size=L, hidden_sizes=tuple(H),
+                         likelihood=likelihood, minibatch_normalisation=bn,
+                         n_iw=n_iw, n_mc=n_mc)
+    params = {k: v.detach().cpu().double()
+              for k, v in eng.named_parameters().items()}
+    assert list(params) == list(om.vae_parameter_shapes(cfg))
+    moving = {k: v.detach().cpu().double()
+              for k, v in eng.named_moving_statistics().items()}
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(_counts(rng, B, F))
+    eps = torch.from_numpy(rng.standard_normal((n_iw * n_mc, B, L)))
+    return eng, cfg, params, moving, x, eps
+
+
+def _close(a, b, rtol=RTOL, what=""):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), 1e-30)
+    err = np.abs(a - b).max() / scale
+    assert err <= rtol, "{}: max err {:.3e} of scale {:.3e}".format(
+        what, err, scale)
+
+
+@pytest.mark.parametrize("likelihood", [
+    "poisson", "negative binomial", "zero-inflated poisson",
+    "zero-inflated negative binomial"])
+@pytest.mark.parametrize("bn", [True, False])
+def test_train_step_matches_oracle(cuda_device, likelihood, bn):
+    F, L, H, B = 203, 7, (24, 20), 37
+    eng, cfg, params, moving, x, eps = _setup(
+        cuda_device, likelihood, F, L, H, B, bn)
+    xd = x.float().to(cuda_device)
+    epsd = eps.float().to(cuda_device)
+    ll = torch.zeros(B, device=cuda_device)
+    klz = torch.zeros(L, device=cuda_device)
+    qz = torch.zeros(B, L, device=cuda_device)
+    sc = eng.step(xd, xd, eps=epsd, training=True, warm_up_weight=0.7,
+                  outputs={"log_p_x_given_z": ll, "kl_neurons": klz,
+                           "q_z_mean": qz}).cpu().numpy()
+    eng.adam_step(1e-3)
+    torch.cuda.synchronize()
+
+    state = om.adam_state(params)
+    new_params, new_moving, out, grads = om.vae_train_step(
+        cfg, dict(params), moving, state, x, x, eps, 1e-3, warm_up_weight=0.7)
+
+    _close(sc[0], out["lower_bound"], what="lower_bound")
+    _close(sc[1], out["lower_bound_weighted"], what="lower_bound_weighted")
+    _close(sc[2], out["reconstruction_error"], what="reconstruction_error")
+    _close(sc[3], out["kl_divergence"], what="kl_divergence")
+    _close(ll.cpu(), out["log_p_x_given_z"].reshape(-1), what="per-cell ll")
+    _close(klz.cpu(), out["kl_divergence_neurons"], what="kl neurons")
+    _close(qz.cpu(), out["q_z_mean"], what="q_z_mean")
+    for name, g in eng.named_gradients().items():
+        if bn and name.endswith("DENSE/biases") and "X_TILDE" not in name \
+                and "POSTERIOR" not in name:
+            # bias under batch norm: mathematically zero gradient
+            assert g.abs().max().item() < 1e-5
+            continue
+        _close(g.cpu(), torch.clamp(grads[name], -1, 1), rtol=2e-4,
+               what="grad " + name)
+    for name, p in eng.named_parameters().items():
+        if bn and name.endswith("DENSE/biases") and "X_TILDE" not in name \
+                and "POSTERIOR" not in name:
+            continue
+        _close(p.cpu(), new_params[name], rtol=2e-4, what="param " + name)
+    for name, m in eng.named_moving_statistics().items():
+        _close(m.cpu(), new_moving[name], rtol=1e-5, what="moving " + name)
+
+
+def test_importance_weighted_step(cuda_device):
+    F, L, H, B = 150, 5, (16,), 19
+    eng, cfg, params, moving, x, eps = _setup(
+        cuda_device, "negative binomial", F, L, H, B, True, n_iw=3, n_mc=2)
+    xd = x.float().to(cuda_device)
+    epsd = eps.float().to(cuda_device)
+    sc = eng.step(xd, xd, eps=epsd, training=True, n_iw=3,
+                  n_mc=2).cpu().numpy()
+    torch.cuda.synchronize()
+    out, grads = om.gradients(
+        lambda p: om.vae_forward(cfg, p, moving, x, x, eps, True, 1.0, {}),
+        params)
+    _close(sc[0], out["lower_bound"], what="lower_bound")
+    _close(sc[2], out["reconstruction_error"], what="reconstruction_error")
+    for name, g in eng.named_gradients().items():
+        if name.endswith("DENSE/biases") and ("ENCODER" in name
+                                              or "DECODER" in name):
+            continue
+        _close(g.cpu(), grads[name], rtol=2e-4, what="grad " + name)
+
+
+def test_evaluation_mode_statistics(cuda_device):
+    F, L, H, B = 180, 6, (20, 20), 23
+    eng, cfg, params, moving, x, eps = _setup(
+        cuda_device, "zero-inflated negative binomial", F, L, H, B, True,
+        n_iw=2, n_mc=2)
+    # non-trivial moving statistics
+    g = torch.Generator().manual_seed(5)
+    for name, m in eng.named_moving_statistics().items():
+        if name.endswith("moving_mean"):
+            m.copy_(torch.randn(m.shape, generator=g) * 0.2)
+        else:
+            m.copy_(torch.rand(m.shape, generator=g) + 0.5)
+    moving = {k: v.detach().cpu().double()
+              for k, v in eng.named_moving_statistics().items()}
+    xd = x.float().to(cuda_device)
+    epsd = eps.float().to(cuda_device)
+    outs = {k: torch.zeros(B, F, device=cuda_device) for k in (
+        "p_x_mean", "p_x_stddev", "stddev_of_p_x_given_z_mean")}
+    ll = torch.zeros(4 * B, device=cuda_device)
+    outs["log_p_x_given_z"] = ll
+    sc = eng.step(xd, xd, eps=epsd, training=False, n_iw=2, n_mc=2,
+                  outputs=outs).cpu().numpy()
+    out = om.vae_forward(cfg, params, moving, x, x, eps, False,
+                         evaluation_statistics=True)
+    _close(sc[0], out["lower_bound"], what="lower_bound")
+    _close(ll.cpu(), out["log_p_x_given_z"].reshape(-1), what="per-cell ll")
+    for k in ("p_x_mean", "p_x_stddev", "stddev_of_p_x_given_z_mean"):
+        _close(outs[k].cpu(), out[k], rtol=2e-4, what=k)
+    # deterministic z
+    sc = eng.step(xd, xd, training=False, deterministic_z=True).cpu().numpy()
+    out = om.vae_forward(cfg, params, moving, x, x, None, False,
+                         deterministic_z=True)
+    _close(sc[0], out["lower_bound"], what="lower_bound (deterministic z)")
