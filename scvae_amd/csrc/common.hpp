@@ -14,6 +14,8 @@ constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
 constexpr float F32_MAX_HALF = 1.7014117331926443e38f;
 constexpr float BN_EPSILON = 1e-3f;
 constexpr float BN_DECAY = 0.999f;
+// assign_moving_average casts the Python double (1.0 - decay) to fp32
+constexpr float BN_UPDATE_RATE = 1e-3f;
 
 // ---- error reporting (per-thread string, returned by scvae_last_error) ----
 void set_error(const char* fmt, ...);

@@ -408,8 +408,8 @@ __global__ void bn_update_moving_kernel(const float* __restrict__ mean,
   float mm = moving_mean[c], mv = moving_var[c];
   const float bessel = (float)R / (float)(R > 1 ? R - 1 : 1);
   for (int g = 0; g < groups; ++g) {
-    mm -= (mm - mean[(size_t)g * N + c]) * (1.f - BN_DECAY);
-    mv -= (mv - var[(size_t)g * N + c] * bessel) * (1.f - BN_DECAY);
+    mm -= (mm - mean[(size_t)g * N + c]) * BN_UPDATE_RATE;
+    mv -= (mv - var[(size_t)g * N + c] * bessel) * BN_UPDATE_RATE;
   }
   moving_mean[c] = mm;
   moving_var[c] = mv;
