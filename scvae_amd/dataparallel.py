@@ -1,0 +1,109 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU,
+``torch.distributed`` (backend ``nccl`` = RCCL over xGMI on ROCm).
+
+The reference is single-process; the build adds exactly
+one form of parallelism: the global minibatch is split into equal contiguous
+row shards, every rank holds a full replica of the weights and Adam slots, and
+per optimiser step there is
+
+* one all-reduce(sum) of the flat fp32 gradient buffer (each rank's gradient is
+  already scaled by 1/global_batch, so the sum is the single-process gradient;
+  clipping to [-1, 1] happens after it, as in va:2751-2755), and
+* per batch-norm layer one all-gather of ``[mean | var]`` in the forward pass
+  (merged with the parallel-variance formula) and one all-reduce of
+  ``[sum dA | sum dA*xhat]`` in the backward pass, so that the result equals
+  single-process batch norm over the whole minibatch (sync batch norm).
+
+The collective logic is backend-agnostic: ``tests/test_dataparallel_cpu.py``
+drives it with ``gloo`` and the oracle as compute stand-in.
+"""
+
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(global_rows, world_size, rank):
+    """Contiguous equal shards; the global minibatch must divide evenly."""
+    if global_rows % world_size:
+        raise ValueError(
+            "Global minibatch of {} rows does not split evenly over {} ranks."
+            .format(global_rows, world_size))
+    per_rank = global_rows // world_size
+    return rank * per_rank, (rank + 1) * per_rank
+
+
+def merge_batch_norm_statistics(gathered, counts):
+    """Chan et al. merge. ``gathered``: [ranks, 2, n] (mean, biased var) per
+    rank; ``counts``: [ranks].  Returns (mean[n], var[n]) of the union."""
+    counts = counts.to(gathered.dtype).view(-1, 1)
+    total = counts.sum()
+    mean = (gathered[:, 0] * counts).sum(dim=0) / total
+    delta = gathered[:, 0] - mean
+    m2 = (counts * (gathered[:, 1] + delta * delta)).sum(dim=0)
+    return mean, m2 / total
+
+
+class GradientSynchroniser:
+    """Collectives of one data-parallel rank, bound to an ``Engine``."""
+
+    def __init__(self, engine, group=None):
+        from scvae_amd import _lib
+        self.engine = engine
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.lib = _lib.load()
+        self._check = _lib.check
+        self._gathered = None
+        self._counts = None
+        engine.set_sync(self._hook)
+
+    def _view(self, address, count):
+        ws = self.engine.workspace
+        offset = address - ws.data_ptr()
+        if offset < 0 or offset + 4 * count > ws.numel():
+            raise RuntimeError("sync buffer is outside the bound workspace")
+        return ws[offset:offset + 4 * count].view(torch.float32)
+
+    def _hook(self, user, address, count, kind, local_rows):
+        try:
+            view = self._view(address, count)
+            if kind == 0:
+                dist.all_reduce(view, group=self.group)
+                return 0
+            n = count // 2
+            need = self.world_size * count
+            if self._gathered is None or self._gathered.numel() < need:
+                self._gathered = torch.empty(
+                    need, dtype=torch.float32, device=view.device)
+            if self._counts is None:
+                self._counts = torch.empty(
+                    self.world_size, dtype=torch.int64, device=view.device)
+            # equal shards (shard_bounds): every rank contributes local_rows
+            self._counts.fill_(int(local_rows))
+            gathered = self._gathered[:need]
+            dist.all_gather_into_tensor(gathered, view, group=self.group)
+            from scvae_amd.engine import current_stream_handle
+            self._check(self.lib.scvae_bn_merge(
+                ctypes.c_void_p(gathered.data_ptr()),
+                ctypes.c_void_p(self._counts.data_ptr()), self.world_size, n,
+                ctypes.c_void_p(view.data_ptr()),
+                current_stream_handle(view.device)), "scvae_bn_merge")
+            return 0
+        except Exception as error:  # surfaced by the C side as rc=-2
+            print("[scvae_amd] sync hook failed:", repr(error), flush=True)
+            return 1
+
+    def all_reduce_gradients(self):
+        dist.all_reduce(self.engine.grads, group=self.group)
+
+    def all_reduce_scalars(self, scalars):
+        dist.all_reduce(scalars, group=self.group)
+        return scalars
+
+    def broadcast_state(self, src=0):
+        for tensor in (self.engine.params, self.engine.adam_m,
+                       self.engine.adam_v, self.engine.moving):
+            dist.broadcast(tensor, src=src, group=self.group)

@@ -232,7 +232,7 @@ class Engine:
     def set_sync(self, callback):
         """Install the data-parallel collective hook (see scvae_sync_fn)."""
         if callback is None:
-            self._sync_cb = _lib.SYNC_FN(0)
+            self._sync_cb = ctypes.cast(None, _lib.SYNC_FN)
         else:
             self._sync_cb = _lib.SYNC_FN(callback)
         _lib.check(self.lib.scvae_plan_set_sync(self.handle, self._sync_cb,

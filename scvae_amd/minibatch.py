@@ -1,0 +1,139 @@
+"""Device-resident count matrix and minibatch fetch.
+
+Replaces the host-side ``x_train[minibatch_indices].toarray()`` /
+``t_train[minibatch_indices].toarray()`` of the reference loops
+(``scvae/models/variational_autoencoder.py:985-998``): the CSR matrix
+(``SparseRowMatrix``, ``scvae/data/sparse.py:22``) is uploaded once and every
+minibatch is gathered and densified on the GPU by ``scvae_csr_densify``.  When
+``x`` and ``t`` are the same matrix (no preprocessing, va:845-861) one dense
+buffer serves both.
+"""
+
+import ctypes
+
+import numpy
+import torch
+
+from scvae_amd import _lib
+from scvae_amd.engine import current_stream_handle
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class DeviceCSR:
+    """CSR count matrix in HBM (int64 indptr, int32 indices, fp32 values)."""
+
+    def __init__(self, indptr, indices, values, shape, device):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.indptr = torch.as_tensor(indptr).to(
+            device=self.device, dtype=torch.int64).contiguous()
+        self.indices = torch.as_tensor(indices).to(
+            device=self.device, dtype=torch.int32).contiguous()
+        self.values = torch.as_tensor(values).to(
+            device=self.device, dtype=torch.float32).contiguous()
+        if self.indptr.numel() != self.shape[0] + 1:
+            raise ValueError("indptr does not match the number of rows.")
+        # data-only term of the count likelihoods: sum_f lgamma(1 + t[b, f])
+        self.row_lgamma1p = torch.zeros(
+            max(self.shape[0], 1), dtype=torch.float32, device=self.device)
+        if self.shape[0]:
+            _lib.check(self.lib.scvae_csr_row_lgamma1p(
+                _ptr(self.indptr), _ptr(self.values), self.shape[0],
+                _ptr(self.row_lgamma1p),
+                current_stream_handle(self.device)), "scvae_csr_row_lgamma1p")
+
+    @classmethod
+    def from_scipy(cls, matrix, device):
+        matrix = matrix.tocsr()
+        matrix.sort_indices()
+        return cls(matrix.indptr.astype(numpy.int64),
+                   matrix.indices.astype(numpy.int32),
+                   matrix.data.astype(numpy.float32), matrix.shape, device)
+
+    @property
+    def number_of_rows(self):
+        return self.shape[0]
+
+    @property
+    def nnz(self):
+        return int(self.values.numel())
+
+    def gather_dense(self, rows, out=None, row_const_out=None):
+        """Dense fp32 ``[len(rows), F]`` minibatch (and its lgamma row term)."""
+        n, F = int(rows.numel()), self.shape[1]
+        if out is None:
+            out = torch.empty((n, F), dtype=torch.float32, device=self.device)
+        stream = current_stream_handle(self.device)
+        _lib.check(self.lib.scvae_csr_densify(
+            _ptr(self.indptr), _ptr(self.indices), _ptr(self.values),
+            _ptr(rows), n, F, _ptr(out), stream), "scvae_csr_densify")
+        if row_const_out is not None:
+            _lib.check(self.lib.scvae_gather_rows(
+                _ptr(self.row_lgamma1p), _ptr(rows), n, _ptr(row_const_out),
+                stream), "scvae_gather_rows")
+        return out
+
+
+def philox_normal(out, row_offset, seed, stream_id):
+    """Fill ``out`` ([rows, cols], fp32, device) with N(0,1) draws keyed by
+    (seed, stream_id, row_offset + row, col)."""
+    lib = _lib.load()
+    rows = out.shape[0] if out.dim() > 1 else out.numel()
+    cols = out.numel() // max(rows, 1)
+    _lib.check(lib.scvae_philox_normal(
+        _ptr(out), rows, cols, int(row_offset), int(seed), int(stream_id),
+        current_stream_handle(out.device)), "scvae_philox_normal")
+    return out
+
+
+def synthetic_count_matrix(n_cells, n_features, density=0.05, n_clusters=8,
+                           seed=60, device="cuda:0", chunk=2048):
+    """Synthetic cell x gene counts of a named shape, generated on the GPU.
+
+    Vectorised restatement of the reference's ``development`` generator
+    (``scvae/data/loaders.py:942-1022``): per cluster and gene
+    ``r ~ 10*U(0,1)``, ``p ~ U(0,1)``, keep probability ``~ U(0,1)``; counts
+    are negative binomial (gamma-Poisson) times a Bernoulli keep mask.  The
+    keep probabilities are rescaled so that the fraction of nonzeros is about
+    ``density`` (10x matrices are 93-98 % zeros).  Returns a ``DeviceCSR`` and
+    the cluster label of every cell.
+    """
+    device = torch.device(device)
+    g = torch.Generator(device=device).manual_seed(int(seed))
+
+    def U(*shape):
+        return torch.rand(*shape, generator=g, device=device)
+
+    r = 10.0 * U(n_clusters, n_features) + 1e-3
+    # NB(r, p) has mean r(1-p)/p; keep p away from 0 so counts stay bounded
+    p = 0.05 + 0.95 * U(n_clusters, n_features)
+    keep = U(n_clusters, n_features)
+    # P(NB > 0) = 1 - p^r ; rescale keep to hit the target density
+    p_nonzero = (keep * (1.0 - p ** r)).mean().item()
+    keep = torch.clamp(keep * (density / max(p_nonzero, 1e-12)), max=1.0)
+    labels = torch.randint(0, n_clusters, (n_cells,), generator=g,
+                           device=device)
+
+    indptr = [torch.zeros(1, dtype=torch.int64, device=device)]
+    indices, values = [], []
+    offset = 0
+    for start in range(0, n_cells, chunk):
+        lab = labels[start:start + chunk]
+        rr, pp, kk = r[lab], p[lab], keep[lab]
+        rate = torch._standard_gamma(rr, generator=g) * (1.0 - pp) / pp
+        counts = torch.poisson(rate, generator=g)
+        counts = counts * (torch.rand(counts.shape, generator=g,
+                                      device=device) < kk)
+        nz = counts.nonzero(as_tuple=False)
+        row_counts = torch.bincount(nz[:, 0], minlength=lab.numel())
+        indptr.append(offset + torch.cumsum(row_counts, 0))
+        offset += int(nz.shape[0])
+        indices.append(nz[:, 1].to(torch.int32))
+        values.append(counts[nz[:, 0], nz[:, 1]].to(torch.float32))
+    matrix = DeviceCSR(torch.cat(indptr), torch.cat(indices),
+                       torch.cat(values), (n_cells, n_features), device)
+    return matrix, labels
