@@ -142,6 +142,12 @@ int scvae_loglik_fwd(int32_t kind, const float* t, const float* const* pre, cons
 int scvae_loglik_bwd(int32_t kind, const float* t, float* const* pre, const float* gw,
                      const float* row_const, float* ll, int64_t rows, int64_t cells, int64_t F,
                      void* stream);
+/* element-wise .log_prob(t) / .mean() / .variance() of the DISTRIBUTIONS registry classes
+ * (scvae/distributions/utilities.py:206-305, zero_inflated.py:180-199); pre = head
+ * pre-activations (n elements each); log_prob and/or (mean, variance) may be NULL */
+int scvae_likelihood_elementwise(int32_t kind, const float* t, const float* const* pre,
+                                 float* log_prob, float* mean, float* variance, int64_t n,
+                                 void* stream);
 /* q(z|x) sample + analytic KL (va:2346-2369, 2624-2656) */
 int scvae_gauss_latent_fwd(const float* mu_pre, const float* ls_pre, const float* eps, float* z,
                            float* kl_elem, float* kl_cell, int64_t S, int64_t cells, int64_t L,

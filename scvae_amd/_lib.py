@@ -106,6 +106,9 @@ SIGNATURES = {
     "scvae_loglik_bwd": (c_int32, [
         c_int32, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p,
         c_int64, c_int64, c_int64, c_void_p]),
+    "scvae_likelihood_elementwise": (c_int32, [
+        c_int32, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p,
+        c_int64, c_void_p]),
     "scvae_gauss_latent_fwd": (c_int32, [
         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
         c_int64, c_int64, c_int32, c_void_p]),

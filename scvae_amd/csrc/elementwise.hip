@@ -143,6 +143,58 @@ int px_statistics(hipStream_t stream, int kind, HeadPtrs pre, int ldp, int S, in
   return 0;
 }
 
+// element-wise log p(t | theta) (including -lgamma(1+t)) and mean/variance, for the
+// DISTRIBUTIONS plugin surface (.log_prob / .mean / .variance of the registry classes)
+template <int KIND>
+__global__ __launch_bounds__(256) void loglik_elementwise_kernel(const float* __restrict__ t,
+                                                                 HeadPtrs pre,
+                                                                 float* __restrict__ out,
+                                                                 float* __restrict__ mean,
+                                                                 float* __restrict__ var, size_t n) {
+  constexpr int P = (KIND == LK_POISSON) ? 1 : (KIND == LK_ZINB ? 3 : 2);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float a[P], g[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) a[j] = pre.p[j][i];
+    if (out != nullptr) {
+      const float tv = t[i];
+      float lp;
+      lik_elem<KIND, false>(tv, a, lp, g);
+      out[i] = lp - lgamma1p(tv);
+    }
+    if (mean != nullptr) {
+      float m, v;
+      lik_mean_var<KIND>(a, m, v);
+      mean[i] = m;
+      var[i] = v;
+    }
+  }
+}
+
+int loglik_elementwise(hipStream_t stream, int kind, const float* t, HeadPtrs pre, float* out,
+                       float* mean, float* var, size_t n) {
+  SCVAE_ARG(pre.p[0] && (out || mean));
+  SCVAE_ARG(!out || t);
+  SCVAE_ARG(!mean || var);
+  if (n == 0) return 0;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+#define SCVAE_LE(K_)                                                                            \
+  hipLaunchKernelGGL((loglik_elementwise_kernel<K_>), dim3(blocks), dim3(256), 0, stream, t, pre, \
+                     out, mean, var, n)
+  switch (kind) {
+    case LK_POISSON: SCVAE_LE(LK_POISSON); break;
+    case LK_NB: SCVAE_LE(LK_NB); break;
+    case LK_ZIP: SCVAE_LE(LK_ZIP); break;
+    case LK_ZINB: SCVAE_LE(LK_ZINB); break;
+    default: set_error("unknown likelihood kind %d", kind); return -1;
+  }
+#undef SCVAE_LE
+  SCVAE_LAUNCH_CHECK("loglik_elementwise_kernel");
+  return 0;
+}
+
 __global__ void sqrt_sum_kernel(const float* a, const float* b, float* out, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x)
@@ -314,49 +366,94 @@ int vae_elbo(hipStream_t stream, const float* ll, const float* kl_cell, int n_iw
 
 // ============================ batch normalisation =========================
 
-// grid (ceil(N/64), groups); 64 columns x 16 row lanes per workgroup.
-// Two-pass (centred) variance like the fused TF kernel: mean, then mean((a-mean)^2).
-__global__ __launch_bounds__(1024) void bn_stats_kernel(const float* __restrict__ a, int lda,
-                                                        int R, int N, float* __restrict__ mean,
-                                                        float* __restrict__ var) {
+// Row-chunked statistics: grid (ceil(N/64), groups, chunks), 64 columns x 16 row lanes per
+// workgroup.  Each workgroup computes the two-pass (centred) mean / M2 of its row chunk
+// (second pass re-reads the chunk from cache); bn_stats_finalize_kernel merges the chunks
+// with the parallel-variance formula in a fixed order (deterministic, no atomics).
+__global__ __launch_bounds__(1024) void bn_stats_partial_kernel(const float* __restrict__ a,
+                                                                int lda, int R, int N, int chunk,
+                                                                float* __restrict__ partial) {
   __shared__ float red[16][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int cl = threadIdx.x & 63;
+  const int c = blockIdx.x * 64 + cl;
   const int rl = threadIdx.x >> 6;
-  const int g = blockIdx.y;
+  const int g = blockIdx.y, z = blockIdx.z, Z = gridDim.z, G = gridDim.y;
+  const int r0 = z * chunk, r1 = min(R, r0 + chunk);
+  const int n = r1 - r0;
   const float* base = a + (size_t)g * R * lda;
   float s = 0.f;
   if (c < N)
-    for (int r = rl; r < R; r += 16) s += base[(size_t)r * lda + c];
-  red[rl][threadIdx.x & 63] = s;
+    for (int r = r0 + rl; r < r1; r += 16) s += base[(size_t)r * lda + c];
+  red[rl][cl] = s;
   __syncthreads();
   float mu = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) mu += red[i][threadIdx.x & 63];
-  mu /= (float)R;
+  for (int i = 0; i < 16; ++i) mu += red[i][cl];
+  mu = n > 0 ? mu / (float)n : 0.f;
   __syncthreads();
   float q = 0.f;
   if (c < N)
-    for (int r = rl; r < R; r += 16) {
+    for (int r = r0 + rl; r < r1; r += 16) {
       const float d = base[(size_t)r * lda + c] - mu;
       q = fmaf(d, d, q);
     }
-  red[rl][threadIdx.x & 63] = q;
+  red[rl][cl] = q;
   __syncthreads();
   if (rl == 0 && c < N) {
-    float v = 0.f;
+    float m2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v += red[i][threadIdx.x & 63];
-    mean[(size_t)g * N + c] = mu;
-    var[(size_t)g * N + c] = v / (float)R;
+    for (int i = 0; i < 16; ++i) m2 += red[i][cl];
+    float* out = partial + (((size_t)z * G + g) * 2) * N;
+    out[c] = mu;
+    out[N + c] = m2;
   }
+  (void)Z;
 }
 
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int R, int N,
+                                         int chunk, int chunks, int G, float* __restrict__ mean,
+                                         float* __restrict__ var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.y;
+  if (c >= N) return;
+  float mu = 0.f;
+  for (int z = 0; z < chunks; ++z) {
+    const int n = min(R, (z + 1) * chunk) - z * chunk;
+    mu += (float)n * partial[(((size_t)z * G + g) * 2) * N + c];
+  }
+  mu /= (float)R;
+  float m2 = 0.f;
+  for (int z = 0; z < chunks; ++z) {
+    const int n = min(R, (z + 1) * chunk) - z * chunk;
+    const float* pz = partial + (((size_t)z * G + g) * 2) * N;
+    const float d = pz[c] - mu;
+    m2 += pz[N + c] + (float)n * d * d;
+  }
+  mean[(size_t)g * N + c] = mu;
+  var[(size_t)g * N + c] = m2 / (float)R;
+}
+
+static inline int bn_chunks(int R, int* chunk) {
+  int chunks = (R + 255) / 256;
+  if (chunks > BN_MAX_CHUNKS) chunks = BN_MAX_CHUNKS;
+  if (chunks < 1) chunks = 1;
+  *chunk = (R + chunks - 1) / chunks;
+  return (R + *chunk - 1) / *chunk;
+}
+
+size_t bn_partial_floats(int groups, int N) { return (size_t)BN_MAX_CHUNKS * groups * 2 * N; }
+
 int bn_stats(hipStream_t stream, const float* a, int lda, int rows_per_group, int groups, int N,
-             float* mean, float* var) {
-  SCVAE_ARG(a && mean && var && rows_per_group > 0 && groups > 0 && N > 0);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3((N + 63) / 64, groups), dim3(1024), 0, stream, a, lda,
-                     rows_per_group, N, mean, var);
-  SCVAE_LAUNCH_CHECK("bn_stats_kernel");
+             float* mean, float* var, float* partial) {
+  SCVAE_ARG(a && mean && var && partial && rows_per_group > 0 && groups > 0 && N > 0);
+  int chunk;
+  const int chunks = bn_chunks(rows_per_group, &chunk);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((N + 63) / 64, groups, chunks), dim3(1024), 0,
+                     stream, a, lda, rows_per_group, N, chunk, partial);
+  SCVAE_LAUNCH_CHECK("bn_stats_partial_kernel");
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((N + 63) / 64, groups), dim3(64), 0, stream,
+                     partial, rows_per_group, N, chunk, chunks, groups, mean, var);
+  SCVAE_LAUNCH_CHECK("bn_stats_finalize_kernel");
   return 0;
 }
 
@@ -424,23 +521,25 @@ int bn_update_moving(hipStream_t stream, const float* mean, const float* var, in
   return 0;
 }
 
-// s1[g,c] = sum_r dA, s2[g,c] = sum_r dA * xhat with dA = dh * (h > 0) [relu]
-__global__ __launch_bounds__(1024) void bn_bwd_stats_kernel(
+// s1[g,c] = sum_r dA, s2[g,c] = sum_r dA * xhat with dA = dh * (h > 0) [relu];
+// row-chunked partial sums + fixed-order finalize
+__global__ __launch_bounds__(1024) void bn_bwd_stats_partial_kernel(
     const float* __restrict__ dh, int lddh, const float* __restrict__ h, int ldh,
     const float* __restrict__ a, int lda, const float* __restrict__ mean,
-    const float* __restrict__ var, int R, int N, int relu, float* __restrict__ s1,
-    float* __restrict__ s2) {
+    const float* __restrict__ var, int R, int N, int relu, int chunk,
+    float* __restrict__ partial) {
   __shared__ float red1[16][64];
   __shared__ float red2[16][64];
   const int cl = threadIdx.x & 63;
   const int c = blockIdx.x * 64 + cl;
   const int rl = threadIdx.x >> 6;
-  const int g = blockIdx.y;
+  const int g = blockIdx.y, z = blockIdx.z, G = gridDim.y;
+  const int r0 = z * chunk, r1 = min(R, r0 + chunk);
   float a1 = 0.f, a2 = 0.f;
   if (c < N) {
     const float mu = mean[(size_t)g * N + c];
     const float istd = rsqrtf(var[(size_t)g * N + c] + BN_EPSILON);
-    for (int r = rl; r < R; r += 16) {
+    for (int r = r0 + rl; r < r1; r += 16) {
       const size_t row = (size_t)g * R + r;
       float d = dh[row * lddh + c];
       if (relu && !(h[row * ldh + c] > 0.f)) d = 0.f;
@@ -456,18 +555,41 @@ __global__ __launch_bounds__(1024) void bn_bwd_stats_kernel(
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { t1 += red1[i][cl]; t2 += red2[i][cl]; }
-    s1[(size_t)g * N + c] = t1;
-    s2[(size_t)g * N + c] = t2;
+    float* out = partial + (((size_t)z * G + g) * 2) * N;
+    out[c] = t1;
+    out[N + c] = t2;
   }
+}
+
+__global__ void bn_bwd_stats_finalize_kernel(const float* __restrict__ partial, int N, int chunks,
+                                             int G, float* __restrict__ s1,
+                                             float* __restrict__ s2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.y;
+  if (c >= N) return;
+  float t1 = 0.f, t2 = 0.f;
+  for (int z = 0; z < chunks; ++z) {
+    const float* pz = partial + (((size_t)z * G + g) * 2) * N;
+    t1 += pz[c];
+    t2 += pz[N + c];
+  }
+  s1[(size_t)g * N + c] = t1;
+  s2[(size_t)g * N + c] = t2;
 }
 
 int bn_bwd_stats(hipStream_t stream, const float* dh, int lddh, const float* h, int ldh,
                  const float* a, int lda, const float* mean, const float* var, int rows_per_group,
-                 int groups, int N, int relu, float* s1, float* s2) {
-  SCVAE_ARG(dh && h && a && mean && var && s1 && s2);
-  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((N + 63) / 64, groups), dim3(1024), 0, stream, dh,
-                     lddh, h, ldh, a, lda, mean, var, rows_per_group, N, relu, s1, s2);
-  SCVAE_LAUNCH_CHECK("bn_bwd_stats_kernel");
+                 int groups, int N, int relu, float* s1, float* s2, float* partial) {
+  SCVAE_ARG(dh && h && a && mean && var && s1 && s2 && partial);
+  int chunk;
+  const int chunks = bn_chunks(rows_per_group, &chunk);
+  hipLaunchKernelGGL(bn_bwd_stats_partial_kernel, dim3((N + 63) / 64, groups, chunks), dim3(1024),
+                     0, stream, dh, lddh, h, ldh, a, lda, mean, var, rows_per_group, N, relu, chunk,
+                     partial);
+  SCVAE_LAUNCH_CHECK("bn_bwd_stats_partial_kernel");
+  hipLaunchKernelGGL(bn_bwd_stats_finalize_kernel, dim3((N + 63) / 64, groups), dim3(64), 0,
+                     stream, partial, N, chunks, groups, s1, s2);
+  SCVAE_LAUNCH_CHECK("bn_bwd_stats_finalize_kernel");
   return 0;
 }
 
@@ -573,34 +695,69 @@ int relu_bwd(hipStream_t stream, const float* dh, const float* h, float* da, siz
   return 0;
 }
 
-// out[c] (+)= scale * sum_r a[r,c]; grid ceil(N/64), 64 columns x 16 row lanes
+// out[c] (+)= scale * sum_r a[r,c].  Small row counts: one workgroup per 64 columns.
+// Large: grid (ceil(N/64), chunks) partial sums into `partial`, then a fixed-order finalize.
 __global__ __launch_bounds__(1024) void col_sum_kernel(const float* __restrict__ a, int lda,
-                                                       int rows, int N, float* __restrict__ out,
-                                                       float scale, int accumulate) {
+                                                       int rows, int N, int chunk,
+                                                       float* __restrict__ out, float scale,
+                                                       int accumulate, int to_partial) {
   __shared__ float red[16][64];
   const int cl = threadIdx.x & 63;
   const int c = blockIdx.x * 64 + cl;
   const int rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * chunk, r1 = min(rows, r0 + chunk);
   float s = 0.f;
   if (c < N)
-    for (int r = rl; r < rows; r += 16) s += a[(size_t)r * lda + c];
+    for (int r = r0 + rl; r < r1; r += 16) s += a[(size_t)r * lda + c];
   red[rl][cl] = s;
   __syncthreads();
   if (rl == 0 && c < N) {
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += red[i][cl];
-    t *= scale;
-    out[c] = accumulate ? out[c] + t : t;
+    if (to_partial) {
+      out[(size_t)blockIdx.y * N + c] = t;
+    } else {
+      t *= scale;
+      out[c] = accumulate ? out[c] + t : t;
+    }
   }
 }
 
+__global__ void col_sum_finalize_kernel(const float* __restrict__ partial, int N, int chunks,
+                                        float* __restrict__ out, float scale, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float t = 0.f;
+  for (int z = 0; z < chunks; ++z) t += partial[(size_t)z * N + c];
+  t *= scale;
+  out[c] = accumulate ? out[c] + t : t;
+}
+
+size_t col_sum_partial_floats(int N) { return (size_t)COLSUM_MAX_CHUNKS * N; }
+
 int col_sum(hipStream_t stream, const float* a, int lda, int rows, int N, float* out, float scale,
-            int accumulate) {
+            int accumulate, float* partial) {
   SCVAE_ARG(a && out && N > 0 && rows >= 0);
-  hipLaunchKernelGGL(col_sum_kernel, dim3((N + 63) / 64), dim3(1024), 0, stream, a, lda, rows, N,
-                     out, scale, accumulate);
+  int chunks = 1;
+  if (partial != nullptr && rows >= 512) {
+    chunks = (rows + 255) / 256;
+    if (chunks > COLSUM_MAX_CHUNKS) chunks = COLSUM_MAX_CHUNKS;
+  }
+  const int chunk = (rows + chunks - 1) / chunks;
+  if (chunks > 1) chunks = (rows + chunk - 1) / chunk;
+  if (chunks <= 1) {
+    hipLaunchKernelGGL(col_sum_kernel, dim3((N + 63) / 64, 1), dim3(1024), 0, stream, a, lda, rows,
+                       N, rows > 0 ? rows : 1, out, scale, accumulate, 0);
+    SCVAE_LAUNCH_CHECK("col_sum_kernel");
+    return 0;
+  }
+  hipLaunchKernelGGL(col_sum_kernel, dim3((N + 63) / 64, chunks), dim3(1024), 0, stream, a, lda,
+                     rows, N, chunk, partial, 1.f, 0, 1);
   SCVAE_LAUNCH_CHECK("col_sum_kernel");
+  hipLaunchKernelGGL(col_sum_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, partial,
+                     N, chunks, out, scale, accumulate);
+  SCVAE_LAUNCH_CHECK("col_sum_finalize_kernel");
   return 0;
 }
 

@@ -33,6 +33,8 @@ int loglik_bwd(hipStream_t stream, int kind, const float* t, int ldt, HeadPtrs p
 int px_statistics(hipStream_t stream, int kind, HeadPtrs pre, int ldp, int S, int B, int F,
                   const float* weight, int ldw, int accumulate, float* p_x_mean,
                   float* mean_of_var, float* var_of_mean);
+int loglik_elementwise(hipStream_t stream, int kind, const float* t, HeadPtrs pre, float* out,
+                       float* mean, float* var, size_t n);
 int sqrt_sum(hipStream_t stream, const float* a, const float* b, float* out, size_t n);
 
 // Gaussian posterior: clip, reparameterise, analytic KL (va:2266-2289, 2346-2369, 2624-2656)
@@ -48,8 +50,12 @@ int vae_elbo(hipStream_t stream, const float* ll, const float* kl_cell, int n_iw
              float kl_weight_total, float row_scale, float* scalars, float* gw);
 
 // batch normalisation (tf.contrib.layers.batch_norm(center=True, scale=False), fused semantics)
+constexpr int BN_MAX_CHUNKS = 64;
+constexpr int COLSUM_MAX_CHUNKS = 32;
+size_t bn_partial_floats(int groups, int N);
+size_t col_sum_partial_floats(int N);
 int bn_stats(hipStream_t stream, const float* a, int lda, int rows_per_group, int groups, int N,
-             float* mean, float* var);
+             float* mean, float* var, float* partial);
 int bn_apply(hipStream_t stream, const float* a, int lda, const float* mean, const float* var,
              int stat_stride, const float* beta, float* h, int ldh, int rows_per_group, int groups,
              int N, int relu);
@@ -57,7 +63,7 @@ int bn_update_moving(hipStream_t stream, const float* mean, const float* var, in
                      int groups, int N, float* moving_mean, float* moving_var);
 int bn_bwd_stats(hipStream_t stream, const float* dh, int lddh, const float* h, int ldh,
                  const float* a, int lda, const float* mean, const float* var, int rows_per_group,
-                 int groups, int N, int relu, float* s1, float* s2);
+                 int groups, int N, int relu, float* s1, float* s2, float* partial);
 int bn_bwd_apply(hipStream_t stream, const float* dh, int lddh, const float* h, int ldh,
                  const float* a, int lda, const float* mean, const float* var, const float* s1,
                  const float* s2, int rows_per_group, int groups, int N, int relu, float inv_count,
@@ -67,7 +73,35 @@ int bn_merge(hipStream_t stream, const float* gathered, const int64_t* counts, i
              float* out);
 int relu_bwd(hipStream_t stream, const float* dh, const float* h, float* da, size_t n);
 int col_sum(hipStream_t stream, const float* a, int lda, int rows, int N, float* out, float scale,
-            int accumulate);
+            int accumulate, float* partial);
+
+// ---- gmvae_kernels.hip ----
+int add_group_rows(hipStream_t s, const float* a0, const float* rows, float* out, int K, int B,
+                   int N, int relu);
+int group_col_sum(hipStream_t s, const float* a, int lda, int R, int G, int N, float scale,
+                  float* out, float* partial);
+int sum_groups(hipStream_t s, const float* a, const float* w, int ldw, int G, int R, int N,
+               float* out);
+int categorical_fwd(hipStream_t s, const float* logits, float* y, float* kl_y_cell, int B, int K);
+int categorical_bwd_gated(hipStream_t s, const float* y, const float* dy, const float* gate,
+                          float c, float* dlogits, int B, int K);
+int softplus_gaussian_fwd(hipStream_t st, const float* qm, const float* qs, const float* Wpm,
+                          const float* bpm, const float* Wps, const float* bps, const float* eps,
+                          float* z, float* klz, float* qvar, int K, int S, int B, int L);
+int softplus_gaussian_bwd(hipStream_t st, const float* qm, const float* qs, const float* Wpm,
+                          const float* bpm, const float* Wps, const float* bps, const float* eps,
+                          const float* dz, const float* gklz, float* dqm, float* dqs, float* dpr,
+                          int K, int S, int B, int L);
+int gmvae_elbo(hipStream_t s, const float* ll, const float* klz, const float* y,
+               const float* kl_y_cell, int K, int S, int B, float inv_gb, float* sums,
+               float* rec_cell);
+int gmvae_elbo_finish(hipStream_t s, const float* sums, float w, float thr, int use_free_nats,
+                      float share, float* scalars, float* gate);
+int gmvae_elbo_bwd(hipStream_t s, const float* ll, const float* klz, const float* y,
+                   const float* gate, int K, int S, int B, float w, float inv_gb, float* gw,
+                   float* gklz, float* dy);
+int prior_stats(hipStream_t s, const float* Wpm, const float* bpm, const float* Wps,
+                const float* bps, int K, int L, float* means, float* variances);
 
 // clip-by-value(+-1) and TF Adam on a flat parameter buffer (va:2742-2759)
 int adam_clip_step(hipStream_t stream, float* theta, float* grad, float* m, float* v, size_t n,

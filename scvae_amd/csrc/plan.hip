@@ -1,22 +1,7 @@
-// Host-side execution plan: the MI355X replacement of the reference's TF graph
-// (build: variational_autoencoder.py:2219-2770; run: session.run in the loops at
-// variational_autoencoder.py:987-1044, 1092-1150, 1969-2014).  A plan owns no device
-// memory: parameters, gradients, moving statistics and workspace are bound by the
-// caller.  scvae_plan_step enqueues the whole forward (+backward) kernel sequence on
-// one stream with no host synchronisation.
-#include <stdarg.h>
-#include <stdio.h>
-#include <string.h>
-
-#include <string>
-#include <vector>
-
-#include "../../include/scvae_hip.h"
-#include "common.hpp"
-#include "kernels.hpp"
+// Host-side execution plan of the VAE + the exported C ABI (see plan.hpp).
+#include "plan.hpp"
 
 namespace scvae {
-
 // ------------------------------ errors ------------------------------------
 static thread_local char g_error[512] = "";
 void set_error(const char* fmt, ...) {
@@ -32,116 +17,7 @@ int check_hip(hipError_t e, const char* what) {
 }
 const char* last_error() { return g_error; }
 
-// ------------------------------ layout ------------------------------------
-constexpr size_t NPOS = (size_t)-1;
-constexpr size_t ALIGN_FLOATS = 64;  // every tensor starts on a 256-byte boundary
-
-struct ParamInfo {
-  std::string name;
-  size_t offset;
-  int rows, cols;  // cols == 0 for vectors
-};
-struct MovingInfo {
-  std::string name;
-  size_t offset;
-  int size;
-};
-struct Dense {
-  int n_in = 0, n_out = 0;
-  size_t w = NPOS, b = NPOS, beta = NPOS;      // offsets in the flat parameter buffer
-  size_t mov_mean = NPOS, mov_var = NPOS;      // offsets in the moving-statistics buffer
-  bool bn = false;
-  // workspace (assigned at bind)
-  float* a = nullptr;      // pre-normalisation output [rows, n_out] (BN only)
-  float* h = nullptr;      // layer output [rows, n_out]
-  float* stats = nullptr;  // [mean | var | s1 | s2], each groups*n_out
-};
-
-struct Layout {
-  std::vector<ParamInfo> params;
-  std::vector<MovingInfo> moving;
-  size_t n_params = 0, n_moving = 0;
-  size_t add(const std::string& name, int rows, int cols) {
-    const size_t off = n_params;
-    params.push_back({name, off, rows, cols});
-    const size_t n = (size_t)rows * (cols ? cols : 1);
-    n_params += (n + ALIGN_FLOATS - 1) / ALIGN_FLOATS * ALIGN_FLOATS;
-    return off;
-  }
-  size_t add_moving(const std::string& name, int size) {
-    const size_t off = n_moving;
-    moving.push_back({name, off, size});
-    n_moving += ((size_t)size + ALIGN_FLOATS - 1) / ALIGN_FLOATS * ALIGN_FLOATS;
-    return off;
-  }
-  Dense dense(const std::string& scope, int n_in, int n_out, bool bn) {
-    Dense d;
-    d.n_in = n_in; d.n_out = n_out; d.bn = bn;
-    d.w = add(scope + "/DENSE/weights", n_in, n_out);
-    d.b = add(scope + "/DENSE/biases", n_out, 0);
-    if (bn) {
-      d.beta = add(scope + "/BATCH_NORM/beta", n_out, 0);
-      d.mov_mean = add_moving(scope + "/BATCH_NORM/moving_mean", n_out);
-      d.mov_var = add_moving(scope + "/BATCH_NORM/moving_variance", n_out);
-    }
-    return d;
-  }
-};
-
-static const char* head_names(int kind, int j) {
-  static const char* P[] = {"LOG_LAMBDA"};
-  static const char* NB[] = {"P", "LOG_R"};
-  static const char* ZIP[] = {"PI", "LOG_LAMBDA"};
-  static const char* ZINB[] = {"PI", "P", "LOG_R"};
-  switch (kind) {
-    case LK_POISSON: return P[j];
-    case LK_NB: return NB[j];
-    case LK_ZIP: return ZIP[j];
-    default: return ZINB[j];
-  }
-}
-
-struct Bump {
-  char* base;
-  size_t used = 0, cap;
-  bool dry;  // dry run: only measure
-  Bump(void* b, size_t c, bool d) : base((char*)b), cap(c), dry(d) {}
-  float* floats(size_t n) {
-    const size_t bytes = (n * sizeof(float) + 255) / 256 * 256;
-    char* p = dry ? nullptr : base + used;
-    used += bytes;
-    return (float*)p;
-  }
-};
-
 }  // namespace scvae
-
-using namespace scvae;
-
-struct scvae_plan {
-  scvae_model_config cfg;
-  Layout layout;
-  int P = 1;  // likelihood heads
-  // VAE graph
-  std::vector<Dense> enc, dec;
-  Dense mu, ls;
-  Dense heads[3];
-  // bound buffers
-  float *params = nullptr, *grads = nullptr, *moving = nullptr;
-  void* ws = nullptr;
-  size_t ws_bytes = 0;
-  int64_t max_cells = 0, max_samples = 0;
-  // workspace views
-  float *mu_pre = nullptr, *ls_pre = nullptr, *kl_elem = nullptr, *kl_cell = nullptr;
-  float *z = nullptr, *ll = nullptr, *gw = nullptr;
-  float* pre[3] = {nullptr, nullptr, nullptr};
-  float *dbuf[3] = {nullptr, nullptr, nullptr}, *dz = nullptr, *dmu = nullptr, *dls = nullptr;
-  float *mov = nullptr, *vom = nullptr;  // evaluate statistics scratch [cells, F]
-  float* gemm_ws = nullptr;
-  size_t gemm_ws_bytes = 0;
-  scvae_sync_fn sync = nullptr;
-  void* sync_user = nullptr;
-};
 
 namespace scvae {
 
@@ -221,19 +97,22 @@ static size_t carve(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_
   track(B, Lz, hn); track(hn, Lz, B); track(B, hn, Lz);
   track(R, F, h1); track(h1, F, R); track(R, h1, F);
   float* gemm_ws = gws ? b.floats(gws / sizeof(float)) : nullptr;
+  size_t pmax = col_sum_partial_floats((int)(F > hmax ? F : hmax));
+  { const size_t q = bn_partial_floats(1, (int)hmax); if (q > pmax) pmax = q; }
+  float* partial = b.floats(pmax);
   if (!dry) {
     p->mu_pre = mu_pre; p->ls_pre = ls_pre; p->kl_elem = kl_elem; p->kl_cell = kl_cell;
     p->z = z; p->ll = ll; p->gw = gw;
     for (int j = 0; j < 3; ++j) p->pre[j] = pre[j];
     p->dbuf[0] = d0; p->dbuf[1] = d1; p->dbuf[2] = d2; p->dz = dz; p->dmu = dmu; p->dls = dls;
     p->mov = mov; p->vom = vom;
-    p->gemm_ws = gemm_ws; p->gemm_ws_bytes = gws;
+    p->gemm_ws = gemm_ws; p->gemm_ws_bytes = gws; p->partial = partial;
   }
   return b.used;
 }
 
 // ---- dense layer forward: fully_connected (+ batch_norm) (+ relu), mu:38-76 ----
-static int dense_forward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_in,
+int dense_forward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_in,
                          int rows, int groups, bool relu, bool training) {
   const float* W = p->params + d.w;
   const float* bias = p->params + d.b;
@@ -249,7 +128,7 @@ static int dense_forward(scvae_plan* p, hipStream_t s, Dense& d, const float* in
     const int rpg = rows / groups;
     float* mean = d.stats;
     float* var = d.stats + (size_t)groups * N;
-    if ((rc = bn_stats(s, d.a, N, rpg, groups, N, mean, var))) return rc;
+    if ((rc = bn_stats(s, d.a, N, rpg, groups, N, mean, var, p->partial))) return rc;
     if (p->sync) {
       // statistics of the global minibatch (sync batch norm); groups == 1 on this path
       if (p->sync(p->sync_user, d.stats, 2 * (int64_t)groups * N, 1, rpg)) {
@@ -267,7 +146,7 @@ static int dense_forward(scvae_plan* p, hipStream_t s, Dense& d, const float* in
 }
 
 // moving-average update (UPDATE_OPS, va:2763-2768); uses the (possibly synced) batch statistics
-static int dense_update_moving(scvae_plan* p, hipStream_t s, Dense& d, int64_t global_rows_per_group,
+int dense_update_moving(scvae_plan* p, hipStream_t s, Dense& d, int64_t global_rows_per_group,
                                int groups) {
   if (!d.bn) return 0;
   const int N = d.n_out;
@@ -275,14 +154,15 @@ static int dense_update_moving(scvae_plan* p, hipStream_t s, Dense& d, int64_t g
                           groups, N, p->moving + d.mov_mean, p->moving + d.mov_var);
 }
 
-// ---- dense layer backward.  dh: gradient w.r.t. the layer output h [rows, n_out];
-// scratch: [rows, n_out]; d_in (optional): gradient w.r.t. the layer input ----
-static int dense_backward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_in,
-                          int rows, int groups, bool relu, const float* dh, float* scratch,
-                          float* d_in, bool accumulate_d_in, int64_t global_rows_per_group) {
+// ---- dense layer backward, part 1: through relu / batch norm.  dh: gradient w.r.t. the
+// layer output h [rows, n_out]; *da_out: gradient w.r.t. the affine output (dh itself, or
+// `scratch`).  Writes dbeta. ----
+int dense_backward_activation(scvae_plan* p, hipStream_t s, Dense& d, int rows, int groups,
+                              bool relu, const float* dh, float* scratch,
+                              int64_t global_rows_per_group, const float** da_out) {
   const int N = d.n_out;
   int rc;
-  const float* da = dh;
+  *da_out = dh;
   if (d.bn) {
     const int rpg = rows / groups;
     float* mean = d.stats;
@@ -290,7 +170,7 @@ static int dense_backward(scvae_plan* p, hipStream_t s, Dense& d, const float* i
     float* s1 = d.stats + 2 * (size_t)groups * N;
     float* s2 = d.stats + 3 * (size_t)groups * N;
     if ((rc = bn_bwd_stats(s, dh, N, d.h, N, d.a, N, mean, var, rpg, groups, N, relu ? 1 : 0, s1,
-                           s2)))
+                           s2, p->partial)))
       return rc;
     // dbeta = sum over this rank's rows of dA (taken before s1 becomes a global sum)
     if ((rc = bn_dbeta(s, s1, groups, N, p->grads + d.beta, 0))) return rc;
@@ -303,16 +183,28 @@ static int dense_backward(scvae_plan* p, hipStream_t s, Dense& d, const float* i
     if ((rc = bn_bwd_apply(s, dh, N, d.h, N, d.a, N, mean, var, s1, s2, rpg, groups, N,
                            relu ? 1 : 0, 1.f / (float)global_rows_per_group, scratch, N)))
       return rc;
-    da = scratch;
+    *da_out = scratch;
   } else if (relu) {
     if ((rc = relu_bwd(s, dh, d.h, scratch, (size_t)rows * N))) return rc;
-    da = scratch;
+    *da_out = scratch;
   }
-  // dW = in^T da ; db = colsum(da)
+  return 0;
+}
+
+// ---- dense layer backward: activation, then dW = in^T dA, db = colsum(dA), d_in = dA W^T ----
+int dense_backward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_in, int rows,
+                   int groups, bool relu, const float* dh, float* scratch, float* d_in,
+                   bool accumulate_d_in, int64_t global_rows_per_group) {
+  const int N = d.n_out;
+  int rc;
+  const float* da = nullptr;
+  if ((rc = dense_backward_activation(p, s, d, rows, groups, relu, dh, scratch,
+                                      global_rows_per_group, &da)))
+    return rc;
   if ((rc = gemm(s, true, false, in, da, nullptr, p->grads + d.w, d.n_in, N, rows, ld_in, N, N,
                  ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
     return rc;
-  if ((rc = col_sum(s, da, N, rows, N, p->grads + d.b, 1.f, 0))) return rc;
+  if ((rc = col_sum(s, da, N, rows, N, p->grads + d.b, 1.f, 0, p->partial))) return rc;
   if (d_in) {
     if ((rc = gemm(s, false, true, da, p->params + d.w, nullptr, d_in, rows, d.n_in, N, N, N,
                    d.n_in, ACT_NONE, accumulate_d_in, p->gemm_ws, p->gemm_ws_bytes)))
@@ -334,7 +226,7 @@ __global__ void fill_kernel(float* __restrict__ dst, float v, size_t n) {
        i += (size_t)gridDim.x * blockDim.x)
     dst[i] = v;
 }
-static int fill(hipStream_t s, float* dst, float v, size_t n) {
+int fill(hipStream_t s, float* dst, float v, size_t n) {
   if (n == 0) return 0;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 1024) blocks = 1024;
@@ -342,7 +234,7 @@ static int fill(hipStream_t s, float* dst, float v, size_t n) {
   SCVAE_LAUNCH_CHECK("fill_kernel");
   return 0;
 }
-static int copy(hipStream_t s, const float* src, float* dst, size_t n) {
+int copy(hipStream_t s, const float* src, float* dst, size_t n) {
   if (n == 0) return 0;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 1024) blocks = 1024;
@@ -386,7 +278,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                              L, a->deterministic_z)))
     return rc;
   if (a->kl_neurons)
-    if ((rc = col_sum(s, p->kl_elem, L, B, L, a->kl_neurons, 1.f / (float)GB, 0))) return rc;
+    if ((rc = col_sum(s, p->kl_elem, L, B, L, a->kl_neurons, 1.f / (float)GB, 0, p->partial))) return rc;
   if (a->q_z_mean)
     if ((rc = copy(s, p->mu_pre, a->q_z_mean, (size_t)B * L))) return rc;
 
@@ -457,7 +349,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       if ((rc = gemm(s, true, false, dch, p->pre[j], nullptr, p->grads + hd.w, h1, F, R, ld, F, F,
                      ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
         return rc;
-      if ((rc = col_sum(s, p->pre[j], F, R, F, p->grads + hd.b, 1.f, 0))) return rc;
+      if ((rc = col_sum(s, p->pre[j], F, R, F, p->grads + hd.b, 1.f, 0, p->partial))) return rc;
       if ((rc = gemm(s, false, true, p->pre[j], p->params + hd.w, nullptr, dcur, R, h1, F, F, F,
                      h1, ACT_NONE, j > 0, p->gemm_ws, p->gemm_ws_bytes)))
         return rc;
@@ -490,7 +382,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     if ((rc = gemm(s, true, false, hn, dpre, nullptr, p->grads + hd.w, hd.n_in, L, B, ldn, L, L,
                    ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
       return rc;
-    if ((rc = col_sum(s, dpre, L, B, L, p->grads + hd.b, 1.f, 0))) return rc;
+    if ((rc = col_sum(s, dpre, L, B, L, p->grads + hd.b, 1.f, 0, p->partial))) return rc;
     if (need_dh)
       if ((rc = gemm(s, false, true, dpre, p->params + hd.w, nullptr, dh, B, hd.n_in, L, L, L,
                      hd.n_in, ACT_NONE, q > 0, p->gemm_ws, p->gemm_ws_bytes)))
@@ -528,14 +420,13 @@ int scvae_plan_create(const scvae_model_config* cfg, scvae_plan** out) {
   SCVAE_ARG(cfg->n_hidden >= 0 && cfg->n_hidden <= SCVAE_MAX_HIDDEN);
   SCVAE_ARG(cfg->likelihood >= 0 && cfg->likelihood <= 3);
   for (int i = 0; i < cfg->n_hidden; ++i) SCVAE_ARG(cfg->hidden[i] > 0);
-  if (cfg->model_type != SCVAE_MODEL_VAE) {
-    scvae::set_error("model_type %d is not built in this library version", cfg->model_type);
-    return -1;
-  }
+  SCVAE_ARG(cfg->model_type == SCVAE_MODEL_VAE || cfg->model_type == SCVAE_MODEL_GMVAE);
+  SCVAE_ARG(cfg->model_type == SCVAE_MODEL_VAE || (cfg->n_clusters >= 1 && cfg->n_clusters <= 1024));
   scvae_plan* p = new scvae_plan();
   p->cfg = *cfg;
   p->P = scvae::likelihood_heads(cfg->likelihood);
-  scvae::build_vae(p);
+  if (cfg->model_type == SCVAE_MODEL_GMVAE) scvae::build_gmvae(p);
+  else scvae::build_vae(p);
   *out = p;
   return 0;
 }
@@ -570,14 +461,19 @@ int scvae_plan_moving_info(const scvae_plan* p, int64_t i, char* name, int64_t* 
 
 int64_t scvae_plan_workspace_bytes(const scvae_plan* p, int64_t max_cells, int64_t max_samples) {
   if (!p || max_cells <= 0 || max_samples <= 0) return -1;
-  return (int64_t)scvae::carve(const_cast<scvae_plan*>(p), nullptr, 0, max_cells, max_samples, true);
+  scvae_plan* q = const_cast<scvae_plan*>(p);
+  if (p->cfg.model_type == SCVAE_MODEL_GMVAE)
+    return (int64_t)scvae::carve_gmvae(q, nullptr, 0, max_cells, max_samples, true);
+  return (int64_t)scvae::carve(q, nullptr, 0, max_cells, max_samples, true);
 }
 
 int scvae_plan_bind(scvae_plan* p, float* params, float* grads, float* moving, void* workspace,
                     int64_t workspace_bytes, int64_t max_cells, int64_t max_samples) {
   SCVAE_ARG(p && params && workspace && max_cells > 0 && max_samples > 0);
   SCVAE_ARG(p->layout.n_moving == 0 || moving);
-  const size_t need = scvae::carve(p, nullptr, 0, max_cells, max_samples, true);
+  const bool gm = p->cfg.model_type == SCVAE_MODEL_GMVAE;
+  const size_t need = gm ? scvae::carve_gmvae(p, nullptr, 0, max_cells, max_samples, true)
+                         : scvae::carve(p, nullptr, 0, max_cells, max_samples, true);
   if ((size_t)workspace_bytes < need) {
     scvae::set_error("workspace too small: %lld < %zu bytes", (long long)workspace_bytes, need);
     return -1;
@@ -586,7 +482,8 @@ int scvae_plan_bind(scvae_plan* p, float* params, float* grads, float* moving, v
   p->params = params; p->grads = grads; p->moving = moving;
   p->ws = workspace; p->ws_bytes = (size_t)workspace_bytes;
   p->max_cells = max_cells; p->max_samples = max_samples;
-  scvae::carve(p, workspace, (size_t)workspace_bytes, max_cells, max_samples, false);
+  if (gm) scvae::carve_gmvae(p, workspace, (size_t)workspace_bytes, max_cells, max_samples, false);
+  else scvae::carve(p, workspace, (size_t)workspace_bytes, max_cells, max_samples, false);
   return 0;
 }
 
@@ -606,6 +503,10 @@ int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
   SCVAE_ARG(a->deterministic_z || a->eps);
   SCVAE_ARG(!a->training || p->grads);
   SCVAE_ARG(!(a->training && a->deterministic_z));
+  if (p->cfg.model_type == SCVAE_MODEL_GMVAE) {
+    SCVAE_ARG(!a->deterministic_z);
+    return scvae::gmvae_step(p, a, (hipStream_t)stream);
+  }
   return scvae::vae_step(p, a, (hipStream_t)stream);
 }
 
@@ -644,6 +545,15 @@ int scvae_loglik_bwd(int32_t kind, const float* t, float* const* pre, const floa
   for (int j = 0; j < scvae::likelihood_heads(kind); ++j) hp.p[j] = pre[j];
   return scvae::loglik_bwd((hipStream_t)stream, kind, t, (int)F, hp, (int)F, gw, row_const, ll,
                            (int)rows, (int)cells, (int)F);
+}
+int scvae_likelihood_elementwise(int32_t kind, const float* t, const float* const* pre,
+                                 float* log_prob, float* mean, float* variance, int64_t n,
+                                 void* stream) {
+  SCVAE_ARG(pre && kind >= 0 && kind <= 3 && n >= 0);
+  scvae::HeadPtrs hp = {{nullptr, nullptr, nullptr}};
+  for (int j = 0; j < scvae::likelihood_heads(kind); ++j) hp.p[j] = const_cast<float*>(pre[j]);
+  return scvae::loglik_elementwise((hipStream_t)stream, kind, t, hp, log_prob, mean, variance,
+                                   (size_t)n);
 }
 int scvae_gauss_latent_fwd(const float* mu_pre, const float* ls_pre, const float* eps, float* z,
                            float* kl_elem, float* kl_cell, int64_t S, int64_t cells, int64_t L,

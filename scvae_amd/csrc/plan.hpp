@@ -1,0 +1,159 @@
+#pragma once
+// (declarations shared by plan.hip and plan_gmvae.hip)
+// Host-side execution plan: the MI355X replacement of the reference's TF graph
+// (build: variational_autoencoder.py:2219-2770; run: session.run in the loops at
+// variational_autoencoder.py:987-1044, 1092-1150, 1969-2014).  A plan owns no device
+// memory: parameters, gradients, moving statistics and workspace are bound by the
+// caller.  scvae_plan_step enqueues the whole forward (+backward) kernel sequence on
+// one stream with no host synchronisation.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/scvae_hip.h"
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace scvae {
+
+// ------------------------------ layout ------------------------------------
+constexpr size_t NPOS = (size_t)-1;
+constexpr size_t ALIGN_FLOATS = 64;  // every tensor starts on a 256-byte boundary
+
+struct ParamInfo {
+  std::string name;
+  size_t offset;
+  int rows, cols;  // cols == 0 for vectors
+};
+struct MovingInfo {
+  std::string name;
+  size_t offset;
+  int size;
+};
+struct Dense {
+  int n_in = 0, n_out = 0;
+  size_t w = NPOS, b = NPOS, beta = NPOS;      // offsets in the flat parameter buffer
+  size_t mov_mean = NPOS, mov_var = NPOS;      // offsets in the moving-statistics buffer
+  bool bn = false;
+  // workspace (assigned at bind)
+  float* a = nullptr;      // pre-normalisation output [rows, n_out] (BN only)
+  float* h = nullptr;      // layer output [rows, n_out]
+  float* stats = nullptr;  // [mean | var | s1 | s2], each groups*n_out
+};
+
+struct Layout {
+  std::vector<ParamInfo> params;
+  std::vector<MovingInfo> moving;
+  size_t n_params = 0, n_moving = 0;
+  size_t add(const std::string& name, int rows, int cols) {
+    const size_t off = n_params;
+    params.push_back({name, off, rows, cols});
+    const size_t n = (size_t)rows * (cols ? cols : 1);
+    n_params += (n + ALIGN_FLOATS - 1) / ALIGN_FLOATS * ALIGN_FLOATS;
+    return off;
+  }
+  size_t add_moving(const std::string& name, int size) {
+    const size_t off = n_moving;
+    moving.push_back({name, off, size});
+    n_moving += ((size_t)size + ALIGN_FLOATS - 1) / ALIGN_FLOATS * ALIGN_FLOATS;
+    return off;
+  }
+  Dense dense(const std::string& scope, int n_in, int n_out, bool bn) {
+    Dense d;
+    d.n_in = n_in; d.n_out = n_out; d.bn = bn;
+    d.w = add(scope + "/DENSE/weights", n_in, n_out);
+    d.b = add(scope + "/DENSE/biases", n_out, 0);
+    if (bn) {
+      d.beta = add(scope + "/BATCH_NORM/beta", n_out, 0);
+      d.mov_mean = add_moving(scope + "/BATCH_NORM/moving_mean", n_out);
+      d.mov_var = add_moving(scope + "/BATCH_NORM/moving_variance", n_out);
+    }
+    return d;
+  }
+};
+
+static const char* head_names(int kind, int j) {
+  static const char* P[] = {"LOG_LAMBDA"};
+  static const char* NB[] = {"P", "LOG_R"};
+  static const char* ZIP[] = {"PI", "LOG_LAMBDA"};
+  static const char* ZINB[] = {"PI", "P", "LOG_R"};
+  switch (kind) {
+    case LK_POISSON: return P[j];
+    case LK_NB: return NB[j];
+    case LK_ZIP: return ZIP[j];
+    default: return ZINB[j];
+  }
+}
+
+struct Bump {
+  char* base;
+  size_t used = 0, cap;
+  bool dry;  // dry run: only measure
+  Bump(void* b, size_t c, bool d) : base((char*)b), cap(c), dry(d) {}
+  float* floats(size_t n) {
+    const size_t bytes = (n * sizeof(float) + 255) / 256 * 256;
+    char* p = dry ? nullptr : base + used;
+    used += bytes;
+    return (float*)p;
+  }
+};
+
+}  // namespace scvae
+
+using namespace scvae;
+
+struct scvae_plan {
+  scvae_model_config cfg;
+  Layout layout;
+  int P = 1;  // likelihood heads
+  // VAE graph
+  std::vector<Dense> enc, dec;
+  Dense mu, ls;
+  Dense heads[3];
+  // bound buffers
+  float *params = nullptr, *grads = nullptr, *moving = nullptr;
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  int64_t max_cells = 0, max_samples = 0;
+  // workspace views
+  float *mu_pre = nullptr, *ls_pre = nullptr, *kl_elem = nullptr, *kl_cell = nullptr;
+  float *z = nullptr, *ll = nullptr, *gw = nullptr;
+  float* pre[3] = {nullptr, nullptr, nullptr};
+  float *dbuf[3] = {nullptr, nullptr, nullptr}, *dz = nullptr, *dmu = nullptr, *dls = nullptr;
+  float *mov = nullptr, *vom = nullptr;  // evaluate statistics scratch [cells, F]
+  float* gemm_ws = nullptr;
+  size_t gemm_ws_bytes = 0;
+  float* partial = nullptr;  // row-chunk partial sums (batch norm, column sums)
+  scvae_sync_fn sync = nullptr;
+  void* sync_user = nullptr;
+  // GMVAE graph (gm:2788-3221)
+  std::vector<Dense> yenc, zenc, xdec;
+  Dense ylogits, qmean, qscale, pmean, pscale;
+  float *logits = nullptr, *yprob = nullptr, *kl_y_cell = nullptr, *a0 = nullptr;
+  float *qm = nullptr, *qs = nullptr, *klz = nullptr, *gklz = nullptr, *dy = nullptr;
+  float *dlogits = nullptr, *dqm = nullptr, *dqs = nullptr, *dprior = nullptr;
+  float *sum_scratch = nullptr;
+};
+
+namespace scvae {
+const char* last_error();
+int dense_forward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_in, int rows,
+                  int groups, bool relu, bool training);
+int dense_update_moving(scvae_plan* p, hipStream_t s, Dense& d, int64_t global_rows_per_group,
+                        int groups);
+int dense_backward_activation(scvae_plan* p, hipStream_t s, Dense& d, int rows, int groups,
+                              bool relu, const float* dh, float* scratch,
+                              int64_t global_rows_per_group, const float** da_out);
+int dense_backward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_in, int rows,
+                   int groups, bool relu, const float* dh, float* scratch, float* d_in,
+                   bool accumulate_d_in, int64_t global_rows_per_group);
+int fill(hipStream_t s, float* dst, float v, size_t n);
+int copy(hipStream_t s, const float* src, float* dst, size_t n);
+int build_gmvae(scvae_plan* p);
+size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t samples, bool dry);
+int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s);
+}  // namespace scvae
+

@@ -1,0 +1,376 @@
+// Execution plan of the Gaussian-mixture VAE: y is marginalised by K passes through the
+// q(z|x,y) encoder and the decoder with shared weights
+// (scvae/models/gaussian_mixture_variational_autoencoder.py:2788-3434).  The K passes run as
+// ONE batch of K*S*B rows with per-pass (grouped) batch-norm statistics, and the first
+// q(z|x,y=k) layer computes x*W_x once and adds row W_y[k] per pass (the reference recomputes
+// x*W_x K times).
+#include <math.h>
+
+#include "plan.hpp"
+
+namespace scvae {
+
+int build_gmvae(scvae_plan* p) {
+  const scvae_model_config& c = p->cfg;
+  const bool bn = c.batch_norm != 0;
+  const int K = c.n_clusters, Lz = c.latent_size, F = c.feature_size;
+  Layout& L = p->layout;
+  char scope[96];
+  int n_in = F;
+  for (int i = 0; i < c.n_hidden; ++i) {
+    snprintf(scope, sizeof scope, "Y/CATEGORICAL/ENCODER/LAYER_%d", i + 1);
+    p->yenc.push_back(L.dense(scope, n_in, c.hidden[i], bn));
+    n_in = c.hidden[i];
+  }
+  p->ylogits = L.dense("Y/CATEGORICAL/LOGITS", n_in, K, false);
+  n_in = F + K;
+  for (int i = 0; i < c.n_hidden; ++i) {
+    snprintf(scope, sizeof scope, "Z/Q/ENCODER/LAYER_%d", i + 1);
+    p->zenc.push_back(L.dense(scope, n_in, c.hidden[i], bn));
+    n_in = c.hidden[i];
+  }
+  p->qmean = L.dense("Z/Q/SOFTPLUS_GAUSSIAN/MEAN", n_in, Lz, false);
+  p->qscale = L.dense("Z/Q/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE", n_in, Lz, false);
+  p->pmean = L.dense("Z/P/SOFTPLUS_GAUSSIAN/MEAN", K, Lz, false);
+  p->pscale = L.dense("Z/P/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE", K, Lz, false);
+  n_in = Lz;
+  // gm:3135-3146: hidden_sizes[::-1] without reverse_order => LAYER_1.. in execution order
+  for (int i = 0; i < c.n_hidden; ++i) {
+    snprintf(scope, sizeof scope, "X/DECODER/LAYER_%d", i + 1);
+    p->xdec.push_back(L.dense(scope, n_in, c.hidden[c.n_hidden - 1 - i], bn));
+    n_in = c.hidden[c.n_hidden - 1 - i];
+  }
+  for (int j = 0; j < p->P; ++j) {
+    snprintf(scope, sizeof scope, "X/DISTRIBUTION/%s", head_names(c.likelihood, j));
+    p->heads[j] = L.dense(scope, n_in, F, false);
+  }
+  return 0;
+}
+
+size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t samples,
+                   bool dry) {
+  const scvae_model_config& c = p->cfg;
+  Bump b(base, cap, dry);
+  const size_t K = c.n_clusters, B = (size_t)cells, KB = K * B, R = K * B * samples;
+  const size_t Lz = c.latent_size, F = c.feature_size;
+  size_t hmax = Lz > K ? Lz : K;
+  size_t gws = 0;
+  auto track = [&](size_t M, size_t N, size_t Kd) {
+    const size_t w = gemm_workspace_bytes((int)M, (int)N, (int)Kd);
+    if (w > gws) gws = w;
+  };
+  auto layer_ws = [&](Dense& d, size_t rows, size_t groups, size_t n_in_eff) {
+    float* a = d.bn ? b.floats(rows * d.n_out) : nullptr;
+    float* h = b.floats(rows * d.n_out);
+    float* st = d.bn ? b.floats(4 * groups * (size_t)d.n_out) : nullptr;
+    if (!dry) { d.a = a; d.h = h; d.stats = st; }
+    if ((size_t)d.n_out > hmax) hmax = d.n_out;
+    track(rows, d.n_out, n_in_eff);
+    track(n_in_eff, d.n_out, rows);
+    track(rows, n_in_eff, d.n_out);
+  };
+  for (auto& d : p->yenc) layer_ws(d, B, 1, d.n_in);
+  for (size_t i = 0; i < p->zenc.size(); ++i)
+    layer_ws(p->zenc[i], KB, K, i == 0 ? F : (size_t)p->zenc[i].n_in);
+  for (auto& d : p->xdec) layer_ws(d, R, K, d.n_in);
+  const size_t h1z = p->zenc.empty() ? F : (size_t)p->zenc[0].n_out;
+  track(B, h1z, F); track(F, h1z, B);
+  float* logits = b.floats(B * K);
+  float* yprob = b.floats(B * K);
+  float* kl_y_cell = b.floats(B);
+  float* a0 = b.floats(B * h1z);
+  float* qm = b.floats(KB * Lz);
+  float* qs = b.floats(KB * Lz);
+  float* z = b.floats(R * Lz);
+  float* klz = b.floats(R);
+  float* gklz = b.floats(R);
+  float* ll = b.floats(R);
+  float* gw = b.floats(R);
+  float* dy = b.floats(B * K);
+  float* dlogits = b.floats(B * K);
+  float* dqm = b.floats(KB * Lz);
+  float* dqs = b.floats(KB * Lz);
+  float* dprior = b.floats(KB * 2 * Lz);
+  float* kl_cell = b.floats(B + 64);  // rec_cell / scalar sums scratch
+  float* pre[3] = {nullptr, nullptr, nullptr};
+  for (int j = 0; j < p->P; ++j) pre[j] = b.floats(R * F);
+  float* d0 = b.floats(R * hmax);
+  float* d1 = b.floats(R * hmax);
+  float* d2 = b.floats(R * hmax);
+  float* dz = b.floats(R * Lz);
+  float* mov = b.floats(B * F);
+  float* vom = b.floats(B * F);
+  float* sum_scratch = b.floats(B * hmax + KB * Lz);
+  const int hn = c.n_hidden ? c.hidden[c.n_hidden - 1] : (int)F;
+  const int h1 = c.n_hidden ? c.hidden[0] : (int)Lz;
+  track(B, K, hn); track(hn, K, B); track(B, hn, K);
+  track(KB, Lz, hn); track(hn, Lz, KB); track(KB, hn, Lz);
+  track(R, F, h1); track(h1, F, R); track(R, h1, F);
+  float* gemm_ws = gws ? b.floats(gws / sizeof(float)) : nullptr;
+  size_t pmax = col_sum_partial_floats((int)(F > hmax ? F : hmax));
+  {
+    const size_t q = bn_partial_floats((int)K, (int)(hmax > 2 * Lz ? hmax : 2 * Lz));
+    if (q > pmax) pmax = q;
+  }
+  float* partial = b.floats(pmax);
+  if (!dry) {
+    p->logits = logits; p->yprob = yprob; p->kl_y_cell = kl_y_cell; p->a0 = a0;
+    p->qm = qm; p->qs = qs; p->z = z; p->klz = klz; p->gklz = gklz; p->ll = ll; p->gw = gw;
+    p->dy = dy; p->dlogits = dlogits; p->dqm = dqm; p->dqs = dqs; p->dprior = dprior;
+    p->kl_cell = kl_cell;
+    for (int j = 0; j < 3; ++j) p->pre[j] = pre[j];
+    p->dbuf[0] = d0; p->dbuf[1] = d1; p->dbuf[2] = d2; p->dz = dz;
+    p->mov = mov; p->vom = vom; p->sum_scratch = sum_scratch;
+    p->gemm_ws = gemm_ws; p->gemm_ws_bytes = gws; p->partial = partial;
+  }
+  return b.used;
+}
+
+int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
+  const scvae_model_config& c = p->cfg;
+  const int K = c.n_clusters, B = (int)a->cells, S = a->n_iw * a->n_mc;
+  const int KB = K * B, SB = S * B, R = K * SB;
+  const int F = c.feature_size, L = c.latent_size;
+  const bool training = a->training != 0;
+  const int64_t GB = a->global_cells > 0 ? a->global_cells : a->cells;
+  const float w = a->warm_up_weight * c.kl_weight;
+  const float inv_gb = 1.f / (float)GB;
+  int rc;
+#define GEMM(...) if ((rc = gemm(s, __VA_ARGS__, p->gemm_ws, p->gemm_ws_bytes))) return rc
+#define TRY(call) if ((rc = (call))) return rc
+
+  // ---------------- q(y|x) (gm:3050-3092) ----------------
+  const float* h = a->x;
+  int ld = F;
+  for (auto& d : p->yenc) {
+    TRY(dense_forward(p, s, d, h, ld, B, 1, true, training));
+    h = d.h; ld = d.n_out;
+  }
+  const float* hy = h;
+  const int ldy = ld;
+  GEMM(false, false, hy, p->params + p->ylogits.w, p->params + p->ylogits.b, p->logits, B, K, ldy,
+       ldy, K, K, ACT_NONE, false);
+  TRY(categorical_fwd(s, p->logits, p->yprob, p->kl_y_cell, B, K));
+  if (a->q_y_logits) TRY(copy(s, p->logits, a->q_y_logits, (size_t)B * K));
+
+  // ---------------- q(z|x,y=k), all k (gm:2936-3007) ----------------
+  const float* hz = a->x;
+  int ldz = F;
+  for (size_t i = 0; i < p->zenc.size(); ++i) {
+    Dense& d = p->zenc[i];
+    if (i == 0) {
+      // x*W[:F] + b once, then + W[F+k] per pass
+      const float* W = p->params + d.w;
+      GEMM(false, false, a->x, W, p->params + d.b, p->a0, B, d.n_out, F, F, d.n_out, d.n_out,
+           ACT_NONE, false);
+      float* target = d.bn ? d.a : d.h;
+      TRY(add_group_rows(s, p->a0, W + (size_t)F * d.n_out, target, K, B, d.n_out, d.bn ? 0 : 1));
+      if (d.bn) {
+        const int N = d.n_out;
+        if (training) {
+          float* mean = d.stats;
+          float* var = d.stats + (size_t)K * N;
+          TRY(bn_stats(s, d.a, N, B, K, N, mean, var, p->partial));
+          if (p->sync && p->sync(p->sync_user, d.stats, 2 * (int64_t)K * N, 1, B)) {
+            set_error("batch-norm sync hook failed");
+            return -2;
+          }
+          TRY(bn_apply(s, d.a, N, mean, var, N, p->params + d.beta, d.h, N, B, K, N, 1));
+        } else {
+          TRY(bn_apply(s, d.a, N, p->moving + d.mov_mean, p->moving + d.mov_var, 0,
+                       p->params + d.beta, d.h, N, KB, 1, N, 1));
+        }
+      }
+    } else {
+      TRY(dense_forward(p, s, d, hz, ldz, KB, K, true, training));
+    }
+    hz = d.h; ldz = d.n_out;
+  }
+  if (p->zenc.empty()) {
+    set_error("GMVAE needs at least one hidden layer");
+    return -1;
+  }
+  GEMM(false, false, hz, p->params + p->qmean.w, p->params + p->qmean.b, p->qm, KB, L, ldz, ldz, L,
+       L, ACT_NONE, false);
+  GEMM(false, false, hz, p->params + p->qscale.w, p->params + p->qscale.b, p->qs, KB, L, ldz, ldz,
+       L, L, ACT_NONE, false);
+  const float* Wpm = p->params + p->pmean.w;
+  const float* bpm = p->params + p->pmean.b;
+  const float* Wps = p->params + p->pscale.w;
+  const float* bps = p->params + p->pscale.b;
+  float* qvar = a->cluster_stats ? p->dqs : nullptr;  // scratch, free in the forward pass
+  TRY(softplus_gaussian_fwd(s, p->qm, p->qs, Wpm, bpm, Wps, bps, a->eps, p->z, p->klz, qvar, K, S,
+                            B, L));
+  if (a->q_z_mean)  // z_mean = sum_k y_k mean_k (gm:2895-2899)
+    TRY(sum_groups(s, p->qm, p->yprob, K, K, B, L, a->q_z_mean));
+  if (a->cluster_stats) {
+    float* cs = a->cluster_stats;
+    TRY(prior_stats(s, Wpm, bpm, Wps, bps, K, L, cs, cs + (size_t)K * L));
+    // q_z_means / q_z_variances: this rank's share of the batch means (gm:2884-2887)
+    TRY(group_col_sum(s, p->qm, L, B, K, L, inv_gb, cs + 2 * (size_t)K * L, p->partial));
+    TRY(group_col_sum(s, qvar, L, B, K, L, inv_gb, cs + 3 * (size_t)K * L, p->partial));
+  }
+
+  // ---------------- decoder p(x|z_k), all k (gm:3094-3221) ----------------
+  const float* dch = p->z;
+  ld = L;
+  for (auto& d : p->xdec) {
+    TRY(dense_forward(p, s, d, dch, ld, R, K, true, training));
+    dch = d.h; ld = d.n_out;
+  }
+  HeadPtrs pre;
+  for (int j = 0; j < 3; ++j) pre.p[j] = p->pre[j];
+  for (int j = 0; j < p->P; ++j) {
+    Dense& hd = p->heads[j];
+    GEMM(false, false, dch, p->params + hd.w, p->params + hd.b, p->pre[j], R, F, hd.n_in, ld, F, F,
+         ACT_NONE, false);
+  }
+  if (a->p_x_mean) {
+    if (!(a->p_x_stddev && a->stddev_of_p_x_given_z_mean)) {
+      set_error("p_x_mean requires p_x_stddev and stddev_of_p_x_given_z_mean");
+      return -1;
+    }
+    for (int k = 0; k < K; ++k) {
+      HeadPtrs pk;
+      for (int j = 0; j < 3; ++j)
+        pk.p[j] = p->pre[j] ? p->pre[j] + (size_t)k * SB * F : nullptr;
+      TRY(px_statistics(s, c.likelihood, pk, F, S, B, F, p->yprob + k, K, k > 0 ? 1 : 0,
+                        a->p_x_mean, p->mov, p->vom));
+    }
+    TRY(sqrt_sum(s, p->vom, p->mov, a->p_x_stddev, (size_t)B * F));
+    TRY(sqrt_sum(s, p->vom, nullptr, a->stddev_of_p_x_given_z_mean, (size_t)B * F));
+  }
+
+  // ---------------- loss (gm:3223-3410) ----------------
+  float* sums = p->kl_cell + B;     // 3 floats (+ gate at [8])
+  float* gate = sums + 8;
+  const float p_y_entropy = logf((float)K);
+  const float thr = c.free_nats_proportion * p_y_entropy;
+  const int use_free_nats = c.free_nats_proportion != 0.f;
+  if (!training) {
+    TRY(loglik_fwd(s, c.likelihood, a->t, F, pre, F, a->row_const, p->ll, R, B, F));
+    TRY(gmvae_elbo(s, p->ll, p->klz, p->yprob, p->kl_y_cell, K, S, B, inv_gb, sums, nullptr));
+    TRY(gmvae_elbo_finish(s, sums, w, thr, use_free_nats, 1.f, a->scalars, gate));
+    if (a->log_p_x_given_z) TRY(copy(s, p->ll, a->log_p_x_given_z, (size_t)R));
+    return 0;
+  }
+  // d(-ELBO_w)/d log p(t|z_k)[k,s,b] = -y[b,k]/(S*GB): known before the likelihood pass
+  TRY(gmvae_elbo_bwd(s, p->klz, p->klz, p->yprob, gate, K, S, B, w, inv_gb, p->gw, p->gklz,
+                     p->dy));  // (fills gw, gklz; dy is recomputed below with ll)
+  TRY(loglik_bwd(s, c.likelihood, a->t, F, pre, F, p->gw, a->row_const, p->ll, R, B, F));
+  TRY(gmvae_elbo(s, p->ll, p->klz, p->yprob, p->kl_y_cell, K, S, B, inv_gb, sums, nullptr));
+  float share = 1.f;
+  if (p->sync) {
+    // the free-nats gate depends on the global kl_divergence_y
+    if (p->sync(p->sync_user, sums, 3, 0, B)) {
+      set_error("ELBO sync hook failed");
+      return -2;
+    }
+    share = (float)a->cells / (float)GB;
+  }
+  TRY(gmvae_elbo_finish(s, sums, w, thr, use_free_nats, share, a->scalars, gate));
+  TRY(gmvae_elbo_bwd(s, p->ll, p->klz, p->yprob, gate, K, S, B, w, inv_gb, p->gw, p->gklz, p->dy));
+  if (a->log_p_x_given_z) TRY(copy(s, p->ll, a->log_p_x_given_z, (size_t)R));
+
+  // ---------------- backward: heads + decoder ----------------
+  float* dcur = p->dbuf[0];
+  float* dalt = p->dbuf[1];
+  float* scratch = p->dbuf[2];
+  {
+    const int h1 = p->heads[0].n_in;
+    for (int j = 0; j < p->P; ++j) {
+      Dense& hd = p->heads[j];
+      GEMM(true, false, dch, p->pre[j], nullptr, p->grads + hd.w, h1, F, R, ld, F, F, ACT_NONE,
+           false);
+      TRY(col_sum(s, p->pre[j], F, R, F, p->grads + hd.b, 1.f, 0, p->partial));
+      GEMM(false, true, p->pre[j], p->params + hd.w, nullptr, dcur, R, h1, F, F, F, h1, ACT_NONE,
+           j > 0);
+    }
+  }
+  const int64_t GSB = GB * S;  // global rows per group (pass) in the decoder
+  for (int i = (int)p->xdec.size() - 1; i >= 0; --i) {
+    Dense& d = p->xdec[i];
+    const float* in = i > 0 ? p->xdec[i - 1].h : p->z;
+    float* d_in = i > 0 ? dalt : p->dz;
+    TRY(dense_backward(p, s, d, in, d.n_in, R, K, true, dcur, scratch, d_in, false, GSB));
+    if (i > 0) { float* t = dcur; dcur = dalt; dalt = t; }
+  }
+
+  // ---------------- backward: latent, prior, q(z|x,y) ----------------
+  TRY(softplus_gaussian_bwd(s, p->qm, p->qs, Wpm, bpm, Wps, bps, a->eps, p->dz, p->gklz, p->dqm,
+                            p->dqs, p->dprior, K, S, B, L));
+  // prior dense layers on the one-hot: dW[k,:] = sum_b, db = sum_k dW[k,:]
+  TRY(group_col_sum(s, p->dprior, 2 * L, B, K, 2 * L, 1.f, p->sum_scratch, p->partial));
+  {
+    // sum_scratch: [K, 2L] = (d pm | d ps) rows; scatter into the two weight matrices
+    float* dWpm = p->grads + p->pmean.w;
+    float* dWps = p->grads + p->pscale.w;
+    TRY(hipMemcpy2DAsync(dWpm, L * sizeof(float), p->sum_scratch, 2 * L * sizeof(float),
+                         L * sizeof(float), K, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : -2);
+    TRY(hipMemcpy2DAsync(dWps, L * sizeof(float), p->sum_scratch + L, 2 * L * sizeof(float),
+                         L * sizeof(float), K, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : -2);
+    TRY(col_sum(s, dWpm, L, K, L, p->grads + p->pmean.b, 1.f, 0, nullptr));
+    TRY(col_sum(s, dWps, L, K, L, p->grads + p->pscale.b, 1.f, 0, nullptr));
+  }
+  float* dh = p->dbuf[0];
+  float* dh_alt = p->dbuf[1];
+  for (int q = 0; q < 2; ++q) {
+    Dense& hd = q == 0 ? p->qmean : p->qscale;
+    const float* dpre = q == 0 ? p->dqm : p->dqs;
+    GEMM(true, false, hz, dpre, nullptr, p->grads + hd.w, hd.n_in, L, KB, ldz, L, L, ACT_NONE,
+         false);
+    TRY(col_sum(s, dpre, L, KB, L, p->grads + hd.b, 1.f, 0, p->partial));
+    GEMM(false, true, dpre, p->params + hd.w, nullptr, dh, KB, hd.n_in, L, L, L, hd.n_in, ACT_NONE,
+         q > 0);
+  }
+  for (int i = (int)p->zenc.size() - 1; i >= 0; --i) {
+    Dense& d = p->zenc[i];
+    if (i > 0) {
+      TRY(dense_backward(p, s, d, p->zenc[i - 1].h, d.n_in, KB, K, true, dh, scratch, dh_alt,
+                         false, GB));
+      float* t = dh; dh = dh_alt; dh_alt = t;
+    } else {
+      const float* da = nullptr;
+      TRY(dense_backward_activation(p, s, d, KB, K, true, dh, scratch, GB, &da));
+      const int N = d.n_out;
+      float* dW = p->grads + d.w;
+      // one-hot rows: dW[F+k,:] = sum_b dA[k,b,:]
+      TRY(group_col_sum(s, da, N, B, K, N, 1.f, dW + (size_t)F * N, p->partial));
+      TRY(col_sum(s, da, N, KB, N, p->grads + d.b, 1.f, 0, p->partial));
+      // data rows: dW[:F] = x^T (sum_k dA[k])
+      TRY(sum_groups(s, da, nullptr, 0, K, B, N, p->sum_scratch));
+      GEMM(true, false, a->x, p->sum_scratch, nullptr, dW, F, N, B, F, N, N, ACT_NONE, false);
+    }
+  }
+
+  // ---------------- backward: q(y|x) ----------------
+  TRY(categorical_bwd_gated(s, p->yprob, p->dy, gate, w * inv_gb, p->dlogits, B, K));
+  {
+    Dense& hd = p->ylogits;
+    GEMM(true, false, hy, p->dlogits, nullptr, p->grads + hd.w, hd.n_in, K, B, ldy, K, K, ACT_NONE,
+         false);
+    TRY(col_sum(s, p->dlogits, K, B, K, p->grads + hd.b, 1.f, 0, p->partial));
+    dh = p->dbuf[0];
+    dh_alt = p->dbuf[1];
+    if (!p->yenc.empty())
+      GEMM(false, true, p->dlogits, p->params + hd.w, nullptr, dh, B, hd.n_in, K, K, K, hd.n_in,
+           ACT_NONE, false);
+  }
+  for (int i = (int)p->yenc.size() - 1; i >= 0; --i) {
+    Dense& d = p->yenc[i];
+    const float* in = i > 0 ? p->yenc[i - 1].h : a->x;
+    float* d_in = i > 0 ? dh_alt : nullptr;
+    TRY(dense_backward(p, s, d, in, d.n_in, B, 1, true, dh, scratch, d_in, false, GB));
+    if (i > 0) { float* t = dh; dh = dh_alt; dh_alt = t; }
+  }
+
+  // ---------------- batch-norm moving averages (K passes update in pass order) --------
+  for (auto& d : p->yenc) TRY(dense_update_moving(p, s, d, GB, 1));
+  for (auto& d : p->zenc) TRY(dense_update_moving(p, s, d, GB, K));
+  for (auto& d : p->xdec) TRY(dense_update_moving(p, s, d, GSB, K));
+#undef GEMM
+#undef TRY
+  return 0;
+}
+
+}  // namespace scvae

@@ -1,0 +1,233 @@
+"""Minimal ``DataSet`` container: the attributes and methods of
+``scvae/data/data_set.py:50`` that the model classes and the CLI consume
+(SURVEY.md section 8b).  Loading of external file formats, preprocessing and
+plotting metadata are outside the hot path and are not provided here; the
+built-in sources are synthetic count matrices (``scvae_amd/data/synthetic.py``).
+"""
+
+import numpy
+import scipy.sparse
+
+from scvae_amd.data.sparse import SparseRowMatrix
+from scvae_amd.defaults import defaults
+from scvae_amd.utilities import normalise_string
+
+
+class DataSet:
+    """Cell x gene count matrix with its metadata."""
+
+    def __init__(self, input_file_or_name, data_format=None, title=None,
+                 specifications=None, values=None, labels=None,
+                 example_names=None, feature_names=None, batch_indices=None,
+                 batch_names=None, feature_selection=None,
+                 example_filter=None, preprocessing_methods=None,
+                 preprocessed_values=None, binarised_values=None,
+                 noisy_preprocessing_methods=None,
+                 total_standard_deviations=None,
+                 explained_standard_deviations=None,
+                 features_mapped=False, kind="full", version="original",
+                 directory=None, **kwargs):
+        self.name = normalise_string(str(input_file_or_name))
+        self.title = title if title is not None else str(input_file_or_name)
+        self.data_format = data_format
+        self.specifications = specifications or {}
+        self.directory = directory or defaults["data"]["directory"]
+        self.features_mapped = features_mapped
+        self.feature_selection = feature_selection or []
+        self.example_filter = example_filter or []
+        self.preprocessing_methods = preprocessing_methods or []
+        self.noisy_preprocessing_methods = noisy_preprocessing_methods or []
+        self.noisy_preprocess = None
+        self.kind = kind
+        self.version = version
+        self.split_indices = None
+        self.label_superset = None
+        self.excluded_classes = []
+        self.class_names = None
+        self.class_name_to_class_id = None
+        self.class_id_to_class_name = None
+        self.number_of_classes = None
+        self.predicted_cluster_ids = None
+        self.predicted_labels = None
+        self.values = None
+        self.preprocessed_values = None
+        self.binarised_values = None
+        self.total_standard_deviations = None
+        self.explained_standard_deviations = None
+        self.count_sum = None
+        self.normalised_count_sum = None
+        self.labels = None
+        self.example_names = None
+        self.feature_names = None
+        self.batch_indices = None
+        self.batch_names = None
+        self.number_of_batches = None
+        self.number_of_examples = None
+        self.number_of_features = None
+        self._generator = kwargs.get("generator")
+        self.update(values=values, labels=labels, example_names=example_names,
+                    feature_names=feature_names, batch_indices=batch_indices,
+                    batch_names=batch_names,
+                    preprocessed_values=preprocessed_values,
+                    binarised_values=binarised_values,
+                    total_standard_deviations=total_standard_deviations,
+                    explained_standard_deviations=(
+                        explained_standard_deviations))
+
+    # -- properties used by the models / CLI --------------------------------
+    @property
+    def has_values(self):
+        return self.values is not None
+
+    @property
+    def has_preprocessed_values(self):
+        return self.preprocessed_values is not None
+
+    @property
+    def has_binarised_values(self):
+        return self.binarised_values is not None
+
+    @property
+    def has_labels(self):
+        return self.labels is not None
+
+    @property
+    def has_batches(self):
+        return self.batch_indices is not None
+
+    @property
+    def number_of_values(self):
+        return self.number_of_examples * self.number_of_features
+
+    # -- construction ---------------------------------------------------------
+    @staticmethod
+    def _as_matrix(values):
+        if values is None:
+            return None
+        if scipy.sparse.issparse(values):
+            return SparseRowMatrix(values.astype(numpy.float32))
+        values = numpy.asarray(values)
+        return values
+
+    def update(self, values=None, labels=None, example_names=None,
+               feature_names=None, batch_indices=None, batch_names=None,
+               preprocessed_values=None, binarised_values=None,
+               total_standard_deviations=None,
+               explained_standard_deviations=None):
+        if values is not None:
+            self.values = self._as_matrix(values)
+            self.number_of_examples, self.number_of_features = (
+                self.values.shape)
+            if scipy.sparse.issparse(self.values):
+                count_sum = numpy.asarray(
+                    self.values.sum(axis=1)).reshape(-1, 1)
+            else:
+                count_sum = self.values.sum(axis=1).reshape(-1, 1)
+            self.count_sum = count_sum.astype(numpy.float32)
+            maximum = self.count_sum.max() if self.count_sum.size else 1.0
+            self.normalised_count_sum = self.count_sum / max(maximum, 1e-30)
+        if labels is not None:
+            self.labels = numpy.asarray(labels)
+            self.class_names = numpy.unique(self.labels).tolist()
+            self.class_name_to_class_id = {
+                name: i for i, name in enumerate(self.class_names)}
+            self.class_id_to_class_name = {
+                i: name for name, i in self.class_name_to_class_id.items()}
+            self.number_of_classes = len(self.class_names)
+        if example_names is not None:
+            self.example_names = numpy.asarray(example_names)
+        if feature_names is not None:
+            self.feature_names = numpy.asarray(feature_names)
+        if batch_indices is not None:
+            self.batch_indices = numpy.asarray(batch_indices).reshape(-1, 1)
+            self.number_of_batches = int(self.batch_indices.max()) + 1
+        if batch_names is not None:
+            self.batch_names = batch_names
+        if preprocessed_values is not None:
+            self.preprocessed_values = self._as_matrix(preprocessed_values)
+        if binarised_values is not None:
+            self.binarised_values = self._as_matrix(binarised_values)
+        if total_standard_deviations is not None:
+            self.total_standard_deviations = total_standard_deviations
+        if explained_standard_deviations is not None:
+            self.explained_standard_deviations = (
+                explained_standard_deviations)
+
+    def load(self):
+        """Materialise a built-in synthetic data set (no files, no network)."""
+        if self.has_values:
+            return
+        if self._generator is None:
+            from scvae_amd.data.synthetic import SYNTHETIC_DATA_SETS
+            key = self.name
+            if key not in SYNTHETIC_DATA_SETS:
+                raise FileNotFoundError(
+                    "Data set `{}` is not a built-in synthetic data set ({}); "
+                    "file loaders are outside the scope of this build."
+                    .format(self.name, ", ".join(sorted(SYNTHETIC_DATA_SETS))))
+            self._generator = SYNTHETIC_DATA_SETS[key]
+        dictionary = self._generator()
+        self.update(values=dictionary["values"],
+                    labels=dictionary.get("labels"),
+                    example_names=dictionary.get("example names"),
+                    feature_names=dictionary.get("feature names"))
+
+    def _subset(self, indices, kind):
+        subset = DataSet(
+            self.name, title=self.title, specifications=self.specifications,
+            values=self.values[indices],
+            labels=self.labels[indices] if self.has_labels else None,
+            example_names=(self.example_names[indices]
+                           if self.example_names is not None else None),
+            feature_names=self.feature_names,
+            batch_indices=(self.batch_indices[indices]
+                           if self.has_batches else None),
+            batch_names=self.batch_names,
+            preprocessed_values=(self.preprocessed_values[indices]
+                                 if self.has_preprocessed_values else None),
+            feature_selection=self.feature_selection,
+            example_filter=self.example_filter,
+            preprocessing_methods=self.preprocessing_methods,
+            noisy_preprocessing_methods=self.noisy_preprocessing_methods,
+            kind=kind, version=self.version)
+        return subset
+
+    def split(self, method=None, fraction=None):
+        """Training/validation/test split (``scvae/data/processing.py:336-486``):
+        ``RandomState(42)`` permutation, ``int(f*n)`` training+validation of
+        which ``int(f*...)`` training (81/9/10 for f = 0.9)."""
+        if method is None:
+            method = defaults["data"]["splitting_method"]
+        if fraction is None:
+            fraction = defaults["data"]["splitting_fraction"]
+        if not self.has_values:
+            self.load()
+        method = normalise_string(method)
+        if method == "default":
+            method = "random"
+        n = self.number_of_examples
+        random_state = numpy.random.RandomState(42)
+        if method == "random":
+            indices = random_state.permutation(n)
+        elif method == "sequential":
+            indices = numpy.arange(n)
+        else:
+            raise ValueError(
+                "Splitting method `{}` not found.".format(method))
+        n_training_validation = int(fraction * n)
+        n_training = int(fraction * n_training_validation)
+        self.split_indices = {
+            "training": indices[:n_training],
+            "validation": indices[n_training:n_training_validation],
+            "test": indices[n_training_validation:],
+        }
+        return tuple(self._subset(self.split_indices[kind], kind)
+                     for kind in ("training", "validation", "test"))
+
+    def clear(self):
+        self.values = None
+        self.preprocessed_values = None
+        self.binarised_values = None
+        self.labels = None
+        self.count_sum = None
+        self.normalised_count_sum = None

@@ -1,0 +1,121 @@
+"""GPU parity: one GMVAE graph execution through the C ABI vs the fp64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as om
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol=1e-4, what=""):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), 1e-30)
+    err = np.abs(a - b).max() / scale
+    assert err <= rtol, "{}: max err {:.3e} of scale {:.3e}".format(
+        what, err, scale)
+
+
+def _setup(device, likelihood, F, L, H, B, K, bn, S=1, free_nats=0.0, seed=0):
+    from scvae_amd.engine import Engine
+    eng = Engine(F, L, H, likelihood, batch_norm=bn, model_type="GMVAE",
+                 n_clusters=K, free_nats_proportion=free_nats, device=device,
+                 seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    for name, p in eng.named_parameters().items():
+        if not name.endswith("weights"):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    cfg = om.ModelConfig(feature_size=F, latent_size=L, hidden_sizes=tuple(H),
+                         likelihood=likelihood, minibatch_normalisation=bn,
+                         n_clusters=K, n_iw=S, n_mc=1,
+                         free_nats_proportion=free_nats)
+    params = {k: v.detach().cpu().double()
+              for k, v in eng.named_parameters().items()}
+    assert list(params) == list(om.gmvae_parameter_shapes(cfg))
+    moving = {k: v.detach().cpu().double()
+              for k, v in eng.named_moving_statistics().items()}
+    rng = np.random.default_rng(seed)
+    lam = rng.gamma(0.5, 3.0, size=(1, F))
+    x = rng.poisson(lam, size=(B, F)).astype(np.float64)
+    x *= rng.random((B, F)) > 0.6
+    x = torch.from_numpy(x)
+    eps = torch.from_numpy(rng.standard_normal((K, S, B, L)))
+    return eng, cfg, params, moving, x, eps
+
+
+@pytest.mark.parametrize("likelihood,bn,S,free_nats", [
+    ("negative binomial", True, 1, 0.0),
+    ("zero-inflated negative binomial", True, 2, 0.0),
+    ("poisson", False, 1, 0.0),
+    ("negative binomial", True, 1, 0.8),   # free-nats threshold active
+    ("zero-inflated poisson", True, 1, 0.0),
+])
+def test_gmvae_train_step_matches_oracle(cuda_device, likelihood, bn, S,
+                                         free_nats):
+    F, L, H, B, K = 157, 6, (24, 16), 29, 4
+    eng, cfg, params, moving, x, eps = _setup(
+        cuda_device, likelihood, F, L, H, B, K, bn, S, free_nats)
+    xd = x.float().to(cuda_device)
+    epsd = eps.float().to(cuda_device)
+    ll = torch.zeros(K * S * B, device=cuda_device)
+    logits = torch.zeros(B, K, device=cuda_device)
+    zmean = torch.zeros(B, L, device=cuda_device)
+    cstats = torch.zeros(4, K, L, device=cuda_device)
+    sc = eng.step(xd, xd, eps=epsd, training=True, n_iw=S, n_mc=1,
+                  warm_up_weight=0.6,
+                  outputs={"log_p_x_given_z": ll, "q_y_logits": logits,
+                           "q_z_mean": zmean, "cluster_stats": cstats}
+                  ).cpu().numpy()
+    eng.adam_step(1e-3)
+    torch.cuda.synchronize()
+
+    state = om.adam_state(params)
+    new_params, new_moving, out, grads = om.gmvae_train_step(
+        cfg, dict(params), moving, state, x, x, eps, 1e-3, warm_up_weight=0.6)
+    _close(sc[0], out["lower_bound"], what="lower_bound")
+    _close(sc[1], out["lower_bound_weighted"], what="lower_bound_weighted")
+    _close(sc[2], out["reconstruction_error"], what="reconstruction_error")
+    _close(sc[3], out["kl_divergence_z"], what="kl_divergence_z")
+    _close(sc[4], out["kl_divergence_y"], rtol=2e-4, what="kl_divergence_y")
+    _close(ll.cpu(), out["log_p_x_given_z"].reshape(-1), what="per-cell ll")
+    _close(logits.cpu(), out["q_y_logits"], what="q_y_logits")
+    _close(zmean.cpu(), out["z_mean"], what="z_mean")
+    _close(cstats[0].cpu(), out["p_z_means"], what="p_z_means")
+    _close(cstats[1].cpu(), out["p_z_variances"], what="p_z_variances")
+    _close(cstats[2].cpu(), out["q_z_means"], what="q_z_means")
+    _close(cstats[3].cpu(), out["q_z_variances"], what="q_z_variances")
+    for name, g in eng.named_gradients().items():
+        if bn and name.endswith("DENSE/biases") and "LAYER_" in name:
+            assert g.abs().max().item() < 1e-5, name
+            continue
+        _close(g.cpu(), grads[name], rtol=3e-4, what="grad " + name)
+    for name, p in eng.named_parameters().items():
+        if bn and name.endswith("DENSE/biases") and "LAYER_" in name:
+            continue
+        got, want = p.cpu(), new_params[name]
+        if bn and name == "Z/Q/ENCODER/LAYER_1/DENSE/weights":
+            # the one-hot rows W[F+k] are cancelled by the per-pass batch norm:
+            # zero gradient, Adam only amplifies rounding noise there
+            assert eng.gradient(name)[F:].abs().max().item() < 1e-5
+            got, want = got[:F], want[:F]
+        _close(got, want, rtol=3e-4, what="param " + name)
+    for name, m in eng.named_moving_statistics().items():
+        _close(m.cpu(), new_moving[name], rtol=2e-5, what="moving " + name)
+
+
+def test_gmvae_evaluation_statistics(cuda_device):
+    F, L, H, B, K, S = 120, 5, (16, 16), 17, 3, 2
+    eng, cfg, params, moving, x, eps = _setup(
+        cuda_device, "negative binomial", F, L, H, B, K, True, S)
+    xd = x.float().to(cuda_device)
+    epsd = eps.float().to(cuda_device)
+    outs = {k: torch.zeros(B, F, device=cuda_device) for k in (
+        "p_x_mean", "p_x_stddev", "stddev_of_p_x_given_z_mean")}
+    sc = eng.step(xd, xd, eps=epsd, training=False, n_iw=S, n_mc=1,
+                  outputs=outs).cpu().numpy()
+    out = om.gmvae_forward(cfg, params, moving, x, x, eps, False,
+                           evaluation_statistics=True)
+    _close(sc[0], out["lower_bound"], what="lower_bound")
+    for k in outs:
+        _close(outs[k].cpu(), out[k], rtol=2e-4, what=k)
