@@ -1,0 +1,214 @@
+"""GPU integration tests of the model classes (train / evaluate / resume) and
+loop-level parity with the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as om
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(n=96, F=60, seed=3, labels=True):
+    from scvae_amd.data import DataSet
+    rng = np.random.default_rng(seed)
+    centres = rng.gamma(1.0, 2.0, size=(3, F))
+    lab = rng.integers(0, 3, size=n)
+    x = rng.poisson(centres[lab]).astype(np.float32)
+    x *= rng.random((n, F)) > 0.5
+    return DataSet("toy", values=x,
+                   labels=np.array(["c%d" % k for k in lab]) if labels
+                   else None,
+                   example_names=np.arange(n).astype(str),
+                   feature_names=np.arange(F).astype(str), kind="training")
+
+
+def test_vae_train_evaluate_resume(tmp_path, cuda_device, capsys):
+    from scvae_amd.models import VariationalAutoencoder
+    from scvae_amd.models.utilities import load_learning_curves
+    full = _data(200, 40)
+    training_set, validation_set, test_set = full.split()
+    model = VariationalAutoencoder(
+        feature_size=40, latent_size=4, hidden_sizes=[16],
+        reconstruction_distribution="negative binomial",
+        log_directory=str(tmp_path))
+    assert not model.has_been_trained()
+    assert model.train(training_set, validation_set, number_of_epochs=3,
+                       minibatch_size=32, learning_rate=1e-2) == 0
+    out = capsys.readouterr().out
+    assert "Epoch 3" in out and "ELBO:" in out and "ENRE:" in out
+    assert model.has_been_trained()
+    curves = load_learning_curves(model)
+    assert len(curves["training"]["lower_bound"]) == 3
+    assert len(curves["validation"]["lower_bound"]) == 3
+    assert np.all(np.isfinite(curves["training"]["lower_bound"]))
+    assert (curves["training"]["lower_bound"][-1]
+            > curves["training"]["lower_bound"][0])
+    # resume: two more epochs from the checkpoint
+    model2 = VariationalAutoencoder(
+        feature_size=40, latent_size=4, hidden_sizes=[16],
+        reconstruction_distribution="negative binomial",
+        log_directory=str(tmp_path))
+    model2.train(training_set, validation_set, number_of_epochs=5,
+                 minibatch_size=32, learning_rate=1e-2)
+    out = capsys.readouterr().out
+    assert "Continue training" in out and "Epoch 5" in out
+    assert len(load_learning_curves(model2)["training"]["lower_bound"]) == 5
+    # already trained
+    model2.train(training_set, validation_set, number_of_epochs=5)
+    assert "already been trained" in capsys.readouterr().out
+
+    transformed, reconstructed, latent = model2.evaluate(
+        test_set, minibatch_size=16,
+        evaluation_subset_indices={0, 3, 7})
+    assert transformed is test_set
+    assert reconstructed.values.shape == (test_set.number_of_examples, 40)
+    assert np.all(reconstructed.values >= 0)
+    assert reconstructed.total_standard_deviations[3].nnz > 0
+    assert reconstructed.total_standard_deviations[1].nnz == 0
+    assert latent["z"].values.shape == (test_set.number_of_examples, 4)
+    assert os.path.exists(os.path.join(model2.log_directory(), "evaluation",
+                                       "scalars.jsonl"))
+    z_only = model2.evaluate(test_set, output_versions="latent",
+                             use_deterministic_z=True, log_results=False)
+    assert set(z_only) == {"z"}
+
+    untrained = VariationalAutoencoder(
+        feature_size=40, latent_size=5, hidden_sizes=[16],
+        log_directory=str(tmp_path))
+    with pytest.raises(Exception, match="not been trained"):
+        untrained.evaluate(test_set)
+
+
+def test_gmvae_train_evaluate(tmp_path, cuda_device, capsys):
+    from scvae_amd.models import GaussianMixtureVariationalAutoencoder
+    data = _data(150, 30)
+    model = GaussianMixtureVariationalAutoencoder(
+        feature_size=30, latent_size=3, hidden_sizes=[12, 12],
+        reconstruction_distribution="zero-inflated negative binomial",
+        number_of_latent_clusters=3, number_of_warm_up_epochs=2,
+        log_directory=str(tmp_path))
+    model.train(data, None, number_of_epochs=2, minibatch_size=50,
+                learning_rate=1e-2)
+    out = capsys.readouterr().out
+    assert "KL_z:" in out and "KL_y:" in out and "Accuracy:" in out
+    assert "Warm-up weight: 0.5" in out
+    transformed, reconstructed, latent = model.evaluate(data)
+    assert latent["y"].values.shape == (150, 3)
+    assert np.allclose(latent["y"].values.sum(axis=1), 1, atol=1e-5)
+    assert latent["z"].values.shape == (150, 3)
+    assert reconstructed.values.shape == (150, 30)
+
+
+def _philox(device, rows, cols, row_offset, seed, stream_id):
+    from scvae_amd.minibatch import philox_normal
+    out = torch.empty(rows, cols, device=device)
+    philox_normal(out, row_offset, seed, stream_id)
+    return out.cpu().double()
+
+
+def test_training_loop_matches_oracle(tmp_path, cuda_device):
+    """One epoch of ``model.train`` (2 steps + epoch-end evaluation) against
+    the oracle driven with the same permutation and the same Philox noise."""
+    from scvae_amd.models import VariationalAutoencoder
+    from scvae_amd.models.utilities import load_learning_curves
+    n, F, L, B = 50, 30, 3, 32
+    data = _data(n, F, labels=False)
+    model = VariationalAutoencoder(
+        feature_size=F, latent_size=L, hidden_sizes=[10],
+        reconstruction_distribution="negative binomial",
+        log_directory=str(tmp_path), device=cuda_device)
+    params = {k: v.detach().cpu().double()
+              for k, v in model.engine.named_parameters().items()}
+    moving = {k: v.detach().cpu().double()
+              for k, v in model.engine.named_moving_statistics().items()}
+    np.random.seed(11)
+    model.train(data, None, number_of_epochs=1, minibatch_size=B,
+                learning_rate=1e-3)
+
+    cfg = om.ModelConfig(feature_size=F, latent_size=L, hidden_sizes=(10,),
+                         likelihood="negative binomial")
+    x = torch.from_numpy(np.asarray(data.values, dtype=np.float64))
+    np.random.seed(11)
+    perm = np.random.permutation(n)
+    state = om.adam_state(params)
+    step = 0
+    for i in range(0, n, B):
+        idx = perm[i:i + B]
+        eps = _philox(cuda_device, len(idx), L, 0, 1, step).unsqueeze(0)
+        params, moving, _, _ = om.vae_train_step(
+            cfg, params, moving, state, x[idx], x[idx], eps, 1e-3)
+        step += 1
+    for name, p in model.engine.named_parameters().items():
+        if name.endswith("DENSE/biases") and ("ENCODER" in name
+                                              or "DECODER" in name):
+            continue
+        err = (p.cpu().double() - params[name]).abs().max().item()
+        assert err <= 3e-4 * params[name].abs().max().item() + 1e-7, name
+    # epoch-end evaluation of the training set: sum(batch means) / (N / B),
+    # evaluated by the oracle at the engine's own (fp32) state: two Adam steps
+    # in, the moving statistics are far from the batch statistics and the
+    # evaluation-mode ELBO amplifies 1e-6 differences in them
+    params = {k: v.detach().cpu().double()
+              for k, v in model.engine.named_parameters().items()}
+    moving = {k: v.detach().cpu().double()
+              for k, v in model.engine.named_moving_statistics().items()}
+    total = 0.0
+    for j, i in enumerate(range(0, n, B)):
+        rows = slice(i, min(i + B, n))
+        cells = rows.stop - rows.start
+        eps = _philox(cuda_device, cells, L, 0, 1,
+                      (1 << 40) + 1 * (1 << 20) + j).unsqueeze(0)
+        out = om.vae_forward(cfg, params, moving, x[rows], x[rows], eps,
+                             False)
+        total += float(out["lower_bound"])
+    expected = total / (n / B)
+    got = load_learning_curves(model)["training"]["lower_bound"][0]
+    assert abs(got - expected) <= 1e-4 * abs(expected)
+
+
+def test_cli_train_and_evaluate(tmp_path, cuda_device, capsys):
+    from scvae_amd import cli
+    arguments = ["synthetic_1k", "-M", str(tmp_path), "-r",
+                 "negative_binomial", "-l", "3", "-H", "20", "-B", "100",
+                 "--split-data-set"]
+    cli.main(["train"] + arguments + ["-e", "1"])
+    out = capsys.readouterr().out
+    assert "Training model for 1 epochs" in out
+    expected = os.path.join(
+        str(tmp_path), "synthetic_1k", "split-random_0.9", "no_preprocessing",
+        "VAE", "gaussian", "negative_binomial-l_3-h_20-mc_1-iw_1-kl-bn")
+    assert os.path.exists(os.path.join(expected, "checkpoint"))
+    results = cli.main(["evaluate"] + arguments)
+    assert "end_of_training" in results
+    transformed, reconstructed, latent = results["end_of_training"]
+    assert latent["z"].values.shape == (100, 3)
+
+
+def test_distribution_registry_objects(cuda_device):
+    import scipy.stats as st
+    from scvae_amd.distributions import DISTRIBUTIONS
+    rng = np.random.default_rng(0)
+    p = rng.uniform(0.05, 0.95, size=(7, 11))
+    log_r = rng.normal(0, 1, size=(7, 11))
+    pi = rng.uniform(0.05, 0.95, size=(7, 11))
+    t = rng.poisson(2.0, size=(7, 11)).astype(np.float64)
+    theta = {"p": torch.tensor(p, device=cuda_device),
+             "log_r": torch.tensor(log_r, device=cuda_device),
+             "pi": torch.tensor(pi, device=cuda_device)}
+    nb = DISTRIBUTIONS["negative binomial"]["class"](theta)
+    want = st.nbinom.logpmf(t, np.exp(log_r), 1 - p)
+    got = nb.log_prob(torch.tensor(t, device=cuda_device)).cpu().numpy()
+    assert np.allclose(got, want, rtol=2e-4, atol=2e-5)
+    assert np.allclose(nb.mean().cpu().numpy(),
+                       st.nbinom.mean(np.exp(log_r), 1 - p), rtol=1e-4)
+    assert np.allclose(nb.variance().cpu().numpy(),
+                       st.nbinom.var(np.exp(log_r), 1 - p), rtol=1e-4)
+    zinb = DISTRIBUTIONS["zero-inflated negative binomial"]["class"](theta)
+    base = st.nbinom.pmf(t, np.exp(log_r), 1 - p)
+    want = np.where(t > 0, np.log(1 - pi) + np.log(base),
+                    np.log(pi + (1 - pi) * base))
+    got = zinb.log_prob(torch.tensor(t, device=cuda_device)).cpu().numpy()
+    assert np.allclose(got, want, rtol=2e-4, atol=2e-5)
