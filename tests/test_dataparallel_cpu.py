@@ -1,0 +1,117 @@
+"""Data-parallel host logic on CPU with the ``gloo`` backend (world size 2):
+row sharding, batch-norm statistic merging, the backward sum exchange and the
+gradient all-reduce give the single-process result.  The compute stand-in is
+plain fp64 torch (the product's kernels need a GPU)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from scvae_amd.dataparallel import (
+    merge_batch_norm_statistics, shard_bounds)
+
+EPS = 1e-3
+
+
+def test_shard_bounds():
+    assert shard_bounds(100, 4, 0) == (0, 25)
+    assert shard_bounds(100, 4, 3) == (75, 100)
+    with pytest.raises(ValueError):
+        shard_bounds(10, 4, 0)
+
+
+def test_merge_batch_norm_statistics_unequal_shards():
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(37, 6, generator=g, dtype=torch.float64) * 3 + 1
+    parts = [a[:5], a[5:20], a[20:]]
+    gathered = torch.stack([
+        torch.stack([p.mean(0), p.var(0, unbiased=False)]) for p in parts])
+    counts = torch.tensor([len(p) for p in parts])
+    mean, var = merge_batch_norm_statistics(gathered, counts)
+    assert torch.allclose(mean, a.mean(0))
+    assert torch.allclose(var, a.var(0, unbiased=False))
+
+
+def _single_process(x, W, b, beta, v):
+    """loss = mean_rows sum_cols relu(BN(x W + b)) * v ; returns grads."""
+    W = W.clone().requires_grad_(True)
+    b = b.clone().requires_grad_(True)
+    beta = beta.clone().requires_grad_(True)
+    a = x @ W + b
+    mean = a.mean(0)
+    var = ((a - mean) ** 2).mean(0)
+    h = torch.relu((a - mean) * torch.rsqrt(var + EPS) + beta)
+    loss = (h * v).sum(dim=1).mean()
+    loss.backward()
+    return loss.detach(), W.grad, b.grad, beta.grad, mean.detach(), var.detach()
+
+
+def _worker(rank, world, port, x, W, b, beta, v, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_bounds(x.shape[0], world, rank)
+        xs = x[lo:hi]
+        n_global = x.shape[0]
+        # forward: local statistics -> all-gather -> merge (sync batch norm)
+        a = xs @ W + b
+        local = torch.stack([a.mean(0), a.var(0, unbiased=False)])
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        counts = torch.full((world,), hi - lo)
+        mean, var = merge_batch_norm_statistics(torch.stack(gathered), counts)
+        istd = torch.rsqrt(var + EPS)
+        xhat = (a - mean) * istd
+        h = torch.relu(xhat + beta)
+        # each rank's share of the global mean (scaled by 1/global rows)
+        loss = (h * v).sum(dim=1).sum() / n_global
+        # backward
+        dh = v.expand_as(h) / n_global
+        dA = dh * (h > 0)
+        dbeta = dA.sum(0)
+        sums = torch.stack([dA.sum(0), (dA * xhat).sum(0)])
+        dist.all_reduce(sums)                       # global s1, s2
+        da = istd * (dA - sums[0] / n_global - xhat * sums[1] / n_global)
+        grads = torch.cat([(xs.T @ da).reshape(-1), da.sum(0), dbeta,
+                           loss.reshape(1)])
+        dist.all_reduce(grads)                      # gradient all-reduce
+        if rank == 0:
+            out.put((grads.clone(), mean.clone(), var.clone()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_step_equals_single_process():
+    g = torch.Generator().manual_seed(1)
+    n, F, H = 24, 7, 5
+    x = torch.poisson(torch.rand(n, F, generator=g, dtype=torch.float64) * 4)
+    W = torch.randn(F, H, generator=g, dtype=torch.float64) * 0.3
+    b = torch.randn(H, generator=g, dtype=torch.float64) * 0.1
+    beta = torch.randn(H, generator=g, dtype=torch.float64) * 0.1
+    v = torch.randn(1, H, generator=g, dtype=torch.float64)
+    loss, gW, gb, gbeta, mean, var = _single_process(x, W, b, beta, v)
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker,
+                         args=(r, 2, port, x, W, b, beta, v, out))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    grads, dmean, dvar = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = torch.cat([gW.reshape(-1), gb, gbeta, loss.reshape(1)])
+    assert torch.allclose(grads, want, rtol=1e-10, atol=1e-12)
+    assert torch.allclose(dmean, mean) and torch.allclose(dvar, var)

@@ -1,0 +1,214 @@
+"""CPU tests of the host-side mirror of the reference interface: names,
+directories, defaults, argument parsing, the scalar store, checkpoints, data
+containers, CLI parser."""
+import os
+
+import numpy as np
+import pytest
+
+from scvae_amd.defaults import defaults
+from scvae_amd.utilities import format_duration, normalise_string
+
+
+def test_normalise_string():
+    assert normalise_string("Negative Binomial") == "negative_binomial"
+    assert normalise_string("zero-inflated negative binomial") == \
+        "zero_inflated_negative_binomial"
+    assert normalise_string("a/b (c), d") == "a_b_c_d"
+    assert normalise_string("GMVAE") == "gmvae"
+
+
+def test_format_duration():
+    assert format_duration(0.0001) == "<1 ms"
+    assert format_duration(0.5) == "500 ms"
+    assert format_duration(12.345) == "12.3 s"
+    assert format_duration(125) == "2m 5s"
+    assert format_duration(3725) == "1h 2m 5s"
+
+
+def test_defaults_are_the_reference_values():
+    m = defaults["models"]
+    assert m["latent_size"] == 2 and m["hidden_sizes"] == [100]
+    assert m["reconstruction_distribution"] == "poisson"
+    assert m["minibatch_normalisation"] is True
+    assert m["minibatch_size"] == 100 and m["learning_rate"] == 1e-4
+    assert m["number_of_epochs"] == 200
+    assert defaults["data"]["splitting_fraction"] == 0.9
+
+
+def test_model_names_and_descriptions():
+    from scvae_amd.models import (
+        GaussianMixtureVariationalAutoencoder, VariationalAutoencoder)
+    vae = VariationalAutoencoder(
+        32738, latent_size=25, hidden_sizes=[100, 100],
+        reconstruction_distribution="negative_binomial")
+    assert vae.type == "VAE"
+    assert vae.name == os.path.join(
+        "VAE", "gaussian", "negative_binomial-l_25-h_100_100-mc_1-iw_1-kl-bn")
+    assert "latent size: 25" in vae.description
+    assert "X_TILDE/LOG_R/DENSE/weights" in vae.parameters
+    gm = GaussianMixtureVariationalAutoencoder(
+        32738, latent_size=100, hidden_sizes=[100, 100],
+        reconstruction_distribution="negative binomial",
+        number_of_latent_clusters=20, number_of_warm_up_epochs=200)
+    assert gm.name == os.path.join(
+        "GMVAE", "gaussian_mixture-c_20",
+        "negative_binomial-l_100-h_100_100-mc_1-iw_1-bn-wu_200")
+    assert gm.number_of_latent_clusters == 20
+    plain = VariationalAutoencoder(
+        100, minibatch_normalisation=False, kl_weight=0.5,
+        number_of_importance_samples=[5, 10])
+    assert plain.name.endswith("poisson-l_2-h_100-mc_1-iw_5-kl-klw_0.5")
+    assert plain.number_of_importance_samples == {
+        "training": 5, "evaluation": 10}
+    assert vae.log_directory(base="m", run_id="a1", best_model=True) == \
+        os.path.join("m", vae.name, "run_a1", "best")
+    with pytest.raises(ValueError):
+        vae.log_directory(early_stopping=True, best_model=True)
+    with pytest.raises(ValueError):
+        vae.log_directory(run_id="not valid!")
+
+
+def test_constructor_errors():
+    from scvae_amd.models import (
+        GaussianMixtureVariationalAutoencoder, VariationalAutoencoder)
+    with pytest.raises(ValueError, match="not supported"):
+        VariationalAutoencoder(10, reconstruction_distribution="lomax")
+    with pytest.raises(TypeError, match="number of batches"):
+        VariationalAutoencoder(10, batch_correction=True)
+    with pytest.raises(ValueError, match="piecewise categorical"):
+        VariationalAutoencoder(
+            10, reconstruction_distribution="zero-inflated poisson",
+            number_of_reconstruction_classes=3)
+    with pytest.raises(NotImplementedError):
+        VariationalAutoencoder(10, number_of_reconstruction_classes=3)
+    with pytest.raises(NotImplementedError):
+        GaussianMixtureVariationalAutoencoder(
+            10, prior_probabilities_method="learn")
+    with pytest.raises(TypeError):
+        GaussianMixtureVariationalAutoencoder(
+            10, prior_probabilities_method="custom")
+
+
+def test_parse_numbers_of_samples():
+    from scvae_amd.models.utilities import parse_numbers_of_samples
+    assert parse_numbers_of_samples(3) == {"training": 3, "evaluation": 3}
+    assert parse_numbers_of_samples([2, 7]) == {"training": 2,
+                                                "evaluation": 7}
+    assert parse_numbers_of_samples({"training": 1, "evaluation": 4}) == {
+        "training": 1, "evaluation": 4}
+    with pytest.raises(ValueError):
+        parse_numbers_of_samples([1, 2, 3])
+    with pytest.raises(TypeError):
+        parse_numbers_of_samples("3")
+
+
+def test_early_stopping_status():
+    from scvae_amd.models.utilities import early_stopping_status
+    assert early_stopping_status(None, 10) == (False, 0)
+    assert early_stopping_status([1, 2, 3, 2.5, 2.4], 10) == (False, 2)
+    assert early_stopping_status([1, 2, 1.5, 3], 10) == (False, 0)
+    stopped, n = early_stopping_status([5, 4, 3, 2], 3)
+    assert stopped and np.isnan(n)
+
+
+def test_scalar_store_and_checkpoints(tmp_path):
+    import torch
+    from scvae_amd.models import VariationalAutoencoder
+    from scvae_amd.models import utilities as mu
+    model = VariationalAutoencoder(10, log_directory=str(tmp_path))
+    log_directory = model.log_directory()
+    assert mu.get_checkpoint_state(log_directory) is None
+    assert not model.has_been_trained()
+    writer = mu.ScalarWriter(os.path.join(log_directory, "training"))
+    valid = mu.ScalarWriter(os.path.join(log_directory, "validation"))
+    for epoch, lb in enumerate([-10.0, -8.0, -9.0], start=1):
+        writer.add_summary({"losses/lower_bound": lb,
+                            "losses/reconstruction_error": lb + 1,
+                            "losses/kl_divergence": 1.0,
+                            "kl_divergence_neurons/0": 0.25,
+                            "kl_divergence_neurons/1": 0.75,
+                            "prior/cluster_0/probability": 1.0,
+                            "prior/cluster_0/mean/dimension_0": 0.0,
+                            "prior/cluster_0/mean/dimension_1": 0.0,
+                            "prior/cluster_0/variance/dimension_0": 1.0,
+                            "prior/cluster_0/variance/dimension_1": 1.0},
+                           global_step=epoch)
+        valid.add_summary({"losses/lower_bound": lb - 1}, global_step=epoch)
+    curves = mu.load_learning_curves(model)
+    assert np.allclose(curves["training"]["lower_bound"], [-10, -8, -9])
+    assert np.allclose(curves["validation"]["lower_bound"], [-11, -9, -10])
+    assert mu.load_number_of_epochs_trained(model) == 3
+    assert mu.load_kl_divergences(model).shape == (3, 2)
+    centroids = mu.load_centroids(model, data_set_kinds="training")
+    assert centroids["prior"]["means"].shape == (3, 1, 2)
+    state = {"params": torch.arange(4.0), "adam_t": 3}
+    path = mu.save_checkpoint(state, log_directory, 3)
+    assert mu.get_checkpoint_state(log_directory) == path
+    assert mu.checkpoint_epoch(path) == 3 and model.has_been_trained()
+    mu.save_checkpoint(state, log_directory, 4)   # max_to_keep=1
+    kept = [f for f in os.listdir(log_directory) if f.startswith("model.ckpt")]
+    assert kept == ["model.ckpt-4.pt"]
+    best = model.log_directory(best_model=True)
+    mu.copy_model_directory(mu.get_checkpoint_state(log_directory), best)
+    assert mu.checkpoint_epoch(mu.get_checkpoint_state(best)) == 4
+    assert os.path.exists(os.path.join(best, "training", "scalars.jsonl"))
+    assert torch.equal(mu.load_checkpoint(
+        mu.get_checkpoint_state(best))["params"], state["params"])
+    assert not mu.better_model_exists(model)
+
+
+def test_data_set_and_split():
+    from scvae_amd.data import DataSet, SparseRowMatrix
+    data_set = DataSet("synthetic_1k")
+    data_set.load()
+    assert data_set.number_of_examples == 1000
+    assert data_set.number_of_features == 100
+    assert isinstance(data_set.values, SparseRowMatrix)
+    assert data_set.has_labels and not data_set.has_preprocessed_values
+    training, validation, test = data_set.split()
+    assert (training.number_of_examples, validation.number_of_examples,
+            test.number_of_examples) == (810, 90, 100)
+    assert (training.kind, validation.kind, test.kind) == (
+        "training", "validation", "test")
+    permutation = np.random.RandomState(42).permutation(1000)
+    assert np.array_equal(data_set.split_indices["training"],
+                          permutation[:810])
+    assert np.array_equal(data_set.split_indices["test"], permutation[900:])
+    dense = data_set.values[permutation[:3]].toarray()
+    assert np.array_equal(training.values[:3].toarray(), dense)
+    assert np.allclose(data_set.count_sum[:, 0],
+                       np.asarray(data_set.values.sum(axis=1)).ravel())
+    with pytest.raises(FileNotFoundError):
+        DataSet("no_such_data_set").load()
+
+
+def test_directory_layout_and_cli_parser(tmp_path):
+    from scvae_amd import cli
+    from scvae_amd.data import DataSet
+    from scvae_amd.data.utilities import build_directory_path
+    d = DataSet("10x PBMC 68k")
+    assert build_directory_path("models", d) == os.path.join(
+        "models", "10x_pbmc_68k", "no_split", "no_preprocessing")
+    assert build_directory_path("models", d, "random", 0.9) == os.path.join(
+        "models", "10x_pbmc_68k", "split-random_0.9", "no_preprocessing")
+    with pytest.raises(SystemExit):
+        cli.main(["train"])          # data set argument is required
+    with pytest.raises(SystemExit):
+        cli.main(["analyse", "x"])   # not part of this build
+    with pytest.raises(ValueError, match="Model type not found"):
+        cli._setup_model(DataSet("synthetic_1k", values=np.ones((4, 3))),
+                         model_type="AE")
+
+
+def test_cluster_accuracy_helpers():
+    from scvae_amd.models.gaussian_mixture_variational_autoencoder import (
+        accuracy, map_cluster_ids_to_label_ids)
+    labels = np.array([0, 0, 1, 1, 2, 2, 2])
+    clusters = np.array([5, 5, 5, 3, 3, 3, 3])
+    predicted = map_cluster_ids_to_label_ids(labels, clusters)
+    assert np.array_equal(predicted, [0, 0, 0, 2, 2, 2, 2])
+    assert accuracy(labels, predicted) == pytest.approx(5 / 7)
+    predicted = map_cluster_ids_to_label_ids(labels, clusters, [2])
+    assert np.array_equal(predicted, [0, 0, 0, 1, 1, 1, 1])
+    assert accuracy(labels, predicted, [2]) == pytest.approx(3 / 4)

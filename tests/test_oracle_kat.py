@@ -1,0 +1,195 @@
+"""Pins the oracle (which cannot be checked against the reference itself:
+"parity unpinned") to independent closed-form implementations."""
+import math
+
+import numpy as np
+import pytest
+import scipy.special as sc
+import scipy.stats as st
+import torch
+
+from oracle import likelihoods as lk
+from oracle import models as om
+
+T = torch.tensor
+rng = np.random.default_rng(0)
+t_np = np.concatenate([np.zeros(5), rng.poisson(3.0, 40), [250., 4000.]])
+a1 = rng.normal(0, 2.5, t_np.size)
+a2 = rng.normal(0, 2.5, t_np.size)
+a3 = rng.normal(0, 2.5, t_np.size)
+
+
+def sigmoid(a):
+    return 1 / (1 + np.exp(-a))
+
+
+def test_poisson_matches_scipy():
+    got = lk.poisson_log_prob(T(t_np), T(a1)).numpy()
+    assert np.allclose(got, st.poisson.logpmf(t_np, np.exp(a1)), rtol=1e-12)
+
+
+def test_negative_binomial_matches_scipy_and_torch():
+    got = lk.negative_binomial_log_prob(T(t_np), T(a1), T(a2)).numpy()
+    want = st.nbinom.logpmf(t_np, np.exp(a2), 1 - sigmoid(a1))
+    assert np.allclose(got, want, rtol=1e-10, atol=1e-10)
+    dist = torch.distributions.NegativeBinomial(
+        total_count=torch.exp(T(a2)), probs=torch.sigmoid(T(a1)))
+    assert np.allclose(got, dist.log_prob(T(t_np)).numpy(), rtol=1e-10,
+                       atol=1e-10)
+    m, v = lk.mean_variance("negative binomial", (T(a1), T(a2)))
+    assert np.allclose(m.numpy(), st.nbinom.mean(np.exp(a2), 1 - sigmoid(a1)))
+    assert np.allclose(v.numpy(), st.nbinom.var(np.exp(a2), 1 - sigmoid(a1)))
+
+
+def test_tfp_logits_form_of_negative_binomial():
+    """TFP 0.7: logits = log p - log1p(-p);
+    r*log_sigmoid(-logits) + x*log_sigmoid(logits) - log-normalisation."""
+    p, r = sigmoid(a1), np.exp(a2)
+    logits = np.log(p) - np.log1p(-p)
+
+    def log_sigmoid(u):
+        return -np.logaddexp(0, -u)
+    want = (r * log_sigmoid(-logits) + t_np * log_sigmoid(logits)
+            + sc.gammaln(r + t_np) - sc.gammaln(1 + t_np) - sc.gammaln(r))
+    got = lk.negative_binomial_log_prob(T(t_np), T(a1), T(a2)).numpy()
+    assert np.allclose(got, want, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("name", ["zero-inflated poisson",
+                                  "zero-inflated negative binomial"])
+def test_zero_inflated_composition(name):
+    """zero_inflated.py:194-199: where(x > 0, log(1-pi) + logp,
+    log(pi + (1-pi) p))."""
+    pi = sigmoid(a3)
+    if name == "zero-inflated poisson":
+        base = st.poisson.pmf(t_np, np.exp(a1))
+        got = lk.zero_inflated_poisson_log_prob(T(t_np), T(a3), T(a1)).numpy()
+        mean, var = st.poisson.mean(np.exp(a1)), st.poisson.var(np.exp(a1))
+        pre = (T(a3), T(a1))
+    else:
+        base = st.nbinom.pmf(t_np, np.exp(a2), 1 - sigmoid(a1))
+        got = lk.zero_inflated_negative_binomial_log_prob(
+            T(t_np), T(a3), T(a1), T(a2)).numpy()
+        mean = st.nbinom.mean(np.exp(a2), 1 - sigmoid(a1))
+        var = st.nbinom.var(np.exp(a2), 1 - sigmoid(a1))
+        pre = (T(a3), T(a1), T(a2))
+    with np.errstate(divide="ignore"):
+        want = np.where(t_np > 0, np.log(1 - pi) + np.log(base),
+                        np.log(pi + (1 - pi) * base))
+    ok = np.isfinite(want)   # scipy's pmf underflows for the huge counts
+    assert np.allclose(got[ok], want[ok], rtol=1e-9, atol=1e-9)
+    m, v = lk.mean_variance(name, pre)
+    assert np.allclose(m.numpy(), (1 - pi) * mean)
+    assert np.allclose(v.numpy(),
+                       (1 - pi) * (var + mean ** 2) - ((1 - pi) * mean) ** 2)
+
+
+def test_support_clips():
+    # log_lambda / log_r clipped to [-10, 10], zero gradient outside
+    a = T([-12.0, 12.0, 3.0], requires_grad=True, dtype=torch.float64)
+    lp = lk.poisson_log_prob(T([2.0, 2.0, 2.0], dtype=torch.float64), a)
+    lp.sum().backward()
+    assert np.allclose(lp.detach().numpy()[:2],
+                       st.poisson.logpmf(2, np.exp([-10.0, 10.0])))
+    assert a.grad[0] == 0 and a.grad[1] == 0 and a.grad[2] != 0
+    # sigmoid output clipped from below at float32.tiny
+    f64 = torch.float64
+    lp = lk.negative_binomial_log_prob(
+        T([3.0], dtype=f64), T([-200.0], dtype=f64), T([0.0], dtype=f64))
+    assert np.isfinite(lp.item())
+    assert abs(lp.item() - 3 * lk.LOGIT_OF_TINY) < 1e-9
+
+
+def test_analytic_gaussian_kl_and_elbo_terms():
+    cfg = om.ModelConfig(feature_size=9, latent_size=4, hidden_sizes=(6,),
+                         likelihood="poisson", n_iw=3, n_mc=2)
+    shapes = om.vae_parameter_shapes(cfg)
+    params = om.init_parameters(shapes, seed=1)
+    moving = om.init_moving_statistics(shapes)
+    g = torch.Generator().manual_seed(0)
+    x = torch.poisson(torch.rand(7, 9, generator=g, dtype=torch.float64) * 3)
+    eps = torch.randn(6, 7, 4, generator=g, dtype=torch.float64)
+    out = om.vae_forward(cfg, params, moving, x, x, eps, True, 0.5)
+    mu, ls = out["q_z_mean"], out["q_z_log_sigma"]
+    q = torch.distributions.Normal(mu, torch.exp(ls))
+    p = torch.distributions.Normal(torch.zeros_like(mu), torch.ones_like(mu))
+    kl = torch.distributions.kl_divergence(q, p)
+    assert torch.allclose(out["kl_divergence_neurons"], kl.mean(dim=0))
+    assert torch.allclose(out["kl_divergence"], kl.mean(dim=0).sum())
+    log_p = out["log_p_x_given_z"]                      # [IW, MC, B]
+    lw = log_p - kl.sum(dim=-1)
+    want = (torch.logsumexp(lw, dim=0) - math.log(3)).mean()
+    assert torch.allclose(out["lower_bound"], want)
+    lw = log_p - 0.5 * kl.sum(dim=-1)
+    want = (torch.logsumexp(lw, dim=0) - math.log(3)).mean()
+    assert torch.allclose(out["lower_bound_weighted"], want)
+    assert torch.allclose(out["reconstruction_error"], log_p.mean())
+
+
+def test_batch_norm_semantics_match_torch():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(13, 5, generator=g, dtype=torch.float64)
+    params = {"S/DENSE/weights": torch.eye(5, dtype=torch.float64),
+              "S/DENSE/biases": torch.zeros(5, dtype=torch.float64),
+              "S/BATCH_NORM/beta": torch.randn(5, generator=g,
+                                               dtype=torch.float64)}
+    moving = {"S/BATCH_NORM/moving_mean": torch.zeros(5, dtype=torch.float64),
+              "S/BATCH_NORM/moving_variance": torch.ones(5,
+                                                         dtype=torch.float64)}
+    new = {}
+    y = om.dense_layer(x, params, "S", True, True, moving, new,
+                       activation=False)
+    rm = torch.zeros(5, dtype=torch.float64)
+    rv = torch.ones(5, dtype=torch.float64)
+    want = torch.nn.functional.batch_norm(
+        x, rm, rv, weight=None, bias=params["S/BATCH_NORM/beta"],
+        training=True, momentum=1 - om.BN_DECAY, eps=om.BN_EPSILON)
+    assert torch.allclose(y, want)
+    # torch also updates running_var with the unbiased variance
+    assert torch.allclose(new["S/BATCH_NORM/moving_mean"], rm)
+    assert torch.allclose(new["S/BATCH_NORM/moving_variance"], rv)
+
+
+def test_tf_adam_first_steps():
+    p = {"w": T([1.0, -2.0, 0.5])}
+    state = om.adam_state(p)
+    g = {"w": T([0.3, -5.0, 0.0])}      # -5 is clipped to -1
+    p = om.clip_and_adam(p, g, state, 0.1)
+    gc = np.array([0.3, -1.0, 0.0])
+    m, v = 0.1 * gc, 0.001 * gc ** 2
+    lr_t = 0.1 * math.sqrt(1 - 0.999) / (1 - 0.9)
+    want = np.array([1.0, -2.0, 0.5]) - lr_t * m / (np.sqrt(v) + 1e-8)
+    assert np.allclose(p["w"].numpy(), want)
+    p = om.clip_and_adam(p, g, state, 0.1)
+    m2, v2 = 0.9 * m + 0.1 * gc, 0.999 * v + 0.001 * gc ** 2
+    lr_t = 0.1 * math.sqrt(1 - 0.999 ** 2) / (1 - 0.9 ** 2)
+    want = want - lr_t * m2 / (np.sqrt(v2) + 1e-8)
+    assert np.allclose(p["w"].numpy(), want)
+
+
+def test_gmvae_loss_terms():
+    cfg = om.ModelConfig(feature_size=8, latent_size=3, hidden_sizes=(5,),
+                         likelihood="negative binomial", n_clusters=4,
+                         n_iw=2, free_nats_proportion=0.9)
+    shapes = om.gmvae_parameter_shapes(cfg)
+    params = om.init_parameters(shapes, seed=2)
+    moving = om.init_moving_statistics(shapes)
+    g = torch.Generator().manual_seed(0)
+    x = torch.poisson(torch.rand(6, 8, generator=g, dtype=torch.float64) * 3)
+    eps = torch.randn(4, 2, 6, 3, generator=g, dtype=torch.float64)
+    out = om.gmvae_forward(cfg, params, moving, x, x, eps, True, 0.7)
+    y = out["y"]
+    q = torch.distributions.Categorical(probs=y)
+    uniform = torch.distributions.Categorical(probs=torch.full((4,), 0.25))
+    kl_y = torch.distributions.kl_divergence(q, uniform).mean()
+    assert torch.allclose(out["kl_divergence_y"], kl_y)
+    rec = (out["log_p_x_given_z"].mean(dim=1) * y.T).sum(dim=0).mean()
+    assert torch.allclose(out["reconstruction_error"], rec)
+    assert torch.allclose(
+        out["lower_bound"],
+        rec - out["kl_divergence_z"] - out["kl_divergence_y"])
+    thr = 0.9 * math.log(4)
+    assert kl_y < thr   # free nats active in this draw
+    assert torch.allclose(
+        out["lower_bound_weighted"],
+        rec - 0.7 * (out["kl_divergence_z"] + thr))
