@@ -84,6 +84,10 @@ int64_t scvae_plan_workspace_bytes(const scvae_plan* plan, int64_t max_cells, in
 int scvae_plan_bind(scvae_plan* plan, float* params, float* grads, float* moving, void* workspace,
                     int64_t workspace_bytes, int64_t max_cells, int64_t max_samples);
 int scvae_plan_set_sync(scvae_plan* plan, scvae_sync_fn fn, void* user);
+/* 1 (default): the X_TILDE heads + likelihood + their backward run as one fused kernel;
+ * 0: separate GEMM and likelihood kernels (same results; kept for A/B tests and for the
+ * evaluate-time statistics, which need the materialised pre-activations) */
+int scvae_plan_set_fused(scvae_plan* plan, int32_t enabled);
 
 /* One graph execution = session.run(...) in the reference loops
  * (train step va:1026-1029 / gm:1094-1097; evaluation va:1124-1135, 1983-2014).

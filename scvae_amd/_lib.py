@@ -91,6 +91,7 @@ SIGNATURES = {
         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
         c_int64]),
     "scvae_plan_set_sync": (c_int32, [c_void_p, SYNC_FN, c_void_p]),
+    "scvae_plan_set_fused": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_step": (c_int32, [c_void_p, POINTER(StepArgs), c_void_p]),
     "scvae_adam_clip_step": (c_int32, [
         c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float,

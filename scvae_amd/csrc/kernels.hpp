@@ -75,6 +75,23 @@ int relu_bwd(hipStream_t stream, const float* dh, const float* h, float* da, siz
 int col_sum(hipStream_t stream, const float* a, int lda, int rows, int N, float* out, float scale,
             int accumulate, float* partial);
 
+// ---- decoder_fused.hip ----
+struct HeadParams {
+  const float* W[3];
+  const float* b[3];
+  float* dW[3];
+  float* db[3];
+};
+bool decoder_fused_supported(int H);
+size_t decoder_fused_workspace_floats(int rows, int H, int F, bool train);
+size_t decoder_fused_lds_bytes(int P, int H, bool train);
+int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
+                          int F, const float* t, int B, const float* row_const, float* ll,
+                          float* workspace);
+int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
+                        int F, const float* t, int B, const float* gw, const float* row_const,
+                        float* ll, float* dd, float* workspace);
+
 // ---- gmvae_kernels.hip ----
 int add_group_rows(hipStream_t s, const float* a0, const float* rows, float* out, int K, int B,
                    int N, int relu);

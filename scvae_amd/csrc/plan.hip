@@ -100,7 +100,11 @@ static size_t carve(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_
   size_t pmax = col_sum_partial_floats((int)(F > hmax ? F : hmax));
   { const size_t q = bn_partial_floats(1, (int)hmax); if (q > pmax) pmax = q; }
   float* partial = b.floats(pmax);
+  float* fused_ws = decoder_fused_supported(h1)
+                        ? b.floats(decoder_fused_workspace_floats((int)R, h1, (int)F, true))
+                        : nullptr;
   if (!dry) {
+    p->fused_ws = fused_ws;
     p->mu_pre = mu_pre; p->ls_pre = ls_pre; p->kl_elem = kl_elem; p->kl_cell = kl_cell;
     p->z = z; p->ll = ll; p->gw = gw;
     for (int j = 0; j < 3; ++j) p->pre[j] = pre[j];
@@ -246,6 +250,18 @@ int copy(hipStream_t s, const float* src, float* dst, size_t n) {
 
 namespace scvae {
 
+HeadParams head_params(scvae_plan* p) {
+  HeadParams hp;
+  for (int j = 0; j < 3; ++j) {
+    const bool on = j < p->P;
+    hp.W[j] = on ? p->params + p->heads[j].w : nullptr;
+    hp.b[j] = on ? p->params + p->heads[j].b : nullptr;
+    hp.dW[j] = (on && p->grads) ? p->grads + p->heads[j].w : nullptr;
+    hp.db[j] = (on && p->grads) ? p->grads + p->heads[j].b : nullptr;
+  }
+  return hp;
+}
+
 static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const scvae_model_config& c = p->cfg;
   const int B = (int)a->cells;
@@ -290,11 +306,19 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   HeadPtrs pre;
   for (int j = 0; j < 3; ++j) pre.p[j] = p->pre[j];
-  for (int j = 0; j < p->P; ++j) {
-    Dense& hd = p->heads[j];
-    if ((rc = gemm(s, false, false, dch, p->params + hd.w, p->params + hd.b, p->pre[j], R, F,
-                   hd.n_in, ld, F, F, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
-      return rc;
+  const int h1 = p->heads[0].n_in;
+  // the fused kernel never materialises the [rows, P*F] pre-activations; the evaluate-time
+  // statistics (p_x_mean, ...) need them, so that request takes the unfused path
+  const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
+                     !a->p_x_mean;
+  const HeadParams hp = head_params(p);
+  if (!fused) {
+    for (int j = 0; j < p->P; ++j) {
+      Dense& hd = p->heads[j];
+      if ((rc = gemm(s, false, false, dch, p->params + hd.w, p->params + hd.b, p->pre[j], R, F,
+                     hd.n_in, ld, F, F, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+        return rc;
+    }
   }
   if (a->p_x_mean) {
     if (!(a->p_x_stddev && a->stddev_of_p_x_given_z_mean)) {
@@ -310,8 +334,13 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   const float row_scale = 1.f / ((float)n_mc * (float)GB);
   if (!training) {
-    if ((rc = loglik_fwd(s, c.likelihood, a->t, F, pre, F, a->row_const, p->ll, R, B, F)))
+    if (fused) {
+      if ((rc = decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, a->t, B, a->row_const,
+                                      p->ll, p->fused_ws)))
+        return rc;
+    } else if ((rc = loglik_fwd(s, c.likelihood, a->t, F, pre, F, a->row_const, p->ll, R, B, F))) {
       return rc;
+    }
     if ((rc = vae_elbo(s, p->ll, p->kl_cell, n_iw, n_mc, B, w, row_scale, a->scalars, nullptr)))
       return rc;
     if (a->log_p_x_given_z)
@@ -320,30 +349,33 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
 
   // ---------------- backward ----------------
-  if (n_iw == 1) {
-    // d(-ELBO_w)/d log p = -1/(MC*B) for every row: one fused likelihood pass
-    if ((rc = fill(s, p->gw, -row_scale, (size_t)R))) return rc;
-    if ((rc = loglik_bwd(s, c.likelihood, a->t, F, pre, F, p->gw, a->row_const, p->ll, R, B, F)))
-      return rc;
-    if ((rc = vae_elbo(s, p->ll, p->kl_cell, n_iw, n_mc, B, w, row_scale, a->scalars, nullptr)))
-      return rc;
-  } else {
-    if ((rc = loglik_fwd(s, c.likelihood, a->t, F, pre, F, a->row_const, p->ll, R, B, F)))
-      return rc;
-    if ((rc = vae_elbo(s, p->ll, p->kl_cell, n_iw, n_mc, B, w, row_scale, a->scalars, p->gw)))
-      return rc;
-    if ((rc = loglik_bwd(s, c.likelihood, a->t, F, pre, F, p->gw, a->row_const, nullptr, R, B,
-                         F)))
-      return rc;
-  }
-  if (a->log_p_x_given_z)
-    if ((rc = copy(s, p->ll, a->log_p_x_given_z, (size_t)R))) return rc;
-
-  // heads: dW_j = d^T G_j, db_j = colsum(G_j), dd (+)= G_j W_j^T
   float* dcur = p->dbuf[0];
   float* dalt = p->dbuf[1];
-  {
-    const int h1 = p->heads[0].n_in;
+  if (n_iw == 1) {
+    // d(-ELBO_w)/d log p = -1/(MC*B) for every row: known before the likelihood pass
+    if ((rc = fill(s, p->gw, -row_scale, (size_t)R))) return rc;
+  } else {
+    // importance weights need all log-likelihoods first
+    if (fused) {
+      if ((rc = decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, a->t, B, a->row_const,
+                                      p->ll, p->fused_ws)))
+        return rc;
+    } else if ((rc = loglik_fwd(s, c.likelihood, a->t, F, pre, F, a->row_const, p->ll, R, B, F))) {
+      return rc;
+    }
+    if ((rc = vae_elbo(s, p->ll, p->kl_cell, n_iw, n_mc, B, w, row_scale, a->scalars, p->gw)))
+      return rc;
+  }
+  if (fused) {
+    // heads forward + likelihood + dW_j, db_j, dd in one kernel
+    if ((rc = decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, a->t, B, p->gw,
+                                  a->row_const, p->ll, dcur, p->fused_ws)))
+      return rc;
+  } else {
+    if ((rc = loglik_bwd(s, c.likelihood, a->t, F, pre, F, p->gw, a->row_const,
+                         n_iw == 1 ? p->ll : nullptr, R, B, F)))
+      return rc;
+    // heads: dW_j = d^T G_j, db_j = colsum(G_j), dd (+)= G_j W_j^T
     for (int j = 0; j < p->P; ++j) {
       Dense& hd = p->heads[j];
       if ((rc = gemm(s, true, false, dch, p->pre[j], nullptr, p->grads + hd.w, h1, F, R, ld, F, F,
@@ -355,6 +387,12 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
         return rc;
     }
   }
+  if (n_iw == 1)
+    if ((rc = vae_elbo(s, p->ll, p->kl_cell, n_iw, n_mc, B, w, row_scale, a->scalars, nullptr)))
+      return rc;
+  if (a->log_p_x_given_z)
+    if ((rc = copy(s, p->ll, a->log_p_x_given_z, (size_t)R))) return rc;
+
   const int64_t GR = GB * S;  // global decoder rows
   // decoder layers, last to first; the first decoder layer's input is z
   for (int i = (int)p->dec.size() - 1; i >= 0; --i) {
@@ -484,6 +522,12 @@ int scvae_plan_bind(scvae_plan* p, float* params, float* grads, float* moving, v
   p->max_cells = max_cells; p->max_samples = max_samples;
   if (gm) scvae::carve_gmvae(p, workspace, (size_t)workspace_bytes, max_cells, max_samples, false);
   else scvae::carve(p, workspace, (size_t)workspace_bytes, max_cells, max_samples, false);
+  return 0;
+}
+
+int scvae_plan_set_fused(scvae_plan* p, int32_t enabled) {
+  SCVAE_ARG(p);
+  p->use_fused = enabled ? 1 : 0;
   return 0;
 }
 

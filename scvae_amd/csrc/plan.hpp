@@ -127,6 +127,8 @@ struct scvae_plan {
   float* gemm_ws = nullptr;
   size_t gemm_ws_bytes = 0;
   float* partial = nullptr;  // row-chunk partial sums (batch norm, column sums)
+  float* fused_ws = nullptr;  // fused decoder: per-strip ll / dd partial slabs
+  int use_fused = 1;          // fused decoder head kernel (0 = unfused GEMM + likelihood path)
   scvae_sync_fn sync = nullptr;
   void* sync_user = nullptr;
   // GMVAE graph (gm:2788-3221)
@@ -151,6 +153,7 @@ int dense_backward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int 
                    int groups, bool relu, const float* dh, float* scratch, float* d_in,
                    bool accumulate_d_in, int64_t global_rows_per_group);
 int fill(hipStream_t s, float* dst, float v, size_t n);
+HeadParams head_params(scvae_plan* p);
 int copy(hipStream_t s, const float* src, float* dst, size_t n);
 int build_gmvae(scvae_plan* p);
 size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t samples, bool dry);

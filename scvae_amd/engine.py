@@ -229,6 +229,11 @@ class Engine:
         self.max_cells, self.max_samples = max_cells, max_samples
         self.scalars = torch.zeros(8, dtype=torch.float32, device=self.device)
 
+    def set_fused(self, enabled):
+        """Select the fused decoder-head kernel (default) or the unfused path."""
+        _lib.check(self.lib.scvae_plan_set_fused(
+            self.handle, 1 if enabled else 0), "scvae_plan_set_fused")
+
     def set_sync(self, callback):
         """Install the data-parallel collective hook (see scvae_sync_fn)."""
         if callback is None:
