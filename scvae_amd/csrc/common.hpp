@@ -78,27 +78,43 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 // ---- scalar math used by the likelihood kernels ----
-// log(sigmoid(a)) = -softplus(-a), stable for any a
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// log(1 + x), x > -1: log(u) * x / (u - 1) with u = fl(1 + x) removes the rounding of 1 + x
+__device__ __forceinline__ float fast_log1p(float x) {
+  const float u = 1.f + x;
+  const float d = u - 1.f;
+  return d == 0.f ? x : __logf(u) * (x * fast_rcp(d));
+}
+// log(sigmoid(a)), log(sigmoid(-a)) and sigmoid(a) from one exp and one log
+__device__ __forceinline__ void log_sigmoid_pair(float a, float& ls_pos, float& ls_neg,
+                                                 float& sig) {
+  const float e = __expf(-fabsf(a));
+  const float l = fast_log1p(e);
+  ls_pos = fminf(a, 0.f) - l;
+  ls_neg = fminf(-a, 0.f) - l;
+  const float s = fast_rcp(1.f + e);
+  sig = a >= 0.f ? s : e * s;
+}
 __device__ __forceinline__ float log_sigmoid(float a) {
-  return fminf(a, 0.f) - log1pf(__expf(-fabsf(a)));
+  return fminf(a, 0.f) - fast_log1p(__expf(-fabsf(a)));
 }
 __device__ __forceinline__ float softplusf(float a) {
-  return fmaxf(a, 0.f) + log1pf(__expf(-fabsf(a)));
+  return fmaxf(a, 0.f) + fast_log1p(__expf(-fabsf(a)));
 }
 __device__ __forceinline__ float sigmoidf(float a) {
   const float e = __expf(-fabsf(a));
-  const float s = 1.f / (1.f + e);
+  const float s = fast_rcp(1.f + e);
   return a >= 0.f ? s : e * s;
 }
 
-// Stirling tail s(y) = 1/(12y) - 1/(360y^3) + 1/(1260y^5), y >= 8
-__device__ __forceinline__ float stirling_tail(float y) {
-  const float iy = 1.f / y, iy2 = iy * iy;
+// Stirling tail s(y) = 1/(12y) - 1/(360y^3) + 1/(1260y^5), y >= 8 (iy = 1/y)
+__device__ __forceinline__ float stirling_tail_r(float iy) {
+  const float iy2 = iy * iy;
   return iy * (8.3333333333e-2f + iy2 * (-2.7777777778e-3f + iy2 * 7.9365079365e-4f));
 }
 // digamma tail u(y) = 1/(2y) + 1/(12y^2) - 1/(120y^4) + 1/(252y^6), psi(y) = log y - u(y)
-__device__ __forceinline__ float digamma_tail(float y) {
-  const float iy = 1.f / y, iy2 = iy * iy;
+__device__ __forceinline__ float digamma_tail_r(float iy) {
+  const float iy2 = iy * iy;
   return 0.5f * iy + iy2 * (8.3333333333e-2f + iy2 * (-8.3333333333e-3f + iy2 * 3.9682539683e-3f));
 }
 
@@ -111,9 +127,9 @@ template <bool WITH_D>
 __device__ __forceinline__ void lgamma_digamma_diff(float r, float t, float& A, float& D) {
   const float x = r + t;
   const float b = r + 8.f, a = x + 8.f;
-  const float q = t / b;
-  const float l1 = log1pf(q);
-  float A8 = t * __logf(a) + (b - 0.5f) * l1 - t + (stirling_tail(a) - stirling_tail(b));
+  const float ib = fast_rcp(b), ia = fast_rcp(a);
+  const float l1 = fast_log1p(t * ib);
+  const float A8 = t * __logf(a) + (b - 0.5f) * l1 - t + (stirling_tail_r(ia) - stirling_tail_r(ib));
   // products of the 8 shift factors, in two groups of 4 (no overflow for t < 1e7)
   float n1 = x, n2 = x + 4.f, d1 = r, d2 = r + 4.f;
   float n1p = 1.f, n2p = 1.f, d1p = 1.f, d2p = 1.f;  // derivatives of the products
@@ -127,13 +143,14 @@ __device__ __forceinline__ void lgamma_digamma_diff(float r, float t, float& A, 
     }
     n1 *= fx1; n2 *= fx2; d1 *= fr1; d2 *= fr2;
   }
+  const float in1 = fast_rcp(n1), in2 = fast_rcp(n2), id1 = fast_rcp(d1), id2 = fast_rcp(d2);
   // log(n1*n2/(d1*d2)) as log(n1/d1) + log(n2/d2): each ratio is >= 1 and finite
-  A = A8 - (__logf(n1 / d1) + __logf(n2 / d2));
+  A = A8 - (__logf(n1 * id1) + __logf(n2 * id2));
   if (WITH_D) {
-    const float D8 = l1 - (digamma_tail(a) - digamma_tail(b));
+    const float D8 = l1 - (digamma_tail_r(ia) - digamma_tail_r(ib));
     // sum_{i<8} 1/(r+i) - 1/(x+i)
-    const float sr = d1p / d1 + d2p / d2;
-    const float sx = n1p / n1 + n2p / n2;
+    const float sr = d1p * id1 + d2p * id2;
+    const float sx = n1p * in1 + n2p * in2;
     D = D8 + (sr - sx);
   } else {
     D = 0.f;

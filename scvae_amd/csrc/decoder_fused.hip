@@ -36,13 +36,16 @@ constexpr int DF_LD = DF_BN + 1; // LDS row stride of the [.., 64] tiles (odd: c
 __host__ __device__ inline int df_ldd(int H) { return H | 1; }   // H even -> H + 1
 __host__ __device__ inline int df_bm(int P) { return P >= 3 ? 32 : 64; }
 
+constexpr int DF_QUEUE = 1024;   // capacity of the per-tile queue of t > 0 elements
+
 size_t decoder_fused_lds_bytes(int P, int H, bool train) {
   const int BM = df_bm(P);
   size_t floats = (size_t)P * H * DF_LD          // Ws
                   + (size_t)BM * df_ldd(H) + 32  // dsh (+ slack for the padded h tile)
                   + (size_t)P * BM * DF_LD       // Gs: pre_j, then G_j in place
                   + (size_t)BM * DF_LD           // ts
-                  + BM + 3 * DF_BN;              // gws, bias
+                  + BM + 3 * DF_BN               // gws, bias
+                  + 3 * DF_QUEUE + 4;            // sparse-correction queue
   // over-reads of the padded h tiles (h up to 127) must stay inside the allocation
   const size_t need = (size_t)((P - 1) * H + 128) * DF_LD + 64;
   if (floats < need) floats = need;
@@ -53,15 +56,17 @@ size_t decoder_fused_lds_bytes(int P, int H, bool train) {
 // BM rows x 64 columns per step; see the file header for the phases.
 template <int KIND, bool TRAIN, int BM>
 __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
-    const float* __restrict__ d, int R, int H, HeadParams hp, int F, const float* __restrict__ t,
-    int B, const float* __restrict__ gw, int inline_lgamma, float* __restrict__ ll_part,
-    float* __restrict__ dd_part) {
-  constexpr int P = (KIND == LK_POISSON) ? 1 : (KIND == LK_ZINB ? 3 : 2);
+    const float* __restrict__ d, int R, int H, unsigned magic_h, HeadParams hp, int F,
+    const float* __restrict__ t, int B, const float* __restrict__ gw, int inline_lgamma,
+    float* __restrict__ ll_part, float* __restrict__ dd_part) {
+  using Traits = LikelihoodTraits<KIND>;
+  constexpr int P = Traits::P;
   constexpr int BN = DF_BN, LD = DF_LD, NT = DF_THREADS;
   constexpr int MT = BM / 32;                 // 32-row tiles per step
   constexpr int TPR = NT / BM;                // epilogue threads per row (8 or 16)
   constexpr int EPT = BN / TPR;               // epilogue elements per thread (8 or 4)
   constexpr int TLOADS = BM * BN / NT;        // t elements staged per thread
+  constexpr int DLOADS = (BM * 126 + NT - 1) / NT;   // upper bound of d elements per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int LDD = df_ldd(H);
   float* Ws = smem;                                   // [P][H][LD]
@@ -69,7 +74,11 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
   float* Gs = dsh + (size_t)BM * LDD + 32;            // [P][BM][LD]
   float* ts = Gs + (size_t)P * BM * LD;               // [BM][LD]
   float* gws = ts + (size_t)BM * LD;                  // [BM]
-  float* bs = gws + BM;                               // [P][BN]
+  float* bs = gws + BM;                               // [3][BN]
+  int* qidx = reinterpret_cast<int*>(bs + 3 * BN);    // [Q] element index row*64 + col
+  float* qr = reinterpret_cast<float*>(qidx + DF_QUEUE);   // [Q] total_count r
+  float* qs = qr + DF_QUEUE;                          // [Q] upstream * clip gate
+  int* qcount = reinterpret_cast<int*>(qs + DF_QUEUE);
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kh = lane >> 5, li = lane & 31;
@@ -77,9 +86,9 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
 
   // ---- strip weights and biases -> LDS (once) ----
   for (int i = tid; i < P * H * BN; i += NT) {
-    const int c = i % BN;
-    const int jh = i / BN;  // j*H + h
-    const int j = jh / H, h = jh % H;
+    const int c = i & (BN - 1);
+    const int jh = i >> 6;  // j*H + h
+    const int j = __umulhi((unsigned)jh, magic_h), h = jh - j * H;
     float v = 0.f;
     if (c0 + c < F) v = hp.W[j][(size_t)h * F + c0 + c];
     Ws[(size_t)jh * LD + c] = v;
@@ -88,6 +97,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
     const int j = tid / BN, c = tid % BN;
     bs[tid] = (c0 + c < F) ? hp.b[j][c0 + c] : 0.f;
   }
+  if (tid == 0) *qcount = 0;
 
   // dW tile of this wave: rows h0..h0+31 (incl. the ones-row h == H -> db), columns n0..n0+31
   const int g2_h0 = (w >> 1) * 32, g2_n0 = (w & 1) * 32;
@@ -99,25 +109,43 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
 
   // epilogue element ownership: row er, columns ec0 .. ec0+EPT-1
   const int er = tid / TPR, ec0 = (tid % TPR) * EPT;
+  const int n_d = BM * H;                     // d-tile elements (contiguous in HBM)
+
+  // register prefetch of the next tile (d: flat contiguous; t: one 256-byte row per wave)
+  float dv[DLOADS], tv[TLOADS];
+  auto prefetch = [&](int m0) {
+    const float* dbase = d + (size_t)m0 * H;
+    const int n_valid = min(R - m0, BM) * H;
+#pragma unroll
+    for (int i = 0; i < DLOADS; ++i) {
+      const int e = i * NT + tid;
+      dv[i] = (e < n_valid) ? dbase[e] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TLOADS; ++i) {
+      const int r = i * (NT / BN) + (tid >> 6), c = tid & 63;
+      const int grow = m0 + r;
+      tv[i] = (grow < R && c0 + c < F) ? t[(size_t)(grow % B) * F + c0 + c] : 0.f;
+    }
+  };
+  prefetch(0);
 
   for (int m0 = 0; m0 < R; m0 += BM) {
-    // ---- stage d tile (+ ones column) and upstream weights; prefetch the t tile ----
-    for (int i = tid; i < BM * H; i += NT) {
-      const int r = i / H, h = i % H;
-      float v = 0.f;
-      if (m0 + r < R) v = d[(size_t)(m0 + r) * H + h];
-      dsh[(size_t)r * LDD + h] = v;
+    // ---- registers -> LDS: d tile (+ ones column), t tile, upstream weights ----
+#pragma unroll
+    for (int i = 0; i < DLOADS; ++i) {
+      const int e = i * NT + tid;
+      if (e < n_d) {
+        const int r = __umulhi((unsigned)e, magic_h), h = e - r * H;
+        dsh[(size_t)r * LDD + h] = dv[i];
+      }
     }
+#pragma unroll
+    for (int i = 0; i < TLOADS; ++i)
+      ts[(size_t)(i * (NT / BN) + (tid >> 6)) * LD + (tid & 63)] = tv[i];
     if (tid < BM) {
       dsh[(size_t)tid * LDD + H] = (m0 + tid < R) ? 1.f : 0.f;
       if (TRAIN) gws[tid] = (m0 + tid < R) ? gw[m0 + tid] : 0.f;
-    }
-    float tv[TLOADS];
-#pragma unroll
-    for (int i = 0; i < TLOADS; ++i) {
-      const int r = i * (NT / BN) + (tid >> 6), c = tid & 63;   // one 256-byte row per wave
-      const int grow = m0 + r;
-      tv[i] = (grow < R && c0 + c < F) ? t[(size_t)(grow % B) * F + c0 + c] : 0.f;
     }
     __syncthreads();
 
@@ -137,39 +165,87 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) out[(size_t)((r & 3) + 8 * (r >> 2)) * LD] = acc[r] + bv;
     }
-#pragma unroll
-    for (int i = 0; i < TLOADS; ++i)
-      ts[(size_t)(i * (NT / BN) + (tid >> 6)) * LD + (tid & 63)] = tv[i];
     __syncthreads();
 
-    // ---- likelihood epilogue: EPT elements of one row per thread, G_j written in place ----
+    // next tile's HBM loads fly under the epilogue and GEMM2/GEMM3
+    if (m0 + BM < R) prefetch(m0 + BM);
+
+    // ---- likelihood epilogue, dense part: EPT elements of one row per thread; G_j in place.
+    //      Elements with t > 0 of the negative-binomial kinds are queued for the correction
+    //      lgamma(r+t)-lgamma(r) / digamma(r+t)-digamma(r) (5 % of a count matrix). ----
+    float lsum = 0.f;
+    const bool row_ok = m0 + er < R;
     {
-      const bool row_ok = m0 + er < R;
       const float up = TRAIN ? gws[er] : 0.f;
-      float lsum = 0.f;
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
         const int c = ec0 + e;
         const bool ok = row_ok && (c0 + c < F);
-        float a[P], g[P], lp;
+        float a[P], g[P], lp, r, rgate;
 #pragma unroll
         for (int j = 0; j < P; ++j) a[j] = Gs[((size_t)j * BM + er) * LD + c];
         const float tval = ts[(size_t)er * LD + c];
-        lik_elem<KIND, TRAIN>(tval, a, lp, g);
-        // the data-only term lgamma(1+t) normally comes from the per-cell row constant
-        if (inline_lgamma) lp -= lgamma1p(tval);
+        lik_dense<KIND, TRAIN>(tval, a, lp, g, r, rgate);
+        float corr = 0.f;   // value left in the t tile: summed into the row's log-likelihood
+        if (ok && tval > 0.f) {
+          bool queued = false;
+          if (Traits::HAS_R) {
+            const int slot = atomicAdd(qcount, 1);
+            if (slot < DF_QUEUE) {
+              qidx[slot] = er * BN + c;
+              qr[slot] = r;
+              qs[slot] = up * rgate;
+              queued = true;
+              corr = tval;   // the queue pass replaces it by the correction
+            }
+          }
+          if (!queued) {
+            if (Traits::HAS_R) {   // queue full (dense data): correct in place
+              float A, D;
+              lgamma_digamma_diff<TRAIN>(r, tval, A, D);
+              lp += A;
+              if (TRAIN) g[P - 1] += rgate * r * D;
+            }
+            if (inline_lgamma) lp -= lgamma1p(tval);
+          }
+        }
         lsum += ok ? lp : 0.f;
+        ts[(size_t)er * LD + c] = corr;
         if (TRAIN) {
 #pragma unroll
           for (int j = 0; j < P; ++j) Gs[((size_t)j * BM + er) * LD + c] = ok ? up * g[j] : 0.f;
         }
       }
+    }
+    __syncthreads();
+    if (Traits::HAS_R) {
+      const int n_q = min(*qcount, DF_QUEUE);
+      for (int s = tid; s < n_q; s += NT) {
+        const int idx = qidx[s];
+        const int row = idx >> 6, c = idx & 63;
+        const float tval = ts[(size_t)row * LD + c];
+        const float r = qr[s];
+        float A, D;
+        lgamma_digamma_diff<TRAIN>(r, tval, A, D);
+        if (inline_lgamma) A -= lgamma1p(tval);
+        ts[(size_t)row * LD + c] = A;
+        if (TRAIN) Gs[((size_t)(P - 1) * BM + row) * LD + c] += qs[s] * r * D;
+      }
+      __syncthreads();
+      if (tid == 0) *qcount = 0;
+    }
+    // ---- per-row partial log-likelihood of this strip (dense part + corrections) ----
+    {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) lsum += ts[(size_t)er * LD + ec0 + e];
 #pragma unroll
       for (int off = 1; off < TPR; off <<= 1) lsum += __shfl_xor(lsum, off, WAVE);
       if ((tid % TPR) == 0 && row_ok) ll_part[(size_t)blockIdx.x * R + m0 + er] = lsum;
     }
-    __syncthreads();
-    if (!TRAIN) continue;
+    if (!TRAIN) {
+      __syncthreads();
+      continue;
+    }
 
     // ---- GEMM2: dW_j[h, col] += sum_row d[row, h] G_j[row, col]   (M = h, N = col, K = row);
     //      row h == H of d^T is all ones, so that row of the result is db_j ----
@@ -287,13 +363,15 @@ static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int
   const int P = likelihood_heads(kind);
   const size_t lds = decoder_fused_lds_bytes(P, H, TRAIN);
   const int strips = (F + DF_BN - 1) / DF_BN;
+  // e / H == umulhi(e, magic_h) for every e < 2^16 used here (H <= 126)
+  const unsigned magic_h = (unsigned)(0x100000000ull / (unsigned)H) + 1u;
 #define SCVAE_DF(K_)                                                                              \
   do {                                                                                            \
     auto kfn = decoder_head_kernel<K_, TRAIN, (K_ == LK_ZINB ? 32 : 64)>;                         \
     SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
-    hipLaunchKernelGGL(kfn, dim3(strips), dim3(DF_THREADS), lds, s, d, rows, H, hp, F, t, B, gw,   \
-                       inline_lgamma, ll_part, dd_part);                                          \
+    hipLaunchKernelGGL(kfn, dim3(strips), dim3(DF_THREADS), lds, s, d, rows, H, magic_h, hp, F, t, \
+                       B, gw, inline_lgamma, ll_part, dd_part);                                   \
   } while (0)
   switch (kind) {
     case LK_POISSON: SCVAE_DF(LK_POISSON); break;

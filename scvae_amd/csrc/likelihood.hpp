@@ -17,40 +17,52 @@
 namespace scvae {
 
 #ifdef __HIPCC__
-// lp  : log p(t | theta) + lgamma(1+t)
-// g[] : d lp / d pre-activation of each head (only if GRAD)
+template <int KIND>
+struct LikelihoodTraits {
+  static constexpr int P = (KIND == LK_POISSON) ? 1 : (KIND == LK_ZINB ? 3 : 2);
+  // negative-binomial kinds carry the terms lgamma(r+t)-lgamma(r) / digamma(r+t)-digamma(r),
+  // which vanish at t == 0 (the "sparse correction")
+  static constexpr bool HAS_R = (KIND == LK_NB || KIND == LK_ZINB);
+};
+
+// Everything except the sparse correction:
+// lp  : log p(t | theta) + lgamma(1+t) - [lgamma(r+t) - lgamma(r)]
+// g[] : d lp / d pre-activation of each head (only if GRAD), without the digamma term
+// r, rgate: total_count and the clip gate of its head (negative-binomial kinds), so that the
+//           caller can add  lp += A(r,t),  g[P-1] += rgate * r * D(r,t)  where t > 0.
 template <int KIND, bool GRAD>
-__device__ __forceinline__ void lik_elem(float t, const float* a, float& lp, float* g) {
+__device__ __forceinline__ void lik_dense(float t, const float* a, float& lp, float* g, float& r,
+                                          float& rgate) {
   if constexpr (KIND == LK_POISSON) {
     const float ll = fminf(fmaxf(a[0], -10.f), 10.f);
     const float lam = __expf(ll);
     lp = t * ll - lam;
     if (GRAD) g[0] = (a[0] >= -10.f && a[0] <= 10.f) ? (t - lam) : 0.f;
+    r = 0.f; rgate = 0.f;
   } else if constexpr (KIND == LK_NB) {
     const float ap = fmaxf(a[0], LOGIT_OF_TINY);
-    const float logp = log_sigmoid(ap), log1mp = log_sigmoid(-ap);
+    float logp, log1mp, p;
+    log_sigmoid_pair(ap, logp, log1mp, p);
     const float lr = fminf(fmaxf(a[1], -10.f), 10.f);
-    const float r = __expf(lr);
-    float A, D;
-    lgamma_digamma_diff<GRAD>(r, t, A, D);
-    lp = r * log1mp + t * logp + A;
+    r = __expf(lr);
+    rgate = (a[1] >= -10.f && a[1] <= 10.f) ? 1.f : 0.f;
+    lp = r * log1mp + t * logp;
     if (GRAD) {
-      const float p = sigmoidf(ap);
       g[0] = (a[0] >= LOGIT_OF_TINY) ? (t * (1.f - p) - r * p) : 0.f;
-      g[1] = (a[1] >= -10.f && a[1] <= 10.f) ? r * (log1mp + D) : 0.f;
+      g[1] = rgate * r * log1mp;
     }
   } else {
     // zero-inflated: head 0 is pi, the rest belong to the base distribution
     float lpb;
     float gb[2];
     if constexpr (KIND == LK_ZIP) {
-      lik_elem<LK_POISSON, GRAD>(t, a + 1, lpb, gb);
+      lik_dense<LK_POISSON, GRAD>(t, a + 1, lpb, gb, r, rgate);
     } else {
-      lik_elem<LK_NB, GRAD>(t, a + 1, lpb, gb);
+      lik_dense<LK_NB, GRAD>(t, a + 1, lpb, gb, r, rgate);
     }
     const float api = fmaxf(a[0], LOGIT_OF_TINY);
-    const float logpi = log_sigmoid(api), log1mpi = log_sigmoid(-api);
-    const float pi = sigmoidf(api);
+    float logpi, log1mpi, pi;
+    log_sigmoid_pair(api, logpi, log1mpi, pi);
     const bool gate = a[0] >= LOGIT_OF_TINY;
     constexpr int NB_HEADS = (KIND == LK_ZIP) ? 1 : 2;
     if (t > 0.f) {
@@ -61,9 +73,10 @@ __device__ __forceinline__ void lik_elem(float t, const float* a, float& lp, flo
         for (int j = 0; j < NB_HEADS; ++j) g[1 + j] = gb[j];
       }
     } else {
+      // zero branch: at t == 0 the base log-probability has no sparse correction
       const float u1 = logpi, u2 = log1mpi + lpb;
       const float m = fmaxf(u1, u2);
-      const float y0 = m + log1pf(__expf(-fabsf(u1 - u2)));
+      const float y0 = m + fast_log1p(__expf(-fabsf(u1 - u2)));
       lp = y0;
       if (GRAD) {
         const float u = __expf(u1 - y0);   // pi / (pi + (1-pi) e^lpb)
@@ -72,6 +85,22 @@ __device__ __forceinline__ void lik_elem(float t, const float* a, float& lp, flo
 #pragma unroll
         for (int j = 0; j < NB_HEADS; ++j) g[1 + j] = w * gb[j];
       }
+    }
+  }
+}
+
+// lp  : log p(t | theta) + lgamma(1+t)
+// g[] : d lp / d pre-activation of each head (only if GRAD)
+template <int KIND, bool GRAD>
+__device__ __forceinline__ void lik_elem(float t, const float* a, float& lp, float* g) {
+  float r, rgate;
+  lik_dense<KIND, GRAD>(t, a, lp, g, r, rgate);
+  if constexpr (LikelihoodTraits<KIND>::HAS_R) {
+    if (t > 0.f) {
+      float A, D;
+      lgamma_digamma_diff<GRAD>(r, t, A, D);
+      lp += A;
+      if (GRAD) g[LikelihoodTraits<KIND>::P - 1] += rgate * r * D;
     }
   }
 }
