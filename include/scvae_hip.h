@@ -146,6 +146,16 @@ int scvae_loglik_fwd(int32_t kind, const float* t, const float* const* pre, cons
 int scvae_loglik_bwd(int32_t kind, const float* t, float* const* pre, const float* gw,
                      const float* row_const, float* ll, int64_t rows, int64_t cells, int64_t F,
                      void* stream);
+/* Fused X_TILDE heads (va:2466-2505) + log p(t|z) summed over genes (va:2583-2590) and, with
+ * train != 0, their backward: dW_j = d^T G_j, db_j = colsum G_j, dd = sum_j G_j W_j^T with
+ * G_j = gw[row] * d log p / d pre_j.  d: [rows, H] (H even, <= 126); W_j: [H, F]; b_j: [F];
+ * t: [cells, F] (row r uses t[r % cells]); ll: [rows]; dd: [rows, H]. */
+int64_t scvae_decoder_fused_workspace_bytes(int64_t rows, int64_t H, int64_t F);
+int scvae_decoder_fused(int32_t kind, int32_t train, const float* d, int64_t rows, int64_t H,
+                        const float* const* W, const float* const* b, float* const* dW,
+                        float* const* db, int64_t F, const float* t, int64_t cells,
+                        const float* gw, const float* row_const, float* ll, float* dd,
+                        void* workspace, void* stream);
 /* element-wise .log_prob(t) / .mean() / .variance() of the DISTRIBUTIONS registry classes
  * (scvae/distributions/utilities.py:206-305, zero_inflated.py:180-199); pre = head
  * pre-activations (n elements each); log_prob and/or (mean, variance) may be NULL */

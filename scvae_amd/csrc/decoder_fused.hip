@@ -307,15 +307,25 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
 }
 
 // ll[r] = sum_strips ll_part[strip][r] - row_const[r % B]
-__global__ __launch_bounds__(256) void ll_reduce_kernel(const float* __restrict__ ll_part,
-                                                        int strips, int R,
-                                                        const float* __restrict__ row_const, int B,
-                                                        float* __restrict__ ll) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= R) return;
+// workgroup = 64 rows x 16 strip lanes (fixed summation order: deterministic)
+__global__ __launch_bounds__(1024) void ll_reduce_kernel(const float* __restrict__ ll_part,
+                                                         int strips, int R,
+                                                         const float* __restrict__ row_const, int B,
+                                                         float* __restrict__ ll) {
+  __shared__ float red[16][64];
+  const int rl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int r = blockIdx.x * 64 + rl;
   float s = 0.f;
-  for (int z = 0; z < strips; ++z) s += ll_part[(size_t)z * R + r];
-  ll[r] = s - (row_const ? row_const[r % B] : 0.f);
+  if (r < R)
+    for (int z = g; z < strips; z += 16) s += ll_part[(size_t)z * R + r];
+  red[g][rl] = s;
+  __syncthreads();
+  if (g == 0 && r < R) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][rl];
+    ll[r] = t - (row_const ? row_const[r % B] : 0.f);
+  }
 }
 
 // dd[i] = sum_strips dd_part[strip][i], i over rows*H (float4 where possible)
@@ -328,7 +338,15 @@ __global__ __launch_bounds__(256) void dd_reduce_kernel(const float* __restrict_
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
        i += (size_t)gridDim.x * blockDim.x) {
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < strips; ++z) {
+    int z = 0;
+    for (; z + 8 <= strips; z += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p4[(size_t)(z + u) * n4 + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; z < strips; ++z) {
       const float4 v = p4[(size_t)z * n4 + i];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -396,7 +414,7 @@ int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int
   int rc = launch_decoder<false>(s, kind, d, rows, H, hp, F, t, B, nullptr, row_const ? 0 : 1, ll_part,
                                  nullptr);
   if (rc) return rc;
-  hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, ll_part, strips,
+  hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 63) / 64), dim3(1024), 0, s, ll_part, strips,
                      rows, row_const, B, ll);
   SCVAE_LAUNCH_CHECK("ll_reduce_kernel");
   return 0;
@@ -415,7 +433,7 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
   int rc = launch_decoder<true>(s, kind, d, rows, H, hp, F, t, B, gw, row_const ? 0 : 1, ll_part,
                                 dd_part);
   if (rc) return rc;
-  hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, ll_part, strips,
+  hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 63) / 64), dim3(1024), 0, s, ll_part, strips,
                      rows, row_const, B, ll);
   SCVAE_LAUNCH_CHECK("ll_reduce_kernel");
   const size_t n = (size_t)rows * H;

@@ -590,6 +590,34 @@ int scvae_loglik_bwd(int32_t kind, const float* t, float* const* pre, const floa
   return scvae::loglik_bwd((hipStream_t)stream, kind, t, (int)F, hp, (int)F, gw, row_const, ll,
                            (int)rows, (int)cells, (int)F);
 }
+int64_t scvae_decoder_fused_workspace_bytes(int64_t rows, int64_t H, int64_t F) {
+  if (!scvae::decoder_fused_supported((int)H)) return -1;
+  return (int64_t)(scvae::decoder_fused_workspace_floats((int)rows, (int)H, (int)F, true) *
+                   sizeof(float));
+}
+int scvae_decoder_fused(int32_t kind, int32_t train, const float* d, int64_t rows, int64_t H,
+                        const float* const* W, const float* const* b, float* const* dW,
+                        float* const* db, int64_t F, const float* t, int64_t cells,
+                        const float* gw, const float* row_const, float* ll, float* dd,
+                        void* workspace, void* stream) {
+  SCVAE_ARG(kind >= 0 && kind <= 3 && W && b);
+  SCVAE_ARG(scvae::decoder_fused_supported((int)H));
+  scvae::HeadParams hp;
+  for (int j = 0; j < 3; ++j) {
+    const bool on = j < scvae::likelihood_heads(kind);
+    hp.W[j] = on ? W[j] : nullptr;
+    hp.b[j] = on ? b[j] : nullptr;
+    hp.dW[j] = (on && dW) ? dW[j] : nullptr;
+    hp.db[j] = (on && db) ? db[j] : nullptr;
+  }
+  if (train) {
+    SCVAE_ARG(dW && db);
+    return scvae::decoder_fused_train((hipStream_t)stream, kind, d, (int)rows, (int)H, hp, (int)F, t,
+                                      (int)cells, gw, row_const, ll, dd, (float*)workspace);
+  }
+  return scvae::decoder_fused_forward((hipStream_t)stream, kind, d, (int)rows, (int)H, hp, (int)F, t,
+                                      (int)cells, row_const, ll, (float*)workspace);
+}
 int scvae_likelihood_elementwise(int32_t kind, const float* t, const float* const* pre,
                                  float* log_prob, float* mean, float* variance, int64_t n,
                                  void* stream) {
