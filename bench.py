@@ -103,21 +103,41 @@ def cpu_baseline(matrix, batch, seconds_budget=15.0):
 
 def time_dominant_kernel(engine, rows, launches=10):
     """Average duration (HIP events on the launch stream) of the dominant
-    kernel of the step, run standalone on the step's own shapes."""
+    kernel of the step -- the fused decoder-head kernel -- run standalone on
+    the step's own shapes (main kernel only, without its two small reductions,
+    so that the figure matches rocprofv3's per-kernel average)."""
     from scvae_amd import _lib
     lib = engine.lib
     F, H = engine.feature_size, engine.hidden_sizes[0]
     dev = engine.device
-    d = torch.randn(rows, H, device=dev)
-    W = engine.parameter("X_TILDE/P/DENSE/weights")
-    bias = engine.parameter("X_TILDE/P/DENSE/biases")
-    out = torch.empty(rows, F, device=dev)
+    kind, heads = _lib.LIKELIHOOD_KINDS[engine.likelihood]
+    P = len(heads)
+    g = torch.Generator(device=dev).manual_seed(5)
+    d = torch.relu(torch.randn(rows, H, device=dev, generator=g))
+    names = ["X_TILDE/{}/DENSE/".format(h.upper()) for h in heads]
+    W = [engine.parameter(n + "weights") for n in names]
+    b = [engine.parameter(n + "biases") for n in names]
+    dW = [torch.empty_like(w) for w in W]
+    db = [torch.empty_like(v) for v in b]
+    t = torch.poisson(torch.full((rows, F), 2.0, device=dev), generator=g)
+    t = t * (torch.rand(rows, F, device=dev, generator=g) < 0.05)
+    gw = torch.full((rows,), -1.0 / rows, device=dev)
+    rc = torch.lgamma(t + 1).sum(dim=1)
+    ll = torch.empty(rows, device=dev)
+    dd = torch.empty(rows, H, device=dev)
+    ws = torch.empty(lib.scvae_decoder_fused_workspace_bytes(rows, H, F),
+                     dtype=torch.uint8, device=dev)
+
+    def arr(ts):
+        return (ctypes.c_void_p * len(ts))(*[x.data_ptr() for x in ts])
+    aW, ab, adW, adb = arr(W), arr(b), arr(dW), arr(db)
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
     def launch():
-        _lib.check(lib.scvae_gemm(
-            0, 0, d.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(),
-            rows, F, H, H, F, F, 0, 0, None, 0, stream), "scvae_gemm")
+        _lib.check(lib.scvae_decoder_fused(
+            kind, 3, d.data_ptr(), rows, H, aW, ab, adW, adb, F, t.data_ptr(),
+            rows, gw.data_ptr(), rc.data_ptr(), ll.data_ptr(), dd.data_ptr(),
+            ws.data_ptr(), stream), "scvae_decoder_fused")
     launch()
     torch.cuda.synchronize(dev)
     start, stop = torch.cuda.Event(True), torch.cuda.Event(True)
@@ -127,9 +147,12 @@ def time_dominant_kernel(engine, rows, launches=10):
     stop.record()
     torch.cuda.synchronize(dev)
     seconds = start.elapsed_time(stop) / 1e3 / launches
-    flops = 2.0 * rows * F * H
+    # algorithmic flops of the decoder heads: forward + dW + dX, 2 flop / MAC
+    flops = 2.0 * rows * F * P * 3 * H
     return {
-        "kernel": "gemm_kernel<false,false> (X_TILDE head: [rows,100]x[100,F])",
+        "kernel": "decoder_head_kernel<{}, true, 64> (X_TILDE heads + "
+                  "likelihood + dW/db/dd, [rows,{}]x[{},{}]x{} heads)".format(
+                      kind, H, H, F, P),
         "bound": "mfma",
         "achieved": flops / seconds / 1e12,
         "peak": PEAK_FP32_MFMA_TFLOPS,
@@ -137,6 +160,7 @@ def time_dominant_kernel(engine, rows, launches=10):
         "frac": flops / seconds / 1e12 / PEAK_FP32_MFMA_TFLOPS,
         "traffic": None,
         "launch_us": seconds * 1e6,
+        "algorithmic_flop_per_launch": flops,
     }
 
 

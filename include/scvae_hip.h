@@ -149,7 +149,9 @@ int scvae_loglik_bwd(int32_t kind, const float* t, float* const* pre, const floa
 /* Fused X_TILDE heads (va:2466-2505) + log p(t|z) summed over genes (va:2583-2590) and, with
  * train != 0, their backward: dW_j = d^T G_j, db_j = colsum G_j, dd = sum_j G_j W_j^T with
  * G_j = gw[row] * d log p / d pre_j.  d: [rows, H] (H even, <= 126); W_j: [H, F]; b_j: [F];
- * t: [cells, F] (row r uses t[r % cells]); ll: [rows]; dd: [rows, H]. */
+ * t: [cells, F] (row r uses t[r % cells]); ll: [rows]; dd: [rows, H].
+ * train: 0 forward, 1 forward+backward, 3 forward+backward main kernel only (the per-strip
+ * partial sums are left unreduced; used by bench.py to time that kernel alone). */
 int64_t scvae_decoder_fused_workspace_bytes(int64_t rows, int64_t H, int64_t F);
 int scvae_decoder_fused(int32_t kind, int32_t train, const float* d, int64_t rows, int64_t H,
                         const float* const* W, const float* const* b, float* const* dW,

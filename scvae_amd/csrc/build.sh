@@ -8,7 +8,7 @@ mkdir -p build
 pids=()
 for src in *.hip; do
   obj=build/${src%.hip}.o
-  if [[ ! -f $obj || $src -nt $obj || common.hpp -nt $obj || kernels.hpp -nt $obj || likelihood.hpp -nt $obj || ../../include/scvae_hip.h -nt $obj ]]; then
+  if [[ ! -f $obj || $src -nt $obj || common.hpp -nt $obj || kernels.hpp -nt $obj || likelihood.hpp -nt $obj || plan.hpp -nt $obj || ../../include/scvae_hip.h -nt $obj ]]; then
     $HIPCC $FLAGS -c "$src" -o "$obj" &
     pids+=($!)
   fi

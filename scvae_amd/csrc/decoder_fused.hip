@@ -423,7 +423,7 @@ int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int
 // Forward + backward: ll[rows], dW_j, db_j (in hp), dd[rows, H]
 int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                         int F, const float* t, int B, const float* gw, const float* row_const,
-                        float* ll, float* dd, float* workspace) {
+                        float* ll, float* dd, float* workspace, bool kernel_only) {
   SCVAE_ARG(d && t && gw && ll && dd && workspace && decoder_fused_supported(H));
   if (rows == 0) return 0;
   const int strips = (F + DF_BN - 1) / DF_BN;
@@ -433,6 +433,7 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
   int rc = launch_decoder<true>(s, kind, d, rows, H, hp, F, t, B, gw, row_const ? 0 : 1, ll_part,
                                 dd_part);
   if (rc) return rc;
+  if (kernel_only) return 0;  // profiling aid: leave the per-strip partials unreduced
   hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 63) / 64), dim3(1024), 0, s, ll_part, strips,
                      rows, row_const, B, ll);
   SCVAE_LAUNCH_CHECK("ll_reduce_kernel");

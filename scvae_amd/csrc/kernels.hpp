@@ -90,7 +90,7 @@ int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int
                           float* workspace);
 int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                         int F, const float* t, int B, const float* gw, const float* row_const,
-                        float* ll, float* dd, float* workspace);
+                        float* ll, float* dd, float* workspace, bool kernel_only = false);
 
 // ---- gmvae_kernels.hip ----
 int add_group_rows(hipStream_t s, const float* a0, const float* rows, float* out, int K, int B,

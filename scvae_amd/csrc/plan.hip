@@ -613,7 +613,8 @@ int scvae_decoder_fused(int32_t kind, int32_t train, const float* d, int64_t row
   if (train) {
     SCVAE_ARG(dW && db);
     return scvae::decoder_fused_train((hipStream_t)stream, kind, d, (int)rows, (int)H, hp, (int)F, t,
-                                      (int)cells, gw, row_const, ll, dd, (float*)workspace);
+                                      (int)cells, gw, row_const, ll, dd, (float*)workspace,
+                                      (train & 2) != 0);
   }
   return scvae::decoder_fused_forward((hipStream_t)stream, kind, d, (int)rows, (int)H, hp, (int)F, t,
                                       (int)cells, row_const, ll, (float*)workspace);

@@ -113,7 +113,11 @@ size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t
     if (q > pmax) pmax = q;
   }
   float* partial = b.floats(pmax);
+  float* fused_ws = decoder_fused_supported(h1)
+                        ? b.floats(decoder_fused_workspace_floats((int)R, h1, (int)F, true))
+                        : nullptr;
   if (!dry) {
+    p->fused_ws = fused_ws;
     p->logits = logits; p->yprob = yprob; p->kl_y_cell = kl_y_cell; p->a0 = a0;
     p->qm = qm; p->qs = qs; p->z = z; p->klz = klz; p->gklz = gklz; p->ll = ll; p->gw = gw;
     p->dy = dy; p->dlogits = dlogits; p->dqm = dqm; p->dqs = dqs; p->dprior = dprior;
@@ -136,8 +140,14 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const float w = a->warm_up_weight * c.kl_weight;
   const float inv_gb = 1.f / (float)GB;
   int rc;
-#define GEMM(...) if ((rc = gemm(s, __VA_ARGS__, p->gemm_ws, p->gemm_ws_bytes))) return rc
-#define TRY(call) if ((rc = (call))) return rc
+#define GEMM(...)                                                              \
+  do {                                                                         \
+    if ((rc = gemm(s, __VA_ARGS__, p->gemm_ws, p->gemm_ws_bytes))) return rc;  \
+  } while (0)
+#define TRY(call)                  \
+  do {                             \
+    if ((rc = (call))) return rc;  \
+  } while (0)
 
   // ---------------- q(y|x) (gm:3050-3092) ----------------
   const float* h = a->x;
@@ -220,10 +230,17 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   HeadPtrs pre;
   for (int j = 0; j < 3; ++j) pre.p[j] = p->pre[j];
-  for (int j = 0; j < p->P; ++j) {
-    Dense& hd = p->heads[j];
-    GEMM(false, false, dch, p->params + hd.w, p->params + hd.b, p->pre[j], R, F, hd.n_in, ld, F, F,
-         ACT_NONE, false);
+  const int h1 = p->heads[0].n_in;
+  // fused heads + likelihood (+ backward) unless the evaluate-time statistics are requested
+  const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
+                     !a->p_x_mean;
+  const HeadParams hp = head_params(p);
+  if (!fused) {
+    for (int j = 0; j < p->P; ++j) {
+      Dense& hd = p->heads[j];
+      GEMM(false, false, dch, p->params + hd.w, p->params + hd.b, p->pre[j], R, F, hd.n_in, ld, F,
+           F, ACT_NONE, false);
+    }
   }
   if (a->p_x_mean) {
     if (!(a->p_x_stddev && a->stddev_of_p_x_given_z_mean)) {
@@ -248,7 +265,11 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const float thr = c.free_nats_proportion * p_y_entropy;
   const int use_free_nats = c.free_nats_proportion != 0.f;
   if (!training) {
-    TRY(loglik_fwd(s, c.likelihood, a->t, F, pre, F, a->row_const, p->ll, R, B, F));
+    if (fused)
+      TRY(decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, a->t, B, a->row_const, p->ll,
+                                p->fused_ws));
+    else
+      TRY(loglik_fwd(s, c.likelihood, a->t, F, pre, F, a->row_const, p->ll, R, B, F));
     TRY(gmvae_elbo(s, p->ll, p->klz, p->yprob, p->kl_y_cell, K, S, B, inv_gb, sums, nullptr));
     TRY(gmvae_elbo_finish(s, sums, w, thr, use_free_nats, 1.f, a->scalars, gate));
     if (a->log_p_x_given_z) TRY(copy(s, p->ll, a->log_p_x_given_z, (size_t)R));
@@ -257,7 +278,15 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   // d(-ELBO_w)/d log p(t|z_k)[k,s,b] = -y[b,k]/(S*GB): known before the likelihood pass
   TRY(gmvae_elbo_bwd(s, p->klz, p->klz, p->yprob, gate, K, S, B, w, inv_gb, p->gw, p->gklz,
                      p->dy));  // (fills gw, gklz; dy is recomputed below with ll)
-  TRY(loglik_bwd(s, c.likelihood, a->t, F, pre, F, p->gw, a->row_const, p->ll, R, B, F));
+  float* dcur = p->dbuf[0];
+  float* dalt = p->dbuf[1];
+  float* scratch = p->dbuf[2];
+  if (fused) {
+    TRY(decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, a->t, B, p->gw, a->row_const,
+                            p->ll, dcur, p->fused_ws));
+  } else {
+    TRY(loglik_bwd(s, c.likelihood, a->t, F, pre, F, p->gw, a->row_const, p->ll, R, B, F));
+  }
   TRY(gmvae_elbo(s, p->ll, p->klz, p->yprob, p->kl_y_cell, K, S, B, inv_gb, sums, nullptr));
   float share = 1.f;
   if (p->sync) {
@@ -273,11 +302,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   if (a->log_p_x_given_z) TRY(copy(s, p->ll, a->log_p_x_given_z, (size_t)R));
 
   // ---------------- backward: heads + decoder ----------------
-  float* dcur = p->dbuf[0];
-  float* dalt = p->dbuf[1];
-  float* scratch = p->dbuf[2];
-  {
-    const int h1 = p->heads[0].n_in;
+  if (!fused) {
     for (int j = 0; j < p->P; ++j) {
       Dense& hd = p->heads[j];
       GEMM(true, false, dch, p->pre[j], nullptr, p->grads + hd.w, h1, F, R, ld, F, F, ACT_NONE,
