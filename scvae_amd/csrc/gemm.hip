@@ -120,6 +120,116 @@ __global__ __launch_bounds__(256) void gemm_kernel(
   }
 }
 
+// Large-shape variant (encoder input layer: X[B,F] W[F,H] and its dW = X^T dY):
+// 128x128 tile per 512-thread workgroup (8 waves, two 32x32 accumulators each sharing the A
+// fragment), BK = 32, B operand row-major [K,N].  TA: A is stored [K,M] (i.e. C = A^T B).
+constexpr int BT = 128;
+constexpr int BBK = 32;
+constexpr int BLD = BT + 4;
+
+template <bool TA>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+    float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, int act, int accumulate,
+    int k_chunk, float* __restrict__ slabs) {
+  __shared__ float As[2][BBK][BLD];
+  __shared__ float Bs[2][BBK][BLD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int mt = w >> 1, ntp = (w & 1) * 2;     // row tile, first of two column tiles
+  const int kh = lane >> 5, li = lane & 31;
+  const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
+  const int kz = blockIdx.z;
+  const int k_begin = kz * k_chunk;
+  const int k_end = min(K, k_begin + k_chunk);
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+
+  // per k-step every thread moves 8 A and 8 B elements
+  float ra[8], rb[8];
+  auto load_tiles = [&](int kt) {
+    if (TA) {
+      // A[k][m]: 32 rows of 128 consecutive m
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int k = (tid >> 7) + 4 * p, m = tid & 127;
+        const int gk = kt + k, gm = m0 + m;
+        ra[p] = (gk < k_end && gm < M) ? A[(size_t)gk * lda + gm] : 0.f;
+      }
+    } else {
+      // A[m][k]: 128 rows of 32 consecutive k
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int m = (tid >> 5) + 16 * p, k = tid & 31;
+        const int gk = kt + k, gm = m0 + m;
+        ra[p] = (gk < k_end && gm < M) ? A[(size_t)gm * lda + gk] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int k = (tid >> 7) + 4 * p, n = tid & 127;
+      const int gk = kt + k, gn = n0 + n;
+      rb[p] = (gk < k_end && gn < N) ? B[(size_t)gk * ldb + gn] : 0.f;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    if (TA) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) As[buf][(tid >> 7) + 4 * p][tid & 127] = ra[p];
+    } else {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) As[buf][tid & 31][(tid >> 5) + 16 * p] = ra[p];
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) Bs[buf][(tid >> 7) + 4 * p][tid & 127] = rb[p];
+  };
+
+  int buf = 0;
+  if (k_begin < k_end) {
+    load_tiles(k_begin);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int kt = k_begin; kt < k_end; kt += BBK) {
+    const bool has_next = kt + BBK < k_end;
+    if (has_next) load_tiles(kt + BBK);
+#pragma unroll
+    for (int kk = 0; kk < BBK; kk += 2) {
+      const float a = As[buf][kk + kh][mt * 32 + li];
+      const float b0 = Bs[buf][kk + kh][ntp * 32 + li];
+      const float b1 = Bs[buf][kk + kh][ntp * 32 + 32 + li];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+    }
+    if (has_next) store_tiles(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int col = n0 + (ntp + q) * 32 + li;
+    if (col >= N) continue;
+    const float bv = (bias != nullptr && slabs == nullptr) ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (row >= M) continue;
+      if (slabs != nullptr) {
+        slabs[((size_t)kz * M + row) * N + col] = acc[q][r];
+      } else {
+        float v = acc[q][r] + bv;
+        if (act == ACT_RELU) v = fmaxf(v, 0.f);
+        float* c = C + (size_t)row * ldc + col;
+        *c = accumulate ? (*c + v) : v;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(
     const float* __restrict__ slabs, const float* __restrict__ bias, float* __restrict__ C, int M,
     int N, int ldc, int splits, int act, int accumulate) {
@@ -136,8 +246,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(
   }
 }
 
+static bool gemm_use_big(bool tb, int M, int N, int K) {
+  return !tb && (double)M * N * K >= 4.0e9 && N >= 64;
+}
+
+static int gemm_big_splits(int M, int N, int K) {
+  const long tiles = (long)((M + BT - 1) / BT) * ((N + BT - 1) / BT);
+  if (tiles >= 192) return 1;
+  long want = (512 + tiles - 1) / tiles;
+  long max_by_k = K / 512;
+  long s = want < max_by_k ? want : max_by_k;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return (int)s;
+}
+
 size_t gemm_workspace_bytes(int M, int N, int K) {
-  const int splits = gemm_choose_splits(M, N, K);
+  int splits = gemm_choose_splits(M, N, K);
+  const int big = gemm_big_splits(M, N, K);
+  if (big > splits) splits = big;
   return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
 }
 
@@ -158,26 +285,39 @@ int gemm(hipStream_t stream, bool ta, bool tb, const float* A, const float* B, c
   SCVAE_ARG(A && B && C);
   SCVAE_ARG(M >= 0 && N >= 0 && K >= 0);
   if (M == 0 || N == 0) return 0;
-  int splits = gemm_choose_splits(M, N, K);
+  const bool big = gemm_use_big(tb, M, N, K);
+  int splits = big ? gemm_big_splits(M, N, K) : gemm_choose_splits(M, N, K);
   if (splits > 1 && (workspace == nullptr ||
                      workspace_bytes < (size_t)splits * M * N * sizeof(float)))
     splits = 1;
+  const int kstep = big ? BBK : GBK;
+  const int tile = big ? BT : GT;
   int k_chunk = K;
   if (splits > 1) {
     k_chunk = (K + splits - 1) / splits;
-    k_chunk = (k_chunk + GBK - 1) / GBK * GBK;
+    k_chunk = (k_chunk + kstep - 1) / kstep * kstep;
     splits = (K + k_chunk - 1) / k_chunk;
   }
-  dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, splits);
+  dim3 grid((N + tile - 1) / tile, (M + tile - 1) / tile, splits);
   float* slabs = splits > 1 ? workspace : nullptr;
   const int acc = accumulate ? 1 : 0;
+  if (big) {
+    if (ta)
+      hipLaunchKernelGGL((gemm_big_kernel<true>), grid, dim3(512), 0, stream, A, B, bias, C, M, N, K,
+                         lda, ldb, ldc, act, acc, k_chunk, slabs);
+    else
+      hipLaunchKernelGGL((gemm_big_kernel<false>), grid, dim3(512), 0, stream, A, B, bias, C, M, N,
+                         K, lda, ldb, ldc, act, acc, k_chunk, slabs);
+    SCVAE_LAUNCH_CHECK("gemm_big_kernel");
+  } else {
 #define SCVAE_GEMM_LAUNCH(TA_, TB_)                                                              \
   hipLaunchKernelGGL((gemm_kernel<TA_, TB_>), grid, dim3(256), 0, stream, A, B, bias, C, M, N, K, \
                      lda, ldb, ldc, act, acc, k_chunk, slabs)
   if (ta) { if (tb) SCVAE_GEMM_LAUNCH(true, true); else SCVAE_GEMM_LAUNCH(true, false); }
   else    { if (tb) SCVAE_GEMM_LAUNCH(false, true); else SCVAE_GEMM_LAUNCH(false, false); }
 #undef SCVAE_GEMM_LAUNCH
-  SCVAE_LAUNCH_CHECK("gemm_kernel");
+    SCVAE_LAUNCH_CHECK("gemm_kernel");
+  }
   if (splits > 1) {
     const size_t total = (size_t)M * N;
     int blocks = (int)((total + 255) / 256);

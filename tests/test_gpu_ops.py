@@ -52,6 +52,32 @@ def test_gemm_matches_fp64(cuda_device, ta, tb, M, N, K):
         assert err < 2e-6 * scale * max(1.0, np.sqrt(K) / 8), (err, scale)
 
 
+@pytest.mark.parametrize("ta", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(300, 100, 140000), (4500, 100, 9000),
+                                   (2100, 130, 16000)])
+def test_big_gemm_matches_fp64(cuda_device, ta, M, N, K):
+    """Shapes routed to the 128x128 kernel (encoder input layer and its dW),
+    with and without split-K, edge tiles in M, N and K."""
+    from scvae_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    A = A * (torch.rand(A.shape, generator=g) < 0.1)      # sparse like counts
+    Bm = torch.randn((K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = (A.double().T if ta else A.double()) @ Bm.double() + bias.double()
+    Ad, Bd, bd = (v.to(cuda_device) for v in (A, Bm, bias))
+    C = torch.zeros((M, N), device=cuda_device)
+    ws_bytes = lib.scvae_gemm_workspace_bytes(M, N, K)
+    ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=cuda_device)
+    _lib.check(lib.scvae_gemm(
+        ta, 0, _p(Ad), _p(Bd), _p(bd), _p(C), M, N, K, Ad.shape[1], N, N, 0, 0,
+        _p(ws), ws_bytes, _stream()), "gemm")
+    torch.cuda.synchronize()
+    err = (C.cpu().double() - ref).abs().max().item()
+    assert err < 3e-5 * ref.abs().max().item(), err
+
+
 @pytest.mark.parametrize("name", list(lk.LIKELIHOOD_PARAMETERS))
 def test_loglik_forward_backward(cuda_device, name):
     from scvae_amd import _lib
