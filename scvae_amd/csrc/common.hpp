@@ -77,6 +77,13 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return s;
 }
 
+// Workgroup barrier that orders LDS traffic only: waits for this wave's LDS operations
+// (lgkmcnt) but NOT for its outstanding global loads/stores (vmcnt), so register prefetches
+// issued before the barrier stay in flight across it.  (__syncthreads() drains vmcnt too.)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---- scalar math used by the likelihood kernels ----
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 // log(1 + x), x > -1: log(u) * x / (u - 1) with u = fl(1 + x) removes the rounding of 1 + x

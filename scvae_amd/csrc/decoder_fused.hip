@@ -217,7 +217,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (Traits::HAS_R) {
       const int n_q = min(*qcount, DF_QUEUE);
       for (int s = tid; s < n_q; s += NT) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
         ts[(size_t)row * LD + c] = A;
         if (TRAIN) Gs[((size_t)(P - 1) * BM + row) * LD + c] += qs[s] * r * D;
       }
-      __syncthreads();
+      lds_barrier();
       if (tid == 0) *qcount = 0;
     }
     // ---- per-row partial log-likelihood of this strip (dense part + corrections) ----
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
       if ((tid % TPR) == 0 && row_ok) ll_part[(size_t)blockIdx.x * R + m0 + er] = lsum;
     }
     if (!TRAIN) {
-      __syncthreads();
+      lds_barrier();
       continue;
     }
 
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 
   if (!TRAIN) return;
@@ -434,8 +434,8 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
                                 dd_part);
   if (rc) return rc;
   if (kernel_only) return 0;  // profiling aid: leave the per-strip partials unreduced
-  hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 63) / 64), dim3(1024), 0, s, ll_part, strips,
-                     rows, row_const, B, ll);
+  hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 63) / 64), dim3(1024), 0, s, ll_part,
+                     strips, rows, row_const, B, ll);
   SCVAE_LAUNCH_CHECK("ll_reduce_kernel");
   const size_t n = (size_t)rows * H;
   if (n % 4 == 0) {
