@@ -101,6 +101,22 @@ def cpu_baseline(matrix, batch, seconds_budget=15.0):
     }
 
 
+def _measured_traffic(rows, F, H, kind):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3
+    PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section);
+    only reported when the profiled shapes are the benchmarked ones."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_decoder_head.json")
+    try:
+        with open(path) as f:
+            pmc = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if (kind != 1 or pmc.get("rows") != rows or pmc.get("features") != F
+            or pmc.get("hidden") != H):
+        return None
+    return pmc["traffic_bytes_per_launch"]
+
+
 def time_dominant_kernel(engine, rows, launches=10):
     """Average duration (HIP events on the launch stream) of the dominant
     kernel of the step -- the fused decoder-head kernel -- run standalone on
@@ -114,7 +130,8 @@ def time_dominant_kernel(engine, rows, launches=10):
     P = len(heads)
     g = torch.Generator(device=dev).manual_seed(5)
     d = torch.relu(torch.randn(rows, H, device=dev, generator=g))
-    names = ["X_TILDE/{}/DENSE/".format(h.upper()) for h in heads]
+    scope = "X/DISTRIBUTION" if engine.model_type == "GMVAE" else "X_TILDE"
+    names = ["{}/{}/DENSE/".format(scope, h.upper()) for h in heads]
     W = [engine.parameter(n + "weights") for n in names]
     b = [engine.parameter(n + "biases") for n in names]
     dW = [torch.empty_like(w) for w in W]
@@ -158,7 +175,7 @@ def time_dominant_kernel(engine, rows, launches=10):
         "peak": PEAK_FP32_MFMA_TFLOPS,
         "unit": "TFLOP/s",
         "frac": flops / seconds / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-        "traffic": None,
+        "traffic": _measured_traffic(rows, F, H, kind),
         "launch_us": seconds * 1e6,
         "algorithmic_flop_per_launch": flops,
     }
@@ -174,6 +191,11 @@ def main():
     ap.add_argument("--cells", type=int, default=N_CELLS)
     ap.add_argument("--features", type=int, default=N_FEATURES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="vae", choices=["vae", "gmvae"],
+                    help="extra (non-headline) workloads for DESIGN.md")
+    ap.add_argument("--clusters", type=int, default=20)
+    ap.add_argument("--latent", type=int, default=LATENT)
+    ap.add_argument("--likelihood", default=LIKELIHOOD)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,7 +224,11 @@ def main():
     F = args.features
     B = args.batch
     GB = B * world
-    engine = Engine(F, LATENT, HIDDEN, LIKELIHOOD, batch_norm=True,
+    gm = args.model == "gmvae"
+    K = args.clusters if gm else 1
+    L = args.latent
+    engine = Engine(F, L, HIDDEN, args.likelihood, batch_norm=True,
+                    model_type="GMVAE" if gm else "VAE", n_clusters=K,
                     device=device, seed=0)
     engine.reserve(B, 1)
     sync = None
@@ -213,7 +239,7 @@ def main():
 
     x = torch.empty(B, F, device=device)
     row_const = torch.empty(B, device=device)
-    eps = torch.empty(1, B, LATENT, device=device)
+    eps = torch.empty(K, B, L, device=device)
     g = torch.Generator(device=device).manual_seed(2)
     n = matrix.number_of_rows
 
@@ -231,8 +257,9 @@ def main():
         rows = perm[cursor + rank * B: cursor + (rank + 1) * B]
         cursor += GB
         matrix.gather_dense(rows, out=x, row_const_out=row_const)
-        philox_normal(eps.view(B, LATENT), row_offset=rank * B, seed=1,
-                      stream_id=step_counter)
+        for k in range(K):
+            philox_normal(eps[k], row_offset=k * GB + rank * B, seed=1,
+                          stream_id=step_counter)
         step_counter += 1
         engine.step(x, x, eps=eps, row_const=row_const, training=True,
                     global_cells=GB)
@@ -265,8 +292,9 @@ def main():
 
     if rank == 0:
         value = args.steps * GB / elapsed
-        heads = 2
-        flops_cell = train_flops_per_cell(F, HIDDEN, LATENT, heads)
+        from scvae_amd import _lib as _l
+        heads = len(_l.LIKELIHOOD_KINDS[args.likelihood][1])
+        flops_cell = train_flops_per_cell(F, HIDDEN, L, heads)
         result = {
             "metric": "cells/sec training (68k-PBMC NB-VAE)",
             "value": value,
@@ -282,9 +310,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "68k-PBMC-shaped synthetic counts {}x{} (~5% "
-                            "nonzero, device CSR), NB VAE hidden 100-100 "
-                            "latent 25 batch-norm, Adam lr 1e-4".format(
-                                args.cells, F),
+                            "nonzero, device CSR), {} {} hidden 100-100 "
+                            "latent {} batch-norm, Adam lr 1e-4".format(
+                                args.cells, F, args.likelihood,
+                                "GMVAE K={}".format(K) if gm else "VAE", L),
                 "cells_per_gpu_per_step": B,
                 "global_batch": GB,
                 "parallelism": "dp{}".format(world),
@@ -294,8 +323,11 @@ def main():
             / PEAK_FP32_MFMA_TFLOPS,
             "last_lower_bound": lower_bound,
         }
-        result["roofline"] = time_dominant_kernel(engine, B)
-        if world == 1 and not args.no_cpu_baseline:
+        if gm:   # informational run: per-cell flops of the VAE formula do not apply
+            result["train_flop_per_cell"] = None
+            result["step_mfma_frac"] = None
+        result["roofline"] = time_dominant_kernel(engine, B * K)
+        if world == 1 and not args.no_cpu_baseline and not gm:
             result["cpu_baseline"] = cpu_baseline(matrix, B)
         print(json.dumps(result), flush=True)
     if world > 1:
