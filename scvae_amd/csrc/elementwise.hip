@@ -812,8 +812,11 @@ int adam_clip_step(hipStream_t stream, float* theta, float* grad, float* m, floa
 
 // ============================== CSR minibatch ==============================
 
-// one workgroup per gathered row: scatter the row's nonzeros into the (pre-zeroed) dense row
-__global__ __launch_bounds__(256) void csr_scatter_kernel(const int64_t* __restrict__ indptr,
+// One workgroup per gathered row writes the whole dense row in one pass: float4 zero fill of
+// the row (16-byte aligned part), a workgroup barrier, then the row's nonzeros.  Both phases of
+// a row are issued by the same workgroup, whose stores to one address stay ordered across
+// __syncthreads(), so no separate memset of the [B, F] buffer is needed.
+__global__ __launch_bounds__(256) void csr_densify_kernel(const int64_t* __restrict__ indptr,
                                                           const int32_t* __restrict__ indices,
                                                           const float* __restrict__ values,
                                                           const int64_t* __restrict__ rows, int F,
@@ -822,6 +825,18 @@ __global__ __launch_bounds__(256) void csr_scatter_kernel(const int64_t* __restr
   const int64_t r = rows[b];
   const int64_t lo = indptr[r], hi = indptr[r + 1];
   float* orow = out + (size_t)b * ldo;
+  // head elements up to the first 16-byte boundary, float4 body, scalar tail
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(orow);
+  int head = (int)(((16 - (addr & 15)) & 15) / 4);
+  if (head > F) head = F;
+  const int n4 = (F - head) / 4;
+  float4* o4 = reinterpret_cast<float4*>(orow + head);
+  for (int i = threadIdx.x; i < n4; i += 256) o4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (threadIdx.x < head) orow[threadIdx.x] = 0.f;
+  const int tail0 = head + 4 * n4;
+  if (tail0 + (int)threadIdx.x < F) orow[tail0 + threadIdx.x] = 0.f;
+  __threadfence_block();
+  __syncthreads();
   for (int64_t j = lo + threadIdx.x; j < hi; j += 256) {
     const int32_t c = indices[j];
     if (c >= 0 && c < F) orow[c] = values[j];
@@ -832,10 +847,9 @@ int csr_densify(hipStream_t stream, const int64_t* indptr, const int32_t* indice
                 const float* values, const int64_t* rows, int B, int F, float* out, int ldo) {
   SCVAE_ARG(indptr && indices && values && rows && out && F > 0 && ldo >= F);
   if (B == 0) return 0;
-  SCVAE_HIP(hipMemsetAsync(out, 0, (size_t)B * ldo * sizeof(float), stream));
-  hipLaunchKernelGGL(csr_scatter_kernel, dim3(B), dim3(256), 0, stream, indptr, indices, values,
+  hipLaunchKernelGGL(csr_densify_kernel, dim3(B), dim3(256), 0, stream, indptr, indices, values,
                      rows, F, out, ldo);
-  SCVAE_LAUNCH_CHECK("csr_scatter_kernel");
+  SCVAE_LAUNCH_CHECK("csr_densify_kernel");
   return 0;
 }
 

@@ -1,0 +1,100 @@
+"""Edge shapes of the fused decoder-head kernel through the C ABI against an
+fp64 torch reference: row / gene counts around the 64-wide tiles, hidden sizes
+around the 32-wide MFMA tiles (incl. multiples of 32, where the ones-column of
+db lands in a tile of its own), queue overflow on dense counts, all kinds."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import likelihoods as lk
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(device, name, rows, cells, F, H, density, seed=0, row_const=True):
+    from scvae_amd import _lib
+    lib = _lib.load()
+    kind, heads = _lib.LIKELIHOOD_KINDS[name]
+    P = len(heads)
+    rng = np.random.default_rng(seed)
+    d = np.maximum(rng.normal(0, 1, (rows, H)), 0)
+    W = [rng.normal(0, 0.3, (H, F)) for _ in range(P)]
+    b = [rng.normal(0, 0.3, F) for _ in range(P)]
+    t = rng.poisson(3.0, (cells, F)) * (rng.random((cells, F)) < density)
+    t = t.astype(np.float64)
+    if t.size:
+        t.flat[0] = 5000.0
+    gw = rng.normal(0, 1, rows)
+
+    T = torch.from_numpy
+    dt = T(d).requires_grad_(True)
+    Wt = [T(w).requires_grad_(True) for w in W]
+    bt = [T(v).requires_grad_(True) for v in b]
+    pre = tuple(dt @ w + v for w, v in zip(Wt, bt))
+    reps = rows // cells
+    ll_ref = lk.log_prob(name, T(t).repeat(reps, 1), pre).sum(dim=1)
+    (ll_ref * T(gw)).sum().backward()
+
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().to(device)
+    dd_, td, gwd = f32(d), f32(t), f32(gw)
+    Wd, bd = [f32(w) for w in W], [f32(v) for v in b]
+    dWd = [torch.full_like(w, 7.0) for w in Wd]
+    dbd = [torch.full_like(v, 7.0) for v in bd]
+    ll = torch.full((rows,), 7.0, device=device)
+    dd = torch.full((rows, H), 7.0, device=device)
+    rc = torch.lgamma(td.double() + 1).sum(dim=1).float() if row_const else None
+    ws = torch.empty(lib.scvae_decoder_fused_workspace_bytes(rows, H, F),
+                     dtype=torch.uint8, device=device)
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[x.data_ptr() for x in ts])
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for train in (0, 1):
+        _lib.check(lib.scvae_decoder_fused(
+            kind, train, dd_.data_ptr(), rows, H, arr(Wd), arr(bd), arr(dWd),
+            arr(dbd), F, td.data_ptr(), cells, gwd.data_ptr(),
+            rc.data_ptr() if rc is not None else None, ll.data_ptr(),
+            dd.data_ptr(), ws.data_ptr(), stream), "scvae_decoder_fused")
+        torch.cuda.synchronize()
+        want = ll_ref.detach().numpy()
+        got = ll.cpu().double().numpy()
+        assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max() + 1e-4, (
+            train, np.abs(got - want).max(), np.abs(want).max())
+
+    def close(got, want, what):
+        want = want.numpy()
+        got = got.cpu().double().numpy()
+        scale = np.abs(want).max() + 1e-12
+        assert np.abs(got - want).max() <= 3e-5 * scale, (
+            what, np.abs(got - want).max(), scale)
+    close(dd, dt.grad, "dd")
+    for j in range(P):
+        close(dWd[j], Wt[j].grad, "dW%d" % j)
+        close(dbd[j], bt[j].grad, "db%d" % j)
+
+
+@pytest.mark.parametrize("rows,F", [(1, 1), (33, 63), (64, 64), (65, 65),
+                                    (130, 200), (97, 129)])
+@pytest.mark.parametrize("name", list(lk.LIKELIHOOD_PARAMETERS))
+def test_tile_edges(cuda_device, name, rows, F):
+    _run(cuda_device, name, rows, rows, F, 20, 0.3)
+
+
+@pytest.mark.parametrize("H", [2, 30, 32, 34, 64, 96, 100, 126])
+def test_hidden_sizes(cuda_device, H):
+    _run(cuda_device, "negative binomial", 70, 70, 150, H, 0.2)
+    _run(cuda_device, "zero-inflated negative binomial", 40, 40, 90, H, 0.2)
+
+
+def test_dense_counts_overflow_the_queue(cuda_device):
+    # every element is nonzero: the t > 0 queue overflows and falls back inline
+    _run(cuda_device, "negative binomial", 128, 128, 256, 32, 1.0)
+    _run(cuda_device, "zero-inflated negative binomial", 64, 64, 128, 32, 1.0)
+
+
+def test_repeated_targets_and_inline_lgamma(cuda_device):
+    # rows = samples x cells (importance samples / GMVAE passes): row r uses t[r % cells]
+    _run(cuda_device, "negative binomial", 96, 32, 100, 24, 0.3)
+    _run(cuda_device, "poisson", 90, 30, 77, 24, 0.3, row_const=False)
+    _run(cuda_device, "zero-inflated poisson", 60, 20, 77, 24, 0.3,
+         row_const=False)
