@@ -36,51 +36,62 @@ constexpr int DF_LD = DF_BN + 1; // LDS row stride of the [.., 64] tiles (odd: c
 __host__ __device__ inline int df_ldd(int H) { return H | 1; }   // H even -> H + 1
 __host__ __device__ inline int df_bm(int P) { return P >= 3 ? 32 : 64; }
 
-constexpr int DF_QUEUE = 1024;   // capacity of the per-tile queue of t > 0 elements
+constexpr int DF_QCAP = 128;     // wave-private queue of t > 0 elements (512 / 256 elements per wave)
 
-size_t decoder_fused_lds_bytes(int P, int H, bool train) {
+__device__ __forceinline__ int df_opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+__device__ __forceinline__ void df_wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+static size_t df_lds_floats(int P, int H, int d_buffers) {
   const int BM = df_bm(P);
-  size_t floats = (size_t)P * H * DF_LD          // Ws
-                  + (size_t)BM * df_ldd(H) + 32  // dsh (+ slack for the padded h tile)
-                  + (size_t)P * BM * DF_LD       // Gs: pre_j, then G_j in place
-                  + (size_t)BM * DF_LD           // ts
-                  + BM + 3 * DF_BN               // gws, bias
-                  + 3 * DF_QUEUE + 4;            // sparse-correction queue
+  size_t floats = (size_t)P * H * DF_LD              // Ws
+                  + d_buffers * ((size_t)BM * df_ldd(H) + 32)  // dsh (+ slack for the padded h tile)
+                  + (size_t)P * BM * DF_LD           // Gs: pre_j, then G_j in place
+                  + 3 * DF_BN                        // bias
+                  + 8 * 4 * DF_QCAP + 4;             // 8 wave-private queues x 4 fields
   // over-reads of the padded h tiles (h up to 127) must stay inside the allocation
   const size_t need = (size_t)((P - 1) * H + 128) * DF_LD + 64;
   if (floats < need) floats = need;
+  return floats;
+}
+constexpr size_t DF_LDS_LIMIT = 160 * 1024;
+// the d tile is double buffered when that fits into the 160 KB of LDS (H <= 110 for two heads)
+static int df_d_buffers(int P, int H) {
+  return df_lds_floats(P, H, 2) * sizeof(float) <= DF_LDS_LIMIT ? 2 : 1;
+}
+size_t decoder_fused_lds_bytes(int P, int H, bool train) {
   (void)train;
-  return floats * sizeof(float);
+  return df_lds_floats(P, H, df_d_buffers(P, H)) * sizeof(float);
 }
 
-// BM rows x 64 columns per step; see the file header for the phases.
+// BM rows x 64 columns per step.  Per step: GEMM1 | epilogue (+ next d tile -> LDS) | GEMM2, GEMM3,
+// three workgroup barriers; the d tile is double buffered, t goes from HBM straight into the
+// registers of the thread that owns the element.
 template <int KIND, bool TRAIN, int BM>
 __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
     const float* __restrict__ d, int R, int H, unsigned magic_h, HeadParams hp, int F,
     const float* __restrict__ t, int B, const float* __restrict__ gw, int inline_lgamma,
-    float* __restrict__ ll_part, float* __restrict__ dd_part) {
+    float* __restrict__ ll_part, float* __restrict__ dd_part, int d_buffers) {
   using Traits = LikelihoodTraits<KIND>;
   constexpr int P = Traits::P;
   constexpr int BN = DF_BN, LD = DF_LD, NT = DF_THREADS;
   constexpr int MT = BM / 32;                 // 32-row tiles per step
-  constexpr int TPR = NT / BM;                // epilogue threads per row (8 or 16)
-  constexpr int EPT = BN / TPR;               // epilogue elements per thread (8 or 4)
-  constexpr int TLOADS = BM * BN / NT;        // t elements staged per thread
+  constexpr int RI = BM / 16;                 // epilogue rows per thread (rows er0 + 16 i)
+  constexpr int EPT = 2 * RI;                 // epilogue elements per thread (columns ec, ec + 32)
   constexpr int DLOADS = (BM * 126 + NT - 1) / NT;   // upper bound of d elements per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int LDD = df_ldd(H);
+  const size_t DBUF = (size_t)BM * LDD + 32;          // one d tile (+32 slack)
   float* Ws = smem;                                   // [P][H][LD]
-  float* dsh = Ws + (size_t)P * H * LD;               // [BM][LDD] (+32 slack); column H = 1
-  float* Gs = dsh + (size_t)BM * LDD + 32;            // [P][BM][LD]
-  float* ts = Gs + (size_t)P * BM * LD;               // [BM][LD]
-  float* gws = ts + (size_t)BM * LD;                  // [BM]
-  float* bs = gws + BM;                               // [3][BN]
-  int* qidx = reinterpret_cast<int*>(bs + 3 * BN);    // [Q] element index row*64 + col
-  float* qr = reinterpret_cast<float*>(qidx + DF_QUEUE);   // [Q] total_count r
-  float* qs = qr + DF_QUEUE;                          // [Q] upstream * clip gate
-  int* qcount = reinterpret_cast<int*>(qs + DF_QUEUE);
+  float* dsh = Ws + (size_t)P * H * LD;               // [d_buffers][BM][LDD]; column H = 1
+  float* Gs = dsh + d_buffers * DBUF;                 // [P][BM][LD]
+  float* bs = Gs + (size_t)P * BM * LD;               // [3][BN]
+  float* qbase = bs + 3 * BN;                         // [8 waves][4][QCAP]
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kh = lane >> 5, li = lane & 31;
   const int c0 = blockIdx.x * BN;
 
@@ -88,16 +99,17 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
   for (int i = tid; i < P * H * BN; i += NT) {
     const int c = i & (BN - 1);
     const int jh = i >> 6;  // j*H + h
-    const int j = __umulhi((unsigned)jh, magic_h), h = jh - j * H;
     float v = 0.f;
-    if (c0 + c < F) v = hp.W[j][(size_t)h * F + c0 + c];
+    if (c0 + c < F) {
+      const int j = __umulhi((unsigned)jh, magic_h), h = jh - j * H;
+      v = hp.W[j][(size_t)h * F + c0 + c];
+    }
     Ws[(size_t)jh * LD + c] = v;
   }
   if (tid < P * BN) {
     const int j = tid / BN, c = tid % BN;
     bs[tid] = (c0 + c < F) ? hp.b[j][c0 + c] : 0.f;
   }
-  if (tid == 0) *qcount = 0;
 
   // dW tile of this wave: rows h0..h0+31 (incl. the ones-row h == H -> db), columns n0..n0+31
   const int g2_h0 = (w >> 1) * 32, g2_n0 = (w & 1) * 32;
@@ -107,162 +119,203 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) accW[j][i] = 0.f;
 
-  // epilogue element ownership: row er, columns ec0 .. ec0+EPT-1
-  const int er = tid / TPR, ec0 = (tid % TPR) * EPT;
-  const int n_d = BM * H;                     // d-tile elements (contiguous in HBM)
+  float dv[DLOADS];          // next d tile: HBM -> registers (under GEMM1) -> LDS (after the epilogue)
+  float tv[EPT], up[RI];     // t / upstream weights of the element owner (loaded a step ahead)
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) tv[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < RI; ++i) up[i] = 0.f;
 
-  // register prefetch of the next tile (d: flat contiguous; t: one 256-byte row per wave)
-  float dv[DLOADS], tv[TLOADS];
-  auto prefetch = [&](int m0) {
-    const float* dbase = d + (size_t)m0 * H;
-    const int n_valid = min(R - m0, BM) * H;
+  // `tq` is an opaque copy of the thread index: per-thread addresses are re-derived in every
+  // phase instead of living in registers across the whole loop
+  auto load_d = [&](int m0, int tq) {
+    const float* dbase = d + (size_t)m0 * H + tq;
+    const int n_valid = (m0 < R) ? min(R - m0, BM) * H : 0;
 #pragma unroll
-    for (int i = 0; i < DLOADS; ++i) {
-      const int e = i * NT + tid;
-      dv[i] = (e < n_valid) ? dbase[e] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < TLOADS; ++i) {
-      const int r = i * (NT / BN) + (tid >> 6), c = tid & 63;
-      const int grow = m0 + r;
-      tv[i] = (grow < R && c0 + c < F) ? t[(size_t)(grow % B) * F + c0 + c] : 0.f;
-    }
+    for (int i = 0; i < DLOADS; ++i) dv[i] = (i * NT + tq < n_valid) ? dbase[i * NT] : 0.f;
   };
-  prefetch(0);
-
-  for (int m0 = 0; m0 < R; m0 += BM) {
-    // ---- registers -> LDS: d tile (+ ones column), t tile, upstream weights ----
+  auto store_d = [&](int m0, int buf, int tq) {
+    float* dst = dsh + (size_t)buf * DBUF;
+    const int n_d = BM * H;
 #pragma unroll
     for (int i = 0; i < DLOADS; ++i) {
-      const int e = i * NT + tid;
+      const int e = i * NT + tq;
       if (e < n_d) {
         const int r = __umulhi((unsigned)e, magic_h), h = e - r * H;
-        dsh[(size_t)r * LDD + h] = dv[i];
+        dst[r * LDD + h] = dv[i];
       }
     }
+    if (tq < BM) dst[tq * LDD + H] = (m0 + tq < R) ? 1.f : 0.f;
+  };
+  // element owner: rows er0 + 16 i, columns ec and ec + 32 (one 128-byte row segment per half
+  // wave: coalesced HBM loads, conflict-free LDS accesses with the odd stride)
+  auto load_t = [&](int m0, int tq) {
+    const int ec = tq & 31, er0 = tq >> 5;
+    if (m0 + BM <= R && c0 + BN <= F && R == B) {   // full tile, no row wrap: no predicates
+      const float* tp = t + (size_t)(m0 + er0) * F + c0 + ec;
 #pragma unroll
-    for (int i = 0; i < TLOADS; ++i)
-      ts[(size_t)(i * (NT / BN) + (tid >> 6)) * LD + (tid & 63)] = tv[i];
-    if (tid < BM) {
-      dsh[(size_t)tid * LDD + H] = (m0 + tid < R) ? 1.f : 0.f;
-      if (TRAIN) gws[tid] = (m0 + tid < R) ? gw[m0 + tid] : 0.f;
+      for (int ri = 0; ri < RI; ++ri) {
+        tv[2 * ri] = tp[(size_t)(16 * ri) * F];
+        tv[2 * ri + 1] = tp[(size_t)(16 * ri) * F + 32];
+        if (TRAIN) up[ri] = gw[m0 + er0 + 16 * ri];
+      }
+    } else {
+#pragma unroll
+      for (int ri = 0; ri < RI; ++ri) {
+        const int grow = m0 + er0 + 16 * ri;
+        const bool rok = grow < R;
+        up[ri] = (TRAIN && rok) ? gw[grow] : 0.f;
+        const float* trow = t + (size_t)(rok ? grow % B : 0) * F + c0;
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci) {
+          const int c = ec + 32 * ci;
+          tv[2 * ri + ci] = (rok && c0 + c < F) ? trow[c] : 0.f;
+        }
+      }
     }
-    __syncthreads();
+  };
 
-    // ---- GEMM1: pre_j = d W_j + b_j, 32x32 tiles spread over the waves -> LDS ----
-    for (int x = w; x < P * MT * 2; x += NT / 64) {
-      const int j = x / (MT * 2), mt = (x / 2) % MT, nt = x & 1;
-      f32x16 acc;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-      const float* arow = dsh + (size_t)(mt * 32 + li) * LDD + kh;      // A[i=row][k=h]
-      const float* bcol = Ws + ((size_t)j * H + kh) * LD + nt * 32 + li; // B[k=h][n=col]
-#pragma unroll 10
-      for (int k = 0; k < H; k += 2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[k], bcol[(size_t)k * LD], acc, 0, 0, 0);
-      const float bv = bs[j * BN + nt * 32 + li];
-      float* out = Gs + ((size_t)j * BM + mt * 32 + 4 * kh) * LD + nt * 32 + li;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) out[(size_t)((r & 3) + 8 * (r >> 2)) * LD] = acc[r] + bv;
-    }
-    __syncthreads();
+  load_d(0, tid);
+  store_d(0, 0, tid);
+  load_t(0, tid);
+  __syncthreads();
 
-    // next tile's HBM loads fly under the epilogue and GEMM2/GEMM3
-    if (m0 + BM < R) prefetch(m0 + BM);
-
-    // ---- likelihood epilogue, dense part: EPT elements of one row per thread; G_j in place.
-    //      Elements with t > 0 of the negative-binomial kinds are queued for the correction
-    //      lgamma(r+t)-lgamma(r) / digamma(r+t)-digamma(r) (5 % of a count matrix). ----
-    float lsum = 0.f;
-    const bool row_ok = m0 + er < R;
+  // with one d buffer the next tile can only be stored once GEMM2 has read the current one
+  const bool store_early = !TRAIN || d_buffers == 2;
+  int buf = 0;
+  for (int m0 = 0; m0 < R; m0 += BM, buf ^= (d_buffers - 1)) {
+    const float* dcur = dsh + (size_t)buf * DBUF;
     {
-      const float up = TRAIN ? gws[er] : 0.f;
+      // ---- GEMM1: pre_j = d W_j + b_j, 32x32 tiles spread over the waves -> LDS ----
+      const int tq = df_opaque(tid);
+      load_d(m0 + BM, tq);                    // next d tile -> registers
+      for (int x = w; x < P * MT * 2; x += NT / 64) {
+        const int j = x / (MT * 2), mt = (x / 2) % MT, nt = x & 1;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const float* arow = dcur + (mt * 32 + li) * LDD + kh;        // A[i=row][k=h]
+        const float* bcol = Ws + (j * H + kh) * LD + nt * 32 + li;   // B[k=h][n=col]
+        int kk = 0;
+        for (; kk + 20 <= H; kk += 20) {
+#pragma unroll
+          for (int u = 0; u < 20; u += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[kk + u], bcol[(kk + u) * LD], acc, 0, 0,
+                                                       0);
+        }
+        for (; kk < H; kk += 2)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[kk], bcol[kk * LD], acc, 0, 0, 0);
+        const float bv = bs[j * BN + nt * 32 + li];
+        float* out = Gs + (j * BM + mt * 32 + 4 * kh) * LD + nt * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2)) * LD] = acc[r] + bv;
+      }
+    }
+    lds_barrier();
+    {
+      // ---- likelihood epilogue in registers; G_j in place of pre_j.  Elements with t > 0 of
+      //      the negative-binomial kinds are compacted per wave (ballots) into a wave-private
+      //      queue for the correction lgamma(r+t)-lgamma(r) / digamma(r+t)-digamma(r), so that
+      //      the expensive code runs on dense lanes (5 % of a count matrix is non-zero) ----
+      const int tq = df_opaque(tid);
+      const int ln = tq & 63;
+      const int ec = tq & 31, er0 = tq >> 5;
+      float* q0 = qbase + (tq >> 6) * 4 * DF_QCAP;                    // r -> A
+      float* q1 = q0 + DF_QCAP;                                       // t
+      float* q2 = q1 + DF_QCAP;                                       // upstream * gate
+      int* q3 = reinterpret_cast<int*>(q2 + DF_QCAP);                 // LDS offset row*LD + col
+      float lsum[RI];
+      int slot[EPT];
+      int q_n = 0;
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
-        const int c = ec0 + e;
-        const bool ok = row_ok && (c0 + c < F);
+        const int ri = e >> 1, ci = e & 1;
+        const int row = er0 + 16 * ri, c = ec + 32 * ci;
+        const bool ok = (m0 + row < R) && (c0 + c < F);
+        const float tval = tv[e];
         float a[P], g[P], lp, r, rgate;
 #pragma unroll
-        for (int j = 0; j < P; ++j) a[j] = Gs[((size_t)j * BM + er) * LD + c];
-        const float tval = ts[(size_t)er * LD + c];
+        for (int j = 0; j < P; ++j) a[j] = Gs[(j * BM + row) * LD + c];
         lik_dense<KIND, TRAIN>(tval, a, lp, g, r, rgate);
-        float corr = 0.f;   // value left in the t tile: summed into the row's log-likelihood
-        if (ok && tval > 0.f) {
-          bool queued = false;
-          if (Traits::HAS_R) {
-            const int slot = atomicAdd(qcount, 1);
-            if (slot < DF_QUEUE) {
-              qidx[slot] = er * BN + c;
-              qr[slot] = r;
-              qs[slot] = up * rgate;
-              queued = true;
-              corr = tval;   // the queue pass replaces it by the correction
-            }
-          }
-          if (!queued) {
-            if (Traits::HAS_R) {   // queue full (dense data): correct in place
+        const bool nz = ok && tval > 0.f;
+        slot[e] = -1;
+        if (Traits::HAS_R) {
+          const unsigned long long mask = __ballot(nz);
+          if (nz) {
+            const int s = q_n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            if (s < DF_QCAP) {
+              slot[e] = s;
+              q0[s] = r;
+              q1[s] = tval;
+              q2[s] = up[ri] * rgate;
+              q3[s] = row * LD + c;
+            } else {   // queue full (dense data): correct in place
               float A, D;
               lgamma_digamma_diff<TRAIN>(r, tval, A, D);
               lp += A;
               if (TRAIN) g[P - 1] += rgate * r * D;
+              if (inline_lgamma) lp -= lgamma1p(tval);
             }
-            if (inline_lgamma) lp -= lgamma1p(tval);
           }
+          q_n += __popcll(mask);
+        } else if (nz && inline_lgamma) {
+          lp -= lgamma1p(tval);
         }
-        lsum += ok ? lp : 0.f;
-        ts[(size_t)er * LD + c] = corr;
+        if (ci == 0) lsum[ri] = ok ? lp : 0.f;
+        else lsum[ri] += ok ? lp : 0.f;
         if (TRAIN) {
 #pragma unroll
-          for (int j = 0; j < P; ++j) Gs[((size_t)j * BM + er) * LD + c] = ok ? up * g[j] : 0.f;
+          for (int j = 0; j < P; ++j) Gs[(j * BM + row) * LD + c] = ok ? up[ri] * g[j] : 0.f;
         }
+        asm volatile("" ::: "memory");   // one element at a time: keeps the register peak low
       }
+      if (Traits::HAS_R) {
+        df_wave_fence();
+        const int n_q = min(q_n, DF_QCAP);
+        for (int s = ln; s < n_q; s += 64) {
+          const float r = q0[s], tval = q1[s];
+          float A, D;
+          lgamma_digamma_diff<TRAIN>(r, tval, A, D);
+          if (inline_lgamma) A -= lgamma1p(tval);
+          q0[s] = A;
+          if (TRAIN) Gs[(P - 1) * BM * LD + q3[s]] += q2[s] * r * D;
+        }
+        df_wave_fence();
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+          if (slot[e] >= 0) lsum[e >> 1] += q0[slot[e]];
+        df_wave_fence();   // the queue is reused in the next step
+      }
+      // ---- per-row partial log-likelihood of this strip ----
+#pragma unroll
+      for (int ri = 0; ri < RI; ++ri) {
+        float sum = lsum[ri];
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) sum += __shfl_xor(sum, off, WAVE);
+        const int grow = m0 + er0 + 16 * ri;
+        if (ec == 0 && grow < R) ll_part[(size_t)blockIdx.x * R + grow] = sum;
+      }
+      // next step's operands: d tile -> the other LDS buffer, t / upstream -> registers
+      if (store_early) store_d(m0 + BM, buf ^ (d_buffers - 1), tq);
+      if (m0 + BM < R) load_t(m0 + BM, tq);
     }
     lds_barrier();
-    if (Traits::HAS_R) {
-      const int n_q = min(*qcount, DF_QUEUE);
-      for (int s = tid; s < n_q; s += NT) {
-        const int idx = qidx[s];
-        const int row = idx >> 6, c = idx & 63;
-        const float tval = ts[(size_t)row * LD + c];
-        const float r = qr[s];
-        float A, D;
-        lgamma_digamma_diff<TRAIN>(r, tval, A, D);
-        if (inline_lgamma) A -= lgamma1p(tval);
-        ts[(size_t)row * LD + c] = A;
-        if (TRAIN) Gs[((size_t)(P - 1) * BM + row) * LD + c] += qs[s] * r * D;
-      }
-      lds_barrier();
-      if (tid == 0) *qcount = 0;
-    }
-    // ---- per-row partial log-likelihood of this strip (dense part + corrections) ----
-    {
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) lsum += ts[(size_t)er * LD + ec0 + e];
-#pragma unroll
-      for (int off = 1; off < TPR; off <<= 1) lsum += __shfl_xor(lsum, off, WAVE);
-      if ((tid % TPR) == 0 && row_ok) ll_part[(size_t)blockIdx.x * R + m0 + er] = lsum;
-    }
-    if (!TRAIN) {
-      lds_barrier();
-      continue;
-    }
-
-    // ---- GEMM2: dW_j[h, col] += sum_row d[row, h] G_j[row, col]   (M = h, N = col, K = row);
-    //      row h == H of d^T is all ones, so that row of the result is db_j ----
-    if (g2_h0 <= H) {
-      const float* ap = dsh + (size_t)kh * LDD + g2_h0 + li;        // A[i=h][k=row] = d[row][h]
-      const float* bp = Gs + (size_t)kh * LD + g2_n0 + li;          // B[k=row][n=col]
+    if (TRAIN) {
+      // ---- GEMM2: dW_j[h, col] += sum_row d[row, h] G_j[row, col]   (M = h, N = col, K = row);
+      //      row h == H of d^T is all ones, so that row of the result is db_j ----
+      if (g2_h0 <= H) {
+        const float* ap = dcur + kh * LDD + g2_h0 + li;                // A[i=h][k=row] = d[row][h]
+        const float* bp = Gs + kh * LD + g2_n0 + li;                   // B[k=row][n=col]
 #pragma unroll 8
-      for (int k = 0; k < BM; k += 2) {
-        const float a = ap[(size_t)k * LDD];
+        for (int k = 0; k < BM; k += 2) {
+          const float a = ap[k * LDD];
 #pragma unroll
-        for (int j = 0; j < P; ++j)
-          accW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[((size_t)j * BM + k) * LD], accW[j],
-                                                         0, 0, 0);
+          for (int j = 0; j < P; ++j)
+            accW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[(j * BM + k) * LD], accW[j], 0, 0, 0);
+        }
       }
-    }
-    // ---- GEMM3: dd[row, h] = sum_j sum_col G_j[row, col] W_j[h, col]   (M = row, N = h, K = col)
-    {
+      // ---- GEMM3: dd[row, h] = sum_j sum_col G_j[row, col] W_j[h, col]   (M = row, N = h, K = col)
       const int mt = w % MT, h0 = (w / MT) * 32;
       if (h0 < H && w < MT * 4) {
         f32x16 accD;
@@ -270,23 +323,34 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
         for (int i = 0; i < 16; ++i) accD[i] = 0.f;
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-          const float* ap = Gs + ((size_t)j * BM + mt * 32 + li) * LD + kh;   // A[i=row][k=col]
-          const float* bp = Ws + ((size_t)j * H + h0 + li) * LD + kh;         // B[k=col][n=h]
+          const float* ap = Gs + (j * BM + mt * 32 + li) * LD + kh;    // A[i=row][k=col]
+          const float* bp = Ws + (j * H + h0 + li) * LD + kh;          // B[k=col][n=h]
 #pragma unroll 8
           for (int k = 0; k < BN; k += 2)
             accD = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bp[k], accD, 0, 0, 0);
         }
         const int h = h0 + li;
         if (h < H) {
+          const int r0 = m0 + mt * 32 + 4 * kh;
+          float* dst = dd_part + ((size_t)blockIdx.x * R + r0) * H + h;
+          if (m0 + BM <= R) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int grow = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (grow < R) dd_part[((size_t)blockIdx.x * R + grow) * H + h] = accD[r];
+            for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * H] = accD[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int ro = (r & 3) + 8 * (r >> 2);
+              if (r0 + ro < R) dst[ro * H] = accD[r];
+            }
           }
         }
       }
+      lds_barrier();
+      if (!store_early) {
+        store_d(m0 + BM, 0, df_opaque(tid));
+        lds_barrier();
+      }
     }
-    lds_barrier();
   }
 
   if (!TRAIN) return;
@@ -374,11 +438,26 @@ size_t decoder_fused_workspace_floats(int rows, int H, int F, bool train) {
   return n + 64;
 }
 
+// 2 (default): two pipelined halves per workgroup (decoder_fused2.hip) where its LDS budget and
+// head count allow; 1: one 8-wave workgroup per strip (this file).  SCVAE_DECODER_VARIANT=1
+// forces the latter (A/B measurements).
+static int g_decoder_variant = 0;
+static int decoder_variant() {
+  if (g_decoder_variant == 0) {
+    const char* e = getenv("SCVAE_DECODER_VARIANT");
+    g_decoder_variant = (e && e[0] == '1') ? 1 : 2;
+  }
+  return g_decoder_variant;
+}
+
 template <bool TRAIN>
 static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                           int F, const float* t, int B, const float* gw, int inline_lgamma,
                           float* ll_part, float* dd_part) {
   const int P = likelihood_heads(kind);
+  if (decoder_variant() == 2 && decoder_fused2_supported(P, H))
+    return decoder_fused2_launch(s, TRAIN, kind, d, rows, H, hp, F, t, B, gw, inline_lgamma, ll_part,
+                                 dd_part);
   const size_t lds = decoder_fused_lds_bytes(P, H, TRAIN);
   const int strips = (F + DF_BN - 1) / DF_BN;
   // e / H == umulhi(e, magic_h) for every e < 2^16 used here (H <= 126)
@@ -389,7 +468,7 @@ static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int
     SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
     hipLaunchKernelGGL(kfn, dim3(strips), dim3(DF_THREADS), lds, s, d, rows, H, magic_h, hp, F, t, \
-                       B, gw, inline_lgamma, ll_part, dd_part);                                   \
+                       B, gw, inline_lgamma, ll_part, dd_part, df_d_buffers(P, H));               \
   } while (0)
   switch (kind) {
     case LK_POISSON: SCVAE_DF(LK_POISSON); break;

@@ -1,0 +1,446 @@
+// Two-half software-pipelined variant of the fused decoder output layer (see decoder_fused.hip
+// for the maths and the reference lines).  Same inputs, outputs and per-strip partial buffers.
+//
+// One workgroup = 16 waves = two halves of 8 waves that share the strip's weights in LDS and walk
+// over alternating 32-row tiles.  A half alternates between
+//     an MFMA slot:  GEMM2 dW_j += d^T G_j (8 waves), then GEMM3 dd = sum_j G_j W_j^T (waves 0-3)
+//                    of tile k-1 next to GEMM1 pre_j = d W_j of tile k (waves 4-7, result kept in
+//                    registers); the HBM loads of t (tile k) and d (tile k+1) are issued here;
+//     a hand-over:   pre_j + b_j and the d tile k+1 go to LDS (short);
+//     a VALU slot:   likelihood epilogue of tile k (all 8 waves): G_j -> LDS, ll partials;
+// and half B runs two slots behind half A, so that while one half feeds the MFMA pipe (two MFMA
+// waves per SIMD) the other half does the VALU / LDS work of the epilogue (two VALU waves per
+// SIMD): the matrix cores do not wait for the likelihood math any more.  The only synchronisation
+// is one workgroup barrier per slot; the d tile is double buffered.
+//
+// The t > 0 corrections of the negative-binomial kinds (lgamma / digamma differences; 5 % of a
+// count matrix) are compacted per wave with ballots into a wave-private LDS queue, so that the
+// expensive code runs once per wave on dense lanes instead of four times on sparse lanes; no
+// LDS atomics, summation order fixed (deterministic).
+#include "common.hpp"
+#include "kernels.hpp"
+#include "likelihood.hpp"
+
+namespace scvae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int D2_THREADS = 1024;  // 16 waves: 4 per SIMD
+constexpr int D2_HALF = 512;
+constexpr int D2_BN = 64;         // columns (genes) per workgroup
+constexpr int D2_LD = D2_BN + 1;  // odd LDS row stride
+constexpr int D2_BM = 32;         // rows per tile (per half)
+constexpr int D2_QCAP = 64;       // wave-private queue capacity (t > 0 elements per 256)
+
+__host__ __device__ inline int d2_ldd(int H) { return H | 1; }
+
+static size_t d2_half_floats(int P, int H) {
+  return 2 * ((size_t)D2_BM * d2_ldd(H) + 32)  // dsh x 2 (+ slack for the padded h tile)
+         + (size_t)P * D2_BM * D2_LD           // Gs
+         + 8 * 4 * D2_QCAP;                    // 8 wave-private queues x 4 fields
+}
+
+size_t decoder_fused2_lds_bytes(int P, int H) {
+  size_t floats = (size_t)P * H * D2_LD + 3 * D2_BN + 2 * d2_half_floats(P, H) + 64;
+  // over-reads of the padded h tiles (h up to 127) must stay inside the allocation
+  const size_t need = (size_t)((P - 1) * H + 128) * D2_LD + 64;
+  if (floats < need) floats = need;
+  // the final dW combine parks half B's accumulators: P x 8 waves x 16 x 64 floats
+  const size_t park = (size_t)P * 8 * 16 * 64;
+  if (floats < park) floats = park;
+  return floats * sizeof(float);
+}
+
+bool decoder_fused2_supported(int P, int H) {
+  return P <= 2 && H >= 2 && H <= 126 && (H % 2) == 0 &&
+         decoder_fused2_lds_bytes(P, H) <= 160 * 1024;
+}
+
+__device__ __forceinline__ int opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+__device__ __forceinline__ void lds_wave_fence() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <int KIND, bool TRAIN>
+__global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
+    const float* __restrict__ d, int R, int H, unsigned magic_h, HeadParams hp, int F,
+    const float* __restrict__ t, int B, const float* __restrict__ gw, int inline_lgamma,
+    float* __restrict__ ll_part, float* __restrict__ dd_part) {
+  using Traits = LikelihoodTraits<KIND>;
+  constexpr int P = Traits::P;
+  constexpr int BN = D2_BN, LD = D2_LD, BM = D2_BM, NH = D2_HALF;
+  constexpr int DLOADS = (BM * 126 + NH - 1) / NH;   // upper bound of d elements per thread
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int LDD = d2_ldd(H);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches
+  const int half = w >> 3, hw = w & 7, th = tid & (NH - 1);
+  const int kh = lane >> 5, li = lane & 31;
+  const int c0 = blockIdx.x * BN;
+
+  float* Ws = smem;                                   // [P][H][LD]
+  float* bs = Ws + (size_t)P * H * LD;                // [3][BN]
+  const size_t DBUF = (size_t)BM * LDD + 32;          // one d tile (+32 slack)
+  const size_t half_floats = 2 * DBUF + (size_t)P * BM * LD + 8 * 4 * D2_QCAP;
+  float* hbase = bs + 3 * BN + (size_t)half * half_floats;
+  float* dsh = hbase;                                 // [2][BM][LDD]; column H = 1
+  float* Gs = dsh + 2 * DBUF;                         // [P][BM][LD]: pre_j, then G_j
+
+  // ---- strip weights and biases -> LDS (once) ----
+  for (int i = tid; i < P * H * BN; i += D2_THREADS) {
+    const int c = i & (BN - 1);
+    const int jh = i >> 6;  // j*H + h
+    float v = 0.f;
+    if (c0 + c < F) {
+      const int j = __umulhi((unsigned)jh, magic_h), h = jh - j * H;
+      v = hp.W[j][(size_t)h * F + c0 + c];
+    }
+    Ws[(size_t)jh * LD + c] = v;
+  }
+  if (tid < P * BN) {
+    const int j = tid / BN, c = tid % BN;
+    bs[tid] = (c0 + c < F) ? hp.b[j][c0 + c] : 0.f;
+  }
+
+  // dW tile of this wave: rows h0..h0+31 (incl. the ones-row h == H -> db), columns n0..n0+31
+  const int g2_h0 = (hw >> 1) * 32, g2_n0 = (hw & 1) * 32;
+  f32x16 accW[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accW[j][i] = 0.f;
+
+  float dv[DLOADS];            // next d tile, in flight from the MFMA slot to the hand-over
+  float tv[4] = {0.f, 0.f, 0.f, 0.f}, up[2] = {0.f, 0.f};   // in flight until the VALU slot
+
+  // `tq` is an opaque copy of the thread's index within its half: the per-thread addresses are
+  // re-derived in every slot instead of living in (spilled) registers across the whole loop.
+  auto load_d = [&](int m0, int tq) {
+    const float* dbase = d + (size_t)m0 * H + tq;
+    const int n_valid = (m0 < R) ? min(R - m0, BM) * H : 0;
+#pragma unroll
+    for (int i = 0; i < DLOADS; ++i) {
+      // (the first loads of a full tile need no predicate: BM * H >= 64 * (i + 1) * 8 ...)
+      dv[i] = (i * NH + tq < n_valid) ? dbase[i * NH] : 0.f;
+    }
+  };
+  auto store_d = [&](int m0, int buf, int tq) {
+    float* dst = dsh + (size_t)buf * DBUF;
+    const int n_d = BM * H;
+#pragma unroll
+    for (int i = 0; i < DLOADS; ++i) {
+      const int e = i * NH + tq;
+      if (e < n_d) {
+        const int r = __umulhi((unsigned)e, magic_h), h = e - r * H;
+        dst[r * LDD + h] = dv[i];
+      }
+    }
+    if (tq < BM) dst[tq * LDD + H] = (m0 + tq < R) ? 1.f : 0.f;
+  };
+
+  const int n_tiles = (R + BM - 1) / BM;
+  const int n_a = (n_tiles + 1) / 2;         // tiles of half A (half B: the odd ones)
+
+  // both halves stage their first tile (tile index = half) into d buffer 0
+  load_d(half * BM, th);
+  store_d(half * BM, 0, th);
+  __syncthreads();
+
+  f32x16 accX;   // GEMM3 (waves 0-3) / GEMM1 (waves 4-7) accumulator, held until the hand-over
+  const int g1_job = hw - 4;                 // GEMM1: head g1_job >> 1, column tile g1_job & 1
+  const bool g1_wave = g1_job >= 0 && g1_job < 2 * P;
+  const bool g3_wave = hw < 4 && hw * 32 < H;
+
+  // Slot schedule (one workgroup barrier after every slot; the slot order is static so that the
+  // register allocator sees the short live ranges of accX / dv / tv):
+  //   A:  M(0) H(0) V(0)  -   M(1) H(1) V(1)  -   ...
+  //   B:   -    -   M(0) H(0) V(0)  -   M(1) H(1) V(1) ...
+  if (half) {
+    lds_barrier();
+    lds_barrier();
+  }
+  const int n_iter = n_a + 1;                // the last iteration drains GEMM2/GEMM3 of the last tile
+  for (int k = 0; k < n_iter; ++k) {
+    const int m0 = (2 * k + half) * BM;      // tile k of this half
+    const int mp = m0 - 2 * BM;              // tile k-1
+    const bool live = m0 < R;
+    const bool live_prev = (k >= 1) && (mp < R);
+    {
+      // ============ MFMA slot: GEMM2 + GEMM3 of tile k-1, GEMM1 of tile k ============
+      __builtin_amdgcn_s_setprio(3);   // MFMA waves first; the other half's VALU work fills the gaps
+      const int tq = opaque(th);
+      const int li = tq & 31, kh = (tq >> 5) & 1;
+      const float* dprev = dsh + (size_t)((k - 1) & 1) * DBUF;
+      const float* dcur = dsh + (size_t)(k & 1) * DBUF;
+      // ---- GEMM2: dW_j[h, col] += sum_row d[row, h] G_j[row, col]; row h == H gives db_j ----
+      if (TRAIN && live_prev && g2_h0 <= H) {
+        const float* ap = dprev + kh * LDD + g2_h0 + li;              // A[i=h][k=row]
+        const float* bp = Gs + kh * LD + g2_n0 + li;                  // B[k=row][n=col]
+#pragma unroll 8
+        for (int kk = 0; kk < BM; kk += 2) {
+          const float a = ap[kk * LDD];
+#pragma unroll
+          for (int j = 0; j < P; ++j)
+            accW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[(j * BM + kk) * LD], accW[j], 0, 0,
+                                                           0);
+        }
+      }
+      // ---- HBM loads: d tile k+1 (stored in the hand-over), t / upstream of tile k (VALU slot);
+      //      they fly under GEMM3 / GEMM1 ----
+      load_d(m0 + 2 * BM, tq);
+      if (live) {
+        const int ec = tq & 31, er0 = tq >> 5;
+        if (m0 + BM <= R && c0 + BN <= F && R == B) {   // full tile, no row wrap: no predicates
+          const float* tp = t + (size_t)(m0 + er0) * F + c0 + ec;
+          tv[0] = tp[0];
+          tv[1] = tp[32];
+          tv[2] = tp[(size_t)16 * F];
+          tv[3] = tp[(size_t)16 * F + 32];
+          if (TRAIN) {
+            up[0] = gw[m0 + er0];
+            up[1] = gw[m0 + er0 + 16];
+          }
+        } else {
+#pragma unroll
+          for (int ri = 0; ri < 2; ++ri) {
+            const int grow = m0 + er0 + 16 * ri;
+            const bool rok = grow < R;
+            up[ri] = (TRAIN && rok) ? gw[grow] : 0.f;
+            const float* trow = t + (size_t)(rok ? grow % B : 0) * F + c0;
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+              const int c = ec + 32 * ci;
+              tv[ri * 2 + ci] = (rok && c0 + c < F) ? trow[c] : 0.f;
+            }
+          }
+        }
+      }
+      if (hw < 4) {
+        // ---- GEMM3: dd[row, h] = sum_j sum_col G_j[row, col] W_j[h, col] ----
+        if (TRAIN && live_prev && g3_wave) {
+          const int h0 = hw * 32;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) accX[i] = 0.f;
+#pragma unroll
+          for (int j = 0; j < P; ++j) {
+            const float* ap = Gs + (j * BM + li) * LD + kh;           // A[i=row][k=col]
+            const float* bp = Ws + (j * H + h0 + li) * LD + kh;       // B[k=col][n=h]
+#pragma unroll 8
+            for (int kk = 0; kk < BN; kk += 2)
+              accX = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk], accX, 0, 0, 0);
+          }
+        }
+      } else if (g1_wave && live) {
+        // ---- GEMM1: pre_j = d W_j (+ b_j in the hand-over), one 32x32 tile per wave ----
+        const int j = g1_job >> 1, nt = g1_job & 1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accX[i] = 0.f;
+        const float* arow = dcur + li * LDD + kh;                     // A[i=row][k=h]
+        const float* bcol = Ws + (j * H + kh) * LD + nt * 32 + li;    // B[k=h][n=col]
+        int kk = 0;
+        for (; kk + 20 <= H; kk += 20) {
+#pragma unroll
+          for (int u = 0; u < 20; u += 2)
+            accX = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[kk + u], bcol[(kk + u) * LD], accX, 0,
+                                                        0, 0);
+        }
+        for (; kk < H; kk += 2)
+          accX = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[kk], bcol[kk * LD], accX, 0, 0, 0);
+      }
+      // the d loads have landed by now: consume the wait here, before the dd stores are issued,
+      // so that the hand-over does not wait for the stores
+#pragma unroll
+      for (int i = 0; i < DLOADS; ++i) asm volatile("" : "+v"(dv[i]));
+      if (TRAIN && live_prev && g3_wave) {
+        const int h = hw * 32 + li;
+        if (h < H) {
+          float* dst = dd_part + ((size_t)blockIdx.x * R + mp + 4 * kh) * H + h;
+          if (mp + BM <= R) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * H] = accX[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int ro = (r & 3) + 8 * (r >> 2);
+              if (mp + 4 * kh + ro < R) dst[ro * H] = accX[r];
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    lds_barrier();
+    {
+      // ============ hand-over (short): d tile k+1 and pre_j of tile k -> LDS ============
+      const int tq = opaque(th);
+      const int li = tq & 31, kh = (tq >> 5) & 1;
+      store_d(m0 + 2 * BM, (k + 1) & 1, tq);
+      if (g1_wave && live) {
+        const int j = g1_job >> 1, nt = g1_job & 1;
+        const float bv = bs[j * BN + nt * 32 + li];
+        float* out = Gs + (j * BM + 4 * kh) * LD + nt * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2)) * LD] = accX[r] + bv;
+      }
+    }
+    lds_barrier();
+    // ============ VALU slot: likelihood epilogue of tile k ============
+    // 2 rows x 2 columns per thread (one 128-byte row segment per half wave: coalesced t loads,
+    // conflict-free LDS accesses with the odd stride); G_j written in place of pre_j
+    if (live) {
+      const int tq = opaque(th);
+      const int lane = tq & 63;
+      const int ec = tq & 31, er0 = tq >> 5;
+      float* q0 = Gs + P * BM * LD + ((tq >> 6) & 7) * 4 * D2_QCAP;   // wave-private queue: r -> A
+      float* q1 = q0 + D2_QCAP;                                        // t
+      float* q2 = q1 + D2_QCAP;                                        // upstream * gate
+      int* q3 = reinterpret_cast<int*>(q2 + D2_QCAP);                  // LDS offset row*LD + col
+      float lsum[2] = {0.f, 0.f};
+      int slot[4];
+      int q_base = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ri = e >> 1, ci = e & 1;
+        const int row = er0 + 16 * ri, c = ec + 32 * ci;
+        const bool ok = (m0 + row < R) && (c0 + c < F);
+        const float tval = tv[e];
+        float a[P], g[P], lp, r, rgate;
+#pragma unroll
+        for (int j = 0; j < P; ++j) a[j] = Gs[(j * BM + row) * LD + c];
+        lik_dense<KIND, TRAIN>(tval, a, lp, g, r, rgate);
+        const bool nz = ok && tval > 0.f;
+        slot[e] = -1;
+        if (Traits::HAS_R) {
+          const unsigned long long mask = __ballot(nz);
+          if (nz) {
+            const int s = q_base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            if (s < D2_QCAP) {
+              slot[e] = s;
+              q0[s] = r;
+              q1[s] = tval;
+              q2[s] = up[ri] * rgate;
+              q3[s] = row * LD + c;
+            } else {   // queue full (dense data): correct in place
+              float A, D;
+              lgamma_digamma_diff<TRAIN>(r, tval, A, D);
+              lp += A;
+              if (TRAIN) g[P - 1] += rgate * r * D;
+              if (inline_lgamma) lp -= lgamma1p(tval);
+            }
+          }
+          q_base += __popcll(mask);
+        } else if (nz && inline_lgamma) {
+          lp -= lgamma1p(tval);
+        }
+        lsum[ri] += ok ? lp : 0.f;
+        if (TRAIN) {
+#pragma unroll
+          for (int j = 0; j < P; ++j) Gs[(j * BM + row) * LD + c] = ok ? up[ri] * g[j] : 0.f;
+        }
+        asm volatile("" ::: "memory");   // one element at a time: keeps the register peak low
+      }
+      if (Traits::HAS_R) {
+        // ---- queue pass: one queued element per lane ----
+        lds_wave_fence();
+        const int n_q = min(q_base, D2_QCAP);
+        if (lane < n_q) {
+          const float r = q0[lane], tval = q1[lane];
+          float A, D;
+          lgamma_digamma_diff<TRAIN>(r, tval, A, D);
+          if (inline_lgamma) A -= lgamma1p(tval);
+          q0[lane] = A;
+          if (TRAIN) Gs[(P - 1) * BM * LD + q3[lane]] += q2[lane] * r * D;
+        }
+        lds_wave_fence();
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (slot[e] >= 0) lsum[e >> 1] += q0[slot[e]];
+        lds_wave_fence();   // the queue is reused by this wave's next tile
+      }
+      // ---- per-row partial log-likelihood of this strip ----
+#pragma unroll
+      for (int ri = 0; ri < 2; ++ri) {
+        float s = lsum[ri];
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) s += __shfl_xor(s, off, WAVE);
+        const int grow = m0 + er0 + 16 * ri;
+        if (ec == 0 && grow < R) ll_part[(size_t)blockIdx.x * R + grow] = s;
+      }
+    }
+    lds_barrier();
+    lds_barrier();
+  }
+  if (!half) {
+    lds_barrier();
+    lds_barrier();
+  }
+
+  if (!TRAIN) return;
+  // ---- combine the two halves' dW accumulators (B parks in LDS, A adds and writes) ----
+  __syncthreads();
+  float* park = smem + (size_t)hw * P * 16 * 64;
+  if (half == 1) {
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) park[(j * 16 + r) * 64 + lane] = accW[j][r];
+  }
+  __syncthreads();
+  if (half == 0 && g2_h0 <= H) {
+    const int c = c0 + g2_n0 + li;
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = accW[j][r] + park[(j * 16 + r) * 64 + lane];
+        const int h = g2_h0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (c < F) {
+          if (h < H) hp.dW[j][(size_t)h * F + c] = v;
+          else if (h == H) hp.db[j][c] = v;
+        }
+      }
+  }
+}
+
+template <bool TRAIN>
+static int launch_decoder2(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
+                           int F, const float* t, int B, const float* gw, int inline_lgamma,
+                           float* ll_part, float* dd_part) {
+  const int P = likelihood_heads(kind);
+  const size_t lds = decoder_fused2_lds_bytes(P, H);
+  const int strips = (F + D2_BN - 1) / D2_BN;
+  const unsigned magic_h = (unsigned)(0x100000000ull / (unsigned)H) + 1u;
+#define SCVAE_D2(K_)                                                                              \
+  do {                                                                                            \
+    auto kfn = decoder_head2_kernel<K_, TRAIN>;                                                   \
+    SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
+    hipLaunchKernelGGL(kfn, dim3(strips), dim3(D2_THREADS), lds, s, d, rows, H, magic_h, hp, F,   \
+                       t, B, gw, inline_lgamma, ll_part, dd_part);                                \
+  } while (0)
+  switch (kind) {
+    case LK_POISSON: SCVAE_D2(LK_POISSON); break;
+    case LK_NB: SCVAE_D2(LK_NB); break;
+    case LK_ZIP: SCVAE_D2(LK_ZIP); break;
+    case LK_ZINB: SCVAE_D2(LK_ZINB); break;
+    default: set_error("unknown likelihood kind %d", kind); return -1;
+  }
+#undef SCVAE_D2
+  SCVAE_LAUNCH_CHECK("decoder_head2_kernel");
+  return 0;
+}
+
+int decoder_fused2_launch(hipStream_t s, bool train, int kind, const float* d, int rows, int H,
+                          HeadParams hp, int F, const float* t, int B, const float* gw,
+                          int inline_lgamma, float* ll_part, float* dd_part) {
+  return train ? launch_decoder2<true>(s, kind, d, rows, H, hp, F, t, B, gw, inline_lgamma, ll_part,
+                                       dd_part)
+               : launch_decoder2<false>(s, kind, d, rows, H, hp, F, t, B, gw, inline_lgamma,
+                                        ll_part, dd_part);
+}
+
+}  // namespace scvae

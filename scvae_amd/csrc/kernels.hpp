@@ -85,6 +85,11 @@ struct HeadParams {
 bool decoder_fused_supported(int H);
 size_t decoder_fused_workspace_floats(int rows, int H, int F, bool train);
 size_t decoder_fused_lds_bytes(int P, int H, bool train);
+bool decoder_fused2_supported(int P, int H);
+size_t decoder_fused2_lds_bytes(int P, int H);
+int decoder_fused2_launch(hipStream_t s, bool train, int kind, const float* d, int rows, int H,
+                          HeadParams hp, int F, const float* t, int B, const float* gw,
+                          int inline_lgamma, float* ll_part, float* dd_part);
 int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                           int F, const float* t, int B, const float* row_const, float* ll,
                           float* workspace);
