@@ -208,13 +208,20 @@ def main():
                 .format(args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback).")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # (several ranks may share a GPU in the 1-GPU debugging set-up below)
+    local_device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_device)
+    device = torch.device("cuda", local_device)
 
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        # RCCL; SCVAE_BENCH_BACKEND=gloo only to exercise the N > 1 code path on a 1-GPU box
+        backend = os.environ.get("SCVAE_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from scvae_amd.engine import Engine
     from scvae_amd.minibatch import philox_normal, synthetic_count_matrix

@@ -31,6 +31,7 @@ static int build_vae(scvae_plan* p) {
     snprintf(scope, sizeof scope, "ENCODER/%d", i + 1);
     p->enc.push_back(L.dense(scope, n_in, c.hidden[i], bn));
     n_in = c.hidden[i];
+    if (i == 0) p->early_reduce_start = L.n_params;   // everything after ENCODER/1
   }
   p->mu = L.dense("POSTERIOR/MU", n_in, c.latent_size, false);
   p->ls = L.dense("POSTERIOR/LOG_SIGMA", n_in, c.latent_size, false);
@@ -46,6 +47,9 @@ static int build_vae(scvae_plan* p) {
     snprintf(scope, sizeof scope, "X_TILDE/%s", head_names(c.likelihood, j));
     p->heads[j] = L.dense(scope, n_in, c.feature_size, false);
   }
+  // the first encoder layer's dW (x^T dA, the last large GEMM of the backward pass) is the only
+  // gradient still missing when the hook is told that the rest may be all-reduced
+  if (!p->enc.empty()) p->early_reduce_layer = &p->enc[0];
   return 0;
 }
 
@@ -205,6 +209,13 @@ int dense_backward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int 
   if ((rc = dense_backward_activation(p, s, d, rows, groups, relu, dh, scratch,
                                       global_rows_per_group, &da)))
     return rc;
+  if (p->sync && p->early_reduce_layer == &d) {
+    if (p->sync(p->sync_user, p->grads + p->early_reduce_start,
+                (int64_t)(p->layout.n_params - p->early_reduce_start), 2, 0)) {
+      set_error("gradient all-reduce hook failed");
+      return -2;
+    }
+  }
   if ((rc = gemm(s, true, false, in, da, nullptr, p->grads + d.w, d.n_in, N, rows, ld_in, N, N,
                  ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
     return rc;

@@ -131,6 +131,11 @@ struct scvae_plan {
   int use_fused = 1;          // fused decoder head kernel (0 = unfused GEMM + likelihood path)
   scvae_sync_fn sync = nullptr;
   void* sync_user = nullptr;
+  // data parallel: when the backward reaches this layer's weight gradient (the last large GEMM of
+  // the step), every gradient at offset >= early_reduce_start is final and is announced to the
+  // hook (kind 2) so that its all-reduce overlaps that GEMM
+  const Dense* early_reduce_layer = nullptr;
+  size_t early_reduce_start = 0;
   // GMVAE graph (gm:2788-3221)
   std::vector<Dense> yenc, zenc, xdec;
   Dense ylogits, qmean, qscale, pmean, pscale;

@@ -8,7 +8,9 @@ per optimiser step there is
 
 * one all-reduce(sum) of the flat fp32 gradient buffer (each rank's gradient is
   already scaled by 1/global_batch, so the sum is the single-process gradient;
-  clipping to [-1, 1] happens after it, as in va:2751-2755), and
+  clipping to [-1, 1] happens after it, as in va:2751-2755), issued in two
+  pieces: everything but the first encoder layer as soon as it is final (it
+  overlaps that layer's weight-gradient GEMM), the rest after the step, and
 * per batch-norm layer one all-gather of ``[mean | var]`` in the forward pass
   (merged with the parallel-variance formula) and one all-reduce of
   ``[sum dA | sum dA*xhat]`` in the backward pass, so that the result equals
@@ -58,6 +60,7 @@ class GradientSynchroniser:
         self._check = _lib.check
         self._gathered = None
         self._counts = None
+        self._pending = []   # (offset, count, work) of gradient ranges reduced early
         engine.set_sync(self._hook)
 
     def _view(self, address, count):
@@ -69,6 +72,17 @@ class GradientSynchroniser:
 
     def _hook(self, user, address, count, kind, local_rows):
         try:
+            if kind == 2:
+                # the tail of the gradient buffer is final: start its all-reduce
+                # now, under the last large GEMM of the backward pass
+                grads = self.engine.grads
+                offset = (address - grads.data_ptr()) // 4
+                if offset < 0 or offset + count > grads.numel():
+                    raise RuntimeError("gradient range is outside the buffer")
+                work = dist.all_reduce(grads[offset:offset + count],
+                                       group=self.group, async_op=True)
+                self._pending.append((offset, count, work))
+                return 0
             view = self._view(address, count)
             if kind == 0:
                 dist.all_reduce(view, group=self.group)
@@ -84,7 +98,15 @@ class GradientSynchroniser:
             # equal shards (shard_bounds): every rank contributes local_rows
             self._counts.fill_(int(local_rows))
             gathered = self._gathered[:need]
-            dist.all_gather_into_tensor(gathered, view, group=self.group)
+            if view.is_cuda and dist.get_backend(self.group) == "gloo":
+                # gloo has no all-gather for device tensors: all-reduce a buffer
+                # that is zero except for this rank's slot (debugging set-up:
+                # several ranks on one GPU)
+                gathered.zero_()
+                gathered[self.rank * count:(self.rank + 1) * count] = view
+                dist.all_reduce(gathered, group=self.group)
+            else:
+                dist.all_gather_into_tensor(gathered, view, group=self.group)
             from scvae_amd.engine import current_stream_handle
             self._check(self.lib.scvae_bn_merge(
                 ctypes.c_void_p(gathered.data_ptr()),
@@ -97,7 +119,19 @@ class GradientSynchroniser:
             return 1
 
     def all_reduce_gradients(self):
-        dist.all_reduce(self.engine.grads, group=self.group)
+        """Sum the gradient buffer over the ranks: the ranges announced early by
+        the step (hook kind 2) are already in flight, the rest is reduced here."""
+        grads = self.engine.grads
+        position = 0
+        for offset, count, _ in sorted(self._pending, key=lambda p: p[0]):
+            if offset > position:
+                dist.all_reduce(grads[position:offset], group=self.group)
+            position = max(position, offset + count)
+        if position < grads.numel():
+            dist.all_reduce(grads[position:], group=self.group)
+        for _, _, work in self._pending:
+            work.wait()
+        self._pending = []
 
     def all_reduce_scalars(self, scalars):
         dist.all_reduce(scalars, group=self.group)
