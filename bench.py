@@ -101,20 +101,20 @@ def cpu_baseline(matrix, batch, seconds_budget=15.0):
     }
 
 
-def _measured_traffic(rows, F, H, kind):
+def _measured_traffic(rows, F, H, kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3
     PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section);
-    only reported when the profiled shapes are the benchmarked ones."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_decoder_head.json")
-    try:
-        with open(path) as f:
-            pmc = json.load(f)
-    except (OSError, ValueError):
-        return None
-    if (kind != 1 or pmc.get("rows") != rows or pmc.get("features") != F
-            or pmc.get("hidden") != H):
-        return None
-    return pmc["traffic_bytes_per_launch"]
+    only reported when the profiled kernel and shapes are the benchmarked ones."""
+    for name in ("r01_pmc_decoder_head2.json", "r01_pmc_decoder_head.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                pmc = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if (pmc.get("kernel") == "scvae::" + kernel and pmc.get("rows") == rows
+                and pmc.get("features") == F and pmc.get("hidden") == H):
+            return pmc["traffic_bytes_per_launch"]
+    return None
 
 
 def time_dominant_kernel(engine, rows, launches=10):
@@ -166,16 +166,20 @@ def time_dominant_kernel(engine, rows, launches=10):
     seconds = start.elapsed_time(stop) / 1e3 / launches
     # algorithmic flops of the decoder heads: forward + dW + dX, 2 flop / MAC
     flops = 2.0 * rows * F * P * 3 * H
+    if lib.scvae_decoder_fused_variant(kind, H) == 2:
+        kernel = "decoder_head2_kernel<{}, true>".format(kind)
+    else:
+        kernel = "decoder_head_kernel<{}, true, {}>".format(
+            kind, 32 if P >= 3 else 64)
     return {
-        "kernel": "decoder_head_kernel<{}, true, 64> (X_TILDE heads + "
-                  "likelihood + dW/db/dd, [rows,{}]x[{},{}]x{} heads)".format(
-                      kind, H, H, F, P),
+        "kernel": "{} (X_TILDE heads + likelihood + dW/db/dd, "
+                  "[rows,{}]x[{},{}]x{} heads)".format(kernel, H, H, F, P),
         "bound": "mfma",
         "achieved": flops / seconds / 1e12,
         "peak": PEAK_FP32_MFMA_TFLOPS,
         "unit": "TFLOP/s",
         "frac": flops / seconds / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-        "traffic": _measured_traffic(rows, F, H, kind),
+        "traffic": _measured_traffic(rows, F, H, kernel),
         "launch_us": seconds * 1e6,
         "algorithmic_flop_per_launch": flops,
     }

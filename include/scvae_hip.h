@@ -159,6 +159,10 @@ int scvae_loglik_bwd(int32_t kind, const float* t, float* const* pre, const floa
  * train: 0 forward, 1 forward+backward, 3 forward+backward main kernel only (the per-strip
  * partial sums are left unreduced; used by bench.py to time that kernel alone). */
 int64_t scvae_decoder_fused_workspace_bytes(int64_t rows, int64_t H, int64_t F);
+/* which schedule scvae_decoder_fused / the step launch for this likelihood and hidden size:
+ * 2 = decoder_head2_kernel (two pipelined halves), 1 = decoder_head_kernel, 0 = unsupported H
+ * (the step then uses the unfused GEMM + likelihood kernels) */
+int32_t scvae_decoder_fused_variant(int32_t kind, int64_t H);
 int scvae_decoder_fused(int32_t kind, int32_t train, const float* d, int64_t rows, int64_t H,
                         const float* const* W, const float* const* b, float* const* dW,
                         float* const* db, int64_t F, const float* t, int64_t cells,

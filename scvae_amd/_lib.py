@@ -109,6 +109,7 @@ SIGNATURES = {
         c_int64, c_int64, c_int64, c_void_p]),
     "scvae_decoder_fused_workspace_bytes": (c_int64, [c_int64, c_int64,
                                                       c_int64]),
+    "scvae_decoder_fused_variant": (c_int32, [c_int32, c_int64]),
     "scvae_decoder_fused": (c_int32, [
         c_int32, c_int32, c_void_p, c_int64, c_int64, POINTER(c_void_p),
         POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int64,

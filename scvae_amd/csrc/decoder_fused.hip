@@ -450,12 +450,16 @@ static int decoder_variant() {
   return g_decoder_variant;
 }
 
+int decoder_fused_variant(int P, int H) {
+  return (decoder_variant() == 2 && decoder_fused2_supported(P, H)) ? 2 : 1;
+}
+
 template <bool TRAIN>
 static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                           int F, const float* t, int B, const float* gw, int inline_lgamma,
                           float* ll_part, float* dd_part) {
   const int P = likelihood_heads(kind);
-  if (decoder_variant() == 2 && decoder_fused2_supported(P, H))
+  if (decoder_fused_variant(P, H) == 2)
     return decoder_fused2_launch(s, TRAIN, kind, d, rows, H, hp, F, t, B, gw, inline_lgamma, ll_part,
                                  dd_part);
   const size_t lds = decoder_fused_lds_bytes(P, H, TRAIN);

@@ -85,6 +85,7 @@ struct HeadParams {
 bool decoder_fused_supported(int H);
 size_t decoder_fused_workspace_floats(int rows, int H, int F, bool train);
 size_t decoder_fused_lds_bytes(int P, int H, bool train);
+int decoder_fused_variant(int P, int H);   // 1: decoder_head_kernel, 2: decoder_head2_kernel
 bool decoder_fused2_supported(int P, int H);
 size_t decoder_fused2_lds_bytes(int P, int H);
 int decoder_fused2_launch(hipStream_t s, bool train, int kind, const float* d, int rows, int H,

@@ -606,6 +606,10 @@ int64_t scvae_decoder_fused_workspace_bytes(int64_t rows, int64_t H, int64_t F) 
   return (int64_t)(scvae::decoder_fused_workspace_floats((int)rows, (int)H, (int)F, true) *
                    sizeof(float));
 }
+int32_t scvae_decoder_fused_variant(int32_t kind, int64_t H) {
+  if (kind < 0 || kind > 3 || !scvae::decoder_fused_supported((int)H)) return 0;
+  return scvae::decoder_fused_variant(scvae::likelihood_heads(kind), (int)H);
+}
 int scvae_decoder_fused(int32_t kind, int32_t train, const float* d, int64_t rows, int64_t H,
                         const float* const* W, const float* const* b, float* const* dW,
                         float* const* db, int64_t F, const float* t, int64_t cells,
