@@ -8,19 +8,25 @@
 //
 // in ONE kernel: the [rows, P*F] pre-activations and their gradients never touch HBM.
 //
-// Decomposition: one workgroup (4 waves) owns a strip of BN = 64 columns (genes) for the whole
-// launch and walks over the rows in tiles of BM = 64:
+// Decomposition: one workgroup (8 waves, 2 per SIMD) owns a strip of BN = 64 columns (genes) for
+// the whole launch and walks over the rows in tiles of BM = 64 (32 for three heads):
 //   * the strip's weights W_j[:, strip] (P x H x 64 fp32) are loaded into LDS once;
-//   * GEMM1 (K = H): each wave computes one 32x32 tile of every head with
-//     v_mfma_f32_32x32x2_f32 and runs the likelihood epilogue on its accumulators in
-//     registers (t is prefetched from HBM in the accumulator layout);
-//   * the G_j tiles go through LDS to become MFMA operands of
-//     GEMM2 dW_j[H, strip] += d^T G_j   (accumulated in registers over all row tiles, written once)
+//   * GEMM1 (K = H): 32x32 v_mfma_f32_32x32x2_f32 tiles spread over the waves, pre_j + b_j -> LDS;
+//   * likelihood epilogue in registers: a thread owns rows r, r+16, .. x columns c, c+32 of the
+//     tile (t is loaded from HBM into the owner's registers one tile ahead), writes G_j in place
+//     of pre_j; the t > 0 corrections of the negative-binomial kinds are compacted per wave
+//     (ballot) into a wave-private LDS queue;
+//   * the G_j tiles are MFMA operands of
+//     GEMM2 dW_j[H, strip] += d^T G_j   (accumulated in registers over all row tiles, written once;
+//                                        an appended ones-column of d makes db_j fall out of it)
 //     GEMM3 dd_part[rows, H] = sum_j G_j W_j^T  (this strip's contribution; summed over the
 //     strips by dd_reduce_kernel in a fixed order: deterministic, no atomics);
 //   * per-row log-likelihood partial sums likewise (ll_reduce_kernel).
+// Three workgroup barriers per tile; the d tile is double buffered when LDS allows.
 // Algorithmic HBM traffic per cell: 4F B (t) + dd slabs; MFMA work 2*P*F*(H + 2*128) flop
 // (the H dimension of GEMM2/GEMM3 is padded to the 32-wide MFMA tile).
+// decoder_fused2.hip holds a second schedule of the same phases (two pipelined half workgroups),
+// which the dispatcher below prefers where it fits.
 #include "common.hpp"
 #include "kernels.hpp"
 #include "likelihood.hpp"

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(
 // fragment), BK = 32, B operand row-major [K,N].  TA: A is stored [K,M] (i.e. C = A^T B).
 constexpr int BT = 128;
 constexpr int BBK = 32;
-constexpr int BLD = BT + 4;
+constexpr int BLD = BT + 1;   // odd: the transposing store of the A[m][k] tile is conflict free
 
 template <bool TA>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(
