@@ -131,6 +131,12 @@ typedef struct scvae_step_args {
                               q_z_variances(sum share) */
 } scvae_step_args;
 int scvae_plan_step(scvae_plan* plan, const scvae_step_args* args, void* stream);
+/* Decoder only, is_training = False: p_x_mean[rows, F] = mean of p(x|z) for given latent values
+ * z[rows, L] -- `session.run(self.p_x_mean, feed_dict={self.z: z, self.is_training: False})`
+ * in model.sample() (va:1680-1715; gm:2055-2079, where the one-hot y selects the fed z).
+ * rows <= the bound max_cells. */
+int scvae_plan_decode(scvae_plan* plan, const float* z, int64_t rows, float* p_x_mean,
+                      void* stream);
 
 /* _setup_optimiser (va:2736-2770): g <- clip(g*grad_scale, +-1); tf.train.AdamOptimizer
  * with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller. */

@@ -204,6 +204,33 @@ def _normal_log_prob(z, mean, sigma):
 
 
 # --------------------------------------------------------------------------
+# decoder only (model.sample(): va:1601-1779, gm:1949-2160)
+# --------------------------------------------------------------------------
+
+def decode_mean(cfg, params, moving, z, model_type="VAE"):
+    """``session.run(self.p_x_mean, {self.z: z, self.is_training: False})``:
+    mean of p(x|z) for given latent values z [rows, L] (moving statistics)."""
+    bn = cfg.minibatch_normalisation
+    H = list(cfg.hidden_sizes)
+    n = len(H)
+    if model_type == "VAE":
+        d = z
+        for i in range(n):
+            d = dense_layer(d, params, "DECODER/{}".format(n - i), bn, False,
+                            moving, None)
+        scope = "X_TILDE/"
+    else:
+        d = _layers(z, params, "X/DECODER", H[::-1], bn, False, moving, None)
+        scope = "X/DISTRIBUTION/"
+    pre = tuple(
+        dense_layer(d, params, scope + p.upper(), False, False, moving, None,
+                    activation=False)
+        for p in cfg.heads)
+    mean, _ = lk.mean_variance(cfg.likelihood, pre)
+    return mean
+
+
+# --------------------------------------------------------------------------
 # VAE
 # --------------------------------------------------------------------------
 

@@ -110,6 +110,8 @@ SIGNATURES = {
     "scvae_decoder_fused_workspace_bytes": (c_int64, [c_int64, c_int64,
                                                       c_int64]),
     "scvae_decoder_fused_variant": (c_int32, [c_int32, c_int64]),
+    "scvae_plan_decode": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p,
+                                    c_void_p]),
     "scvae_decoder_fused": (c_int32, [
         c_int32, c_int32, c_void_p, c_int64, c_int64, POINTER(c_void_p),
         POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int64,

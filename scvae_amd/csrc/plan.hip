@@ -548,6 +548,34 @@ int scvae_plan_set_sync(scvae_plan* p, scvae_sync_fn fn, void* user) {
   return 0;
 }
 
+int scvae_plan_decode(scvae_plan* p, const float* z, int64_t rows, float* p_x_mean,
+                      void* stream) {
+  SCVAE_ARG(p && z && p_x_mean);
+  SCVAE_ARG(p->params && p->ws);
+  SCVAE_ARG(rows > 0 && rows <= p->max_cells);
+  using namespace scvae;
+  hipStream_t s = (hipStream_t)stream;
+  const scvae_model_config& c = p->cfg;
+  const int R = (int)rows, F = c.feature_size;
+  std::vector<Dense>& dec = c.model_type == SCVAE_MODEL_GMVAE ? p->xdec : p->dec;
+  int rc;
+  const float* h = z;
+  int ld = c.latent_size;
+  for (auto& d : dec) {
+    if ((rc = dense_forward(p, s, d, h, ld, R, 1, true, false))) return rc;
+    h = d.h; ld = d.n_out;
+  }
+  HeadPtrs pre;
+  for (int j = 0; j < 3; ++j) pre.p[j] = p->pre[j];
+  for (int j = 0; j < p->P; ++j) {
+    Dense& hd = p->heads[j];
+    if ((rc = gemm(s, false, false, h, p->params + hd.w, p->params + hd.b, p->pre[j], R, F, hd.n_in,
+                   ld, F, F, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+      return rc;
+  }
+  return px_statistics(s, c.likelihood, pre, F, 1, R, F, nullptr, 0, 0, p_x_mean, p->mov, p->vom);
+}
+
 int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
   SCVAE_ARG(p && a);
   SCVAE_ARG(p->params && p->ws);

@@ -274,6 +274,20 @@ class Engine:
             "scvae_plan_step")
         return out_scalars
 
+    def decode(self, z, out=None):
+        """Mean of p(x|z) for latent values ``z`` [rows, L] with the moving
+        batch-norm statistics (the decoder half of the graph; ``model.sample``).
+        """
+        rows = z.shape[0]
+        self.reserve(rows, 1)
+        if out is None:
+            out = torch.empty(rows, self.feature_size, device=self.device)
+        z = z.contiguous()
+        _lib.check(self.lib.scvae_plan_decode(
+            self.handle, _ptr(z), rows, _ptr(out),
+            current_stream_handle(self.device)), "scvae_plan_decode")
+        return out
+
     def adam_step(self, learning_rate, grad_scale=1.0):
         """clip-by-value(+-1) + ``tf.train.AdamOptimizer`` update (va:2742-2759)."""
         self.adam_t += 1

@@ -376,6 +376,32 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
                 (3, "kl_divergence_z", "KL_z"),
                 (4, "kl_divergence_y", "KL_y")]
 
+    def _sample_prior(self, count, seed, stream_id):
+        """y ~ p(y) (one-hot), z = z_y with z_k ~ p(z|y=k) (gm:2816-2826,
+        2901-2910): only the component selected by y reaches p_x_mean, so only
+        that one is drawn and decoded."""
+        from scvae_amd.minibatch import philox_normal
+        device = self.engine.device
+        probabilities, means, variances = self._prior_summary()
+        generator = torch.Generator(device=device).manual_seed(
+            (int(seed) << 20) ^ int(stream_id))
+        y = torch.multinomial(
+            torch.as_tensor(probabilities, dtype=torch.float32,
+                            device=device),
+            count, replacement=True, generator=generator)
+        eps = torch.empty(count, self.latent_size, device=device)
+        philox_normal(eps, row_offset=0, seed=seed, stream_id=stream_id)
+        mean = torch.as_tensor(means, dtype=torch.float32, device=device)[y]
+        std = torch.as_tensor(variances, dtype=torch.float32,
+                              device=device)[y].sqrt()
+        z = mean + std * eps
+        y_one_hot = torch.nn.functional.one_hot(
+            y, self.n_clusters).to(torch.int32)
+        return z, {"y": y_one_hot}
+
+    def _latent_feature_name(self, key, index):
+        return "{} variable {}".format(key, index + 1)
+
     def _prior_summary(self):
         """p(y) probabilities and p(z|y) means / variances (gm:2879-2882)."""
         engine = self.engine

@@ -9,6 +9,7 @@ import copy
 import os
 
 import numpy
+import torch
 
 from scvae_amd.defaults import defaults
 from scvae_amd.distributions import (
@@ -322,6 +323,13 @@ class VariationalAutoencoder(ModelBase):
         minibatch_size /= (self.number_of_importance_samples[scenario]
                            * self.number_of_monte_carlo_samples[scenario])
         return int(numpy.ceil(minibatch_size))
+
+    def _sample_prior(self, count, seed, stream_id):
+        """z ~ N(0, I) (``self.p_z.sample``, va:2393-2394)."""
+        from scvae_amd.minibatch import philox_normal
+        z = torch.empty(count, self.latent_size, device=self.engine.device)
+        philox_normal(z, row_offset=0, seed=seed, stream_id=stream_id)
+        return z, {}
 
     def _prior_summary(self):
         # gaussian prior N(0, 1): one "cluster"; the reference logs the

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import likelihoods as lk
 from oracle import models as om
 
 pytestmark = pytest.mark.gpu
@@ -212,3 +213,66 @@ def test_distribution_registry_objects(cuda_device):
                     np.log(pi + (1 - pi) * base))
     got = zinb.log_prob(torch.tensor(t, device=cuda_device)).cpu().numpy()
     assert np.allclose(got, want, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("model_type", ["VAE", "GMVAE"])
+def test_decode_matches_oracle(cuda_device, model_type):
+    """``scvae_plan_decode`` (the decoder half, evaluation mode) against the
+    oracle for given latent values, every likelihood."""
+    from scvae_amd.engine import Engine
+    F, L, H, K, rows = 70, 4, (12, 10), 3, 37
+    rng = np.random.default_rng(5)
+    for likelihood in lk.LIKELIHOOD_PARAMETERS:
+        eng = Engine(F, L, H, likelihood, batch_norm=True,
+                     model_type=model_type, n_clusters=K, device=cuda_device,
+                     seed=4)
+        # moving statistics away from their initial values
+        with torch.no_grad():
+            eng.moving.copy_(torch.from_numpy(
+                rng.uniform(0.5, 1.5, eng.moving.numel()).astype(np.float32)))
+        z = torch.from_numpy(rng.standard_normal((rows, L)).astype(np.float32))
+        got = eng.decode(z.to(cuda_device)).cpu().double()
+        cfg = om.ModelConfig(feature_size=F, latent_size=L, hidden_sizes=H,
+                             likelihood=likelihood, n_clusters=K)
+        params = {k: v.detach().cpu().double()
+                  for k, v in eng.named_parameters().items()}
+        moving = {k: v.detach().cpu().double()
+                  for k, v in eng.named_moving_statistics().items()}
+        want = om.decode_mean(cfg, params, moving, z.double(), model_type)
+        err = (got - want).abs().max().item()
+        assert err <= 1e-4 * want.abs().max().item() + 1e-6, (likelihood, err)
+
+
+@pytest.mark.parametrize("model_type", ["VAE", "GMVAE"])
+def test_sample_from_trained_model(tmp_path, cuda_device, capsys, model_type):
+    from scvae_amd.models import (
+        GaussianMixtureVariationalAutoencoder, VariationalAutoencoder)
+    data = _data(64, 40, labels=False)
+    if model_type == "VAE":
+        model = VariationalAutoencoder(
+            feature_size=40, latent_size=3, hidden_sizes=[8],
+            reconstruction_distribution="negative binomial",
+            log_directory=str(tmp_path), device=cuda_device)
+    else:
+        model = GaussianMixtureVariationalAutoencoder(
+            feature_size=40, latent_size=3, hidden_sizes=[8],
+            reconstruction_distribution="negative binomial",
+            number_of_latent_clusters=4,
+            log_directory=str(tmp_path), device=cuda_device)
+    with pytest.raises(Exception, match="not been trained"):
+        model.sample(sample_size=10)
+    model.train(data, None, number_of_epochs=1, minibatch_size=32)
+    reconstruction, latent = model.sample(sample_size=50, minibatch_size=16)
+    assert reconstruction.values.shape == (50, 40)
+    assert reconstruction.kind == "sample"
+    assert reconstruction.version == "reconstructed"
+    assert np.isfinite(reconstruction.values).all()
+    assert (reconstruction.values >= 0).all()
+    assert latent["z"].values.shape == (50, 3)
+    if model_type == "GMVAE":
+        y = latent["y"].values
+        assert y.shape == (50, 4) and (y.sum(axis=1) == 1).all()
+        # the decoded mean belongs to the z that was drawn
+        z = torch.from_numpy(np.asarray(latent["z"].values, np.float32))
+        again = model.engine.decode(z.to(cuda_device)).cpu().numpy()
+        assert np.allclose(again, reconstruction.values, rtol=1e-5, atol=1e-6)
