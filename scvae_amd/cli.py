@@ -194,8 +194,10 @@ def evaluate(data_set_file_or_name, data_format=None, data_directory=None,
              split_data_set=None, splitting_method=None,
              splitting_fraction=None, minibatch_size=None, run_id=None,
              models_directory=None, evaluation_set_kind=None,
-             model_versions=None, **keyword_arguments):
+             sample_size=None, model_versions=None, **keyword_arguments):
     """Evaluate model on data set (``cli.py:267-566``)."""
+    if sample_size is None:
+        sample_size = defaults["models"]["sample_size"]
     if split_data_set is None:
         split_data_set = defaults["data"]["split_data_set"]
     if splitting_method is None:
@@ -271,6 +273,16 @@ def evaluate(data_set_file_or_name, data_format=None, data_directory=None,
             use_early_stopping_model=use_early_stopping_model,
             output_versions="all")
         print()
+        if sample_size:   # cli.py:494-505
+            print(subtitle("Sampling ({})".format(
+                model_version.replace("_", " "))))
+            sample_reconstruction_set, _ = model.sample(
+                sample_size=sample_size, minibatch_size=minibatch_size,
+                run_id=run_id, use_best_model=use_best_model,
+                use_early_stopping_model=use_early_stopping_model)
+            results[model_version] = (
+                results[model_version], sample_reconstruction_set)
+            print()
     return results
 
 
@@ -473,6 +485,10 @@ def main(arguments=None):
         "--evaluation-set-kind", metavar="KIND",
         default=_parse_default(defaults["evaluation"]["data_set_kind"]),
         help="kind of subset to evaluate and analyse")
+    parser_evaluate.add_argument(
+        "--sample-size", metavar="SIZE", type=int,
+        default=_parse_default(defaults["models"]["sample_size"]),
+        help="sample size for sampling model")
     parser_evaluate.add_argument(
         "--model-versions", metavar="VERSION", nargs="+",
         default=_parse_default(defaults["evaluation"]["model_versions"]),

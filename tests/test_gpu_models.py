@@ -186,6 +186,10 @@ def test_cli_train_and_evaluate(tmp_path, cuda_device, capsys):
     assert "end_of_training" in results
     transformed, reconstructed, latent = results["end_of_training"]
     assert latent["z"].values.shape == (100, 3)
+    results = cli.main(["evaluate"] + arguments + ["--sample-size", "20"])
+    (_, _, latent), sampled = results["end_of_training"]
+    assert sampled.values.shape == (20, transformed.values.shape[1])
+    assert "Sampling 20 examples from model." in capsys.readouterr().out
 
 
 def test_distribution_registry_objects(cuda_device):
