@@ -53,6 +53,9 @@ typedef struct scvae_model_config {
   int32_t n_clusters;         /* K (GMVAE), 1 for the VAE */
   float kl_weight;
   float free_nats_proportion; /* proportion_of_free_nats_for_y_kl_divergence */
+  int32_t decoder_extra;      /* E: extra decoder input columns appended to z -- one-hot batch
+                                 indices (batch_correction) and/or the normalised count sum
+                                 (use_count_sum_as_feature), va:2407-2441, gm:3094-3130 */
 } scvae_model_config;
 
 typedef struct scvae_plan scvae_plan; /* opaque */
@@ -129,6 +132,9 @@ typedef struct scvae_step_args {
   float* stddev_of_p_x_given_z_mean; /* [cells, F] */
   float* cluster_stats;    /* GMVAE: [4, K, L] p_z_means, p_z_variances, q_z_means(sum share),
                               q_z_variances(sum share) */
+  /* [cells, E] extra decoder inputs (required when cfg.decoder_extra > 0), tiled over the
+   * samples like t: the decoder's first layer sees [z | decoder_extra] */
+  const float* decoder_extra;
 } scvae_step_args;
 int scvae_plan_step(scvae_plan* plan, const scvae_step_args* args, void* stream);
 /* Decoder only, is_training = False: p_x_mean[rows, F] = mean of p(x|z) for given latent values

@@ -53,6 +53,10 @@ class ModelConfig:
     # GMVAE only
     n_clusters: int = 1
     free_nats_proportion: float = 0.0
+    # extra decoder input columns appended to z: one-hot batch indices
+    # (batch_correction) and/or the normalised count sum
+    # (use_count_sum_as_feature), va:2407-2441, gm:3094-3130
+    decoder_extra_size: int = 0
 
     @property
     def heads(self):
@@ -84,7 +88,7 @@ def vae_parameter_shapes(cfg):
     shapes += _dense_entries("POSTERIOR/MU", n_in, cfg.latent_size, False)
     shapes += _dense_entries("POSTERIOR/LOG_SIGMA", n_in, cfg.latent_size,
                              False)
-    n_in = cfg.latent_size
+    n_in = cfg.latent_size + cfg.decoder_extra_size
     # reverse_order=True: sizes reversed, scopes numbered n..1
     for i, h in enumerate(H[::-1]):
         shapes += _dense_entries("DECODER/{}".format(n - i), n_in, h, bn)
@@ -117,7 +121,7 @@ def gmvae_parameter_shapes(cfg):
     shapes += _dense_entries("Z/P/SOFTPLUS_GAUSSIAN/MEAN", K, L, False)
     shapes += _dense_entries("Z/P/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE", K, L,
                              False)
-    n_in = L
+    n_in = L + cfg.decoder_extra_size
     for i, h in enumerate(H[::-1]):
         shapes += _dense_entries(
             "X/DECODER/LAYER_{}".format(i + 1), n_in, h, bn)
@@ -236,7 +240,7 @@ def decode_mean(cfg, params, moving, z, model_type="VAE"):
 
 def vae_forward(cfg, params, moving, x, t, eps, training, warm_up_weight=1.0,
                 new_moving=None, deterministic_z=False, analytical_kl=True,
-                evaluation_statistics=False):
+                evaluation_statistics=False, decoder_extra=None):
     """One graph execution.  ``eps``: [S, B, L] standard-normal draws
     (S = n_iw * n_mc, IW-major) or None with ``deterministic_z``."""
     bn = cfg.minibatch_normalisation
@@ -266,6 +270,8 @@ def vae_forward(cfg, params, moving, x, t, eps, training, warm_up_weight=1.0,
     S = z.shape[0]
 
     d = z.reshape(S * B, L)
+    if decoder_extra is not None:   # tf.tile(extra, [S, 1]); tf.concat
+        d = torch.cat([d, decoder_extra.repeat(S, 1)], dim=1)
     for i in range(n):
         d = dense_layer(d, params, "DECODER/{}".format(n - i), bn, training,
                         moving, new_moving)
@@ -337,7 +343,7 @@ def _clip_big(a):
 
 def gmvae_forward(cfg, params, moving, x, t, eps, training,
                   warm_up_weight=1.0, new_moving=None,
-                  evaluation_statistics=False):
+                  evaluation_statistics=False, decoder_extra=None):
     """``eps``: [K, S, B, L].  Uniform p(y) (the default
     ``prior_probabilities_method``)."""
     bn = cfg.minibatch_normalisation
@@ -384,8 +390,11 @@ def gmvae_forward(cfg, params, moving, x, t, eps, training,
         p_mean = _clip_big(Wpm[k] + bpm)
         p_sigma = torch.sqrt(F.softplus(_clip_big(Wps[k] + bps)))
 
-        d = _layers(z.reshape(S * B, L), params, "X/DECODER", H[::-1], bn,
-                    training, moving, new_moving)
+        d = z.reshape(S * B, L)
+        if decoder_extra is not None:
+            d = torch.cat([d, decoder_extra.repeat(S, 1)], dim=1)
+        d = _layers(d, params, "X/DECODER", H[::-1], bn, training, moving,
+                    new_moving)
         pre = tuple(
             dense_layer(d, params, "X/DISTRIBUTION/" + p.upper(), False,
                         training, moving, None, activation=False)

@@ -40,6 +40,7 @@ class ModelConfig(Structure):
         ("n_clusters", c_int32),
         ("kl_weight", c_float),
         ("free_nats_proportion", c_float),
+        ("decoder_extra", c_int32),
     ]
 
 
@@ -65,6 +66,7 @@ class StepArgs(Structure):
         ("p_x_stddev", c_void_p),
         ("stddev_of_p_x_given_z_mean", c_void_p),
         ("cluster_stats", c_void_p),
+        ("decoder_extra", c_void_p),
     ]
 
 

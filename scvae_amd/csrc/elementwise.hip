@@ -761,6 +761,52 @@ int col_sum(hipStream_t stream, const float* a, int lda, int rows, int N, float*
   return 0;
 }
 
+// ---- decoder input [z | extra] (batch one-hot / count sum appended to z, va:2407-2441) ----
+__global__ __launch_bounds__(256) void concat_extra_kernel(const float* __restrict__ z, int L,
+                                                           const float* __restrict__ extra, int E,
+                                                           size_t rows, size_t cells,
+                                                           float* __restrict__ out) {
+  const int W = L + E;
+  const size_t total = rows * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / W;
+    const int c = (int)(i - r * W);
+    out[i] = c < L ? z[r * L + c] : extra[(r % cells) * E + (c - L)];
+  }
+}
+__global__ __launch_bounds__(256) void slice_cols_kernel(const float* __restrict__ in, int ld,
+                                                         int L, size_t rows,
+                                                         float* __restrict__ out) {
+  const size_t total = rows * L;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / L;
+    out[i] = in[r * ld + (i - r * L)];
+  }
+}
+int concat_extra(hipStream_t stream, const float* z, int L, const float* extra, int E, size_t rows,
+                 size_t cells, float* out) {
+  SCVAE_ARG(z && extra && out && L > 0 && E > 0 && cells > 0);
+  if (rows == 0) return 0;
+  size_t blocks = (rows * (L + E) + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(concat_extra_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, z, L, extra,
+                     E, rows, cells, out);
+  SCVAE_LAUNCH_CHECK("concat_extra_kernel");
+  return 0;
+}
+int slice_cols(hipStream_t stream, const float* in, int ld, int L, size_t rows, float* out) {
+  SCVAE_ARG(in && out && L > 0 && ld >= L);
+  if (rows == 0) return 0;
+  size_t blocks = (rows * L + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(slice_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, ld, L,
+                     rows, out);
+  SCVAE_LAUNCH_CHECK("slice_cols_kernel");
+  return 0;
+}
+
 // ================================ optimiser ================================
 
 // g <- clip(g * grad_scale, -1, 1); TF Adam: m,v update; theta -= lr_t * m / (sqrt(v) + eps)

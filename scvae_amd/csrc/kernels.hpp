@@ -71,6 +71,10 @@ int bn_bwd_apply(hipStream_t stream, const float* dh, int lddh, const float* h, 
 int bn_dbeta(hipStream_t stream, const float* s1, int groups, int N, float* dbeta, int accumulate);
 int bn_merge(hipStream_t stream, const float* gathered, const int64_t* counts, int ranks, int n,
              float* out);
+// out[r, :] = [z[r, :L] | extra[r % cells, :E]];  slice: out[r, :L] = in[r, :L] of [rows, ld]
+int concat_extra(hipStream_t stream, const float* z, int L, const float* extra, int E, size_t rows,
+                 size_t cells, float* out);
+int slice_cols(hipStream_t stream, const float* in, int ld, int L, size_t rows, float* out);
 int relu_bwd(hipStream_t stream, const float* dh, const float* h, float* da, size_t n);
 int col_sum(hipStream_t stream, const float* a, int lda, int rows, int N, float* out, float scale,
             int accumulate, float* partial);

@@ -35,7 +35,7 @@ static int build_vae(scvae_plan* p) {
   }
   p->mu = L.dense("POSTERIOR/MU", n_in, c.latent_size, false);
   p->ls = L.dense("POSTERIOR/LOG_SIGMA", n_in, c.latent_size, false);
-  n_in = c.latent_size;
+  n_in = c.latent_size + c.decoder_extra;   // decoder input [z | batch one-hot | count sum]
   // dense_layers(reverse_order=True): sizes reversed, scopes numbered n..1 (mu:102-105)
   for (int i = 0; i < c.n_hidden; ++i) {
     const int h = c.hidden[c.n_hidden - 1 - i];
@@ -107,8 +107,12 @@ static size_t carve(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_
   float* fused_ws = decoder_fused_supported(h1)
                         ? b.floats(decoder_fused_workspace_floats((int)R, h1, (int)F, true))
                         : nullptr;
+  const size_t E = (size_t)c.decoder_extra;
+  float* zcat = E ? b.floats(R * (Lz + E)) : nullptr;
+  float* dzcat = E ? b.floats(R * (Lz + E)) : nullptr;
   if (!dry) {
     p->fused_ws = fused_ws;
+    p->zcat = zcat; p->dzcat = dzcat;
     p->mu_pre = mu_pre; p->ls_pre = ls_pre; p->kl_elem = kl_elem; p->kl_cell = kl_cell;
     p->z = z; p->ll = ll; p->gw = gw;
     for (int j = 0; j < 3; ++j) p->pre[j] = pre[j];
@@ -309,8 +313,15 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   if (a->q_z_mean)
     if ((rc = copy(s, p->mu_pre, a->q_z_mean, (size_t)B * L))) return rc;
 
-  const float* dch = p->z;
-  ld = L;
+  const int E = c.decoder_extra;
+  const float* dec_in = p->z;   // decoder input: z, or [z | extra] (va:2407-2441)
+  if (E > 0) {
+    if ((rc = concat_extra(s, p->z, L, a->decoder_extra, E, (size_t)R, (size_t)B, p->zcat)))
+      return rc;
+    dec_in = p->zcat;
+  }
+  const float* dch = dec_in;
+  ld = L + E;
   for (auto& d : p->dec) {
     if ((rc = dense_forward(p, s, d, dch, ld, R, 1, true, training))) return rc;
     dch = d.h; ld = d.n_out;
@@ -408,14 +419,16 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   // decoder layers, last to first; the first decoder layer's input is z
   for (int i = (int)p->dec.size() - 1; i >= 0; --i) {
     Dense& d = p->dec[i];
-    const float* in = i > 0 ? p->dec[i - 1].h : p->z;
+    const float* in = i > 0 ? p->dec[i - 1].h : dec_in;
     const int ld_in = d.n_in;
-    float* d_in = i > 0 ? dalt : p->dz;
+    float* d_in = i > 0 ? dalt : (E > 0 ? p->dzcat : p->dz);
     float* scratch = p->dbuf[2];
     if ((rc = dense_backward(p, s, d, in, ld_in, R, 1, true, dcur, scratch, d_in, false, GR)))
       return rc;
     if (i > 0) { float* t = dcur; dcur = dalt; dalt = t; }
   }
+  if (E > 0 && !p->dec.empty())
+    if ((rc = slice_cols(s, p->dzcat, L + E, L, (size_t)R, p->dz))) return rc;
   // latent: dz -> dmu_pre, dls_pre  (d(-ELBO_w)/dKL_cell = w / B_global)
   if ((rc = gauss_latent_bwd(s, p->mu_pre, p->ls_pre, a->eps, p->dz, w / (float)GB, p->dmu, p->dls,
                              S, B, L)))
@@ -471,6 +484,8 @@ int scvae_plan_create(const scvae_model_config* cfg, scvae_plan** out) {
   for (int i = 0; i < cfg->n_hidden; ++i) SCVAE_ARG(cfg->hidden[i] > 0);
   SCVAE_ARG(cfg->model_type == SCVAE_MODEL_VAE || cfg->model_type == SCVAE_MODEL_GMVAE);
   SCVAE_ARG(cfg->model_type == SCVAE_MODEL_VAE || (cfg->n_clusters >= 1 && cfg->n_clusters <= 1024));
+  SCVAE_ARG(cfg->decoder_extra >= 0 && cfg->decoder_extra <= 4096);
+  SCVAE_ARG(cfg->decoder_extra == 0 || cfg->n_hidden > 0);
   scvae_plan* p = new scvae_plan();
   p->cfg = *cfg;
   p->P = scvae::likelihood_heads(cfg->likelihood);
@@ -553,6 +568,10 @@ int scvae_plan_decode(scvae_plan* p, const float* z, int64_t rows, float* p_x_me
   SCVAE_ARG(p && z && p_x_mean);
   SCVAE_ARG(p->params && p->ws);
   SCVAE_ARG(rows > 0 && rows <= p->max_cells);
+  if (p->cfg.decoder_extra > 0) {   // as the reference: NotImplementedError (va:1638-1650)
+    scvae::set_error("sampling with batch correction / count-sum decoder inputs is not supported");
+    return -1;
+  }
   using namespace scvae;
   hipStream_t s = (hipStream_t)stream;
   const scvae_model_config& c = p->cfg;
@@ -584,6 +603,7 @@ int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
   SCVAE_ARG(a->n_iw > 0 && a->n_mc > 0);
   SCVAE_ARG(a->deterministic_z || (int64_t)a->n_iw * a->n_mc <= p->max_samples);
   SCVAE_ARG(a->deterministic_z || a->eps);
+  SCVAE_ARG(p->cfg.decoder_extra == 0 || a->decoder_extra);
   SCVAE_ARG(!a->training || p->grads);
   SCVAE_ARG(!(a->training && a->deterministic_z));
   if (p->cfg.model_type == SCVAE_MODEL_GMVAE) {

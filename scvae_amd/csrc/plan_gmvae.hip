@@ -33,7 +33,7 @@ int build_gmvae(scvae_plan* p) {
   p->qscale = L.dense("Z/Q/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE", n_in, Lz, false);
   p->pmean = L.dense("Z/P/SOFTPLUS_GAUSSIAN/MEAN", K, Lz, false);
   p->pscale = L.dense("Z/P/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE", K, Lz, false);
-  n_in = Lz;
+  n_in = Lz + c.decoder_extra;   // decoder input [z | batch one-hot | count sum]
   // gm:3135-3146: hidden_sizes[::-1] without reverse_order => LAYER_1.. in execution order
   for (int i = 0; i < c.n_hidden; ++i) {
     snprintf(scope, sizeof scope, "X/DECODER/LAYER_%d", i + 1);
@@ -116,8 +116,12 @@ size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t
   float* fused_ws = decoder_fused_supported(h1)
                         ? b.floats(decoder_fused_workspace_floats((int)R, h1, (int)F, true))
                         : nullptr;
+  const size_t E = (size_t)c.decoder_extra;
+  float* zcat = E ? b.floats(R * (Lz + E)) : nullptr;
+  float* dzcat = E ? b.floats(R * (Lz + E)) : nullptr;
   if (!dry) {
     p->fused_ws = fused_ws;
+    p->zcat = zcat; p->dzcat = dzcat;
     p->logits = logits; p->yprob = yprob; p->kl_y_cell = kl_y_cell; p->a0 = a0;
     p->qm = qm; p->qs = qs; p->z = z; p->klz = klz; p->gklz = gklz; p->ll = ll; p->gw = gw;
     p->dy = dy; p->dlogits = dlogits; p->dqm = dqm; p->dqs = dqs; p->dprior = dprior;
@@ -222,8 +226,14 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
 
   // ---------------- decoder p(x|z_k), all k (gm:3094-3221) ----------------
-  const float* dch = p->z;
-  ld = L;
+  const int E = c.decoder_extra;
+  const float* dec_in = p->z;   // decoder input: z_k, or [z_k | extra] (gm:3094-3130)
+  if (E > 0) {
+    TRY(concat_extra(s, p->z, L, a->decoder_extra, E, (size_t)R, (size_t)B, p->zcat));
+    dec_in = p->zcat;
+  }
+  const float* dch = dec_in;
+  ld = L + E;
   for (auto& d : p->xdec) {
     TRY(dense_forward(p, s, d, dch, ld, R, K, true, training));
     dch = d.h; ld = d.n_out;
@@ -315,11 +325,12 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const int64_t GSB = GB * S;  // global rows per group (pass) in the decoder
   for (int i = (int)p->xdec.size() - 1; i >= 0; --i) {
     Dense& d = p->xdec[i];
-    const float* in = i > 0 ? p->xdec[i - 1].h : p->z;
-    float* d_in = i > 0 ? dalt : p->dz;
+    const float* in = i > 0 ? p->xdec[i - 1].h : dec_in;
+    float* d_in = i > 0 ? dalt : (E > 0 ? p->dzcat : p->dz);
     TRY(dense_backward(p, s, d, in, d.n_in, R, K, true, dcur, scratch, d_in, false, GSB));
     if (i > 0) { float* t = dcur; dcur = dalt; dalt = t; }
   }
+  if (E > 0 && !p->xdec.empty()) TRY(slice_cols(s, p->dzcat, L + E, L, (size_t)R, p->dz));
 
   // ---------------- backward: latent, prior, q(z|x,y) ----------------
   TRY(softplus_gaussian_bwd(s, p->qm, p->qs, Wpm, bpm, Wps, bps, a->eps, p->dz, p->gklz, p->dqm,

@@ -38,7 +38,7 @@ class Engine:
     def __init__(self, feature_size, latent_size, hidden_sizes, likelihood,
                  batch_norm=True, model_type="VAE", n_clusters=1,
                  kl_weight=1.0, free_nats_proportion=0.0, device=None,
-                 seed=0):
+                 seed=0, decoder_extra=0):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError(
@@ -52,6 +52,7 @@ class Engine:
         self.latent_size = int(latent_size)
         self.hidden_sizes = [int(h) for h in hidden_sizes]
         self.n_clusters = int(n_clusters)
+        self.decoder_extra = int(decoder_extra)
         if len(self.hidden_sizes) > _lib.MAX_HIDDEN:
             raise ValueError("At most {} hidden layers are supported.".format(
                 _lib.MAX_HIDDEN))
@@ -69,6 +70,7 @@ class Engine:
         cfg.n_clusters = self.n_clusters
         cfg.kl_weight = float(kl_weight)
         cfg.free_nats_proportion = float(free_nats_proportion)
+        cfg.decoder_extra = self.decoder_extra
         self.config = cfg
 
         handle = ctypes.c_void_p()
@@ -246,7 +248,8 @@ class Engine:
     # ---- execution -----------------------------------------------------------
     def step(self, x, t, eps=None, row_const=None, training=False,
              n_iw=1, n_mc=1, warm_up_weight=1.0, deterministic_z=False,
-             global_cells=None, outputs=None, scalars=None):
+             global_cells=None, outputs=None, scalars=None,
+             decoder_extra=None):
         """One graph execution (no host synchronisation).  ``outputs`` maps
         optional output names of ``scvae_step_args`` to preallocated tensors.
         Returns the device tensor of scalars."""
@@ -257,6 +260,13 @@ class Engine:
         a.x = x.data_ptr()
         a.t = t.data_ptr()
         a.row_const = row_const.data_ptr() if row_const is not None else None
+        if self.decoder_extra:
+            if (decoder_extra is None or tuple(decoder_extra.shape)
+                    != (cells, self.decoder_extra)):
+                raise ValueError(
+                    "decoder_extra must be [cells, {}]".format(
+                        self.decoder_extra))
+            a.decoder_extra = decoder_extra.data_ptr()
         a.eps = eps.data_ptr() if eps is not None else None
         a.cells = cells
         a.global_cells = global_cells if global_cells else cells

@@ -178,7 +178,40 @@ class ModelBase:
             x = upload(data_set.preprocessed_values)
         else:
             x = t
+        t.decoder_extra = self._decoder_extra_inputs(data_set)
         return x, t
+
+    @property
+    def decoder_extra_size(self):
+        """Columns appended to z at the decoder input: one-hot batch indices
+        (batch correction) and the normalised count sum (va:2407-2441)."""
+        size = 0
+        if self.batch_correction:
+            size += int(self.number_of_batches)
+        if self.use_count_sum_as_feature:
+            size += 1
+        return size
+
+    def _decoder_extra_inputs(self, data_set):
+        """[N, E] device tensor of the extra decoder inputs of a data set (the
+        ``batch_indices`` / ``count_sum_feature`` feeds, va:1012-1023)."""
+        if not self.decoder_extra_size:
+            return None
+        device = self.engine.device
+        parts = []
+        if self.batch_correction:
+            batch_indices = mu.batch_indices_for_subset(data_set)
+            indices = torch.as_tensor(
+                numpy.asarray(batch_indices).reshape(-1), dtype=torch.int64,
+                device=device)
+            parts.append(torch.nn.functional.one_hot(
+                indices, int(self.number_of_batches)).to(torch.float32))
+        if self.use_count_sum_as_feature:
+            parts.append(torch.as_tensor(
+                numpy.asarray(data_set.normalised_count_sum,
+                              dtype=numpy.float32).reshape(-1, 1),
+                device=device))
+        return torch.cat(parts, dim=1).contiguous()
 
     # ======================================================================
     # training
@@ -426,10 +459,12 @@ class ModelBase:
                 eps = eps_buffer[:int(numpy.prod(
                     self._eps_shape(samples, cells)))]
                 self._draw_noise(eps, samples, cells, global_cells, lo, step)
+                de = (t_train.decoder_extra.index_select(0, rows)
+                      if t_train.decoder_extra is not None else None)
                 scalars = engine.step(
                     xb, tb, eps=eps, row_const=rc, training=True, n_iw=n_iw,
                     n_mc=n_mc, warm_up_weight=warm_up_weight,
-                    global_cells=global_cells)
+                    global_cells=global_cells, decoder_extra=de)
                 if sync is not None:
                     sync.all_reduce_gradients()
                 engine.adam_step(learning_rate)
@@ -684,9 +719,11 @@ class ModelBase:
                    "kl_neurons": kl_neurons[j]}
             out.update(self._evaluation_step_outputs(
                 extra, outputs, i, j, cells))
+            de = (t.decoder_extra.index_select(0, rows)
+                  if getattr(t, "decoder_extra", None) is not None else None)
             engine.step(xb, tb, eps=eps, row_const=rc, training=False,
                         n_iw=n_iw, n_mc=n_mc, deterministic_z=deterministic_z,
-                        outputs=out, scalars=scalars[j])
+                        outputs=out, scalars=scalars[j], decoder_extra=de)
         if sync is not None:
             for tensor in [scalars, kl_neurons, latent] + [
                     v for v in extra.values() if torch.is_tensor(v)]:
@@ -937,6 +974,11 @@ class ModelBase:
             model_string = "model for run {}".format(run_id)
         else:
             model_string = "model"
+        if self.batch_correction:   # as va:1639-1650
+            raise NotImplementedError("Sampling with batch correction.")
+        if self.use_count_sum_as_feature:
+            raise NotImplementedError(
+                "Sampling with count sum as additional latent feature.")
 
         log_directory = self.log_directory(
             run_id=run_id, early_stopping=use_early_stopping_model,

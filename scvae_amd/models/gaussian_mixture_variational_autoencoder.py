@@ -207,10 +207,10 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
         if self.k_max:
             raise mu.not_in_this_build(
                 "Piecewise categorical likelihood (-k)", "gm:3192-3219")
-        if self.batch_correction:
-            raise mu.not_in_this_build("Batch correction", "gm:3101-3116")
-        if self.use_count_sum_as_feature or self.use_count_sum_as_parameter:
-            raise mu.not_in_this_build("Count-sum inputs", "gm:3118-3125")
+        if self.use_count_sum_as_parameter:
+            raise mu.not_in_this_build(
+                "Count sum as a likelihood parameter (constrained Poisson, "
+                "multinomial)", "gm:3118-3125")
         if self.dropout_parts:
             raise mu.not_in_this_build("Dropout", "mu:45-50")
         if self.prior_probabilities_method != "uniform":
@@ -243,7 +243,8 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
             batch_norm=bool(self.minibatch_normalisation), model_type="GMVAE",
             n_clusters=self.n_clusters, kl_weight=self.kl_weight_value,
             free_nats_proportion=(
-                self.proportion_of_free_nats_for_y_kl_divergence))
+                self.proportion_of_free_nats_for_y_kl_divergence),
+            decoder_extra=self.decoder_extra_size)
 
     def _parameter_shapes(self):
         table = []
@@ -269,7 +270,7 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
         dense("Z/Q/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE", n_in, L, False)
         dense("Z/P/SOFTPLUS_GAUSSIAN/MEAN", K, L, False)
         dense("Z/P/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE", K, L, False)
-        n_in = L
+        n_in = L + self.decoder_extra_size
         for i, h in enumerate(H[::-1]):
             dense("X/DECODER/LAYER_{}".format(i + 1), n_in, h, bn)
             n_in = h

@@ -178,10 +178,10 @@ class VariationalAutoencoder(ModelBase):
         if self.k_max:
             raise mu.not_in_this_build(
                 "Piecewise categorical likelihood (-k)", "va:2507-2532")
-        if self.batch_correction:
-            raise mu.not_in_this_build("Batch correction", "va:2409-2424")
-        if self.use_count_sum_as_feature or self.use_count_sum_as_parameter:
-            raise mu.not_in_this_build("Count-sum inputs", "va:2400-2433")
+        if self.use_count_sum_as_parameter:
+            raise mu.not_in_this_build(
+                "Count sum as a likelihood parameter (constrained Poisson, "
+                "multinomial)", "va:2400-2433")
         if self.dropout_parts:
             raise mu.not_in_this_build("Dropout", "mu:45-50")
         if (self.inference_architecture != "MLP"
@@ -210,7 +210,8 @@ class VariationalAutoencoder(ModelBase):
             hidden_sizes=self.hidden_sizes,
             likelihood=self.reconstruction_distribution_name,
             batch_norm=bool(self.minibatch_normalisation), model_type="VAE",
-            kl_weight=self.kl_weight_value)
+            kl_weight=self.kl_weight_value,
+            decoder_extra=self.decoder_extra_size)
 
     def _parameter_shapes(self):
         table = []
@@ -228,7 +229,7 @@ class VariationalAutoencoder(ModelBase):
             n_in = h
         dense("POSTERIOR/MU", n_in, self.latent_size, False)
         dense("POSTERIOR/LOG_SIGMA", n_in, self.latent_size, False)
-        n_in = self.latent_size
+        n_in = self.latent_size + self.decoder_extra_size
         for i, h in enumerate(H[::-1]):
             dense("DECODER/{}".format(len(H) - i), n_in, h, bn)
             n_in = h
