@@ -561,9 +561,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_stats_partial_kernel(
   }
 }
 
+// Fixed-order merge of the row-chunk partials.  The group-0 workgroups also do the two small
+// per-layer jobs that need nothing else: dbeta = sum over groups of s1 (this rank's rows, before
+// any data-parallel exchange of s1) and the moving-average update of the layer's batch statistics
+// (UPDATE_OPS, va:2763-2768; group after group, Bessel-corrected variance).
 __global__ void bn_bwd_stats_finalize_kernel(const float* __restrict__ partial, int N, int chunks,
                                              int G, float* __restrict__ s1,
-                                             float* __restrict__ s2) {
+                                             float* __restrict__ s2, float* __restrict__ dbeta,
+                                             const float* __restrict__ mean,
+                                             const float* __restrict__ var,
+                                             float* __restrict__ moving_mean,
+                                             float* __restrict__ moving_var, float bessel) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const int g = blockIdx.y;
   if (c >= N) return;
@@ -575,20 +583,44 @@ __global__ void bn_bwd_stats_finalize_kernel(const float* __restrict__ partial, 
   }
   s1[(size_t)g * N + c] = t1;
   s2[(size_t)g * N + c] = t2;
+  if (g != 0) return;
+  if (dbeta != nullptr) {
+    float total = t1;
+    for (int q = 1; q < G; ++q) {
+      float tq = 0.f;
+      for (int z = 0; z < chunks; ++z) tq += partial[(((size_t)z * G + q) * 2) * N + c];
+      total += tq;
+    }
+    dbeta[c] = total;
+  }
+  if (moving_mean != nullptr) {
+    float mm = moving_mean[c], mv = moving_var[c];
+    for (int q = 0; q < G; ++q) {
+      mm -= (mm - mean[(size_t)q * N + c]) * BN_UPDATE_RATE;
+      mv -= (mv - var[(size_t)q * N + c] * bessel) * BN_UPDATE_RATE;
+    }
+    moving_mean[c] = mm;
+    moving_var[c] = mv;
+  }
 }
 
 int bn_bwd_stats(hipStream_t stream, const float* dh, int lddh, const float* h, int ldh,
                  const float* a, int lda, const float* mean, const float* var, int rows_per_group,
-                 int groups, int N, int relu, float* s1, float* s2, float* partial) {
+                 int groups, int N, int relu, float* s1, float* s2, float* partial, float* dbeta,
+                 float* moving_mean, float* moving_var, int64_t global_rows_per_group) {
   SCVAE_ARG(dh && h && a && mean && var && s1 && s2 && partial);
+  SCVAE_ARG((moving_mean == nullptr) == (moving_var == nullptr));
   int chunk;
   const int chunks = bn_chunks(rows_per_group, &chunk);
   hipLaunchKernelGGL(bn_bwd_stats_partial_kernel, dim3((N + 63) / 64, groups, chunks), dim3(1024),
                      0, stream, dh, lddh, h, ldh, a, lda, mean, var, rows_per_group, N, relu, chunk,
                      partial);
   SCVAE_LAUNCH_CHECK("bn_bwd_stats_partial_kernel");
+  const int64_t R = global_rows_per_group;
+  const float bessel = (float)R / (float)(R > 1 ? R - 1 : 1);
   hipLaunchKernelGGL(bn_bwd_stats_finalize_kernel, dim3((N + 63) / 64, groups), dim3(64), 0,
-                     stream, partial, N, chunks, groups, s1, s2);
+                     stream, partial, N, chunks, groups, s1, s2, dbeta, mean, var, moving_mean,
+                     moving_var, bessel);
   SCVAE_LAUNCH_CHECK("bn_bwd_stats_finalize_kernel");
   return 0;
 }

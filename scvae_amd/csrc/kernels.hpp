@@ -63,7 +63,9 @@ int bn_update_moving(hipStream_t stream, const float* mean, const float* var, in
                      int groups, int N, float* moving_mean, float* moving_var);
 int bn_bwd_stats(hipStream_t stream, const float* dh, int lddh, const float* h, int ldh,
                  const float* a, int lda, const float* mean, const float* var, int rows_per_group,
-                 int groups, int N, int relu, float* s1, float* s2, float* partial);
+                 int groups, int N, int relu, float* s1, float* s2, float* partial,
+                 float* dbeta = nullptr, float* moving_mean = nullptr,
+                 float* moving_var = nullptr, int64_t global_rows_per_group = 1);
 int bn_bwd_apply(hipStream_t stream, const float* dh, int lddh, const float* h, int ldh,
                  const float* a, int lda, const float* mean, const float* var, const float* s1,
                  const float* s2, int rows_per_group, int groups, int N, int relu, float inv_count,

@@ -181,11 +181,13 @@ int dense_backward_activation(scvae_plan* p, hipStream_t s, Dense& d, int rows, 
     float* var = d.stats + (size_t)groups * N;
     float* s1 = d.stats + 2 * (size_t)groups * N;
     float* s2 = d.stats + 3 * (size_t)groups * N;
+    // the statistics launch also writes dbeta (sum over this rank's rows of dA, taken before s1
+    // becomes a global sum) and updates the layer's moving averages from the (possibly synced)
+    // batch statistics of the forward pass
     if ((rc = bn_bwd_stats(s, dh, N, d.h, N, d.a, N, mean, var, rpg, groups, N, relu ? 1 : 0, s1,
-                           s2, p->partial)))
+                           s2, p->partial, p->grads + d.beta, p->moving + d.mov_mean,
+                           p->moving + d.mov_var, global_rows_per_group)))
       return rc;
-    // dbeta = sum over this rank's rows of dA (taken before s1 becomes a global sum)
-    if ((rc = bn_dbeta(s, s1, groups, N, p->grads + d.beta, 0))) return rc;
     if (p->sync) {
       if (p->sync(p->sync_user, s1, 2 * (int64_t)groups * N, 0, rpg)) {
         set_error("batch-norm backward sync hook failed");
@@ -223,7 +225,10 @@ int dense_backward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int 
   if ((rc = gemm(s, true, false, in, da, nullptr, p->grads + d.w, d.n_in, N, rows, ld_in, N, N,
                  ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
     return rc;
-  if ((rc = col_sum(s, da, N, rows, N, p->grads + d.b, 1.f, 0, p->partial))) return rc;
+  // bias of a batch-normalised layer: the batch mean is subtracted again, its gradient is
+  // identically zero (the reference computes rounding noise there); the slot was zeroed at bind
+  if (!d.bn)
+    if ((rc = col_sum(s, da, N, rows, N, p->grads + d.b, 1.f, 0, p->partial))) return rc;
   if (d_in) {
     if ((rc = gemm(s, false, true, da, p->params + d.w, nullptr, d_in, rows, d.n_in, N, N, N,
                    d.n_in, ACT_NONE, accumulate_d_in, p->gemm_ws, p->gemm_ws_bytes)))
@@ -375,8 +380,13 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   float* dalt = p->dbuf[1];
   if (n_iw == 1) {
     // d(-ELBO_w)/d log p = -1/(MC*B) for every row: known before the likelihood pass
-    if ((rc = fill(s, p->gw, -row_scale, (size_t)R))) return rc;
+    if (p->gw_rows < (size_t)R || p->gw_value != -row_scale) {
+      if ((rc = fill(s, p->gw, -row_scale, (size_t)R))) return rc;
+      p->gw_value = -row_scale;
+      p->gw_rows = (size_t)R;
+    }
   } else {
+    p->gw_rows = 0;   // vae_elbo below overwrites gw with the importance weights
     // importance weights need all log-likelihoods first
     if (fused) {
       if ((rc = decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, a->t, B, a->row_const,
@@ -460,11 +470,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       return rc;
     if (i > 0) { float* t = dh; dh = dh_alt; dh_alt = t; }
   }
-  // batch-norm moving averages
-  for (auto& d : p->enc)
-    if ((rc = dense_update_moving(p, s, d, GB, 1))) return rc;
-  for (auto& d : p->dec)
-    if ((rc = dense_update_moving(p, s, d, GR, 1))) return rc;
+  // (the batch-norm moving averages were updated by the layers' backward statistics launches)
   return 0;
 }
 
@@ -544,10 +550,17 @@ int scvae_plan_bind(scvae_plan* p, float* params, float* grads, float* moving, v
   }
   SCVAE_ARG(((uintptr_t)workspace % 256) == 0 && ((uintptr_t)params % 256) == 0);
   p->params = params; p->grads = grads; p->moving = moving;
+  p->gw_rows = 0;
   p->ws = workspace; p->ws_bytes = (size_t)workspace_bytes;
   p->max_cells = max_cells; p->max_samples = max_samples;
   if (gm) scvae::carve_gmvae(p, workspace, (size_t)workspace_bytes, max_cells, max_samples, false);
   else scvae::carve(p, workspace, (size_t)workspace_bytes, max_cells, max_samples, false);
+  if (grads) {
+    // bias gradients of batch-normalised layers are identically zero and never written
+    for (auto* layers : {&p->enc, &p->dec, &p->yenc, &p->zenc, &p->xdec})
+      for (auto& d : *layers)
+        if (d.bn) SCVAE_HIP(hipMemset(grads + d.b, 0, (size_t)d.n_out * sizeof(float)));
+  }
   return 0;
 }
 

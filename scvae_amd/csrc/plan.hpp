@@ -128,6 +128,8 @@ struct scvae_plan {
   size_t gemm_ws_bytes = 0;
   float* partial = nullptr;  // row-chunk partial sums (batch norm, column sums)
   float* fused_ws = nullptr;  // fused decoder: per-strip ll / dd partial slabs
+  float gw_value = 0.f;       // what the first gw_rows entries of `gw` currently hold (VAE, IW = 1:
+  size_t gw_rows = 0;         //  the constant -1/(MC*B) is only rewritten when it changes)
   float *zcat = nullptr, *dzcat = nullptr;  // [rows, L + E]: decoder input [z | extra] and its gradient
   int use_fused = 1;          // fused decoder head kernel (0 = unfused GEMM + likelihood path)
   scvae_sync_fn sync = nullptr;

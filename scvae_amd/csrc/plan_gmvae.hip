@@ -372,7 +372,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       float* dW = p->grads + d.w;
       // one-hot rows: dW[F+k,:] = sum_b dA[k,b,:]
       TRY(group_col_sum(s, da, N, B, K, N, 1.f, dW + (size_t)F * N, p->partial));
-      TRY(col_sum(s, da, N, KB, N, p->grads + d.b, 1.f, 0, p->partial));
+      if (!d.bn) TRY(col_sum(s, da, N, KB, N, p->grads + d.b, 1.f, 0, p->partial));
       // data rows: dW[:F] = x^T (sum_k dA[k])
       TRY(sum_groups(s, da, nullptr, 0, K, B, N, p->sum_scratch));
       GEMM(true, false, a->x, p->sum_scratch, nullptr, dW, F, N, B, F, N, N, ACT_NONE, false);
@@ -401,9 +401,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
 
   // ---------------- batch-norm moving averages (K passes update in pass order) --------
-  for (auto& d : p->yenc) TRY(dense_update_moving(p, s, d, GB, 1));
-  for (auto& d : p->zenc) TRY(dense_update_moving(p, s, d, GB, K));
-  for (auto& d : p->xdec) TRY(dense_update_moving(p, s, d, GSB, K));
+  // (the batch-norm moving averages were updated by the layers' backward statistics launches)
 #undef GEMM
 #undef TRY
   return 0;
