@@ -1,0 +1,116 @@
+"""Parity at the benchmark's full size (4096 cells x 32 738 genes, NB VAE 100-100-25), where the
+fp64 oracle cannot run the whole step in seconds:
+
+* the fused decoder-head kernel against the unfused path (GEMM + element-wise likelihood kernels),
+  two independent implementations of the same maths, on ELBO, per-cell log-likelihood and every
+  gradient;
+* the oracle on a subset of the cells in evaluation mode (moving statistics make the rows
+  independent), per-cell log-likelihood and KL;
+* size-independent properties: lower_bound == reconstruction_error - kl_divergence, bitwise
+  reproducibility of a repeated step, and row-permutation equivariance of the per-cell outputs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as om
+
+pytestmark = pytest.mark.gpu
+
+CELLS, F, H, L = 4096, 32738, (100, 100), 25
+
+
+@pytest.fixture(scope="module")
+def full_size(cuda_device):
+    from scvae_amd.engine import Engine
+    from scvae_amd.minibatch import philox_normal, synthetic_count_matrix
+    eng = Engine(F, L, H, "negative binomial", batch_norm=True,
+                 device=cuda_device, seed=0)
+    g = torch.Generator().manual_seed(1)
+    for name, p in eng.named_parameters().items():
+        if not name.endswith("weights"):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    for name, m in eng.named_moving_statistics().items():
+        if name.endswith("moving_mean"):
+            m.copy_(torch.randn(m.shape, generator=g) * 0.2)
+        else:
+            m.copy_(torch.rand(m.shape, generator=g) + 0.5)
+    matrix, _ = synthetic_count_matrix(CELLS, F, density=0.05, seed=60,
+                                       device=cuda_device)
+    x = torch.empty(CELLS, F, device=cuda_device)
+    row_const = torch.empty(CELLS, device=cuda_device)
+    matrix.gather_dense(torch.arange(CELLS, device=cuda_device), out=x,
+                        row_const_out=row_const)
+    eps = torch.empty(1, CELLS, L, device=cuda_device)
+    philox_normal(eps[0], row_offset=0, seed=1, stream_id=0)
+    return eng, x, row_const, eps
+
+
+def _training_step(eng, x, row_const, eps):
+    ll = torch.zeros(CELLS, device=x.device)
+    scalars = eng.step(x, x, eps=eps, row_const=row_const, training=True,
+                       outputs={"log_p_x_given_z": ll}).clone()
+    torch.cuda.synchronize()
+    return scalars.cpu().numpy(), ll.cpu().numpy(), eng.grads.clone()
+
+
+def test_fused_and_unfused_paths_agree(full_size):
+    eng, x, row_const, eps = full_size
+    from scvae_amd import _lib
+    assert eng.lib.scvae_decoder_fused_variant(_lib.LIKELIHOOD_KINDS[
+        "negative binomial"][0], H[0]) in (1, 2)
+    eng.set_fused(True)
+    s_f, ll_f, g_f = _training_step(eng, x, row_const, eps)
+    again = _training_step(eng, x, row_const, eps)
+    assert np.array_equal(s_f, again[0]) and torch.equal(g_f, again[2]), \
+        "a repeated step must be bitwise reproducible"
+    eng.set_fused(False)
+    s_u, ll_u, g_u = _training_step(eng, x, row_const, eps)
+    eng.set_fused(True)
+    assert abs(s_f[0] - s_u[0]) <= 1e-6 * abs(s_u[0])
+    assert np.abs(ll_f - ll_u).max() <= 1e-5 * np.abs(ll_u).max()
+    # lower_bound == reconstruction_error - kl_divergence (va:2596-2632)
+    assert abs(s_f[0] - (s_f[2] - s_f[3])) <= 1e-6 * abs(s_f[0])
+    for name, (offset, shape) in eng.param_table.items():
+        n = int(np.prod(shape))
+        a, b = g_f[offset:offset + n], g_u[offset:offset + n]
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 1e-4 * scale + 1e-12, name
+
+
+def test_subset_of_cells_matches_oracle_in_evaluation_mode(full_size):
+    eng, x, row_const, eps = full_size
+    ll = torch.zeros(CELLS, device=x.device)
+    eng.step(x, x, eps=eps, row_const=row_const, training=False,
+             outputs={"log_p_x_given_z": ll})
+    torch.cuda.synchronize()
+    rows = np.arange(0, CELLS, 97)[:40]
+    cfg = om.ModelConfig(feature_size=F, latent_size=L, hidden_sizes=H,
+                         likelihood="negative binomial")
+    params = {k: v.detach().cpu().double()
+              for k, v in eng.named_parameters().items()}
+    moving = {k: v.detach().cpu().double()
+              for k, v in eng.named_moving_statistics().items()}
+    xs = x[rows].cpu().double()
+    out = om.vae_forward(cfg, params, moving, xs, xs,
+                         eps[:, rows].cpu().double(), False)
+    want = out["log_p_x_given_z"].reshape(-1).numpy()
+    got = ll.cpu().numpy()[rows]
+    assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+
+
+def test_per_cell_outputs_follow_a_row_permutation(full_size):
+    eng, x, row_const, eps = full_size
+    dev = x.device
+    ll = torch.zeros(CELLS, device=dev)
+    eng.step(x, x, eps=eps, row_const=row_const, training=False,
+             outputs={"log_p_x_given_z": ll})
+    perm = torch.randperm(CELLS, generator=torch.Generator().manual_seed(3)
+                          ).to(dev)
+    ll_p = torch.zeros(CELLS, device=dev)
+    eng.step(x[perm].contiguous(), x[perm].contiguous(),
+             eps=eps[:, perm].contiguous(),
+             row_const=row_const[perm].contiguous(), training=False,
+             outputs={"log_p_x_given_z": ll_p})
+    torch.cuda.synchronize()
+    assert (ll_p - ll[perm]).abs().max().item() <= 2e-6 * ll.abs().max().item()
