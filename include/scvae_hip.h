@@ -53,6 +53,10 @@ typedef struct scvae_model_config {
   int32_t n_clusters;         /* K (GMVAE), 1 for the VAE */
   float kl_weight;
   float free_nats_proportion; /* proportion_of_free_nats_for_y_kl_divergence */
+  int32_t k_max;              /* piecewise categorical likelihood (-k, va:2507-2532,
+                                 distributions/categorised.py): counts below k_max are classes
+                                 of a categorical head P_K [F * (k_max + 1)]; 0 = off.  Poisson
+                                 and negative binomial only */
   int32_t decoder_extra;      /* E: extra decoder input columns appended to z -- one-hot batch
                                  indices (batch_correction) and/or the normalised count sum
                                  (use_count_sum_as_feature), va:2407-2441, gm:3094-3130 */

@@ -103,6 +103,34 @@ def log_prob(name, t, pre):
     raise ValueError(name)
 
 
+def categorised_log_prob(name, t, pre, logits, k_max):
+    """``Categorised(dist, cat)`` of distributions/categorised.py:255-263:
+    counts 0..k_max-1 are classes of a categorical, class k_max stands for
+    "k_max or more" and hands the excess ``t - k_max`` to the count
+    distribution.  ``logits``: [..., F, k_max + 1]."""
+    log_pi = torch.log_softmax(logits, dim=-1)
+    classes = torch.clamp(t, 0, k_max).to(torch.int64)
+    cat = torch.gather(log_pi, -1, classes.unsqueeze(-1)).squeeze(-1)
+    tail = t >= k_max
+    # evaluated only where it counts (tf.where also masks the other branch)
+    excess = torch.where(tail, t - k_max, torch.zeros_like(t))
+    return cat + torch.where(tail, log_prob(name, excess, pre),
+                             torch.zeros_like(t))
+
+
+def categorised_mean_variance(name, pre, logits, k_max):
+    """categorised.py:210-253."""
+    pi = torch.softmax(logits, dim=-1)
+    ks = torch.arange(k_max, dtype=logits.dtype)
+    cat_mean = (pi[..., :k_max] * ks).sum(dim=-1)
+    cat_second = (pi[..., :k_max] * ks * ks).sum(dim=-1)
+    m, v = mean_variance(name, pre)
+    tail = pi[..., k_max]
+    mean = cat_mean + tail * (m + k_max)
+    second = cat_second + tail * (2 * k_max * m + v + m * m + k_max ** 2)
+    return mean, second - mean * mean
+
+
 def mean_variance(name, pre):
     """E[x|z], Var[x|z] of the decoder distribution (TFP semantics)."""
     if name == "poisson":

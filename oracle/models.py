@@ -57,6 +57,9 @@ class ModelConfig:
     # (batch_correction) and/or the normalised count sum
     # (use_count_sum_as_feature), va:2407-2441, gm:3094-3130
     decoder_extra_size: int = 0
+    # piecewise categorical likelihood (-k): counts below k_max are classes of
+    # a categorical head P_K, va:2507-2532 (0 = off)
+    k_max: int = 0
 
     @property
     def heads(self):
@@ -96,6 +99,9 @@ def vae_parameter_shapes(cfg):
     for p in cfg.heads:
         shapes += _dense_entries("X_TILDE/" + p.upper(), n_in,
                                  cfg.feature_size, False)
+    if cfg.k_max:
+        shapes += _dense_entries(
+            "X_TILDE/P_K", n_in, cfg.feature_size * (cfg.k_max + 1), False)
     return OrderedDict(shapes)
 
 
@@ -129,6 +135,9 @@ def gmvae_parameter_shapes(cfg):
     for p in cfg.heads:
         shapes += _dense_entries("X/DISTRIBUTION/" + p.upper(), n_in, Fs,
                                  False)
+    if cfg.k_max:
+        shapes += _dense_entries("X/DISTRIBUTION/P_K", n_in,
+                                 Fs * (cfg.k_max + 1), False)
     return OrderedDict(shapes)
 
 
@@ -207,6 +216,25 @@ def _normal_log_prob(z, mean, sigma):
             - HALF_LOG_2PI)
 
 
+def _decoder_distribution(cfg, d, params, scope, training, moving):
+    """Head pre-activations (and the P_K logits) of p(x|z) from the last
+    decoder layer ``d``; returns (log_prob(t), mean_variance()) closures."""
+    pre = tuple(
+        dense_layer(d, params, scope + p.upper(), False, training, moving,
+                    None, activation=False)
+        for p in cfg.heads)
+    if not cfg.k_max:
+        return (lambda t: lk.log_prob(cfg.likelihood, t, pre),
+                lambda: lk.mean_variance(cfg.likelihood, pre))
+    logits = dense_layer(d, params, scope + "P_K", False, training, moving,
+                         None, activation=False)
+    logits = logits.reshape(d.shape[0], cfg.feature_size, cfg.k_max + 1)
+    return (lambda t: lk.categorised_log_prob(cfg.likelihood, t, pre, logits,
+                                              cfg.k_max),
+            lambda: lk.categorised_mean_variance(cfg.likelihood, pre, logits,
+                                                 cfg.k_max))
+
+
 # --------------------------------------------------------------------------
 # decoder only (model.sample(): va:1601-1779, gm:1949-2160)
 # --------------------------------------------------------------------------
@@ -226,12 +254,9 @@ def decode_mean(cfg, params, moving, z, model_type="VAE"):
     else:
         d = _layers(z, params, "X/DECODER", H[::-1], bn, False, moving, None)
         scope = "X/DISTRIBUTION/"
-    pre = tuple(
-        dense_layer(d, params, scope + p.upper(), False, False, moving, None,
-                    activation=False)
-        for p in cfg.heads)
-    mean, _ = lk.mean_variance(cfg.likelihood, pre)
-    return mean
+    _, mean_variance = _decoder_distribution(cfg, d, params, scope, False,
+                                             moving)
+    return mean_variance()[0]
 
 
 # --------------------------------------------------------------------------
@@ -275,13 +300,11 @@ def vae_forward(cfg, params, moving, x, t, eps, training, warm_up_weight=1.0,
     for i in range(n):
         d = dense_layer(d, params, "DECODER/{}".format(n - i), bn, training,
                         moving, new_moving)
-    pre = tuple(
-        dense_layer(d, params, "X_TILDE/" + p.upper(), False, training,
-                    moving, None, activation=False)
-        for p in cfg.heads)
+    log_prob, mean_variance = _decoder_distribution(
+        cfg, d, params, "X_TILDE/", training, moving)
 
     t_tiled = t.repeat(S, 1)
-    log_p = lk.log_prob(cfg.likelihood, t_tiled, pre).sum(dim=-1)
+    log_p = log_prob(t_tiled).sum(dim=-1)
     log_p = log_p.reshape(n_iw, n_mc, B)
 
     if analytical_kl:
@@ -311,7 +334,7 @@ def vae_forward(cfg, params, moving, x, t, eps, training, warm_up_weight=1.0,
         log_p - w * kl_cell, 0).mean()
 
     if evaluation_statistics:
-        m, v = lk.mean_variance(cfg.likelihood, pre)
+        m, v = mean_variance()
         m = m.reshape(n_iw, n_mc, B, -1)
         v = v.reshape(n_iw, n_mc, B, -1)
         p_x_mean = m.mean(dim=1).mean(dim=0)
@@ -395,11 +418,9 @@ def gmvae_forward(cfg, params, moving, x, t, eps, training,
             d = torch.cat([d, decoder_extra.repeat(S, 1)], dim=1)
         d = _layers(d, params, "X/DECODER", H[::-1], bn, training, moving,
                     new_moving)
-        pre = tuple(
-            dense_layer(d, params, "X/DISTRIBUTION/" + p.upper(), False,
-                        training, moving, None, activation=False)
-            for p in cfg.heads)
-        log_p = lk.log_prob(cfg.likelihood, t_tiled, pre).sum(dim=-1)
+        log_prob, mean_variance = _decoder_distribution(
+            cfg, d, params, "X/DISTRIBUTION/", training, moving)
+        log_p = log_prob(t_tiled).sum(dim=-1)
         log_p = log_p.reshape(S, B)
         log_p_all.append(log_p)
 
@@ -417,7 +438,7 @@ def gmvae_forward(cfg, params, moving, x, t, eps, training,
         q_z_variances.append((q_sigma ** 2).mean(dim=0))
 
         if evaluation_statistics:
-            m, v = lk.mean_variance(cfg.likelihood, pre)
+            m, v = mean_variance()
             m = m.reshape(S, B, -1)
             v = v.reshape(S, B, -1)
             pxm = m.mean(dim=0) * yk.unsqueeze(-1)

@@ -40,6 +40,7 @@ class ModelConfig(Structure):
         ("n_clusters", c_int32),
         ("kl_weight", c_float),
         ("free_nats_proportion", c_float),
+        ("k_max", c_int32),
         ("decoder_extra", c_int32),
     ]
 

@@ -85,6 +85,174 @@ int loglik_bwd(hipStream_t stream, int kind, const float* t, int ldt, HeadPtrs p
   return launch_loglik<true>(stream, kind, t, ldt, pre, ldp, gw, row_const, ll, rows, B, F);
 }
 
+// ---- piecewise categorical likelihood (-k) ----
+// log-softmax over the K+1 logits of one (row, feature); returns the log-normaliser
+__device__ __forceinline__ float cat_log_normaliser(const float* __restrict__ l, int C) {
+  float m = l[0];
+  for (int c = 1; c < C; ++c) m = fmaxf(m, l[c]);
+  float sum = 0.f;
+  for (int c = 0; c < C; ++c) sum += __expf(l[c] - m);
+  return m + __logf(sum);
+}
+
+template <int KIND, bool GRAD>
+__global__ __launch_bounds__(256) void loglik_cat_rows_kernel(
+    const float* __restrict__ t, int ldt, HeadPtrs pre, int ldp, float* __restrict__ logits, int K,
+    const float* __restrict__ gw, float* __restrict__ ll, int B, int F) {
+  constexpr int P = (KIND == LK_POISSON) ? 1 : 2;
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  const int C = K + 1;
+  const float* trow = t + (size_t)(r % B) * ldt;
+  float* lrow = logits + (size_t)r * F * C;
+  const float g_up = GRAD ? gw[r] : 0.f;
+  float acc = 0.f;
+  for (int f = threadIdx.x; f < F; f += 256) {
+    const float tv = trow[f];
+    float* l = lrow + (size_t)f * C;
+    const float lse = cat_log_normaliser(l, C);
+    // cast(clip(x, 0, K), int32), categorised.py:257-258
+    const int cls = (int)fminf(fmaxf(tv, 0.f), (float)K);
+    float lp = l[cls] - lse;
+    float a[P], g[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) { a[j] = pre.p[j][(size_t)r * ldp + f]; g[j] = 0.f; }
+    if (tv >= (float)K) {
+      float lpd;
+      lik_elem<KIND, GRAD>(tv - (float)K, a, lpd, g);
+      lp += lpd - lgamma1p(tv - (float)K);
+    }
+    acc += lp;
+    if (GRAD) {
+#pragma unroll
+      for (int j = 0; j < P; ++j) pre.p[j][(size_t)r * ldp + f] = g_up * g[j];
+      for (int c = 0; c < C; ++c) {
+        const float soft = __expf(l[c] - lse);
+        l[c] = g_up * ((c == cls ? 1.f : 0.f) - soft);
+      }
+    }
+  }
+  acc = block_sum<256>(acc, red);
+  if (threadIdx.x == 0 && ll != nullptr) ll[r] = acc;
+}
+
+template <bool GRAD>
+static int launch_loglik_cat(hipStream_t stream, int kind, const float* t, int ldt, HeadPtrs pre,
+                             int ldp, float* logits, int K, const float* gw, float* ll, int rows,
+                             int B, int F) {
+  SCVAE_ARG(t && pre.p[0] && logits && K > 0 && K <= 64 && rows >= 0 && B > 0 && F > 0);
+  if (rows == 0) return 0;
+  dim3 grid(rows), block(256);
+  switch (kind) {
+    case LK_POISSON:
+      hipLaunchKernelGGL((loglik_cat_rows_kernel<LK_POISSON, GRAD>), grid, block, 0, stream, t, ldt,
+                         pre, ldp, logits, K, gw, ll, B, F);
+      break;
+    case LK_NB:
+      hipLaunchKernelGGL((loglik_cat_rows_kernel<LK_NB, GRAD>), grid, block, 0, stream, t, ldt, pre,
+                         ldp, logits, K, gw, ll, B, F);
+      break;
+    default:
+      set_error("the piecewise categorical likelihood wraps Poisson or negative binomial only");
+      return -1;
+  }
+  SCVAE_LAUNCH_CHECK("loglik_cat_rows_kernel");
+  return 0;
+}
+int loglik_cat_fwd(hipStream_t stream, int kind, const float* t, int ldt, HeadPtrs pre, int ldp,
+                   float* logits, int K, float* ll, int rows, int B, int F) {
+  SCVAE_ARG(ll);
+  return launch_loglik_cat<false>(stream, kind, t, ldt, pre, ldp, logits, K, nullptr, ll, rows, B,
+                                  F);
+}
+int loglik_cat_bwd(hipStream_t stream, int kind, const float* t, int ldt, HeadPtrs pre, int ldp,
+                   float* logits, int K, const float* gw, float* ll, int rows, int B, int F) {
+  SCVAE_ARG(gw);
+  return launch_loglik_cat<true>(stream, kind, t, ldt, pre, ldp, logits, K, gw, ll, rows, B, F);
+}
+
+// mean and variance of Categorised(dist, cat) (categorised.py:210-253)
+template <int KIND>
+__device__ __forceinline__ void cat_mean_var(const float* a, const float* __restrict__ l, int K,
+                                             float& mean, float& var) {
+  const int C = K + 1;
+  const float lse = cat_log_normaliser(l, C);
+  float m1 = 0.f, m2 = 0.f;
+  for (int c = 0; c < K; ++c) {
+    const float pi = __expf(l[c] - lse);
+    m1 += (float)c * pi;
+    m2 += (float)(c * c) * pi;
+  }
+  const float tail = __expf(l[K] - lse);
+  float dm, dv;
+  lik_mean_var<KIND>(a, dm, dv);
+  const float k = (float)K;
+  mean = m1 + tail * (dm + k);
+  var = m2 + tail * (2.f * k * dm + dv + dm * dm + k * k) - mean * mean;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void px_statistics_cat_kernel(
+    HeadPtrs pre, int ldp, const float* __restrict__ logits, int K, int S, int B, int F,
+    const float* __restrict__ weight, int ldw, int accumulate, float* __restrict__ p_x_mean,
+    float* __restrict__ mean_of_var, float* __restrict__ var_of_mean) {
+  constexpr int P = (KIND == LK_POISSON) ? 1 : 2;
+  const int b = blockIdx.y;
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  const int C = K + 1;
+  const float wgt = weight ? weight[(size_t)b * ldw] : 1.f;
+  const float inv_s = 1.f / (float)S;
+  float ms = 0.f, vs = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const size_t row = (size_t)s * B + b;
+    float a[P], m, v;
+#pragma unroll
+    for (int j = 0; j < P; ++j) a[j] = pre.p[j][row * ldp + f];
+    cat_mean_var<KIND>(a, logits + (row * F + f) * C, K, m, v);
+    ms += m; vs += v;
+  }
+  const float pm = ms * inv_s * wgt;
+  float vom = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const size_t row = (size_t)s * B + b;
+    float a[P], m, v;
+#pragma unroll
+    for (int j = 0; j < P; ++j) a[j] = pre.p[j][row * ldp + f];
+    cat_mean_var<KIND>(a, logits + (row * F + f) * C, K, m, v);
+    vom += (m - pm) * (m - pm);
+  }
+  vom *= inv_s * wgt;
+  const float mov = vs * inv_s * wgt;
+  const size_t o = (size_t)b * F + f;
+  if (accumulate) { p_x_mean[o] += pm; mean_of_var[o] += mov; var_of_mean[o] += vom; }
+  else { p_x_mean[o] = pm; mean_of_var[o] = mov; var_of_mean[o] = vom; }
+}
+
+int px_statistics_cat(hipStream_t stream, int kind, HeadPtrs pre, int ldp, const float* logits,
+                      int K, int S, int B, int F, const float* weight, int ldw, int accumulate,
+                      float* p_x_mean, float* mean_of_var, float* var_of_mean) {
+  SCVAE_ARG(pre.p[0] && logits && K > 0 && p_x_mean && mean_of_var && var_of_mean && S > 0 && F > 0);
+  if (B == 0) return 0;
+  dim3 grid((F + 255) / 256, B), block(256);
+  switch (kind) {
+    case LK_POISSON:
+      hipLaunchKernelGGL((px_statistics_cat_kernel<LK_POISSON>), grid, block, 0, stream, pre, ldp,
+                         logits, K, S, B, F, weight, ldw, accumulate, p_x_mean, mean_of_var,
+                         var_of_mean);
+      break;
+    case LK_NB:
+      hipLaunchKernelGGL((px_statistics_cat_kernel<LK_NB>), grid, block, 0, stream, pre, ldp, logits,
+                         K, S, B, F, weight, ldw, accumulate, p_x_mean, mean_of_var, var_of_mean);
+      break;
+    default:
+      set_error("the piecewise categorical likelihood wraps Poisson or negative binomial only");
+      return -1;
+  }
+  SCVAE_LAUNCH_CHECK("px_statistics_cat_kernel");
+  return 0;
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void px_statistics_kernel(HeadPtrs pre, int ldp, int S, int B,
                                                             int F, const float* __restrict__ weight,

@@ -27,6 +27,19 @@ int loglik_fwd(hipStream_t stream, int kind, const float* t, int ldt, HeadPtrs p
 // in place: pre_j <- gw[r] * d loglik / d pre_j ; also (re)computes ll if ll != null
 int loglik_bwd(hipStream_t stream, int kind, const float* t, int ldt, HeadPtrs pre, int ldp,
                const float* gw, const float* row_const, float* ll, int rows, int B, int F);
+// Piecewise categorical likelihood (`Categorised`, distributions/categorised.py:210-263; -k):
+// `logits` [rows, F*(K+1)] of the P_K head, class c of feature f at f*(K+1)+c.  Counts below K are
+// classes of the categorical, class K hands the excess t-K to the count distribution (kind:
+// Poisson or negative binomial).  GRAD form: pre_j and logits are overwritten by
+// gw[r] * d loglik / d(.).  The data term lgamma(1 + t - K) is evaluated inline.
+int loglik_cat_fwd(hipStream_t stream, int kind, const float* t, int ldt, HeadPtrs pre, int ldp,
+                   float* logits, int K, float* ll, int rows, int B, int F);
+int loglik_cat_bwd(hipStream_t stream, int kind, const float* t, int ldt, HeadPtrs pre, int ldp,
+                   float* logits, int K, const float* gw, float* ll, int rows, int B, int F);
+// px_statistics with the categorised mean / variance (categorised.py:210-253)
+int px_statistics_cat(hipStream_t stream, int kind, HeadPtrs pre, int ldp, const float* logits,
+                      int K, int S, int B, int F, const float* weight, int ldw, int accumulate,
+                      float* p_x_mean, float* mean_of_var, float* var_of_mean);
 // evaluate-time statistics over the S samples of each cell (va:2665-2713):
 // p_x_mean, p_x_stddev, stddev_of_p_x_given_z_mean, each [B,F]. `weight` (optional, [B], stride
 // ldw) and `accumulate` implement the GMVAE mixture sums (gm:3311-3386).

@@ -47,6 +47,8 @@ static int build_vae(scvae_plan* p) {
     snprintf(scope, sizeof scope, "X_TILDE/%s", head_names(c.likelihood, j));
     p->heads[j] = L.dense(scope, n_in, c.feature_size, false);
   }
+  if (c.k_max > 0)
+    p->head_k = L.dense("X_TILDE/P_K", n_in, c.feature_size * (c.k_max + 1), false);
   // the first encoder layer's dW (x^T dA, the last large GEMM of the backward pass) is the only
   // gradient still missing when the hook is told that the rest may be all-reduced
   if (!p->enc.empty()) p->early_reduce_layer = &p->enc[0];
@@ -100,8 +102,13 @@ static size_t carve(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_
   const int h1 = c.n_hidden ? c.hidden[0] : c.latent_size;
   track(B, Lz, hn); track(hn, Lz, B); track(B, hn, Lz);
   track(R, F, h1); track(h1, F, R); track(R, h1, F);
+  if (c.k_max > 0) {
+    const size_t FC = F * (size_t)(c.k_max + 1);
+    track(R, FC, h1); track(h1, FC, R); track(R, h1, FC);
+  }
   float* gemm_ws = gws ? b.floats(gws / sizeof(float)) : nullptr;
   size_t pmax = col_sum_partial_floats((int)(F > hmax ? F : hmax));
+  if (c.k_max > 0) pmax = col_sum_partial_floats((int)(F * (size_t)(c.k_max + 1)));
   { const size_t q = bn_partial_floats(1, (int)hmax); if (q > pmax) pmax = q; }
   float* partial = b.floats(pmax);
   float* fused_ws = decoder_fused_supported(h1)
@@ -110,9 +117,11 @@ static size_t carve(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_
   const size_t E = (size_t)c.decoder_extra;
   float* zcat = E ? b.floats(R * (Lz + E)) : nullptr;
   float* dzcat = E ? b.floats(R * (Lz + E)) : nullptr;
+  float* pre_k = c.k_max > 0 ? b.floats(R * F * (size_t)(c.k_max + 1)) : nullptr;
   if (!dry) {
     p->fused_ws = fused_ws;
     p->zcat = zcat; p->dzcat = dzcat;
+    p->pre_k = pre_k;
     p->mu_pre = mu_pre; p->ls_pre = ls_pre; p->kl_elem = kl_elem; p->kl_cell = kl_cell;
     p->z = z; p->ll = ll; p->gw = gw;
     for (int j = 0; j < 3; ++j) p->pre[j] = pre[j];
@@ -336,8 +345,9 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const int h1 = p->heads[0].n_in;
   // the fused kernel never materialises the [rows, P*F] pre-activations; the evaluate-time
   // statistics (p_x_mean, ...) need them, so that request takes the unfused path
+  const int KM = c.k_max, FC = F * (KM + 1);   // piecewise categorical likelihood: unfused path
   const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
-                     !a->p_x_mean;
+                     !a->p_x_mean && KM == 0;
   const HeadParams hp = head_params(p);
   if (!fused) {
     for (int j = 0; j < p->P; ++j) {
@@ -346,28 +356,41 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                      hd.n_in, ld, F, F, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
         return rc;
     }
+    if (KM > 0) {
+      Dense& hk = p->head_k;
+      if ((rc = gemm(s, false, false, dch, p->params + hk.w, p->params + hk.b, p->pre_k, R, FC,
+                     hk.n_in, ld, FC, FC, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+        return rc;
+    }
   }
+  // per-row log-likelihood, forward only
+  auto loglik_forward = [&]() -> int {
+    if (fused)
+      return decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, a->t, B, a->row_const, p->ll,
+                                   p->fused_ws);
+    if (KM > 0)
+      return loglik_cat_fwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->ll, R, B, F);
+    return loglik_fwd(s, c.likelihood, a->t, F, pre, F, a->row_const, p->ll, R, B, F);
+  };
   if (a->p_x_mean) {
     if (!(a->p_x_stddev && a->stddev_of_p_x_given_z_mean)) {
       set_error("p_x_mean requires p_x_stddev and stddev_of_p_x_given_z_mean");
       return -1;
     }
-    if ((rc = px_statistics(s, c.likelihood, pre, F, S, B, F, nullptr, 0, 0, a->p_x_mean, p->mov,
-                            p->vom)))
-      return rc;
+    if (KM > 0)
+      rc = px_statistics_cat(s, c.likelihood, pre, F, p->pre_k, KM, S, B, F, nullptr, 0, 0,
+                             a->p_x_mean, p->mov, p->vom);
+    else
+      rc = px_statistics(s, c.likelihood, pre, F, S, B, F, nullptr, 0, 0, a->p_x_mean, p->mov,
+                         p->vom);
+    if (rc) return rc;
     if ((rc = sqrt_sum(s, p->vom, p->mov, a->p_x_stddev, (size_t)B * F))) return rc;
     if ((rc = sqrt_sum(s, p->vom, nullptr, a->stddev_of_p_x_given_z_mean, (size_t)B * F)))
       return rc;
   }
   const float row_scale = 1.f / ((float)n_mc * (float)GB);
   if (!training) {
-    if (fused) {
-      if ((rc = decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, a->t, B, a->row_const,
-                                      p->ll, p->fused_ws)))
-        return rc;
-    } else if ((rc = loglik_fwd(s, c.likelihood, a->t, F, pre, F, a->row_const, p->ll, R, B, F))) {
-      return rc;
-    }
+    if ((rc = loglik_forward())) return rc;
     if ((rc = vae_elbo(s, p->ll, p->kl_cell, n_iw, n_mc, B, w, row_scale, a->scalars, nullptr)))
       return rc;
     if (a->log_p_x_given_z)
@@ -388,13 +411,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   } else {
     p->gw_rows = 0;   // vae_elbo below overwrites gw with the importance weights
     // importance weights need all log-likelihoods first
-    if (fused) {
-      if ((rc = decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, a->t, B, a->row_const,
-                                      p->ll, p->fused_ws)))
-        return rc;
-    } else if ((rc = loglik_fwd(s, c.likelihood, a->t, F, pre, F, a->row_const, p->ll, R, B, F))) {
-      return rc;
-    }
+    if ((rc = loglik_forward())) return rc;
     if ((rc = vae_elbo(s, p->ll, p->kl_cell, n_iw, n_mc, B, w, row_scale, a->scalars, p->gw)))
       return rc;
   }
@@ -404,9 +421,13 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                                   a->row_const, p->ll, dcur, p->fused_ws)))
       return rc;
   } else {
-    if ((rc = loglik_bwd(s, c.likelihood, a->t, F, pre, F, p->gw, a->row_const,
-                         n_iw == 1 ? p->ll : nullptr, R, B, F)))
-      return rc;
+    if (KM > 0)
+      rc = loglik_cat_bwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->gw,
+                          n_iw == 1 ? p->ll : nullptr, R, B, F);
+    else
+      rc = loglik_bwd(s, c.likelihood, a->t, F, pre, F, p->gw, a->row_const,
+                      n_iw == 1 ? p->ll : nullptr, R, B, F);
+    if (rc) return rc;
     // heads: dW_j = d^T G_j, db_j = colsum(G_j), dd (+)= G_j W_j^T
     for (int j = 0; j < p->P; ++j) {
       Dense& hd = p->heads[j];
@@ -416,6 +437,16 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       if ((rc = col_sum(s, p->pre[j], F, R, F, p->grads + hd.b, 1.f, 0, p->partial))) return rc;
       if ((rc = gemm(s, false, true, p->pre[j], p->params + hd.w, nullptr, dcur, R, h1, F, F, F,
                      h1, ACT_NONE, j > 0, p->gemm_ws, p->gemm_ws_bytes)))
+        return rc;
+    }
+    if (KM > 0) {   // the P_K head, same three products on [rows, F * (K + 1)]
+      Dense& hk = p->head_k;
+      if ((rc = gemm(s, true, false, dch, p->pre_k, nullptr, p->grads + hk.w, h1, FC, R, ld, FC, FC,
+                     ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+        return rc;
+      if ((rc = col_sum(s, p->pre_k, FC, R, FC, p->grads + hk.b, 1.f, 0, p->partial))) return rc;
+      if ((rc = gemm(s, false, true, p->pre_k, p->params + hk.w, nullptr, dcur, R, h1, FC, FC, FC,
+                     h1, ACT_NONE, true, p->gemm_ws, p->gemm_ws_bytes)))
         return rc;
     }
   }
@@ -491,6 +522,8 @@ int scvae_plan_create(const scvae_model_config* cfg, scvae_plan** out) {
   SCVAE_ARG(cfg->model_type == SCVAE_MODEL_VAE || cfg->model_type == SCVAE_MODEL_GMVAE);
   SCVAE_ARG(cfg->model_type == SCVAE_MODEL_VAE || (cfg->n_clusters >= 1 && cfg->n_clusters <= 1024));
   SCVAE_ARG(cfg->decoder_extra >= 0 && cfg->decoder_extra <= 4096);
+  SCVAE_ARG(cfg->k_max >= 0 && cfg->k_max <= 64);
+  SCVAE_ARG(cfg->k_max == 0 || cfg->likelihood == SCVAE_POISSON || cfg->likelihood == SCVAE_NB);
   SCVAE_ARG(cfg->decoder_extra == 0 || cfg->n_hidden > 0);
   scvae_plan* p = new scvae_plan();
   p->cfg = *cfg;
@@ -604,6 +637,15 @@ int scvae_plan_decode(scvae_plan* p, const float* z, int64_t rows, float* p_x_me
     if ((rc = gemm(s, false, false, h, p->params + hd.w, p->params + hd.b, p->pre[j], R, F, hd.n_in,
                    ld, F, F, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
       return rc;
+  }
+  if (c.k_max > 0) {
+    Dense& hk = p->head_k;
+    const int FC = F * (c.k_max + 1);
+    if ((rc = gemm(s, false, false, h, p->params + hk.w, p->params + hk.b, p->pre_k, R, FC, hk.n_in,
+                   ld, FC, FC, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+      return rc;
+    return px_statistics_cat(s, c.likelihood, pre, F, p->pre_k, c.k_max, 1, R, F, nullptr, 0, 0,
+                             p_x_mean, p->mov, p->vom);
   }
   return px_statistics(s, c.likelihood, pre, F, 1, R, F, nullptr, 0, 0, p_x_mean, p->mov, p->vom);
 }

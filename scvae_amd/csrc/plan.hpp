@@ -113,6 +113,8 @@ struct scvae_plan {
   std::vector<Dense> enc, dec;
   Dense mu, ls;
   Dense heads[3];
+  Dense head_k;               // P_K logits of the piecewise categorical likelihood (cfg.k_max > 0)
+  float* pre_k = nullptr;     // [rows, F * (k_max + 1)]
   // bound buffers
   float *params = nullptr, *grads = nullptr, *moving = nullptr;
   void* ws = nullptr;

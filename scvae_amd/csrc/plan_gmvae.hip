@@ -44,6 +44,7 @@ int build_gmvae(scvae_plan* p) {
     snprintf(scope, sizeof scope, "X/DISTRIBUTION/%s", head_names(c.likelihood, j));
     p->heads[j] = L.dense(scope, n_in, F, false);
   }
+  if (c.k_max > 0) p->head_k = L.dense("X/DISTRIBUTION/P_K", n_in, F * (c.k_max + 1), false);
   return 0;
 }
 
@@ -106,8 +107,13 @@ size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t
   track(B, K, hn); track(hn, K, B); track(B, hn, K);
   track(KB, Lz, hn); track(hn, Lz, KB); track(KB, hn, Lz);
   track(R, F, h1); track(h1, F, R); track(R, h1, F);
+  if (c.k_max > 0) {
+    const size_t FC = F * (size_t)(c.k_max + 1);
+    track(R, FC, h1); track(h1, FC, R); track(R, h1, FC);
+  }
   float* gemm_ws = gws ? b.floats(gws / sizeof(float)) : nullptr;
   size_t pmax = col_sum_partial_floats((int)(F > hmax ? F : hmax));
+  if (c.k_max > 0) pmax = col_sum_partial_floats((int)(F * (size_t)(c.k_max + 1)));
   {
     const size_t q = bn_partial_floats((int)K, (int)(hmax > 2 * Lz ? hmax : 2 * Lz));
     if (q > pmax) pmax = q;
@@ -119,9 +125,11 @@ size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t
   const size_t E = (size_t)c.decoder_extra;
   float* zcat = E ? b.floats(R * (Lz + E)) : nullptr;
   float* dzcat = E ? b.floats(R * (Lz + E)) : nullptr;
+  float* pre_k = c.k_max > 0 ? b.floats(R * F * (size_t)(c.k_max + 1)) : nullptr;
   if (!dry) {
     p->fused_ws = fused_ws;
     p->zcat = zcat; p->dzcat = dzcat;
+    p->pre_k = pre_k;
     p->logits = logits; p->yprob = yprob; p->kl_y_cell = kl_y_cell; p->a0 = a0;
     p->qm = qm; p->qs = qs; p->z = z; p->klz = klz; p->gklz = gklz; p->ll = ll; p->gw = gw;
     p->dy = dy; p->dlogits = dlogits; p->dqm = dqm; p->dqs = dqs; p->dprior = dprior;
@@ -242,14 +250,20 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   for (int j = 0; j < 3; ++j) pre.p[j] = p->pre[j];
   const int h1 = p->heads[0].n_in;
   // fused heads + likelihood (+ backward) unless the evaluate-time statistics are requested
+  const int KM = c.k_max, FC = F * (KM + 1);   // piecewise categorical likelihood: unfused path
   const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
-                     !a->p_x_mean;
+                     !a->p_x_mean && KM == 0;
   const HeadParams hp = head_params(p);
   if (!fused) {
     for (int j = 0; j < p->P; ++j) {
       Dense& hd = p->heads[j];
       GEMM(false, false, dch, p->params + hd.w, p->params + hd.b, p->pre[j], R, F, hd.n_in, ld, F,
            F, ACT_NONE, false);
+    }
+    if (KM > 0) {
+      Dense& hk = p->head_k;
+      GEMM(false, false, dch, p->params + hk.w, p->params + hk.b, p->pre_k, R, FC, hk.n_in, ld, FC,
+           FC, ACT_NONE, false);
     }
   }
   if (a->p_x_mean) {
@@ -261,8 +275,12 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       HeadPtrs pk;
       for (int j = 0; j < 3; ++j)
         pk.p[j] = p->pre[j] ? p->pre[j] + (size_t)k * SB * F : nullptr;
-      TRY(px_statistics(s, c.likelihood, pk, F, S, B, F, p->yprob + k, K, k > 0 ? 1 : 0,
-                        a->p_x_mean, p->mov, p->vom));
+      if (KM > 0)
+        TRY(px_statistics_cat(s, c.likelihood, pk, F, p->pre_k + (size_t)k * SB * FC, KM, S, B, F,
+                              p->yprob + k, K, k > 0 ? 1 : 0, a->p_x_mean, p->mov, p->vom));
+      else
+        TRY(px_statistics(s, c.likelihood, pk, F, S, B, F, p->yprob + k, K, k > 0 ? 1 : 0,
+                          a->p_x_mean, p->mov, p->vom));
     }
     TRY(sqrt_sum(s, p->vom, p->mov, a->p_x_stddev, (size_t)B * F));
     TRY(sqrt_sum(s, p->vom, nullptr, a->stddev_of_p_x_given_z_mean, (size_t)B * F));
@@ -278,6 +296,8 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     if (fused)
       TRY(decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, a->t, B, a->row_const, p->ll,
                                 p->fused_ws));
+    else if (KM > 0)
+      TRY(loglik_cat_fwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->ll, R, B, F));
     else
       TRY(loglik_fwd(s, c.likelihood, a->t, F, pre, F, a->row_const, p->ll, R, B, F));
     TRY(gmvae_elbo(s, p->ll, p->klz, p->yprob, p->kl_y_cell, K, S, B, inv_gb, sums, nullptr));
@@ -294,6 +314,8 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   if (fused) {
     TRY(decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, a->t, B, p->gw, a->row_const,
                             p->ll, dcur, p->fused_ws));
+  } else if (KM > 0) {
+    TRY(loglik_cat_bwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->gw, p->ll, R, B, F));
   } else {
     TRY(loglik_bwd(s, c.likelihood, a->t, F, pre, F, p->gw, a->row_const, p->ll, R, B, F));
   }
@@ -320,6 +342,14 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       TRY(col_sum(s, p->pre[j], F, R, F, p->grads + hd.b, 1.f, 0, p->partial));
       GEMM(false, true, p->pre[j], p->params + hd.w, nullptr, dcur, R, h1, F, F, F, h1, ACT_NONE,
            j > 0);
+    }
+    if (KM > 0) {   // the P_K head, same three products on [rows, F * (K + 1)]
+      Dense& hk = p->head_k;
+      GEMM(true, false, dch, p->pre_k, nullptr, p->grads + hk.w, h1, FC, R, ld, FC, FC, ACT_NONE,
+           false);
+      TRY(col_sum(s, p->pre_k, FC, R, FC, p->grads + hk.b, 1.f, 0, p->partial));
+      GEMM(false, true, p->pre_k, p->params + hk.w, nullptr, dcur, R, h1, FC, FC, FC, h1, ACT_NONE,
+           true);
     }
   }
   const int64_t GSB = GB * S;  // global rows per group (pass) in the decoder

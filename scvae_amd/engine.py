@@ -38,7 +38,7 @@ class Engine:
     def __init__(self, feature_size, latent_size, hidden_sizes, likelihood,
                  batch_norm=True, model_type="VAE", n_clusters=1,
                  kl_weight=1.0, free_nats_proportion=0.0, device=None,
-                 seed=0, decoder_extra=0):
+                 seed=0, decoder_extra=0, k_max=0):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError(
@@ -53,6 +53,7 @@ class Engine:
         self.hidden_sizes = [int(h) for h in hidden_sizes]
         self.n_clusters = int(n_clusters)
         self.decoder_extra = int(decoder_extra)
+        self.k_max = int(k_max or 0)
         if len(self.hidden_sizes) > _lib.MAX_HIDDEN:
             raise ValueError("At most {} hidden layers are supported.".format(
                 _lib.MAX_HIDDEN))
@@ -71,6 +72,7 @@ class Engine:
         cfg.kl_weight = float(kl_weight)
         cfg.free_nats_proportion = float(free_nats_proportion)
         cfg.decoder_extra = self.decoder_extra
+        cfg.k_max = self.k_max
         self.config = cfg
 
         handle = ctypes.c_void_p()

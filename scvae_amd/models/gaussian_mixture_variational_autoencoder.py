@@ -204,9 +204,6 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
             reconstruction_distribution=self.reconstruction_distribution_name,
             number_of_reconstruction_classes=self.k_max)
 
-        if self.k_max:
-            raise mu.not_in_this_build(
-                "Piecewise categorical likelihood (-k)", "gm:3192-3219")
         if self.use_count_sum_as_parameter:
             raise mu.not_in_this_build(
                 "Count sum as a likelihood parameter (constrained Poisson, "
@@ -244,7 +241,7 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
             n_clusters=self.n_clusters, kl_weight=self.kl_weight_value,
             free_nats_proportion=(
                 self.proportion_of_free_nats_for_y_kl_divergence),
-            decoder_extra=self.decoder_extra_size)
+            decoder_extra=self.decoder_extra_size, k_max=self.k_max)
 
     def _parameter_shapes(self):
         table = []
@@ -276,6 +273,8 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
             n_in = h
         for parameter in self.reconstruction_distribution["parameters"]:
             dense("X/DISTRIBUTION/" + parameter.upper(), n_in, F, False)
+        if self.k_max:
+            dense("X/DISTRIBUTION/P_K", n_in, F * (self.k_max + 1), False)
         return table
 
     # -- names -------------------------------------------------------------------

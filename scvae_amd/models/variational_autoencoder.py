@@ -175,9 +175,6 @@ class VariationalAutoencoder(ModelBase):
             parameterise_latent_posterior=self.parameterise_latent_posterior)
 
         # options of the reference graph that have no kernels in this build
-        if self.k_max:
-            raise mu.not_in_this_build(
-                "Piecewise categorical likelihood (-k)", "va:2507-2532")
         if self.use_count_sum_as_parameter:
             raise mu.not_in_this_build(
                 "Count sum as a likelihood parameter (constrained Poisson, "
@@ -211,7 +208,7 @@ class VariationalAutoencoder(ModelBase):
             likelihood=self.reconstruction_distribution_name,
             batch_norm=bool(self.minibatch_normalisation), model_type="VAE",
             kl_weight=self.kl_weight_value,
-            decoder_extra=self.decoder_extra_size)
+            decoder_extra=self.decoder_extra_size, k_max=self.k_max)
 
     def _parameter_shapes(self):
         table = []
@@ -235,6 +232,9 @@ class VariationalAutoencoder(ModelBase):
             n_in = h
         for parameter in self.reconstruction_distribution["parameters"]:
             dense("X_TILDE/" + parameter.upper(), n_in, self.feature_size,
+                  False)
+        if self.k_max:
+            dense("X_TILDE/P_K", n_in, self.feature_size * (self.k_max + 1),
                   False)
         return table
 

@@ -80,8 +80,13 @@ def test_constructor_errors():
         VariationalAutoencoder(
             10, reconstruction_distribution="zero-inflated poisson",
             number_of_reconstruction_classes=3)
+    # built: the piecewise categorical likelihood, batch correction, count sums
+    model = VariationalAutoencoder(10, number_of_reconstruction_classes=3,
+                                   batch_correction=True, number_of_batches=2,
+                                   count_sum=True)
+    assert model.k_max == 3 and model.decoder_extra_size == 3
     with pytest.raises(NotImplementedError):
-        VariationalAutoencoder(10, number_of_reconstruction_classes=3)
+        VariationalAutoencoder(10, dropout_keep_probabilities=[0.9])
     with pytest.raises(NotImplementedError):
         GaussianMixtureVariationalAutoencoder(
             10, prior_probabilities_method="learn")
