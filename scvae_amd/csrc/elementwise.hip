@@ -578,31 +578,49 @@ __global__ __launch_bounds__(1024) void bn_stats_partial_kernel(const float* __r
   (void)Z;
 }
 
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int R, int N,
-                                         int chunk, int chunks, int G, float* __restrict__ mean,
-                                         float* __restrict__ var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// 64 columns x 16 chunk lanes per workgroup; the chunk lanes are combined in a fixed order
+// (lane l takes chunks l, l+16, ...; then lanes 0..15 in sequence): deterministic.
+__global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(
+    const float* __restrict__ partial, int R, int N, int chunk, int chunks, int G,
+    float* __restrict__ mean, float* __restrict__ var) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, zl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   const int g = blockIdx.y;
-  if (c >= N) return;
+  float acc = 0.f;
+  if (c < N)
+    for (int z = zl; z < chunks; z += 16) {
+      const int n = min(R, (z + 1) * chunk) - z * chunk;
+      acc += (float)n * partial[(((size_t)z * G + g) * 2) * N + c];
+    }
+  red[zl][cl] = acc;
+  __syncthreads();
   float mu = 0.f;
-  for (int z = 0; z < chunks; ++z) {
-    const int n = min(R, (z + 1) * chunk) - z * chunk;
-    mu += (float)n * partial[(((size_t)z * G + g) * 2) * N + c];
-  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mu += red[i][cl];
   mu /= (float)R;
-  float m2 = 0.f;
-  for (int z = 0; z < chunks; ++z) {
-    const int n = min(R, (z + 1) * chunk) - z * chunk;
-    const float* pz = partial + (((size_t)z * G + g) * 2) * N;
-    const float d = pz[c] - mu;
-    m2 += pz[N + c] + (float)n * d * d;
+  __syncthreads();
+  acc = 0.f;
+  if (c < N)
+    for (int z = zl; z < chunks; z += 16) {
+      const int n = min(R, (z + 1) * chunk) - z * chunk;
+      const float* pz = partial + (((size_t)z * G + g) * 2) * N;
+      const float d = pz[c] - mu;
+      acc += pz[N + c] + (float)n * d * d;
+    }
+  red[zl][cl] = acc;
+  __syncthreads();
+  if (zl == 0 && c < N) {
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m2 += red[i][cl];
+    mean[(size_t)g * N + c] = mu;
+    var[(size_t)g * N + c] = m2 / (float)R;
   }
-  mean[(size_t)g * N + c] = mu;
-  var[(size_t)g * N + c] = m2 / (float)R;
 }
 
 static inline int bn_chunks(int R, int* chunk) {
-  int chunks = (R + 255) / 256;
+  int chunks = (R + 63) / 64;   // 64-row chunks: 4 rows per thread, enough workgroups to fill the chip
   if (chunks > BN_MAX_CHUNKS) chunks = BN_MAX_CHUNKS;
   if (chunks < 1) chunks = 1;
   *chunk = (R + chunks - 1) / chunks;
@@ -619,7 +637,7 @@ int bn_stats(hipStream_t stream, const float* a, int lda, int rows_per_group, in
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((N + 63) / 64, groups, chunks), dim3(1024), 0,
                      stream, a, lda, rows_per_group, N, chunk, partial);
   SCVAE_LAUNCH_CHECK("bn_stats_partial_kernel");
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((N + 63) / 64, groups), dim3(64), 0, stream,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((N + 63) / 64, groups), dim3(1024), 0, stream,
                      partial, rows_per_group, N, chunk, chunks, groups, mean, var);
   SCVAE_LAUNCH_CHECK("bn_stats_finalize_kernel");
   return 0;
@@ -733,35 +751,51 @@ __global__ __launch_bounds__(1024) void bn_bwd_stats_partial_kernel(
 // per-layer jobs that need nothing else: dbeta = sum over groups of s1 (this rank's rows, before
 // any data-parallel exchange of s1) and the moving-average update of the layer's batch statistics
 // (UPDATE_OPS, va:2763-2768; group after group, Bessel-corrected variance).
-__global__ void bn_bwd_stats_finalize_kernel(const float* __restrict__ partial, int N, int chunks,
-                                             int G, float* __restrict__ s1,
-                                             float* __restrict__ s2, float* __restrict__ dbeta,
-                                             const float* __restrict__ mean,
-                                             const float* __restrict__ var,
-                                             float* __restrict__ moving_mean,
-                                             float* __restrict__ moving_var, float bessel) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(1024) void bn_bwd_stats_finalize_kernel(
+    const float* __restrict__ partial, int N, int chunks, int G, float* __restrict__ s1,
+    float* __restrict__ s2, float* __restrict__ dbeta, const float* __restrict__ mean,
+    const float* __restrict__ var, float* __restrict__ moving_mean,
+    float* __restrict__ moving_var, float bessel) {
+  __shared__ float red1[16][64];
+  __shared__ float red2[16][64];
+  const int cl = threadIdx.x & 63, zl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   const int g = blockIdx.y;
-  if (c >= N) return;
-  float t1 = 0.f, t2 = 0.f;
-  for (int z = 0; z < chunks; ++z) {
-    const float* pz = partial + (((size_t)z * G + g) * 2) * N;
-    t1 += pz[c];
-    t2 += pz[N + c];
+  // chunk lane zl sums chunks zl, zl+16, ...; lanes combined in sequence (fixed order)
+  auto group_sums = [&](int q, float& t1, float& t2) {
+    float a1 = 0.f, a2 = 0.f;
+    if (c < N)
+      for (int z = zl; z < chunks; z += 16) {
+        const float* pz = partial + (((size_t)z * G + q) * 2) * N;
+        a1 += pz[c];
+        a2 += pz[N + c];
+      }
+    __syncthreads();   // (previous use of the buffers)
+    red1[zl][cl] = a1;
+    red2[zl][cl] = a2;
+    __syncthreads();
+    t1 = 0.f; t2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { t1 += red1[i][cl]; t2 += red2[i][cl]; }
+  };
+  float t1, t2;
+  group_sums(g, t1, t2);
+  const bool writer = zl == 0 && c < N;
+  if (writer) {
+    s1[(size_t)g * N + c] = t1;
+    s2[(size_t)g * N + c] = t2;
   }
-  s1[(size_t)g * N + c] = t1;
-  s2[(size_t)g * N + c] = t2;
-  if (g != 0) return;
+  if (g != 0) return;   // (uniform per workgroup)
   if (dbeta != nullptr) {
     float total = t1;
     for (int q = 1; q < G; ++q) {
-      float tq = 0.f;
-      for (int z = 0; z < chunks; ++z) tq += partial[(((size_t)z * G + q) * 2) * N + c];
-      total += tq;
+      float u1, u2;
+      group_sums(q, u1, u2);
+      total += u1;
     }
-    dbeta[c] = total;
+    if (writer) dbeta[c] = total;
   }
-  if (moving_mean != nullptr) {
+  if (moving_mean != nullptr && writer) {
     float mm = moving_mean[c], mv = moving_var[c];
     for (int q = 0; q < G; ++q) {
       mm -= (mm - mean[(size_t)q * N + c]) * BN_UPDATE_RATE;
@@ -786,7 +820,7 @@ int bn_bwd_stats(hipStream_t stream, const float* dh, int lddh, const float* h, 
   SCVAE_LAUNCH_CHECK("bn_bwd_stats_partial_kernel");
   const int64_t R = global_rows_per_group;
   const float bessel = (float)R / (float)(R > 1 ? R - 1 : 1);
-  hipLaunchKernelGGL(bn_bwd_stats_finalize_kernel, dim3((N + 63) / 64, groups), dim3(64), 0,
+  hipLaunchKernelGGL(bn_bwd_stats_finalize_kernel, dim3((N + 63) / 64, groups), dim3(1024), 0,
                      stream, partial, N, chunks, groups, s1, s2, dbeta, mean, var, moving_mean,
                      moving_var, bessel);
   SCVAE_LAUNCH_CHECK("bn_bwd_stats_finalize_kernel");
