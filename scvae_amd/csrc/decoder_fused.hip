@@ -377,23 +377,24 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
 }
 
 // ll[r] = sum_strips ll_part[strip][r] - row_const[r % B]
-// workgroup = 64 rows x 16 strip lanes (fixed summation order: deterministic)
+// workgroup = 16 rows x 64 strip lanes (fixed summation order: deterministic); rows/16 workgroups
+// keep every CU busy on this 8 MB read
 __global__ __launch_bounds__(1024) void ll_reduce_kernel(const float* __restrict__ ll_part,
                                                          int strips, int R,
                                                          const float* __restrict__ row_const, int B,
                                                          float* __restrict__ ll) {
-  __shared__ float red[16][64];
-  const int rl = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int r = blockIdx.x * 64 + rl;
+  __shared__ float red[64][17];
+  const int rl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int r = blockIdx.x * 16 + rl;
   float s = 0.f;
   if (r < R)
-    for (int z = g; z < strips; z += 16) s += ll_part[(size_t)z * R + r];
+    for (int z = g; z < strips; z += 64) s += ll_part[(size_t)z * R + r];
   red[g][rl] = s;
   __syncthreads();
   if (g == 0 && r < R) {
     float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t += red[i][rl];
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) t += red[i][rl];
     ll[r] = t - (row_const ? row_const[r % B] : 0.f);
   }
 }
@@ -503,7 +504,7 @@ int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int
   int rc = launch_decoder<false>(s, kind, d, rows, H, hp, F, t, B, nullptr, row_const ? 0 : 1, ll_part,
                                  nullptr);
   if (rc) return rc;
-  hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 63) / 64), dim3(1024), 0, s, ll_part, strips,
+  hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 15) / 16), dim3(1024), 0, s, ll_part, strips,
                      rows, row_const, B, ll);
   SCVAE_LAUNCH_CHECK("ll_reduce_kernel");
   return 0;
@@ -523,7 +524,7 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
                                 dd_part);
   if (rc) return rc;
   if (kernel_only) return 0;  // profiling aid: leave the per-strip partials unreduced
-  hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 63) / 64), dim3(1024), 0, s, ll_part,
+  hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 15) / 16), dim3(1024), 0, s, ll_part,
                      strips, rows, row_const, B, ll);
   SCVAE_LAUNCH_CHECK("ll_reduce_kernel");
   const size_t n = (size_t)rows * H;

@@ -476,16 +476,18 @@ int gauss_latent_bwd(hipStream_t stream, const float* mu_pre, const float* ls_pr
 
 // single workgroup; ll index = (r*n_mc + m)*B + b.  row_scale = 1/(n_mc*B_global)
 // lets a data-parallel rank emit its share of the global means (summed by all-reduce).
-__global__ __launch_bounds__(256) void vae_elbo_kernel(const float* __restrict__ ll,
+__global__ __launch_bounds__(1024) void vae_elbo_kernel(const float* __restrict__ ll,
                                                        const float* __restrict__ kl_cell, int n_iw,
                                                        int n_mc, int B, float w, float row_scale,
                                                        float* __restrict__ scalars,
                                                        float* __restrict__ gw) {
-  __shared__ float red[4];
+  __shared__ float red[16];
   float lb = 0.f, lbw = 0.f, rec = 0.f, klsum = 0.f;
   const int pairs = n_mc * B;
-  for (int i = threadIdx.x; i < pairs; i += 256) {
-    const int m = i / B, b = i % B;
+  // (m, b) advance without a division per element: 1024 = q*B + rem
+  const int step_m = 1024 / B, step_b = 1024 % B;
+  int m = threadIdx.x / B, b = threadIdx.x % B;
+  for (int i = threadIdx.x; i < pairs; i += 1024) {
     const float kl = kl_cell[b];
     if (m == 0) klsum += kl;
     float mx = -INFINITY, mxw = -INFINITY;
@@ -510,11 +512,13 @@ __global__ __launch_bounds__(256) void vae_elbo_kernel(const float* __restrict__
         gw[o] = -__expf(ll[o] - w * kl - mxw) / sew * row_scale;
       }
     }
+    m += step_m; b += step_b;
+    if (b >= B) { b -= B; ++m; }
   }
-  lb = block_sum<256>(lb, red);
-  lbw = block_sum<256>(lbw, red);
-  rec = block_sum<256>(rec, red);
-  klsum = block_sum<256>(klsum, red);
+  lb = block_sum<1024>(lb, red);
+  lbw = block_sum<1024>(lbw, red);
+  rec = block_sum<1024>(rec, red);
+  klsum = block_sum<1024>(klsum, red);
   if (threadIdx.x == 0) {
     scalars[0] = lb * row_scale;
     scalars[1] = lbw * row_scale;
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(256) void vae_elbo_kernel(const float* __restrict__
 int vae_elbo(hipStream_t stream, const float* ll, const float* kl_cell, int n_iw, int n_mc, int B,
              float kl_weight_total, float row_scale, float* scalars, float* gw) {
   SCVAE_ARG(ll && kl_cell && scalars && n_iw > 0 && n_mc > 0 && B > 0);
-  hipLaunchKernelGGL(vae_elbo_kernel, dim3(1), dim3(256), 0, stream, ll, kl_cell, n_iw, n_mc, B,
+  hipLaunchKernelGGL(vae_elbo_kernel, dim3(1), dim3(1024), 0, stream, ll, kl_cell, n_iw, n_mc, B,
                      kl_weight_total, row_scale, scalars, gw);
   SCVAE_LAUNCH_CHECK("vae_elbo_kernel");
   return 0;

@@ -246,6 +246,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(
   }
 }
 
+// Many splits of a small output: 16 elements x 16 split lanes per workgroup; a lane sums splits
+// l, l+16, ..., the lanes are then combined in sequence (fixed order: deterministic).
+__global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(
+    const float* __restrict__ slabs, const float* __restrict__ bias, float* __restrict__ C, int M,
+    int N, int ldc, int splits, int act, int accumulate) {
+  __shared__ float red[16][17];
+  const size_t total = (size_t)M * N;
+  const int il = threadIdx.x & 15, zl = threadIdx.x >> 4;
+  const size_t i = (size_t)blockIdx.x * 16 + il;
+  float s = 0.f;
+  if (i < total)
+    for (int z = zl; z < splits; z += 16) s += slabs[(size_t)z * total + i];
+  red[zl][il] = s;
+  __syncthreads();
+  if (zl == 0 && i < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][il];
+    const int row = (int)(i / N), col = (int)(i % N);
+    if (bias) t += bias[col];
+    if (act == ACT_RELU) t = fmaxf(t, 0.f);
+    float* c = C + (size_t)row * ldc + col;
+    *c = accumulate ? (*c + t) : t;
+  }
+}
+
 static bool gemm_use_big(bool tb, int M, int N, int K) {
   return !tb && (double)M * N * K >= 4.0e9 && N >= 64;
 }
@@ -272,7 +298,7 @@ int gemm_choose_splits(int M, int N, int K) {
   const long tiles = (long)((M + GT - 1) / GT) * ((N + GT - 1) / GT);
   if (tiles >= 256 || K < 1024) return 1;
   long want = (512 + tiles - 1) / tiles;          // aim for ~2 workgroups per CU
-  long max_by_k = K / 256;                        // keep >= 256 of K per split
+  long max_by_k = K / 64;                         // keep >= 64 of K (4 k-steps) per split
   long s = want < max_by_k ? want : max_by_k;
   if (s < 1) s = 1;
   if (s > 64) s = 64;
@@ -322,8 +348,13 @@ int gemm(hipStream_t stream, bool ta, bool tb, const float* A, const float* B, c
     const size_t total = (size_t)M * N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slabs, bias, C, M,
-                       N, ldc, splits, act, acc);
+    if (splits >= 16 && total <= (size_t)1 << 16) {
+      hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256),
+                         0, stream, slabs, bias, C, M, N, ldc, splits, act, acc);
+    } else {
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slabs, bias, C,
+                         M, N, ldc, splits, act, acc);
+    }
     SCVAE_LAUNCH_CHECK("splitk_reduce_kernel");
   }
   return 0;
