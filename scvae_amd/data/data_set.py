@@ -5,6 +5,8 @@ plotting metadata are outside the hot path and are not provided here; the
 built-in sources are synthetic count matrices (``scvae_amd/data/synthetic.py``).
 """
 
+import os
+
 import numpy
 import scipy.sparse
 
@@ -27,6 +29,13 @@ class DataSet:
                  explained_standard_deviations=None,
                  features_mapped=False, kind="full", version="original",
                  directory=None, **kwargs):
+        # a path to a local file, or the name of a built-in synthetic data set
+        self.path = None
+        if isinstance(input_file_or_name, str) and os.path.isfile(
+                input_file_or_name):
+            from scvae_amd.data.loaders import data_set_name_from_path
+            self.path = input_file_or_name
+            input_file_or_name = data_set_name_from_path(self.path)
         self.name = normalise_string(str(input_file_or_name))
         self.title = title if title is not None else str(input_file_or_name)
         self.data_format = data_format
@@ -154,16 +163,31 @@ class DataSet:
                 explained_standard_deviations)
 
     def load(self):
-        """Materialise a built-in synthetic data set (no files, no network)."""
+        """Load a local file (``scvae_amd/data/loaders.py``) or materialise a
+        built-in synthetic data set; nothing is downloaded."""
         if self.has_values:
             return
+        if self.path is not None and self._generator is None:
+            from scvae_amd.data.loaders import LOADERS, infer_data_format
+            data_format = self.data_format
+            if data_format in (None, "infer"):
+                data_format = infer_data_format(self.path)
+            data_format = normalise_string(data_format)
+            if data_format not in LOADERS:
+                raise ValueError(
+                    "Data format `{}` not recognised (known: {}).".format(
+                        data_format, ", ".join(sorted(LOADERS))))
+            self.data_format = data_format
+            path = self.path
+            self._generator = lambda: LOADERS[data_format](path)
         if self._generator is None:
             from scvae_amd.data.synthetic import SYNTHETIC_DATA_SETS
             key = self.name
             if key not in SYNTHETIC_DATA_SETS:
                 raise FileNotFoundError(
-                    "Data set `{}` is not a built-in synthetic data set ({}); "
-                    "file loaders are outside the scope of this build."
+                    "Data set `{}` is neither a file nor a built-in synthetic "
+                    "data set ({}); the catalogue of downloadable data sets "
+                    "is outside the scope of this build."
                     .format(self.name, ", ".join(sorted(SYNTHETIC_DATA_SETS))))
             self._generator = SYNTHETIC_DATA_SETS[key]
         dictionary = self._generator()

@@ -1,0 +1,160 @@
+"""File loaders for local count matrices (``scvae/data/loaders.py``): the
+formats that need nothing but NumPy / SciPy.
+
+* ``10x``        -- a CellRanger ``*.tar.gz`` with ``matrix.mtx``,
+                    ``barcodes.tsv`` and ``genes.tsv`` in one directory
+                    (loaders.py:651-721); the ``.h5`` variant needs PyTables,
+                    which this image does not have.
+* ``matrix_ebf`` / ``matrix_fbe`` -- a (gzipped) tab-separated text matrix,
+                    examples-by-features or features-by-examples, optionally
+                    with a header row and a first column of names
+                    (loaders.py:391-404, 801-880).
+
+Downloading from the catalogue of URLs (``data_sets.json``) is outside this
+build: the file has to be on disk.
+"""
+
+import gzip
+import os
+import tarfile
+
+import numpy
+import scipy.io
+import scipy.sparse
+
+LOADERS = {}
+
+
+def _register_loader(name):
+    def decorator(function):
+        LOADERS[name] = function
+        return function
+    return decorator
+
+
+def infer_data_format(path):
+    """Format from the file name (the reference takes it from its catalogue)."""
+    name = os.path.basename(path).lower()
+    if name.endswith(".tar.gz") or name.endswith(".tgz"):
+        return "10x"
+    if name.endswith(".h5"):
+        return "10x"
+    if name.endswith((".tsv", ".tsv.gz", ".txt", ".txt.gz")):
+        return "matrix_ebf"
+    raise ValueError(
+        "Cannot infer the data format of `{}`; pass --format.".format(path))
+
+
+def data_set_name_from_path(path):
+    name = os.path.basename(path)
+    for extension in (".tar.gz", ".tgz", ".tsv.gz", ".txt.gz", ".h5", ".tsv",
+                      ".txt"):
+        if name.lower().endswith(extension):
+            return name[:-len(extension)]
+    return os.path.splitext(name)[0]
+
+
+@_register_loader("10x")
+def load_10x_data_set(path):
+    if path.endswith(".h5"):
+        raise NotImplementedError(
+            "10x HDF5 files need PyTables, which is not available here; use "
+            "the matrix.mtx tarball (loaders.py:658-676).")
+    multiple_directories_error = NotImplementedError(
+        "Cannot handle 10x data sets with multiple directories.")
+    parent_paths = set()
+    values = example_names = feature_names = None
+    with tarfile.open(path, mode="r:gz") as tarball:
+        for member in sorted(tarball, key=lambda member: member.name):
+            if not member.isfile():
+                continue
+            parent_path, filename = os.path.split(member.name)
+            parent_paths.add(parent_path)
+            if len(parent_paths) > 1:
+                raise multiple_directories_error
+            name, extension = os.path.splitext(filename)
+            with tarball.extractfile(member) as data_file:
+                if filename == "matrix.mtx":
+                    values = scipy.io.mmread(data_file)
+                elif extension == ".tsv":
+                    names = numpy.array(data_file.read().splitlines())
+                    if name == "barcodes":
+                        example_names = names
+                    elif name == "genes":
+                        feature_names = names
+    if values is None or example_names is None or feature_names is None:
+        raise ValueError(
+            "`{}` does not hold matrix.mtx, barcodes.tsv and genes.tsv."
+            .format(path))
+    # the matrix is stored genes x cells
+    values = scipy.sparse.csr_matrix(values.T, dtype=numpy.float32)
+    return {
+        "values": values,
+        "labels": None,
+        "example names": example_names.astype("U"),
+        "feature names": feature_names.astype("U"),
+    }
+
+
+def _is_float(text):
+    try:
+        float(text)
+        return True
+    except ValueError:
+        return False
+
+
+def _load_tab_separated_matrix(path):
+    opener = gzip.open if path.endswith("gz") else open
+    rows, row_names, column_headers = [], [], None
+    with opener(path, mode="rt") as tsv_file:
+        for line in tsv_file:
+            elements = line.split()
+            if len(elements) <= 1:
+                continue
+            if (column_headers is None and not rows and len(elements) == 2
+                    and all(element.isdigit() for element in elements)):
+                continue   # a shape line before the header
+            if column_headers is None and not rows and not all(
+                    _is_float(element) for element in elements):
+                column_headers = elements
+                continue
+            if not _is_float(elements[0]):
+                row_names.append(elements[0])
+                elements = elements[1:]
+            rows.append(numpy.asarray(elements, dtype=numpy.float32))
+    values = numpy.vstack(rows)
+    if column_headers is not None and len(column_headers) == values.shape[1] + 1:
+        column_headers = column_headers[1:]   # header of the name column
+    return values, (numpy.array(row_names) if row_names else None), (
+        numpy.array(column_headers) if column_headers is not None else None)
+
+
+def _load_matrix(path, orientation):
+    values, row_names, column_names = _load_tab_separated_matrix(path)
+    if orientation == "fbe":
+        values = values.T
+        row_names, column_names = column_names, row_names
+    n_examples, n_features = values.shape
+    if row_names is None:
+        row_names = numpy.array(
+            ["example {}".format(i + 1) for i in range(n_examples)])
+    if column_names is None:
+        column_names = numpy.array(
+            ["feature {}".format(j + 1) for j in range(n_features)])
+    return {
+        "values": scipy.sparse.csr_matrix(values, dtype=numpy.float32),
+        "labels": None,
+        "example names": row_names.astype("U"),
+        "feature names": column_names.astype("U"),
+    }
+
+
+@_register_loader("matrix_ebf")
+def load_ebf_matrix_as_data_set(path):
+    return _load_matrix(path, "ebf")
+
+
+@_register_loader("matrix_fbe")
+def load_fbe_matrix_as_data_set(path):
+    return _load_matrix(path, "fbe")

@@ -217,3 +217,63 @@ def test_cluster_accuracy_helpers():
     predicted = map_cluster_ids_to_label_ids(labels, clusters, [2])
     assert np.array_equal(predicted, [0, 0, 0, 1, 1, 1, 1])
     assert accuracy(labels, predicted, [2]) == pytest.approx(3 / 4)
+
+
+def test_file_loaders(tmp_path):
+    """10x matrix.mtx tarball and tab-separated matrices (loaders.py:651-721,
+    391-404) through DataSet / the 81-9-10 split."""
+    import gzip
+    import io
+    import tarfile
+
+    import scipy.io
+    import scipy.sparse
+    from scvae_amd.data import DataSet
+    rng = np.random.default_rng(0)
+    genes, cells = 7, 30
+    counts = scipy.sparse.random(genes, cells, density=0.3, random_state=1,
+                                 data_rvs=lambda n: rng.integers(1, 9, n))
+    counts = counts.tocoo().astype(np.int64)
+    tar_path = tmp_path / "pbmc_tiny.tar.gz"
+    with tarfile.open(tar_path, "w:gz") as tarball:
+        def add(name, payload):
+            info = tarfile.TarInfo("filtered_matrices/hg19/" + name)
+            info.size = len(payload)
+            tarball.addfile(info, io.BytesIO(payload))
+        buffer = io.BytesIO()
+        scipy.io.mmwrite(buffer, counts)
+        add("matrix.mtx", buffer.getvalue())
+        add("barcodes.tsv", "\n".join(
+            "CELL{}-1".format(i) for i in range(cells)).encode())
+        add("genes.tsv", "\n".join(
+            "ENSG{}\tG{}".format(j, j) for j in range(genes)).encode())
+    data = DataSet(str(tar_path))
+    assert data.name == "pbmc_tiny"
+    data.load()
+    assert data.data_format == "10x"
+    assert data.values.shape == (cells, genes)
+    assert np.array_equal(np.asarray(data.values.todense()),
+                          counts.toarray().T)
+    assert data.example_names[3] == "CELL3-1"
+    assert data.feature_names[2] == "ENSG2\tG2"
+    training, validation, test = DataSet(str(tar_path)).split()
+    assert (training.number_of_examples + validation.number_of_examples
+            + test.number_of_examples) == cells
+
+    dense = counts.toarray().T
+    tsv_path = tmp_path / "matrix.tsv.gz"
+    with gzip.open(tsv_path, "wt") as handle:
+        handle.write("cell\t" + "\t".join(
+            "g{}".format(j) for j in range(genes)) + "\n")
+        for i in range(cells):
+            handle.write("c{}\t".format(i) + "\t".join(
+                str(v) for v in dense[i]) + "\n")
+    data = DataSet(str(tsv_path), data_format="matrix_ebf")
+    data.load()
+    assert np.array_equal(np.asarray(data.values.todense()), dense)
+    assert data.feature_names[1] == "g1" and data.example_names[4] == "c4"
+    flipped = DataSet(str(tsv_path), data_format="matrix_fbe")
+    flipped.load()
+    assert flipped.values.shape == (genes, cells)
+    with pytest.raises(FileNotFoundError):
+        DataSet("no_such_data_set").load()
