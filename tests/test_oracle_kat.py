@@ -193,3 +193,40 @@ def test_gmvae_loss_terms():
     assert torch.allclose(
         out["lower_bound_weighted"],
         rec - 0.7 * (out["kl_divergence_z"] + thr))
+
+
+@pytest.mark.parametrize("name", ["poisson", "negative binomial"])
+def test_categorised_likelihood_against_explicit_pmf(name):
+    """``Categorised`` (distributions/categorised.py:210-263) against its
+    definition spelled out with scipy: P(x = k) = pi_k for k < K and
+    pi_K * P_dist(x - K) for x >= K; mean and variance by summing that pmf."""
+    K = 3
+    n = 12
+    local = np.random.default_rng(4)
+    logits = local.normal(0, 1.5, (n, K + 1))
+    b1 = np.clip(local.normal(0, 1.0, n), -3, 3)
+    b2 = np.clip(local.normal(0, 1.0, n), -3, 3)
+    pre = (T(b1),) if name == "poisson" else (T(b1), T(b2))
+    pi = sc.softmax(logits, axis=1)
+    if name == "poisson":
+        dist = st.poisson(np.exp(b1))
+    else:
+        dist = st.nbinom(np.exp(b2), 1 - sigmoid(b1))
+    counts = np.arange(0, 4000)
+
+    def pmf(x):   # [len(x), n]
+        x = np.asarray(x)[:, None]
+        head = np.take_along_axis(
+            pi.T, np.clip(x, 0, K).astype(int) * np.ones((1, n), int), axis=0)
+        return np.where(x < K, head, pi[:, K] * dist.pmf(x - K))
+    table = pmf(counts)
+    assert np.allclose(table.sum(axis=0), 1.0, atol=1e-9)
+    t = np.array([0, 1, 2, 3, 4, 7, 30, 0, 2, 3, 5, 11], dtype=np.float64)
+    got = lk.categorised_log_prob(name, T(t), pre, T(logits), K).numpy()
+    want = np.log(pmf(t)[np.arange(n), np.arange(n)])
+    assert np.allclose(got, want, rtol=1e-10, atol=1e-12)
+    mean, var = lk.categorised_mean_variance(name, pre, T(logits), K)
+    m1 = (counts[:, None] * table).sum(axis=0)
+    m2 = (counts[:, None] ** 2 * table).sum(axis=0)
+    assert np.allclose(mean.numpy(), m1, rtol=1e-8)
+    assert np.allclose(var.numpy(), m2 - m1 ** 2, rtol=1e-7)
