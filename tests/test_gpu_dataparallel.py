@@ -129,3 +129,73 @@ def test_two_ranks_equal_single_process(cuda_device, tmp_path, model_type):
              nprocs=2, join=True)
     worst = float(result.read_text())
     assert worst <= 2e-5, worst
+
+
+def _model_train_worker(rank, port, directory, result_path):
+    """Both ranks share cuda:0 (gloo): ``model.train`` + ``model.evaluate`` under
+    data parallelism."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        from scvae_amd.data import DataSet
+        from scvae_amd.models import VariationalAutoencoder
+        rng = np.random.default_rng(5)
+        n, F = 96, 40
+        values = (rng.poisson(2.0, (n, F)) * (rng.random((n, F)) > 0.5)
+                  ).astype(np.float32)
+        data = DataSet("dp", values=values,
+                       example_names=np.array(["c%d" % i for i in range(n)]),
+                       feature_names=np.array(["g%d" % i for i in range(F)]))
+        model = VariationalAutoencoder(
+            feature_size=F, latent_size=3, hidden_sizes=[10],
+            reconstruction_distribution="negative binomial",
+            log_directory=os.path.join(directory, "dp"), device="cuda:0")
+        np.random.seed(11)
+        model.train(data, None, number_of_epochs=2, minibatch_size=32,
+                    learning_rate=1e-3)
+        _, _, latent = model.evaluate(data, log_results=False)
+        z = np.asarray(latent["z"].values)
+        params = model.engine.params.clone()
+        if rank == 0:
+            single = VariationalAutoencoder(
+                feature_size=F, latent_size=3, hidden_sizes=[10],
+                reconstruction_distribution="negative binomial",
+                log_directory=os.path.join(directory, "single"),
+                device="cuda:0")
+            # (a model outside the process group: train it as one process)
+            import scvae_amd.models.base as base
+            original = base._distributed
+            base._distributed = lambda: (1, 0)
+            try:
+                np.random.seed(11)
+                single.train(data, None, number_of_epochs=2,
+                             minibatch_size=32, learning_rate=1e-3)
+                _, _, latent_single = single.evaluate(data, log_results=False)
+            finally:
+                base._distributed = original
+            reference = single.engine.params
+            worst = ((params - reference).abs().max()
+                     / reference.abs().max()).item()
+            worst_z = float(np.abs(z - np.asarray(
+                latent_single["z"].values)).max())
+            with open(result_path, "w") as handle:
+                handle.write(repr((worst, worst_z)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_model_train_two_ranks_equals_single_process(cuda_device, tmp_path):
+    """The training / evaluation loops of the model class under two data-parallel
+    ranks (rank-0 logging and checkpoints, broadcast permutation, sharded
+    evaluation) reproduce the single-process run."""
+    import torch.multiprocessing as mp
+    result = tmp_path / "worst.txt"
+    port = 29850 + (os.getpid() % 100)
+    mp.spawn(_model_train_worker, args=(port, str(tmp_path), str(result)),
+             nprocs=2, join=True)
+    worst, worst_z = eval(result.read_text())
+    assert worst <= 5e-4, worst
+    assert worst_z <= 5e-3, worst_z
