@@ -421,6 +421,7 @@ class ModelBase:
 
         from scvae_amd.minibatch import philox_normal
 
+        checkpoint_writer = mu.CheckpointWriter()
         for epoch in range(epoch_start, number_of_epochs):
             epoch_time_start = time()
             if self.number_of_warm_up_epochs:
@@ -554,6 +555,7 @@ class ModelBase:
                             "Saving model parameters for previous epoch.")
                         saving_time_start = time()
                         lower_bound_valid_early_stopping = lower_bound_valid
+                        checkpoint_writer.wait()
                         current_checkpoint = mu.get_checkpoint_state(
                             log_directory)
                         if master and current_checkpoint:
@@ -588,9 +590,9 @@ class ModelBase:
             # Saving model parameters (update checkpoint)
             say("    Saving model parameters.")
             saving_time_start = time()
-            if master:
-                mu.save_checkpoint(engine.state_dict(), log_directory,
-                                   epoch + 1)
+            if master:   # (written in the background, see CheckpointWriter)
+                checkpoint_writer.save(engine.state_dict(), log_directory,
+                                       epoch + 1)
             say("    Model parameters saved ({}).".format(
                 format_duration(time() - saving_time_start)))
 
@@ -600,6 +602,7 @@ class ModelBase:
                     "Saving model parameters as best model parameters.")
                 saving_time_start = time()
                 lower_bound_valid_maximum = lower_bound_valid
+                checkpoint_writer.wait()
                 current_checkpoint = mu.get_checkpoint_state(log_directory)
                 if master and current_checkpoint:
                     mu.copy_model_directory(
@@ -622,6 +625,7 @@ class ModelBase:
                     run_id=run_id, analyses_directory=analyses_directory)
                 say()
 
+        checkpoint_writer.wait()
         training_duration = time() - training_time_start
         say("{} trained for {} epochs ({}).".format(
             capitalise_string(model_string), number_of_epochs,

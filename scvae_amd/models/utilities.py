@@ -139,6 +139,37 @@ def save_checkpoint(state, log_directory, epoch):
     return os.path.join(log_directory, name)
 
 
+class CheckpointWriter:
+    """Writes checkpoints on a background thread: the training loop only pays
+    for the device-to-host copy of the state (``engine.state_dict()``), the
+    serialisation and the file system work overlap the next epoch.  Whoever
+    reads the checkpoint files calls ``wait()`` first."""
+
+    def __init__(self):
+        self._thread = None
+        self._error = None
+
+    def save(self, state, log_directory, epoch):
+        import threading
+        self.wait()
+
+        def work():
+            try:
+                save_checkpoint(state, log_directory, epoch)
+            except BaseException as error:   # surfaced by the next wait()
+                self._error = error
+        self._thread = threading.Thread(target=work, daemon=False)
+        self._thread.start()
+
+    def wait(self):
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        if self._error is not None:
+            error, self._error = self._error, None
+            raise error
+
+
 def load_checkpoint(checkpoint_path):
     import torch
     return torch.load(checkpoint_path, map_location="cpu",
