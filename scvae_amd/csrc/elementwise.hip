@@ -1116,7 +1116,7 @@ __global__ __launch_bounds__(256) void csr_densify_kernel(const int64_t* __restr
   const int n4 = (F - head) / 4;
   float4* o4 = reinterpret_cast<float4*>(orow + head);
   for (int i = threadIdx.x; i < n4; i += 256) o4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (threadIdx.x < head) orow[threadIdx.x] = 0.f;
+  if ((int)threadIdx.x < head) orow[threadIdx.x] = 0.f;
   const int tail0 = head + 4 * n4;
   if (tail0 + (int)threadIdx.x < F) orow[tail0 + threadIdx.x] = 0.f;
   __threadfence_block();

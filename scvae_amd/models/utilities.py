@@ -22,7 +22,7 @@ from string import ascii_uppercase
 import numpy
 
 from scvae_amd.utilities import (
-    capitalise_string, enumerate_strings, normalise_string)
+    capitalise_string, enumerate_strings)
 
 CHECKPOINT_INDEX = "checkpoint"
 CHECKPOINT_PREFIX = "model.ckpt"
