@@ -16,6 +16,7 @@
 namespace scvae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GT = 64;   // tile edge
 constexpr int GBK = 16;  // k-step staged per barrier
@@ -230,6 +231,141 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(
   }
 }
 
+// Narrow-N variant for the same two products when N is not a multiple of 32 (the reference's
+// default hidden size is 100): 256 rows x N columns per 512-thread workgroup, every wave one
+// 32-row tile with all NT = N / 32 full 32-wide column tiles (A fragment shared), and the
+// N % 32 <= 8 remainder columns through v_mfma_f32_4x4x1 (64 rows x 4 columns per instruction)
+// instead of a padded fourth tile: 100 columns cost 3.06 tiles of MFMA work instead of 4.
+constexpr int NBM = 256;          // rows per workgroup
+constexpr int NBK = 16;           // k-step per barrier
+constexpr int NLDA = NBM + 1;     // odd: conflict-free transposing store of A[m][k]
+constexpr int NBN = 104;          // at most 96 + 8 columns
+constexpr int NLDB = NBN + 1;
+
+template <bool TA>
+__global__ __launch_bounds__(512, 2) void gemm_narrow_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+    float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, int act, int accumulate,
+    int k_chunk, float* __restrict__ slabs) {
+  __shared__ float As[2][NBK][NLDA];
+  __shared__ float Bs[2][NBK][NLDB];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kh = lane >> 5, li = lane & 31;
+  const int m0 = blockIdx.y * NBM;
+  const int kz = blockIdx.z;
+  const int k_begin = kz * k_chunk;
+  const int k_end = min(K, k_begin + k_chunk);
+  const int NT = N / 32;                 // full column tiles (1..3)
+  const int rem0 = NT * 32;              // first remainder column
+  const int groups = (N - rem0 + 3) / 4; // 4-column remainder groups (0..2)
+  // remainder job of this wave: 64-row block (w & 3), column group (w >> 2)
+  const bool rem_wave = (w >> 2) < groups;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+  float accR[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // staging: A 256 x 16 (8 per thread), B 16 x 104 (<= 4 per thread)
+  float ra[8], rb[4];
+  auto load_tiles = [&](int kt) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      int m, k;
+      if (TA) { m = tid & 255; k = (tid >> 8) + 2 * p; }       // A[k][m]: 256 consecutive m
+      else    { k = tid & 15; m = (tid >> 4) + 32 * p; }       // A[m][k]: 16 consecutive k
+      const int gm = m0 + m, gk = kt + k;
+      float v = 0.f;
+      if (gm < M && gk < k_end) v = TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
+      ra[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int e = p * 512 + tid;           // 16 x 104 = 1664 elements
+      const int k = e / NBN, n = e - k * NBN;
+      const int gk = kt + k;
+      float v = 0.f;
+      if (k < NBK && n < N && gk < k_end) v = B[(size_t)gk * ldb + n];
+      rb[p] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      int m, k;
+      if (TA) { m = tid & 255; k = (tid >> 8) + 2 * p; }
+      else    { k = tid & 15; m = (tid >> 4) + 32 * p; }
+      As[buf][k][m] = ra[p];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int e = p * 512 + tid;
+      const int k = e / NBN, n = e - k * NBN;
+      if (k < NBK) Bs[buf][k][n] = rb[p];
+    }
+  };
+
+  int buf = 0;
+  if (k_begin < k_end) {
+    load_tiles(k_begin);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int kt = k_begin; kt < k_end; kt += NBK) {
+    const bool has_next = kt + NBK < k_end;
+    if (has_next) load_tiles(kt + NBK);
+#pragma unroll
+    for (int kk = 0; kk < NBK; kk += 2) {
+      const float a = As[buf][kk + kh][w * 32 + li];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (q < NT)
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[buf][kk + kh][q * 32 + li], acc[q], 0,
+                                                        0, 0);
+    }
+    if (rem_wave) {
+      // 16 blocks x (4 rows x 4 columns): lane l gives A = row 64*(w&3) + l, B = column
+      // rem0 + 4*(w>>2) + (l & 3)
+      const int rr = (w & 3) * 64 + lane, cc = rem0 + (w >> 2) * 4 + (lane & 3);
+      f32x4 r4 = {accR[0], accR[1], accR[2], accR[3]};
+#pragma unroll
+      for (int kk = 0; kk < NBK; ++kk)
+        r4 = __builtin_amdgcn_mfma_f32_4x4x1f32(As[buf][kk][rr], Bs[buf][kk][cc], r4, 0, 0, 0);
+      accR[0] = r4[0]; accR[1] = r4[1]; accR[2] = r4[2]; accR[3] = r4[3];
+    }
+    if (has_next) store_tiles(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  auto emit = [&](int row, int col, float v) {
+    if (row >= M || col >= N) return;
+    if (slabs != nullptr) {
+      slabs[((size_t)kz * M + row) * N + col] = v;
+    } else {
+      if (bias != nullptr) v += bias[col];
+      if (act == ACT_RELU) v = fmaxf(v, 0.f);
+      float* c = C + (size_t)row * ldc + col;
+      *c = accumulate ? (*c + v) : v;
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    if (q >= NT) break;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      emit(m0 + w * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh, q * 32 + li, acc[q][r]);
+  }
+  if (rem_wave) {
+    // lane l, register i: row 64*(w&3) + 4*(l>>2) + i, column rem0 + 4*(w>>2) + (l & 3)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      emit(m0 + (w & 3) * 64 + 4 * (lane >> 2) + i, rem0 + (w >> 2) * 4 + (lane & 3), accR[i]);
+  }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(
     const float* __restrict__ slabs, const float* __restrict__ bias, float* __restrict__ C, int M,
     int N, int ldc, int splits, int act, int accumulate) {
@@ -291,6 +427,15 @@ size_t gemm_workspace_bytes(int M, int N, int K) {
   int splits = gemm_choose_splits(M, N, K);
   const int big = gemm_big_splits(M, N, K);
   if (big > splits) splits = big;
+  {   // narrow-N kernel (see gemm())
+    const long tiles = (M + NBM - 1) / NBM;
+    if (tiles < 384) {
+      long want = (512 + tiles - 1) / tiles, max_by_k = K / 256;
+      long sn = want < max_by_k ? want : max_by_k;
+      if (sn > 64) sn = 64;
+      if (sn > splits) splits = (int)sn;
+    }
+  }
   return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
 }
 
@@ -312,6 +457,47 @@ int gemm(hipStream_t stream, bool ta, bool tb, const float* A, const float* B, c
   SCVAE_ARG(M >= 0 && N >= 0 && K >= 0);
   if (M == 0 || N == 0) return 0;
   const bool big = gemm_use_big(tb, M, N, K);
+  // N = 32 q + r with r <= 8 (e.g. the default hidden size 100): no padding of N
+  const bool narrow = big && N >= 32 && N <= NBN && (N % 32) != 0 && (N % 32) <= 8 && ldb >= N;
+  if (narrow) {
+    int splits = 1;
+    const long tiles = (M + NBM - 1) / NBM;
+    if (tiles < 384) {
+      // two workgroups per CU in total (a 1.5-wave grid costs more than it gains)
+      long want = (512 + tiles - 1) / tiles, max_by_k = K / 256;
+      splits = (int)(want < max_by_k ? want : max_by_k);
+      if (splits < 1) splits = 1;
+      if (splits > 64) splits = 64;
+    }
+    if (splits > 1 && (workspace == nullptr ||
+                       workspace_bytes < (size_t)splits * M * N * sizeof(float)))
+      splits = 1;
+    int k_chunk = K;
+    if (splits > 1) {
+      k_chunk = (K + splits - 1) / splits;
+      k_chunk = (k_chunk + NBK - 1) / NBK * NBK;
+      splits = (K + k_chunk - 1) / k_chunk;
+    }
+    dim3 grid(1, (M + NBM - 1) / NBM, splits);
+    float* slabs = splits > 1 ? workspace : nullptr;
+    const int acc = accumulate ? 1 : 0;
+    if (ta)
+      hipLaunchKernelGGL((gemm_narrow_kernel<true>), grid, dim3(512), 0, stream, A, B, bias, C, M,
+                         N, K, lda, ldb, ldc, act, acc, k_chunk, slabs);
+    else
+      hipLaunchKernelGGL((gemm_narrow_kernel<false>), grid, dim3(512), 0, stream, A, B, bias, C, M,
+                         N, K, lda, ldb, ldc, act, acc, k_chunk, slabs);
+    SCVAE_LAUNCH_CHECK("gemm_narrow_kernel");
+    if (splits > 1) {
+      const size_t total = (size_t)M * N;
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slabs, bias, C,
+                         M, N, ldc, splits, act, acc);
+      SCVAE_LAUNCH_CHECK("splitk_reduce_kernel");
+    }
+    return 0;
+  }
   int splits = big ? gemm_big_splits(M, N, K) : gemm_choose_splits(M, N, K);
   if (splits > 1 && (workspace == nullptr ||
                      workspace_bytes < (size_t)splits * M * N * sizeof(float)))

@@ -54,10 +54,14 @@ def test_gemm_matches_fp64(cuda_device, ta, tb, M, N, K):
 
 @pytest.mark.parametrize("ta", [0, 1])
 @pytest.mark.parametrize("M,N,K", [(300, 100, 140000), (4500, 100, 9000),
-                                   (2100, 130, 16000)])
+                                   (2100, 130, 16000),
+                                   # narrow-N kernel: 1-3 full column tiles + a
+                                   # remainder of 1..8 columns (4x4x1 MFMA groups)
+                                   (700, 97, 60000), (520, 104, 80000),
+                                   (1000, 68, 70000), (900, 37, 120000)])
 def test_big_gemm_matches_fp64(cuda_device, ta, M, N, K):
-    """Shapes routed to the 128x128 kernel (encoder input layer and its dW),
-    with and without split-K, edge tiles in M, N and K."""
+    """Shapes routed to the 128x128 and the narrow-N kernels (encoder input layer
+    and its dW), with and without split-K, edge tiles in M, N and K."""
     from scvae_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(M + N + K)

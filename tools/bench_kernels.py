@@ -84,9 +84,11 @@ def main():
         us, 2.0 * R * F * H / us / 1e6))
     dy = torch.randn(R, H, device=dev, generator=g)
     dW1 = torch.empty(F, H, device=dev)
+    dws_bytes = lib.scvae_gemm_workspace_bytes(F, H, R)
+    dws = torch.empty(max(dws_bytes, 4), dtype=torch.uint8, device=dev)
     us = timeit(lambda: _lib.check(lib.scvae_gemm(
         1, 0, x.data_ptr(), dy.data_ptr(), None, dW1.data_ptr(), F, H, R, F, H,
-        H, 0, 0, None, 0, stream), "gemm"))
+        H, 0, 0, dws.data_ptr(), dws_bytes, stream), "gemm"))
     print("encoder-1 dW         : {:9.1f} us  {:6.1f} TFLOP/s".format(
         us, 2.0 * R * F * H / us / 1e6))
 
