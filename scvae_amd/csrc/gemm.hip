@@ -266,7 +266,12 @@ __global__ __launch_bounds__(512, 2) void gemm_narrow_kernel(
   for (int q = 0; q < 3; ++q)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
-  float accR[4] = {0.f, 0.f, 0.f, 0.f};
+  // the 4x4x1 MFMA has a ~40-cycle dependent latency at an 8-12-cycle issue rate
+  // (tools/probe/mfma_latency.hip): two independent accumulator chains (k parity), summed at
+  // the end; four would push the kernel over 128 VGPRs (one workgroup per CU instead of two)
+  f32x4 accR[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) accR[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // staging: A 256 x 16 (8 per thread), B 16 x 104 (<= 4 per thread)
   float ra[8], rb[4];
@@ -329,11 +334,10 @@ __global__ __launch_bounds__(512, 2) void gemm_narrow_kernel(
       // 16 blocks x (4 rows x 4 columns): lane l gives A = row 64*(w&3) + l, B = column
       // rem0 + 4*(w>>2) + (l & 3)
       const int rr = (w & 3) * 64 + lane, cc = rem0 + (w >> 2) * 4 + (lane & 3);
-      f32x4 r4 = {accR[0], accR[1], accR[2], accR[3]};
 #pragma unroll
       for (int kk = 0; kk < NBK; ++kk)
-        r4 = __builtin_amdgcn_mfma_f32_4x4x1f32(As[buf][kk][rr], Bs[buf][kk][cc], r4, 0, 0, 0);
-      accR[0] = r4[0]; accR[1] = r4[1]; accR[2] = r4[2]; accR[3] = r4[3];
+        accR[kk & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(As[buf][kk][rr], Bs[buf][kk][cc],
+                                                          accR[kk & 1], 0, 0, 0);
     }
     if (has_next) store_tiles(buf ^ 1);
     __syncthreads();
@@ -362,7 +366,8 @@ __global__ __launch_bounds__(512, 2) void gemm_narrow_kernel(
     // lane l, register i: row 64*(w&3) + 4*(l>>2) + i, column rem0 + 4*(w>>2) + (l & 3)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      emit(m0 + (w & 3) * 64 + 4 * (lane >> 2) + i, rem0 + (w >> 2) * 4 + (lane & 3), accR[i]);
+      emit(m0 + (w & 3) * 64 + 4 * (lane >> 2) + i, rem0 + (w >> 2) * 4 + (lane & 3),
+           accR[0][i] + accR[1][i]);
   }
 }
 
