@@ -130,8 +130,25 @@ __device__ __forceinline__ float digamma_tail_r(float iy) {
 // the recurrence, and the shifted difference is taken analytically
 //   lgamma(b+t)-lgamma(b) = t*log(b+t) + (b-1/2)*log1p(t/b) - t + s(b+t)-s(b)
 // so there is no cancellation of two large lgamma values.  Exactly 0 at t == 0.
+// Small integer counts (the bulk of a count matrix): lgamma(r+t)-lgamma(r) = log prod_{i<t}(r+i)
+// and digamma(r+t)-digamma(r) = sum_{i<t} 1/(r+i) = P'/P by the product recurrence -- one log and
+// one reciprocal.  r <= e^10, t <= 8: the product stays below 6e34.
 template <bool WITH_D>
-__device__ __forceinline__ void lgamma_digamma_diff(float r, float t, float& A, float& D) {
+__device__ __forceinline__ void lgamma_digamma_diff_small(float r, float t, float& A, float& D) {
+  float P = 1.f, Q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float f = r + (float)i;
+    const bool on = (float)i < t;
+    if (WITH_D) Q = on ? fmaf(Q, f, P) : Q;
+    P = on ? P * f : P;
+  }
+  A = __logf(P);
+  D = WITH_D ? Q * fast_rcp(P) : 0.f;
+}
+
+template <bool WITH_D>
+__device__ __forceinline__ void lgamma_digamma_diff_general(float r, float t, float& A, float& D) {
   const float x = r + t;
   const float b = r + 8.f, a = x + 8.f;
   const float ib = fast_rcp(b), ia = fast_rcp(a);
@@ -162,6 +179,12 @@ __device__ __forceinline__ void lgamma_digamma_diff(float r, float t, float& A, 
   } else {
     D = 0.f;
   }
+}
+
+template <bool WITH_D>
+__device__ __forceinline__ void lgamma_digamma_diff(float r, float t, float& A, float& D) {
+  if (t <= 8.f && t == __builtin_rintf(t)) lgamma_digamma_diff_small<WITH_D>(r, t, A, D);
+  else lgamma_digamma_diff_general<WITH_D>(r, t, A, D);
 }
 
 // lgamma(1+t) for t >= 0 (data-only term of the count likelihoods)
