@@ -180,3 +180,37 @@ def test_csr_densify(cuda_device):
     assert np.array_equal(out.cpu().numpy(), dense[[49, 7, 0, 7, 13]])
     want = torch.lgamma(torch.from_numpy(dense).double() + 1).sum(dim=1)
     assert np.allclose(lg.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_gemm_small_shape_sweep(cuda_device):
+    """Every transpose combination over a grid of small / ragged shapes (the
+    [rows, <=128] layers of the model), with and without accumulation."""
+    import ctypes
+    import itertools
+    from scvae_amd import _lib
+    lib = _lib.load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(0)
+    for ta, tb in itertools.product((0, 1), (0, 1)):
+        for M, N, K in itertools.product((1, 11, 28, 64, 84, 130),
+                                         (1, 4, 16, 25, 100),
+                                         (1, 2, 7, 16, 84, 100)):
+            for acc in (0, 1):
+                A = rng.standard_normal((K, M) if ta else (M, K))
+                B = rng.standard_normal((N, K) if tb else (K, N))
+                C0 = rng.standard_normal((M, N))
+                Ad = torch.tensor(A, dtype=torch.float32, device=cuda_device)
+                Bd = torch.tensor(B, dtype=torch.float32, device=cuda_device)
+                Cd = torch.tensor(C0, dtype=torch.float32, device=cuda_device)
+                ws_bytes = lib.scvae_gemm_workspace_bytes(M, N, K)
+                ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8,
+                                 device=cuda_device)
+                _lib.check(lib.scvae_gemm(
+                    ta, tb, Ad.data_ptr(), Bd.data_ptr(), None, Cd.data_ptr(),
+                    M, N, K, Ad.shape[1], Bd.shape[1], N, 0, acc,
+                    ws.data_ptr(), ws_bytes, stream), "gemm")
+                want = ((A.T if ta else A) @ (B.T if tb else B)
+                        + (C0 if acc else 0))
+                err = np.abs(Cd.cpu().double().numpy() - want).max()
+                assert err <= 1e-5 * max(1.0, np.abs(want).max()) * max(
+                    1.0, np.sqrt(K)), (ta, tb, M, N, K, acc, err)

@@ -77,3 +77,82 @@ def test_fused_equals_unfused_on_random_models(cuda_device, seed):
         tolerance = 2e-3 if (c["gm"] or c["n_iw"] > 1) else 2e-4
         assert np.abs(a - b).max() <= tolerance * np.abs(b).max() + 1e-7, (
             name, c)
+
+
+def _oracle_case(seed):
+    rng = np.random.default_rng(5000 + seed)
+    likelihood = LIKELIHOODS[int(rng.integers(0, 4))]
+    k_max = int(rng.choice([0, 0, 2, 4])) if "zero" not in likelihood else 0
+    return dict(
+        gm=bool(rng.integers(0, 2)), F=int(rng.integers(2, 150)),
+        L=int(rng.integers(1, 8)),
+        H=tuple(int(2 * rng.integers(1, 20)) for _ in range(rng.integers(1, 3))),
+        B=int(rng.integers(2, 40)), K=int(rng.integers(1, 4)),
+        S=int(rng.integers(1, 3)), likelihood=likelihood,
+        bn=bool(rng.integers(0, 2)), extra=int(rng.choice([0, 0, 2])),
+        k_max=k_max, free_nats=float(rng.choice([0.0, 0.5])),
+        warm_up=float(rng.choice([1.0, 0.3])))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_models_against_the_oracle(cuda_device, seed):
+    from oracle import models as om
+    from scvae_amd.engine import Engine
+    c = _oracle_case(seed)
+    rng = np.random.default_rng(7000 + seed)
+    gm = c["gm"]
+    eng = Engine(c["F"], c["L"], c["H"], c["likelihood"], batch_norm=c["bn"],
+                 model_type="GMVAE" if gm else "VAE", n_clusters=c["K"],
+                 device=cuda_device, seed=seed, decoder_extra=c["extra"],
+                 k_max=c["k_max"], free_nats_proportion=c["free_nats"])
+    g = torch.Generator().manual_seed(seed)
+    for name, p in eng.named_parameters().items():
+        if not name.endswith("weights"):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    cfg = om.ModelConfig(
+        feature_size=c["F"], latent_size=c["L"], hidden_sizes=c["H"],
+        likelihood=c["likelihood"], minibatch_normalisation=c["bn"],
+        n_iw=c["S"], n_mc=1, n_clusters=c["K"],
+        free_nats_proportion=c["free_nats"], decoder_extra_size=c["extra"],
+        k_max=c["k_max"])
+    params = {k: v.detach().cpu().double()
+              for k, v in eng.named_parameters().items()}
+    moving = {k: v.detach().cpu().double()
+              for k, v in eng.named_moving_statistics().items()}
+    B, F, L, S = c["B"], c["F"], c["L"], c["S"]
+    x = torch.from_numpy((rng.poisson(2.5, (B, F))
+                          * (rng.random((B, F)) < 0.5)).astype(np.float64))
+    eps = torch.from_numpy(rng.standard_normal(
+        (c["K"], S, B, L) if gm else (S, B, L)))
+    extra = (torch.from_numpy(rng.random((B, c["extra"])))
+             if c["extra"] else None)
+    rows = (c["K"] if gm else 1) * S * B
+    ll = torch.zeros(rows, device=cuda_device)
+    sc = eng.step(
+        x.float().to(cuda_device), x.float().to(cuda_device),
+        eps=eps.float().to(cuda_device), training=True, n_iw=S, n_mc=1,
+        warm_up_weight=c["warm_up"],
+        decoder_extra=(extra.float().to(cuda_device)
+                       if extra is not None else None),
+        outputs={"log_p_x_given_z": ll}).cpu().numpy()
+    torch.cuda.synchronize()
+    forward = om.gmvae_forward if gm else om.vae_forward
+    out, grads = om.gradients(
+        lambda p: forward(cfg, p, moving, x, x, eps, True, c["warm_up"],
+                          decoder_extra=extra), params)
+    assert abs(sc[0] - float(out["lower_bound"])) <= 1e-4 * abs(
+        float(out["lower_bound"])), c
+    assert abs(sc[1] - float(out["lower_bound_weighted"])) <= 1e-4 * abs(
+        float(out["lower_bound_weighted"])), c
+    want = out["log_p_x_given_z"].reshape(-1).numpy()
+    assert np.abs(ll.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max(), c
+    for name, got in eng.named_gradients().items():
+        if c["bn"] and name.endswith("DENSE/biases") and (
+                "LAYER_" in name or "ENCODER/" in name or "DECODER/" in name):
+            continue
+        w = grads[name]
+        got = got.cpu().double()
+        if gm and c["bn"] and name == "Z/Q/ENCODER/LAYER_1/DENSE/weights":
+            got, w = got[:F], w[:F]
+        scale = w.abs().max().item()
+        assert (got - w).abs().max().item() <= 1e-3 * scale + 1e-7, (name, c)
