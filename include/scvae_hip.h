@@ -57,6 +57,9 @@ typedef struct scvae_model_config {
                                  distributions/categorised.py): counts below k_max are classes
                                  of a categorical head P_K [F * (k_max + 1)]; 0 = off.  Poisson
                                  and negative binomial only */
+  int32_t prior_mode;         /* GMVAE p(y), gm:2794-2808 (prior_probabilities_method): 0 uniform,
+                                 1 custom (fixed logits in a hidden slot of the parameter buffer,
+                                 see scvae_plan_prior_offset), 2 learn (trainable Y/P/LOGITS) */
   int32_t decoder_extra;      /* E: extra decoder input columns appended to z -- one-hot batch
                                  indices (batch_correction) and/or the normalised count sum
                                  (use_count_sum_as_feature), va:2407-2441, gm:3094-3130 */
@@ -91,6 +94,10 @@ int64_t scvae_plan_moving_floats(const scvae_plan* plan);  /* BN moving mean/var
 int scvae_plan_param_info(const scvae_plan* plan, int64_t index, char* name /*SCVAE_NAME_MAX*/,
                           int64_t* offset, int64_t* rows, int64_t* cols);
 int64_t scvae_plan_moving_count(const scvae_plan* plan);
+/* float offset of the K prior logits of p(y) in the parameter buffer (prior_mode 1: the caller
+ * writes log(prior_probabilities) there once, the step never changes them; prior_mode 2: the
+ * trainable Y/P/LOGITS); -1 for the uniform prior */
+int64_t scvae_plan_prior_offset(const scvae_plan* plan);
 int scvae_plan_moving_info(const scvae_plan* plan, int64_t index, char* name, int64_t* offset,
                            int64_t* size);
 int64_t scvae_plan_workspace_bytes(const scvae_plan* plan, int64_t max_cells, int64_t max_samples);

@@ -57,6 +57,10 @@ class ModelConfig:
     # (batch_correction) and/or the normalised count sum
     # (use_count_sum_as_feature), va:2407-2441, gm:3094-3130
     decoder_extra_size: int = 0
+    # GMVAE p(y), gm:2794-2808: "uniform", "custom" (``prior_probabilities``, a
+    # constant) or "learn" (trainable variable Y/P/LOGITS, initialised to zeros)
+    prior_probabilities_method: str = "uniform"
+    prior_probabilities: Tuple[float, ...] = ()
     # piecewise categorical likelihood (-k): counts below k_max are classes of
     # a categorical head P_K, va:2507-2532 (0 = off)
     k_max: int = 0
@@ -110,6 +114,8 @@ def gmvae_parameter_shapes(cfg):
     H = list(cfg.hidden_sizes)
     K, L, Fs = cfg.n_clusters, cfg.latent_size, cfg.feature_size
     shapes = []
+    if cfg.prior_probabilities_method == "learn":
+        shapes.append(("Y/P/LOGITS", (K,)))
     n_in = Fs
     for i, h in enumerate(H):
         shapes += _dense_entries(
@@ -383,8 +389,17 @@ def gmvae_forward(cfg, params, moving, x, t, eps, training,
     log_y = torch.log_softmax(logits, dim=-1)
     y = torch.exp(log_y)
     entropy = -(y * log_y).sum(dim=-1)
-    p_y_entropy = math.log(K)
-    kl_y_cell = p_y_entropy - entropy
+    if cfg.prior_probabilities_method == "uniform":   # gm:3242-3254
+        p_y_entropy = math.log(K)
+        kl_y_cell = p_y_entropy - entropy
+    else:   # tfp kl_divergence(Categorical q, Categorical p), gm:3256-3258
+        if cfg.prior_probabilities_method == "learn":
+            log_p_y = torch.log_softmax(params["Y/P/LOGITS"], dim=-1)
+        else:
+            log_p_y = torch.log_softmax(torch.log(torch.as_tensor(
+                cfg.prior_probabilities, dtype=logits.dtype)), dim=-1)
+        kl_y_cell = (y * (log_y - log_p_y)).sum(dim=-1)
+        p_y_entropy = -(torch.exp(log_p_y) * log_p_y).sum()
 
     Wpm = params["Z/P/SOFTPLUS_GAUSSIAN/MEAN/DENSE/weights"]
     bpm = params["Z/P/SOFTPLUS_GAUSSIAN/MEAN/DENSE/biases"]
@@ -453,7 +468,8 @@ def gmvae_forward(cfg, params, moving, x, t, eps, training,
     rec = rec_cell.mean()
     if cfg.free_nats_proportion:
         thr = cfg.free_nats_proportion * p_y_entropy
-        kl_y_mod = torch.where(kl_y > thr, kl_y, torch.full_like(kl_y, thr))
+        kl_y_mod = torch.where(kl_y > thr, kl_y,
+                               torch.as_tensor(thr, dtype=kl_y.dtype))
     else:
         kl_y_mod = kl_y
     w = warm_up_weight * cfg.kl_weight

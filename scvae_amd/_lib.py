@@ -41,6 +41,7 @@ class ModelConfig(Structure):
         ("kl_weight", c_float),
         ("free_nats_proportion", c_float),
         ("k_max", c_int32),
+        ("prior_mode", c_int32),
         ("decoder_extra", c_int32),
     ]
 
@@ -113,6 +114,7 @@ SIGNATURES = {
     "scvae_decoder_fused_workspace_bytes": (c_int64, [c_int64, c_int64,
                                                       c_int64]),
     "scvae_decoder_fused_variant": (c_int32, [c_int32, c_int64]),
+    "scvae_plan_prior_offset": (c_int64, [c_void_p]),
     "scvae_plan_decode": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p,
                                     c_void_p]),
     "scvae_decoder_fused": (c_int32, [

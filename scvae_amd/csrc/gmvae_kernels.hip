@@ -113,10 +113,23 @@ int sum_groups(hipStream_t s, const float* a, const float* w, int ldw, int G, in
 
 // q(y|x) = Categorical(logits) (gm:3050-3092): y = softmax, KL(q(y|x) || uniform) = log K - H[q]
 // one wave per cell
+// log-normaliser of the prior logits (wave-wide; K is small)
+__device__ __forceinline__ float prior_log_normaliser(const float* __restrict__ m, int K,
+                                                      int lane) {
+  float mx = -INFINITY;
+  for (int k = lane; k < K; k += 64) mx = fmaxf(mx, m[k]);
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int k = lane; k < K; k += 64) se += __expf(m[k] - mx);
+  se = wave_sum(se);
+  return mx + __logf(se);
+}
+
 __global__ __launch_bounds__(256) void categorical_fwd_kernel(const float* __restrict__ logits,
                                                               float* __restrict__ y,
                                                               float* __restrict__ kl_y_cell, int B,
-                                                              int K) {
+                                                              int K,
+                                                              const float* __restrict__ prior) {
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (b >= B) return;
@@ -128,21 +141,24 @@ __global__ __launch_bounds__(256) void categorical_fwd_kernel(const float* __res
   for (int k = lane; k < K; k += 64) se += __expf(row[k] - mx);
   se = wave_sum(se);
   const float lse = mx + __logf(se);
-  float h = 0.f;
+  const float lse_p = prior ? prior_log_normaliser(prior, K, lane) : 0.f;
+  float h = 0.f;   // uniform: -sum q log q; otherwise sum q (log q - log p)
   for (int k = lane; k < K; k += 64) {
     const float ly = row[k] - lse;
     const float p = __expf(ly);
     y[(size_t)b * K + k] = p;
-    h -= p * ly;
+    if (prior) h += p * (ly - (prior[k] - lse_p));
+    else h -= p * ly;
   }
   h = wave_sum(h);
-  if (lane == 0) kl_y_cell[b] = __logf((float)K) - h;
+  if (lane == 0) kl_y_cell[b] = prior ? h : __logf((float)K) - h;
 }
-int categorical_fwd(hipStream_t s, const float* logits, float* y, float* kl_y_cell, int B, int K) {
+int categorical_fwd(hipStream_t s, const float* logits, float* y, float* kl_y_cell, int B, int K,
+                    const float* prior_logits) {
   SCVAE_ARG(logits && y && kl_y_cell && K > 0);
   if (B == 0) return 0;
   hipLaunchKernelGGL(categorical_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, s, logits, y,
-                     kl_y_cell, B, K);
+                     kl_y_cell, B, K, prior_logits);
   SCVAE_LAUNCH_CHECK("categorical_fwd_kernel");
   return 0;
 }
@@ -335,8 +351,22 @@ __global__ __launch_bounds__(256) void gmvae_elbo_sums_kernel(const float* __res
 // phase B: scalars from the (global) sums; free-nats gate (gm:3391-3398) -> gate[0]
 __global__ void gmvae_elbo_finish_kernel(const float* __restrict__ sums, float w, float thr,
                                          int use_free_nats, float share,
-                                         float* __restrict__ scalars, float* __restrict__ gate) {
+                                         float* __restrict__ scalars, float* __restrict__ gate,
+                                         const float* __restrict__ prior, int K, float free_nats) {
   const float rec = sums[0], kz = sums[1], ky = sums[2];
+  if (prior != nullptr) {   // thr = free_nats * H[p(y)] (gm:3258-3261)
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, prior[k]);
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) se += __expf(prior[k] - mx);
+    const float lse = mx + __logf(se);
+    float h = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float lp = prior[k] - lse;
+      h -= __expf(lp) * lp;
+    }
+    thr = free_nats * h;
+  }
   const float ky_mod = use_free_nats ? (ky > thr ? ky : thr) : ky;
   // `share` scales the global values back to this rank's share (scalars are summed by the
   // caller over ranks); 1 on a single GPU
@@ -357,10 +387,11 @@ int gmvae_elbo(hipStream_t s, const float* ll, const float* klz, const float* y,
   return 0;
 }
 int gmvae_elbo_finish(hipStream_t s, const float* sums, float w, float thr, int use_free_nats,
-                      float share, float* scalars, float* gate) {
+                      float share, float* scalars, float* gate, const float* prior_logits, int K,
+                      float free_nats) {
   SCVAE_ARG(sums && scalars && gate);
   hipLaunchKernelGGL(gmvae_elbo_finish_kernel, dim3(1), dim3(1), 0, s, sums, w, thr, use_free_nats,
-                     share, scalars, gate);
+                     share, scalars, gate, prior_logits, K, free_nats);
   SCVAE_LAUNCH_CHECK("gmvae_elbo_finish_kernel");
   return 0;
 }
@@ -408,32 +439,75 @@ int gmvae_elbo_bwd(hipStream_t s, const float* ll, const float* klz, const float
 // dlogits = softmax-bwd(dy) + (w * gate / GB) * d kl_y_cell
 __global__ __launch_bounds__(256) void categorical_bwd_gated_kernel(
     const float* __restrict__ y, const float* __restrict__ dy, const float* __restrict__ gate,
-    float c, float* __restrict__ dlogits, int B, int K) {
+    float c, float* __restrict__ dlogits, int B, int K, const float* __restrict__ prior) {
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (b >= B) return;
   const float cc = c * gate[0];
+  const float lse_p = prior ? prior_log_normaliser(prior, K, lane) : 0.f;
+  // h = -KL_b + const: the KL gradient is q_j (log q_j - log p_j - KL_b); with the uniform prior
+  // log p_j is constant and drops out against KL_b = log K - H
   float dot = 0.f, h = 0.f;
   for (int k = lane; k < K; k += 64) {
     const float p = y[(size_t)b * K + k];
     dot += p * dy[(size_t)b * K + k];
-    h -= p > 0.f ? p * __logf(p) : 0.f;
+    const float lq = p > 0.f ? __logf(p) : 0.f;
+    h -= p * (lq - (prior ? prior[k] - lse_p : 0.f));
   }
   dot = wave_sum(dot);
   h = wave_sum(h);
   for (int k = lane; k < K; k += 64) {
     const float p = y[(size_t)b * K + k];
-    const float lp = p > 0.f ? __logf(p) : 0.f;
-    dlogits[(size_t)b * K + k] = p * (dy[(size_t)b * K + k] - dot) + cc * p * (lp + h);
+    const float lq = p > 0.f ? __logf(p) : 0.f;
+    const float rel = lq - (prior ? prior[k] - lse_p : 0.f);
+    dlogits[(size_t)b * K + k] = p * (dy[(size_t)b * K + k] - dot) + cc * p * (rel + h);
   }
 }
 int categorical_bwd_gated(hipStream_t s, const float* y, const float* dy, const float* gate,
-                          float c, float* dlogits, int B, int K) {
+                          float c, float* dlogits, int B, int K, const float* prior_logits) {
   SCVAE_ARG(y && dy && gate && dlogits);
   if (B == 0) return 0;
   hipLaunchKernelGGL(categorical_bwd_gated_kernel, dim3((B + 3) / 4), dim3(256), 0, s, y, dy, gate,
-                     c, dlogits, B, K);
+                     c, dlogits, B, K, prior_logits);
   SCVAE_LAUNCH_CHECK("categorical_bwd_gated_kernel");
+  return 0;
+}
+
+// gradient of w * max(mean_b KL_y, free_nats * H[p]) w.r.t. the prior logits m (one workgroup):
+//   KL_b = sum_k q_bk (log q_bk - log p_k)        =>  dKL_b/dm_j = p_j - q_bj
+//   H[p] = -sum_k p_k log p_k                      =>  dH/dm_j   = -p_j (log p_j + H)
+__global__ __launch_bounds__(256) void prior_logits_bwd_kernel(
+    const float* __restrict__ y, const float* __restrict__ prior, const float* __restrict__ gate,
+    float c, float off_scale, float free_nats, int B, int K, float* __restrict__ dprior) {
+  __shared__ float red[4];
+  float mx = -INFINITY;
+  for (int k = 0; k < K; ++k) mx = fmaxf(mx, prior[k]);
+  float se = 0.f;
+  for (int k = 0; k < K; ++k) se += __expf(prior[k] - mx);
+  const float lse = mx + __logf(se);
+  float H = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float lp = prior[k] - lse;
+    H -= __expf(lp) * lp;
+  }
+  const bool on = gate[0] != 0.f;
+  for (int j = 0; j < K; ++j) {
+    const float lp = prior[j] - lse, pj = __expf(lp);
+    float acc = 0.f;
+    if (on)
+      for (int b = threadIdx.x; b < B; b += 256) acc += pj - y[(size_t)b * K + j];
+    acc = block_sum<256>(acc, red);
+    if (threadIdx.x == 0)
+      dprior[j] = on ? c * acc : off_scale * free_nats * (-pj * (lp + H));
+    __syncthreads();
+  }
+}
+int prior_logits_bwd(hipStream_t s, const float* y, const float* prior_logits, const float* gate,
+                     float c, float off_scale, float free_nats, int B, int K, float* dprior) {
+  SCVAE_ARG(y && prior_logits && gate && dprior && K > 0);
+  hipLaunchKernelGGL(prior_logits_bwd_kernel, dim3(1), dim3(256), 0, s, y, prior_logits, gate, c,
+                     off_scale, free_nats, B, K, dprior);
+  SCVAE_LAUNCH_CHECK("prior_logits_bwd_kernel");
   return 0;
 }
 

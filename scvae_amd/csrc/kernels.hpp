@@ -124,9 +124,18 @@ int group_col_sum(hipStream_t s, const float* a, int lda, int R, int G, int N, f
                   float* out, float* partial);
 int sum_groups(hipStream_t s, const float* a, const float* w, int ldw, int G, int R, int N,
                float* out);
-int categorical_fwd(hipStream_t s, const float* logits, float* y, float* kl_y_cell, int B, int K);
+// `prior_logits` (K floats or NULL = uniform p(y)): kl_y_cell[b] = KL(q(y|x_b) || p(y))
+// (gm:3242-3258: log K - H[q] for the uniform prior, tfp kl_divergence otherwise)
+int categorical_fwd(hipStream_t s, const float* logits, float* y, float* kl_y_cell, int B, int K,
+                    const float* prior_logits = nullptr);
+// d/d prior_logits of w * max(mean_b KL_y, free_nats * H[p]) (learned p(y), gm:2799-2803):
+// gate on:  c * sum_b (p_j - q_bj);  gate off: off_scale * free_nats * dH[p]/dm_j
+int prior_logits_bwd(hipStream_t s, const float* y, const float* prior_logits, const float* gate,
+                     float c, float off_scale, float free_nats, int B, int K, float* dprior);
+// (with `prior_logits`: the KL term's gradient is q_j (log q_j - log p_j - KL_b))
 int categorical_bwd_gated(hipStream_t s, const float* y, const float* dy, const float* gate,
-                          float c, float* dlogits, int B, int K);
+                          float c, float* dlogits, int B, int K,
+                          const float* prior_logits = nullptr);
 int softplus_gaussian_fwd(hipStream_t st, const float* qm, const float* qs, const float* Wpm,
                           const float* bpm, const float* Wps, const float* bps, const float* eps,
                           float* z, float* klz, float* qvar, int K, int S, int B, int L);
@@ -137,8 +146,11 @@ int softplus_gaussian_bwd(hipStream_t st, const float* qm, const float* qs, cons
 int gmvae_elbo(hipStream_t s, const float* ll, const float* klz, const float* y,
                const float* kl_y_cell, int K, int S, int B, float inv_gb, float* sums,
                float* rec_cell);
+// thr = free_nats * H[p(y)]: `thr` as given for the uniform prior, computed on the device from
+// `prior_logits` (K floats) otherwise
 int gmvae_elbo_finish(hipStream_t s, const float* sums, float w, float thr, int use_free_nats,
-                      float share, float* scalars, float* gate);
+                      float share, float* scalars, float* gate,
+                      const float* prior_logits = nullptr, int K = 0, float free_nats = 0.f);
 int gmvae_elbo_bwd(hipStream_t s, const float* ll, const float* klz, const float* y,
                    const float* gate, int K, int S, int B, float w, float inv_gb, float* gw,
                    float* gklz, float* dy);

@@ -523,6 +523,8 @@ int scvae_plan_create(const scvae_model_config* cfg, scvae_plan** out) {
   SCVAE_ARG(cfg->model_type == SCVAE_MODEL_VAE || (cfg->n_clusters >= 1 && cfg->n_clusters <= 1024));
   SCVAE_ARG(cfg->decoder_extra >= 0 && cfg->decoder_extra <= 4096);
   SCVAE_ARG(cfg->k_max >= 0 && cfg->k_max <= 64);
+  SCVAE_ARG(cfg->prior_mode >= 0 && cfg->prior_mode <= 2);
+  SCVAE_ARG(cfg->prior_mode == 0 || cfg->model_type == SCVAE_MODEL_GMVAE);
   SCVAE_ARG(cfg->k_max == 0 || cfg->likelihood == SCVAE_POISSON || cfg->likelihood == SCVAE_NB);
   SCVAE_ARG(cfg->decoder_extra == 0 || cfg->n_hidden > 0);
   scvae_plan* p = new scvae_plan();
@@ -550,6 +552,10 @@ int scvae_plan_param_info(const scvae_plan* p, int64_t i, char* name, int64_t* o
   if (rows) *rows = q.rows;
   if (cols) *cols = q.cols;
   return 0;
+}
+
+int64_t scvae_plan_prior_offset(const scvae_plan* p) {
+  return (p && p->prior_off != scvae::NPOS) ? (int64_t)p->prior_off : -1;
 }
 
 int scvae_plan_moving_info(const scvae_plan* p, int64_t i, char* name, int64_t* offset,
@@ -593,6 +599,8 @@ int scvae_plan_bind(scvae_plan* p, float* params, float* grads, float* moving, v
     for (auto* layers : {&p->enc, &p->dec, &p->yenc, &p->zenc, &p->xdec})
       for (auto& d : *layers)
         if (d.bn) SCVAE_HIP(hipMemset(grads + d.b, 0, (size_t)d.n_out * sizeof(float)));
+    if (p->cfg.prior_mode == 1)   // fixed prior logits: no gradient, ever
+      SCVAE_HIP(hipMemset(grads + p->prior_off, 0, (size_t)p->cfg.n_clusters * sizeof(float)));
   }
   return 0;
 }

@@ -144,6 +144,7 @@ struct scvae_plan {
   // GMVAE graph (gm:2788-3221)
   std::vector<Dense> yenc, zenc, xdec;
   Dense ylogits, qmean, qscale, pmean, pscale;
+  size_t prior_off = NPOS;    // K logits of p(y) in the parameter buffer (cfg.prior_mode != 0)
   float *logits = nullptr, *yprob = nullptr, *kl_y_cell = nullptr, *a0 = nullptr;
   float *qm = nullptr, *qs = nullptr, *klz = nullptr, *gklz = nullptr, *dy = nullptr;
   float *dlogits = nullptr, *dqm = nullptr, *dqs = nullptr, *dprior = nullptr;

@@ -17,6 +17,8 @@ int build_gmvae(scvae_plan* p) {
   Layout& L = p->layout;
   char scope[96];
   int n_in = F;
+  // learned p(y): tf.Variable "LOGITS" in scope Y/P, the first variable of the graph (gm:2799-2803)
+  if (c.prior_mode == 2) p->prior_off = L.add("Y/P/LOGITS", K, 0);
   for (int i = 0; i < c.n_hidden; ++i) {
     snprintf(scope, sizeof scope, "Y/CATEGORICAL/ENCODER/LAYER_%d", i + 1);
     p->yenc.push_back(L.dense(scope, n_in, c.hidden[i], bn));
@@ -45,6 +47,12 @@ int build_gmvae(scvae_plan* p) {
     p->heads[j] = L.dense(scope, n_in, F, false);
   }
   if (c.k_max > 0) p->head_k = L.dense("X/DISTRIBUTION/P_K", n_in, F * (c.k_max + 1), false);
+  if (c.prior_mode == 1) {
+    // custom p(y) (a tf.constant in the reference): K fixed logits in a slot of the parameter
+    // buffer that is not listed among the variables; its gradient slot stays zero
+    p->prior_off = L.n_params;
+    L.n_params += ((size_t)K + ALIGN_FLOATS - 1) / ALIGN_FLOATS * ALIGN_FLOATS;
+  }
   return 0;
 }
 
@@ -172,7 +180,8 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const int ldy = ld;
   GEMM(false, false, hy, p->params + p->ylogits.w, p->params + p->ylogits.b, p->logits, B, K, ldy,
        ldy, K, K, ACT_NONE, false);
-  TRY(categorical_fwd(s, p->logits, p->yprob, p->kl_y_cell, B, K));
+  const float* prior = p->prior_off != NPOS ? p->params + p->prior_off : nullptr;
+  TRY(categorical_fwd(s, p->logits, p->yprob, p->kl_y_cell, B, K, prior));
   if (a->q_y_logits) TRY(copy(s, p->logits, a->q_y_logits, (size_t)B * K));
 
   // ---------------- q(z|x,y=k), all k (gm:2936-3007) ----------------
@@ -301,7 +310,8 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     else
       TRY(loglik_fwd(s, c.likelihood, a->t, F, pre, F, a->row_const, p->ll, R, B, F));
     TRY(gmvae_elbo(s, p->ll, p->klz, p->yprob, p->kl_y_cell, K, S, B, inv_gb, sums, nullptr));
-    TRY(gmvae_elbo_finish(s, sums, w, thr, use_free_nats, 1.f, a->scalars, gate));
+    TRY(gmvae_elbo_finish(s, sums, w, thr, use_free_nats, 1.f, a->scalars, gate, prior, K,
+                          c.free_nats_proportion));
     if (a->log_p_x_given_z) TRY(copy(s, p->ll, a->log_p_x_given_z, (size_t)R));
     return 0;
   }
@@ -329,7 +339,8 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     }
     share = (float)a->cells / (float)GB;
   }
-  TRY(gmvae_elbo_finish(s, sums, w, thr, use_free_nats, share, a->scalars, gate));
+  TRY(gmvae_elbo_finish(s, sums, w, thr, use_free_nats, share, a->scalars, gate, prior, K,
+                        c.free_nats_proportion));
   TRY(gmvae_elbo_bwd(s, p->ll, p->klz, p->yprob, gate, K, S, B, w, inv_gb, p->gw, p->gklz, p->dy));
   if (a->log_p_x_given_z) TRY(copy(s, p->ll, a->log_p_x_given_z, (size_t)R));
 
@@ -410,7 +421,10 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
 
   // ---------------- backward: q(y|x) ----------------
-  TRY(categorical_bwd_gated(s, p->yprob, p->dy, gate, w * inv_gb, p->dlogits, B, K));
+  TRY(categorical_bwd_gated(s, p->yprob, p->dy, gate, w * inv_gb, p->dlogits, B, K, prior));
+  if (c.prior_mode == 2)   // learned p(y): this rank's share of the gradient of w * KL_y_modified
+    TRY(prior_logits_bwd(s, p->yprob, prior, gate, w * inv_gb, w * share, c.free_nats_proportion,
+                         B, K, p->grads + p->prior_off));
   {
     Dense& hd = p->ylogits;
     GEMM(true, false, hy, p->dlogits, nullptr, p->grads + hd.w, hd.n_in, K, B, ldy, K, K, ACT_NONE,

@@ -38,7 +38,9 @@ class Engine:
     def __init__(self, feature_size, latent_size, hidden_sizes, likelihood,
                  batch_norm=True, model_type="VAE", n_clusters=1,
                  kl_weight=1.0, free_nats_proportion=0.0, device=None,
-                 seed=0, decoder_extra=0, k_max=0):
+                 seed=0, decoder_extra=0, k_max=0,
+                 prior_probabilities_method="uniform",
+                 prior_probabilities=None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError(
@@ -54,6 +56,14 @@ class Engine:
         self.n_clusters = int(n_clusters)
         self.decoder_extra = int(decoder_extra)
         self.k_max = int(k_max or 0)
+        self.prior_probabilities_method = prior_probabilities_method
+        self.prior_probabilities = (
+            None if prior_probabilities is None
+            else [float(p) for p in prior_probabilities])
+        if prior_probabilities_method == "custom" and (
+                self.prior_probabilities is None
+                or len(self.prior_probabilities) != self.n_clusters):
+            raise ValueError("custom prior probabilities: one per cluster")
         if len(self.hidden_sizes) > _lib.MAX_HIDDEN:
             raise ValueError("At most {} hidden layers are supported.".format(
                 _lib.MAX_HIDDEN))
@@ -73,6 +83,8 @@ class Engine:
         cfg.free_nats_proportion = float(free_nats_proportion)
         cfg.decoder_extra = self.decoder_extra
         cfg.k_max = self.k_max
+        cfg.prior_mode = {"uniform": 0, "custom": 1, "learn": 2}[
+            prior_probabilities_method]
         self.config = cfg
 
         handle = ctypes.c_void_p()
@@ -184,6 +196,19 @@ class Engine:
         self.adam_v.zero_()
         self.grads.zero_()
         self.adam_t = 0
+        if self.prior_probabilities_method == "custom":
+            # tf.log(tf.constant(prior_probabilities)), gm:2796-2798
+            self.prior_logits.copy_(torch.log(torch.tensor(
+                self.prior_probabilities, dtype=torch.float64)).float())
+
+    @property
+    def prior_logits(self):
+        """The K logits of p(y) (view into the parameter buffer), or None for
+        the uniform prior."""
+        offset = self.lib.scvae_plan_prior_offset(self.handle)
+        if offset < 0:
+            return None
+        return self.params[offset:offset + self.n_clusters]
 
     def load_parameters(self, named, moving=None):
         for k, v in named.items():

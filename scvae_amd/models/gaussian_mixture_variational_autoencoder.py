@@ -57,7 +57,7 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
     Arguments follow gm:136-326: ``feature_size``, ``latent_size``,
     ``hidden_sizes``, ``reconstruction_distribution``,
     ``number_of_reconstruction_classes``, ``latent_distribution``,
-    ``prior_probabilities_method`` (only ``uniform`` is built),
+    ``prior_probabilities_method`` (``uniform``, ``custom``, ``learn``),
     ``prior_probabilities``, ``number_of_latent_clusters``,
     ``minibatch_normalisation``, ``batch_correction``, ``number_of_batches``,
     ``number_of_warm_up_epochs``, ``log_directory`` and the keyword arguments
@@ -210,10 +210,6 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
                 "multinomial)", "gm:3118-3125")
         if self.dropout_parts:
             raise mu.not_in_this_build("Dropout", "mu:45-50")
-        if self.prior_probabilities_method != "uniform":
-            raise mu.not_in_this_build(
-                "`{}` prior probabilities".format(
-                    self.prior_probabilities_method), "gm:2797-2803")
         if self.latent_distribution_name != "gaussian mixture":
             raise mu.not_in_this_build(
                 "Latent distribution `{}`".format(
@@ -241,7 +237,9 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
             n_clusters=self.n_clusters, kl_weight=self.kl_weight_value,
             free_nats_proportion=(
                 self.proportion_of_free_nats_for_y_kl_divergence),
-            decoder_extra=self.decoder_extra_size, k_max=self.k_max)
+            decoder_extra=self.decoder_extra_size, k_max=self.k_max,
+            prior_probabilities_method=self.prior_probabilities_method,
+            prior_probabilities=self.prior_probabilities)
 
     def _parameter_shapes(self):
         table = []
@@ -254,6 +252,8 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
             table.append((scope + "/DENSE/biases", (n_out,)))
             if with_bn:
                 table.append((scope + "/BATCH_NORM/beta", (n_out,)))
+        if self.prior_probabilities_method == "learn":
+            table.append(("Y/P/LOGITS", (K,)))
         n_in = F
         for i, h in enumerate(H):
             dense("Y/CATEGORICAL/ENCODER/LAYER_{}".format(i + 1), n_in, h, bn)
@@ -415,7 +415,13 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
         means = (Wm + bm).cpu().numpy()
         variances = torch.nn.functional.softplus(Ws + bs).cpu().numpy()
         del L
-        return (numpy.full(K, 1.0 / K), means, variances)
+        prior_logits = engine.prior_logits
+        if prior_logits is None:
+            probabilities = numpy.full(K, 1.0 / K)
+        else:   # p_y_probabilities = softmax(p_y_logits), gm:2815-2816
+            probabilities = torch.softmax(
+                prior_logits.double(), dim=0).cpu().numpy()
+        return (probabilities, means, variances)
 
     def _centroids(self, prior):
         probabilities, means, variances = prior

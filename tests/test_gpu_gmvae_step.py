@@ -119,3 +119,66 @@ def test_gmvae_evaluation_statistics(cuda_device):
     _close(sc[0], out["lower_bound"], what="lower_bound")
     for k in outs:
         _close(outs[k].cpu(), out[k], rtol=2e-4, what=k)
+
+
+@pytest.mark.parametrize("method,free_nats", [("custom", 0.0), ("learn", 0.0),
+                                              ("learn", 0.95),
+                                              ("custom", 0.95)])
+def test_non_uniform_prior_over_clusters(cuda_device, method, free_nats):
+    """p(y) given (`custom`) or trainable (`learn`, variable Y/P/LOGITS):
+    KL(q(y|x) || p(y)), the free-nats threshold on H[p(y)] and the gradient of
+    the prior logits (gm:2794-2808, 3242-3261)."""
+    from scvae_amd.engine import Engine
+    F, L, H, B, K = 60, 4, (12,), 26, 4
+    prior = (0.1, 0.2, 0.3, 0.4)
+    eng = Engine(F, L, H, "negative binomial", batch_norm=True,
+                 model_type="GMVAE", n_clusters=K, device=cuda_device, seed=1,
+                 free_nats_proportion=free_nats,
+                 prior_probabilities_method=method,
+                 prior_probabilities=prior if method == "custom" else None)
+    g = torch.Generator().manual_seed(3)
+    for name, p in eng.named_parameters().items():
+        if not name.endswith("weights"):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+    cfg = om.ModelConfig(feature_size=F, latent_size=L, hidden_sizes=H,
+                         likelihood="negative binomial", n_clusters=K,
+                         free_nats_proportion=free_nats,
+                         prior_probabilities_method=method,
+                         prior_probabilities=prior if method == "custom"
+                         else ())
+    params = {k: v.detach().cpu().double()
+              for k, v in eng.named_parameters().items()}
+    assert list(params) == list(om.gmvae_parameter_shapes(cfg))
+    assert (list(params)[0] == "Y/P/LOGITS") == (method == "learn")
+    if method == "custom":
+        assert torch.allclose(eng.prior_logits.cpu().double(),
+                              torch.log(torch.tensor(prior,
+                                                     dtype=torch.float64)),
+                              atol=1e-6)
+    moving = {k: v.detach().cpu().double()
+              for k, v in eng.named_moving_statistics().items()}
+    rng = np.random.default_rng(2)
+    x = torch.from_numpy((rng.poisson(2.0, (B, F))
+                          * (rng.random((B, F)) > 0.5)).astype(np.float64))
+    eps = torch.from_numpy(rng.standard_normal((K, 1, B, L)))
+    sc = eng.step(x.float().to(cuda_device), x.float().to(cuda_device),
+                  eps=eps.float().to(cuda_device), training=True,
+                  warm_up_weight=0.8).cpu().numpy()
+    out, grads = om.gradients(
+        lambda p: om.gmvae_forward(cfg, p, moving, x, x, eps, True, 0.8),
+        params)
+    _close(sc[0], out["lower_bound"], what="lower_bound")
+    _close(sc[1], out["lower_bound_weighted"], what="lower_bound_weighted")
+    _close(sc[4], out["kl_divergence_y"], rtol=2e-4, what="kl_divergence_y")
+    for name, got in eng.named_gradients().items():
+        if name.endswith("DENSE/biases") and "LAYER_" in name:
+            continue
+        want = grads[name]
+        got = got.cpu()
+        if name == "Z/Q/ENCODER/LAYER_1/DENSE/weights":
+            got, want = got[:F], want[:F]
+        _close(got, want, rtol=5e-4, what="grad " + name)
+    if method == "custom":   # the fixed logits never move
+        before = eng.prior_logits.clone()
+        eng.adam_step(1e-2)
+        assert torch.equal(before, eng.prior_logits)

@@ -87,9 +87,13 @@ def test_constructor_errors():
     assert model.k_max == 3 and model.decoder_extra_size == 3
     with pytest.raises(NotImplementedError):
         VariationalAutoencoder(10, dropout_keep_probabilities=[0.9])
+    learned = GaussianMixtureVariationalAutoencoder(
+        10, prior_probabilities_method="learn")
+    assert ("Y/P/LOGITS", (learned.n_clusters,)) == learned._parameter_shapes()[0]
+    assert "p_learn" in learned.name
     with pytest.raises(NotImplementedError):
         GaussianMixtureVariationalAutoencoder(
-            10, prior_probabilities_method="learn")
+            10, prior_probabilities_method="infer")
     with pytest.raises(TypeError):
         GaussianMixtureVariationalAutoencoder(
             10, prior_probabilities_method="custom")
