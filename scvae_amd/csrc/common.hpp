@@ -86,11 +86,16 @@ __device__ __forceinline__ void lds_barrier() {
 
 // ---- scalar math used by the likelihood kernels ----
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// natural log of a normal positive float: v_log_f32 (1 ulp) times ln 2.  (__logf expands to a
+// dozen instructions: denormal range handling and a hi/lo multiply by ln 2, neither needed here)
+__device__ __forceinline__ float fast_log(float x) {
+  return __builtin_amdgcn_logf(x) * 0.6931471805599453f;
+}
 // log(1 + x), x > -1: log(u) * x / (u - 1) with u = fl(1 + x) removes the rounding of 1 + x
 __device__ __forceinline__ float fast_log1p(float x) {
   const float u = 1.f + x;
   const float d = u - 1.f;
-  return d == 0.f ? x : __logf(u) * (x * fast_rcp(d));
+  return d == 0.f ? x : fast_log(u) * (x * fast_rcp(d));
 }
 // log(sigmoid(a)), log(sigmoid(-a)) and sigmoid(a) from one exp and one log
 __device__ __forceinline__ void log_sigmoid_pair(float a, float& ls_pos, float& ls_neg,
@@ -143,7 +148,7 @@ __device__ __forceinline__ void lgamma_digamma_diff_small(float r, float t, floa
     if (WITH_D) Q = on ? fmaf(Q, f, P) : Q;
     P = on ? P * f : P;
   }
-  A = __logf(P);
+  A = fast_log(P);
   D = WITH_D ? Q * fast_rcp(P) : 0.f;
 }
 
@@ -153,7 +158,7 @@ __device__ __forceinline__ void lgamma_digamma_diff_general(float r, float t, fl
   const float b = r + 8.f, a = x + 8.f;
   const float ib = fast_rcp(b), ia = fast_rcp(a);
   const float l1 = fast_log1p(t * ib);
-  const float A8 = t * __logf(a) + (b - 0.5f) * l1 - t + (stirling_tail_r(ia) - stirling_tail_r(ib));
+  const float A8 = t * fast_log(a) + (b - 0.5f) * l1 - t + (stirling_tail_r(ia) - stirling_tail_r(ib));
   // products of the 8 shift factors, in two groups of 4 (no overflow for t < 1e7)
   float n1 = x, n2 = x + 4.f, d1 = r, d2 = r + 4.f;
   float n1p = 1.f, n2p = 1.f, d1p = 1.f, d2p = 1.f;  // derivatives of the products
@@ -169,7 +174,7 @@ __device__ __forceinline__ void lgamma_digamma_diff_general(float r, float t, fl
   }
   const float in1 = fast_rcp(n1), in2 = fast_rcp(n2), id1 = fast_rcp(d1), id2 = fast_rcp(d2);
   // log(n1*n2/(d1*d2)) as log(n1/d1) + log(n2/d2): each ratio is >= 1 and finite
-  A = A8 - (__logf(n1 * id1) + __logf(n2 * id2));
+  A = A8 - (fast_log(n1 * id1) + fast_log(n2 * id2));
   if (WITH_D) {
     const float D8 = l1 - (digamma_tail_r(ia) - digamma_tail_r(ib));
     // sum_{i<8} 1/(r+i) - 1/(x+i)
