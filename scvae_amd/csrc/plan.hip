@@ -470,6 +470,9 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   if (E > 0 && !p->dec.empty())
     if ((rc = slice_cols(s, p->dzcat, L + E, L, (size_t)R, p->dz))) return rc;
+  // no hidden layers: the heads sit directly on z, their dd is dz
+  if (p->dec.empty())
+    if ((rc = copy(s, dcur, p->dz, (size_t)R * L))) return rc;
   // latent: dz -> dmu_pre, dls_pre  (d(-ELBO_w)/dKL_cell = w / B_global)
   if ((rc = gauss_latent_bwd(s, p->mu_pre, p->ls_pre, a->eps, p->dz, w / (float)GB, p->dmu, p->dls,
                              S, B, L)))

@@ -155,3 +155,19 @@ def test_evaluation_mode_statistics(cuda_device):
     out = om.vae_forward(cfg, params, moving, x, x, None, False,
                          deterministic_z=True)
     _close(sc[0], out["lower_bound"], what="lower_bound (deterministic z)")
+
+
+@pytest.mark.parametrize("likelihood", ["negative binomial", "poisson"])
+def test_model_without_hidden_layers(cuda_device, likelihood):
+    """``hidden_sizes=[]``: posterior heads on x, likelihood heads directly on z
+    (the reference's dense_layers() with an empty list)."""
+    F, L, B = 40, 6, 17
+    eng, cfg, params, moving, x, eps = _setup(
+        cuda_device, likelihood, F, L, (), B, True)
+    sc = eng.step(x.float().to(cuda_device), x.float().to(cuda_device),
+                  eps=eps.float().to(cuda_device), training=True).cpu().numpy()
+    out, grads = om.gradients(
+        lambda p: om.vae_forward(cfg, p, moving, x, x, eps, True), params)
+    _close(sc[0], out["lower_bound"], what="lower_bound")
+    for name, g in eng.named_gradients().items():
+        _close(g.cpu(), grads[name], rtol=2e-4, what="grad " + name)
