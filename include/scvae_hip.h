@@ -60,6 +60,10 @@ typedef struct scvae_model_config {
   int32_t prior_mode;         /* GMVAE p(y), gm:2794-2808 (prior_probabilities_method): 0 uniform,
                                  1 custom (fixed logits in a hidden slot of the parameter buffer,
                                  see scvae_plan_prior_offset), 2 learn (trainable Y/P/LOGITS) */
+  int32_t linear_factor;      /* VAE: bit 0 inference_architecture == "LFM" (posterior heads
+                                 directly on x, va:2233-2234), bit 1 generative_architecture ==
+                                 "LFM" (likelihood heads directly on z, va:2456-2457): the hidden
+                                 layers of that side are not built */
   int32_t decoder_extra;      /* E: extra decoder input columns appended to z -- one-hot batch
                                  indices (batch_correction) and/or the normalised count sum
                                  (use_count_sum_as_feature), va:2407-2441, gm:3094-3130 */

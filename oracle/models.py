@@ -57,6 +57,10 @@ class ModelConfig:
     # (batch_correction) and/or the normalised count sum
     # (use_count_sum_as_feature), va:2407-2441, gm:3094-3130
     decoder_extra_size: int = 0
+    # linear factor model on either side (va:2233-2234, 2456-2457): that side's
+    # hidden layers are not built
+    inference_architecture: str = "MLP"
+    generative_architecture: str = "MLP"
     # GMVAE p(y), gm:2794-2808: "uniform", "custom" (``prior_probabilities``, a
     # constant) or "learn" (trainable variable Y/P/LOGITS, initialised to zeros)
     prior_probabilities_method: str = "uniform"
@@ -89,7 +93,7 @@ def vae_parameter_shapes(cfg):
     n = len(H)
     shapes = []
     n_in = cfg.feature_size
-    for i, h in enumerate(H):
+    for i, h in enumerate(H if cfg.inference_architecture == "MLP" else []):
         shapes += _dense_entries("ENCODER/{}".format(i + 1), n_in, h, bn)
         n_in = h
     shapes += _dense_entries("POSTERIOR/MU", n_in, cfg.latent_size, False)
@@ -97,7 +101,8 @@ def vae_parameter_shapes(cfg):
                              False)
     n_in = cfg.latent_size + cfg.decoder_extra_size
     # reverse_order=True: sizes reversed, scopes numbered n..1
-    for i, h in enumerate(H[::-1]):
+    for i, h in enumerate(H[::-1] if cfg.generative_architecture == "MLP"
+                          else []):
         shapes += _dense_entries("DECODER/{}".format(n - i), n_in, h, bn)
         n_in = h
     for p in cfg.heads:
@@ -253,7 +258,7 @@ def decode_mean(cfg, params, moving, z, model_type="VAE"):
     n = len(H)
     if model_type == "VAE":
         d = z
-        for i in range(n):
+        for i in range(n if cfg.generative_architecture == "MLP" else 0):
             d = dense_layer(d, params, "DECODER/{}".format(n - i), bn, False,
                             moving, None)
         scope = "X_TILDE/"
@@ -281,7 +286,7 @@ def vae_forward(cfg, params, moving, x, t, eps, training, warm_up_weight=1.0,
     L = cfg.latent_size
 
     h = x
-    for i in range(n):
+    for i in range(n if cfg.inference_architecture == "MLP" else 0):
         h = dense_layer(h, params, "ENCODER/{}".format(i + 1), bn, training,
                         moving, new_moving)
     mu = dense_layer(h, params, "POSTERIOR/MU", False, training, moving,
@@ -303,7 +308,7 @@ def vae_forward(cfg, params, moving, x, t, eps, training, warm_up_weight=1.0,
     d = z.reshape(S * B, L)
     if decoder_extra is not None:   # tf.tile(extra, [S, 1]); tf.concat
         d = torch.cat([d, decoder_extra.repeat(S, 1)], dim=1)
-    for i in range(n):
+    for i in range(n if cfg.generative_architecture == "MLP" else 0):
         d = dense_layer(d, params, "DECODER/{}".format(n - i), bn, training,
                         moving, new_moving)
     log_prob, mean_variance = _decoder_distribution(

@@ -42,6 +42,7 @@ class ModelConfig(Structure):
         ("free_nats_proportion", c_float),
         ("k_max", c_int32),
         ("prior_mode", c_int32),
+        ("linear_factor", c_int32),
         ("decoder_extra", c_int32),
     ]
 

@@ -27,7 +27,9 @@ static int build_vae(scvae_plan* p) {
   Layout& L = p->layout;
   int n_in = c.feature_size;
   char scope[64];
-  for (int i = 0; i < c.n_hidden; ++i) {
+  const int n_enc = (c.linear_factor & 1) ? 0 : c.n_hidden;   // LFM: no hidden layers on that side
+  const int n_dec = (c.linear_factor & 2) ? 0 : c.n_hidden;
+  for (int i = 0; i < n_enc; ++i) {
     snprintf(scope, sizeof scope, "ENCODER/%d", i + 1);
     p->enc.push_back(L.dense(scope, n_in, c.hidden[i], bn));
     n_in = c.hidden[i];
@@ -37,7 +39,7 @@ static int build_vae(scvae_plan* p) {
   p->ls = L.dense("POSTERIOR/LOG_SIGMA", n_in, c.latent_size, false);
   n_in = c.latent_size + c.decoder_extra;   // decoder input [z | batch one-hot | count sum]
   // dense_layers(reverse_order=True): sizes reversed, scopes numbered n..1 (mu:102-105)
-  for (int i = 0; i < c.n_hidden; ++i) {
+  for (int i = 0; i < n_dec; ++i) {
     const int h = c.hidden[c.n_hidden - 1 - i];
     snprintf(scope, sizeof scope, "DECODER/%d", c.n_hidden - i);
     p->dec.push_back(L.dense(scope, n_in, h, bn));
@@ -98,8 +100,8 @@ static size_t carve(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_
   float* dls = b.floats(B * Lz);
   float* mov = b.floats(B * F);
   float* vom = b.floats(B * F);
-  const int hn = c.n_hidden ? c.hidden[c.n_hidden - 1] : c.feature_size;
-  const int h1 = c.n_hidden ? c.hidden[0] : c.latent_size;
+  const int hn = p->enc.empty() ? c.feature_size : p->enc.back().n_out;
+  const int h1 = p->heads[0].n_in;
   track(B, Lz, hn); track(hn, Lz, B); track(B, hn, Lz);
   track(R, F, h1); track(h1, F, R); track(R, h1, F);
   if (c.k_max > 0) {
@@ -529,7 +531,9 @@ int scvae_plan_create(const scvae_model_config* cfg, scvae_plan** out) {
   SCVAE_ARG(cfg->prior_mode >= 0 && cfg->prior_mode <= 2);
   SCVAE_ARG(cfg->prior_mode == 0 || cfg->model_type == SCVAE_MODEL_GMVAE);
   SCVAE_ARG(cfg->k_max == 0 || cfg->likelihood == SCVAE_POISSON || cfg->likelihood == SCVAE_NB);
-  SCVAE_ARG(cfg->decoder_extra == 0 || cfg->n_hidden > 0);
+  SCVAE_ARG(cfg->linear_factor >= 0 && cfg->linear_factor <= 3);
+  SCVAE_ARG(cfg->linear_factor == 0 || cfg->model_type == SCVAE_MODEL_VAE);
+  SCVAE_ARG(cfg->decoder_extra == 0 || (cfg->n_hidden > 0 && !(cfg->linear_factor & 2)));
   scvae_plan* p = new scvae_plan();
   p->cfg = *cfg;
   p->P = scvae::likelihood_heads(cfg->likelihood);

@@ -40,7 +40,8 @@ class Engine:
                  kl_weight=1.0, free_nats_proportion=0.0, device=None,
                  seed=0, decoder_extra=0, k_max=0,
                  prior_probabilities_method="uniform",
-                 prior_probabilities=None):
+                 prior_probabilities=None, inference_architecture="MLP",
+                 generative_architecture="MLP"):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError(
@@ -85,6 +86,9 @@ class Engine:
         cfg.k_max = self.k_max
         cfg.prior_mode = {"uniform": 0, "custom": 1, "learn": 2}[
             prior_probabilities_method]
+        cfg.linear_factor = (
+            (1 if inference_architecture.upper() == "LFM" else 0)
+            | (2 if generative_architecture.upper() == "LFM" else 0))
         self.config = cfg
 
         handle = ctypes.c_void_p()

@@ -181,10 +181,12 @@ class VariationalAutoencoder(ModelBase):
                 "multinomial)", "va:2400-2433")
         if self.dropout_parts:
             raise mu.not_in_this_build("Dropout", "mu:45-50")
-        if (self.inference_architecture != "MLP"
-                or self.generative_architecture != "MLP"):
-            raise mu.not_in_this_build(
-                "Linear-factor-model architectures", "va:2233-2239")
+        for architecture in (self.inference_architecture,
+                             self.generative_architecture):
+            if architecture not in ("MLP", "LFM"):
+                raise ValueError(
+                    "The architectures can only be a neural network (MLP) "
+                    "or a linear factor model (LFM).")
         if self.parameterise_latent_posterior:
             raise mu.not_in_this_build(
                 "Parameterised latent posterior", "va:2332-2344")
@@ -208,7 +210,9 @@ class VariationalAutoencoder(ModelBase):
             likelihood=self.reconstruction_distribution_name,
             batch_norm=bool(self.minibatch_normalisation), model_type="VAE",
             kl_weight=self.kl_weight_value,
-            decoder_extra=self.decoder_extra_size, k_max=self.k_max)
+            decoder_extra=self.decoder_extra_size, k_max=self.k_max,
+            inference_architecture=self.inference_architecture,
+            generative_architecture=self.generative_architecture)
 
     def _parameter_shapes(self):
         table = []
@@ -221,13 +225,15 @@ class VariationalAutoencoder(ModelBase):
             if with_bn:
                 table.append((scope + "/BATCH_NORM/beta", (n_out,)))
         n_in = self.feature_size
-        for i, h in enumerate(H):
+        for i, h in enumerate(H if self.inference_architecture == "MLP"
+                              else []):
             dense("ENCODER/{}".format(i + 1), n_in, h, bn)
             n_in = h
         dense("POSTERIOR/MU", n_in, self.latent_size, False)
         dense("POSTERIOR/LOG_SIGMA", n_in, self.latent_size, False)
         n_in = self.latent_size + self.decoder_extra_size
-        for i, h in enumerate(H[::-1]):
+        for i, h in enumerate(H[::-1] if self.generative_architecture == "MLP"
+                              else []):
             dense("DECODER/{}".format(len(H) - i), n_in, h, bn)
             n_in = h
         for parameter in self.reconstruction_distribution["parameters"]:

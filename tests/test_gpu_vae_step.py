@@ -171,3 +171,48 @@ def test_model_without_hidden_layers(cuda_device, likelihood):
     _close(sc[0], out["lower_bound"], what="lower_bound")
     for name, g in eng.named_gradients().items():
         _close(g.cpu(), grads[name], rtol=2e-4, what="grad " + name)
+
+
+@pytest.mark.parametrize("inference,generative", [("LFM", "MLP"), ("MLP", "LFM"),
+                                                  ("LFM", "LFM")])
+def test_linear_factor_architectures(cuda_device, inference, generative):
+    """``inference_architecture`` / ``generative_architecture`` = "LFM": the
+    hidden layers of that side are not built (va:2233-2234, 2456-2457)."""
+    from scvae_amd.engine import Engine
+    F, L, H, B = 50, 6, (14, 12), 19
+    eng = Engine(F, L, H, "negative binomial", batch_norm=True,
+                 device=cuda_device, seed=0, inference_architecture=inference,
+                 generative_architecture=generative)
+    g = torch.Generator().manual_seed(1)
+    for name, p in eng.named_parameters().items():
+        if not name.endswith("weights"):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    cfg = om.ModelConfig(feature_size=F, latent_size=L, hidden_sizes=H,
+                         likelihood="negative binomial",
+                         inference_architecture=inference,
+                         generative_architecture=generative)
+    params = {k: v.detach().cpu().double()
+              for k, v in eng.named_parameters().items()}
+    assert list(params) == list(om.vae_parameter_shapes(cfg))
+    assert any("ENCODER" in k for k in params) == (inference == "MLP")
+    assert any("DECODER" in k for k in params) == (generative == "MLP")
+    moving = {k: v.detach().cpu().double()
+              for k, v in eng.named_moving_statistics().items()}
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(_counts(rng, B, F))
+    eps = torch.from_numpy(rng.standard_normal((1, B, L)))
+    sc = eng.step(x.float().to(cuda_device), x.float().to(cuda_device),
+                  eps=eps.float().to(cuda_device), training=True).cpu().numpy()
+    out, grads = om.gradients(
+        lambda p: om.vae_forward(cfg, p, moving, x, x, eps, True), params)
+    _close(sc[0], out["lower_bound"], what="lower_bound")
+    for name, g in eng.named_gradients().items():
+        if name.endswith("DENSE/biases") and ("ENCODER/" in name
+                                              or "DECODER/" in name):
+            continue
+        _close(g.cpu(), grads[name], rtol=2e-4, what="grad " + name)
+    z = torch.from_numpy(rng.standard_normal((5, L)))
+    moving = {k: v.detach().cpu().double()    # updated by the training step
+              for k, v in eng.named_moving_statistics().items()}
+    _close(eng.decode(z.float().to(cuda_device)).cpu(),
+           om.decode_mean(cfg, params, moving, z), rtol=2e-4, what="decode")
