@@ -17,6 +17,8 @@
 // count matrix) are compacted per wave with ballots into a wave-private LDS queue, so that the
 // expensive code runs once per wave on dense lanes instead of four times on sparse lanes; no
 // LDS atomics, summation order fixed (deterministic).
+#include <type_traits>
+
 #include "common.hpp"
 #include "kernels.hpp"
 #include "likelihood.hpp"
@@ -290,7 +292,9 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
     // ============ VALU slot: likelihood epilogue of tile k ============
     // 2 rows x 2 columns per thread (one 128-byte row segment per half wave: coalesced t loads,
     // conflict-free LDS accesses with the odd stride); G_j written in place of pre_j
-    if (live) {
+    // (full tiles take the copy without the row / column bound checks)
+    auto epilogue = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
       const int tq = opaque(th);
       const int lane = tq & 63;
       const int ec = tq & 31, er0 = tq >> 5;
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
       for (int e = 0; e < 4; ++e) {
         const int ri = e >> 1, ci = e & 1;
         const int row = er0 + 16 * ri, c = ec + 32 * ci;
-        const bool ok = (m0 + row < R) && (c0 + c < F);
+        const bool ok = FULL || ((m0 + row < R) && (c0 + c < F));
         const float tval = tv[e];
         float a[P], g[P], lp, r, rgate;
 #pragma unroll
@@ -368,8 +372,12 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
 #pragma unroll
         for (int off = 1; off < 32; off <<= 1) s += __shfl_xor(s, off, WAVE);
         const int grow = m0 + er0 + 16 * ri;
-        if (ec == 0 && grow < R) ll_part[(size_t)blockIdx.x * R + grow] = s;
+        if (ec == 0 && (FULL || grow < R)) ll_part[(size_t)blockIdx.x * R + grow] = s;
       }
+        };
+    if (live) {
+      if (m0 + BM <= R && c0 + BN <= F) epilogue(std::true_type{});
+      else epilogue(std::false_type{});
     }
     lds_barrier();
     lds_barrier();
