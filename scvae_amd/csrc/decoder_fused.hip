@@ -27,6 +27,8 @@
 // (the H dimension of GEMM2/GEMM3 is padded to the 32-wide MFMA tile).
 // decoder_fused2.hip holds a second schedule of the same phases (two pipelined half workgroups),
 // which the dispatcher below prefers where it fits.
+#include <type_traits>
+
 #include "common.hpp"
 #include "kernels.hpp"
 #include "likelihood.hpp"
@@ -223,85 +225,92 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
       //      the negative-binomial kinds are compacted per wave (ballots) into a wave-private
       //      queue for the correction lgamma(r+t)-lgamma(r) / digamma(r+t)-digamma(r), so that
       //      the expensive code runs on dense lanes (5 % of a count matrix is non-zero) ----
-      const int tq = df_opaque(tid);
-      const int ln = tq & 63;
-      const int ec = tq & 31, er0 = tq >> 5;
-      float* q0 = qbase + (tq >> 6) * 4 * DF_QCAP;                    // r -> A
-      float* q1 = q0 + DF_QCAP;                                       // t
-      float* q2 = q1 + DF_QCAP;                                       // upstream * gate
-      int* q3 = reinterpret_cast<int*>(q2 + DF_QCAP);                 // LDS offset row*LD + col
-      float lsum[RI];
-      int slot[EPT];
-      int q_n = 0;
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        const int ri = e >> 1, ci = e & 1;
-        const int row = er0 + 16 * ri, c = ec + 32 * ci;
-        const bool ok = (m0 + row < R) && (c0 + c < F);
-        const float tval = tv[e];
-        float a[P], g[P], lp, r, rgate;
-#pragma unroll
-        for (int j = 0; j < P; ++j) a[j] = Gs[(j * BM + row) * LD + c];
-        lik_dense<KIND, TRAIN>(tval, a, lp, g, r, rgate);
-        const bool nz = ok && tval > 0.f;
-        slot[e] = -1;
-        if (Traits::HAS_R) {
-          const unsigned long long mask = __ballot(nz);
-          if (nz) {
-            const int s = q_n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-            if (s < DF_QCAP) {
-              slot[e] = s;
-              q0[s] = r;
-              q1[s] = tval;
-              q2[s] = up[ri] * rgate;
-              q3[s] = row * LD + c;
-            } else {   // queue full (dense data): correct in place
-              float A, D;
-              lgamma_digamma_diff<TRAIN>(r, tval, A, D);
-              lp += A;
-              if (TRAIN) g[P - 1] += rgate * r * D;
-              if (inline_lgamma) lp -= lgamma1p(tval);
+      // (full tiles take the copy without the row / column bound checks)
+      auto epilogue = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int tq = df_opaque(tid);
+        const int ln = tq & 63;
+        const int ec = tq & 31, er0 = tq >> 5;
+        float* q0 = qbase + (tq >> 6) * 4 * DF_QCAP;                    // r -> A
+        float* q1 = q0 + DF_QCAP;                                       // t
+        float* q2 = q1 + DF_QCAP;                                       // upstream * gate
+        int* q3 = reinterpret_cast<int*>(q2 + DF_QCAP);                 // LDS offset row*LD + col
+        float lsum[RI];
+        int slot[EPT];
+        int q_n = 0;
+  #pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const int ri = e >> 1, ci = e & 1;
+          const int row = er0 + 16 * ri, c = ec + 32 * ci;
+          const bool ok = FULL || ((m0 + row < R) && (c0 + c < F));
+          const float tval = tv[e];
+          float a[P], g[P], lp, r, rgate;
+  #pragma unroll
+          for (int j = 0; j < P; ++j) a[j] = Gs[(j * BM + row) * LD + c];
+          lik_dense<KIND, TRAIN>(tval, a, lp, g, r, rgate);
+          const bool nz = ok && tval > 0.f;
+          slot[e] = -1;
+          if (Traits::HAS_R) {
+            const unsigned long long mask = __ballot(nz);
+            if (nz) {
+              const int s = q_n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+              if (s < DF_QCAP) {
+                slot[e] = s;
+                q0[s] = r;
+                q1[s] = tval;
+                q2[s] = up[ri] * rgate;
+                q3[s] = row * LD + c;
+              } else {   // queue full (dense data): correct in place
+                float A, D;
+                lgamma_digamma_diff<TRAIN>(r, tval, A, D);
+                lp += A;
+                if (TRAIN) g[P - 1] += rgate * r * D;
+                if (inline_lgamma) lp -= lgamma1p(tval);
+              }
             }
+            q_n += __popcll(mask);
+          } else if (nz && inline_lgamma) {
+            lp -= lgamma1p(tval);
           }
-          q_n += __popcll(mask);
-        } else if (nz && inline_lgamma) {
-          lp -= lgamma1p(tval);
+          if (ci == 0) lsum[ri] = ok ? lp : 0.f;
+          else lsum[ri] += ok ? lp : 0.f;
+          if (TRAIN) {
+  #pragma unroll
+            for (int j = 0; j < P; ++j) Gs[(j * BM + row) * LD + c] = ok ? up[ri] * g[j] : 0.f;
+          }
+          asm volatile("" ::: "memory");   // one element at a time: keeps the register peak low
         }
-        if (ci == 0) lsum[ri] = ok ? lp : 0.f;
-        else lsum[ri] += ok ? lp : 0.f;
-        if (TRAIN) {
-#pragma unroll
-          for (int j = 0; j < P; ++j) Gs[(j * BM + row) * LD + c] = ok ? up[ri] * g[j] : 0.f;
+        if (Traits::HAS_R) {
+          df_wave_fence();
+          const int n_q = min(q_n, DF_QCAP);
+          for (int s = ln; s < n_q; s += 64) {
+            const float r = q0[s], tval = q1[s];
+            float A, D;
+            lgamma_digamma_diff<TRAIN>(r, tval, A, D);
+            if (inline_lgamma) A -= lgamma1p(tval);
+            q0[s] = A;
+            if (TRAIN) Gs[(P - 1) * BM * LD + q3[s]] += q2[s] * r * D;
+          }
+          df_wave_fence();
+  #pragma unroll
+          for (int e = 0; e < EPT; ++e)
+            if (slot[e] >= 0) lsum[e >> 1] += q0[slot[e]];
+          df_wave_fence();   // the queue is reused in the next step
         }
-        asm volatile("" ::: "memory");   // one element at a time: keeps the register peak low
-      }
-      if (Traits::HAS_R) {
-        df_wave_fence();
-        const int n_q = min(q_n, DF_QCAP);
-        for (int s = ln; s < n_q; s += 64) {
-          const float r = q0[s], tval = q1[s];
-          float A, D;
-          lgamma_digamma_diff<TRAIN>(r, tval, A, D);
-          if (inline_lgamma) A -= lgamma1p(tval);
-          q0[s] = A;
-          if (TRAIN) Gs[(P - 1) * BM * LD + q3[s]] += q2[s] * r * D;
+        // ---- per-row partial log-likelihood of this strip ----
+  #pragma unroll
+        for (int ri = 0; ri < RI; ++ri) {
+          float sum = lsum[ri];
+  #pragma unroll
+          for (int off = 1; off < 32; off <<= 1) sum += __shfl_xor(sum, off, WAVE);
+          const int grow = m0 + er0 + 16 * ri;
+          if (ec == 0 && (FULL || grow < R)) ll_part[(size_t)blockIdx.x * R + grow] = sum;
         }
-        df_wave_fence();
-#pragma unroll
-        for (int e = 0; e < EPT; ++e)
-          if (slot[e] >= 0) lsum[e >> 1] += q0[slot[e]];
-        df_wave_fence();   // the queue is reused in the next step
-      }
-      // ---- per-row partial log-likelihood of this strip ----
-#pragma unroll
-      for (int ri = 0; ri < RI; ++ri) {
-        float sum = lsum[ri];
-#pragma unroll
-        for (int off = 1; off < 32; off <<= 1) sum += __shfl_xor(sum, off, WAVE);
-        const int grow = m0 + er0 + 16 * ri;
-        if (ec == 0 && grow < R) ll_part[(size_t)blockIdx.x * R + grow] = sum;
-      }
+      };
+      if (m0 + BM <= R && c0 + BN <= F) epilogue(std::true_type{});
+      else epilogue(std::false_type{});
+      const int tq = df_opaque(tid);
       // next step's operands: d tile -> the other LDS buffer, t / upstream -> registers
       if (store_early) store_d(m0 + BM, buf ^ (d_buffers - 1), tq);
       if (m0 + BM < R) load_t(m0 + BM, tq);
