@@ -67,6 +67,11 @@ typedef struct scvae_model_config {
   int32_t decoder_extra;      /* E: extra decoder input columns appended to z -- one-hot batch
                                  indices (batch_correction) and/or the normalised count sum
                                  (use_count_sum_as_feature), va:2407-2441, gm:3094-3130 */
+  int32_t latent_mode;        /* VAE: bit 0 Monte-Carlo KL term, log q(z|x) - log p(z) at the
+                                 samples (analytical_kl_term == False, va:2633-2640; the GMVAE's
+                                 KL(z) is always of that form); bit 1 latent_distribution ==
+                                 "unit-variance gaussian" (du:323-337): the posterior's log_sigma
+                                 is the constant 0 and POSTERIOR/LOG_SIGMA is not built */
 } scvae_model_config;
 
 typedef struct scvae_plan scvae_plan; /* opaque */

@@ -68,6 +68,12 @@ class ModelConfig:
     # piecewise categorical likelihood (-k): counts below k_max are classes of
     # a categorical head P_K, va:2507-2532 (0 = off)
     k_max: int = 0
+    # VAE latent part, du:309-338: "gaussian" or "unit-variance gaussian" (the
+    # posterior's log_sigma is the constant 0.0, no POSTERIOR/LOG_SIGMA
+    # layer); analytical_kl_term (va:186-192, 2624-2640): closed-form
+    # KL(q||p), else log q(z|x) - log p(z) evaluated at the samples
+    latent_distribution: str = "gaussian"
+    analytical_kl_term: bool = True
 
     @property
     def heads(self):
@@ -97,8 +103,9 @@ def vae_parameter_shapes(cfg):
         shapes += _dense_entries("ENCODER/{}".format(i + 1), n_in, h, bn)
         n_in = h
     shapes += _dense_entries("POSTERIOR/MU", n_in, cfg.latent_size, False)
-    shapes += _dense_entries("POSTERIOR/LOG_SIGMA", n_in, cfg.latent_size,
-                             False)
+    if cfg.latent_distribution != "unit-variance gaussian":
+        shapes += _dense_entries("POSTERIOR/LOG_SIGMA", n_in, cfg.latent_size,
+                                 False)
     n_in = cfg.latent_size + cfg.decoder_extra_size
     # reverse_order=True: sizes reversed, scopes numbered n..1
     for i, h in enumerate(H[::-1] if cfg.generative_architecture == "MLP"
@@ -275,7 +282,7 @@ def decode_mean(cfg, params, moving, z, model_type="VAE"):
 # --------------------------------------------------------------------------
 
 def vae_forward(cfg, params, moving, x, t, eps, training, warm_up_weight=1.0,
-                new_moving=None, deterministic_z=False, analytical_kl=True,
+                new_moving=None, deterministic_z=False, analytical_kl=None,
                 evaluation_statistics=False, decoder_extra=None):
     """One graph execution.  ``eps``: [S, B, L] standard-normal draws
     (S = n_iw * n_mc, IW-major) or None with ``deterministic_z``."""
@@ -292,10 +299,16 @@ def vae_forward(cfg, params, moving, x, t, eps, training, warm_up_weight=1.0,
     mu = dense_layer(h, params, "POSTERIOR/MU", False, training, moving,
                      None, activation=False)
     mu = torch.clamp(mu, -FLOAT32_MAX_HALF, FLOAT32_MAX_HALF)
-    log_sigma = dense_layer(h, params, "POSTERIOR/LOG_SIGMA", False, training,
-                            moving, None, activation=False)
-    log_sigma = torch.clamp(log_sigma, -3.0, 3.0)
+    if cfg.latent_distribution == "unit-variance gaussian":
+        # a constant parameter skips the layer and its clip (va:2253-2265)
+        log_sigma = torch.zeros_like(mu)
+    else:
+        log_sigma = dense_layer(h, params, "POSTERIOR/LOG_SIGMA", False,
+                                training, moving, None, activation=False)
+        log_sigma = torch.clamp(log_sigma, -3.0, 3.0)
     sigma = torch.exp(log_sigma)
+    if analytical_kl is None:
+        analytical_kl = cfg.analytical_kl_term
 
     if deterministic_z:
         n_iw, n_mc = 1, 1

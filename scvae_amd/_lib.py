@@ -44,6 +44,7 @@ class ModelConfig(Structure):
         ("prior_mode", c_int32),
         ("linear_factor", c_int32),
         ("decoder_extra", c_int32),
+        ("latent_mode", c_int32),
     ]
 
 

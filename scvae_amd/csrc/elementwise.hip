@@ -380,94 +380,144 @@ int sqrt_sum(hipStream_t stream, const float* a, const float* b, float* out, siz
 
 // ============================ Gaussian latent =============================
 
-// one workgroup (64*ceil(L/64) threads) per cell b
+// one workgroup (64*ceil(L/64) threads) per cell b.  ls_pre == nullptr: the posterior's
+// log_sigma is the constant 0 ("unit-variance gaussian", du:323-337).  kl_sample != nullptr:
+// Monte-Carlo KL (va:2633-2640), log q(z|x) - log p(z) at every sample,
+//   kl[s,b,l] = (z^2 - eps^2) / 2 - log sigma,   kl_sample[s*B + b] = sum_l kl[s,b,l],
+// and kl_elem[b,l] = mean_s kl[s,b,l] (so that its column mean is kl_divergence_neurons).
 __global__ void gauss_latent_fwd_kernel(const float* __restrict__ mu_pre,
                                         const float* __restrict__ ls_pre,
                                         const float* __restrict__ eps, float* __restrict__ z,
                                         float* __restrict__ kl_elem, float* __restrict__ kl_cell,
-                                        int S, int B, int L, int deterministic) {
+                                        float* __restrict__ kl_sample, int S, int B, int L,
+                                        int deterministic) {
   __shared__ float red[16];
   const int b = blockIdx.x, l = threadIdx.x;
-  float kl = 0.f;
-  if (l < L) {
-    const size_t i = (size_t)b * L + l;
-    const float mu = fminf(fmaxf(mu_pre[i], -F32_MAX_HALF), F32_MAX_HALF);
-    const float ls = fminf(fmaxf(ls_pre[i], -3.f), 3.f);
-    const float sigma = __expf(ls);
-    if (deterministic) {
-      z[i] = mu;
-    } else {
-      for (int s = 0; s < S; ++s) {
-        const size_t o = ((size_t)s * B + b) * L + l;
-        z[o] = fmaf(sigma, eps[o], mu);
-      }
-    }
-    kl = 0.5f * (mu * mu + sigma * sigma - 1.f) - ls;
-    kl_elem[i] = kl;
-  }
-  // block reduction over L (blockDim.x is a multiple of 64, <= 1024)
-  kl = wave_sum(kl);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  if (lane == 0) red[w] = kl;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float s = 0.f;
-    for (int i = 0; i < nw; ++i) s += red[i];
-    kl_cell[b] = s;
+  const bool live = l < L;
+  const size_t i = (size_t)b * L + (live ? l : 0);
+  const float mu = fminf(fmaxf(mu_pre[i], -F32_MAX_HALF), F32_MAX_HALF);
+  const float ls = ls_pre ? fminf(fmaxf(ls_pre[i], -3.f), 3.f) : 0.f;
+  const float sigma = ls_pre ? __expf(ls) : 1.f;
+  if (kl_sample == nullptr) {
+    float kl = 0.f;
+    if (live) {
+      if (deterministic) {
+        z[i] = mu;
+      } else {
+        for (int s = 0; s < S; ++s) {
+          const size_t o = ((size_t)s * B + b) * L + l;
+          z[o] = fmaf(sigma, eps[o], mu);
+        }
+      }
+      kl = 0.5f * (mu * mu + sigma * sigma - 1.f) - ls;
+      kl_elem[i] = kl;
+    }
+    // block reduction over L (blockDim.x is a multiple of 64, <= 1024)
+    kl = wave_sum(kl);
+    if (lane == 0) red[w] = kl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float s = 0.f;
+      for (int q = 0; q < nw; ++q) s += red[q];
+      kl_cell[b] = s;
+    }
+    return;
   }
+  float mean_kl = 0.f;
+  for (int s = 0; s < S; ++s) {
+    float kl = 0.f;
+    if (live) {
+      const size_t o = ((size_t)s * B + b) * L + l;
+      const float e = deterministic ? 0.f : eps[o];
+      const float zz = fmaf(sigma, e, mu);
+      z[o] = zz;
+      kl = 0.5f * (zz * zz - e * e) - ls;
+      mean_kl += kl;
+    }
+    kl = wave_sum(kl);
+    if (nw > 1) {
+      __syncthreads();
+      if (lane == 0) red[w] = kl;
+      __syncthreads();
+      kl = 0.f;
+      for (int q = 0; q < nw; ++q) kl += red[q];
+    }
+    if (threadIdx.x == 0) kl_sample[(size_t)s * B + b] = kl;
+  }
+  if (live) kl_elem[i] = mean_kl / (float)S;
 }
 
 int gauss_latent_fwd(hipStream_t stream, const float* mu_pre, const float* ls_pre,
-                     const float* eps, float* z, float* kl_elem, float* kl_cell, int S, int B,
-                     int L, int deterministic) {
-  SCVAE_ARG(mu_pre && ls_pre && z && kl_elem && kl_cell);
+                     const float* eps, float* z, float* kl_elem, float* kl_cell,
+                     float* kl_sample, int S, int B, int L, int deterministic) {
+  SCVAE_ARG(mu_pre && z && kl_elem && (kl_cell || kl_sample));
   SCVAE_ARG(deterministic || eps);
   SCVAE_ARG(L > 0 && L <= 1024 && S > 0);
   if (B == 0) return 0;
   const int threads = (L + 63) / 64 * 64;
   hipLaunchKernelGGL(gauss_latent_fwd_kernel, dim3(B), dim3(threads), 0, stream, mu_pre, ls_pre,
-                     eps, z, kl_elem, kl_cell, S, B, L, deterministic);
+                     eps, z, kl_elem, kl_cell, kl_sample, S, B, L, deterministic);
   SCVAE_LAUNCH_CHECK("gauss_latent_fwd_kernel");
   return 0;
 }
 
+// Analytic KL (kl_gw == nullptr): d loss / d KL_cell = kl_coeff for every cell.  Monte-Carlo KL:
+// d loss / d kl[s,b] = c_sb = -kl_coeff * kl_gw[s*B + b] (kl_gw = d loss / d log p(x|z) of the
+// row, kl_coeff = the KL weight), and with dz' = dz + c_sb * z
+//   d mu = sum_s dz',   d log_sigma = sigma * sum_s dz' * eps - sum_s c_sb.
 __global__ void gauss_latent_bwd_kernel(const float* __restrict__ mu_pre,
                                         const float* __restrict__ ls_pre,
                                         const float* __restrict__ eps,
                                         const float* __restrict__ dz, float kl_coeff,
+                                        const float* __restrict__ kl_gw,
                                         float* __restrict__ dmu_pre, float* __restrict__ dls_pre,
                                         int S, int B, int L) {
   const size_t n = (size_t)B * L;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x) {
-    const float mp = mu_pre[i], lp = ls_pre[i];
+    const float mp = mu_pre[i], lp = ls_pre ? ls_pre[i] : 0.f;
     const float mu = fminf(fmaxf(mp, -F32_MAX_HALF), F32_MAX_HALF);
     const float ls = fminf(fmaxf(lp, -3.f), 3.f);
-    const float sigma = __expf(ls);
-    float gz = 0.f, gze = 0.f;
+    const float sigma = ls_pre ? __expf(ls) : 1.f;
+    const size_t b = i / (size_t)L;
+    float gz = 0.f, gze = 0.f, csum = 0.f;
     for (int s = 0; s < S; ++s) {
       const size_t o = (size_t)s * n + i;
-      const float d = dz[o];
+      const float e = eps[o];
+      float d = dz[o];
+      if (kl_gw) {
+        const float c = -kl_coeff * kl_gw[(size_t)s * B + b];
+        d = fmaf(c, fmaf(sigma, e, mu), d);
+        csum += c;
+      }
       gz += d;
-      gze += d * eps[o];
+      gze += d * e;
     }
-    const float gmu = gz + kl_coeff * mu;
-    const float gls = gze * sigma + kl_coeff * (sigma * sigma - 1.f);
+    float gmu, gls;
+    if (kl_gw) {
+      gmu = gz;
+      gls = gze * sigma - csum;
+    } else {
+      gmu = gz + kl_coeff * mu;
+      gls = gze * sigma + kl_coeff * (sigma * sigma - 1.f);
+    }
     dmu_pre[i] = (mp >= -F32_MAX_HALF && mp <= F32_MAX_HALF) ? gmu : 0.f;
-    dls_pre[i] = (lp >= -3.f && lp <= 3.f) ? gls : 0.f;
+    if (dls_pre) dls_pre[i] = (lp >= -3.f && lp <= 3.f) ? gls : 0.f;
   }
 }
 
 int gauss_latent_bwd(hipStream_t stream, const float* mu_pre, const float* ls_pre,
-                     const float* eps, const float* dz, float kl_coeff, float* dmu_pre,
-                     float* dls_pre, int S, int B, int L) {
-  SCVAE_ARG(mu_pre && ls_pre && eps && dz && dmu_pre && dls_pre);
+                     const float* eps, const float* dz, float kl_coeff, const float* kl_gw,
+                     float* dmu_pre, float* dls_pre, int S, int B, int L) {
+  SCVAE_ARG(mu_pre && eps && dz && dmu_pre);
+  SCVAE_ARG((ls_pre == nullptr) == (dls_pre == nullptr));
   if (B == 0) return 0;
   const size_t n = (size_t)B * L;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(gauss_latent_bwd_kernel, dim3(blocks), dim3(256), 0, stream, mu_pre, ls_pre,
-                     eps, dz, kl_coeff, dmu_pre, dls_pre, S, B, L);
+                     eps, dz, kl_coeff, kl_gw, dmu_pre, dls_pre, S, B, L);
   SCVAE_LAUNCH_CHECK("gauss_latent_bwd_kernel");
   return 0;
 }
@@ -477,8 +527,9 @@ int gauss_latent_bwd(hipStream_t stream, const float* mu_pre, const float* ls_pr
 // single workgroup; ll index = (r*n_mc + m)*B + b.  row_scale = 1/(n_mc*B_global)
 // lets a data-parallel rank emit its share of the global means (summed by all-reduce).
 __global__ __launch_bounds__(1024) void vae_elbo_kernel(const float* __restrict__ ll,
-                                                       const float* __restrict__ kl_cell, int n_iw,
-                                                       int n_mc, int B, float w, float row_scale,
+                                                       const float* __restrict__ kl_cell,
+                                                       int kl_per_sample, int n_iw, int n_mc,
+                                                       int B, float w, float row_scale,
                                                        float* __restrict__ scalars,
                                                        float* __restrict__ gw) {
   __shared__ float red[16];
@@ -488,18 +539,23 @@ __global__ __launch_bounds__(1024) void vae_elbo_kernel(const float* __restrict_
   const int step_m = 1024 / B, step_b = 1024 % B;
   int m = threadIdx.x / B, b = threadIdx.x % B;
   for (int i = threadIdx.x; i < pairs; i += 1024) {
-    const float kl = kl_cell[b];
-    if (m == 0) klsum += kl;
+    // analytic KL: one value per cell; Monte-Carlo KL: one per sample row (va:2656)
+    float kl = kl_cell[b];
+    if (!kl_per_sample && m == 0) klsum += kl;
     float mx = -INFINITY, mxw = -INFINITY;
     for (int r = 0; r < n_iw; ++r) {
-      const float v = ll[((size_t)r * n_mc + m) * B + b];
+      const size_t o = ((size_t)r * n_mc + m) * B + b;
+      const float v = ll[o];
+      if (kl_per_sample) { kl = kl_cell[o]; klsum += kl; }
       rec += v;
       mx = fmaxf(mx, v - kl);
       mxw = fmaxf(mxw, v - w * kl);
     }
     float se = 0.f, sew = 0.f;
     for (int r = 0; r < n_iw; ++r) {
-      const float v = ll[((size_t)r * n_mc + m) * B + b];
+      const size_t o = ((size_t)r * n_mc + m) * B + b;
+      const float v = ll[o];
+      if (kl_per_sample) kl = kl_cell[o];
       se += __expf(v - kl - mx);
       sew += __expf(v - w * kl - mxw);
     }
@@ -509,6 +565,7 @@ __global__ __launch_bounds__(1024) void vae_elbo_kernel(const float* __restrict_
     if (gw != nullptr) {
       for (int r = 0; r < n_iw; ++r) {
         const size_t o = ((size_t)r * n_mc + m) * B + b;
+        if (kl_per_sample) kl = kl_cell[o];
         gw[o] = -__expf(ll[o] - w * kl - mxw) / sew * row_scale;
       }
     }
@@ -523,15 +580,16 @@ __global__ __launch_bounds__(1024) void vae_elbo_kernel(const float* __restrict_
     scalars[0] = lb * row_scale;
     scalars[1] = lbw * row_scale;
     scalars[2] = rec * row_scale / (float)n_iw;
-    scalars[3] = klsum * row_scale * (float)n_mc;
+    scalars[3] = kl_per_sample ? klsum * row_scale / (float)n_iw : klsum * row_scale * (float)n_mc;
   }
 }
 
-int vae_elbo(hipStream_t stream, const float* ll, const float* kl_cell, int n_iw, int n_mc, int B,
-             float kl_weight_total, float row_scale, float* scalars, float* gw) {
+int vae_elbo(hipStream_t stream, const float* ll, const float* kl_cell, int kl_per_sample,
+             int n_iw, int n_mc, int B, float kl_weight_total, float row_scale, float* scalars,
+             float* gw) {
   SCVAE_ARG(ll && kl_cell && scalars && n_iw > 0 && n_mc > 0 && B > 0);
-  hipLaunchKernelGGL(vae_elbo_kernel, dim3(1), dim3(1024), 0, stream, ll, kl_cell, n_iw, n_mc, B,
-                     kl_weight_total, row_scale, scalars, gw);
+  hipLaunchKernelGGL(vae_elbo_kernel, dim3(1), dim3(1024), 0, stream, ll, kl_cell, kl_per_sample,
+                     n_iw, n_mc, B, kl_weight_total, row_scale, scalars, gw);
   SCVAE_LAUNCH_CHECK("vae_elbo_kernel");
   return 0;
 }

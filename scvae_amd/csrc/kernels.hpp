@@ -50,17 +50,21 @@ int loglik_elementwise(hipStream_t stream, int kind, const float* t, HeadPtrs pr
                        float* mean, float* var, size_t n);
 int sqrt_sum(hipStream_t stream, const float* a, const float* b, float* out, size_t n);
 
-// Gaussian posterior: clip, reparameterise, analytic KL (va:2266-2289, 2346-2369, 2624-2656)
+// Gaussian posterior: clip, reparameterise, KL (va:2266-2289, 2346-2369, 2624-2656).
+// kl_sample / kl_gw non-null: Monte-Carlo KL per sample row (va:2633-2640), else analytic per
+// cell; ls_pre == nullptr: unit-variance posterior (du:323-337).
 int gauss_latent_fwd(hipStream_t stream, const float* mu_pre, const float* ls_pre,
-                     const float* eps, float* z, float* kl_elem, float* kl_cell, int S, int B,
-                     int L, int deterministic);
+                     const float* eps, float* z, float* kl_elem, float* kl_cell,
+                     float* kl_sample, int S, int B, int L, int deterministic);
 int gauss_latent_bwd(hipStream_t stream, const float* mu_pre, const float* ls_pre,
-                     const float* eps, const float* dz, float kl_coeff, float* dmu_pre,
-                     float* dls_pre, int S, int B, int L);
+                     const float* eps, const float* dz, float kl_coeff, const float* kl_gw,
+                     float* dmu_pre, float* dls_pre, int S, int B, int L);
 // ELBO terms and d(-ELBO_weighted)/d loglik (va:2717-2734, mu:129-137)
 // scalars: [0] lower_bound [1] lower_bound_weighted [2] reconstruction_error [3] kl_divergence
-int vae_elbo(hipStream_t stream, const float* ll, const float* kl_cell, int n_iw, int n_mc, int B,
-             float kl_weight_total, float row_scale, float* scalars, float* gw);
+// kl_per_sample: kl_cell holds [n_iw * n_mc * B] Monte-Carlo values instead of [B] analytic ones
+int vae_elbo(hipStream_t stream, const float* ll, const float* kl_cell, int kl_per_sample,
+             int n_iw, int n_mc, int B, float kl_weight_total, float row_scale, float* scalars,
+             float* gw);
 
 // batch normalisation (tf.contrib.layers.batch_norm(center=True, scale=False), fused semantics)
 constexpr int BN_MAX_CHUNKS = 64;

@@ -36,7 +36,8 @@ static int build_vae(scvae_plan* p) {
     if (i == 0) p->early_reduce_start = L.n_params;   // everything after ENCODER/1
   }
   p->mu = L.dense("POSTERIOR/MU", n_in, c.latent_size, false);
-  p->ls = L.dense("POSTERIOR/LOG_SIGMA", n_in, c.latent_size, false);
+  // "unit-variance gaussian" (du:323-337): log_sigma is the constant 0, no LOG_SIGMA layer
+  if (!(c.latent_mode & 2)) p->ls = L.dense("POSTERIOR/LOG_SIGMA", n_in, c.latent_size, false);
   n_in = c.latent_size + c.decoder_extra;   // decoder input [z | batch one-hot | count sum]
   // dense_layers(reverse_order=True): sizes reversed, scopes numbered n..1 (mu:102-105)
   for (int i = 0; i < n_dec; ++i) {
@@ -86,7 +87,7 @@ static size_t carve(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_
   float* mu_pre = b.floats(B * Lz);
   float* ls_pre = b.floats(B * Lz);
   float* kl_elem = b.floats(B * Lz);
-  float* kl_cell = b.floats(B);
+  float* kl_cell = b.floats((c.latent_mode & 1) ? R : B);   // Monte-Carlo KL: one per sample row
   float* z = b.floats(R * Lz);
   float* ll = b.floats(R);
   float* gw = b.floats(R);
@@ -318,11 +319,15 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   if ((rc = gemm(s, false, false, h, p->params + mu.w, p->params + mu.b, p->mu_pre, B, L, mu.n_in,
                  ld, L, L, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
     return rc;
-  if ((rc = gemm(s, false, false, h, p->params + ls.w, p->params + ls.b, p->ls_pre, B, L, ls.n_in,
-                 ld, L, L, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
-    return rc;
-  if ((rc = gauss_latent_fwd(s, p->mu_pre, p->ls_pre, a->eps, p->z, p->kl_elem, p->kl_cell, S, B,
-                             L, a->deterministic_z)))
+  const bool mc_kl = (c.latent_mode & 1) != 0;      // va:2633-2640
+  const bool unit_var = (c.latent_mode & 2) != 0;   // du:323-337
+  const float* ls_pre = unit_var ? nullptr : p->ls_pre;
+  if (!unit_var)
+    if ((rc = gemm(s, false, false, h, p->params + ls.w, p->params + ls.b, p->ls_pre, B, L,
+                   ls.n_in, ld, L, L, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+      return rc;
+  if ((rc = gauss_latent_fwd(s, p->mu_pre, ls_pre, a->eps, p->z, p->kl_elem, p->kl_cell,
+                             mc_kl ? p->kl_cell : nullptr, S, B, L, a->deterministic_z)))
     return rc;
   if (a->kl_neurons)
     if ((rc = col_sum(s, p->kl_elem, L, B, L, a->kl_neurons, 1.f / (float)GB, 0, p->partial))) return rc;
@@ -393,7 +398,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const float row_scale = 1.f / ((float)n_mc * (float)GB);
   if (!training) {
     if ((rc = loglik_forward())) return rc;
-    if ((rc = vae_elbo(s, p->ll, p->kl_cell, n_iw, n_mc, B, w, row_scale, a->scalars, nullptr)))
+    if ((rc = vae_elbo(s, p->ll, p->kl_cell, mc_kl, n_iw, n_mc, B, w, row_scale, a->scalars, nullptr)))
       return rc;
     if (a->log_p_x_given_z)
       if ((rc = copy(s, p->ll, a->log_p_x_given_z, (size_t)R))) return rc;
@@ -414,7 +419,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     p->gw_rows = 0;   // vae_elbo below overwrites gw with the importance weights
     // importance weights need all log-likelihoods first
     if ((rc = loglik_forward())) return rc;
-    if ((rc = vae_elbo(s, p->ll, p->kl_cell, n_iw, n_mc, B, w, row_scale, a->scalars, p->gw)))
+    if ((rc = vae_elbo(s, p->ll, p->kl_cell, mc_kl, n_iw, n_mc, B, w, row_scale, a->scalars, p->gw)))
       return rc;
   }
   if (fused) {
@@ -453,7 +458,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     }
   }
   if (n_iw == 1)
-    if ((rc = vae_elbo(s, p->ll, p->kl_cell, n_iw, n_mc, B, w, row_scale, a->scalars, nullptr)))
+    if ((rc = vae_elbo(s, p->ll, p->kl_cell, mc_kl, n_iw, n_mc, B, w, row_scale, a->scalars, nullptr)))
       return rc;
   if (a->log_p_x_given_z)
     if ((rc = copy(s, p->ll, a->log_p_x_given_z, (size_t)R))) return rc;
@@ -476,15 +481,17 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   if (p->dec.empty())
     if ((rc = copy(s, dcur, p->dz, (size_t)R * L))) return rc;
   // latent: dz -> dmu_pre, dls_pre  (d(-ELBO_w)/dKL_cell = w / B_global)
-  if ((rc = gauss_latent_bwd(s, p->mu_pre, p->ls_pre, a->eps, p->dz, w / (float)GB, p->dmu, p->dls,
-                             S, B, L)))
+  //         Monte-Carlo KL: d(-ELBO_w)/dKL[s,b] = -w * gw[s,b]
+  if ((rc = gauss_latent_bwd(s, p->mu_pre, ls_pre, a->eps, p->dz, mc_kl ? w : w / (float)GB,
+                             mc_kl ? p->gw : nullptr, p->dmu, unit_var ? nullptr : p->dls, S, B,
+                             L)))
     return rc;
   const float* hn = p->enc.empty() ? a->x : p->enc.back().h;
   const int ldn = p->enc.empty() ? F : p->enc.back().n_out;
   float* dh = p->dbuf[0];
   float* dh_alt = p->dbuf[1];
   const bool need_dh = !p->enc.empty();
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < (unit_var ? 1 : 2); ++q) {
     Dense& hd = q == 0 ? mu : ls;
     const float* dpre = q == 0 ? p->dmu : p->dls;
     if ((rc = gemm(s, true, false, hn, dpre, nullptr, p->grads + hd.w, hd.n_in, L, B, ldn, L, L,
@@ -534,6 +541,8 @@ int scvae_plan_create(const scvae_model_config* cfg, scvae_plan** out) {
   SCVAE_ARG(cfg->linear_factor >= 0 && cfg->linear_factor <= 3);
   SCVAE_ARG(cfg->linear_factor == 0 || cfg->model_type == SCVAE_MODEL_VAE);
   SCVAE_ARG(cfg->decoder_extra == 0 || (cfg->n_hidden > 0 && !(cfg->linear_factor & 2)));
+  SCVAE_ARG(cfg->latent_mode >= 0 && cfg->latent_mode <= 3);
+  SCVAE_ARG(cfg->latent_mode == 0 || cfg->model_type == SCVAE_MODEL_VAE);
   scvae_plan* p = new scvae_plan();
   p->cfg = *cfg;
   p->P = scvae::likelihood_heads(cfg->likelihood);
@@ -765,7 +774,7 @@ int scvae_gauss_latent_fwd(const float* mu_pre, const float* ls_pre, const float
                            float* kl_elem, float* kl_cell, int64_t S, int64_t cells, int64_t L,
                            int32_t deterministic, void* stream) {
   return scvae::gauss_latent_fwd((hipStream_t)stream, mu_pre, ls_pre, eps, z, kl_elem, kl_cell,
-                                 (int)S, (int)cells, (int)L, deterministic);
+                                 nullptr, (int)S, (int)cells, (int)L, deterministic);
 }
 int scvae_csr_densify(const int64_t* indptr, const int32_t* indices, const float* values,
                       const int64_t* rows, int64_t n, int64_t F, float* out, void* stream) {

@@ -41,7 +41,8 @@ class Engine:
                  seed=0, decoder_extra=0, k_max=0,
                  prior_probabilities_method="uniform",
                  prior_probabilities=None, inference_architecture="MLP",
-                 generative_architecture="MLP"):
+                 generative_architecture="MLP",
+                 latent_distribution="gaussian", analytical_kl_term=True):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError(
@@ -89,6 +90,17 @@ class Engine:
         cfg.linear_factor = (
             (1 if inference_architecture.upper() == "LFM" else 0)
             | (2 if generative_architecture.upper() == "LFM" else 0))
+        if latent_distribution not in ("gaussian", "unit-variance gaussian"):
+            raise ValueError("VAE latent distribution `{}`.".format(
+                latent_distribution))
+        self.latent_distribution = latent_distribution
+        self.analytical_kl_term = bool(analytical_kl_term)
+        cfg.latent_mode = 0
+        if model_type != "GMVAE":
+            cfg.latent_mode = (
+                (0 if self.analytical_kl_term else 1)
+                | (2 if latent_distribution == "unit-variance gaussian"
+                   else 0))
         self.config = cfg
 
         handle = ctypes.c_void_p()

@@ -187,14 +187,14 @@ class VariationalAutoencoder(ModelBase):
                 raise ValueError(
                     "The architectures can only be a neural network (MLP) "
                     "or a linear factor model (LFM).")
-        if self.parameterise_latent_posterior:
+        # parameterise_latent_posterior (va:2332-2344) only passes the
+        # validation above for a mixture latent distribution, which
+        # LATENT_DISTRIBUTIONS (du:309-338) does not hold.
+        if self.latent_distribution_name not in (
+                "gaussian", "unit-variance gaussian"):
             raise mu.not_in_this_build(
-                "Parameterised latent posterior", "va:2332-2344")
-        if (self.latent_distribution_name != "gaussian"
-                or not self.analytical_kl_term):
-            raise mu.not_in_this_build(
-                "Monte Carlo KL term / unit-variance posterior",
-                "va:2633-2640")
+                "Latent distribution `{}`".format(
+                    self.latent_distribution_name), "du:309-338")
         if self.reconstruction_distribution_name not in (
                 "poisson", "negative binomial", "zero-inflated poisson",
                 "zero-inflated negative binomial"):
@@ -212,7 +212,9 @@ class VariationalAutoencoder(ModelBase):
             kl_weight=self.kl_weight_value,
             decoder_extra=self.decoder_extra_size, k_max=self.k_max,
             inference_architecture=self.inference_architecture,
-            generative_architecture=self.generative_architecture)
+            generative_architecture=self.generative_architecture,
+            latent_distribution=self.latent_distribution_name,
+            analytical_kl_term=bool(self.analytical_kl_term))
 
     def _parameter_shapes(self):
         table = []
@@ -230,7 +232,8 @@ class VariationalAutoencoder(ModelBase):
             dense("ENCODER/{}".format(i + 1), n_in, h, bn)
             n_in = h
         dense("POSTERIOR/MU", n_in, self.latent_size, False)
-        dense("POSTERIOR/LOG_SIGMA", n_in, self.latent_size, False)
+        if self.latent_distribution_name != "unit-variance gaussian":
+            dense("POSTERIOR/LOG_SIGMA", n_in, self.latent_size, False)
         n_in = self.latent_size + self.decoder_extra_size
         for i, h in enumerate(H[::-1] if self.generative_architecture == "MLP"
                               else []):
