@@ -72,6 +72,11 @@ typedef struct scvae_model_config {
                                  KL(z) is always of that form); bit 1 latent_distribution ==
                                  "unit-variance gaussian" (du:323-337): the posterior's log_sigma
                                  is the constant 0 and POSTERIOR/LOG_SIGMA is not built */
+  float dropout_keep[4];      /* dropout_keep_probabilities (va:245-269, gm:281-301), applied to
+                                 the input connections of a dense layer while training
+                                 (mu:45-50): [0] h: hidden layers and every parameter head,
+                                 [1] x: first encoder layer, [2] z: first decoder layer,
+                                 [3] y: GMVAE p(z|y) layers.  0 or 1: no dropout */
 } scvae_model_config;
 
 typedef struct scvae_plan scvae_plan; /* opaque */
@@ -155,6 +160,10 @@ typedef struct scvae_step_args {
   /* [cells, E] extra decoder inputs (required when cfg.decoder_extra > 0), tiled over the
    * samples like t: the decoder's first layer sees [z | decoder_extra] */
   const float* decoder_extra;
+  /* dropout (training steps of a plan with a dropout_keep in ]0, 1[): seed of this step's
+   * masks, a new value every step; the mask of every layer input is a function of
+   * (dropout_seed, site, row, column), see scvae_dropout_apply */
+  uint64_t dropout_seed;
 } scvae_step_args;
 int scvae_plan_step(scvae_plan* plan, const scvae_step_args* args, void* stream);
 /* Decoder only, is_training = False: p_x_mean[rows, F] = mean of p(x|z) for given latent values
@@ -210,6 +219,15 @@ int scvae_likelihood_elementwise(int32_t kind, const float* t, const float* cons
 int scvae_gauss_latent_fwd(const float* mu_pre, const float* ls_pre, const float* eps, float* z,
                            float* kl_elem, float* kl_cell, int64_t S, int64_t cells, int64_t L,
                            int32_t deterministic, void* stream);
+/* tf.nn.dropout as the plan applies it (mu:45-50): out (+)= in * m / keep, m the Bernoulli(keep)
+ * mask of (seed, site, row, column) [Philox4x32-10]; in, out: [rows, cols] contiguous.  Sites of
+ * a VAE plan: i (ENCODER/i+1), 16 (POSTERIOR/MU), 17 (POSTERIOR/LOG_SIGMA), 32+i (i-th decoder
+ * layer in execution order), 48+j (X_TILDE head j), 51 (X_TILDE/P_K); of a GMVAE plan: 64+i
+ * (Y/CATEGORICAL/ENCODER/LAYER_i+1), 80 (Y/CATEGORICAL/LOGITS), i (Z/Q/ENCODER/LAYER_i+1),
+ * 16, 17 (Z/Q mean, scale), 24, 25 (Z/P mean, scale), 32+i (X/DECODER/LAYER_i+1), 48+j, 51
+ * (X/DISTRIBUTION heads); rows of the K passes are stacked, pass-major. */
+int scvae_dropout_apply(const float* in, float* out, int64_t rows, int64_t cols, float keep,
+                        uint64_t seed, int32_t site, int32_t accumulate, void* stream);
 /* minibatch fetch x_train[idx].toarray() (va:985-998) from a device-resident CSR matrix */
 int scvae_csr_densify(const int64_t* indptr, const int32_t* indices, const float* values,
                       const int64_t* rows, int64_t n, int64_t F, float* out, void* stream);

@@ -188,11 +188,22 @@ def init_moving_statistics(shapes, dtype=torch.float64):
 # --------------------------------------------------------------------------
 
 def dense_layer(x, params, scope, bn, training, moving, new_moving,
-                activation=True, extra_row=None):
+                activation=True, extra_row=None, dropout=None):
     """utilities.py:38-76.  ``extra_row`` adds one weight row (GMVAE one-hot
-    input column) to the affine map."""
+    input column) to the affine map.  ``dropout``: dict scope -> the tensor
+    ``mask / keep_prob`` of ``tf.nn.dropout`` on this layer's inputs
+    (utilities.py:45-50, training only; the mask is an explicit input like
+    eps so that a run can be reproduced)."""
     W = params[scope + "/DENSE/weights"]
     b = params[scope + "/DENSE/biases"]
+    if training and dropout is not None and scope in dropout:
+        if extra_row is not None:   # the one-hot column is part of the input
+            n_x = x.shape[1]
+            xy = torch.zeros(x.shape[0], W.shape[0], dtype=x.dtype)
+            xy[:, :n_x] = x
+            xy[:, n_x + extra_row] = 1.0
+            x, extra_row = xy, None
+        x = x * dropout[scope]
     if extra_row is None:
         a = x @ W + b
     else:
@@ -234,18 +245,19 @@ def _normal_log_prob(z, mean, sigma):
             - HALF_LOG_2PI)
 
 
-def _decoder_distribution(cfg, d, params, scope, training, moving):
+def _decoder_distribution(cfg, d, params, scope, training, moving,
+                          dropout=None):
     """Head pre-activations (and the P_K logits) of p(x|z) from the last
     decoder layer ``d``; returns (log_prob(t), mean_variance()) closures."""
     pre = tuple(
         dense_layer(d, params, scope + p.upper(), False, training, moving,
-                    None, activation=False)
+                    None, activation=False, dropout=dropout)
         for p in cfg.heads)
     if not cfg.k_max:
         return (lambda t: lk.log_prob(cfg.likelihood, t, pre),
                 lambda: lk.mean_variance(cfg.likelihood, pre))
     logits = dense_layer(d, params, scope + "P_K", False, training, moving,
-                         None, activation=False)
+                         None, activation=False, dropout=dropout)
     logits = logits.reshape(d.shape[0], cfg.feature_size, cfg.k_max + 1)
     return (lambda t: lk.categorised_log_prob(cfg.likelihood, t, pre, logits,
                                               cfg.k_max),
@@ -283,9 +295,11 @@ def decode_mean(cfg, params, moving, z, model_type="VAE"):
 
 def vae_forward(cfg, params, moving, x, t, eps, training, warm_up_weight=1.0,
                 new_moving=None, deterministic_z=False, analytical_kl=None,
-                evaluation_statistics=False, decoder_extra=None):
+                evaluation_statistics=False, decoder_extra=None,
+                dropout=None):
     """One graph execution.  ``eps``: [S, B, L] standard-normal draws
-    (S = n_iw * n_mc, IW-major) or None with ``deterministic_z``."""
+    (S = n_iw * n_mc, IW-major) or None with ``deterministic_z``.
+    ``dropout``: {layer scope: mask / keep_prob} (see dense_layer)."""
     bn = cfg.minibatch_normalisation
     H = list(cfg.hidden_sizes)
     n = len(H)
@@ -295,16 +309,17 @@ def vae_forward(cfg, params, moving, x, t, eps, training, warm_up_weight=1.0,
     h = x
     for i in range(n if cfg.inference_architecture == "MLP" else 0):
         h = dense_layer(h, params, "ENCODER/{}".format(i + 1), bn, training,
-                        moving, new_moving)
+                        moving, new_moving, dropout=dropout)
     mu = dense_layer(h, params, "POSTERIOR/MU", False, training, moving,
-                     None, activation=False)
+                     None, activation=False, dropout=dropout)
     mu = torch.clamp(mu, -FLOAT32_MAX_HALF, FLOAT32_MAX_HALF)
     if cfg.latent_distribution == "unit-variance gaussian":
         # a constant parameter skips the layer and its clip (va:2253-2265)
         log_sigma = torch.zeros_like(mu)
     else:
         log_sigma = dense_layer(h, params, "POSTERIOR/LOG_SIGMA", False,
-                                training, moving, None, activation=False)
+                                training, moving, None, activation=False,
+                                dropout=dropout)
         log_sigma = torch.clamp(log_sigma, -3.0, 3.0)
     sigma = torch.exp(log_sigma)
     if analytical_kl is None:
@@ -323,9 +338,9 @@ def vae_forward(cfg, params, moving, x, t, eps, training, warm_up_weight=1.0,
         d = torch.cat([d, decoder_extra.repeat(S, 1)], dim=1)
     for i in range(n if cfg.generative_architecture == "MLP" else 0):
         d = dense_layer(d, params, "DECODER/{}".format(n - i), bn, training,
-                        moving, new_moving)
+                        moving, new_moving, dropout=dropout)
     log_prob, mean_variance = _decoder_distribution(
-        cfg, d, params, "X_TILDE/", training, moving)
+        cfg, d, params, "X_TILDE/", training, moving, dropout)
 
     t_tiled = t.repeat(S, 1)
     log_p = log_prob(t_tiled).sum(dim=-1)

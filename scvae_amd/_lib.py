@@ -45,6 +45,7 @@ class ModelConfig(Structure):
         ("linear_factor", c_int32),
         ("decoder_extra", c_int32),
         ("latent_mode", c_int32),
+        ("dropout_keep", c_float * 4),
     ]
 
 
@@ -71,6 +72,7 @@ class StepArgs(Structure):
         ("stddev_of_p_x_given_z_mean", c_void_p),
         ("cluster_stats", c_void_p),
         ("decoder_extra", c_void_p),
+        ("dropout_seed", c_uint64),
     ]
 
 
@@ -139,6 +141,9 @@ SIGNATURES = {
         c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "scvae_philox_normal": (c_int32, [
         c_void_p, c_int64, c_int64, c_int64, c_uint64, c_uint64, c_void_p]),
+    "scvae_dropout_apply": (c_int32, [
+        c_void_p, c_void_p, c_int64, c_int64, c_float, c_uint64, c_int32,
+        c_int32, c_void_p]),
     "scvae_bn_merge": (c_int32, [
         c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
 }

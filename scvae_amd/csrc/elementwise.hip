@@ -1335,4 +1335,58 @@ int philox_normal(hipStream_t stream, float* out, int64_t rows, int cols, int64_
   return 0;
 }
 
+// ================================ dropout ==================================
+
+// tf.contrib.layers.dropout(inputs, keep_prob, is_training) -> tf.nn.dropout (mu:45-50):
+// out = in * m / keep, m ~ Bernoulli(keep) per element.  The mask is a pure function of
+// (seed, site, row, column): Philox4x32-10 with key = seed and counter = (row_lo, row_hi,
+// column / 4, 0x80000000 | site), element kept iff its uniform draw is below keep.  The backward
+// pass calls the same kernel on the gradient (optionally accumulating), so no mask is stored.
+__global__ __launch_bounds__(256) void dropout_apply_kernel(
+    const float* __restrict__ in, int ld_in, float* __restrict__ out, int ld_out, int64_t rows,
+    int cols, float keep, float inv_keep, uint32_t seed_lo, uint32_t seed_hi, uint32_t site,
+    int accumulate) {
+  const int groups = (cols + 3) / 4;
+  const int64_t total = rows * groups;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / groups;
+    const int cg = (int)(i % groups);
+    uint32_t c[4] = {(uint32_t)row, (uint32_t)((uint64_t)row >> 32), (uint32_t)cg,
+                     0x80000000u | site};
+    uint32_t k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = cg * 4 + j;
+      if (col >= cols) break;
+      const float u = ((float)(c[j] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+      const float v = u < keep ? in[row * ld_in + col] * inv_keep : 0.f;
+      float* o = out + row * ld_out + col;
+      *o = accumulate ? *o + v : v;
+    }
+  }
+}
+
+int dropout_apply(hipStream_t stream, const float* in, int ld_in, float* out, int ld_out,
+                  int64_t rows, int cols, float keep, uint64_t seed, uint32_t site,
+                  int accumulate) {
+  SCVAE_ARG(in && out && rows >= 0 && cols > 0 && ld_in >= cols && ld_out >= cols);
+  SCVAE_ARG(keep > 0.f && keep <= 1.f && site < 0x80000000u);
+  if (rows == 0) return 0;
+  const int64_t total = rows * ((cols + 3) / 4);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, ld_in,
+                     out, ld_out, rows, cols, keep, 1.f / keep, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), site, accumulate);
+  SCVAE_LAUNCH_CHECK("dropout_apply_kernel");
+  return 0;
+}
+
 }  // namespace scvae

@@ -176,5 +176,9 @@ int gather_rows_f32(hipStream_t stream, const float* src, const int64_t* rows, i
 // (seed, stream id, global row, column): identical for any sharding of the rows
 int philox_normal(hipStream_t stream, float* out, int64_t rows, int cols, int64_t row_offset,
                   uint64_t seed, uint64_t stream_id);
+// dropout (mu:45-50): out (+)= in * mask(seed, site, row, col) / keep; forward and backward
+int dropout_apply(hipStream_t stream, const float* in, int ld_in, float* out, int ld_out,
+                  int64_t rows, int cols, float keep, uint64_t seed, uint32_t site,
+                  int accumulate);
 
 }  // namespace scvae

@@ -55,6 +55,20 @@ static int build_vae(scvae_plan* p) {
   // the first encoder layer's dW (x^T dA, the last large GEMM of the backward pass) is the only
   // gradient still missing when the hook is told that the rest may be all-reduced
   if (!p->enc.empty()) p->early_reduce_layer = &p->enc[0];
+  // dropout of the input connections (va:2221-2232, 2286-2287, 2444-2455, 2487, 2516)
+  const float kh = dropout_keep(c, 0), kx = dropout_keep(c, 1), kz = dropout_keep(c, 2);
+  for (size_t i = 0; i < p->enc.size(); ++i) {
+    p->enc[i].keep = i == 0 ? kx : kh;
+    p->enc[i].site = (uint32_t)i;
+  }
+  p->mu.keep = kh; p->mu.site = 16;
+  p->ls.keep = kh; p->ls.site = 17;
+  for (size_t i = 0; i < p->dec.size(); ++i) {
+    p->dec[i].keep = i == 0 ? kz : kh;
+    p->dec[i].site = 32 + (uint32_t)i;
+  }
+  for (int j = 0; j < p->P; ++j) { p->heads[j].keep = kh; p->heads[j].site = 48 + j; }
+  p->head_k.keep = kh; p->head_k.site = 51;
   return 0;
 }
 
@@ -121,6 +135,17 @@ static size_t carve(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_
   float* zcat = E ? b.floats(R * (Lz + E)) : nullptr;
   float* dzcat = E ? b.floats(R * (Lz + E)) : nullptr;
   float* pre_k = c.k_max > 0 ? b.floats(R * F * (size_t)(c.k_max + 1)) : nullptr;
+  // dropped-out layer inputs of the training pass (kept for the weight gradients)
+  auto drop_ws = [&](Dense& d, size_t rows) {
+    float* q = (d.keep > 0.f && d.n_in > 0) ? b.floats(rows * (size_t)d.n_in) : nullptr;
+    if (!dry) d.in_drop = q;
+  };
+  for (auto& d : p->enc) drop_ws(d, B);
+  drop_ws(p->mu, B);
+  if (!(c.latent_mode & 2)) drop_ws(p->ls, B);
+  for (auto& d : p->dec) drop_ws(d, R);
+  for (int j = 0; j < p->P; ++j) drop_ws(p->heads[j], R);
+  if (c.k_max > 0) drop_ws(p->head_k, R);
   if (!dry) {
     p->fused_ws = fused_ws;
     p->zcat = zcat; p->dzcat = dzcat;
@@ -136,10 +161,36 @@ static size_t carve(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_
 }
 
 // ---- dense layer forward: fully_connected (+ batch_norm) (+ relu), mu:38-76 ----
+float dropout_keep(const scvae_model_config& c, int which) {
+  const float k = c.dropout_keep[which];
+  return (k > 0.f && k < 1.f) ? k : 0.f;   // p in {0, 1, False}: no dropout (mu:45)
+}
+
+int dense_input(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_in, int rows,
+                bool training, const float** in_out, int* ld_out) {
+  *in_out = in; *ld_out = ld_in;
+  if (!training || d.keep <= 0.f) return 0;
+  int rc = dropout_apply(s, in, ld_in, d.in_drop, d.n_in, rows, d.n_in, d.keep, p->drop_seed,
+                         d.site, 0);
+  if (rc) return rc;
+  *in_out = d.in_drop; *ld_out = d.n_in;
+  return 0;
+}
+
+int dense_input_backward(scvae_plan* p, hipStream_t s, const Dense& d, const float* g, float* out,
+                         int rows, bool accumulate) {
+  return dropout_apply(s, g, d.n_in, out, d.n_in, rows, d.n_in, d.keep, p->drop_seed, d.site,
+                       accumulate ? 1 : 0);
+}
+
 int dense_forward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_in,
                          int rows, int groups, bool relu, bool training) {
   const float* W = p->params + d.w;
   const float* bias = p->params + d.b;
+  {
+    int rc = dense_input(p, s, d, in, ld_in, rows, training, &in, &ld_in);
+    if (rc) return rc;
+  }
   if (!d.bn) {
     return gemm(s, false, false, in, W, bias, d.h, rows, d.n_out, d.n_in, ld_in, d.n_out, d.n_out,
                 relu ? ACT_RELU : ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes);
@@ -224,6 +275,7 @@ int dense_backward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int 
   const int N = d.n_out;
   int rc;
   const float* da = nullptr;
+  if (d.keep > 0.f) { in = d.in_drop; ld_in = d.n_in; }   // what the forward GEMM read
   if ((rc = dense_backward_activation(p, s, d, rows, groups, relu, dh, scratch,
                                       global_rows_per_group, &da)))
     return rc;
@@ -242,9 +294,15 @@ int dense_backward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int 
   if (!d.bn)
     if ((rc = col_sum(s, da, N, rows, N, p->grads + d.b, 1.f, 0, p->partial))) return rc;
   if (d_in) {
+    if (d.keep > 0.f && accumulate_d_in) {
+      set_error("dense_backward: accumulation into a dropped-out input");
+      return -1;
+    }
     if ((rc = gemm(s, false, true, da, p->params + d.w, nullptr, d_in, rows, d.n_in, N, N, N,
                    d.n_in, ACT_NONE, accumulate_d_in, p->gemm_ws, p->gemm_ws_bytes)))
       return rc;
+    if (d.keep > 0.f)
+      if ((rc = dense_input_backward(p, s, d, d_in, d_in, rows, false))) return rc;
   }
   return 0;
 }
@@ -306,6 +364,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const int64_t GB = a->global_cells > 0 ? a->global_cells : a->cells;
   const float w = a->warm_up_weight * c.kl_weight;
   int rc;
+  p->drop_seed = a->dropout_seed;
 
   // ---------------- forward ----------------
   const float* h = a->x;
@@ -316,16 +375,23 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   Dense& mu = p->mu;
   Dense& ls = p->ls;
-  if ((rc = gemm(s, false, false, h, p->params + mu.w, p->params + mu.b, p->mu_pre, B, L, mu.n_in,
-                 ld, L, L, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+  // every parameter layer draws its own mask of the encoder output (va:2281-2289)
+  const float* h_mu = h;
+  const float* h_ls = h;
+  int ld_mu = ld, ld_ls = ld;
+  if ((rc = dense_input(p, s, mu, h, ld, B, training, &h_mu, &ld_mu))) return rc;
+  if ((rc = gemm(s, false, false, h_mu, p->params + mu.w, p->params + mu.b, p->mu_pre, B, L,
+                 mu.n_in, ld_mu, L, L, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
     return rc;
   const bool mc_kl = (c.latent_mode & 1) != 0;      // va:2633-2640
   const bool unit_var = (c.latent_mode & 2) != 0;   // du:323-337
   const float* ls_pre = unit_var ? nullptr : p->ls_pre;
-  if (!unit_var)
-    if ((rc = gemm(s, false, false, h, p->params + ls.w, p->params + ls.b, p->ls_pre, B, L,
-                   ls.n_in, ld, L, L, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+  if (!unit_var) {
+    if ((rc = dense_input(p, s, ls, h, ld, B, training, &h_ls, &ld_ls))) return rc;
+    if ((rc = gemm(s, false, false, h_ls, p->params + ls.w, p->params + ls.b, p->ls_pre, B, L,
+                   ls.n_in, ld_ls, L, L, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
       return rc;
+  }
   if ((rc = gauss_latent_fwd(s, p->mu_pre, ls_pre, a->eps, p->z, p->kl_elem, p->kl_cell,
                              mc_kl ? p->kl_cell : nullptr, S, B, L, a->deterministic_z)))
     return rc;
@@ -353,20 +419,27 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   // the fused kernel never materialises the [rows, P*F] pre-activations; the evaluate-time
   // statistics (p_x_mean, ...) need them, so that request takes the unfused path
   const int KM = c.k_max, FC = F * (KM + 1);   // piecewise categorical likelihood: unfused path
+  // dropout gives every head its own mask of the decoder output (va:2475-2488, 2507-2518):
+  // the fused kernel shares one tile of it between the heads, so that training pass is unfused
+  const bool head_drop = training && p->heads[0].keep > 0.f;
   const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
-                     !a->p_x_mean && KM == 0;
+                     !a->p_x_mean && KM == 0 && !head_drop;
   const HeadParams hp = head_params(p);
+  const float* head_in[4] = {dch, dch, dch, dch};   // [3]: the P_K head
   if (!fused) {
+    int ldh = ld;
     for (int j = 0; j < p->P; ++j) {
       Dense& hd = p->heads[j];
-      if ((rc = gemm(s, false, false, dch, p->params + hd.w, p->params + hd.b, p->pre[j], R, F,
-                     hd.n_in, ld, F, F, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+      if ((rc = dense_input(p, s, hd, dch, ld, R, training, &head_in[j], &ldh))) return rc;
+      if ((rc = gemm(s, false, false, head_in[j], p->params + hd.w, p->params + hd.b, p->pre[j], R,
+                     F, hd.n_in, ldh, F, F, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
         return rc;
     }
     if (KM > 0) {
       Dense& hk = p->head_k;
-      if ((rc = gemm(s, false, false, dch, p->params + hk.w, p->params + hk.b, p->pre_k, R, FC,
-                     hk.n_in, ld, FC, FC, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+      if ((rc = dense_input(p, s, hk, dch, ld, R, training, &head_in[3], &ldh))) return rc;
+      if ((rc = gemm(s, false, false, head_in[3], p->params + hk.w, p->params + hk.b, p->pre_k, R,
+                     FC, hk.n_in, ldh, FC, FC, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
         return rc;
     }
   }
@@ -436,25 +509,31 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                       n_iw == 1 ? p->ll : nullptr, R, B, F);
     if (rc) return rc;
     // heads: dW_j = d^T G_j, db_j = colsum(G_j), dd (+)= G_j W_j^T
+    // with dropout every head's dd passes its own mask before the sum (through dalt)
     for (int j = 0; j < p->P; ++j) {
       Dense& hd = p->heads[j];
-      if ((rc = gemm(s, true, false, dch, p->pre[j], nullptr, p->grads + hd.w, h1, F, R, ld, F, F,
-                     ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+      if ((rc = gemm(s, true, false, head_in[j], p->pre[j], nullptr, p->grads + hd.w, h1, F, R, h1,
+                     F, F, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
         return rc;
       if ((rc = col_sum(s, p->pre[j], F, R, F, p->grads + hd.b, 1.f, 0, p->partial))) return rc;
-      if ((rc = gemm(s, false, true, p->pre[j], p->params + hd.w, nullptr, dcur, R, h1, F, F, F,
-                     h1, ACT_NONE, j > 0, p->gemm_ws, p->gemm_ws_bytes)))
+      if ((rc = gemm(s, false, true, p->pre[j], p->params + hd.w, nullptr, head_drop ? dalt : dcur,
+                     R, h1, F, F, F, h1, ACT_NONE, !head_drop && j > 0, p->gemm_ws,
+                     p->gemm_ws_bytes)))
         return rc;
+      if (head_drop)
+        if ((rc = dense_input_backward(p, s, hd, dalt, dcur, R, j > 0))) return rc;
     }
     if (KM > 0) {   // the P_K head, same three products on [rows, F * (K + 1)]
       Dense& hk = p->head_k;
-      if ((rc = gemm(s, true, false, dch, p->pre_k, nullptr, p->grads + hk.w, h1, FC, R, ld, FC, FC,
-                     ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+      if ((rc = gemm(s, true, false, head_in[3], p->pre_k, nullptr, p->grads + hk.w, h1, FC, R, h1,
+                     FC, FC, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
         return rc;
       if ((rc = col_sum(s, p->pre_k, FC, R, FC, p->grads + hk.b, 1.f, 0, p->partial))) return rc;
-      if ((rc = gemm(s, false, true, p->pre_k, p->params + hk.w, nullptr, dcur, R, h1, FC, FC, FC,
-                     h1, ACT_NONE, true, p->gemm_ws, p->gemm_ws_bytes)))
+      if ((rc = gemm(s, false, true, p->pre_k, p->params + hk.w, nullptr, head_drop ? dalt : dcur,
+                     R, h1, FC, FC, FC, h1, ACT_NONE, !head_drop, p->gemm_ws, p->gemm_ws_bytes)))
         return rc;
+      if (head_drop)
+        if ((rc = dense_input_backward(p, s, hk, dalt, dcur, R, true))) return rc;
     }
   }
   if (n_iw == 1)
@@ -486,22 +565,27 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                              mc_kl ? p->gw : nullptr, p->dmu, unit_var ? nullptr : p->dls, S, B,
                              L)))
     return rc;
-  const float* hn = p->enc.empty() ? a->x : p->enc.back().h;
-  const int ldn = p->enc.empty() ? F : p->enc.back().n_out;
   float* dh = p->dbuf[0];
   float* dh_alt = p->dbuf[1];
   const bool need_dh = !p->enc.empty();
   for (int q = 0; q < (unit_var ? 1 : 2); ++q) {
     Dense& hd = q == 0 ? mu : ls;
     const float* dpre = q == 0 ? p->dmu : p->dls;
-    if ((rc = gemm(s, true, false, hn, dpre, nullptr, p->grads + hd.w, hd.n_in, L, B, ldn, L, L,
+    const float* hq = q == 0 ? h_mu : h_ls;        // the (dropped-out) input of that layer
+    const int ldq = q == 0 ? ld_mu : ld_ls;
+    const bool drop = hd.keep > 0.f;
+    if ((rc = gemm(s, true, false, hq, dpre, nullptr, p->grads + hd.w, hd.n_in, L, B, ldq, L, L,
                    ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
       return rc;
     if ((rc = col_sum(s, dpre, L, B, L, p->grads + hd.b, 1.f, 0, p->partial))) return rc;
-    if (need_dh)
-      if ((rc = gemm(s, false, true, dpre, p->params + hd.w, nullptr, dh, B, hd.n_in, L, L, L,
-                     hd.n_in, ACT_NONE, q > 0, p->gemm_ws, p->gemm_ws_bytes)))
+    if (need_dh) {
+      if ((rc = gemm(s, false, true, dpre, p->params + hd.w, nullptr, drop ? dh_alt : dh, B,
+                     hd.n_in, L, L, L, hd.n_in, ACT_NONE, !drop && q > 0, p->gemm_ws,
+                     p->gemm_ws_bytes)))
         return rc;
+      if (drop)
+        if ((rc = dense_input_backward(p, s, hd, dh_alt, dh, B, q > 0))) return rc;
+    }
   }
   for (int i = (int)p->enc.size() - 1; i >= 0; --i) {
     Dense& d = p->enc[i];
@@ -543,6 +627,9 @@ int scvae_plan_create(const scvae_model_config* cfg, scvae_plan** out) {
   SCVAE_ARG(cfg->decoder_extra == 0 || (cfg->n_hidden > 0 && !(cfg->linear_factor & 2)));
   SCVAE_ARG(cfg->latent_mode >= 0 && cfg->latent_mode <= 3);
   SCVAE_ARG(cfg->latent_mode == 0 || cfg->model_type == SCVAE_MODEL_VAE);
+  for (int i = 0; i < 4; ++i) SCVAE_ARG(cfg->dropout_keep[i] >= 0.f && cfg->dropout_keep[i] <= 1.f);
+  if (cfg->model_type == SCVAE_MODEL_GMVAE)
+    for (int i = 0; i < 4; ++i) SCVAE_ARG(scvae::dropout_keep(*cfg, i) == 0.f);
   scvae_plan* p = new scvae_plan();
   p->cfg = *cfg;
   p->P = scvae::likelihood_heads(cfg->likelihood);
@@ -775,6 +862,12 @@ int scvae_gauss_latent_fwd(const float* mu_pre, const float* ls_pre, const float
                            int32_t deterministic, void* stream) {
   return scvae::gauss_latent_fwd((hipStream_t)stream, mu_pre, ls_pre, eps, z, kl_elem, kl_cell,
                                  nullptr, (int)S, (int)cells, (int)L, deterministic);
+}
+int scvae_dropout_apply(const float* in, float* out, int64_t rows, int64_t cols, float keep,
+                        uint64_t seed, int32_t site, int32_t accumulate, void* stream) {
+  SCVAE_ARG(site >= 0 && cols > 0 && cols <= INT32_MAX);
+  return scvae::dropout_apply((hipStream_t)stream, in, (int)cols, out, (int)cols, rows, (int)cols,
+                              keep, seed, (uint32_t)site, accumulate);
 }
 int scvae_csr_densify(const int64_t* indptr, const int32_t* indices, const float* values,
                       const int64_t* rows, int64_t n, int64_t F, float* out, void* stream) {

@@ -42,6 +42,10 @@ struct Dense {
   float* a = nullptr;      // pre-normalisation output [rows, n_out] (BN only)
   float* h = nullptr;      // layer output [rows, n_out]
   float* stats = nullptr;  // [mean | var | s1 | s2], each groups*n_out
+  // dropout of the layer's input connections (mu:45-50); keep == 0: none
+  float keep = 0.f;
+  uint32_t site = 0;           // which mask stream of the step (see dropout_apply)
+  float* in_drop = nullptr;    // [rows, n_in] the dropped-out input of the training pass
 };
 
 struct Layout {
@@ -134,6 +138,7 @@ struct scvae_plan {
   size_t gw_rows = 0;         //  the constant -1/(MC*B) is only rewritten when it changes)
   float *zcat = nullptr, *dzcat = nullptr;  // [rows, L + E]: decoder input [z | extra] and its gradient
   int use_fused = 1;          // fused decoder head kernel (0 = unfused GEMM + likelihood path)
+  uint64_t drop_seed = 0;     // dropout: this step's mask seed (scvae_step_args.dropout_seed)
   scvae_sync_fn sync = nullptr;
   void* sync_user = nullptr;
   // data parallel: when the backward reaches this layer's weight gradient (the last large GEMM of
@@ -163,6 +168,13 @@ int dense_backward_activation(scvae_plan* p, hipStream_t s, Dense& d, int rows, 
 int dense_backward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_in, int rows,
                    int groups, bool relu, const float* dh, float* scratch, float* d_in,
                    bool accumulate_d_in, int64_t global_rows_per_group);
+// dropout of a layer's input: in training returns d.in_drop (= mask * in / keep), else `in`
+int dense_input(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_in, int rows,
+                bool training, const float** in_out, int* ld_out);
+// the same mask on the gradient w.r.t. that input: out (+)= mask * g / keep
+int dense_input_backward(scvae_plan* p, hipStream_t s, const Dense& d, const float* g, float* out,
+                         int rows, bool accumulate);
+float dropout_keep(const scvae_model_config& c, int which);
 int fill(hipStream_t s, float* dst, float v, size_t n);
 HeadParams head_params(scvae_plan* p);
 int copy(hipStream_t s, const float* src, float* dst, size_t n);

@@ -42,7 +42,8 @@ class Engine:
                  prior_probabilities_method="uniform",
                  prior_probabilities=None, inference_architecture="MLP",
                  generative_architecture="MLP",
-                 latent_distribution="gaussian", analytical_kl_term=True):
+                 latent_distribution="gaussian", analytical_kl_term=True,
+                 dropout_keep_probabilities=None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError(
@@ -101,6 +102,16 @@ class Engine:
                 (0 if self.analytical_kl_term else 1)
                 | (2 if latent_distribution == "unit-variance gaussian"
                    else 0))
+        # (h, x, z, y) keep probabilities; False / 0 / 1: none (mu:45)
+        keeps = [float(k) if k else 0.0
+                 for k in (dropout_keep_probabilities or ())]
+        keeps = (keeps + [0.0] * 4)[:4]
+        self.dropout_keep_probabilities = tuple(
+            k if 0.0 < k < 1.0 else 0.0 for k in keeps)
+        for i, k in enumerate(self.dropout_keep_probabilities):
+            cfg.dropout_keep[i] = k
+        self.uses_dropout = any(self.dropout_keep_probabilities)
+        self._dropout_steps = 0
         self.config = cfg
 
         handle = ctypes.c_void_p()
@@ -292,10 +303,12 @@ class Engine:
     def step(self, x, t, eps=None, row_const=None, training=False,
              n_iw=1, n_mc=1, warm_up_weight=1.0, deterministic_z=False,
              global_cells=None, outputs=None, scalars=None,
-             decoder_extra=None):
+             decoder_extra=None, dropout_seed=None):
         """One graph execution (no host synchronisation).  ``outputs`` maps
         optional output names of ``scvae_step_args`` to preallocated tensors.
-        Returns the device tensor of scalars."""
+        ``dropout_seed``: seed of this training step's dropout masks (default:
+        a counter of the training steps taken).  Returns the device tensor of
+        scalars."""
         cells = x.shape[0]
         samples = 1 if deterministic_z else n_iw * n_mc
         self.reserve(cells, samples)
@@ -311,6 +324,11 @@ class Engine:
                         self.decoder_extra))
             a.decoder_extra = decoder_extra.data_ptr()
         a.eps = eps.data_ptr() if eps is not None else None
+        if training and self.uses_dropout:
+            if dropout_seed is None:
+                self._dropout_steps += 1
+                dropout_seed = (0x5C7AE << 40) + self._dropout_steps
+            a.dropout_seed = int(dropout_seed) & 0xFFFFFFFFFFFFFFFF
         a.cells = cells
         a.global_cells = global_cells if global_cells else cells
         a.n_iw, a.n_mc = n_iw, n_mc
@@ -326,6 +344,18 @@ class Engine:
             self.handle, ctypes.byref(a), current_stream_handle(self.device)),
             "scvae_plan_step")
         return out_scalars
+
+    def dropout_mask(self, site, rows, cols, keep, dropout_seed):
+        """The [rows, cols] tensor ``mask / keep`` that a training step with
+        ``dropout_seed`` multiplies into the input of layer ``site`` (site
+        numbers: include/scvae_hip.h, scvae_dropout_apply)."""
+        ones = torch.ones(rows, cols, device=self.device)
+        out = torch.empty_like(ones)
+        _lib.check(self.lib.scvae_dropout_apply(
+            _ptr(ones), _ptr(out), rows, cols, float(keep),
+            int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, int(site), 0,
+            current_stream_handle(self.device)), "scvae_dropout_apply")
+        return out
 
     def decode(self, z, out=None):
         """Mean of p(x|z) for latent values ``z`` [rows, L] with the moving
