@@ -390,12 +390,13 @@ def vae_forward(cfg, params, moving, x, t, eps, training, warm_up_weight=1.0,
 # --------------------------------------------------------------------------
 
 def _layers(x, params, prefix, sizes, bn, training, moving, new_moving,
-            extra_row=None):
+            extra_row=None, dropout=None):
     h = x
     for i in range(len(sizes)):
         h = dense_layer(h, params, "{}/LAYER_{}".format(prefix, i + 1), bn,
                         training, moving, new_moving,
-                        extra_row=extra_row if i == 0 else None)
+                        extra_row=extra_row if i == 0 else None,
+                        dropout=dropout)
     return h
 
 
@@ -405,9 +406,12 @@ def _clip_big(a):
 
 def gmvae_forward(cfg, params, moving, x, t, eps, training,
                   warm_up_weight=1.0, new_moving=None,
-                  evaluation_statistics=False, decoder_extra=None):
-    """``eps``: [K, S, B, L].  Uniform p(y) (the default
-    ``prior_probabilities_method``)."""
+                  evaluation_statistics=False, decoder_extra=None,
+                  dropout=None):
+    """``eps``: [K, S, B, L].  ``dropout``: {layer scope: mask / keep_prob}
+    (see dense_layer); the layers under Z/ and X/ are built once per cluster
+    (gm:2859-2922), each copy with its own dropout op, so their entries carry
+    a leading axis of K passes."""
     bn = cfg.minibatch_normalisation
     H = list(cfg.hidden_sizes)
     K, L = cfg.n_clusters, cfg.latent_size
@@ -415,10 +419,12 @@ def gmvae_forward(cfg, params, moving, x, t, eps, training,
     S = cfg.n_iw * cfg.n_mc
 
     # q(y|x)
+    if not training:
+        dropout = None
     hy = _layers(x, params, "Y/CATEGORICAL/ENCODER", H, bn, training, moving,
-                 new_moving)
+                 new_moving, dropout=dropout)
     logits = dense_layer(hy, params, "Y/CATEGORICAL/LOGITS", False, training,
-                         moving, None, activation=False)
+                         moving, None, activation=False, dropout=dropout)
     log_y = torch.log_softmax(logits, dim=-1)
     y = torch.exp(log_y)
     entropy = -(y * log_y).sum(dim=-1)
@@ -448,26 +454,38 @@ def gmvae_forward(cfg, params, moving, x, t, eps, training,
     p_z_means, p_z_variances, q_z_means, q_z_variances = [], [], [], []
     p_x_means, mean_of_var, var_of_mean = [], [], []
     for k in range(K):
+        dk = None
+        if dropout is not None:   # this pass's masks
+            dk = {scope: m[k] for scope, m in dropout.items()
+                  if scope.startswith(("Z/", "X/"))}
         h = _layers(x, params, "Z/Q/ENCODER", H, bn, training, moving,
-                    new_moving, extra_row=k)
+                    new_moving, extra_row=k, dropout=dk)
         q_mean = _clip_big(dense_layer(
             h, params, "Z/Q/SOFTPLUS_GAUSSIAN/MEAN", False, training, moving,
-            None, activation=False))
+            None, activation=False, dropout=dk))
         q_s = _clip_big(dense_layer(
             h, params, "Z/Q/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE", False,
-            training, moving, None, activation=False))
+            training, moving, None, activation=False, dropout=dk))
         q_sigma = torch.sqrt(F.softplus(q_s))
         z = q_mean.unsqueeze(0) + q_sigma.unsqueeze(0) * eps[k]   # [S,B,L]
-        p_mean = _clip_big(Wpm[k] + bpm)
-        p_sigma = torch.sqrt(F.softplus(_clip_big(Wps[k] + bps)))
+        # p(z|y=k): dense layers on the one-hot row (gm:3024-3040); their
+        # dropout mask [K] keeps or drops the one non-zero input
+        one_hot_m = torch.zeros(K, dtype=Wpm.dtype)
+        one_hot_m[k] = 1.0
+        one_hot_s = one_hot_m
+        if dk and "Z/P/SOFTPLUS_GAUSSIAN/MEAN" in dk:
+            one_hot_m = one_hot_m * dk["Z/P/SOFTPLUS_GAUSSIAN/MEAN"]
+            one_hot_s = one_hot_s * dk["Z/P/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE"]
+        p_mean = _clip_big(one_hot_m @ Wpm + bpm)
+        p_sigma = torch.sqrt(F.softplus(_clip_big(one_hot_s @ Wps + bps)))
 
         d = z.reshape(S * B, L)
         if decoder_extra is not None:
             d = torch.cat([d, decoder_extra.repeat(S, 1)], dim=1)
         d = _layers(d, params, "X/DECODER", H[::-1], bn, training, moving,
-                    new_moving)
+                    new_moving, dropout=dk)
         log_prob, mean_variance = _decoder_distribution(
-            cfg, d, params, "X/DISTRIBUTION/", training, moving)
+            cfg, d, params, "X/DISTRIBUTION/", training, moving, dk)
         log_p = log_prob(t_tiled).sum(dim=-1)
         log_p = log_p.reshape(S, B)
         log_p_all.append(log_p)

@@ -1389,4 +1389,53 @@ int dropout_apply(hipStream_t stream, const float* in, int ld_in, float* out, in
   return 0;
 }
 
+// rows of a [K, N] matrix scaled by the mask element (row k, column k): dropout of a one-hot
+// input, whose only non-zero is on the diagonal (the GMVAE's p(z|y=k) layers, gm:3024-3040)
+__global__ void dropout_scale_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                          int K, int N, float keep, float inv_keep,
+                                          uint32_t seed_lo, uint32_t seed_hi, uint32_t site) {
+  const int k = blockIdx.x;
+  uint32_t c[4] = {(uint32_t)k, 0u, (uint32_t)(k >> 2), 0x80000000u | site};
+  uint32_t k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const uint32_t bits = (k & 3) == 0 ? c[0] : (k & 3) == 1 ? c[1] : (k & 3) == 2 ? c[2] : c[3];
+  const float u = ((float)(bits >> 8) + 0.5f) * 5.9604644775390625e-8f;
+  const float m = u < keep ? inv_keep : 0.f;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) out[(size_t)k * N + n] = in[(size_t)k * N + n] * m;
+}
+
+int dropout_scale_rows(hipStream_t stream, const float* in, float* out, int K, int N, float keep,
+                       uint64_t seed, uint32_t site) {
+  SCVAE_ARG(in && out && K > 0 && N > 0 && keep > 0.f && keep <= 1.f);
+  hipLaunchKernelGGL(dropout_scale_rows_kernel, dim3(K), dim3(64), 0, stream, in, out, K, N, keep,
+                     1.f / keep, (uint32_t)seed, (uint32_t)(seed >> 32), site);
+  SCVAE_LAUNCH_CHECK("dropout_scale_rows_kernel");
+  return 0;
+}
+
+// out[k*B + b, :] = [x[b, :F] | one_hot(k, K)]: the input of the GMVAE's q(z|x,y=k) encoder
+// (gm:2862-2866), materialised for all K passes (needed only when that input is dropped out)
+__global__ __launch_bounds__(256) void tile_onehot_kernel(const float* __restrict__ x,
+                                                          float* __restrict__ out, int K, int B,
+                                                          int F) {
+  const int row = blockIdx.x;            // k*B + b
+  const int k = row / B, b = row % B;
+  float* o = out + (size_t)row * (F + K);
+  const float* xi = x + (size_t)b * F;
+  for (int c = threadIdx.x; c < F + K; c += 256) o[c] = c < F ? xi[c] : (c - F == k ? 1.f : 0.f);
+}
+
+int tile_onehot(hipStream_t stream, const float* x, float* out, int K, int B, int F) {
+  SCVAE_ARG(x && out && K > 0 && F > 0);
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(tile_onehot_kernel, dim3(K * B), dim3(256), 0, stream, x, out, K, B, F);
+  SCVAE_LAUNCH_CHECK("tile_onehot_kernel");
+  return 0;
+}
+
 }  // namespace scvae

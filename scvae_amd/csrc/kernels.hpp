@@ -180,5 +180,10 @@ int philox_normal(hipStream_t stream, float* out, int64_t rows, int cols, int64_
 int dropout_apply(hipStream_t stream, const float* in, int ld_in, float* out, int ld_out,
                   int64_t rows, int cols, float keep, uint64_t seed, uint32_t site,
                   int accumulate);
+// out[k, :] = in[k, :] * mask(seed, site, row k, column k) / keep (dropout of a one-hot input)
+int dropout_scale_rows(hipStream_t stream, const float* in, float* out, int K, int N, float keep,
+                       uint64_t seed, uint32_t site);
+// out[k*B + b, :] = [x[b, :] | one_hot(k)]  ([K*B, F + K])
+int tile_onehot(hipStream_t stream, const float* x, float* out, int K, int B, int F);
 
 }  // namespace scvae

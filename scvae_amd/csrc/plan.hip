@@ -185,12 +185,16 @@ int dense_input_backward(scvae_plan* p, hipStream_t s, const Dense& d, const flo
 
 int dense_forward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_in,
                          int rows, int groups, bool relu, bool training) {
+  int rc = dense_input(p, s, d, in, ld_in, rows, training, &in, &ld_in);
+  if (rc) return rc;
+  return dense_affine(p, s, d, in, ld_in, rows, groups, relu, training);
+}
+
+// fully_connected (+ batch_norm) (+ relu) on an input that already passed the dropout
+int dense_affine(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_in, int rows,
+                 int groups, bool relu, bool training) {
   const float* W = p->params + d.w;
   const float* bias = p->params + d.b;
-  {
-    int rc = dense_input(p, s, d, in, ld_in, rows, training, &in, &ld_in);
-    if (rc) return rc;
-  }
   if (!d.bn) {
     return gemm(s, false, false, in, W, bias, d.h, rows, d.n_out, d.n_in, ld_in, d.n_out, d.n_out,
                 relu ? ACT_RELU : ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes);
@@ -628,8 +632,6 @@ int scvae_plan_create(const scvae_model_config* cfg, scvae_plan** out) {
   SCVAE_ARG(cfg->latent_mode >= 0 && cfg->latent_mode <= 3);
   SCVAE_ARG(cfg->latent_mode == 0 || cfg->model_type == SCVAE_MODEL_VAE);
   for (int i = 0; i < 4; ++i) SCVAE_ARG(cfg->dropout_keep[i] >= 0.f && cfg->dropout_keep[i] <= 1.f);
-  if (cfg->model_type == SCVAE_MODEL_GMVAE)
-    for (int i = 0; i < 4; ++i) SCVAE_ARG(scvae::dropout_keep(*cfg, i) == 0.f);
   scvae_plan* p = new scvae_plan();
   p->cfg = *cfg;
   p->P = scvae::likelihood_heads(cfg->likelihood);

@@ -53,6 +53,29 @@ int build_gmvae(scvae_plan* p) {
     p->prior_off = L.n_params;
     L.n_params += ((size_t)K + ALIGN_FLOATS - 1) / ALIGN_FLOATS * ALIGN_FLOATS;
   }
+  // dropout of the input connections (gm:2946-2953, 2978-2984, 3034-3040, 3058-3065, 3080-3086,
+  // 3137-3143, 3167-3172, 3197-3202); sites: include/scvae_hip.h, scvae_dropout_apply
+  const float kh = dropout_keep(c, 0), kx = dropout_keep(c, 1), kz = dropout_keep(c, 2);
+  const float ky = dropout_keep(c, 3);
+  for (size_t i = 0; i < p->yenc.size(); ++i) {
+    p->yenc[i].keep = i == 0 ? kx : kh;
+    p->yenc[i].site = 64 + (uint32_t)i;
+  }
+  p->ylogits.keep = kh; p->ylogits.site = 80;
+  for (size_t i = 0; i < p->zenc.size(); ++i) {
+    p->zenc[i].keep = i == 0 ? kx : kh;
+    p->zenc[i].site = (uint32_t)i;
+  }
+  p->qmean.keep = kh; p->qmean.site = 16;
+  p->qscale.keep = kh; p->qscale.site = 17;
+  p->pmean.keep = ky; p->pmean.site = 24;
+  p->pscale.keep = ky; p->pscale.site = 25;
+  for (size_t i = 0; i < p->xdec.size(); ++i) {
+    p->xdec[i].keep = i == 0 ? kz : kh;
+    p->xdec[i].site = 32 + (uint32_t)i;
+  }
+  for (int j = 0; j < p->P; ++j) { p->heads[j].keep = kh; p->heads[j].site = 48 + j; }
+  p->head_k.keep = kh; p->head_k.site = 51;
   return 0;
 }
 
@@ -84,6 +107,7 @@ size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t
   for (auto& d : p->xdec) layer_ws(d, R, K, d.n_in);
   const size_t h1z = p->zenc.empty() ? F : (size_t)p->zenc[0].n_out;
   track(B, h1z, F); track(F, h1z, B);
+  if (dropout_keep(c, 1) > 0.f) { track(KB, h1z, F + K); track(F + K, h1z, KB); }
   float* logits = b.floats(B * K);
   float* yprob = b.floats(B * K);
   float* kl_y_cell = b.floats(B);
@@ -134,6 +158,22 @@ size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t
   float* zcat = E ? b.floats(R * (Lz + E)) : nullptr;
   float* dzcat = E ? b.floats(R * (Lz + E)) : nullptr;
   float* pre_k = c.k_max > 0 ? b.floats(R * F * (size_t)(c.k_max + 1)) : nullptr;
+  // dropped-out layer inputs of the training pass (kept for the weight gradients); the p(z|y)
+  // layers keep their effective (row-scaled) weights [K, L] there
+  auto drop_ws = [&](Dense& d, size_t rows) {
+    float* q = d.keep > 0.f ? b.floats(rows * (size_t)d.n_in) : nullptr;
+    if (!dry) d.in_drop = q;
+  };
+  for (auto& d : p->yenc) drop_ws(d, B);
+  drop_ws(p->ylogits, B);
+  for (auto& d : p->zenc) drop_ws(d, KB);   // zenc[0]: [K*B, F + K]
+  drop_ws(p->qmean, KB);
+  drop_ws(p->qscale, KB);
+  { Dense& d = p->pmean; float* q = d.keep > 0.f ? b.floats(K * Lz) : nullptr; if (!dry) d.in_drop = q; }
+  { Dense& d = p->pscale; float* q = d.keep > 0.f ? b.floats(K * Lz) : nullptr; if (!dry) d.in_drop = q; }
+  for (auto& d : p->xdec) drop_ws(d, R);
+  for (int j = 0; j < p->P; ++j) drop_ws(p->heads[j], R);
+  if (c.k_max > 0) drop_ws(p->head_k, R);
   if (!dry) {
     p->fused_ws = fused_ws;
     p->zcat = zcat; p->dzcat = dzcat;
@@ -160,6 +200,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const float w = a->warm_up_weight * c.kl_weight;
   const float inv_gb = 1.f / (float)GB;
   int rc;
+  p->drop_seed = a->dropout_seed;
 #define GEMM(...)                                                              \
   do {                                                                         \
     if ((rc = gemm(s, __VA_ARGS__, p->gemm_ws, p->gemm_ws_bytes))) return rc;  \
@@ -177,9 +218,10 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     h = d.h; ld = d.n_out;
   }
   const float* hy = h;
-  const int ldy = ld;
-  GEMM(false, false, hy, p->params + p->ylogits.w, p->params + p->ylogits.b, p->logits, B, K, ldy,
-       ldy, K, K, ACT_NONE, false);
+  int ldy = ld;
+  TRY(dense_input(p, s, p->ylogits, h, ld, B, training, &hy, &ldy));
+  GEMM(false, false, hy, p->params + p->ylogits.w, p->params + p->ylogits.b, p->logits, B, K,
+       p->ylogits.n_in, ldy, K, K, ACT_NONE, false);
   const float* prior = p->prior_off != NPOS ? p->params + p->prior_off : nullptr;
   TRY(categorical_fwd(s, p->logits, p->yprob, p->kl_y_cell, B, K, prior));
   if (a->q_y_logits) TRY(copy(s, p->logits, a->q_y_logits, (size_t)B * K));
@@ -189,7 +231,13 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   int ldz = F;
   for (size_t i = 0; i < p->zenc.size(); ++i) {
     Dense& d = p->zenc[i];
-    if (i == 0) {
+    if (i == 0 && training && d.keep > 0.f) {
+      // every pass drops its own elements of [x | one-hot]: K separate inputs, one GEMM
+      TRY(tile_onehot(s, a->x, d.in_drop, K, B, F));
+      TRY(dropout_apply(s, d.in_drop, F + K, d.in_drop, F + K, KB, F + K, d.keep, p->drop_seed,
+                        d.site, 0));
+      TRY(dense_affine(p, s, d, d.in_drop, F + K, KB, K, true, training));
+    } else if (i == 0) {
       // x*W[:F] + b once, then + W[F+k] per pass
       const float* W = p->params + d.w;
       GEMM(false, false, a->x, W, p->params + d.b, p->a0, B, d.n_out, F, F, d.n_out, d.n_out,
@@ -221,14 +269,30 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     set_error("GMVAE needs at least one hidden layer");
     return -1;
   }
-  GEMM(false, false, hz, p->params + p->qmean.w, p->params + p->qmean.b, p->qm, KB, L, ldz, ldz, L,
-       L, ACT_NONE, false);
-  GEMM(false, false, hz, p->params + p->qscale.w, p->params + p->qscale.b, p->qs, KB, L, ldz, ldz,
-       L, L, ACT_NONE, false);
+  const float* hz_m = hz;
+  const float* hz_s = hz;
+  int ldz_m = ldz, ldz_s = ldz;
+  TRY(dense_input(p, s, p->qmean, hz, ldz, KB, training, &hz_m, &ldz_m));
+  TRY(dense_input(p, s, p->qscale, hz, ldz, KB, training, &hz_s, &ldz_s));
+  GEMM(false, false, hz_m, p->params + p->qmean.w, p->params + p->qmean.b, p->qm, KB, L,
+       p->qmean.n_in, ldz_m, L, L, ACT_NONE, false);
+  GEMM(false, false, hz_s, p->params + p->qscale.w, p->params + p->qscale.b, p->qs, KB, L,
+       p->qscale.n_in, ldz_s, L, L, ACT_NONE, false);
   const float* Wpm = p->params + p->pmean.w;
   const float* bpm = p->params + p->pmean.b;
   const float* Wps = p->params + p->pscale.w;
   const float* bps = p->params + p->pscale.b;
+  // p(z|y=k): a dense layer on the one-hot (gm:3009-3048); its dropout keeps or drops the one
+  // non-zero input of pass k, i.e. scales row k of the weights
+  const bool prior_drop = training && p->pmean.keep > 0.f;
+  if (prior_drop) {
+    TRY(dropout_scale_rows(s, Wpm, p->pmean.in_drop, K, L, p->pmean.keep, p->drop_seed,
+                           p->pmean.site));
+    TRY(dropout_scale_rows(s, Wps, p->pscale.in_drop, K, L, p->pscale.keep, p->drop_seed,
+                           p->pscale.site));
+    Wpm = p->pmean.in_drop;
+    Wps = p->pscale.in_drop;
+  }
   float* qvar = a->cluster_stats ? p->dqs : nullptr;  // scratch, free in the forward pass
   TRY(softplus_gaussian_fwd(s, p->qm, p->qs, Wpm, bpm, Wps, bps, a->eps, p->z, p->klz, qvar, K, S,
                             B, L));
@@ -260,19 +324,25 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const int h1 = p->heads[0].n_in;
   // fused heads + likelihood (+ backward) unless the evaluate-time statistics are requested
   const int KM = c.k_max, FC = F * (KM + 1);   // piecewise categorical likelihood: unfused path
+  // (dropout: every head draws its own mask of the decoder output, so that pass is unfused)
+  const bool head_drop = training && p->heads[0].keep > 0.f;
   const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
-                     !a->p_x_mean && KM == 0;
+                     !a->p_x_mean && KM == 0 && !head_drop;
   const HeadParams hp = head_params(p);
+  const float* head_in[4] = {dch, dch, dch, dch};   // [3]: the P_K head
   if (!fused) {
+    int ldh = ld;
     for (int j = 0; j < p->P; ++j) {
       Dense& hd = p->heads[j];
-      GEMM(false, false, dch, p->params + hd.w, p->params + hd.b, p->pre[j], R, F, hd.n_in, ld, F,
-           F, ACT_NONE, false);
+      TRY(dense_input(p, s, hd, dch, ld, R, training, &head_in[j], &ldh));
+      GEMM(false, false, head_in[j], p->params + hd.w, p->params + hd.b, p->pre[j], R, F, hd.n_in,
+           ldh, F, F, ACT_NONE, false);
     }
     if (KM > 0) {
       Dense& hk = p->head_k;
-      GEMM(false, false, dch, p->params + hk.w, p->params + hk.b, p->pre_k, R, FC, hk.n_in, ld, FC,
-           FC, ACT_NONE, false);
+      TRY(dense_input(p, s, hk, dch, ld, R, training, &head_in[3], &ldh));
+      GEMM(false, false, head_in[3], p->params + hk.w, p->params + hk.b, p->pre_k, R, FC, hk.n_in,
+           ldh, FC, FC, ACT_NONE, false);
     }
   }
   if (a->p_x_mean) {
@@ -348,19 +418,21 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   if (!fused) {
     for (int j = 0; j < p->P; ++j) {
       Dense& hd = p->heads[j];
-      GEMM(true, false, dch, p->pre[j], nullptr, p->grads + hd.w, h1, F, R, ld, F, F, ACT_NONE,
-           false);
+      GEMM(true, false, head_in[j], p->pre[j], nullptr, p->grads + hd.w, h1, F, R, h1, F, F,
+           ACT_NONE, false);
       TRY(col_sum(s, p->pre[j], F, R, F, p->grads + hd.b, 1.f, 0, p->partial));
-      GEMM(false, true, p->pre[j], p->params + hd.w, nullptr, dcur, R, h1, F, F, F, h1, ACT_NONE,
-           j > 0);
+      GEMM(false, true, p->pre[j], p->params + hd.w, nullptr, head_drop ? dalt : dcur, R, h1, F, F,
+           F, h1, ACT_NONE, !head_drop && j > 0);
+      if (head_drop) TRY(dense_input_backward(p, s, hd, dalt, dcur, R, j > 0));
     }
     if (KM > 0) {   // the P_K head, same three products on [rows, F * (K + 1)]
       Dense& hk = p->head_k;
-      GEMM(true, false, dch, p->pre_k, nullptr, p->grads + hk.w, h1, FC, R, ld, FC, FC, ACT_NONE,
-           false);
+      GEMM(true, false, head_in[3], p->pre_k, nullptr, p->grads + hk.w, h1, FC, R, h1, FC, FC,
+           ACT_NONE, false);
       TRY(col_sum(s, p->pre_k, FC, R, FC, p->grads + hk.b, 1.f, 0, p->partial));
-      GEMM(false, true, p->pre_k, p->params + hk.w, nullptr, dcur, R, h1, FC, FC, FC, h1, ACT_NONE,
-           true);
+      GEMM(false, true, p->pre_k, p->params + hk.w, nullptr, head_drop ? dalt : dcur, R, h1, FC,
+           FC, FC, h1, ACT_NONE, !head_drop);
+      if (head_drop) TRY(dense_input_backward(p, s, hk, dalt, dcur, R, true));
     }
   }
   const int64_t GSB = GB * S;  // global rows per group (pass) in the decoder
@@ -388,17 +460,24 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                          L * sizeof(float), K, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : -2);
     TRY(col_sum(s, dWpm, L, K, L, p->grads + p->pmean.b, 1.f, 0, nullptr));
     TRY(col_sum(s, dWps, L, K, L, p->grads + p->pscale.b, 1.f, 0, nullptr));
+    if (prior_drop) {   // the weights saw the masked one-hot; the biases did not
+      TRY(dropout_scale_rows(s, dWpm, dWpm, K, L, p->pmean.keep, p->drop_seed, p->pmean.site));
+      TRY(dropout_scale_rows(s, dWps, dWps, K, L, p->pscale.keep, p->drop_seed, p->pscale.site));
+    }
   }
   float* dh = p->dbuf[0];
   float* dh_alt = p->dbuf[1];
   for (int q = 0; q < 2; ++q) {
     Dense& hd = q == 0 ? p->qmean : p->qscale;
     const float* dpre = q == 0 ? p->dqm : p->dqs;
-    GEMM(true, false, hz, dpre, nullptr, p->grads + hd.w, hd.n_in, L, KB, ldz, L, L, ACT_NONE,
+    const float* hq = q == 0 ? hz_m : hz_s;   // the (dropped-out) input of that layer
+    const bool drop = hd.keep > 0.f;
+    GEMM(true, false, hq, dpre, nullptr, p->grads + hd.w, hd.n_in, L, KB, hd.n_in, L, L, ACT_NONE,
          false);
     TRY(col_sum(s, dpre, L, KB, L, p->grads + hd.b, 1.f, 0, p->partial));
-    GEMM(false, true, dpre, p->params + hd.w, nullptr, dh, KB, hd.n_in, L, L, L, hd.n_in, ACT_NONE,
-         q > 0);
+    GEMM(false, true, dpre, p->params + hd.w, nullptr, drop ? dh_alt : dh, KB, hd.n_in, L, L, L,
+         hd.n_in, ACT_NONE, !drop && q > 0);
+    if (drop) TRY(dense_input_backward(p, s, hd, dh_alt, dh, KB, q > 0));
   }
   for (int i = (int)p->zenc.size() - 1; i >= 0; --i) {
     Dense& d = p->zenc[i];
@@ -411,12 +490,17 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       TRY(dense_backward_activation(p, s, d, KB, K, true, dh, scratch, GB, &da));
       const int N = d.n_out;
       float* dW = p->grads + d.w;
-      // one-hot rows: dW[F+k,:] = sum_b dA[k,b,:]
-      TRY(group_col_sum(s, da, N, B, K, N, 1.f, dW + (size_t)F * N, p->partial));
       if (!d.bn) TRY(col_sum(s, da, N, KB, N, p->grads + d.b, 1.f, 0, p->partial));
-      // data rows: dW[:F] = x^T (sum_k dA[k])
-      TRY(sum_groups(s, da, nullptr, 0, K, B, N, p->sum_scratch));
-      GEMM(true, false, a->x, p->sum_scratch, nullptr, dW, F, N, B, F, N, N, ACT_NONE, false);
+      if (d.keep > 0.f) {
+        // the K passes read K different dropped-out inputs: dW = [x | one-hot]_dropped^T dA
+        GEMM(true, false, d.in_drop, da, nullptr, dW, F + K, N, KB, F + K, N, N, ACT_NONE, false);
+      } else {
+        // one-hot rows: dW[F+k,:] = sum_b dA[k,b,:]
+        TRY(group_col_sum(s, da, N, B, K, N, 1.f, dW + (size_t)F * N, p->partial));
+        // data rows: dW[:F] = x^T (sum_k dA[k])
+        TRY(sum_groups(s, da, nullptr, 0, K, B, N, p->sum_scratch));
+        GEMM(true, false, a->x, p->sum_scratch, nullptr, dW, F, N, B, F, N, N, ACT_NONE, false);
+      }
     }
   }
 
@@ -432,9 +516,11 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     TRY(col_sum(s, p->dlogits, K, B, K, p->grads + hd.b, 1.f, 0, p->partial));
     dh = p->dbuf[0];
     dh_alt = p->dbuf[1];
-    if (!p->yenc.empty())
+    if (!p->yenc.empty()) {
       GEMM(false, true, p->dlogits, p->params + hd.w, nullptr, dh, B, hd.n_in, K, K, K, hd.n_in,
            ACT_NONE, false);
+      if (hd.keep > 0.f) TRY(dense_input_backward(p, s, hd, dh, dh, B, false));
+    }
   }
   for (int i = (int)p->yenc.size() - 1; i >= 0; --i) {
     Dense& d = p->yenc[i];

@@ -465,7 +465,9 @@ class ModelBase:
                 scalars = engine.step(
                     xb, tb, eps=eps, row_const=rc, training=True, n_iw=n_iw,
                     n_mc=n_mc, warm_up_weight=warm_up_weight,
-                    global_cells=global_cells, decoder_extra=de)
+                    global_cells=global_cells, decoder_extra=de,
+                    dropout_seed=((self.noise_seed * 1000003 + rank) << 40)
+                    + step + 1)
                 if sync is not None:
                     sync.all_reduce_gradients()
                 engine.adam_step(learning_rate)

@@ -167,11 +167,26 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
         if dropout is None:
             dropout = dm["dropout_keep_probabilities"]
         self.dropout_keep_probabilities = dropout
+        # keep probabilities for 4 kinds of layers: [h, x, z, y] (gm:281-305)
+        self.dropout_keep_probability_y = False
+        self.dropout_keep_probability_z = False
+        self.dropout_keep_probability_x = False
+        self.dropout_keep_probability_h = False
         self.dropout_parts = []
         if isinstance(dropout, (list, tuple)):
+            if len(dropout) >= 4:
+                self.dropout_keep_probability_y = dropout[3]
+            if len(dropout) >= 3:
+                self.dropout_keep_probability_z = dropout[2]
+            if len(dropout) >= 2:
+                self.dropout_keep_probability_x = dropout[1]
+            if len(dropout) >= 1:
+                self.dropout_keep_probability_h = dropout[0]
             self.dropout_parts = [str(p) for p in dropout if p and p != 1]
-        elif dropout and dropout != 1:
-            self.dropout_parts = [str(dropout)]
+        else:
+            self.dropout_keep_probability_h = dropout
+            if dropout and dropout != 1:
+                self.dropout_parts = [str(dropout)]
 
         count_sum = kwargs.get("count_sum")
         if count_sum is None:
@@ -208,8 +223,6 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
             raise mu.not_in_this_build(
                 "Count sum as a likelihood parameter (constrained Poisson, "
                 "multinomial)", "gm:3118-3125")
-        if self.dropout_parts:
-            raise mu.not_in_this_build("Dropout", "mu:45-50")
         if self.latent_distribution_name != "gaussian mixture":
             raise mu.not_in_this_build(
                 "Latent distribution `{}`".format(
@@ -239,7 +252,12 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
                 self.proportion_of_free_nats_for_y_kl_divergence),
             decoder_extra=self.decoder_extra_size, k_max=self.k_max,
             prior_probabilities_method=self.prior_probabilities_method,
-            prior_probabilities=self.prior_probabilities)
+            prior_probabilities=self.prior_probabilities,
+            dropout_keep_probabilities=(
+                self.dropout_keep_probability_h,
+                self.dropout_keep_probability_x,
+                self.dropout_keep_probability_z,
+                self.dropout_keep_probability_y))
 
     def _parameter_shapes(self):
         table = []

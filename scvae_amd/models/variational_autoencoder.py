@@ -134,11 +134,23 @@ class VariationalAutoencoder(ModelBase):
         if dropout is None:
             dropout = dm["dropout_keep_probabilities"]
         self.dropout_keep_probabilities = dropout
+        # keep probabilities for 3 kinds of layers: [h, x, z] (va:245-269)
+        self.dropout_keep_probability_z = False
+        self.dropout_keep_probability_x = False
+        self.dropout_keep_probability_h = False
         self.dropout_parts = []
         if isinstance(dropout, (list, tuple)):
+            if len(dropout) >= 3:
+                self.dropout_keep_probability_z = dropout[2]
+            if len(dropout) >= 2:
+                self.dropout_keep_probability_x = dropout[1]
+            if len(dropout) >= 1:
+                self.dropout_keep_probability_h = dropout[0]
             self.dropout_parts = [str(p) for p in dropout if p and p != 1]
-        elif dropout and dropout != 1:
-            self.dropout_parts = [str(dropout)]
+        else:
+            self.dropout_keep_probability_h = dropout
+            if dropout and dropout != 1:
+                self.dropout_parts = [str(dropout)]
 
         count_sum = kwargs.get("count_sum")
         if count_sum is None:
@@ -179,8 +191,6 @@ class VariationalAutoencoder(ModelBase):
             raise mu.not_in_this_build(
                 "Count sum as a likelihood parameter (constrained Poisson, "
                 "multinomial)", "va:2400-2433")
-        if self.dropout_parts:
-            raise mu.not_in_this_build("Dropout", "mu:45-50")
         for architecture in (self.inference_architecture,
                              self.generative_architecture):
             if architecture not in ("MLP", "LFM"):
@@ -214,7 +224,11 @@ class VariationalAutoencoder(ModelBase):
             inference_architecture=self.inference_architecture,
             generative_architecture=self.generative_architecture,
             latent_distribution=self.latent_distribution_name,
-            analytical_kl_term=bool(self.analytical_kl_term))
+            analytical_kl_term=bool(self.analytical_kl_term),
+            dropout_keep_probabilities=(
+                self.dropout_keep_probability_h,
+                self.dropout_keep_probability_x,
+                self.dropout_keep_probability_z))
 
     def _parameter_shapes(self):
         table = []

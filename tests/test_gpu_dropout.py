@@ -210,3 +210,157 @@ def test_default_seed_changes_every_step(cuda_device):
     eng = Engine(F, L, H, "poisson", device=cuda_device,
                  dropout_keep_probabilities=(1, False, 0))
     assert not eng.uses_dropout
+
+
+# ------------------------------- GMVAE -------------------------------------
+
+def _gmvae_masks(eng, cfg, B, S, keeps, k_max=0):
+    """{oracle layer scope: mask / keep}; the layers under Z/ and X/ carry a
+    leading axis of K passes (the HIP path stacks the passes' rows)."""
+    kh, kx, kz, ky = keeps
+    H = list(cfg.hidden_sizes)
+    K, F, L = cfg.n_clusters, cfg.feature_size, cfg.latent_size
+    masks = {}
+
+    def add(scope, site, rows, width, keep, passes=0):
+        if not keep:
+            return
+        if passes:
+            m = eng.dropout_mask(site, passes * rows, width, keep, SEED)
+            masks[scope] = m.view(passes, rows, width).cpu().double()
+        else:
+            masks[scope] = eng.dropout_mask(
+                site, rows, width, keep, SEED).cpu().double()
+
+    width = F
+    for i, h in enumerate(H):
+        add("Y/CATEGORICAL/ENCODER/LAYER_{}".format(i + 1), 64 + i, B, width,
+            kx if i == 0 else kh)
+        width = h
+    add("Y/CATEGORICAL/LOGITS", 80, B, width, kh)
+    width = F + K
+    for i, h in enumerate(H):
+        add("Z/Q/ENCODER/LAYER_{}".format(i + 1), i, B, width,
+            kx if i == 0 else kh, passes=K)
+        width = h
+    add("Z/Q/SOFTPLUS_GAUSSIAN/MEAN", 16, B, width, kh, passes=K)
+    add("Z/Q/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE", 17, B, width, kh, passes=K)
+    if ky:   # [K passes, K one-hot columns]
+        for scope, site in (("MEAN", 24), ("SOFTPLUS_SCALE", 25)):
+            masks["Z/P/SOFTPLUS_GAUSSIAN/" + scope] = eng.dropout_mask(
+                site, K, K, ky, SEED).cpu().double()
+    width = L
+    for i, h in enumerate(H[::-1]):
+        add("X/DECODER/LAYER_{}".format(i + 1), 32 + i, S * B, width,
+            kz if i == 0 else kh, passes=K)
+        width = h
+    for j, head in enumerate(cfg.heads):
+        add("X/DISTRIBUTION/" + head.upper(), 48 + j, S * B, width, kh,
+            passes=K)
+    if k_max:
+        add("X/DISTRIBUTION/P_K", 51, S * B, width, kh, passes=K)
+    return masks
+
+
+@pytest.mark.parametrize("keeps", [
+    (0.8, 0.0, 0.0, 0.0), (0.0, 0.9, 0.0, 0.0), (0.0, 0.0, 0.7, 0.0),
+    (0.0, 0.0, 0.0, 0.5), (0.8, 0.9, 0.7, 0.6)])
+@pytest.mark.parametrize("likelihood,k_max,S,bn", [
+    ("negative binomial", 0, 1, True),
+    ("zero-inflated poisson", 0, 2, True),
+    ("poisson", 2, 1, False),
+])
+def test_gmvae_train_step_matches_oracle(cuda_device, keeps, likelihood,
+                                         k_max, S, bn):
+    from scvae_amd.engine import Engine
+    F, L, H, B, K = 90, 5, (18, 14), 27, 4
+    eng = Engine(F, L, H, likelihood, batch_norm=bn, model_type="GMVAE",
+                 n_clusters=K, device=cuda_device, k_max=k_max,
+                 dropout_keep_probabilities=keeps)
+    g = torch.Generator().manual_seed(1)
+    for name, p in eng.named_parameters().items():
+        if not name.endswith("weights"):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    cfg = om.ModelConfig(feature_size=F, latent_size=L, hidden_sizes=H,
+                         likelihood=likelihood, minibatch_normalisation=bn,
+                         n_clusters=K, n_iw=S, n_mc=1, k_max=k_max)
+    params = {k: v.detach().cpu().double()
+              for k, v in eng.named_parameters().items()}
+    moving = {k: v.detach().cpu().double()
+              for k, v in eng.named_moving_statistics().items()}
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(_counts(rng, B, F))
+    eps = torch.from_numpy(rng.standard_normal((K, S, B, L)))
+    masks = _gmvae_masks(eng, cfg, B, S, keeps, k_max)
+    assert masks
+
+    xd = x.float().to(cuda_device)
+    ll = torch.zeros(K * S * B, device=cuda_device)
+    sc = eng.step(xd, xd, eps=eps.float().to(cuda_device), training=True,
+                  n_iw=S, n_mc=1, warm_up_weight=0.7, dropout_seed=SEED,
+                  outputs={"log_p_x_given_z": ll}).cpu().numpy()
+    torch.cuda.synchronize()
+    new_moving = {}
+    out, grads = om.gradients(
+        lambda p: om.gmvae_forward(cfg, p, moving, x, x, eps, True, 0.7,
+                                   new_moving, dropout=masks), params)
+    _close(sc[0], out["lower_bound"], what="lower_bound")
+    _close(sc[1], out["lower_bound_weighted"], what="lower_bound_weighted")
+    _close(sc[3], out["kl_divergence_z"], what="kl_divergence_z")
+    _close(sc[4], out["kl_divergence_y"], rtol=2e-4, what="kl_divergence_y")
+    _close(ll.cpu(), out["log_p_x_given_z"].reshape(-1), what="per-cell ll")
+    for name, g in eng.named_gradients().items():
+        if bn and name.endswith("DENSE/biases") and "LAYER_" in name:
+            continue
+        got, want = g.cpu(), grads[name]
+        if (bn and name == "Z/Q/ENCODER/LAYER_1/DENSE/weights"
+                and not keeps[1]):
+            got, want = got[:F], want[:F]   # one-hot rows: cancelled by BN
+        _close(got, want, rtol=3e-4, what="grad " + name)
+    for name, m in eng.named_moving_statistics().items():
+        _close(m.cpu(), new_moving[name], rtol=2e-5, what="moving " + name)
+
+    # evaluation: no dropout
+    sc = eng.step(xd, xd, eps=eps.float().to(cuda_device), training=False,
+                  n_iw=S, n_mc=1).cpu().numpy()
+    moving = {k: v.detach().cpu().double()
+              for k, v in eng.named_moving_statistics().items()}
+    out = om.gmvae_forward(cfg, params, moving, x, x, eps, False,
+                           dropout=masks)
+    _close(sc[0], out["lower_bound"], what="lower_bound (evaluation)")
+
+
+# ----------------------------- model classes --------------------------------
+
+def _toy_data(n=120, F=40):
+    from scvae_amd.data import DataSet
+    rng = np.random.default_rng(5)
+    x = rng.poisson(2.0, size=(n, F)).astype(np.float32)
+    return DataSet("toy", values=x, example_names=np.arange(n).astype(str),
+                   feature_names=np.arange(F).astype(str), kind="training")
+
+
+def test_model_classes_train_with_dropout(cuda_device, tmp_path):
+    from scvae_amd.models import (
+        GaussianMixtureVariationalAutoencoder, VariationalAutoencoder)
+    from scvae_amd.models.utilities import load_learning_curves
+    data = _toy_data()
+    for cls, keeps, extra in (
+            (VariationalAutoencoder, [0.9, 0.8, 0.7], {}),
+            (GaussianMixtureVariationalAutoencoder, [0.9, 0.8, 0.7, 0.6],
+             {"number_of_latent_clusters": 3})):
+        model = cls(feature_size=40, latent_size=3, hidden_sizes=[12, 10],
+                    reconstruction_distribution="negative binomial",
+                    dropout_keep_probabilities=keeps,
+                    log_directory=str(tmp_path), **extra)
+        assert "dropout_" + "_".join(map(str, keeps)) in model.name
+        assert model.train(data, data, number_of_epochs=3,
+                           minibatch_size=30, learning_rate=1e-2) == 0
+        assert model.engine.uses_dropout
+        curves = load_learning_curves(model)
+        # the epoch evaluations run without dropout and improve
+        lb = curves["validation"]["lower_bound"]
+        assert np.isfinite(lb).all() and lb[-1] > lb[0]
+        out = model.evaluate(data, minibatch_size=30,
+                             output_versions="reconstructed")
+        assert np.isfinite(out.values).all()

@@ -85,8 +85,21 @@ def test_constructor_errors():
                                    batch_correction=True, number_of_batches=2,
                                    count_sum=True)
     assert model.k_max == 3 and model.decoder_extra_size == 3
-    with pytest.raises(NotImplementedError):
-        VariationalAutoencoder(10, dropout_keep_probabilities=[0.9])
+    # built: dropout, the sampled KL term, the unit-variance posterior
+    model = VariationalAutoencoder(10, dropout_keep_probabilities=[0.9, 1, 0.5])
+    assert (model.dropout_keep_probability_h, model.dropout_keep_probability_x,
+            model.dropout_keep_probability_z) == (0.9, 1, 0.5)
+    assert model.name.endswith("dropout_0.9_0.5")
+    assert model._engine_arguments()["dropout_keep_probabilities"] == (
+        0.9, 1, 0.5)
+    model = VariationalAutoencoder(
+        10, latent_distribution="unit-variance gaussian")
+    assert model.analytical_kl_term is False
+    assert not any("LOG_SIGMA" in name
+                   for name, _ in model._parameter_shapes())
+    model = GaussianMixtureVariationalAutoencoder(
+        10, dropout_keep_probabilities=[0.9, 0.8, 0.7, 0.6])
+    assert model.dropout_keep_probability_y == 0.6
     learned = GaussianMixtureVariationalAutoencoder(
         10, prior_probabilities_method="learn")
     assert ("Y/P/LOGITS", (learned.n_clusters,)) == learned._parameter_shapes()[0]
