@@ -182,6 +182,49 @@ def test_csr_densify(cuda_device):
     assert np.allclose(lg.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("F", [1, 3, 5, 4097, 8191, 8192, 8193, 16390, 20001])
+def test_csr_densify_segments_and_alignment(cuda_device, F):
+    """Widths around the 8192-column segments, odd row pitches (every
+    misalignment of a row start), unsorted column indices; a canary row after
+    the output must stay untouched."""
+    import scipy.sparse as sp
+    from scvae_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(F)
+    N = 9
+    dense = (rng.poisson(0.2, size=(N, F))
+             * rng.integers(1, 50, size=(N, F))).astype(np.float32)
+    dense[3] = 0
+    dense[:, 0] = 7
+    dense[:, F - 1] = 9
+    m = sp.csr_matrix(dense)
+    # shuffle the entries inside every row: the kernel assumes no order
+    data, idx = m.data.copy(), m.indices.copy()
+    for r in range(N):
+        lo, hi = m.indptr[r], m.indptr[r + 1]
+        perm = rng.permutation(hi - lo)
+        data[lo:hi] = data[lo:hi][perm]
+        idx[lo:hi] = idx[lo:hi][perm]
+    indptr = torch.from_numpy(m.indptr.astype(np.int64)).to(cuda_device)
+    indices = torch.from_numpy(idx.astype(np.int32)).to(cuda_device)
+    values = torch.from_numpy(data.astype(np.float32)).to(cuda_device)
+    order = [8, 3, 0, 5, 5, 1, 2]
+    rows = torch.tensor(order, dtype=torch.int64, device=cuda_device)
+    for offset in range(4):   # start of the output buffer: any 4-byte phase
+        buf = torch.full((offset + (len(order) + 1) * F,), -1.0,
+                         device=cuda_device)
+        out = buf[offset:]
+        _lib.check(lib.scvae_csr_densify(
+            _p(indptr), _p(indices), _p(values), _p(rows), len(order), F,
+            ctypes.c_void_p(out.data_ptr()), _stream()), "densify")
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert np.array_equal(got[:len(order) * F].reshape(-1, F),
+                              dense[order]), (F, offset)
+        assert (got[len(order) * F:] == -1).all() and (
+            buf[:offset].cpu().numpy() == -1).all()
+
+
 def test_gemm_small_shape_sweep(cuda_device):
     """Every transpose combination over a grid of small / ragged shapes (the
     [rows, <=128] layers of the model), with and without accumulation."""
