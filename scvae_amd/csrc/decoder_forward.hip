@@ -1,0 +1,271 @@
+// Forward-only decoder output layer: X_TILDE heads + count likelihood + row sum in one kernel,
+// for the graph executions with is_training = False (the epoch-end evaluations of train(),
+// va:1092-1150 / 1251-1304, evaluate(), va:1969-2055) and the first pass of an importance-
+// weighted training step.  Same inputs and per-strip partial buffer as the training kernels
+// (decoder_fused.hip), a different organisation, because nothing has to go back to the matrix
+// cores after the likelihood:
+//
+//   * a workgroup owns a 64-gene strip (weights and biases in LDS for the whole kernel); its waves
+//     walk over their own 32-row tiles independently -- no workgroup barrier in the loop, and no
+//     LDS staging of d: in the k-slot layout chosen below a lane's share of the d tile is one
+//     contiguous run of its row, read from L2 with 8-byte loads into the registers that feed the
+//     MFMAs (the next tile's run is requested as soon as the last MFMA of the tile is issued);
+//   * a wave computes the TRANSPOSED head tile pre_j^T[gene, row] = W_j^T d^T with
+//     v_mfma_f32_32x32x2: in the result layout a lane then holds 16 genes of ONE row, so the
+//     likelihood of its 16 elements sums into one register, and the row sum of the tile is that
+//     register plus the one of lane ^ 32.  The pre-activations never leave the registers;
+//   * the bias rides along as an extra contraction step (d gets a ones column, W_j the bias row);
+//   * t is read from HBM straight into that register layout (8-byte loads), in flight under
+//     the MFMAs;
+//   * the t > 0 corrections of the negative-binomial kinds, lgamma(r+t) - lgamma(r), are the
+//     expensive part of an element but needed for 5 % of them: each lane walks over its own
+//     non-zero elements (bit mask + find-first-set), so the cost follows the largest count of a
+//     lane (about 3 of 16) instead of 16.
+//
+// MFMA work 2 * P * (H + 2) flop per element; algorithmic HBM traffic 4 B per element (t).
+#include <type_traits>
+
+#include "common.hpp"
+#include "kernels.hpp"
+#include "likelihood.hpp"
+
+namespace scvae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int FW_BN = 64;         // genes per workgroup (= the strip width of ll_part)
+constexpr int FW_LD = FW_BN + 1;  // odd LDS row stride of the weight strip
+constexpr int FW_BM = 32;         // rows per wave tile
+constexpr int FW_HMAX = 126;
+
+// contraction length: H, the ones column (bias), zero padding up to a multiple of 8, so that each
+// of the two k-slots covers a multiple of 4 positions.  The number of MFMA steps, HK / 2, is a
+// template parameter of the kernel (in units of 4 steps): the d operands live in registers, which
+// only works with compile-time indices, and a guard per step makes the compiler copy the
+// accumulators at every merge point.
+__host__ __device__ inline int fw_hk(int H) { return (H + 8) / 8 * 8; }
+
+static size_t fw_lds_bytes(int P, int H) { return (size_t)P * fw_hk(H) * FW_LD * sizeof(float); }
+bool decoder_forward_supported(int P, int H) {
+  return H >= 2 && H <= FW_HMAX && (H % 2) == 0 && fw_lds_bytes(P, H) <= 160 * 1024;
+}
+
+// One of 16 registers by a per-lane index: a binary tree of 15 v_cndmask under the four lane masks
+// of the index bits.  (Written with inline asm: as C++ selects the compiler folds the tree into a
+// dynamically indexed array, which for a per-lane index means scratch memory.)
+struct IndexMasks { unsigned long long m[4]; };
+__device__ __forceinline__ IndexMasks index_masks(int idx) {
+  IndexMasks k;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) k.m[b] = __builtin_amdgcn_ballot_w64((idx >> b) & 1);
+  return k;
+}
+__device__ __forceinline__ float cnd(float lo, float hi, unsigned long long mask) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(lo), "v"(hi), "s"(mask));
+  return r;
+}
+__device__ __forceinline__ float select16(const float (&v)[16], const IndexMasks& k) {
+  float a[8], b[4], c[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = cnd(v[2 * i], v[2 * i + 1], k.m[0]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b[i] = cnd(a[2 * i], a[2 * i + 1], k.m[1]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) c[i] = cnd(b[2 * i], b[2 * i + 1], k.m[2]);
+  return cnd(c[0], c[1], k.m[3]);
+}
+
+template <int KIND, int KS4>
+__global__ __launch_bounds__(512) void decoder_forward_kernel(
+    const float* __restrict__ d, int R, int H, HeadParams hp, int F, const float* __restrict__ t,
+    int B, int inline_lgamma, float* __restrict__ ll_part) {
+  using Traits = LikelihoodTraits<KIND>;
+  constexpr int P = Traits::P;
+  constexpr int NW = 8;
+  constexpr int BN = FW_BN, LD = FW_LD, BM = FW_BM;
+  extern __shared__ __attribute__((aligned(16))) float Ws[];   // [P][HK][LD]; row H = bias
+  constexpr int HS = 4 * KS4;         // MFMA steps; k-slot kh covers positions [kh*HS, kh*HS+HS)
+  constexpr int HK = 2 * HS;          // == fw_hk(H)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int c0 = blockIdx.x * BN;
+
+  // ---- strip weights (rows 0..H-1), biases (row H), zeros (rows H+1..HK-1) -> LDS, once ----
+  {
+    const int c = tid & (BN - 1);
+    const bool col_ok = c0 + c < F;
+    const int rows_per_pass = NW;                      // NW * 64 threads = NW rows of 64 genes
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const float* Wj = hp.W[j] + c0 + c;
+      float* dst = Ws + (size_t)j * HK * LD + c;
+      int pos = tid >> 6;
+      for (; pos + 7 * rows_per_pass < H; pos += 8 * rows_per_pass) {   // 8 loads in flight
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          v[u] = col_ok ? Wj[(size_t)(pos + u * rows_per_pass) * F] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dst[(size_t)(pos + u * rows_per_pass) * LD] = v[u];
+      }
+      for (; pos < HK; pos += rows_per_pass) {
+        float v = 0.f;
+        if (col_ok) {
+          if (pos < H) v = Wj[(size_t)pos * F];
+          else if (pos == H) v = hp.b[j][c0 + c];
+        }
+        dst[(size_t)pos * LD] = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- this lane's share of a d tile: row li, positions [kh*HS, kh*HS + HS), as the B operand
+  //      of step s in dB[s].  H is even and HS is even: pairs never straddle H. ----
+  float dB[HS];
+  auto load_d = [&](int m0) {
+    const int row = min(m0 + li, R - 1);             // (rows beyond R: results are not stored)
+    const float* src = d + (size_t)row * H + kh * HS;
+    const int p0 = kh * HS;
+#pragma unroll
+    for (int q = 0; q < HS / 2; ++q) {
+      const int pos = p0 + 2 * q;
+      float2 v;
+      if (pos < H) v = *reinterpret_cast<const float2*>(src + 2 * q);
+      else v = make_float2(pos == H ? 1.f : 0.f, 0.f);
+      dB[2 * q] = v.x; dB[2 * q + 1] = v.y;
+    }
+  };
+  const bool pairs = (F & 1) == 0;     // 8-byte loads of t: every row start is 8-byte aligned
+  const int n_tiles = (R + BM - 1) / BM;
+
+  load_d(w * BM);
+  for (int tile = w; tile < n_tiles; tile += NW) {
+    const int m0 = tile * BM;
+    const int row = m0 + li;
+    const bool row_ok = row < R;
+    const float* trow = t + (size_t)((row_ok ? row : R - 1) % B) * F;
+    float lane_sum = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      // ---- t of this lane's 16 elements: genes cbase + 8*(i>>2) + (i&3), row li ----
+      const int cbase = c0 + cb * 32 + 4 * kh;
+      float tv[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = cbase + 8 * g;
+        if (pairs) {
+          const float2 lo = (c + 1 < F) ? *reinterpret_cast<const float2*>(trow + c)
+                                        : make_float2(0.f, 0.f);
+          const float2 hi = (c + 3 < F) ? *reinterpret_cast<const float2*>(trow + c + 2)
+                                        : make_float2(0.f, 0.f);
+          tv[4 * g] = lo.x; tv[4 * g + 1] = lo.y; tv[4 * g + 2] = hi.x; tv[4 * g + 3] = hi.y;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) tv[4 * g + u] = (c + u < F) ? trow[c + u] : 0.f;
+        }
+      }
+      // ---- pre_j^T[gene, row] = sum_pos Ws_j[pos, gene] * d[row, pos] ----
+      f32x16 acc[P];
+#pragma unroll
+      for (int j = 0; j < P; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+      const float* ap = Ws + (size_t)(kh * HS) * LD + cb * 32 + li;   // A[m = gene][k-slot kh]
+#pragma unroll
+      for (int s = 0; s < HS; ++s)
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(j * HK + s) * LD], dB[s], acc[j], 0, 0,
+                                                        0);
+      // the d registers are free again: request this wave's next tile, it arrives during the
+      // likelihood math below
+      if (cb == 1) load_d(m0 + NW * BM);
+      // ---- likelihood of the 16 elements ----
+      unsigned nz = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float a[P], lp, g[P], r, rgate;
+#pragma unroll
+        for (int j = 0; j < P; ++j) a[j] = acc[j][i];
+        lik_dense<KIND, false>(tv[i], a, lp, g, r, rgate);
+        const int c = cbase + 8 * (i >> 2) + (i & 3);
+        lane_sum += (c < F) ? lp : 0.f;
+        nz |= (tv[i] > 0.f) ? (1u << i) : 0u;    // (t of a gene beyond F was loaded as 0)
+        // four elements at a time: the 16 are independent, interleaving all of them only
+        // costs registers
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- t > 0: + lgamma(r+t) - lgamma(r)  [- lgamma(1+t) unless the caller adds it] ----
+      if (Traits::HAS_R || inline_lgamma) {
+        while (__builtin_amdgcn_ballot_w64(nz != 0) != 0) {
+          const bool on = nz != 0;
+          const int idx = on ? __builtin_ctz(nz) : 0;
+          nz &= nz - 1;
+          const IndexMasks km = index_masks(idx);
+          const float tt = select16(tv, km);
+          float corr = 0.f;
+          if (Traits::HAS_R) {
+            // total_count = exp(clip(log_r pre-activation)), the last head (du:266-305)
+            float lr[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) lr[i] = acc[P - 1][i];
+            const float r = __expf(fminf(fmaxf(select16(lr, km), -10.f), 10.f));
+            // one form for the whole wave: the product recurrence if every pending count is a
+            // small integer, else the general form (exact for those as well)
+            const bool small = !on || (tt <= 8.f && tt == __builtin_rintf(tt));
+            float A, D;
+            if (__builtin_amdgcn_ballot_w64(!small) == 0)
+              lgamma_digamma_diff_small<false>(r, on ? tt : 0.f, A, D);
+            else
+              lgamma_digamma_diff_general<false>(r, on ? tt : 1.f, A, D);
+            corr = A;
+          }
+          if (inline_lgamma) corr -= lgamma1p(tt);
+          lane_sum += on ? corr : 0.f;
+        }
+      }
+    }
+    // row sum of the strip: this lane's 32 genes + the 32 of lane ^ 32
+    lane_sum += __shfl_xor(lane_sum, 32, 64);
+    if (kh == 0 && row_ok) ll_part[(size_t)blockIdx.x * R + row] = lane_sum;
+  }
+}
+
+int decoder_forward_launch(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
+                           int F, const float* t, int B, int inline_lgamma, float* ll_part) {
+  const int P = likelihood_heads(kind);
+  const size_t lds = fw_lds_bytes(P, H);
+  const int strips = (F + FW_BN - 1) / FW_BN;
+#define SCVAE_FW(K_, KS_)                                                                       \
+  case KS_: {                                                                                   \
+    auto kfn = decoder_forward_kernel<K_, KS_>;                                                 \
+    SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                          \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
+    hipLaunchKernelGGL(kfn, dim3(strips), dim3(512), lds, s, d, rows, H, hp, F, t, B,           \
+                       inline_lgamma, ll_part);                                                 \
+  } break
+#define SCVAE_FWK(K_)                                                                           \
+  switch (fw_hk(H) / 8) {                                                                       \
+    SCVAE_FW(K_, 1); SCVAE_FW(K_, 2); SCVAE_FW(K_, 3); SCVAE_FW(K_, 4); SCVAE_FW(K_, 5);        \
+    SCVAE_FW(K_, 6); SCVAE_FW(K_, 7); SCVAE_FW(K_, 8); SCVAE_FW(K_, 9); SCVAE_FW(K_, 10);       \
+    SCVAE_FW(K_, 11); SCVAE_FW(K_, 12); SCVAE_FW(K_, 13); SCVAE_FW(K_, 14); SCVAE_FW(K_, 15);   \
+    SCVAE_FW(K_, 16);                                                                           \
+    default: set_error("decoder_forward: hidden size %d", H); return -1;                        \
+  }
+  switch (kind) {
+    case LK_POISSON: SCVAE_FWK(LK_POISSON); break;
+    case LK_NB: SCVAE_FWK(LK_NB); break;
+    case LK_ZIP: SCVAE_FWK(LK_ZIP); break;
+    case LK_ZINB: SCVAE_FWK(LK_ZINB); break;
+    default: set_error("unknown likelihood kind %d", kind); return -1;
+  }
+#undef SCVAE_FWK
+#undef SCVAE_FW
+  SCVAE_LAUNCH_CHECK("decoder_forward_kernel");
+  return 0;
+}
+
+}  // namespace scvae

@@ -510,8 +510,18 @@ int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int
   if (rows == 0) return 0;
   const int strips = (F + DF_BN - 1) / DF_BN;
   float* ll_part = workspace;
-  int rc = launch_decoder<false>(s, kind, d, rows, H, hp, F, t, B, nullptr, row_const ? 0 : 1, ll_part,
-                                 nullptr);
+  // the register-resident forward kernel (decoder_forward.hip) where its LDS budget allows;
+  // SCVAE_DECODER_FORWARD=0 keeps the forward instantiation of the training kernels (A/B runs)
+  static const bool use_forward = [] {
+    const char* e = getenv("SCVAE_DECODER_FORWARD");
+    return !(e && e[0] == '0');
+  }();
+  int rc;
+  if (use_forward && decoder_forward_supported(likelihood_heads(kind), H))
+    rc = decoder_forward_launch(s, kind, d, rows, H, hp, F, t, B, row_const ? 0 : 1, ll_part);
+  else
+    rc = launch_decoder<false>(s, kind, d, rows, H, hp, F, t, B, nullptr, row_const ? 0 : 1,
+                               ll_part, nullptr);
   if (rc) return rc;
   hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 15) / 16), dim3(1024), 0, s, ll_part, strips,
                      rows, row_const, B, ll);

@@ -121,6 +121,11 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
                         int F, const float* t, int B, const float* gw, const float* row_const,
                         float* ll, float* dd, float* workspace, bool kernel_only = false);
 
+// forward-only variant with the pre-activations in registers (decoder_forward.hip)
+bool decoder_forward_supported(int P, int H);
+int decoder_forward_launch(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
+                           int F, const float* t, int B, int inline_lgamma, float* ll_part);
+
 // ---- gmvae_kernels.hip ----
 int add_group_rows(hipStream_t s, const float* a0, const float* rows, float* out, int K, int B,
                    int N, int relu);
