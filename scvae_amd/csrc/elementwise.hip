@@ -742,33 +742,6 @@ int bn_apply(hipStream_t stream, const float* a, int lda, const float* mean, con
   return 0;
 }
 
-// moving <- moving - (moving - batch) * (1 - decay), applied group after group (the K
-// passes of the GMVAE share one pair of moving statistics); variance is Bessel-corrected.
-__global__ void bn_update_moving_kernel(const float* __restrict__ mean,
-                                        const float* __restrict__ var, int R, int groups, int N,
-                                        float* __restrict__ moving_mean,
-                                        float* __restrict__ moving_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
-  float mm = moving_mean[c], mv = moving_var[c];
-  const float bessel = (float)R / (float)(R > 1 ? R - 1 : 1);
-  for (int g = 0; g < groups; ++g) {
-    mm -= (mm - mean[(size_t)g * N + c]) * BN_UPDATE_RATE;
-    mv -= (mv - var[(size_t)g * N + c] * bessel) * BN_UPDATE_RATE;
-  }
-  moving_mean[c] = mm;
-  moving_var[c] = mv;
-}
-
-int bn_update_moving(hipStream_t stream, const float* mean, const float* var, int rows_per_group,
-                     int groups, int N, float* moving_mean, float* moving_var) {
-  SCVAE_ARG(mean && var && moving_mean && moving_var && N > 0);
-  hipLaunchKernelGGL(bn_update_moving_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, mean, var,
-                     rows_per_group, groups, N, moving_mean, moving_var);
-  SCVAE_LAUNCH_CHECK("bn_update_moving_kernel");
-  return 0;
-}
-
 // s1[g,c] = sum_r dA, s2[g,c] = sum_r dA * xhat with dA = dh * (h > 0) [relu];
 // row-chunked partial sums + fixed-order finalize
 __global__ __launch_bounds__(1024) void bn_bwd_stats_partial_kernel(
@@ -912,15 +885,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   }
 }
 
-__global__ void bn_dbeta_kernel(const float* __restrict__ s1, int groups, int N,
-                                float* __restrict__ dbeta, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
-  float s = 0.f;
-  for (int g = 0; g < groups; ++g) s += s1[(size_t)g * N + c];
-  dbeta[c] = accumulate ? dbeta[c] + s : s;
-}
-
 int bn_bwd_apply(hipStream_t stream, const float* dh, int lddh, const float* h, int ldh,
                  const float* a, int lda, const float* mean, const float* var, const float* s1,
                  const float* s2, int rows_per_group, int groups, int N, int relu, float inv_count,
@@ -933,15 +897,6 @@ int bn_bwd_apply(hipStream_t stream, const float* dh, int lddh, const float* h, 
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, stream, dh, lddh, h, ldh, a,
                      lda, mean, var, s1, s2, rows_per_group, groups, N, relu, inv_count, da, ldda);
   SCVAE_LAUNCH_CHECK("bn_bwd_apply_kernel");
-  return 0;
-}
-
-int bn_dbeta(hipStream_t stream, const float* s1, int groups, int N, float* dbeta,
-             int accumulate) {
-  SCVAE_ARG(s1 && dbeta && N > 0);
-  hipLaunchKernelGGL(bn_dbeta_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, s1, groups, N,
-                     dbeta, accumulate);
-  SCVAE_LAUNCH_CHECK("bn_dbeta_kernel");
   return 0;
 }
 

@@ -76,8 +76,6 @@ int bn_stats(hipStream_t stream, const float* a, int lda, int rows_per_group, in
 int bn_apply(hipStream_t stream, const float* a, int lda, const float* mean, const float* var,
              int stat_stride, const float* beta, float* h, int ldh, int rows_per_group, int groups,
              int N, int relu);
-int bn_update_moving(hipStream_t stream, const float* mean, const float* var, int rows_per_group,
-                     int groups, int N, float* moving_mean, float* moving_var);
 int bn_bwd_stats(hipStream_t stream, const float* dh, int lddh, const float* h, int ldh,
                  const float* a, int lda, const float* mean, const float* var, int rows_per_group,
                  int groups, int N, int relu, float* s1, float* s2, float* partial,
@@ -87,7 +85,6 @@ int bn_bwd_apply(hipStream_t stream, const float* dh, int lddh, const float* h, 
                  const float* a, int lda, const float* mean, const float* var, const float* s1,
                  const float* s2, int rows_per_group, int groups, int N, int relu, float inv_count,
                  float* da, int ldda);
-int bn_dbeta(hipStream_t stream, const float* s1, int groups, int N, float* dbeta, int accumulate);
 int bn_merge(hipStream_t stream, const float* gathered, const int64_t* counts, int ranks, int n,
              float* out);
 // out[r, :] = [z[r, :L] | extra[r % cells, :E]];  slice: out[r, :L] = in[r, :L] of [rows, ld]

@@ -224,15 +224,6 @@ int dense_affine(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld
                   d.h, N, rows, 1, N, relu ? 1 : 0);
 }
 
-// moving-average update (UPDATE_OPS, va:2763-2768); uses the (possibly synced) batch statistics
-int dense_update_moving(scvae_plan* p, hipStream_t s, Dense& d, int64_t global_rows_per_group,
-                               int groups) {
-  if (!d.bn) return 0;
-  const int N = d.n_out;
-  return bn_update_moving(s, d.stats, d.stats + (size_t)groups * N, (int)global_rows_per_group,
-                          groups, N, p->moving + d.mov_mean, p->moving + d.mov_var);
-}
-
 // ---- dense layer backward, part 1: through relu / batch norm.  dh: gradient w.r.t. the
 // layer output h [rows, n_out]; *da_out: gradient w.r.t. the affine output (dh itself, or
 // `scratch`).  Writes dbeta. ----

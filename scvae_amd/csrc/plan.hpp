@@ -162,8 +162,6 @@ int dense_forward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int l
                   int groups, bool relu, bool training);
 int dense_affine(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_in, int rows,
                  int groups, bool relu, bool training);
-int dense_update_moving(scvae_plan* p, hipStream_t s, Dense& d, int64_t global_rows_per_group,
-                        int groups);
 int dense_backward_activation(scvae_plan* p, hipStream_t s, Dense& d, int rows, int groups,
                               bool relu, const float* dh, float* scratch,
                               int64_t global_rows_per_group, const float** da_out);
