@@ -155,6 +155,35 @@ def test_philox_normal_is_sharding_invariant(cuda_device):
     assert not torch.equal(full, other)
 
 
+def test_random_streams_match_the_numpy_restatement(cuda_device):
+    """Bit-exact known answers for the counter-based generator: the dropout
+    masks and the N(0,1) draws of the kernels against oracle/philox.py, which
+    itself reproduces Random123's published vectors (test_oracle_kat.py)."""
+    from oracle import philox
+    from scvae_amd import _lib
+    lib = _lib.load()
+    for rows, cols, keep, seed, site in [
+            (37, 101, 0.8, 0x1234ABCD5678, 3), (5, 4, 0.5, 7, 0),
+            (130, 33, 0.9, 2 ** 63 + 11, 51), (1, 1, 0.25, 1, 80)]:
+        ones = torch.ones(rows, cols, device=cuda_device)
+        out = torch.empty_like(ones)
+        _lib.check(lib.scvae_dropout_apply(
+            _p(ones), _p(out), rows, cols, keep, seed, site, 0, _stream()),
+            "dropout")
+        torch.cuda.synchronize()
+        want = philox.dropout_mask(rows, cols, keep, seed, site)
+        assert np.array_equal(out.cpu().numpy(), want), (rows, cols, site)
+    for rows, cols, offset, seed, stream_id in [
+            (50, 25, 0, 1, 0), (33, 7, 1000, 0xDEADBEEF12, 41),
+            (8, 100, 2 ** 33, 5, 2)]:
+        out = torch.empty(rows, cols, device=cuda_device)
+        _lib.check(lib.scvae_philox_normal(
+            _p(out), rows, cols, offset, seed, stream_id, _stream()), "philox")
+        torch.cuda.synchronize()
+        want = philox.standard_normal(rows, cols, offset, seed, stream_id)
+        assert np.abs(out.cpu().numpy() - want).max() < 2e-5
+
+
 def test_csr_densify(cuda_device):
     import scipy.sparse as sp
     from scvae_amd import _lib

@@ -230,3 +230,34 @@ def test_categorised_likelihood_against_explicit_pmf(name):
     m2 = (counts[:, None] ** 2 * table).sum(axis=0)
     assert np.allclose(mean.numpy(), m1, rtol=1e-8)
     assert np.allclose(var.numpy(), m2 - m1 ** 2, rtol=1e-7)
+
+
+def test_philox_known_answer_vectors():
+    """Philox4x32-10 against the known-answer vectors published with
+    Random123 (kat_vectors): the generator behind the HIP path's noise and
+    dropout masks is pinned to a published golden."""
+    from oracle import philox
+    vectors = [
+        ((0, 0, 0, 0), (0, 0),
+         (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+        ((0xffffffff,) * 4, (0xffffffff,) * 2,
+         (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+        ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344),
+         (0xa4093822, 0x299f31d0),
+         (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+    ]
+    for counter, key, want in vectors:
+        got = philox.philox4x32_10(np.array(counter, dtype=np.uint32),
+                                   np.array(key, dtype=np.uint32))
+        assert got.tolist() == list(want)
+    # batched evaluation equals one-by-one evaluation
+    counters = np.array([v[0] for v in vectors], dtype=np.uint32)
+    keys = np.array([v[1] for v in vectors], dtype=np.uint32)
+    assert philox.philox4x32_10(counters, keys).tolist() == [
+        list(v[2]) for v in vectors]
+    # the derived draws: uniform in (0, 1), normal moments, mask frequency
+    z = philox.standard_normal(2000, 7, 0, 99, 3)
+    assert abs(z.mean()) < 0.03 and abs(z.std() - 1) < 0.03
+    m = philox.dropout_mask(500, 33, 0.8, 5, 2)
+    assert set(np.unique(m)) == {np.float32(0), np.float32(1) / np.float32(0.8)}
+    assert abs((m > 0).mean() - 0.8) < 0.01
