@@ -194,8 +194,16 @@ def evaluate(data_set_file_or_name, data_format=None, data_directory=None,
              split_data_set=None, splitting_method=None,
              splitting_fraction=None, minibatch_size=None, run_id=None,
              models_directory=None, evaluation_set_kind=None,
-             sample_size=None, model_versions=None, **keyword_arguments):
+             sample_size=None, model_versions=None, prediction_method=None,
+             prediction_training_set_kind=None, **keyword_arguments):
     """Evaluate model on data set (``cli.py:267-566``)."""
+    if prediction_method is None:
+        prediction_method = defaults["evaluation"]["prediction_method"]
+    if prediction_training_set_kind is None:
+        prediction_training_set_kind = defaults["evaluation"][
+            "prediction_training_set_kind"]
+    prediction_training_set_kind = normalise_string(
+        prediction_training_set_kind)
     if sample_size is None:
         sample_size = defaults["models"]["sample_size"]
     if split_data_set is None:
@@ -222,14 +230,20 @@ def evaluate(data_set_file_or_name, data_format=None, data_directory=None,
     training_set, validation_set, test_set = subsets
     if split_data_set:
         kinds = {"training": training_set, "validation": validation_set,
-                 "test": test_set}
+                 "test": test_set, "full": data_set}
         if evaluation_set_kind not in kinds:
             raise ValueError(
                 "Evaluation set kind `{}` not found.".format(
                     evaluation_set_kind))
         evaluation_set = kinds[evaluation_set_kind]
+        prediction_training_set = kinds.get(prediction_training_set_kind)
+        if prediction_method and prediction_training_set is None:
+            raise ValueError(
+                "Prediction training set kind `{}` not found.".format(
+                    prediction_training_set_kind))
     else:
         evaluation_set = data_set
+        prediction_training_set = data_set
     evaluation_subset_indices = indices_for_evaluation_subset(evaluation_set)
 
     models_directory = build_directory_path(
@@ -259,6 +273,24 @@ def evaluate(data_set_file_or_name, data_format=None, data_directory=None,
     print(model.description)
     print()
 
+    prediction_specifications = None
+    if prediction_method:   # cli.py:450-461
+        from scvae_amd.analyses.prediction import PredictionSpecifications
+        number_of_clusters = model_arguments["number_of_classes"]
+        if number_of_clusters is None:
+            number_of_clusters = getattr(
+                model, "number_of_latent_clusters", None)
+        prediction_specifications = PredictionSpecifications(
+            method=prediction_method, number_of_clusters=number_of_clusters,
+            training_set_kind=prediction_training_set.kind)
+        print("Prediction method: {}.".format(
+            prediction_specifications.method))
+        print("Number of clusters: {}.".format(
+            prediction_specifications.number_of_clusters))
+        print("Prediction training set: {} set.".format(
+            prediction_specifications.training_set_kind))
+        print()
+
     results = {}
     for model_version in model_versions:
         use_best_model = model_version == "best_model"
@@ -283,7 +315,48 @@ def evaluate(data_set_file_or_name, data_format=None, data_directory=None,
             results[model_version] = (
                 results[model_version], sample_reconstruction_set)
             print()
+        if prediction_specifications is not None:   # cli.py:509-543
+            _predict(model, results[model_version], prediction_training_set,
+                     prediction_specifications, minibatch_size, run_id,
+                     use_best_model, use_early_stopping_model, model_version)
     return results
+
+
+def _predict(model, version_results, prediction_training_set, specifications,
+             minibatch_size, run_id, use_best_model, use_early_stopping_model,
+             model_version):
+    """Cluster the latent representation and attach the predicted labels to
+    every version of the evaluation set (``cli.py:509-543``)."""
+    from scvae_amd.analyses.prediction import (
+        clustering_metrics, predict_labels)
+    print(subtitle("Prediction ({})".format(model_version.replace("_", " "))))
+    evaluation_results = (version_results[0]
+                          if isinstance(version_results, tuple)
+                          else version_results)
+    transformed, reconstructed, latent_sets = evaluation_results
+    latent_training_sets = model.evaluate(
+        evaluation_set=prediction_training_set, minibatch_size=minibatch_size,
+        run_id=run_id, use_best_model=use_best_model,
+        use_early_stopping_model=use_early_stopping_model,
+        output_versions="latent", log_results=False)
+    print()
+    cluster_ids, predicted_labels, predicted_superset_labels = predict_labels(
+        training_set=latent_training_sets["z"],
+        evaluation_set=latent_sets["z"], specifications=specifications)
+    for version in [transformed, reconstructed] + list(latent_sets.values()):
+        version.update_predictions(
+            prediction_specifications=specifications,
+            predicted_cluster_ids=cluster_ids,
+            predicted_labels=predicted_labels)
+    if cluster_ids is not None and transformed.has_labels:
+        metrics = clustering_metrics(
+            transformed.labels, cluster_ids, predicted_labels,
+            transformed.excluded_classes)
+        print("Clustering of the {} set ({}):".format(
+            transformed.kind, specifications.name))
+        for name, value in metrics.items():
+            print("    {}: {:.4f}".format(name, value))
+    print()
 
 
 def _parse_default(default):
@@ -489,6 +562,17 @@ def main(arguments=None):
         "--sample-size", metavar="SIZE", type=int,
         default=_parse_default(defaults["models"]["sample_size"]),
         help="sample size for sampling model")
+    parser_evaluate.add_argument(
+        "--prediction-method", "-P", metavar="METHOD",
+        default=_parse_default(defaults["evaluation"]["prediction_method"]),
+        help="method for predicting labels (k-means, or model for the "
+             "clusters of a GMVAE)")
+    parser_evaluate.add_argument(
+        "--prediction-training-set-kind", metavar="KIND",
+        default=_parse_default(
+            defaults["evaluation"]["prediction_training_set_kind"]),
+        help="kind of subset to fit the prediction method on: training, "
+             "validation, test, or full")
     parser_evaluate.add_argument(
         "--model-versions", metavar="VERSION", nargs="+",
         default=_parse_default(defaults["evaluation"]["model_versions"]),

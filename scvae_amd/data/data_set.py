@@ -56,8 +56,11 @@ class DataSet:
         self.class_name_to_class_id = None
         self.class_id_to_class_name = None
         self.number_of_classes = None
+        self.prediction_specifications = None
         self.predicted_cluster_ids = None
         self.predicted_labels = None
+        self.predicted_class_names = None
+        self.number_of_predicted_classes = None
         self.values = None
         self.preprocessed_values = None
         self.binarised_values = None
@@ -82,6 +85,33 @@ class DataSet:
                     total_standard_deviations=total_standard_deviations,
                     explained_standard_deviations=(
                         explained_standard_deviations))
+
+    # -- predictions (data_set.py:682-742) ---------------------------------
+    def update_predictions(self, prediction_specifications=None,
+                           predicted_cluster_ids=None, predicted_labels=None,
+                           predicted_class_names=None, **unused):
+        if prediction_specifications is not None:
+            self.prediction_specifications = prediction_specifications
+        if predicted_cluster_ids is not None:
+            self.predicted_cluster_ids = predicted_cluster_ids
+        if predicted_labels is not None:
+            self.predicted_labels = predicted_labels
+            if predicted_class_names is None:
+                predicted_class_names = numpy.unique(predicted_labels).tolist()
+            self.predicted_class_names = predicted_class_names
+            self.number_of_predicted_classes = len(predicted_class_names)
+
+    def reset_predictions(self):
+        self.prediction_specifications = None
+        self.predicted_cluster_ids = None
+        self.predicted_labels = None
+        self.predicted_class_names = None
+        self.number_of_predicted_classes = None
+
+    @property
+    def has_predictions(self):
+        return (self.predicted_cluster_ids is not None
+                or self.predicted_labels is not None)
 
     # -- properties used by the models / CLI --------------------------------
     @property

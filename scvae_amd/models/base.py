@@ -948,9 +948,14 @@ class ModelBase:
             latent_sets = self._latent_evaluation_sets(
                 evaluation, wrap, latent_names)
             output_sets[output_versions.index("latent")] = latent_sets
+        self._attach_predictions(output_sets, evaluation, evaluation_set)
         if len(output_sets) == 1:
             output_sets = output_sets[0]
         return output_sets
+
+    def _attach_predictions(self, output_sets, evaluation, evaluation_set):
+        """Models that cluster by themselves (GMVAE, gm:2744-2781) label every
+        output set with their cluster assignment."""
 
     def _latent_evaluation_sets(self, evaluation, wrap, latent_names):
         return {"z": wrap(evaluation["latent_values"], "z",

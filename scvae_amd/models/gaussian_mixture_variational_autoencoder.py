@@ -494,6 +494,26 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
                 label_ids, cluster_ids, excluded)
             result["accuracy"] = float(accuracy(label_ids, predicted,
                                                 excluded))
+            result["predicted_labels"] = numpy.array([
+                data_set.class_id_to_class_name[i] for i in predicted])
+
+    def _attach_predictions(self, output_sets, evaluation, evaluation_set):
+        """gm:2744-2781: the argmax cluster of q(y|x) as "model" prediction on
+        every returned version of the evaluation set."""
+        from scvae_amd.analyses.prediction import PredictionSpecifications
+        specifications = PredictionSpecifications(
+            method="model", number_of_clusters=self.n_clusters,
+            training_set_kind=None)
+        for output_set in output_sets:
+            members = (list(output_set.values())
+                       if isinstance(output_set, dict) else [output_set])
+            for member in members:
+                if member is None:
+                    continue
+                member.update_predictions(
+                    prediction_specifications=specifications,
+                    predicted_cluster_ids=evaluation.get("cluster_ids"),
+                    predicted_labels=evaluation.get("predicted_labels"))
 
     def _print_extra(self, say, evaluation, data_set):
         if evaluation.get("accuracy") is not None:

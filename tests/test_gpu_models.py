@@ -192,6 +192,41 @@ def test_cli_train_and_evaluate(tmp_path, cuda_device, capsys):
     assert "Sampling 20 examples from model." in capsys.readouterr().out
 
 
+def test_cli_evaluate_with_label_prediction(tmp_path, cuda_device, capsys):
+    """``scvae evaluate -P k-means`` (cli.py:450-543): latent values of the
+    prediction training set -> k-means -> labels on every output version; the
+    GMVAE labels its outputs with its own clusters ("model")."""
+    from scvae_amd import cli
+    arguments = ["synthetic_1k", "-M", str(tmp_path), "-r", "poisson", "-l",
+                 "3", "-H", "20", "-B", "100", "--split-data-set"]
+    cli.main(["train"] + arguments + ["-e", "2"])
+    capsys.readouterr()
+    results = cli.main(["evaluate"] + arguments + [
+        "-P", "k-means", "--prediction-training-set-kind", "validation"])
+    out = capsys.readouterr().out
+    assert "Prediction method: k-means." in out
+    assert "Prediction training set: validation set." in out
+    assert "Predicting labels for evaluation set using k-means" in out
+    transformed, reconstructed, latent = results["end_of_training"]
+    for version in (transformed, reconstructed, latent["z"]):
+        assert version.prediction_specifications.name.startswith("kmeans_")
+        assert len(version.predicted_cluster_ids) == 100
+        if transformed.has_labels:
+            assert len(version.predicted_labels) == 100
+    if transformed.has_labels:
+        assert "adjusted Rand index" in out
+    # GMVAE: evaluate() attaches the model's own clustering
+    arguments = ["synthetic_1k", "-M", str(tmp_path), "-m", "GMVAE", "-r",
+                 "poisson", "-l", "3", "-H", "20", "-B", "100", "-K", "3",
+                 "--split-data-set"]
+    cli.main(["train"] + arguments + ["-e", "1"])
+    results = cli.main(["evaluate"] + arguments)
+    transformed, reconstructed, latent = results["end_of_training"]
+    for version in (reconstructed, latent["z"], latent["y"]):
+        assert version.prediction_specifications.method == "model"
+        assert set(np.unique(version.predicted_cluster_ids)) <= {0, 1, 2}
+
+
 def test_distribution_registry_objects(cuda_device):
     import scipy.stats as st
     from scvae_amd.distributions import DISTRIBUTIONS
