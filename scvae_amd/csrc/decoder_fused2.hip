@@ -91,16 +91,25 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
   float* dsh = hbase;                                 // [2][BM][LDD]; column H = 1
   float* Gs = dsh + 2 * DBUF;                         // [P][BM][LD]: pre_j, then G_j
 
-  // ---- strip weights and biases -> LDS (once) ----
-  for (int i = tid; i < P * H * BN; i += D2_THREADS) {
-    const int c = i & (BN - 1);
-    const int jh = i >> 6;  // j*H + h
-    float v = 0.f;
-    if (c0 + c < F) {
-      const int j = __umulhi((unsigned)jh, magic_h), h = jh - j * H;
-      v = hp.W[j][(size_t)h * F + c0 + c];
+  // ---- strip weights and biases -> LDS (once): eight HBM loads in flight per thread ----
+  {
+    const int c = tid & (BN - 1);
+    const bool col_ok = c0 + c < F;
+    constexpr int RPP = D2_THREADS / 64;                        // rows of 64 genes per pass
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const float* Wj = hp.W[j] + c0 + c;
+      float* dst = Ws + (size_t)j * H * LD + c;
+      int h = tid >> 6;
+      for (; h + 7 * RPP < H; h += 8 * RPP) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = col_ok ? Wj[(size_t)(h + u * RPP) * F] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dst[(size_t)(h + u * RPP) * LD] = v[u];
+      }
+      for (; h < H; h += RPP) dst[(size_t)h * LD] = col_ok ? Wj[(size_t)h * F] : 0.f;
     }
-    Ws[(size_t)jh * LD + c] = v;
   }
   if (tid < P * BN) {
     const int j = tid / BN, c = tid % BN;
