@@ -359,12 +359,12 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
           float* dst = dd_part + ((size_t)blockIdx.x * R + r0) * H + h;
           if (m0 + BM <= R) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * H] = accD[r];
+            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(accD[r], dst + ((r & 3) + 8 * (r >> 2)) * H);
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int ro = (r & 3) + 8 * (r >> 2);
-              if (r0 + ro < R) dst[ro * H] = accD[r];
+              if (r0 + ro < R) __builtin_nontemporal_store(accD[r], dst + ro * H);
             }
           }
         }
@@ -431,7 +431,12 @@ __global__ __launch_bounds__(256) void dd_reduce_kernel(const float* __restrict_
     for (; z + 8 <= strips; z += 8) {
       float4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p4[(size_t)(z + u) * n4 + i];
+      for (int u = 0; u < 8; ++u) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 q = __builtin_nontemporal_load(
+            reinterpret_cast<const f32x4*>(p4 + (size_t)(z + u) * n4 + i));
+        v[u] = make_float4(q.x, q.y, q.z, q.w);
+      }
 #pragma unroll
       for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
     }

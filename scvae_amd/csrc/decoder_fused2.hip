@@ -265,18 +265,21 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
       // so that the hand-over does not wait for the stores
 #pragma unroll
       for (int i = 0; i < DLOADS; ++i) asm volatile("" : "+v"(dv[i]));
+      // (non-temporal stores: 419 MB of dd slabs per launch that are read exactly once, by
+      //  dd_reduce_kernel -- written through, they do not linger as dirty lines in the 256 MB
+      //  infinity cache and get evicted in the middle of that reduce: 151 -> 123 us)
       if (TRAIN && live_prev && g3_wave) {
         const int h = hw * 32 + li;
         if (h < H) {
           float* dst = dd_part + ((size_t)blockIdx.x * R + mp + 4 * kh) * H + h;
           if (mp + BM <= R) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * H] = accX[r];
+            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(accX[r], dst + ((r & 3) + 8 * (r >> 2)) * H);
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int ro = (r & 3) + 8 * (r >> 2);
-              if (mp + 4 * kh + ro < R) dst[ro * H] = accX[r];
+              if (mp + 4 * kh + ro < R) __builtin_nontemporal_store(accX[r], dst + ro * H);
             }
           }
         }

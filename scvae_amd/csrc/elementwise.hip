@@ -1164,7 +1164,12 @@ __global__ __launch_bounds__(1024) void csr_densify_lds_kernel(
   if ((reinterpret_cast<uintptr_t>(orow) & 15) == 0) {
     float4* o4 = reinterpret_cast<float4*>(orow);
     const int full = F / 4;
-    for (int i = threadIdx.x; i < full; i += 1024) o4[i] = row4[i];
+    for (int i = threadIdx.x; i < full; i += 1024) {
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const float4 v = row4[i];
+      f32x4 q = {v.x, v.y, v.z, v.w};
+      __builtin_nontemporal_store(q, reinterpret_cast<f32x4*>(o4 + i));
+    }
     for (int i = 4 * full + threadIdx.x; i < F; i += 1024) orow[i] = row[i];
   } else {
     for (int i = threadIdx.x; i < F; i += 1024) orow[i] = row[i];
