@@ -238,7 +238,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(
 // instead of a padded fourth tile: 100 columns cost 3.06 tiles of MFMA work instead of 4.
 constexpr int NBM = 256;          // rows per workgroup
 constexpr int NBK = 16;           // k-step per barrier
-constexpr int NLDA = NBM + 1;     // odd: conflict-free transposing store of A[m][k]
+constexpr int NLDA = NBM + 4;     // k-stride of 4 banks: the A[m][k] store (4 k-groups x 16 rows
+                                  // per wave) then puts exactly two lanes on every bank
 constexpr int NBN = 104;          // at most 96 + 8 columns
 constexpr int NLDB = NBN + 1;
 
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void gemm_narrow_kernel(
     const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
     float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, int act, int accumulate,
     int k_chunk, float* __restrict__ slabs) {
-  __shared__ float As[2][NBK][NLDA];
+  __shared__ __attribute__((aligned(16))) float As[2][NBK][NLDA];
   __shared__ float Bs[2][NBK][NLDB];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kh = lane >> 5, li = lane & 31;
@@ -273,18 +274,34 @@ __global__ __launch_bounds__(512, 2) void gemm_narrow_kernel(
 #pragma unroll
   for (int q = 0; q < 2; ++q) accR[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // staging: A 256 x 16 (8 per thread), B 16 x 104 (<= 4 per thread)
+  // staging: A 256 x 16 (8 per thread), B 16 x 104 (<= 4 per thread).  A[m][k] (row-major
+  // input, any pitch): two 16-byte loads of 4 consecutive k per thread (global loads need only
+  // 4-byte alignment); A[k][m]: 8 x 4 bytes, 256 consecutive m per instruction (16-byte loads
+  // were slower there: 285 -> 305 us).
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
   float ra[8], rb[4];
   auto load_tiles = [&](int kt) {
+    if (TA) {
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      int m, k;
-      if (TA) { m = tid & 255; k = (tid >> 8) + 2 * p; }       // A[k][m]: 256 consecutive m
-      else    { k = tid & 15; m = (tid >> 4) + 32 * p; }       // A[m][k]: 16 consecutive k
-      const int gm = m0 + m, gk = kt + k;
-      float v = 0.f;
-      if (gm < M && gk < k_end) v = TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
-      ra[p] = v;
+      for (int p = 0; p < 8; ++p) {
+        const int m = tid & 255, k = (tid >> 8) + 2 * p;      // A[k][m]: 256 consecutive m
+        const int gm = m0 + m, gk = kt + k;
+        ra[p] = (gm < M && gk < k_end) ? A[(size_t)gk * lda + gm] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int k = (tid & 3) * 4, m = (tid >> 2) + 128 * p;
+        const int gm = m0 + m, gk = kt + k;
+        const float* src = A + (size_t)gm * lda + gk;
+        if (gm < M && gk + 3 < k_end) {
+          const f32x4u v = *reinterpret_cast<const f32x4u*>(src);
+          ra[4 * p] = v.x; ra[4 * p + 1] = v.y; ra[4 * p + 2] = v.z; ra[4 * p + 3] = v.w;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) ra[4 * p + u] = (gm < M && gk + u < k_end) ? src[u] : 0.f;
+        }
+      }
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -297,12 +314,13 @@ __global__ __launch_bounds__(512, 2) void gemm_narrow_kernel(
     }
   };
   auto store_tiles = [&](int buf) {
+    if (TA) {
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      int m, k;
-      if (TA) { m = tid & 255; k = (tid >> 8) + 2 * p; }
-      else    { k = tid & 15; m = (tid >> 4) + 32 * p; }
-      As[buf][k][m] = ra[p];
+      for (int p = 0; p < 8; ++p) As[buf][(tid >> 8) + 2 * p][tid & 255] = ra[p];
+    } else {
+#pragma unroll
+      for (int p = 0; p < 8; ++p)
+        As[buf][(tid & 3) * 4 + (p & 3)][(tid >> 2) + 128 * (p >> 2)] = ra[p];
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
