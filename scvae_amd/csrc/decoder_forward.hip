@@ -15,7 +15,7 @@
 //     likelihood of its 16 elements sums into one register, and the row sum of the tile is that
 //     register plus the one of lane ^ 32.  The pre-activations never leave the registers;
 //   * the bias rides along as an extra contraction step (d gets a ones column, W_j the bias row);
-//   * t is read from HBM straight into that register layout (8-byte loads), in flight under
+//   * t is read from HBM straight into that register layout (16-byte loads), in flight under
 //     the MFMAs;
 //   * the t > 0 corrections of the negative-binomial kinds, lgamma(r+t) - lgamma(r), are the
 //     expensive part of an element but needed for 5 % of them: each lane walks over its own
@@ -138,7 +138,6 @@ __global__ __launch_bounds__(512) void decoder_forward_kernel(
       dB[2 * q] = v.x; dB[2 * q + 1] = v.y;
     }
   };
-  const bool pairs = (F & 1) == 0;     // 8-byte loads of t: every row start is 8-byte aligned
   const int n_tiles = (R + BM - 1) / BM;
 
   load_d(w * BM);
@@ -156,12 +155,10 @@ __global__ __launch_bounds__(512) void decoder_forward_kernel(
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int c = cbase + 8 * g;
-        if (pairs) {
-          const float2 lo = (c + 1 < F) ? *reinterpret_cast<const float2*>(trow + c)
-                                        : make_float2(0.f, 0.f);
-          const float2 hi = (c + 3 < F) ? *reinterpret_cast<const float2*>(trow + c + 2)
-                                        : make_float2(0.f, 0.f);
-          tv[4 * g] = lo.x; tv[4 * g + 1] = lo.y; tv[4 * g + 2] = hi.x; tv[4 * g + 3] = hi.y;
+        if (c + 3 < F) {   // one 16-byte load (global loads need only 4-byte alignment)
+          typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+          const f32x4u v = *reinterpret_cast<const f32x4u*>(trow + c);
+          tv[4 * g] = v.x; tv[4 * g + 1] = v.y; tv[4 * g + 2] = v.z; tv[4 * g + 3] = v.w;
         } else {
 #pragma unroll
           for (int u = 0; u < 4; ++u) tv[4 * g + u] = (c + u < F) ? trow[c + u] : 0.f;
