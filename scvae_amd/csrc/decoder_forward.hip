@@ -8,7 +8,7 @@
 //   * a workgroup owns a 64-gene strip (weights and biases in LDS for the whole kernel); its waves
 //     walk over their own 32-row tiles independently -- no workgroup barrier in the loop, and no
 //     LDS staging of d: in the k-slot layout chosen below a lane's share of the d tile is one
-//     contiguous run of its row, read from L2 with 8-byte loads into the registers that feed the
+//     contiguous run of its row, read from L2 with 16-byte loads into the registers that feed the
 //     MFMAs (the next tile's run is requested as soon as the last MFMA of the tile is issued);
 //   * a wave computes the TRANSPOSED head tile pre_j^T[gene, row] = W_j^T d^T with
 //     v_mfma_f32_32x32x2: in the result layout a lane then holds 16 genes of ONE row, so the
@@ -129,13 +129,23 @@ __global__ __launch_bounds__(512) void decoder_forward_kernel(
     const int row = min(m0 + li, R - 1);             // (rows beyond R: results are not stored)
     const float* src = d + (size_t)row * H + kh * HS;
     const int p0 = kh * HS;
+    // HS is a multiple of 4 and H is even: a group of 4 positions is inside the row, or holds
+    // its last two elements, or starts at the ones column / in the zero padding
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 #pragma unroll
-    for (int q = 0; q < HS / 2; ++q) {
-      const int pos = p0 + 2 * q;
-      float2 v;
-      if (pos < H) v = *reinterpret_cast<const float2*>(src + 2 * q);
-      else v = make_float2(pos == H ? 1.f : 0.f, 0.f);
-      dB[2 * q] = v.x; dB[2 * q + 1] = v.y;
+    for (int q = 0; q < HS / 4; ++q) {
+      const int pos = p0 + 4 * q;
+      f32x4u v = {0.f, 0.f, 0.f, 0.f};
+      if (pos + 3 < H) {
+        v = *reinterpret_cast<const f32x4u*>(src + 4 * q);
+      } else if (pos + 1 < H) {
+        const f32x2u lo = *reinterpret_cast<const f32x2u*>(src + 4 * q);
+        v.x = lo.x; v.y = lo.y; v.z = 1.f;       // pos + 2 == H: the ones column
+      } else if (pos == H) {
+        v.x = 1.f;
+      }
+      dB[4 * q] = v.x; dB[4 * q + 1] = v.y; dB[4 * q + 2] = v.z; dB[4 * q + 3] = v.w;
     }
   };
   const int n_tiles = (R + BM - 1) / BM;
