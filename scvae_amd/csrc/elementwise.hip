@@ -1161,18 +1161,17 @@ __global__ __launch_bounds__(1024) void csr_densify_lds_kernel(
   }
   __syncthreads();
   float* orow = out + (size_t)b * ldo;
-  if ((reinterpret_cast<uintptr_t>(orow) & 15) == 0) {
-    float4* o4 = reinterpret_cast<float4*>(orow);
+  // 16-byte non-temporal stores whatever the row pitch (global accesses need only 4-byte
+  // alignment): the dense batch is written once and streamed by its readers
+  {
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     const int full = F / 4;
     for (int i = threadIdx.x; i < full; i += 1024) {
-      typedef float f32x4 __attribute__((ext_vector_type(4)));
       const float4 v = row4[i];
-      f32x4 q = {v.x, v.y, v.z, v.w};
-      __builtin_nontemporal_store(q, reinterpret_cast<f32x4*>(o4 + i));
+      const f32x4u q = {v.x, v.y, v.z, v.w};
+      __builtin_nontemporal_store(q, reinterpret_cast<f32x4u*>(orow + 4 * i));
     }
     for (int i = 4 * full + threadIdx.x; i < F; i += 1024) orow[i] = row[i];
-  } else {
-    for (int i = threadIdx.x; i < F; i += 1024) orow[i] = row[i];
   }
 }
 
