@@ -71,7 +71,10 @@ typedef struct scvae_model_config {
                                  samples (analytical_kl_term == False, va:2633-2640; the GMVAE's
                                  KL(z) is always of that form); bit 1 latent_distribution ==
                                  "unit-variance gaussian" (du:323-337): the posterior's log_sigma
-                                 is the constant 0 and POSTERIOR/LOG_SIGMA is not built */
+                                 is the constant 0 and POSTERIOR/LOG_SIGMA is not built.
+                                 GMVAE: bit 2 (value 4) "legacy gaussian mixture" (du:349-352):
+                                 the z layers live in scope MODIFIED_GAUSSIAN instead of
+                                 SOFTPLUS_GAUSSIAN, same graph */
   float dropout_keep[4];      /* dropout_keep_probabilities (va:245-269, gm:281-301), applied to
                                  the input connections of a dense layer while training
                                  (mu:45-50): [0] h: hidden layers and every parameter head,

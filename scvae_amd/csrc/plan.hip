@@ -620,8 +620,9 @@ int scvae_plan_create(const scvae_model_config* cfg, scvae_plan** out) {
   SCVAE_ARG(cfg->linear_factor >= 0 && cfg->linear_factor <= 3);
   SCVAE_ARG(cfg->linear_factor == 0 || cfg->model_type == SCVAE_MODEL_VAE);
   SCVAE_ARG(cfg->decoder_extra == 0 || (cfg->n_hidden > 0 && !(cfg->linear_factor & 2)));
-  SCVAE_ARG(cfg->latent_mode >= 0 && cfg->latent_mode <= 3);
-  SCVAE_ARG(cfg->latent_mode == 0 || cfg->model_type == SCVAE_MODEL_VAE);
+  SCVAE_ARG(cfg->model_type == SCVAE_MODEL_VAE
+                ? (cfg->latent_mode >= 0 && cfg->latent_mode <= 3)
+                : (cfg->latent_mode == 0 || cfg->latent_mode == 4));
   for (int i = 0; i < 4; ++i) SCVAE_ARG(cfg->dropout_keep[i] >= 0.f && cfg->dropout_keep[i] <= 1.f);
   scvae_plan* p = new scvae_plan();
   p->cfg = *cfg;

@@ -31,10 +31,13 @@ int build_gmvae(scvae_plan* p) {
     p->zenc.push_back(L.dense(scope, n_in, c.hidden[i], bn));
     n_in = c.hidden[i];
   }
-  p->qmean = L.dense("Z/Q/SOFTPLUS_GAUSSIAN/MEAN", n_in, Lz, false);
-  p->qscale = L.dense("Z/Q/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE", n_in, Lz, false);
-  p->pmean = L.dense("Z/P/SOFTPLUS_GAUSSIAN/MEAN", K, Lz, false);
-  p->pscale = L.dense("Z/P/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE", K, Lz, false);
+  // the scope is the upper-cased distribution name (gm:2962-2963, 3013-3014): "softplus gaussian",
+  // or its alias "modified gaussian" of the "legacy gaussian mixture" (du:307, 349-352)
+  const std::string dist = (c.latent_mode & 4) ? "MODIFIED_GAUSSIAN" : "SOFTPLUS_GAUSSIAN";
+  p->qmean = L.dense("Z/Q/" + dist + "/MEAN", n_in, Lz, false);
+  p->qscale = L.dense("Z/Q/" + dist + "/SOFTPLUS_SCALE", n_in, Lz, false);
+  p->pmean = L.dense("Z/P/" + dist + "/MEAN", K, Lz, false);
+  p->pscale = L.dense("Z/P/" + dist + "/SOFTPLUS_SCALE", K, Lz, false);
   n_in = Lz + c.decoder_extra;   // decoder input [z | batch one-hot | count sum]
   // gm:3135-3146: hidden_sizes[::-1] without reverse_order => LAYER_1.. in execution order
   for (int i = 0; i < c.n_hidden; ++i) {

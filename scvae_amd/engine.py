@@ -91,13 +91,18 @@ class Engine:
         cfg.linear_factor = (
             (1 if inference_architecture.upper() == "LFM" else 0)
             | (2 if generative_architecture.upper() == "LFM" else 0))
-        if latent_distribution not in ("gaussian", "unit-variance gaussian"):
-            raise ValueError("VAE latent distribution `{}`.".format(
+        if latent_distribution not in (
+                "gaussian", "unit-variance gaussian", "gaussian mixture",
+                "legacy gaussian mixture"):
+            raise ValueError("Latent distribution `{}`.".format(
                 latent_distribution))
         self.latent_distribution = latent_distribution
         self.analytical_kl_term = bool(analytical_kl_term)
         cfg.latent_mode = 0
-        if model_type != "GMVAE":
+        if model_type == "GMVAE":
+            if latent_distribution == "legacy gaussian mixture":
+                cfg.latent_mode = 4
+        else:
             cfg.latent_mode = (
                 (0 if self.analytical_kl_term else 1)
                 | (2 if latent_distribution == "unit-variance gaussian"

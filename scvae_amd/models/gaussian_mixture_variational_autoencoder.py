@@ -110,6 +110,10 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
             analytical_kl_term = True
         self.latent_distribution_name = latent_distribution
         self.analytical_kl_term = analytical_kl_term
+        # variable scope of the z layers: the upper-cased distribution name
+        # (gm:2962-2963), MODIFIED_GAUSSIAN for the legacy mixture
+        self._z_scope = normalise_string(
+            self.latent_distribution["z posterior"]).upper()
 
         if number_of_latent_clusters is None:
             number_of_latent_clusters = dm["number_of_classes"]
@@ -253,6 +257,10 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
             decoder_extra=self.decoder_extra_size, k_max=self.k_max,
             prior_probabilities_method=self.prior_probabilities_method,
             prior_probabilities=self.prior_probabilities,
+            latent_distribution=(
+                "legacy gaussian mixture"
+                if self._z_scope == "MODIFIED_GAUSSIAN"
+                else "gaussian mixture"),
             dropout_keep_probabilities=(
                 self.dropout_keep_probability_h,
                 self.dropout_keep_probability_x,
@@ -281,10 +289,10 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
         for i, h in enumerate(H):
             dense("Z/Q/ENCODER/LAYER_{}".format(i + 1), n_in, h, bn)
             n_in = h
-        dense("Z/Q/SOFTPLUS_GAUSSIAN/MEAN", n_in, L, False)
-        dense("Z/Q/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE", n_in, L, False)
-        dense("Z/P/SOFTPLUS_GAUSSIAN/MEAN", K, L, False)
-        dense("Z/P/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE", K, L, False)
+        dense("Z/Q/" + self._z_scope + "/MEAN", n_in, L, False)
+        dense("Z/Q/" + self._z_scope + "/SOFTPLUS_SCALE", n_in, L, False)
+        dense("Z/P/" + self._z_scope + "/MEAN", K, L, False)
+        dense("Z/P/" + self._z_scope + "/SOFTPLUS_SCALE", K, L, False)
         n_in = L + self.decoder_extra_size
         for i, h in enumerate(H[::-1]):
             dense("X/DECODER/LAYER_{}".format(i + 1), n_in, h, bn)
@@ -424,12 +432,12 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
         """p(y) probabilities and p(z|y) means / variances (gm:2879-2882)."""
         engine = self.engine
         K, L = self.n_clusters, self.latent_size
-        Wm = engine.parameter("Z/P/SOFTPLUS_GAUSSIAN/MEAN/DENSE/weights")
-        bm = engine.parameter("Z/P/SOFTPLUS_GAUSSIAN/MEAN/DENSE/biases")
+        Wm = engine.parameter("Z/P/" + self._z_scope + "/MEAN/DENSE/weights")
+        bm = engine.parameter("Z/P/" + self._z_scope + "/MEAN/DENSE/biases")
         Ws = engine.parameter(
-            "Z/P/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE/DENSE/weights")
+            "Z/P/" + self._z_scope + "/SOFTPLUS_SCALE/DENSE/weights")
         bs = engine.parameter(
-            "Z/P/SOFTPLUS_GAUSSIAN/SOFTPLUS_SCALE/DENSE/biases")
+            "Z/P/" + self._z_scope + "/SOFTPLUS_SCALE/DENSE/biases")
         means = (Wm + bm).cpu().numpy()
         variances = torch.nn.functional.softplus(Ws + bs).cpu().numpy()
         del L

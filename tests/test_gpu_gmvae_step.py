@@ -182,3 +182,28 @@ def test_non_uniform_prior_over_clusters(cuda_device, method, free_nats):
         before = eng.prior_logits.clone()
         eng.adam_step(1e-2)
         assert torch.equal(before, eng.prior_logits)
+
+
+def test_legacy_gaussian_mixture_is_the_same_graph(cuda_device):
+    """latent_mode 4: scope MODIFIED_GAUSSIAN instead of SOFTPLUS_GAUSSIAN
+    (du:349-352), identical arithmetic."""
+    from scvae_amd.engine import Engine
+    F, L, H, B, K = 60, 4, (12,), 15, 3
+    kwargs = dict(batch_norm=True, model_type="GMVAE", n_clusters=K,
+                  device=cuda_device, seed=3)
+    modern = Engine(F, L, H, "negative binomial", **kwargs)
+    legacy = Engine(F, L, H, "negative binomial",
+                    latent_distribution="legacy gaussian mixture", **kwargs)
+    names = list(legacy.named_parameters())
+    assert "Z/P/MODIFIED_GAUSSIAN/SOFTPLUS_SCALE/DENSE/biases" in names
+    assert [n.replace("MODIFIED", "SOFTPLUS") for n in names] == list(
+        modern.named_parameters())
+    legacy.params.copy_(modern.params)
+    rng = np.random.default_rng(1)
+    x = torch.from_numpy(rng.poisson(1.5, size=(B, F)).astype(np.float32)).to(
+        cuda_device)
+    eps = torch.randn(K, 1, B, L, device=cuda_device)
+    a = modern.step(x, x, eps=eps, training=True).clone()
+    b = legacy.step(x, x, eps=eps, training=True).clone()
+    assert torch.equal(a, b)
+    assert torch.equal(modern.grads, legacy.grads)

@@ -352,3 +352,22 @@ def test_label_prediction_from_latent_values():
     assert (again[0] == cluster_ids).all() and (again[1] == predicted).all()
     test.reset_predictions()
     assert not test.has_predictions
+
+
+def test_legacy_gaussian_mixture_scopes():
+    """du:349-352 / gm:192-197: the legacy mixture is the same graph under the
+    scope MODIFIED_GAUSSIAN, named "gaussian mixture" with the `kl` tag."""
+    from scvae_amd.models import GaussianMixtureVariationalAutoencoder
+    legacy = GaussianMixtureVariationalAutoencoder(
+        10, latent_distribution="legacy gaussian mixture")
+    modern = GaussianMixtureVariationalAutoencoder(10)
+    assert legacy.latent_distribution_name == "gaussian mixture"
+    assert legacy.analytical_kl_term and not modern.analytical_kl_term
+    names = [n for n, _ in legacy._parameter_shapes()]
+    assert "Z/Q/MODIFIED_GAUSSIAN/MEAN/DENSE/weights" in names
+    assert not any("SOFTPLUS_GAUSSIAN" in n for n in names)
+    assert [n.replace("MODIFIED", "SOFTPLUS") for n in names] == [
+        n for n, _ in modern._parameter_shapes()]
+    assert legacy._engine_arguments()["latent_distribution"] == (
+        "legacy gaussian mixture")
+    assert "-kl" in legacy.name and "-kl" not in modern.name
