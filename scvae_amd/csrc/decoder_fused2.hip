@@ -265,7 +265,7 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
       // so that the hand-over does not wait for the stores
 #pragma unroll
       for (int i = 0; i < DLOADS; ++i) asm volatile("" : "+v"(dv[i]));
-      // (non-temporal stores: 419 MB of dd slabs per launch that are read exactly once, by
+      // (non-temporal stores: 839 MB of dd slabs per launch that are read exactly once, by
       //  dd_reduce_kernel -- written through, they do not linger as dirty lines in the 256 MB
       //  infinity cache and get evicted in the middle of that reduce: 151 -> 123 us)
       if (TRAIN && live_prev && g3_wave) {

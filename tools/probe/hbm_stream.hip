@@ -122,7 +122,7 @@ int main() {
            2.0 * ((size_t)419 << 20) / t / 1e9);
   }
   {
-    const int slabs = 256; const size_t n4 = 4096 * 100 / 4;   // 256 x [4096, 100] floats = 419 MB
+    const int slabs = 512; const size_t n4 = 4096 * 100 / 4;   // 512 x [4096, 100] floats = 839 MB
     const double bytes = (double)slabs * n4 * 16;
     auto report = [&](const char* name, float ms) { printf("%-44s %7.1f us  %.2f TB/s\n", name, ms * 1e3, bytes / ms / 1e9); };
     const int blocks = (int)((n4 + 255) / 256);
