@@ -33,7 +33,10 @@ enum {
   SCVAE_POISSON = 0, /* log_lambda            */
   SCVAE_NB = 1,      /* p, log_r              */
   SCVAE_ZIP = 2,     /* pi, log_lambda        */
-  SCVAE_ZINB = 3     /* pi, p, log_r          */
+  SCVAE_ZINB = 3,    /* pi, p, log_r          */
+  SCVAE_CONSTRAINED_POISSON = 4 /* lambda: softmax over the genes, rate = lambda * count sum of
+                        the cell (du:218-228, va:2400-2405, 2490-2496); needs
+                        scvae_step_args.count_sum; heads and likelihood run unfused */
 };
 
 enum { SCVAE_MODEL_VAE = 0, SCVAE_MODEL_GMVAE = 1 };
@@ -167,6 +170,9 @@ typedef struct scvae_step_args {
    * masks, a new value every step; the mask of every layer input is a function of
    * (dropout_seed, site, row, column), see scvae_dropout_apply */
   uint64_t dropout_seed;
+  /* [cells] count sum N of every cell (count_sum_parameter, va:1017-1019): the total of the
+   * constrained Poisson's rates.  Required for SCVAE_CONSTRAINED_POISSON, ignored otherwise */
+  const float* count_sum;
 } scvae_step_args;
 int scvae_plan_step(scvae_plan* plan, const scvae_step_args* args, void* stream);
 /* Decoder only, is_training = False: p_x_mean[rows, F] = mean of p(x|z) for given latent values

@@ -45,6 +45,9 @@ LIKELIHOOD_PARAMETERS = {
     "negative binomial": ("p", "log_r"),
     "zero-inflated poisson": ("pi", "log_lambda"),
     "zero-inflated negative binomial": ("pi", "p", "log_r"),
+    # du:218-228: activation softmax over the genes, rate = lambda * N with N
+    # the count sum of the cell (va:2400-2405, 2490-2496)
+    "constrained poisson": ("lambda",),
 }
 
 
@@ -90,8 +93,23 @@ def zero_inflated_negative_binomial_log_prob(t, pi_pre, p_pre, log_r_pre):
     return _zero_inflate(t, pi_pre, base, base)
 
 
-def log_prob(name, t, pre):
+def constrained_poisson_rate(lambda_pre, count_sum):
+    """``clip(softmax(pre), tiny, 1 - tiny) * N``; ``count_sum``: [rows, 1]."""
+    lam = torch.softmax(lambda_pre, dim=-1)
+    lam = torch.clamp(lam, min=FLOAT32_TINY, max=1.0)
+    return lam * count_sum
+
+
+def constrained_poisson_log_prob(t, lambda_pre, count_sum):
+    """``tfp.distributions.Poisson(rate=lambda * N).log_prob(t)``."""
+    rate = constrained_poisson_rate(lambda_pre, count_sum)
+    return torch.xlogy(t, rate) - torch.lgamma(t + 1.0) - rate
+
+
+def log_prob(name, t, pre, count_sum=None):
     """``pre``: tuple of head pre-activations in registry order."""
+    if name == "constrained poisson":
+        return constrained_poisson_log_prob(t, pre[0], count_sum)
     if name == "poisson":
         return poisson_log_prob(t, *pre)
     if name == "negative binomial":
@@ -131,8 +149,11 @@ def categorised_mean_variance(name, pre, logits, k_max):
     return mean, second - mean * mean
 
 
-def mean_variance(name, pre):
+def mean_variance(name, pre, count_sum=None):
     """E[x|z], Var[x|z] of the decoder distribution (TFP semantics)."""
+    if name == "constrained poisson":
+        rate = constrained_poisson_rate(pre[0], count_sum)
+        return rate, rate
     if name == "poisson":
         lam = torch.exp(_clip_log(pre[0]))
         return lam, lam

@@ -246,16 +246,18 @@ def _normal_log_prob(z, mean, sigma):
 
 
 def _decoder_distribution(cfg, d, params, scope, training, moving,
-                          dropout=None):
+                          dropout=None, count_sum=None):
     """Head pre-activations (and the P_K logits) of p(x|z) from the last
-    decoder layer ``d``; returns (log_prob(t), mean_variance()) closures."""
+    decoder layer ``d``; returns (log_prob(t), mean_variance()) closures.
+    ``count_sum``: [rows, 1], the N of the constrained Poisson (already
+    tiled over the samples, va:2400-2405)."""
     pre = tuple(
         dense_layer(d, params, scope + p.upper(), False, training, moving,
                     None, activation=False, dropout=dropout)
         for p in cfg.heads)
     if not cfg.k_max:
-        return (lambda t: lk.log_prob(cfg.likelihood, t, pre),
-                lambda: lk.mean_variance(cfg.likelihood, pre))
+        return (lambda t: lk.log_prob(cfg.likelihood, t, pre, count_sum),
+                lambda: lk.mean_variance(cfg.likelihood, pre, count_sum))
     logits = dense_layer(d, params, scope + "P_K", False, training, moving,
                          None, activation=False, dropout=dropout)
     logits = logits.reshape(d.shape[0], cfg.feature_size, cfg.k_max + 1)
@@ -296,7 +298,7 @@ def decode_mean(cfg, params, moving, z, model_type="VAE"):
 def vae_forward(cfg, params, moving, x, t, eps, training, warm_up_weight=1.0,
                 new_moving=None, deterministic_z=False, analytical_kl=None,
                 evaluation_statistics=False, decoder_extra=None,
-                dropout=None):
+                dropout=None, count_sum=None):
     """One graph execution.  ``eps``: [S, B, L] standard-normal draws
     (S = n_iw * n_mc, IW-major) or None with ``deterministic_z``.
     ``dropout``: {layer scope: mask / keep_prob} (see dense_layer)."""
@@ -340,7 +342,8 @@ def vae_forward(cfg, params, moving, x, t, eps, training, warm_up_weight=1.0,
         d = dense_layer(d, params, "DECODER/{}".format(n - i), bn, training,
                         moving, new_moving, dropout=dropout)
     log_prob, mean_variance = _decoder_distribution(
-        cfg, d, params, "X_TILDE/", training, moving, dropout)
+        cfg, d, params, "X_TILDE/", training, moving, dropout,
+        None if count_sum is None else count_sum.reshape(-1, 1).repeat(S, 1))
 
     t_tiled = t.repeat(S, 1)
     log_p = log_prob(t_tiled).sum(dim=-1)
@@ -407,7 +410,7 @@ def _clip_big(a):
 def gmvae_forward(cfg, params, moving, x, t, eps, training,
                   warm_up_weight=1.0, new_moving=None,
                   evaluation_statistics=False, decoder_extra=None,
-                  dropout=None):
+                  dropout=None, count_sum=None):
     """``eps``: [K, S, B, L].  ``dropout``: {layer scope: mask / keep_prob}
     (see dense_layer); the layers under Z/ and X/ are built once per cluster
     (gm:2859-2922), each copy with its own dropout op, so their entries carry
@@ -485,7 +488,9 @@ def gmvae_forward(cfg, params, moving, x, t, eps, training,
         d = _layers(d, params, "X/DECODER", H[::-1], bn, training, moving,
                     new_moving, dropout=dk)
         log_prob, mean_variance = _decoder_distribution(
-            cfg, d, params, "X/DISTRIBUTION/", training, moving, dk)
+            cfg, d, params, "X/DISTRIBUTION/", training, moving, dk,
+            None if count_sum is None
+            else count_sum.reshape(-1, 1).repeat(S, 1))
         log_p = log_prob(t_tiled).sum(dim=-1)
         log_p = log_p.reshape(S, B)
         log_p_all.append(log_p)

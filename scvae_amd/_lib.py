@@ -16,7 +16,7 @@ LIBRARY_PATH = os.path.join(_HERE, "csrc", "libscvae_hip.so")
 MAX_HIDDEN = 8
 NAME_MAX = 96
 
-POISSON, NB, ZIP, ZINB = 0, 1, 2, 3
+POISSON, NB, ZIP, ZINB, CONSTRAINED_POISSON = 0, 1, 2, 3, 4
 MODEL_VAE, MODEL_GMVAE = 0, 1
 
 #: registry name -> (kind, head parameter names in registry order)
@@ -25,6 +25,7 @@ LIKELIHOOD_KINDS = {
     "negative binomial": (NB, ("p", "log_r")),
     "zero-inflated poisson": (ZIP, ("pi", "log_lambda")),
     "zero-inflated negative binomial": (ZINB, ("pi", "p", "log_r")),
+    "constrained poisson": (CONSTRAINED_POISSON, ("lambda",)),
 }
 
 
@@ -73,6 +74,7 @@ class StepArgs(Structure):
         ("cluster_stats", c_void_p),
         ("decoder_extra", c_void_p),
         ("dropout_seed", c_uint64),
+        ("count_sum", c_void_p),
     ]
 
 

@@ -10,6 +10,7 @@ namespace scvae {
 constexpr int WAVE = 64;
 constexpr float F32_TINY = 1.1754943508222875e-38f;
 constexpr float LOGIT_OF_TINY = -87.33654475055310898657f;  // log(float32.tiny)
+constexpr float LOG_F32_TINY = LOGIT_OF_TINY;
 constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
 constexpr float F32_MAX_HALF = 1.7014117331926443e38f;
 constexpr float BN_EPSILON = 1e-3f;
@@ -44,10 +45,12 @@ enum Likelihood : int {
   LK_POISSON = 0,  // heads: log_lambda
   LK_NB = 1,       // heads: p, log_r
   LK_ZIP = 2,      // heads: pi, log_lambda
-  LK_ZINB = 3      // heads: pi, p, log_r
+  LK_ZINB = 3,     // heads: pi, p, log_r
+  LK_CPOISSON = 4  // constrained Poisson (du:218-228): head lambda = softmax over the genes,
+                   // rate = lambda * N with N the count sum of the cell; unfused path only
 };
-__host__ __device__ inline int likelihood_heads(int kind) {
-  return kind == LK_POISSON ? 1 : (kind == LK_ZINB ? 3 : 2);
+__host__ __device__ constexpr int likelihood_heads(int kind) {
+  return (kind == LK_POISSON || kind == LK_CPOISSON) ? 1 : (kind == LK_ZINB ? 3 : 2);
 }
 
 #ifdef __HIPCC__

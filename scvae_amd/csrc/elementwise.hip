@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void loglik_rows_kernel(const float* __restric
                                                           const float* __restrict__ gw,
                                                           const float* __restrict__ row_const,
                                                           float* __restrict__ ll, int B, int F) {
-  constexpr int P = (KIND == LK_POISSON) ? 1 : (KIND == LK_ZINB ? 3 : 2);
+  constexpr int P = likelihood_heads(KIND);
   __shared__ float red[4];
   const int r = blockIdx.x;
   const int b = r % B;
@@ -83,6 +83,117 @@ int loglik_bwd(hipStream_t stream, int kind, const float* t, int ldt, HeadPtrs p
                const float* gw, const float* row_const, float* ll, int rows, int B, int F) {
   SCVAE_ARG(gw);
   return launch_loglik<true>(stream, kind, t, ldt, pre, ldp, gw, row_const, ll, rows, B, F);
+}
+
+// ---- constrained Poisson (du:218-228; N = count sum of the cell, va:2400-2405, 2490-2496) ----
+// lambda = clip(softmax_F(pre), tiny, 1), rate = lambda * N,
+//   sum_f log p(t_f) = sum_f t_f * log(rate_f) - rate_f - lgamma(1 + t_f).
+// One workgroup per row; the row of logits is staged in LDS (F <= 38 000) and walked four times:
+// max, sum of exponentials, log-probability (+ the sum S = sum_f gate_f (t_f - N lambda_f) the
+// gradient needs), and, if GRAD, pre_g <- gw * (gate_g (t_g - N lambda_g) - lambda_g S).
+// gate_f = [lambda_f >= tiny]: the clip's pass-through (always 1 unless a logit is 87 below the
+// row maximum).  RATE: overwrite pre with the rate instead (evaluate-time statistics).
+template <bool GRAD, bool RATE>
+__global__ __launch_bounds__(1024) void cpoisson_rows_kernel(
+    const float* __restrict__ t, int ldt, float* __restrict__ pre, int ldp,
+    const float* __restrict__ gw, const float* __restrict__ count_sum,
+    const float* __restrict__ row_const, float* __restrict__ ll, int B, int F) {
+  extern __shared__ float row[];
+  __shared__ float red[16];
+  const int r = blockIdx.x, b = r % B;
+  float* prow = pre + (size_t)r * ldp;
+  const float* trow = t + (size_t)b * ldt;
+  const float N = count_sum[b];
+  float mx = -INFINITY;
+  for (int f = threadIdx.x; f < F; f += 1024) {
+    const float v = prow[f];
+    row[f] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = wave_max(mx);
+  {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
+  }
+  float se = 0.f;
+  for (int f = threadIdx.x; f < F; f += 1024) se += __expf(row[f] - mx);
+  se = block_sum<1024>(se, red);
+  const float lse = mx + __logf(se);
+  const float log_n = __logf(fmaxf(N, F32_TINY));
+  if (RATE) {
+    for (int f = threadIdx.x; f < F; f += 1024)
+      prow[f] = fmaxf(__expf(row[f] - lse), F32_TINY) * N;
+    return;
+  }
+  float lp = 0.f, S = 0.f;
+  for (int f = threadIdx.x; f < F; f += 1024) {
+    const float tv = trow[f];
+    const float log_lam = row[f] - lse;
+    const float lam = __expf(log_lam);
+    const bool gate = lam >= F32_TINY;
+    const float lam_c = gate ? lam : F32_TINY;
+    const float log_rate = (gate ? log_lam : LOG_F32_TINY) + log_n;
+    lp += (tv > 0.f ? tv * log_rate : 0.f) - lam_c * N;
+    if (row_const == nullptr) lp -= lgamma1p(tv);
+    if (GRAD && gate) S += tv - N * lam;
+  }
+  lp = block_sum<1024>(lp, red);
+  if (GRAD) {
+    S = block_sum<1024>(S, red);
+    const float g_up = gw[r];
+    for (int f = threadIdx.x; f < F; f += 1024) {
+      const float lam = __expf(row[f] - lse);
+      const float own = lam >= F32_TINY ? trow[f] - N * lam : 0.f;
+      prow[f] = g_up * (own - lam * S);
+    }
+  }
+  if (threadIdx.x == 0 && ll != nullptr) ll[r] = lp - (row_const ? row_const[b] : 0.f);
+}
+
+template <bool GRAD, bool RATE>
+static int launch_cpoisson(hipStream_t stream, const float* t, int ldt, float* pre, int ldp,
+                           const float* gw, const float* count_sum, const float* row_const,
+                           float* ll, int rows, int B, int F) {
+  SCVAE_ARG(pre && count_sum && rows >= 0 && B > 0 && F > 0);
+  SCVAE_ARG(RATE || t);
+  if (rows == 0) return 0;
+  const size_t lds = (size_t)F * sizeof(float);
+  if (lds > 152 * 1024) {
+    set_error("constrained Poisson: %d genes do not fit into LDS", F);
+    return -1;
+  }
+  auto kfn = cpoisson_rows_kernel<GRAD, RATE>;
+  SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kfn, dim3(rows), dim3(1024), lds, stream, t, ldt, pre, ldp, gw, count_sum,
+                     row_const, ll, B, F);
+  SCVAE_LAUNCH_CHECK("cpoisson_rows_kernel");
+  return 0;
+}
+
+int cpoisson_fwd(hipStream_t stream, const float* t, int ldt, float* pre, int ldp,
+                 const float* count_sum, const float* row_const, float* ll, int rows, int B,
+                 int F) {
+  SCVAE_ARG(ll);
+  return launch_cpoisson<false, false>(stream, t, ldt, pre, ldp, nullptr, count_sum, row_const, ll,
+                                       rows, B, F);
+}
+int cpoisson_bwd(hipStream_t stream, const float* t, int ldt, float* pre, int ldp, const float* gw,
+                 const float* count_sum, const float* row_const, float* ll, int rows, int B,
+                 int F) {
+  SCVAE_ARG(gw);
+  return launch_cpoisson<true, false>(stream, t, ldt, pre, ldp, gw, count_sum, row_const, ll, rows,
+                                      B, F);
+}
+int cpoisson_rate(hipStream_t stream, float* pre, int ldp, const float* count_sum, int rows, int B,
+                  int F) {
+  return launch_cpoisson<false, true>(stream, nullptr, 0, pre, ldp, nullptr, count_sum, nullptr,
+                                      nullptr, rows, B, F);
 }
 
 // ---- piecewise categorical likelihood (-k) ----
@@ -260,7 +371,7 @@ __global__ __launch_bounds__(256) void px_statistics_kernel(HeadPtrs pre, int ld
                                                             float* __restrict__ p_x_mean,
                                                             float* __restrict__ mean_of_var,
                                                             float* __restrict__ var_of_mean) {
-  constexpr int P = (KIND == LK_POISSON) ? 1 : (KIND == LK_ZINB ? 3 : 2);
+  constexpr int P = likelihood_heads(KIND);
   const int b = blockIdx.y;
   const int f = blockIdx.x * 256 + threadIdx.x;
   if (f >= F) return;
@@ -304,6 +415,7 @@ int px_statistics(hipStream_t stream, int kind, HeadPtrs pre, int ldp, int S, in
     case LK_NB: SCVAE_PX(LK_NB); break;
     case LK_ZIP: SCVAE_PX(LK_ZIP); break;
     case LK_ZINB: SCVAE_PX(LK_ZINB); break;
+    case LK_CPOISSON: SCVAE_PX(LK_CPOISSON); break;
     default: set_error("unknown likelihood kind %d", kind); return -1;
   }
 #undef SCVAE_PX
@@ -319,7 +431,7 @@ __global__ __launch_bounds__(256) void loglik_elementwise_kernel(const float* __
                                                                  float* __restrict__ out,
                                                                  float* __restrict__ mean,
                                                                  float* __restrict__ var, size_t n) {
-  constexpr int P = (KIND == LK_POISSON) ? 1 : (KIND == LK_ZINB ? 3 : 2);
+  constexpr int P = likelihood_heads(KIND);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x) {
     float a[P], g[P];

@@ -27,6 +27,14 @@ int loglik_fwd(hipStream_t stream, int kind, const float* t, int ldt, HeadPtrs p
 // in place: pre_j <- gw[r] * d loglik / d pre_j ; also (re)computes ll if ll != null
 int loglik_bwd(hipStream_t stream, int kind, const float* t, int ldt, HeadPtrs pre, int ldp,
                const float* gw, const float* row_const, float* ll, int rows, int B, int F);
+// constrained Poisson (du:218-228): softmax over the genes times the cell's count sum; `pre`
+// [rows, F] logits, overwritten with the upstream-scaled gradient (bwd) or the rate (rate)
+int cpoisson_fwd(hipStream_t stream, const float* t, int ldt, float* pre, int ldp,
+                 const float* count_sum, const float* row_const, float* ll, int rows, int B, int F);
+int cpoisson_bwd(hipStream_t stream, const float* t, int ldt, float* pre, int ldp, const float* gw,
+                 const float* count_sum, const float* row_const, float* ll, int rows, int B, int F);
+int cpoisson_rate(hipStream_t stream, float* pre, int ldp, const float* count_sum, int rows, int B,
+                  int F);
 // Piecewise categorical likelihood (`Categorised`, distributions/categorised.py:210-263; -k):
 // `logits` [rows, F*(K+1)] of the P_K head, class c of feature f at f*(K+1)+c.  Counts below K are
 // classes of the categorical, class K hands the excess t-K to the count distribution (kind:

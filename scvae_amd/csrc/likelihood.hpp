@@ -19,7 +19,7 @@ namespace scvae {
 #ifdef __HIPCC__
 template <int KIND>
 struct LikelihoodTraits {
-  static constexpr int P = (KIND == LK_POISSON) ? 1 : (KIND == LK_ZINB ? 3 : 2);
+  static constexpr int P = likelihood_heads(KIND);
   // negative-binomial kinds carry the terms lgamma(r+t)-lgamma(r) / digamma(r+t)-digamma(r),
   // which vanish at t == 0 (the "sparse correction")
   static constexpr bool HAS_R = (KIND == LK_NB || KIND == LK_ZINB);
@@ -108,7 +108,10 @@ __device__ __forceinline__ void lik_elem(float t, const float* a, float& lp, flo
 // E[x|z] and Var[x|z] (TFP semantics; evaluate-time statistics, va:2665-2713)
 template <int KIND>
 __device__ __forceinline__ void lik_mean_var(const float* a, float& mean, float& var) {
-  if constexpr (KIND == LK_POISSON) {
+  if constexpr (KIND == LK_CPOISSON) {
+    // (the head has been normalised to the rate lambda * N by cpoisson_rate_rows)
+    mean = a[0]; var = a[0];
+  } else if constexpr (KIND == LK_POISSON) {
     const float lam = __expf(fminf(fmaxf(a[0], -10.f), 10.f));
     mean = lam; var = lam;
   } else if constexpr (KIND == LK_NB) {

@@ -417,8 +417,13 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   // dropout gives every head its own mask of the decoder output (va:2475-2488, 2507-2518):
   // the fused kernel shares one tile of it between the heads, so that training pass is unfused
   const bool head_drop = training && p->heads[0].keep > 0.f;
+  const bool cpoisson = c.likelihood == LK_CPOISSON;   // row softmax: unfused
+  if (cpoisson && !a->count_sum) {
+    set_error("the constrained Poisson likelihood needs scvae_step_args.count_sum");
+    return -1;
+  }
   const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
-                     !a->p_x_mean && KM == 0 && !head_drop;
+                     !a->p_x_mean && KM == 0 && !head_drop && !cpoisson;
   const HeadParams hp = head_params(p);
   const float* head_in[4] = {dch, dch, dch, dch};   // [3]: the P_K head
   if (!fused) {
@@ -445,12 +450,26 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                                    p->fused_ws);
     if (KM > 0)
       return loglik_cat_fwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->ll, R, B, F);
+    if (cpoisson)
+      return cpoisson_fwd(s, a->t, F, p->pre[0], F, a->count_sum, a->row_const, p->ll, R, B, F);
     return loglik_fwd(s, c.likelihood, a->t, F, pre, F, a->row_const, p->ll, R, B, F);
   };
+  bool ll_done = false;
   if (a->p_x_mean) {
     if (!(a->p_x_stddev && a->stddev_of_p_x_given_z_mean)) {
       set_error("p_x_mean requires p_x_stddev and stddev_of_p_x_given_z_mean");
       return -1;
+    }
+    if (cpoisson) {
+      // the statistics want the rates, the likelihood the logits: likelihood first, then the
+      // logits are normalised in place
+      if (training) {
+        set_error("p_x_mean in a training step of the constrained Poisson likelihood");
+        return -1;
+      }
+      if ((rc = loglik_forward())) return rc;
+      ll_done = true;
+      if ((rc = cpoisson_rate(s, p->pre[0], F, a->count_sum, R, B, F))) return rc;
     }
     if (KM > 0)
       rc = px_statistics_cat(s, c.likelihood, pre, F, p->pre_k, KM, S, B, F, nullptr, 0, 0,
@@ -465,7 +484,8 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   const float row_scale = 1.f / ((float)n_mc * (float)GB);
   if (!training) {
-    if ((rc = loglik_forward())) return rc;
+    if (!ll_done)
+      if ((rc = loglik_forward())) return rc;
     if ((rc = vae_elbo(s, p->ll, p->kl_cell, mc_kl, n_iw, n_mc, B, w, row_scale, a->scalars, nullptr)))
       return rc;
     if (a->log_p_x_given_z)
@@ -499,6 +519,9 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     if (KM > 0)
       rc = loglik_cat_bwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->gw,
                           n_iw == 1 ? p->ll : nullptr, R, B, F);
+    else if (cpoisson)
+      rc = cpoisson_bwd(s, a->t, F, p->pre[0], F, p->gw, a->count_sum, a->row_const,
+                        n_iw == 1 ? p->ll : nullptr, R, B, F);
     else
       rc = loglik_bwd(s, c.likelihood, a->t, F, pre, F, p->gw, a->row_const,
                       n_iw == 1 ? p->ll : nullptr, R, B, F);
@@ -608,7 +631,7 @@ int scvae_plan_create(const scvae_model_config* cfg, scvae_plan** out) {
   SCVAE_ARG(cfg && out);
   SCVAE_ARG(cfg->feature_size > 0 && cfg->latent_size > 0 && cfg->latent_size <= 1024);
   SCVAE_ARG(cfg->n_hidden >= 0 && cfg->n_hidden <= SCVAE_MAX_HIDDEN);
-  SCVAE_ARG(cfg->likelihood >= 0 && cfg->likelihood <= 3);
+  SCVAE_ARG(cfg->likelihood >= 0 && cfg->likelihood <= 4);
   for (int i = 0; i < cfg->n_hidden; ++i) SCVAE_ARG(cfg->hidden[i] > 0);
   SCVAE_ARG(cfg->model_type == SCVAE_MODEL_VAE || cfg->model_type == SCVAE_MODEL_GMVAE);
   SCVAE_ARG(cfg->model_type == SCVAE_MODEL_VAE || (cfg->n_clusters >= 1 && cfg->n_clusters <= 1024));

@@ -329,8 +329,13 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const int KM = c.k_max, FC = F * (KM + 1);   // piecewise categorical likelihood: unfused path
   // (dropout: every head draws its own mask of the decoder output, so that pass is unfused)
   const bool head_drop = training && p->heads[0].keep > 0.f;
+  const bool cpoisson = c.likelihood == LK_CPOISSON;   // row softmax: unfused
+  if (cpoisson && !a->count_sum) {
+    set_error("the constrained Poisson likelihood needs scvae_step_args.count_sum");
+    return -1;
+  }
   const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
-                     !a->p_x_mean && KM == 0 && !head_drop;
+                     !a->p_x_mean && KM == 0 && !head_drop && !cpoisson;
   const HeadParams hp = head_params(p);
   const float* head_in[4] = {dch, dch, dch, dch};   // [3]: the P_K head
   if (!fused) {
@@ -348,10 +353,20 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
            ldh, FC, FC, ACT_NONE, false);
     }
   }
+  bool ll_done = false;
   if (a->p_x_mean) {
     if (!(a->p_x_stddev && a->stddev_of_p_x_given_z_mean)) {
       set_error("p_x_mean requires p_x_stddev and stddev_of_p_x_given_z_mean");
       return -1;
+    }
+    if (cpoisson) {   // likelihood of the logits first, then rates in place for the statistics
+      if (training) {
+        set_error("p_x_mean in a training step of the constrained Poisson likelihood");
+        return -1;
+      }
+      TRY(cpoisson_fwd(s, a->t, F, p->pre[0], F, a->count_sum, a->row_const, p->ll, R, B, F));
+      ll_done = true;
+      TRY(cpoisson_rate(s, p->pre[0], F, a->count_sum, R, B, F));
     }
     for (int k = 0; k < K; ++k) {
       HeadPtrs pk;
@@ -380,7 +395,10 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                                 p->fused_ws));
     else if (KM > 0)
       TRY(loglik_cat_fwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->ll, R, B, F));
-    else
+    else if (cpoisson) {
+      if (!ll_done)
+        TRY(cpoisson_fwd(s, a->t, F, p->pre[0], F, a->count_sum, a->row_const, p->ll, R, B, F));
+    } else
       TRY(loglik_fwd(s, c.likelihood, a->t, F, pre, F, a->row_const, p->ll, R, B, F));
     TRY(gmvae_elbo(s, p->ll, p->klz, p->yprob, p->kl_y_cell, K, S, B, inv_gb, sums, nullptr));
     TRY(gmvae_elbo_finish(s, sums, w, thr, use_free_nats, 1.f, a->scalars, gate, prior, K,
@@ -399,6 +417,8 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                             p->ll, dcur, p->fused_ws));
   } else if (KM > 0) {
     TRY(loglik_cat_bwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->gw, p->ll, R, B, F));
+  } else if (cpoisson) {
+    TRY(cpoisson_bwd(s, a->t, F, p->pre[0], F, p->gw, a->count_sum, a->row_const, p->ll, R, B, F));
   } else {
     TRY(loglik_bwd(s, c.likelihood, a->t, F, pre, F, p->gw, a->row_const, p->ll, R, B, F));
   }

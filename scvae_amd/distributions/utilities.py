@@ -254,11 +254,48 @@ DISTRIBUTIONS = {
 }
 DISTRIBUTIONS["modified gaussian"] = DISTRIBUTIONS["softplus gaussian"]
 
+
+class ConstrainedPoisson:
+    """``Poisson(rate=theta["lambda"] * N)`` (du:218-228): ``lambda`` is the
+    softmax over the genes the model applied, ``N`` the count sums of the
+    cells, broadcast against it.  (Element-wise torch arithmetic on the
+    caller's device; inside a training step the softmax, the likelihood and
+    its gradient are one row kernel, csrc/elementwise.hip.)"""
+
+    def __init__(self, theta, N):
+        self.rate = theta["lambda"] * N
+
+    def log_prob(self, x):
+        x = torch.as_tensor(x, dtype=self.rate.dtype, device=self.rate.device)
+        return torch.xlogy(x, self.rate) - torch.lgamma(x + 1) - self.rate
+
+    def prob(self, x):
+        return torch.exp(self.log_prob(x))
+
+    def mean(self):
+        return self.rate
+
+    def variance(self):
+        return self.rate
+
+    def stddev(self):
+        return torch.sqrt(self.rate)
+
+
+DISTRIBUTIONS["constrained poisson"] = {
+    "parameters": {
+        "lambda": {
+            "support": [0, 1],
+            "activation function": lambda x: torch.softmax(x, dim=-1)
+        }
+    },
+    "class": lambda theta, N: ConstrainedPoisson(theta, N)
+}
+
 #: reference likelihoods that this build does not provide kernels for
 UNSUPPORTED_DISTRIBUTIONS = (
     "multivariate gaussian", "gaussian mixture", "log-normal",
-    "exponentially_modified_gaussian", "gamma", "bernoulli",
-    "constrained poisson", "lomax")
+    "exponentially_modified_gaussian", "gamma", "bernoulli", "lomax")
 
 LATENT_DISTRIBUTIONS = {
     "gaussian": {

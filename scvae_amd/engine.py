@@ -308,7 +308,7 @@ class Engine:
     def step(self, x, t, eps=None, row_const=None, training=False,
              n_iw=1, n_mc=1, warm_up_weight=1.0, deterministic_z=False,
              global_cells=None, outputs=None, scalars=None,
-             decoder_extra=None, dropout_seed=None):
+             decoder_extra=None, dropout_seed=None, count_sum=None):
         """One graph execution (no host synchronisation).  ``outputs`` maps
         optional output names of ``scvae_step_args`` to preallocated tensors.
         ``dropout_seed``: seed of this training step's dropout masks (default:
@@ -329,6 +329,12 @@ class Engine:
                         self.decoder_extra))
             a.decoder_extra = decoder_extra.data_ptr()
         a.eps = eps.data_ptr() if eps is not None else None
+        if self.likelihood == "constrained poisson":
+            # N of every cell: the total of the constrained rates (va:1017-1019)
+            if count_sum is None or count_sum.numel() != cells:
+                raise ValueError("count_sum must hold one value per cell")
+            count_sum = count_sum.reshape(-1).contiguous()
+            a.count_sum = count_sum.data_ptr()
         if training and self.uses_dropout:
             if dropout_seed is None:
                 self._dropout_steps += 1

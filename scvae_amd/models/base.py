@@ -179,6 +179,13 @@ class ModelBase:
         else:
             x = t
         t.decoder_extra = self._decoder_extra_inputs(data_set)
+        # N of the constrained Poisson: the count sums of the data set
+        # (count_sum_parameter, va:823-826, 1017-1019)
+        t.count_sum = None
+        if self.use_count_sum_as_parameter:
+            t.count_sum = torch.as_tensor(
+                numpy.asarray(data_set.count_sum, dtype=numpy.float32)
+                .reshape(-1), device=self.engine.device)
         return x, t
 
     @property
@@ -462,10 +469,13 @@ class ModelBase:
                 self._draw_noise(eps, samples, cells, global_cells, lo, step)
                 de = (t_train.decoder_extra.index_select(0, rows)
                       if t_train.decoder_extra is not None else None)
+                cs = (t_train.count_sum.index_select(0, rows)
+                      if t_train.count_sum is not None else None)
                 scalars = engine.step(
                     xb, tb, eps=eps, row_const=rc, training=True, n_iw=n_iw,
                     n_mc=n_mc, warm_up_weight=warm_up_weight,
                     global_cells=global_cells, decoder_extra=de,
+                    count_sum=cs,
                     dropout_seed=((self.noise_seed * 1000003 + rank) << 40)
                     + step + 1)
                 if sync is not None:
@@ -727,9 +737,12 @@ class ModelBase:
                 extra, outputs, i, j, cells))
             de = (t.decoder_extra.index_select(0, rows)
                   if getattr(t, "decoder_extra", None) is not None else None)
+            cs = (t.count_sum.index_select(0, rows)
+                  if getattr(t, "count_sum", None) is not None else None)
             engine.step(xb, tb, eps=eps, row_const=rc, training=False,
                         n_iw=n_iw, n_mc=n_mc, deterministic_z=deterministic_z,
-                        outputs=out, scalars=scalars[j], decoder_extra=de)
+                        outputs=out, scalars=scalars[j], decoder_extra=de,
+                        count_sum=cs)
         if sync is not None:
             for tensor in [scalars, kl_neurons, latent] + [
                     v for v in extra.values() if torch.is_tensor(v)]:
@@ -987,6 +1000,10 @@ class ModelBase:
             model_string = "model"
         if self.batch_correction:   # as va:1639-1650
             raise NotImplementedError("Sampling with batch correction.")
+        if self.use_count_sum_as_parameter:
+            raise NotImplementedError(
+                "Sampling with count sum as reconstruction distribution "
+                "parameter.")
         if self.use_count_sum_as_feature:
             raise NotImplementedError(
                 "Sampling with count sum as additional latent feature.")

@@ -223,10 +223,6 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
             reconstruction_distribution=self.reconstruction_distribution_name,
             number_of_reconstruction_classes=self.k_max)
 
-        if self.use_count_sum_as_parameter:
-            raise mu.not_in_this_build(
-                "Count sum as a likelihood parameter (constrained Poisson, "
-                "multinomial)", "gm:3118-3125")
         if self.latent_distribution_name != "gaussian mixture":
             raise mu.not_in_this_build(
                 "Latent distribution `{}`".format(
@@ -235,7 +231,7 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
             raise ValueError("The GMVAE needs at least one hidden layer.")
         if self.reconstruction_distribution_name not in (
                 "poisson", "negative binomial", "zero-inflated poisson",
-                "zero-inflated negative binomial"):
+                "zero-inflated negative binomial", "constrained poisson"):
             raise mu.not_in_this_build(
                 "Likelihood `{}`".format(
                     self.reconstruction_distribution_name), "du:30-307")

@@ -187,10 +187,6 @@ class VariationalAutoencoder(ModelBase):
             parameterise_latent_posterior=self.parameterise_latent_posterior)
 
         # options of the reference graph that have no kernels in this build
-        if self.use_count_sum_as_parameter:
-            raise mu.not_in_this_build(
-                "Count sum as a likelihood parameter (constrained Poisson, "
-                "multinomial)", "va:2400-2433")
         for architecture in (self.inference_architecture,
                              self.generative_architecture):
             if architecture not in ("MLP", "LFM"):
@@ -207,7 +203,7 @@ class VariationalAutoencoder(ModelBase):
                     self.latent_distribution_name), "du:309-338")
         if self.reconstruction_distribution_name not in (
                 "poisson", "negative binomial", "zero-inflated poisson",
-                "zero-inflated negative binomial"):
+                "zero-inflated negative binomial", "constrained poisson"):
             raise mu.not_in_this_build(
                 "Likelihood `{}`".format(
                     self.reconstruction_distribution_name), "du:30-307")

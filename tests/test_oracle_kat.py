@@ -261,3 +261,25 @@ def test_philox_known_answer_vectors():
     m = philox.dropout_mask(500, 33, 0.8, 5, 2)
     assert set(np.unique(m)) == {np.float32(0), np.float32(1) / np.float32(0.8)}
     assert abs((m > 0).mean() - 0.8) < 0.01
+
+
+def test_constrained_poisson_matches_scipy():
+    """du:218-228: Poisson(rate = softmax(pre) * N) against scipy; the rates
+    of a cell sum to its count sum; gradient wrt the logits is t - T*lambda."""
+    import scipy.stats as st
+    rng = np.random.default_rng(0)
+    pre = torch.from_numpy(rng.normal(0, 1.5, (6, 13))).requires_grad_(True)
+    t = torch.from_numpy(rng.poisson(2.0, (6, 13)).astype(np.float64))
+    N = t.sum(dim=1, keepdim=True) + 3.0   # N need not equal sum(t)
+    got = lk.log_prob("constrained poisson", t, (pre,), N)
+    lam = np.exp(pre.detach().numpy())
+    lam /= lam.sum(axis=1, keepdims=True)
+    want = st.poisson.logpmf(t.numpy(), lam * N.numpy())
+    assert np.allclose(got.detach().numpy(), want, rtol=1e-12, atol=1e-12)
+    mean, var = lk.mean_variance("constrained poisson", (pre,), N)
+    assert np.allclose(mean.detach().sum(dim=1), N.reshape(-1))
+    assert torch.equal(mean, var)
+    got.sum().backward()
+    T = t.sum(dim=1, keepdim=True)
+    assert np.allclose(pre.grad.numpy(), (t - T * torch.from_numpy(lam)).numpy(),
+                       atol=1e-10)
