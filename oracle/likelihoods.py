@@ -51,6 +51,12 @@ LIKELIHOOD_PARAMETERS = {
 }
 
 
+#: the likelihoods that factorise over the genes (everything but the
+#: constrained Poisson, whose softmax couples the genes of a cell)
+ELEMENTWISE_LIKELIHOODS = tuple(
+    name for name in LIKELIHOOD_PARAMETERS if name != "constrained poisson")
+
+
 def _clip_log(a):
     """identity activation clipped to the support [-10, 10]."""
     return torch.clamp(a, -10.0, 10.0)

@@ -742,6 +742,10 @@ int scvae_plan_decode(scvae_plan* p, const float* z, int64_t rows, float* p_x_me
   SCVAE_ARG(p && z && p_x_mean);
   SCVAE_ARG(p->params && p->ws);
   SCVAE_ARG(rows > 0 && rows <= p->max_cells);
+  if (p->cfg.likelihood == LK_CPOISSON) {   // as the reference: NotImplementedError (va:1642-1645)
+    set_error("decode: sampling with the count sum as a likelihood parameter is not defined");
+    return -1;
+  }
   if (p->cfg.decoder_extra > 0) {   // as the reference: NotImplementedError (va:1638-1650)
     scvae::set_error("sampling with batch correction / count-sum decoder inputs is not supported");
     return -1;

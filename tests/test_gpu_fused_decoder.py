@@ -75,7 +75,7 @@ def _run(device, name, rows, cells, F, H, density, seed=0, row_const=True):
 
 @pytest.mark.parametrize("rows,F", [(1, 1), (33, 63), (64, 64), (65, 65),
                                     (130, 200), (97, 129)])
-@pytest.mark.parametrize("name", list(lk.LIKELIHOOD_PARAMETERS))
+@pytest.mark.parametrize("name", list(lk.ELEMENTWISE_LIKELIHOODS))
 def test_tile_edges(cuda_device, name, rows, F):
     _run(cuda_device, name, rows, rows, F, 20, 0.3)
 

@@ -261,7 +261,7 @@ def test_decode_matches_oracle(cuda_device, model_type):
     from scvae_amd.engine import Engine
     F, L, H, K, rows = 70, 4, (12, 10), 3, 37
     rng = np.random.default_rng(5)
-    for likelihood in lk.LIKELIHOOD_PARAMETERS:
+    for likelihood in lk.ELEMENTWISE_LIKELIHOODS:
         eng = Engine(F, L, H, likelihood, batch_norm=True,
                      model_type=model_type, n_clusters=K, device=cuda_device,
                      seed=4)

@@ -82,7 +82,7 @@ def test_big_gemm_matches_fp64(cuda_device, ta, M, N, K):
     assert err < 3e-5 * ref.abs().max().item(), err
 
 
-@pytest.mark.parametrize("name", list(lk.LIKELIHOOD_PARAMETERS))
+@pytest.mark.parametrize("name", list(lk.ELEMENTWISE_LIKELIHOODS))
 def test_loglik_forward_backward(cuda_device, name):
     from scvae_amd import _lib
     lib = _lib.load()
