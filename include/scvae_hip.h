@@ -34,9 +34,10 @@ enum {
   SCVAE_NB = 1,      /* p, log_r              */
   SCVAE_ZIP = 2,     /* pi, log_lambda        */
   SCVAE_ZINB = 3,    /* pi, p, log_r          */
-  SCVAE_CONSTRAINED_POISSON = 4 /* lambda: softmax over the genes, rate = lambda * count sum of
+  SCVAE_CONSTRAINED_POISSON = 4, /* lambda: softmax over the genes, rate = lambda * count sum of
                         the cell (du:218-228, va:2400-2405, 2490-2496); needs
                         scvae_step_args.count_sum; heads and likelihood run unfused */
+  SCVAE_BERNOULLI = 5 /* logits (du:194-204), targets binarised by the caller; unfused */
 };
 
 enum { SCVAE_MODEL_VAE = 0, SCVAE_MODEL_GMVAE = 1 };

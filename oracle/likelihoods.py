@@ -48,13 +48,16 @@ LIKELIHOOD_PARAMETERS = {
     # du:218-228: activation softmax over the genes, rate = lambda * N with N
     # the count sum of the cell (va:2400-2405, 2490-2496)
     "constrained poisson": ("lambda",),
+    # du:194-204: tfp.distributions.Bernoulli(logits=...), binarised targets
+    "bernoulli": ("logits",),
 }
 
 
-#: the likelihoods that factorise over the genes (everything but the
-#: constrained Poisson, whose softmax couples the genes of a cell)
-ELEMENTWISE_LIKELIHOODS = tuple(
-    name for name in LIKELIHOOD_PARAMETERS if name != "constrained poisson")
+#: the count likelihoods of the fused decoder kernels (their data term
+#: -lgamma(1 + t) is added by the caller once per cell)
+ELEMENTWISE_LIKELIHOODS = (
+    "poisson", "negative binomial", "zero-inflated poisson",
+    "zero-inflated negative binomial")
 
 
 def _clip_log(a):
@@ -116,6 +119,8 @@ def log_prob(name, t, pre, count_sum=None):
     """``pre``: tuple of head pre-activations in registry order."""
     if name == "constrained poisson":
         return constrained_poisson_log_prob(t, pre[0], count_sum)
+    if name == "bernoulli":   # -sigmoid_cross_entropy_with_logits
+        return t * F.logsigmoid(pre[0]) + (1.0 - t) * F.logsigmoid(-pre[0])
     if name == "poisson":
         return poisson_log_prob(t, *pre)
     if name == "negative binomial":
@@ -160,6 +165,9 @@ def mean_variance(name, pre, count_sum=None):
     if name == "constrained poisson":
         rate = constrained_poisson_rate(pre[0], count_sum)
         return rate, rate
+    if name == "bernoulli":
+        p = torch.sigmoid(pre[0])
+        return p, p * (1.0 - p)
     if name == "poisson":
         lam = torch.exp(_clip_log(pre[0]))
         return lam, lam

@@ -16,7 +16,7 @@ LIBRARY_PATH = os.path.join(_HERE, "csrc", "libscvae_hip.so")
 MAX_HIDDEN = 8
 NAME_MAX = 96
 
-POISSON, NB, ZIP, ZINB, CONSTRAINED_POISSON = 0, 1, 2, 3, 4
+POISSON, NB, ZIP, ZINB, CONSTRAINED_POISSON, BERNOULLI = 0, 1, 2, 3, 4, 5
 MODEL_VAE, MODEL_GMVAE = 0, 1
 
 #: registry name -> (kind, head parameter names in registry order)
@@ -26,6 +26,7 @@ LIKELIHOOD_KINDS = {
     "zero-inflated poisson": (ZIP, ("pi", "log_lambda")),
     "zero-inflated negative binomial": (ZINB, ("pi", "p", "log_r")),
     "constrained poisson": (CONSTRAINED_POISSON, ("lambda",)),
+    "bernoulli": (BERNOULLI, ("logits",)),
 }
 
 

@@ -46,11 +46,14 @@ enum Likelihood : int {
   LK_NB = 1,       // heads: p, log_r
   LK_ZIP = 2,      // heads: pi, log_lambda
   LK_ZINB = 3,     // heads: pi, p, log_r
-  LK_CPOISSON = 4  // constrained Poisson (du:218-228): head lambda = softmax over the genes,
+  LK_CPOISSON = 4, // constrained Poisson (du:218-228): head lambda = softmax over the genes,
                    // rate = lambda * N with N the count sum of the cell; unfused path only
+  LK_BERNOULLI = 5 // heads: logits (du:194-204; binarised targets); unfused path only
 };
 __host__ __device__ constexpr int likelihood_heads(int kind) {
-  return (kind == LK_POISSON || kind == LK_CPOISSON) ? 1 : (kind == LK_ZINB ? 3 : 2);
+  return (kind == LK_POISSON || kind == LK_CPOISSON || kind == LK_BERNOULLI)
+             ? 1
+             : (kind == LK_ZINB ? 3 : 2);
 }
 
 #ifdef __HIPCC__

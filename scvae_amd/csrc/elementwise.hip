@@ -65,6 +65,10 @@ static int launch_loglik(hipStream_t stream, int kind, const float* t, int ldt, 
       hipLaunchKernelGGL((loglik_rows_kernel<LK_ZINB, GRAD>), grid, block, 0, stream, t, ldt, pre,
                          ldp, gw, row_const, ll, B, F);
       break;
+    case LK_BERNOULLI:
+      hipLaunchKernelGGL((loglik_rows_kernel<LK_BERNOULLI, GRAD>), grid, block, 0, stream, t, ldt,
+                         pre, ldp, gw, row_const, ll, B, F);
+      break;
     default:
       set_error("unknown likelihood kind %d", kind);
       return -1;
@@ -416,6 +420,7 @@ int px_statistics(hipStream_t stream, int kind, HeadPtrs pre, int ldp, int S, in
     case LK_ZIP: SCVAE_PX(LK_ZIP); break;
     case LK_ZINB: SCVAE_PX(LK_ZINB); break;
     case LK_CPOISSON: SCVAE_PX(LK_CPOISSON); break;
+    case LK_BERNOULLI: SCVAE_PX(LK_BERNOULLI); break;
     default: set_error("unknown likelihood kind %d", kind); return -1;
   }
 #undef SCVAE_PX
@@ -468,6 +473,7 @@ int loglik_elementwise(hipStream_t stream, int kind, const float* t, HeadPtrs pr
     case LK_NB: SCVAE_LE(LK_NB); break;
     case LK_ZIP: SCVAE_LE(LK_ZIP); break;
     case LK_ZINB: SCVAE_LE(LK_ZINB); break;
+    case LK_BERNOULLI: SCVAE_LE(LK_BERNOULLI); break;
     default: set_error("unknown likelihood kind %d", kind); return -1;
   }
 #undef SCVAE_LE

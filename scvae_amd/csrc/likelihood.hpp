@@ -33,7 +33,14 @@ struct LikelihoodTraits {
 template <int KIND, bool GRAD>
 __device__ __forceinline__ void lik_dense(float t, const float* a, float& lp, float* g, float& r,
                                           float& rgate) {
-  if constexpr (KIND == LK_POISSON) {
+  if constexpr (KIND == LK_BERNOULLI) {
+    // tfp.distributions.Bernoulli(logits): t log sigmoid(a) + (1 - t) log sigmoid(-a)
+    float ls_pos, ls_neg, sig;
+    log_sigmoid_pair(a[0], ls_pos, ls_neg, sig);
+    lp = t * ls_pos + (1.f - t) * ls_neg;
+    if (GRAD) g[0] = t - sig;
+    r = 0.f; rgate = 0.f;
+  } else if constexpr (KIND == LK_POISSON) {
     const float ll = fminf(fmaxf(a[0], -10.f), 10.f);
     const float lam = __expf(ll);
     lp = t * ll - lam;
@@ -111,6 +118,9 @@ __device__ __forceinline__ void lik_mean_var(const float* a, float& mean, float&
   if constexpr (KIND == LK_CPOISSON) {
     // (the head has been normalised to the rate lambda * N by cpoisson_rate_rows)
     mean = a[0]; var = a[0];
+  } else if constexpr (KIND == LK_BERNOULLI) {
+    const float pr = sigmoidf(a[0]);
+    mean = pr; var = pr * (1.f - pr);
   } else if constexpr (KIND == LK_POISSON) {
     const float lam = __expf(fminf(fmaxf(a[0], -10.f), 10.f));
     mean = lam; var = lam;

@@ -423,7 +423,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     return -1;
   }
   const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
-                     !a->p_x_mean && KM == 0 && !head_drop && !cpoisson;
+                     !a->p_x_mean && KM == 0 && !head_drop && c.likelihood <= LK_ZINB;
   const HeadParams hp = head_params(p);
   const float* head_in[4] = {dch, dch, dch, dch};   // [3]: the P_K head
   if (!fused) {
@@ -631,7 +631,7 @@ int scvae_plan_create(const scvae_model_config* cfg, scvae_plan** out) {
   SCVAE_ARG(cfg && out);
   SCVAE_ARG(cfg->feature_size > 0 && cfg->latent_size > 0 && cfg->latent_size <= 1024);
   SCVAE_ARG(cfg->n_hidden >= 0 && cfg->n_hidden <= SCVAE_MAX_HIDDEN);
-  SCVAE_ARG(cfg->likelihood >= 0 && cfg->likelihood <= 4);
+  SCVAE_ARG(cfg->likelihood >= 0 && cfg->likelihood <= 5);
   for (int i = 0; i < cfg->n_hidden; ++i) SCVAE_ARG(cfg->hidden[i] > 0);
   SCVAE_ARG(cfg->model_type == SCVAE_MODEL_VAE || cfg->model_type == SCVAE_MODEL_GMVAE);
   SCVAE_ARG(cfg->model_type == SCVAE_MODEL_VAE || (cfg->n_clusters >= 1 && cfg->n_clusters <= 1024));
@@ -872,7 +872,7 @@ int scvae_decoder_fused(int32_t kind, int32_t train, const float* d, int64_t row
 int scvae_likelihood_elementwise(int32_t kind, const float* t, const float* const* pre,
                                  float* log_prob, float* mean, float* variance, int64_t n,
                                  void* stream) {
-  SCVAE_ARG(pre && kind >= 0 && kind <= 3 && n >= 0);
+  SCVAE_ARG(pre && ((kind >= 0 && kind <= 3) || kind == LK_BERNOULLI) && n >= 0);
   scvae::HeadPtrs hp = {{nullptr, nullptr, nullptr}};
   for (int j = 0; j < scvae::likelihood_heads(kind); ++j) hp.p[j] = const_cast<float*>(pre[j]);
   return scvae::loglik_elementwise((hipStream_t)stream, kind, t, hp, log_prob, mean, variance,

@@ -85,8 +85,10 @@ static const char* head_names(int kind, int j) {
   static const char* ZIP[] = {"PI", "LOG_LAMBDA"};
   static const char* ZINB[] = {"PI", "P", "LOG_R"};
   static const char* CP[] = {"LAMBDA"};
+  static const char* BE[] = {"LOGITS"};
   switch (kind) {
     case LK_CPOISSON: return CP[j];
+    case LK_BERNOULLI: return BE[j];
     case LK_POISSON: return P[j];
     case LK_NB: return NB[j];
     case LK_ZIP: return ZIP[j];

@@ -335,7 +335,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     return -1;
   }
   const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
-                     !a->p_x_mean && KM == 0 && !head_drop && !cpoisson;
+                     !a->p_x_mean && KM == 0 && !head_drop && c.likelihood <= LK_ZINB;
   const HeadParams hp = head_params(p);
   const float* head_in[4] = {dch, dch, dch, dch};   // [3]: the P_K head
   if (!fused) {

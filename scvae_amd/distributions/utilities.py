@@ -282,6 +282,15 @@ class ConstrainedPoisson:
         return torch.sqrt(self.rate)
 
 
+DISTRIBUTIONS["bernoulli"] = {
+    "parameters": {
+        "logits": {
+            "support": [-numpy.inf, numpy.inf],
+            "activation function": identity
+        }
+    },
+    "class": _count("bernoulli")
+}
 DISTRIBUTIONS["constrained poisson"] = {
     "parameters": {
         "lambda": {
@@ -295,7 +304,7 @@ DISTRIBUTIONS["constrained poisson"] = {
 #: reference likelihoods that this build does not provide kernels for
 UNSUPPORTED_DISTRIBUTIONS = (
     "multivariate gaussian", "gaussian mixture", "log-normal",
-    "exponentially_modified_gaussian", "gamma", "bernoulli", "lomax")
+    "exponentially_modified_gaussian", "gamma", "lomax")
 
 LATENT_DISTRIBUTIONS = {
     "gaussian": {

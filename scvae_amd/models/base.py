@@ -165,17 +165,35 @@ class ModelBase:
         if data_set.noisy_preprocess or data_set.noisy_preprocessing_methods:
             raise mu.not_in_this_build(
                 "Noisy preprocessing at every epoch", "va:960-976")
-        if self.reconstruction_distribution_name == "bernoulli":
-            raise mu.not_in_this_build("Bernoulli likelihood", "du:194-204")
 
         def upload(values):
             if not scipy.sparse.issparse(values):
                 values = scipy.sparse.csr_matrix(
                     numpy.asarray(values, dtype=numpy.float32))
             return DeviceCSR.from_scipy(values, self.engine.device)
-        t = upload(data_set.values)
+        if self.reconstruction_distribution_name == "bernoulli":
+            # the Bernoulli likelihood models the binarised values
+            # (va:854-857; "binarise" = values > 0.5, data/processing.py:511-513)
+            if data_set.has_binarised_values:
+                t = upload(data_set.binarised_values)
+            else:
+                values = data_set.values
+                if scipy.sparse.issparse(values):
+                    values = scipy.sparse.csr_matrix(values)
+                    binarised = values.copy()
+                    binarised.data = (binarised.data > 0.5).astype(
+                        numpy.float32)
+                    binarised.eliminate_zeros()
+                else:
+                    binarised = (numpy.asarray(values) > 0.5).astype(
+                        numpy.float32)
+                t = upload(binarised)
+        else:
+            t = upload(data_set.values)
         if data_set.has_preprocessed_values:
             x = upload(data_set.preprocessed_values)
+        elif self.reconstruction_distribution_name == "bernoulli":
+            x = upload(data_set.values)
         else:
             x = t
         t.decoder_extra = self._decoder_extra_inputs(data_set)

@@ -231,7 +231,8 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
             raise ValueError("The GMVAE needs at least one hidden layer.")
         if self.reconstruction_distribution_name not in (
                 "poisson", "negative binomial", "zero-inflated poisson",
-                "zero-inflated negative binomial", "constrained poisson"):
+                "zero-inflated negative binomial", "constrained poisson",
+                "bernoulli"):
             raise mu.not_in_this_build(
                 "Likelihood `{}`".format(
                     self.reconstruction_distribution_name), "du:30-307")

@@ -203,7 +203,8 @@ class VariationalAutoencoder(ModelBase):
                     self.latent_distribution_name), "du:309-338")
         if self.reconstruction_distribution_name not in (
                 "poisson", "negative binomial", "zero-inflated poisson",
-                "zero-inflated negative binomial", "constrained poisson"):
+                "zero-inflated negative binomial", "constrained poisson",
+                "bernoulli"):
             raise mu.not_in_this_build(
                 "Likelihood `{}`".format(
                     self.reconstruction_distribution_name), "du:30-307")

@@ -155,3 +155,91 @@ def test_model_class_trains_and_evaluates(cuda_device, tmp_path):
     assert np.allclose(values.sum(axis=1), x.sum(axis=1), rtol=1e-4)
     with pytest.raises(NotImplementedError):
         model.sample(sample_size=5)
+
+
+# ------------------------------ Bernoulli -----------------------------------
+
+@pytest.mark.parametrize("model_type", ["VAE", "GMVAE"])
+def test_bernoulli_step_matches_oracle(cuda_device, model_type):
+    """du:194-204: Bernoulli(logits) on binarised targets, the raw counts as
+    encoder input (va:845-857)."""
+    from scvae_amd.engine import Engine
+    F, L, H, B, K = 110, 4, (16, 12), 23, 3
+    gm = model_type == "GMVAE"
+    eng = Engine(F, L, H, "bernoulli", model_type=model_type,
+                 n_clusters=K if gm else 1, device=cuda_device)
+    assert any(n.endswith("LOGITS/DENSE/weights") and "X" in n
+               for n in eng.named_parameters())
+    g = torch.Generator().manual_seed(1)
+    for name, p in eng.named_parameters().items():
+        if not name.endswith("weights"):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    cfg = om.ModelConfig(feature_size=F, latent_size=L, hidden_sizes=H,
+                         likelihood="bernoulli", n_clusters=K if gm else 1)
+    params = {k: v.detach().cpu().double()
+              for k, v in eng.named_parameters().items()}
+    moving = {k: v.detach().cpu().double()
+              for k, v in eng.named_moving_statistics().items()}
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(_counts(rng, B, F))
+    t = (x > 0.5).double()
+    eps = torch.from_numpy(rng.standard_normal(
+        (K, 1, B, L) if gm else (1, B, L)))
+    xd, td = x.float().to(cuda_device), t.float().to(cuda_device)
+    outs = {k: torch.zeros(B, F, device=cuda_device) for k in (
+        "p_x_mean", "p_x_stddev", "stddev_of_p_x_given_z_mean")}
+    sc = eng.step(xd, td, eps=eps.float().to(cuda_device),
+                  training=True).cpu().numpy()
+    torch.cuda.synchronize()
+    forward = om.gmvae_forward if gm else om.vae_forward
+    out, grads = om.gradients(
+        lambda p: forward(cfg, p, moving, x, t, eps, True, 1.0, {}), params)
+    _close(sc[0], out["lower_bound"], what="lower_bound")
+    for name, gr in eng.named_gradients().items():
+        if _skip_bias(name):
+            continue
+        got, want = gr.cpu(), grads[name]
+        if name == "Z/Q/ENCODER/LAYER_1/DENSE/weights":
+            got, want = got[:F], want[:F]
+        _close(got, want, rtol=3e-4, what="grad " + name)
+    moving = {k: v.detach().cpu().double()
+              for k, v in eng.named_moving_statistics().items()}
+    sc = eng.step(xd, td, eps=eps.float().to(cuda_device), training=False,
+                  outputs=outs).cpu().numpy()
+    out = forward(cfg, params, moving, x, t, eps, False,
+                  evaluation_statistics=True)
+    _close(sc[0], out["lower_bound"], what="lower_bound (evaluation)")
+    _close(outs["p_x_mean"].cpu(), out["p_x_mean"], rtol=2e-4, what="p_x_mean")
+    _close(outs["p_x_stddev"].cpu(), out["p_x_stddev"], rtol=2e-4,
+           what="p_x_stddev")
+    assert float(outs["p_x_mean"].min()) >= 0 and float(
+        outs["p_x_mean"].max()) <= 1
+
+
+def test_bernoulli_model_class(cuda_device, tmp_path):
+    from scvae_amd.data import DataSet
+    from scvae_amd.distributions import DISTRIBUTIONS
+    from scvae_amd.models import VariationalAutoencoder
+    from scvae_amd.models.utilities import load_learning_curves
+    rng = np.random.default_rng(5)
+    x = rng.poisson(0.8, size=(120, 40)).astype(np.float32)
+    data = DataSet("toy", values=x, example_names=np.arange(120).astype(str),
+                   feature_names=np.arange(40).astype(str), kind="training")
+    model = VariationalAutoencoder(
+        feature_size=40, latent_size=3, hidden_sizes=[12],
+        reconstruction_distribution="bernoulli", log_directory=str(tmp_path))
+    assert model.train(data, data, number_of_epochs=3, minibatch_size=30,
+                       learning_rate=1e-2) == 0
+    lb = load_learning_curves(model)["validation"]["lower_bound"]
+    assert np.isfinite(lb).all() and lb[-1] > lb[0]
+    # a Bernoulli log-likelihood is never positive
+    assert max(load_learning_curves(model)["validation"][
+        "reconstruction_error"]) <= 0
+    logits = torch.tensor([[-2.0, 0.0, 3.0]], device=cuda_device)
+    d = DISTRIBUTIONS["bernoulli"]["class"]({"logits": logits})
+    want = torch.distributions.Bernoulli(logits=logits.cpu())
+    t = torch.tensor([[0.0, 1.0, 1.0]])
+    assert torch.allclose(d.log_prob(t.to(cuda_device)).cpu(),
+                          want.log_prob(t), atol=1e-6)
+    assert torch.allclose(d.mean().cpu(), want.mean, atol=1e-6)
+    assert torch.allclose(d.variance().cpu(), want.variance, atol=1e-6)
