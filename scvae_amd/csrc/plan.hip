@@ -335,6 +335,55 @@ int copy(hipStream_t s, const float* src, float* dst, size_t n) {
 
 namespace scvae {
 
+// ---- unfused X_TILDE heads (shared by the VAE and the GMVAE step) ----
+// pre_j = head_in_j W_j + b_j for every likelihood head and the P_K head, each on its own
+// dropped-out copy of the decoder output in a training step with dropout (va:2475-2518)
+int heads_forward(scvae_plan* p, hipStream_t s, const float* dch, int ld, int R, bool training,
+                  const float* (&head_in)[4]) {
+  const int F = p->cfg.feature_size, KM = p->cfg.k_max, FC = F * (KM + 1);
+  int rc, ldh = ld;
+  for (int j = 0; j < p->P; ++j) {
+    Dense& hd = p->heads[j];
+    if ((rc = dense_input(p, s, hd, dch, ld, R, training, &head_in[j], &ldh))) return rc;
+    if ((rc = gemm(s, false, false, head_in[j], p->params + hd.w, p->params + hd.b, p->pre[j], R, F,
+                   hd.n_in, ldh, F, F, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+      return rc;
+  }
+  if (KM > 0) {
+    Dense& hk = p->head_k;
+    if ((rc = dense_input(p, s, hk, dch, ld, R, training, &head_in[3], &ldh))) return rc;
+    if ((rc = gemm(s, false, false, head_in[3], p->params + hk.w, p->params + hk.b, p->pre_k, R, FC,
+                   hk.n_in, ldh, FC, FC, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+      return rc;
+  }
+  return 0;
+}
+
+// dW_j = head_in_j^T G_j, db_j = colsum(G_j), dd = sum_j G_j W_j^T with G_j in place of pre_j;
+// with dropout every head's dd passes its own mask before the sum (through `scratch`)
+int heads_backward(scvae_plan* p, hipStream_t s, const float* const (&head_in)[4], int R,
+                   bool head_drop, float* dd, float* scratch) {
+  const int F = p->cfg.feature_size, KM = p->cfg.k_max, FC = F * (KM + 1);
+  const int h1 = p->heads[0].n_in;
+  int rc;
+  auto one = [&](Dense& hd, const float* in, float* G, int N, bool first) -> int {
+    if ((rc = gemm(s, true, false, in, G, nullptr, p->grads + hd.w, h1, N, R, h1, N, N, ACT_NONE,
+                   false, p->gemm_ws, p->gemm_ws_bytes)))
+      return rc;
+    if ((rc = col_sum(s, G, N, R, N, p->grads + hd.b, 1.f, 0, p->partial))) return rc;
+    if ((rc = gemm(s, false, true, G, p->params + hd.w, nullptr, head_drop ? scratch : dd, R, h1,
+                   N, N, N, h1, ACT_NONE, !head_drop && !first, p->gemm_ws, p->gemm_ws_bytes)))
+      return rc;
+    if (head_drop) return dense_input_backward(p, s, hd, scratch, dd, R, !first);
+    return 0;
+  };
+  for (int j = 0; j < p->P; ++j)
+    if ((rc = one(p->heads[j], head_in[j], p->pre[j], F, j == 0))) return rc;
+  if (KM > 0)   // the P_K head, same three products on [rows, F * (K + 1)]
+    if ((rc = one(p->head_k, head_in[3], p->pre_k, FC, false))) return rc;
+  return 0;
+}
+
 HeadParams head_params(scvae_plan* p) {
   HeadParams hp;
   for (int j = 0; j < 3; ++j) {
@@ -413,7 +462,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const int h1 = p->heads[0].n_in;
   // the fused kernel never materialises the [rows, P*F] pre-activations; the evaluate-time
   // statistics (p_x_mean, ...) need them, so that request takes the unfused path
-  const int KM = c.k_max, FC = F * (KM + 1);   // piecewise categorical likelihood: unfused path
+  const int KM = c.k_max;   // piecewise categorical likelihood: unfused path
   // dropout gives every head its own mask of the decoder output (va:2475-2488, 2507-2518):
   // the fused kernel shares one tile of it between the heads, so that training pass is unfused
   const bool head_drop = training && p->heads[0].keep > 0.f;
@@ -426,23 +475,8 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                      !a->p_x_mean && KM == 0 && !head_drop && c.likelihood <= LK_ZINB;
   const HeadParams hp = head_params(p);
   const float* head_in[4] = {dch, dch, dch, dch};   // [3]: the P_K head
-  if (!fused) {
-    int ldh = ld;
-    for (int j = 0; j < p->P; ++j) {
-      Dense& hd = p->heads[j];
-      if ((rc = dense_input(p, s, hd, dch, ld, R, training, &head_in[j], &ldh))) return rc;
-      if ((rc = gemm(s, false, false, head_in[j], p->params + hd.w, p->params + hd.b, p->pre[j], R,
-                     F, hd.n_in, ldh, F, F, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
-        return rc;
-    }
-    if (KM > 0) {
-      Dense& hk = p->head_k;
-      if ((rc = dense_input(p, s, hk, dch, ld, R, training, &head_in[3], &ldh))) return rc;
-      if ((rc = gemm(s, false, false, head_in[3], p->params + hk.w, p->params + hk.b, p->pre_k, R,
-                     FC, hk.n_in, ldh, FC, FC, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
-        return rc;
-    }
-  }
+  if (!fused)
+    if ((rc = heads_forward(p, s, dch, ld, R, training, head_in))) return rc;
   // per-row log-likelihood, forward only
   auto loglik_forward = [&]() -> int {
     if (fused)
@@ -526,33 +560,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       rc = loglik_bwd(s, c.likelihood, a->t, F, pre, F, p->gw, a->row_const,
                       n_iw == 1 ? p->ll : nullptr, R, B, F);
     if (rc) return rc;
-    // heads: dW_j = d^T G_j, db_j = colsum(G_j), dd (+)= G_j W_j^T
-    // with dropout every head's dd passes its own mask before the sum (through dalt)
-    for (int j = 0; j < p->P; ++j) {
-      Dense& hd = p->heads[j];
-      if ((rc = gemm(s, true, false, head_in[j], p->pre[j], nullptr, p->grads + hd.w, h1, F, R, h1,
-                     F, F, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
-        return rc;
-      if ((rc = col_sum(s, p->pre[j], F, R, F, p->grads + hd.b, 1.f, 0, p->partial))) return rc;
-      if ((rc = gemm(s, false, true, p->pre[j], p->params + hd.w, nullptr, head_drop ? dalt : dcur,
-                     R, h1, F, F, F, h1, ACT_NONE, !head_drop && j > 0, p->gemm_ws,
-                     p->gemm_ws_bytes)))
-        return rc;
-      if (head_drop)
-        if ((rc = dense_input_backward(p, s, hd, dalt, dcur, R, j > 0))) return rc;
-    }
-    if (KM > 0) {   // the P_K head, same three products on [rows, F * (K + 1)]
-      Dense& hk = p->head_k;
-      if ((rc = gemm(s, true, false, head_in[3], p->pre_k, nullptr, p->grads + hk.w, h1, FC, R, h1,
-                     FC, FC, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
-        return rc;
-      if ((rc = col_sum(s, p->pre_k, FC, R, FC, p->grads + hk.b, 1.f, 0, p->partial))) return rc;
-      if ((rc = gemm(s, false, true, p->pre_k, p->params + hk.w, nullptr, head_drop ? dalt : dcur,
-                     R, h1, FC, FC, FC, h1, ACT_NONE, !head_drop, p->gemm_ws, p->gemm_ws_bytes)))
-        return rc;
-      if (head_drop)
-        if ((rc = dense_input_backward(p, s, hk, dalt, dcur, R, true))) return rc;
-    }
+    if ((rc = heads_backward(p, s, head_in, R, head_drop, dcur, dalt))) return rc;
   }
   if (n_iw == 1)
     if ((rc = vae_elbo(s, p->ll, p->kl_cell, mc_kl, n_iw, n_mc, B, w, row_scale, a->scalars, nullptr)))

@@ -181,6 +181,10 @@ int dense_input_backward(scvae_plan* p, hipStream_t s, const Dense& d, const flo
 float dropout_keep(const scvae_model_config& c, int which);
 int fill(hipStream_t s, float* dst, float v, size_t n);
 HeadParams head_params(scvae_plan* p);
+int heads_forward(scvae_plan* p, hipStream_t s, const float* dch, int ld, int R, bool training,
+                  const float* (&head_in)[4]);
+int heads_backward(scvae_plan* p, hipStream_t s, const float* const (&head_in)[4], int R,
+                   bool head_drop, float* dd, float* scratch);
 int copy(hipStream_t s, const float* src, float* dst, size_t n);
 int build_gmvae(scvae_plan* p);
 size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t samples, bool dry);

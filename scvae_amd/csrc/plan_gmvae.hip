@@ -338,21 +338,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                      !a->p_x_mean && KM == 0 && !head_drop && c.likelihood <= LK_ZINB;
   const HeadParams hp = head_params(p);
   const float* head_in[4] = {dch, dch, dch, dch};   // [3]: the P_K head
-  if (!fused) {
-    int ldh = ld;
-    for (int j = 0; j < p->P; ++j) {
-      Dense& hd = p->heads[j];
-      TRY(dense_input(p, s, hd, dch, ld, R, training, &head_in[j], &ldh));
-      GEMM(false, false, head_in[j], p->params + hd.w, p->params + hd.b, p->pre[j], R, F, hd.n_in,
-           ldh, F, F, ACT_NONE, false);
-    }
-    if (KM > 0) {
-      Dense& hk = p->head_k;
-      TRY(dense_input(p, s, hk, dch, ld, R, training, &head_in[3], &ldh));
-      GEMM(false, false, head_in[3], p->params + hk.w, p->params + hk.b, p->pre_k, R, FC, hk.n_in,
-           ldh, FC, FC, ACT_NONE, false);
-    }
-  }
+  if (!fused) TRY(heads_forward(p, s, dch, ld, R, training, head_in));
   bool ll_done = false;
   if (a->p_x_mean) {
     if (!(a->p_x_stddev && a->stddev_of_p_x_given_z_mean)) {
@@ -438,26 +424,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   if (a->log_p_x_given_z) TRY(copy(s, p->ll, a->log_p_x_given_z, (size_t)R));
 
   // ---------------- backward: heads + decoder ----------------
-  if (!fused) {
-    for (int j = 0; j < p->P; ++j) {
-      Dense& hd = p->heads[j];
-      GEMM(true, false, head_in[j], p->pre[j], nullptr, p->grads + hd.w, h1, F, R, h1, F, F,
-           ACT_NONE, false);
-      TRY(col_sum(s, p->pre[j], F, R, F, p->grads + hd.b, 1.f, 0, p->partial));
-      GEMM(false, true, p->pre[j], p->params + hd.w, nullptr, head_drop ? dalt : dcur, R, h1, F, F,
-           F, h1, ACT_NONE, !head_drop && j > 0);
-      if (head_drop) TRY(dense_input_backward(p, s, hd, dalt, dcur, R, j > 0));
-    }
-    if (KM > 0) {   // the P_K head, same three products on [rows, F * (K + 1)]
-      Dense& hk = p->head_k;
-      GEMM(true, false, head_in[3], p->pre_k, nullptr, p->grads + hk.w, h1, FC, R, h1, FC, FC,
-           ACT_NONE, false);
-      TRY(col_sum(s, p->pre_k, FC, R, FC, p->grads + hk.b, 1.f, 0, p->partial));
-      GEMM(false, true, p->pre_k, p->params + hk.w, nullptr, head_drop ? dalt : dcur, R, h1, FC,
-           FC, FC, h1, ACT_NONE, !head_drop);
-      if (head_drop) TRY(dense_input_backward(p, s, hk, dalt, dcur, R, true));
-    }
-  }
+  if (!fused) TRY(heads_backward(p, s, head_in, R, head_drop, dcur, dalt));
   const int64_t GSB = GB * S;  // global rows per group (pass) in the decoder
   for (int i = (int)p->xdec.size() - 1; i >= 0; --i) {
     Dense& d = p->xdec[i];
