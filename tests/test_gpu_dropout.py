@@ -249,7 +249,7 @@ def _gmvae_masks(eng, cfg, B, S, keeps, k_max=0):
         for scope, site in (("MEAN", 24), ("SOFTPLUS_SCALE", 25)):
             masks["Z/P/SOFTPLUS_GAUSSIAN/" + scope] = eng.dropout_mask(
                 site, K, K, ky, SEED).cpu().double()
-    width = L
+    width = L + cfg.decoder_extra_size
     for i, h in enumerate(H[::-1]):
         add("X/DECODER/LAYER_{}".format(i + 1), 32 + i, S * B, width,
             kz if i == 0 else kh, passes=K)
