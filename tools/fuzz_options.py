@@ -157,6 +157,23 @@ def run(c, seed, device):
                 and not c["keeps"][1]):
             got, want = got[:F], want[:F]
         check(got, want, 3e-3 if (gm or c["n_iw"] > 1) else 5e-4, "grad " + name)
+    # ---- evaluation step (is_training = False) with the reconstruction statistics ----
+    moving = {k: v.detach().cpu().double()
+              for k, v in eng.named_moving_statistics().items()}
+    outs = {k: torch.zeros(B, F, device=device) for k in (
+        "p_x_mean", "p_x_stddev", "stddev_of_p_x_given_z_mean")}
+    step_kwargs.pop("dropout_seed", None)
+    oracle_kwargs.pop("dropout", None)
+    sc = eng.step(x.float().to(device), t.float().to(device),
+                  eps=eps.float().to(device), training=False, n_iw=c["n_iw"],
+                  n_mc=c["n_mc"], warm_up_weight=c["warm_up"], outputs=outs,
+                  **step_kwargs).cpu().numpy()
+    torch.cuda.synchronize()
+    out = forward(cfg, params, moving, x, t, eps, False, c["warm_up"],
+                  evaluation_statistics=True, **oracle_kwargs)
+    check(sc[0], out["lower_bound"], 2e-4, "lower_bound (evaluation)")
+    check(outs["p_x_mean"].cpu(), out["p_x_mean"], 5e-4, "p_x_mean")
+    check(outs["p_x_stddev"].cpu(), out["p_x_stddev"], 5e-4, "p_x_stddev")
     return problems
 
 
