@@ -65,7 +65,8 @@ def test_step_with_sync_hook_equals_plain_step(cuda_device, single_rank_group,
 def _two_rank_worker(rank, port, model_type, result_path):
     """Rank body: both ranks share cuda:0 (gloo carries the collectives), each
     steps its half of the minibatch; rank 0 also steps the whole minibatch in a
-    second engine and compares."""
+    second engine and compares.  ``model_type`` "<MODEL>-options" switches on
+    graph options whose terms are sharded or reduced in their own way."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=2)
@@ -73,27 +74,54 @@ def _two_rank_worker(rank, port, model_type, result_path):
         from scvae_amd.dataparallel import GradientSynchroniser, shard_bounds
         from scvae_amd.engine import Engine
         device = torch.device("cuda:0")
+        options = model_type.endswith("-options")
+        model_type = model_type.split("-")[0]
         F, L, H, B, K = 130, 5, (20, 16), 48, 3
+        n_iw = 2 if options else 1
         rng = np.random.default_rng(0)
         x = torch.from_numpy(
             (rng.poisson(2.0, (B, F)) * (rng.random((B, F)) > 0.6))
             .astype(np.float32)).to(device)
-        shape = (1, B, L) if model_type == "VAE" else (K, 1, B, L)
+        x[:, 0] += 1
+        shape = (n_iw, B, L) if model_type == "VAE" else (K, n_iw, B, L)
         eps = torch.from_numpy(
             rng.standard_normal(shape).astype(np.float32)).to(device)
+        extra = count_sum = None
+        kwargs = dict(batch_norm=True, model_type=model_type, n_clusters=K,
+                      device=device, seed=3, free_nats_proportion=0.5)
+        likelihood = "negative binomial"
+        if options and model_type == "VAE":
+            # count sums sharded with the cells, per-sample KL, importance weights
+            likelihood = "constrained poisson"
+            kwargs.update(analytical_kl_term=False)
+            count_sum = x.sum(dim=1)
+        elif options:
+            # learned p(y) (its gradient is a share per rank), -k head, extras
+            kwargs.update(prior_probabilities_method="learn", k_max=2,
+                          decoder_extra=2)
+            extra = torch.from_numpy(
+                rng.random((B, 2)).astype(np.float32)).to(device)
 
         def engine():
-            return Engine(F, L, H, "negative binomial", batch_norm=True,
-                          model_type=model_type, n_clusters=K, device=device,
-                          seed=3, free_nats_proportion=0.5)
+            eng = Engine(F, L, H, likelihood, **kwargs)
+            if "Y/P/LOGITS" in eng.named_parameters():
+                eng.parameter("Y/P/LOGITS").copy_(
+                    torch.tensor([0.3, -0.2, 0.1]))
+            return eng
+
+        def step(eng, lo, hi, **more):
+            return eng.step(
+                x[lo:hi].contiguous(), x[lo:hi].contiguous(),
+                eps=eps[..., lo:hi, :].contiguous(), training=True, n_iw=n_iw,
+                decoder_extra=(extra[lo:hi].contiguous()
+                               if extra is not None else None),
+                count_sum=(count_sum[lo:hi].contiguous()
+                           if count_sum is not None else None), **more).clone()
         eng = engine()
         sync = GradientSynchroniser(eng)
         sync.broadcast_state(0)
         lo, hi = shard_bounds(B, 2, rank)
-        eps_local = eps[..., lo:hi, :].contiguous()
-        scalars = eng.step(x[lo:hi].contiguous(), x[lo:hi].contiguous(),
-                           eps=eps_local, training=True,
-                           global_cells=B).clone()
+        scalars = step(eng, lo, hi, global_cells=B)
         # the VAE step announces everything but ENCODER/1 for an early all-reduce
         assert len(sync._pending) == (1 if model_type == "VAE" else 0)
         sync.all_reduce_gradients()
@@ -102,7 +130,7 @@ def _two_rank_worker(rank, port, model_type, result_path):
         torch.cuda.synchronize()
         if rank == 0:
             ref = engine()
-            ref_scalars = ref.step(x, x, eps=eps, training=True).clone()
+            ref_scalars = step(ref, 0, B)
             torch.cuda.synchronize()
             worst = 0.0
             for a, b in ((scalars, ref_scalars), (eng.grads, ref.grads),
@@ -117,18 +145,20 @@ def _two_rank_worker(rank, port, model_type, result_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model_type", ["VAE", "GMVAE"])
+@pytest.mark.parametrize("model_type", ["VAE", "GMVAE", "VAE-options",
+                                        "GMVAE-options"])
 def test_two_ranks_equal_single_process(cuda_device, tmp_path, model_type):
     """Data parallel over 2 ranks == single process on the whole minibatch:
     gradients after the all-reduce, scalar sums, synchronised batch-norm moving
     statistics (real HIP kernels on both ranks; gloo only moves the bytes)."""
     import torch.multiprocessing as mp
     result = tmp_path / "worst.txt"
-    port = 29600 + (os.getpid() % 200) + (0 if model_type == "VAE" else 1)
+    port = 29600 + (os.getpid() % 200) + ["VAE", "GMVAE", "VAE-options",
+                                          "GMVAE-options"].index(model_type)
     mp.spawn(_two_rank_worker, args=(port, model_type, str(result)),
              nprocs=2, join=True)
     worst = float(result.read_text())
-    assert worst <= 2e-5, worst
+    assert worst <= (1e-4 if model_type.endswith("options") else 2e-5), worst
 
 
 def _model_train_worker(rank, port, directory, result_path):
