@@ -156,3 +156,40 @@ def test_gmvae_fused_and_unfused_paths_agree_at_full_width(cuda_device,
         # (the q(y|x) gradients take differences of per-cluster log-likelihoods of
         # magnitude 1e4: their fp32 rounding shows at the 1e-4 level)
         assert (a - b).abs().max().item() <= 5e-4 * scale + 1e-12, name
+
+
+def test_dropout_at_full_size(full_size, cuda_device):
+    """Dropout on every site at the benchmark's size: the masks are a function
+    of the seed (bitwise repeatable step, different seed -> different step), a
+    mask keeps its fraction of a [4096, 32738] input, and the gradient of the
+    first encoder layer only sees the genes / cells its mask kept."""
+    from scvae_amd.engine import Engine
+    _, x, row_const, eps = full_size
+    keeps = (0.9, 0.8, 0.7)
+    eng = Engine(F, L, H, "negative binomial", batch_norm=True,
+                 device=cuda_device, seed=0, dropout_keep_probabilities=keeps)
+
+    def step(seed):
+        scalars = eng.step(x, x, eps=eps, row_const=row_const, training=True,
+                           dropout_seed=seed).clone()
+        torch.cuda.synchronize()
+        return scalars.cpu().numpy(), eng.grads.clone()
+    s1, g1 = step(11)
+    s2, g2 = step(11)
+    s3, g3 = step(12)
+    assert np.isfinite(s1[:4]).all() and torch.isfinite(g1).all()
+    assert np.array_equal(s1, s2) and torch.equal(g1, g2)
+    assert s1[0] != s3[0] and not torch.equal(g1, g3)
+    mask = eng.dropout_mask(0, CELLS, F, keeps[1], 11)
+    kept = (mask > 0)
+    assert abs(kept.float().mean().item() - keeps[1]) < 1e-3
+    # dW(ENCODER/1) = (x * mask / keep)^T dA: a gene whose kept entries are all
+    # zero counts gets a zero row
+    dead = ((x * mask) != 0).sum(dim=0) == 0
+    if dead.any():
+        dW = eng.gradient("ENCODER/1/DENSE/weights")
+        assert dW[dead].abs().max().item() == 0.0
+    # evaluation ignores the dropout and takes the fused path
+    a = eng.step(x, x, eps=eps, row_const=row_const, training=False).clone()
+    b = eng.step(x, x, eps=eps, row_const=row_const, training=False).clone()
+    assert torch.equal(a, b)
