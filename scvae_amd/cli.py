@@ -113,12 +113,16 @@ def _model_arguments(arguments):
 
 def _load_data(data_set_file_or_name, data_format, data_directory,
                preprocessing_methods, noisy_preprocessing_methods,
-               split_data_set, splitting_method, splitting_fraction):
+               split_data_set, splitting_method, splitting_fraction,
+               binarise_values=False):
     data_set = DataSet(
         data_set_file_or_name, data_format=data_format,
         directory=data_directory,
         preprocessing_methods=preprocessing_methods,
         noisy_preprocessing_methods=noisy_preprocessing_methods)
+    if binarise_values:   # targets of the Bernoulli likelihood (cli.py:144-160)
+        data_set.load()
+        data_set.binarise()
     if split_data_set:
         subsets = data_set.split(method=splitting_method,
                                  fraction=splitting_fraction)
@@ -150,7 +154,9 @@ def train(data_set_file_or_name, data_format=None, data_directory=None,
     data_set, subsets, splitting_method, splitting_fraction = _load_data(
         data_set_file_or_name, data_format, data_directory,
         preprocessing_methods, noisy_preprocessing_methods, split_data_set,
-        splitting_method, splitting_fraction)
+        splitting_method, splitting_fraction,
+        binarise_values=normalise_string(str(keyword_arguments.get(
+            "reconstruction_distribution"))) == "bernoulli")
     training_set, validation_set, _ = subsets
 
     models_directory = build_directory_path(
@@ -226,7 +232,9 @@ def evaluate(data_set_file_or_name, data_format=None, data_directory=None,
     data_set, subsets, splitting_method, splitting_fraction = _load_data(
         data_set_file_or_name, data_format, data_directory,
         preprocessing_methods, noisy_preprocessing_methods, split_data_set,
-        splitting_method, splitting_fraction)
+        splitting_method, splitting_fraction,
+        binarise_values=normalise_string(str(keyword_arguments.get(
+            "reconstruction_distribution"))) == "bernoulli")
     training_set, validation_set, test_set = subsets
     if split_data_set:
         kinds = {"training": training_set, "validation": validation_set,

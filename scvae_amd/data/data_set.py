@@ -225,6 +225,25 @@ class DataSet:
                     labels=dictionary.get("labels"),
                     example_names=dictionary.get("example names"),
                     feature_names=dictionary.get("feature names"))
+        self.preprocess()
+
+    def preprocess(self):
+        """``preprocessing_methods`` applied to the values once
+        (data_set.py:817-905: the result is the models' input x, the counts
+        stay the target t); ``binarise()`` for the Bernoulli likelihood."""
+        if self.preprocessing_methods and not self.has_preprocessed_values:
+            from scvae_amd.data.processing import build_preprocessor
+            print("Preprocessing values ({}).".format(
+                ", ".join(self.preprocessing_methods)))
+            self.update(preprocessed_values=build_preprocessor(
+                self.preprocessing_methods)(self.values))
+
+    def binarise(self):
+        """data_set.py:984-1024: values > 0.5 as the Bernoulli targets."""
+        if not self.has_binarised_values:
+            from scvae_amd.data.processing import build_preprocessor
+            self.update(binarised_values=build_preprocessor(["binarise"])(
+                self.values))
 
     def _subset(self, indices, kind):
         subset = DataSet(
@@ -239,6 +258,8 @@ class DataSet:
             batch_names=self.batch_names,
             preprocessed_values=(self.preprocessed_values[indices]
                                  if self.has_preprocessed_values else None),
+            binarised_values=(self.binarised_values[indices]
+                              if self.has_binarised_values else None),
             feature_selection=self.feature_selection,
             example_filter=self.example_filter,
             preprocessing_methods=self.preprocessing_methods,

@@ -192,6 +192,31 @@ def test_cli_train_and_evaluate(tmp_path, cuda_device, capsys):
     assert "Sampling 20 examples from model." in capsys.readouterr().out
 
 
+def test_cli_with_preprocessed_input(tmp_path, cuda_device, capsys):
+    """``-p log``: the encoder sees log1p(counts), the likelihood the counts
+    (data_set.py:817-905, va:845-861); ``-r bernoulli`` binarises the targets."""
+    from scvae_amd import cli
+    arguments = ["synthetic_1k", "-M", str(tmp_path), "-r", "poisson", "-l",
+                 "3", "-H", "20", "-B", "100", "--split-data-set", "-p", "log"]
+    cli.main(["train"] + arguments + ["-e", "2"])
+    out = capsys.readouterr().out
+    assert "Preprocessing values (log)." in out
+    assert os.path.isdir(os.path.join(
+        str(tmp_path), "synthetic_1k", "split-random_0.9", "log"))
+    results = cli.main(["evaluate"] + arguments)
+    transformed, reconstructed, latent = results["end_of_training"]
+    assert transformed.has_preprocessed_values
+    assert np.isfinite(np.asarray(reconstructed.values)).all()
+    arguments = ["synthetic_1k", "-M", str(tmp_path), "-r", "bernoulli", "-l",
+                 "3", "-H", "20", "-B", "100", "--split-data-set"]
+    cli.main(["train"] + arguments + ["-e", "1"])
+    results = cli.main(["evaluate"] + arguments)
+    transformed, reconstructed, latent = results["end_of_training"]
+    assert transformed.has_binarised_values
+    values = np.asarray(reconstructed.values)
+    assert values.min() >= 0 and values.max() <= 1
+
+
 def test_cli_evaluate_with_label_prediction(tmp_path, cuda_device, capsys):
     """``scvae evaluate -P k-means`` (cli.py:450-543): latent values of the
     prediction training set -> k-means -> labels on every output version; the

@@ -371,3 +371,47 @@ def test_legacy_gaussian_mixture_scopes():
     assert legacy._engine_arguments()["latent_distribution"] == (
         "legacy gaussian mixture")
     assert "-kl" in legacy.name and "-kl" not in modern.name
+
+
+def test_preprocessing_methods():
+    """data/processing.py:305-333, 496-513: log / exp / normalise / binarise,
+    sparse stays sparse, applied once when the data set is loaded."""
+    import scipy.sparse as sp
+    from scvae_amd.data import DataSet
+    from scvae_amd.data.processing import build_preprocessor
+    rng = np.random.default_rng(0)
+    dense = (rng.poisson(1.0, size=(30, 12)) * (rng.random((30, 12)) < 0.5)
+             ).astype(np.float32)
+    sparse = sp.csr_matrix(dense)
+    for methods, want in (
+            (["log"], np.log1p(dense)),
+            (["exp"], np.expm1(dense)),
+            (["binarise"], (dense > 0.5).astype(np.float32)),
+            (["log", "binarise"], (np.log1p(dense) > 0.5).astype(np.float32)),
+            ([], dense)):
+        f = build_preprocessor(methods)
+        assert np.allclose(f(dense), want, rtol=1e-6)
+        got = f(sparse)
+        assert sp.issparse(got) and np.allclose(got.toarray(), want, rtol=1e-6)
+    norms = np.sqrt((dense ** 2).sum(axis=0))
+    want = dense / np.where(norms > 0, norms, 1)
+    assert np.allclose(build_preprocessor(["normalise"])(dense), want, rtol=1e-5)
+    assert np.allclose(build_preprocessor(["normalise"])(sparse).toarray(),
+                       want, rtol=1e-5)
+    with pytest.raises(ValueError, match="not found"):
+        build_preprocessor(["square"])
+    with pytest.raises(NotImplementedError):
+        build_preprocessor(["binarise"], noisy=True)
+    data = DataSet("toy", values=sparse, preprocessing_methods=["log"],
+                   example_names=np.arange(30).astype(str),
+                   feature_names=np.arange(12).astype(str))
+    data.preprocess()
+    assert np.allclose(data.preprocessed_values.toarray(), np.log1p(dense))
+    assert np.array_equal(data.values.toarray(), dense)   # the target stays
+    training, validation, test = data.split()
+    assert training.has_preprocessed_values
+    assert np.allclose(
+        training.preprocessed_values.toarray(),
+        np.log1p(training.values.toarray()))
+    data.binarise()
+    assert set(np.unique(data.binarised_values.toarray())) <= {0.0, 1.0}
