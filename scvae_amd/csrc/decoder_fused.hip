@@ -448,6 +448,47 @@ __global__ __launch_bounds__(256) void dd_reduce_kernel(const float* __restrict_
   }
 }
 
+// The same sum for small batches (rows*H/4 below DD_SPLIT_MAX float4 columns): one thread per
+// column leaves a B = 100 step with 10 workgroups walking 512 slabs one after the other (42 us of
+// latency).  Here a workgroup owns 16 columns and its 16 thread groups each sum every 16th slab;
+// the groups are combined through LDS in a fixed order (deterministic, no atomics).
+constexpr size_t DD_SPLIT_MAX = 32768;
+__global__ __launch_bounds__(256) void dd_reduce_split_kernel(const float* __restrict__ dd_part,
+                                                              int strips, size_t n,
+                                                              float* __restrict__ dd) {
+  __shared__ float4 red[16][16];
+  const size_t n4 = n / 4;
+  const float4* p4 = reinterpret_cast<const float4*>(dd_part);
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const size_t i = (size_t)blockIdx.x * 16 + cl;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    int z = g;
+    for (; z + 7 * 16 < strips; z += 8 * 16) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p4[(size_t)(z + u * 16) * n4 + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; z < strips; z += 16) {
+      const float4 v = p4[(size_t)z * n4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  red[g][cl] = s;
+  __syncthreads();
+  if (g == 0 && i < n4) {
+    float4 t = red[0][cl];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const float4 v = red[k][cl];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    reinterpret_cast<float4*>(dd)[i] = t;
+  }
+}
+
 __global__ __launch_bounds__(256) void dd_reduce_scalar_kernel(const float* __restrict__ dd_part,
                                                                int strips, size_t n,
                                                                float* __restrict__ dd) {
@@ -561,7 +602,10 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
                      strips, rows, row_const, B, ll);
   SCVAE_LAUNCH_CHECK("ll_reduce_kernel");
   const size_t n = (size_t)rows * H;
-  if (n % 4 == 0) {
+  if (n % 4 == 0 && n / 4 <= DD_SPLIT_MAX) {
+    hipLaunchKernelGGL(dd_reduce_split_kernel, dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0,
+                       s, dd_part, strips, n, dd);
+  } else if (n % 4 == 0) {
     size_t blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(dd_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dd_part, strips,
