@@ -469,7 +469,7 @@ int gemm_choose_splits(int M, int N, int K) {
   long max_by_k = K / 64;                         // keep >= 64 of K (4 k-steps) per split
   long s = want < max_by_k ? want : max_by_k;
   if (s < 1) s = 1;
-  if (s > 64) s = 64;
+  if (s > 128) s = 128;
   return (int)s;
 }
 
