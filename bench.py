@@ -199,7 +199,11 @@ def main():
                     help="extra (non-headline) workloads for DESIGN.md")
     ap.add_argument("--clusters", type=int, default=20)
     ap.add_argument("--latent", type=int, default=LATENT)
-    ap.add_argument("--likelihood", default=LIKELIHOOD)
+    ap.add_argument("--likelihood", default=LIKELIHOOD,
+                    choices=["poisson", "negative binomial", "zero-inflated poisson",
+                             "zero-inflated negative binomial"],
+                    help="count likelihoods of the fused decoder-head kernel (the roofline "
+                         "probe launches that kernel on its own)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
