@@ -1,0 +1,210 @@
+"""One full *training* step of every BASELINE.json configuration, at the
+configuration's own gene count / likelihood / latent size / cluster count,
+against the fp64 oracle: ELBO terms, per-cell reconstruction log-likelihood
+(per element, 1e-4 relative), every gradient, the post-Adam weights and the
+batch-norm moving statistics.
+
+    cfg2  NB VAE        F = 32 738  H 100-100  L 25            B = 100, 1536
+    cfg3  ZINB VAE      F = 32 738  H 100-100  L 100           B = 100
+    cfg4  NB GMVAE      F = 32 738  H 100-100  L 100  K = 20   B = 16
+    cfg5  ZINB GMVAE    F = 27 998  H 100-100  L 100  K = 20   B = 16
+
+B = 100 is the reference's default minibatch (``scvae/defaults.json:51``) and
+the regime of the small-batch kernels (``dd_reduce_split_kernel``, 128-slab
+split-K); the GMVAE batches keep the fp64 oracle (K passes of the decoder with
+autograd) within seconds.  The count matrix is the benchmark's generator
+(``synthetic_count_matrix``, ~5 % nonzeros) through the production minibatch
+path (device CSR gather + densify + the lgamma row term).
+
+Follows va:2560-2734 (VAE loss), gm:3223-3434 (GMVAE loss), va:2736-2770
+(clip + Adam).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as om
+from _parity import (LL_ATOL, LL_RTOL, close_elementwise, close_maxnorm,
+                     close_scalar)
+
+pytestmark = pytest.mark.gpu
+
+H = (100, 100)
+LEARNING_RATE = 1e-4           # the reference's default (defaults.json:52)
+
+
+def _minibatch(device, cells, features, seed):
+    from scvae_amd.minibatch import synthetic_count_matrix
+    matrix, _ = synthetic_count_matrix(cells, features, density=0.05,
+                                       seed=seed, device=device)
+    x = torch.empty(cells, features, device=device)
+    row_const = torch.empty(cells, device=device)
+    matrix.gather_dense(torch.arange(cells, device=device), out=x,
+                        row_const_out=row_const)
+    return x, row_const
+
+
+def _perturb(engine, seed):
+    """Biases / beta away from zero, moving statistics away from (0, 1)."""
+    g = torch.Generator().manual_seed(seed)
+    for name, p in engine.named_parameters().items():
+        if not name.endswith("weights"):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    for name, m in engine.named_moving_statistics().items():
+        if name.endswith("moving_mean"):
+            m.copy_(torch.randn(m.shape, generator=g) * 0.2)
+        else:
+            m.copy_(torch.rand(m.shape, generator=g) + 0.5)
+
+
+def _host_state(engine):
+    params = {k: v.detach().cpu().double()
+              for k, v in engine.named_parameters().items()}
+    moving = {k: v.detach().cpu().double()
+              for k, v in engine.named_moving_statistics().items()}
+    return params, moving
+
+
+def _bn_bias(name):
+    """Bias of a batch-normalised dense layer: identically zero gradient (the
+    batch mean is subtracted again); the build leaves it at zero, the oracle's
+    autograd computes rounding residue there."""
+    return name.endswith("DENSE/biases") and (
+        "ENCODER/" in name or "DECODER/" in name or "LAYER_" in name)
+
+
+@pytest.mark.parametrize("config,likelihood,features,latent,cells", [
+    ("cfg2", "negative binomial", 32738, 25, 100),
+    ("cfg3", "zero-inflated negative binomial", 32738, 100, 100),
+    # the throughput regime's kernels (streaming dd reduce, 64-slab split-K)
+    # take over above ~1300 rows: one batch there as well
+    ("cfg2-large-batch", "negative binomial", 32738, 25, 1536),
+])
+def test_vae_training_step_at_baseline_shape(cuda_device, config, likelihood,
+                                             features, latent, cells):
+    from scvae_amd.engine import Engine
+    B, F, L = cells, features, latent
+    eng = Engine(F, L, H, likelihood, batch_norm=True, device=cuda_device,
+                 seed=0)
+    _perturb(eng, 1)
+    x, row_const = _minibatch(cuda_device, B, F, seed=60)
+    rng = np.random.default_rng(7)
+    eps = torch.from_numpy(rng.standard_normal((1, B, L)))
+    cfg = om.ModelConfig(feature_size=F, latent_size=L, hidden_sizes=H,
+                         likelihood=likelihood)
+    params, moving = _host_state(eng)
+    assert list(params) == list(om.vae_parameter_shapes(cfg))
+
+    ll = torch.zeros(B, device=cuda_device)
+    klz = torch.zeros(L, device=cuda_device)
+    qz = torch.zeros(B, L, device=cuda_device)
+    warm_up = 0.7
+    sc = eng.step(x, x, eps=eps.float().to(cuda_device), row_const=row_const,
+                  training=True, warm_up_weight=warm_up,
+                  outputs={"log_p_x_given_z": ll, "kl_neurons": klz,
+                           "q_z_mean": qz}).cpu().numpy()
+    eng.adam_step(LEARNING_RATE)
+    torch.cuda.synchronize()
+    assert np.isfinite(sc[:4]).all()
+
+    xh = x.cpu().double()
+    new_params, new_moving, out, grads = om.vae_train_step(
+        cfg, dict(params), moving, om.adam_state(params), xh, xh, eps,
+        LEARNING_RATE, warm_up_weight=warm_up)
+
+    close_scalar(sc[0], out["lower_bound"], what="lower_bound")
+    close_scalar(sc[1], out["lower_bound_weighted"],
+                 what="lower_bound_weighted")
+    close_scalar(sc[2], out["reconstruction_error"],
+                 what="reconstruction_error")
+    close_scalar(sc[3], out["kl_divergence"], what="kl_divergence")
+    close_elementwise(ll, out["log_p_x_given_z"].reshape(-1), rtol=LL_RTOL,
+                      atol=LL_ATOL, what="per-cell log-likelihood")
+    close_elementwise(klz, out["kl_divergence_neurons"], rtol=1e-4, atol=1e-6,
+                      what="kl per latent unit")
+    close_elementwise(qz, out["q_z_mean"], rtol=1e-4, atol=1e-5,
+                      what="q_z_mean")
+    for name, g in eng.named_gradients().items():
+        if _bn_bias(name):
+            assert g.abs().max().item() == 0.0, name
+            continue
+        close_maxnorm(g, grads[name], rtol=2e-4, what="grad " + name)
+    for name, p in eng.named_parameters().items():
+        if _bn_bias(name):
+            continue
+        close_maxnorm(p, new_params[name], rtol=2e-4, what="param " + name)
+    for name, m in eng.named_moving_statistics().items():
+        close_elementwise(m, new_moving[name], rtol=1e-5, atol=1e-7,
+                          what="moving " + name)
+
+
+@pytest.mark.parametrize("config,likelihood,features", [
+    ("cfg4", "negative binomial", 32738),
+    ("cfg5", "zero-inflated negative binomial", 27998),
+])
+def test_gmvae_training_step_at_baseline_shape(cuda_device, config,
+                                               likelihood, features):
+    from scvae_amd.engine import Engine
+    B, F, L, K = 16, features, 100, 20
+    eng = Engine(F, L, H, likelihood, batch_norm=True, model_type="GMVAE",
+                 n_clusters=K, device=cuda_device, seed=0)
+    _perturb(eng, 2)
+    x, row_const = _minibatch(cuda_device, B, F, seed=61)
+    rng = np.random.default_rng(8)
+    eps = torch.from_numpy(rng.standard_normal((K, 1, B, L)))
+    cfg = om.ModelConfig(feature_size=F, latent_size=L, hidden_sizes=H,
+                         likelihood=likelihood, n_clusters=K)
+    params, moving = _host_state(eng)
+    assert list(params) == list(om.gmvae_parameter_shapes(cfg))
+
+    ll = torch.zeros(K * B, device=cuda_device)
+    logits = torch.zeros(B, K, device=cuda_device)
+    zmean = torch.zeros(B, L, device=cuda_device)
+    warm_up = 0.6
+    sc = eng.step(x, x, eps=eps.float().to(cuda_device), row_const=row_const,
+                  training=True, warm_up_weight=warm_up,
+                  outputs={"log_p_x_given_z": ll, "q_y_logits": logits,
+                           "q_z_mean": zmean}).cpu().numpy()
+    eng.adam_step(LEARNING_RATE)
+    torch.cuda.synchronize()
+    assert np.isfinite(sc[:5]).all()
+
+    xh = x.cpu().double()
+    new_params, new_moving, out, grads = om.gmvae_train_step(
+        cfg, dict(params), moving, om.adam_state(params), xh, xh, eps,
+        LEARNING_RATE, warm_up_weight=warm_up)
+
+    close_scalar(sc[0], out["lower_bound"], what="lower_bound")
+    close_scalar(sc[1], out["lower_bound_weighted"],
+                 what="lower_bound_weighted")
+    close_scalar(sc[2], out["reconstruction_error"],
+                 what="reconstruction_error")
+    close_scalar(sc[3], out["kl_divergence_z"], what="kl_divergence_z")
+    close_scalar(sc[4], out["kl_divergence_y"], rtol=2e-4, atol=1e-6,
+                 what="kl_divergence_y")
+    close_elementwise(ll, out["log_p_x_given_z"].reshape(-1), rtol=LL_RTOL,
+                      atol=LL_ATOL, what="per-cell log-likelihood")
+    close_elementwise(logits, out["q_y_logits"], rtol=1e-4, atol=1e-5,
+                      what="q_y_logits")
+    close_elementwise(zmean, out["z_mean"], rtol=1e-4, atol=1e-5,
+                      what="z_mean")
+    for name, g in eng.named_gradients().items():
+        if _bn_bias(name):
+            assert g.abs().max().item() == 0.0, name
+            continue
+        got, want = g.cpu(), grads[name]
+        if name == "Z/Q/ENCODER/LAYER_1/DENSE/weights":
+            # the one-hot rows W[F+k] are cancelled by the per-pass batch norm
+            assert got[F:].abs().max().item() < 1e-5
+            got, want = got[:F], want[:F]
+        close_maxnorm(got, want, rtol=5e-4, what="grad " + name)
+    for name, p in eng.named_parameters().items():
+        if _bn_bias(name):
+            continue
+        got, want = p.cpu(), new_params[name]
+        if name == "Z/Q/ENCODER/LAYER_1/DENSE/weights":
+            got, want = got[:F], want[:F]
+        close_maxnorm(got, want, rtol=3e-4, what="param " + name)
+    for name, m in eng.named_moving_statistics().items():
+        close_elementwise(m, new_moving[name], rtol=2e-5, atol=1e-7,
+                          what="moving " + name)

@@ -7,6 +7,7 @@ import torch
 
 from oracle import models as om
 
+from _parity import LL_ATOL, LL_RTOL, close_elementwise
 pytestmark = pytest.mark.gpu
 
 
@@ -60,7 +61,8 @@ def test_step_with_categorised_likelihood(cuda_device, model_type, likelihood,
     out, grads = om.gradients(
         lambda p: forward(cfg, p, moving, x, x, eps, True), params)
     _close(sc[0], out["lower_bound"], 1e-4, "lower_bound")
-    _close(ll.cpu(), out["log_p_x_given_z"].reshape(-1), 1e-4, "per-cell ll")
+    close_elementwise(ll, out["log_p_x_given_z"].reshape(-1), rtol=LL_RTOL,
+                      atol=LL_ATOL, what="per-cell ll")
     for name, g in eng.named_gradients().items():
         if name.endswith("DENSE/biases") and (
                 "LAYER_" in name or "ENCODER/" in name or "DECODER/" in name):

@@ -7,6 +7,7 @@ import torch
 
 from oracle import models as om
 
+from _parity import LL_ATOL, LL_RTOL, close_elementwise
 pytestmark = pytest.mark.gpu
 
 
@@ -66,7 +67,8 @@ def test_step_with_decoder_extra_matches_oracle(cuda_device, model_type, S):
         lambda p: forward(cfg, p, moving, x, x, eps, True,
                           decoder_extra=extra), params)
     _close(sc[0], out["lower_bound"], 1e-4, "lower_bound")
-    _close(ll.cpu(), out["log_p_x_given_z"].reshape(-1), 1e-4, "per-cell ll")
+    close_elementwise(ll, out["log_p_x_given_z"].reshape(-1), rtol=LL_RTOL,
+                      atol=LL_ATOL, what="per-cell ll")
     first = "X/DECODER/LAYER_1" if gm else "DECODER/{}".format(len(H))
     assert eng.gradient(first + "/DENSE/weights").shape[0] == L + E
     for name, g in eng.named_gradients().items():

@@ -15,6 +15,7 @@ import torch
 
 from oracle import models as om
 
+from _parity import LL_ATOL, LL_RTOL, close_elementwise
 pytestmark = pytest.mark.gpu
 
 CELLS, F, H, L = 4096, 32738, (100, 100), 25
@@ -96,7 +97,8 @@ def test_subset_of_cells_matches_oracle_in_evaluation_mode(full_size):
                          eps[:, rows].cpu().double(), False)
     want = out["log_p_x_given_z"].reshape(-1).numpy()
     got = ll.cpu().numpy()[rows]
-    assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+    close_elementwise(got, want, rtol=LL_RTOL, atol=LL_ATOL,
+                      what="per-cell log-likelihood")
 
 
 def test_per_cell_outputs_follow_a_row_permutation(full_size):

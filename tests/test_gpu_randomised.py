@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+from _parity import LL_ATOL, LL_RTOL, close_elementwise
 pytestmark = pytest.mark.gpu
 
 LIKELIHOODS = ["poisson", "negative binomial", "zero-inflated poisson",
@@ -145,7 +146,8 @@ def test_random_models_against_the_oracle(cuda_device, seed):
     assert abs(sc[1] - float(out["lower_bound_weighted"])) <= 1e-4 * abs(
         float(out["lower_bound_weighted"])), c
     want = out["log_p_x_given_z"].reshape(-1).numpy()
-    assert np.abs(ll.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max(), c
+    close_elementwise(ll, want, rtol=LL_RTOL, atol=LL_ATOL,
+                      what="per-cell log-likelihood {}".format(c))
     for name, got in eng.named_gradients().items():
         if c["bn"] and name.endswith("DENSE/biases") and (
                 "LAYER_" in name or "ENCODER/" in name or "DECODER/" in name):
