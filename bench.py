@@ -8,23 +8,30 @@ CSR row gather + densify, encoder/decoder forward, likelihood + KL + ELBO,
 backward, (gradient all-reduce), clip + Adam.  Inputs (the CSR matrix) are
 resident in HBM before the timed region.
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task description) with two extra
-objects: ``roofline`` (dominant kernel vs the fp32-MFMA / HBM peak, timed live
-with HIP events) and ``cpu_baseline`` (the torch-CPU fp32 port of the same step,
-``oracle/``, timed on a bounded sample on the host cores; rank 0, N=1 only).
+For N > 1 the script starts one rank per GPU itself (it re-executes under
+``python -m torch.distributed.run --nproc-per-node N``, rendezvous on
+127.0.0.1) unless it already runs under a launcher (WORLD_SIZE set), so both
+``python bench.py --gpus 8`` and ``python -m torch.distributed.run ... bench.py
+--gpus 8`` work.  Ranks talk over RCCL (torch backend "nccl").
+
+Prints ONE JSON line on rank 0 (contract in the task description) with extra
+objects: ``roofline`` (dominant kernel vs the fp32-MFMA peak, timed live with
+HIP events), ``cpu_baseline`` (the torch-CPU fp32 port of the same step,
+``oracle/``, on the host cores; rank 0, N = 1 only) and ``other_workloads``
+(the other BASELINE.json configurations' models measured in the same run).
 """
 
 import argparse
 import ctypes
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -35,6 +42,44 @@ HIDDEN, LATENT = (100, 100), 25
 LIKELIHOOD = "negative binomial"
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+MIN_WARM_SECONDS = 1.0          # real steps before the timed window, whatever --warmup says
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096,
+                    help="cells per GPU per step (weak scaling)")
+    ap.add_argument("--cells", type=int, default=N_CELLS)
+    ap.add_argument("--features", type=int, default=N_FEATURES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true")
+    ap.add_argument("--model", default="vae", choices=["vae", "gmvae"],
+                    help="extra (non-headline) workloads for DESIGN.md")
+    ap.add_argument("--clusters", type=int, default=20)
+    ap.add_argument("--latent", type=int, default=LATENT)
+    ap.add_argument("--likelihood", default=LIKELIHOOD,
+                    choices=["poisson", "negative binomial", "zero-inflated poisson",
+                             "zero-inflated negative binomial"],
+                    help="count likelihoods of the fused decoder-head kernel (the roofline "
+                         "probe launches that kernel on its own)")
+    return ap.parse_args()
+
+
+def respawn_one_rank_per_gpu(args):
+    """``python bench.py --gpus N`` without a launcher: become the launcher."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def train_flops_per_cell(F, hidden, latent, heads):
@@ -51,15 +96,33 @@ def train_flops_per_cell(F, hidden, latent, heads):
     return 2.0 * train
 
 
-def cpu_baseline(matrix, batch, seconds_budget=15.0):
-    """The reference-equivalent CPU path: scipy CSR gather + densify (x and t
-    separately, as va:997-998 does), then the torch-CPU fp32 port of the step
-    (oracle/models.py) on all host cores."""
+# ----------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1): the torch-CPU fp32 port of the step
+# ----------------------------------------------------------------------------
+def _cpu_model_string():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(matrix, batch):
+    """The reference-equivalent CPU path: scipy CSR
+    gather + densify (x and t separately, as va:997-998 does), then the
+    torch-CPU fp32 port of the step (oracle/models.py).  Two regimes: the
+    reference's default minibatch B = 100 (all usable cores and one thread)
+    and the benchmark's B.  The intra-op thread count is calibrated first (an
+    oversubscribed pool is several times slower than a smaller one)."""
     import numpy
     import scipy.sparse as sp
+    import torch
     from oracle import models as om
-    torch.set_num_threads(os.cpu_count())
-    n_rows = min(matrix.number_of_rows, 4 * batch)
+    cores = len(os.sched_getaffinity(0))
+    n_rows = min(matrix.number_of_rows, 2 * batch)
     indptr = matrix.indptr[:n_rows + 1].cpu().numpy()
     nnz = int(indptr[-1])
     host = sp.csr_matrix(
@@ -69,43 +132,78 @@ def cpu_baseline(matrix, batch, seconds_budget=15.0):
     cfg = om.ModelConfig(feature_size=matrix.shape[1], latent_size=LATENT,
                          hidden_sizes=HIDDEN, likelihood=LIKELIHOOD)
     shapes = om.vae_parameter_shapes(cfg)
-    params = om.init_parameters(shapes, dtype=torch.float32)
-    moving = om.init_moving_statistics(shapes, dtype=torch.float32)
-    state = om.adam_state(params)
     rng = numpy.random.RandomState(2)
-    steps, elapsed = 0, 0.0
+
+    def run(b, threads, max_steps, budget, warm):
+        """-> (median seconds per step, timed steps)"""
+        torch.set_num_threads(threads)
+        params = om.init_parameters(shapes, dtype=torch.float32)
+        moving = om.init_moving_statistics(shapes, dtype=torch.float32)
+        state = om.adam_state(params)
+        times, spent = [], 0.0
+        for i in range(warm + max_steps):
+            idx = rng.permutation(n_rows)[:b]
+            t0 = time.perf_counter()
+            x = torch.from_numpy(host[idx].toarray())
+            t = torch.from_numpy(host[idx].toarray())
+            eps = torch.randn(1, b, LATENT)
+            params, moving, _, _ = om.vae_train_step(
+                cfg, params, moving, state, x, t, eps, 1e-4)
+            dt = time.perf_counter() - t0
+            if i >= warm:
+                times.append(dt)
+                spent += dt
+                if spent >= budget and len(times) >= 5:
+                    break
+                if budget > 0 and spent >= 3 * budget and len(times) >= 2:
+                    break   # hard cap: the default run must finish within minutes
+        return statistics.median(times), len(times)
+
+    # calibrate the pool size on the small regime
+    candidates = sorted({c for c in (cores, 128, 64, 32, 16, 8) if c <= cores},
+                        reverse=True)
+    best_threads, best = candidates[0], None
+    for c in candidates:
+        sec, _ = run(100, c, 3, 0.0, 1)
+        if best is None or sec < best:
+            best_threads, best = c, sec
+    small_sec, small_n = run(100, best_threads, 50, 8.0, 3)
+    single_sec, single_n = run(100, 1, 20, 5.0, 1)
     b = min(batch, n_rows)
-    while True:
-        idx = rng.permutation(n_rows)[:b]
-        t0 = time.perf_counter()
-        x = torch.from_numpy(host[idx].toarray())
-        t = torch.from_numpy(host[idx].toarray())
-        eps = torch.randn(1, b, LATENT)
-        params, moving, _, _ = om.vae_train_step(
-            cfg, params, moving, state, x, t, eps, 1e-4)
-        dt = time.perf_counter() - t0
-        if steps > 0:          # first step is warm-up
-            elapsed += dt
-        steps += 1
-        if steps >= 2 and (elapsed >= seconds_budget or steps >= 12):
-            break
-    timed = steps - 1
+    big_sec, big_n = run(b, best_threads, 8, 20.0, 1)
+    torch.set_num_threads(cores)
     return {
-        "value": timed * b / elapsed,
+        "value": b / big_sec,
         "unit": "cells/s",
-        "cores": os.cpu_count(),
+        "cores": best_threads,
         "kind": "port",
-        "sample": "{} timed steps of {} cells (same model, same F), torch-CPU "
-                  "fp32 port incl. scipy CSR gather+densify x2".format(
-                      timed, b),
+        "sample": "median of {} timed steps of {} cells (same model, same F) after 1 "
+                  "warm-up step, torch-CPU fp32 port (oracle/models.py) incl. scipy CSR "
+                  "gather+densify x2, {} intra-op threads (best of {} on {} usable cores)"
+                  .format(big_n, b, best_threads, candidates, cores),
+        "cpu_model": _cpu_model_string(),
+        "usable_cores": cores,
+        "minibatch_100": {
+            "value": 100 / small_sec, "unit": "cells/s", "cores": best_threads,
+            "steps": small_n,
+            "note": "the reference's default minibatch (defaults.json:51), median"},
+        "single_thread_minibatch_100": {
+            "value": 100 / single_sec, "unit": "cells/s", "cores": 1,
+            "steps": single_n},
     }
 
 
+# ----------------------------------------------------------------------------
+# roofline of the dominant kernel
+# ----------------------------------------------------------------------------
 def _measured_traffic(rows, F, H, kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3
     PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section);
     only reported when the profiled kernel and shapes are the benchmarked ones."""
-    for name in ("r01_pmc_decoder_head2.json", "r01_pmc_decoder_head.json"):
+    names = sorted((n for n in os.listdir(os.path.join(ROOT, "profiles"))
+                    if n.endswith(".json") and "pmc_decoder_head" in n),
+                   reverse=True)   # newest round first
+    for name in names:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pmc = json.load(f)
@@ -122,6 +220,7 @@ def time_dominant_kernel(engine, rows, launches=10):
     kernel of the step -- the fused decoder-head kernel -- run standalone on
     the step's own shapes (main kernel only, without its two small reductions,
     so that the figure matches rocprofv3's per-kernel average)."""
+    import torch
     from scvae_amd import _lib
     lib = engine.lib
     F, H = engine.feature_size, engine.hidden_sizes[0]
@@ -155,7 +254,8 @@ def time_dominant_kernel(engine, rows, launches=10):
             kind, 3, d.data_ptr(), rows, H, aW, ab, adW, adb, F, t.data_ptr(),
             rows, gw.data_ptr(), rc.data_ptr(), ll.data_ptr(), dd.data_ptr(),
             ws.data_ptr(), stream), "scvae_decoder_fused")
-    launch()
+    for _ in range(3):
+        launch()
     torch.cuda.synchronize(dev)
     start, stop = torch.cuda.Event(True), torch.cuda.Event(True)
     start.record()
@@ -185,35 +285,165 @@ def time_dominant_kernel(engine, rows, launches=10):
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096,
-                    help="cells per GPU per step (weak scaling)")
-    ap.add_argument("--cells", type=int, default=N_CELLS)
-    ap.add_argument("--features", type=int, default=N_FEATURES)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--model", default="vae", choices=["vae", "gmvae"],
-                    help="extra (non-headline) workloads for DESIGN.md")
-    ap.add_argument("--clusters", type=int, default=20)
-    ap.add_argument("--latent", type=int, default=LATENT)
-    ap.add_argument("--likelihood", default=LIKELIHOOD,
-                    choices=["poisson", "negative binomial", "zero-inflated poisson",
-                             "zero-inflated negative binomial"],
-                    help="count likelihoods of the fused decoder-head kernel (the roofline "
-                         "probe launches that kernel on its own)")
-    args = ap.parse_args()
+# ----------------------------------------------------------------------------
+# a training workload on one rank
+# ----------------------------------------------------------------------------
+class Workload:
+    """Model + minibatch buffers + the per-step sequence
+    (gather/densify -> noise -> step -> [all-reduce] -> clip + Adam)."""
 
+    def __init__(self, matrix, device, batch, likelihood, latent, model="vae",
+                 clusters=20, world=1, rank=0, data_parallel=False):
+        import torch
+        from scvae_amd.engine import Engine
+        self.torch = torch
+        self.matrix, self.device = matrix, device
+        self.B, self.world, self.rank = batch, world, rank
+        self.GB = batch * world
+        self.gm = model == "gmvae"
+        self.K = clusters if self.gm else 1
+        self.L = latent
+        F = matrix.shape[1]
+        self.engine = Engine(F, latent, HIDDEN, likelihood, batch_norm=True,
+                             model_type="GMVAE" if self.gm else "VAE",
+                             n_clusters=self.K, device=device, seed=0)
+        self.engine.reserve(batch, 1)
+        self.sync = None
+        if data_parallel:
+            from scvae_amd.dataparallel import GradientSynchroniser
+            self.sync = GradientSynchroniser(self.engine)
+            self.sync.broadcast_state(0)
+        self.x = torch.empty(batch, F, device=device)
+        self.row_const = torch.empty(batch, device=device)
+        self.eps = torch.empty(self.K, batch, latent, device=device)
+        self.generator = torch.Generator(device=device).manual_seed(2)
+        self.perm = self._permutation()
+        self.cursor = 0
+        self.step_counter = 0
+
+    def _permutation(self):
+        return self.torch.randperm(self.matrix.number_of_rows,
+                                   generator=self.generator, device=self.device)
+
+    def one_step(self):
+        from scvae_amd.minibatch import philox_normal
+        n, B, GB, rank = self.matrix.number_of_rows, self.B, self.GB, self.rank
+        if self.cursor + GB > n:
+            self.perm = self._permutation()
+            self.cursor = 0
+        rows = self.perm[self.cursor + rank * B: self.cursor + (rank + 1) * B]
+        self.cursor += GB
+        self.matrix.gather_dense(rows, out=self.x, row_const_out=self.row_const)
+        for k in range(self.K):
+            philox_normal(self.eps[k], row_offset=k * GB + rank * B, seed=1,
+                          stream_id=self.step_counter)
+        self.step_counter += 1
+        self.engine.step(self.x, self.x, eps=self.eps, row_const=self.row_const,
+                         training=True, global_cells=GB, row_offset=rank * B)
+        if self.sync is not None:
+            self.sync.all_reduce_gradients()
+        self.engine.adam_step(1e-4)
+
+    def run(self, steps, warmup, barrier, min_warm_seconds=MIN_WARM_SECONDS):
+        """Warm up (>= warmup steps and >= min_warm_seconds of real steps; the
+        number of steps is agreed over the ranks by running in chunks between
+        barriers), then time exactly ``steps`` steps between barrier + device
+        synchronisation.  Per-step durations come from HIP events on the
+        launch stream (no synchronisation inside the window)."""
+        torch = self.torch
+        for _ in range(warmup):
+            self.one_step()
+        barrier()
+        t0 = time.perf_counter()
+        warm_steps = warmup
+        while True:
+            more = time.perf_counter() - t0 < min_warm_seconds
+            if self.world > 1:   # rank 0 decides: all ranks leave the loop together
+                import torch.distributed as dist
+                flag = torch.tensor([1.0 if more else 0.0], device=self.device)
+                dist.broadcast(flag, src=0)
+                more = flag.item() != 0.0
+            if not more:
+                break
+            for _ in range(8):
+                self.one_step()
+            warm_steps += 8
+            barrier()
+        events = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        barrier()
+        t0 = time.perf_counter()
+        events[0].record()
+        for i in range(steps):
+            self.one_step()
+            events[i + 1].record()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        per_step = [events[i].elapsed_time(events[i + 1]) for i in range(steps)]
+        return elapsed, per_step, warm_steps
+
+
+def describe(cells, F, likelihood, gm, K, L):
+    return ("68k-PBMC-shaped synthetic counts {}x{} (~5% nonzero, device CSR), {} {} "
+            "hidden 100-100 latent {} batch-norm, Adam lr 1e-4".format(
+                cells, F, likelihood, "GMVAE K={}".format(K) if gm else "VAE", L))
+
+
+def other_workloads(matrix, device, barrier):
+    """The other BASELINE.json configurations' models, measured in the same
+    run (rank 0, N = 1): cells/s of the same step sequence."""
+    import torch
+    from scvae_amd.minibatch import synthetic_count_matrix
+    out = {}
+
+    def measure(key, note, mat, batch, likelihood, latent, model, steps):
+        w = Workload(mat, device, batch, likelihood, latent, model=model, clusters=20)
+        elapsed, per_step, _ = w.run(steps, 2, barrier, min_warm_seconds=0.3)
+        out[key] = {
+            "workload": note,
+            "cells_per_step": batch,
+            "steps": steps,
+            "ms_per_step": elapsed / steps * 1e3,
+            "step_ms_median": statistics.median(per_step),
+            "value": steps * batch / elapsed,
+            "unit": "cells/s",
+            "last_lower_bound": float(w.engine.scalars[0].item()),
+        }
+        del w
+        torch.cuda.empty_cache()
+
+    n, F = matrix.shape
+    measure("headline_model_minibatch_100",
+            "cfg2/headline model at the reference's default minibatch: " +
+            describe(n, F, LIKELIHOOD, False, 1, LATENT),
+            matrix, 100, LIKELIHOOD, LATENT, "vae", 200)
+    measure("cfg3_zinb_vae_latent_100",
+            describe(n, F, "zero-inflated negative binomial", False, 1, 100),
+            matrix, 4096, "zero-inflated negative binomial", 100, "vae", 20)
+    measure("cfg4_nb_gmvae_k20_latent_100",
+            describe(n, F, "negative binomial", True, 20, 100),
+            matrix, 512, "negative binomial", 100, "gmvae", 10)
+    # cfg5's gene count (10x 1.3M mouse brain: 27 998 genes); rows are a sample,
+    # the step only ever sees one minibatch
+    m5, _ = synthetic_count_matrix(16384, 27998, density=0.05, seed=61, device=device)
+    measure("cfg5_zinb_gmvae_k20_latent_100_f27998",
+            "1.3M-mouse-brain-shaped synthetic counts (16384-row sample)x27998, "
+            "zero-inflated negative binomial GMVAE K=20 hidden 100-100 latent 100",
+            m5, 512, "zero-inflated negative binomial", 100, "gmvae", 10)
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(respawn_one_rank_per_gpu(args))
+
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(
-                "--gpus {} needs torch.distributed.run with one rank per GPU"
-                .format(args.gpus))
+        raise SystemExit("--gpus {} but the launcher started {} ranks".format(
+            args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback).")
     # (several ranks may share a GPU in the 1-GPU debugging set-up below)
@@ -222,6 +452,7 @@ def main():
     device = torch.device("cuda", local_device)
 
     import torch.distributed as dist
+    backend, ranks_seen = None, 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL; SCVAE_BENCH_BACKEND=gloo only to exercise the N > 1 code path on a 1-GPU box
@@ -230,79 +461,38 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        # one all-reduce over the communicator: how many ranks RCCL really connects
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
 
-    from scvae_amd.engine import Engine
-    from scvae_amd.minibatch import philox_normal, synthetic_count_matrix
+    from scvae_amd.minibatch import synthetic_count_matrix
 
     matrix, _ = synthetic_count_matrix(
         args.cells, args.features, density=0.05, seed=60, device=device)
-    F = args.features
-    B = args.batch
-    GB = B * world
+    F, B, L = args.features, args.batch, args.latent
     gm = args.model == "gmvae"
     K = args.clusters if gm else 1
-    L = args.latent
-    engine = Engine(F, L, HIDDEN, args.likelihood, batch_norm=True,
-                    model_type="GMVAE" if gm else "VAE", n_clusters=K,
-                    device=device, seed=0)
-    engine.reserve(B, 1)
-    sync = None
-    if world > 1:
-        from scvae_amd.dataparallel import GradientSynchroniser
-        sync = GradientSynchroniser(engine)
-        sync.broadcast_state(0)
-
-    x = torch.empty(B, F, device=device)
-    row_const = torch.empty(B, device=device)
-    eps = torch.empty(K, B, L, device=device)
-    g = torch.Generator(device=device).manual_seed(2)
-    n = matrix.number_of_rows
-
-    def new_permutation():
-        return torch.randperm(n, generator=g, device=device)
-    perm = new_permutation()
-    cursor = 0
-    step_counter = 0
-
-    def one_step():
-        nonlocal perm, cursor, step_counter
-        if cursor + GB > n:
-            perm = new_permutation()
-            cursor = 0
-        rows = perm[cursor + rank * B: cursor + (rank + 1) * B]
-        cursor += GB
-        matrix.gather_dense(rows, out=x, row_const_out=row_const)
-        for k in range(K):
-            philox_normal(eps[k], row_offset=k * GB + rank * B, seed=1,
-                          stream_id=step_counter)
-        step_counter += 1
-        engine.step(x, x, eps=eps, row_const=row_const, training=True,
-                    global_cells=GB)
-        if sync is not None:
-            sync.all_reduce_gradients()
-        engine.adam_step(1e-4)
+    work = Workload(matrix, device, B, args.likelihood, L, model=args.model,
+                    clusters=args.clusters, world=world, rank=rank,
+                    data_parallel=world > 1)
+    GB = work.GB
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, per_step, warm_steps = work.run(args.steps, args.warmup, barrier)
     if world > 1:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    engine = work.engine
     scalars = engine.scalars.clone()
-    if sync is not None:
-        sync.all_reduce_scalars(scalars)
+    if work.sync is not None:
+        work.sync.all_reduce_scalars(scalars)
     lower_bound = float(scalars[0].item())
 
     if rank == 0:
@@ -324,15 +514,18 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "68k-PBMC-shaped synthetic counts {}x{} (~5% "
-                            "nonzero, device CSR), {} {} hidden 100-100 "
-                            "latent {} batch-norm, Adam lr 1e-4".format(
-                                args.cells, F, args.likelihood,
-                                "GMVAE K={}".format(K) if gm else "VAE", L),
+                "workload": describe(args.cells, F, args.likelihood, gm, K, L),
                 "cells_per_gpu_per_step": B,
                 "global_batch": GB,
                 "parallelism": "dp{}".format(world),
             },
+            "collective_backend": ("rccl (torch 'nccl')" if backend == "nccl"
+                                   else backend),
+            "ranks_in_communicator": ranks_seen,
+            "warm_steps_before_timing": warm_steps,
+            "step_ms_min": min(per_step),
+            "step_ms_median": statistics.median(per_step),
+            "step_ms_max": max(per_step),
             "train_flop_per_cell": flops_cell,
             "step_mfma_frac": value / world * flops_cell / 1e12
             / PEAK_FP32_MFMA_TFLOPS,
@@ -342,7 +535,10 @@ def main():
             result["train_flop_per_cell"] = None
             result["step_mfma_frac"] = None
         result["roofline"] = time_dominant_kernel(engine, B * K)
-        if world == 1 and not args.no_cpu_baseline and not gm:
+        headline = (not gm and args.likelihood == LIKELIHOOD and L == LATENT)
+        if world == 1 and headline and not args.no_other_workloads:
+            result["other_workloads"] = other_workloads(matrix, device, barrier)
+        if world == 1 and not args.no_cpu_baseline and headline:
             result["cpu_baseline"] = cpu_baseline(matrix, B)
         print(json.dumps(result), flush=True)
     if world > 1:

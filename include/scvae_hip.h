@@ -140,7 +140,11 @@ int scvae_plan_set_fused(scvae_plan* plan, int32_t enabled);
  * written to the bound grads buffer (and BN moving statistics are updated).
  * scalars (device, 8 floats): [0] lower_bound [1] lower_bound_weighted
  * [2] reconstruction_error [3] kl_divergence (VAE) / kl_divergence_z (GMVAE)
- * [4] kl_divergence_y (GMVAE) ; each is this rank's share of the global mean. */
+ * [4] kl_divergence_y (GMVAE) ; each is this rank's share of the global mean.
+ * [7] is NOT overwritten but incremented by 1 whenever the execution's lower_bound is not
+ * finite: a caller that keeps passing the same buffer gets a sticky counter of non-finite
+ * steps.  (The reference tests the loss at the steps it prints, va:1034-1044; with the counter
+ * the same test at the same steps also catches a non-finite loss of any step in between.) */
 typedef struct scvae_step_args {
   const float* x;
   const float* t;
@@ -174,6 +178,10 @@ typedef struct scvae_step_args {
   /* [cells] count sum N of every cell (count_sum_parameter, va:1017-1019): the total of the
    * constrained Poisson's rates.  Required for SCVAE_CONSTRAINED_POISSON, ignored otherwise */
   const float* count_sum;
+  /* data parallel: index of this rank's first cell within the global minibatch of
+   * global_cells cells (0 on a single GPU).  The dropout masks are a function of the global
+   * row, so a sharded step draws exactly the masks of the single-process step */
+  int64_t row_offset;
 } scvae_step_args;
 int scvae_plan_step(scvae_plan* plan, const scvae_step_args* args, void* stream);
 /* Decoder only, is_training = False: p_x_mean[rows, F] = mean of p(x|z) for given latent values
@@ -244,7 +252,8 @@ int scvae_csr_densify(const int64_t* indptr, const int32_t* indices, const float
 int scvae_csr_row_lgamma1p(const int64_t* indptr, const float* values, int64_t n_rows, float* out,
                            void* stream);
 int scvae_gather_rows(const float* src, const int64_t* rows, int64_t n, float* out, void* stream);
-/* q.sample() noise: Philox4x32-10 + Box-Muller keyed by (seed, stream_id, row_offset+row, col) */
+/* q.sample() noise: Philox4x32-10 + Box-Muller keyed by (seed, stream_id, row_offset+row, col):
+ * key = (seed_lo, seed_hi ^ stream_id_hi), counter = (row_lo, row_hi, col / 4, stream_id_lo) */
 int scvae_philox_normal(float* out, int64_t rows, int64_t cols, int64_t row_offset, uint64_t seed,
                         uint64_t stream_id, void* stream);
 /* batch-norm statistic merge for the data-parallel hook: gathered = [ranks][mean(n)|var(n)],

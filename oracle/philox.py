@@ -75,7 +75,11 @@ def standard_normal(rows, cols, row_offset, seed, stream_id):
     """scvae_philox_normal: Box-Muller on the uniform pairs (0, 1), (2, 3) of
     every counter."""
     groups = (cols + 3) // 4
-    u = uniform(_draws(rows, groups * 4, row_offset, seed, stream_id))
+    # 64-bit stream id: low word -> counter word 3, high word folded into key 1
+    stream_id = int(stream_id)
+    seed = int(seed) ^ ((stream_id >> 32) << 32)
+    u = uniform(_draws(rows, groups * 4, row_offset, seed,
+                       stream_id & 0xFFFFFFFF))
     u = u.reshape(rows, groups, 4).astype(np.float64)
     r0 = np.sqrt(-2.0 * np.log(u[..., 0]))
     r1 = np.sqrt(-2.0 * np.log(u[..., 2]))

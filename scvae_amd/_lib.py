@@ -76,6 +76,7 @@ class StepArgs(Structure):
         ("decoder_extra", c_void_p),
         ("dropout_seed", c_uint64),
         ("count_sum", c_void_p),
+        ("row_offset", c_int64),
     ]
 
 

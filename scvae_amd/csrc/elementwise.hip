@@ -699,6 +699,9 @@ __global__ __launch_bounds__(1024) void vae_elbo_kernel(const float* __restrict_
     scalars[1] = lbw * row_scale;
     scalars[2] = rec * row_scale / (float)n_iw;
     scalars[3] = kl_per_sample ? klsum * row_scale / (float)n_iw : klsum * row_scale * (float)n_mc;
+    // sticky: executions since the caller last zeroed the buffer whose ELBO was not finite
+    // (the reference tests the loss at the steps it prints, va:1034-1044: polled there)
+    if (!isfinite(lb)) scalars[7] += 1.f;
   }
 }
 
@@ -1407,7 +1410,10 @@ int philox_normal(hipStream_t stream, float* out, int64_t rows, int cols, int64_
   int64_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, out, rows,
-                     cols, row_offset, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)stream_id);
+                     cols, row_offset, (uint32_t)seed,
+                     // the high half of the 64-bit stream id goes into the key (callers use the
+                     // high bits as domain separators: evaluation passes, model.sample())
+                     (uint32_t)(seed >> 32) ^ (uint32_t)(stream_id >> 32), (uint32_t)stream_id);
   SCVAE_LAUNCH_CHECK("philox_normal_kernel");
   return 0;
 }
@@ -1422,15 +1428,19 @@ int philox_normal(hipStream_t stream, float* out, int64_t rows, int cols, int64_
 __global__ __launch_bounds__(256) void dropout_apply_kernel(
     const float* __restrict__ in, int ld_in, float* __restrict__ out, int ld_out, int64_t rows,
     int cols, float keep, float inv_keep, uint32_t seed_lo, uint32_t seed_hi, uint32_t site,
-    int accumulate) {
+    int accumulate, RowMap map) {
   const int groups = (cols + 3) / 4;
   const int64_t total = rows * groups;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = i / groups;
     const int cg = (int)(i % groups);
-    uint32_t c[4] = {(uint32_t)row, (uint32_t)((uint64_t)row >> 32), (uint32_t)cg,
-                     0x80000000u | site};
+    // the mask belongs to the row of the *global* minibatch (data parallel: rows of a rank's
+    // shard are block `row / cells` of the stacked passes, cell `offset + row % cells`)
+    const uint64_t grow = map.cells > 0
+        ? (uint64_t)((row / map.cells) * map.global_cells + map.offset + row % map.cells)
+        : (uint64_t)row;
+    uint32_t c[4] = {(uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)cg, 0x80000000u | site};
     uint32_t k0 = seed_lo, k1 = seed_hi;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -1452,7 +1462,7 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(
 
 int dropout_apply(hipStream_t stream, const float* in, int ld_in, float* out, int ld_out,
                   int64_t rows, int cols, float keep, uint64_t seed, uint32_t site,
-                  int accumulate) {
+                  int accumulate, RowMap map) {
   SCVAE_ARG(in && out && rows >= 0 && cols > 0 && ld_in >= cols && ld_out >= cols);
   SCVAE_ARG(keep > 0.f && keep <= 1.f && site < 0x80000000u);
   if (rows == 0) return 0;
@@ -1461,7 +1471,7 @@ int dropout_apply(hipStream_t stream, const float* in, int ld_in, float* out, in
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, ld_in,
                      out, ld_out, rows, cols, keep, 1.f / keep, (uint32_t)seed,
-                     (uint32_t)(seed >> 32), site, accumulate);
+                     (uint32_t)(seed >> 32), site, accumulate, map);
   SCVAE_LAUNCH_CHECK("dropout_apply_kernel");
   return 0;
 }

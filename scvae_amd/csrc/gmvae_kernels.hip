@@ -375,6 +375,7 @@ __global__ void gmvae_elbo_finish_kernel(const float* __restrict__ sums, float w
   scalars[2] = rec * share;
   scalars[3] = kz * share;
   scalars[4] = ky * share;
+  if (!isfinite(rec - (kz + ky))) scalars[7] += 1.f;   // sticky non-finite counter (gm:1124-1127)
   gate[0] = use_free_nats ? (ky > thr ? 1.f : 0.f) : 1.f;
 }
 int gmvae_elbo(hipStream_t s, const float* ll, const float* klz, const float* y,

@@ -186,10 +186,17 @@ int gather_rows_f32(hipStream_t stream, const float* src, const int64_t* rows, i
 // (seed, stream id, global row, column): identical for any sharding of the rows
 int philox_normal(hipStream_t stream, float* out, int64_t rows, int cols, int64_t row_offset,
                   uint64_t seed, uint64_t stream_id);
-// dropout (mu:45-50): out (+)= in * mask(seed, site, row, col) / keep; forward and backward
+// Local row -> row of the global minibatch (data parallel).  A buffer of `rows` rows stacks
+// rows / cells passes (samples, GMVAE clusters) of this rank's `cells` cells, which are cells
+// offset .. offset + cells - 1 of the global_cells cells of the step: local row p*cells + b is
+// global row p*global_cells + offset + b.  cells == 0: identity.
+struct RowMap {
+  int64_t cells = 0, global_cells = 0, offset = 0;
+};
+// dropout (mu:45-50): out (+)= in * mask(seed, site, global row, col) / keep; forward and backward
 int dropout_apply(hipStream_t stream, const float* in, int ld_in, float* out, int ld_out,
                   int64_t rows, int cols, float keep, uint64_t seed, uint32_t site,
-                  int accumulate);
+                  int accumulate, RowMap map = RowMap());
 // out[k, :] = in[k, :] * mask(seed, site, row k, column k) / keep (dropout of a one-hot input)
 int dropout_scale_rows(hipStream_t stream, const float* in, float* out, int K, int N, float keep,
                        uint64_t seed, uint32_t site);

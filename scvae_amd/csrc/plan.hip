@@ -171,7 +171,7 @@ int dense_input(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_
   *in_out = in; *ld_out = ld_in;
   if (!training || d.keep <= 0.f) return 0;
   int rc = dropout_apply(s, in, ld_in, d.in_drop, d.n_in, rows, d.n_in, d.keep, p->drop_seed,
-                         d.site, 0);
+                         d.site, 0, p->drop_rows);
   if (rc) return rc;
   *in_out = d.in_drop; *ld_out = d.n_in;
   return 0;
@@ -180,7 +180,7 @@ int dense_input(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_
 int dense_input_backward(scvae_plan* p, hipStream_t s, const Dense& d, const float* g, float* out,
                          int rows, bool accumulate) {
   return dropout_apply(s, g, d.n_in, out, d.n_in, rows, d.n_in, d.keep, p->drop_seed, d.site,
-                       accumulate ? 1 : 0);
+                       accumulate ? 1 : 0, p->drop_rows);
 }
 
 int dense_forward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_in,
@@ -801,6 +801,15 @@ int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
   SCVAE_ARG(p->cfg.decoder_extra == 0 || a->decoder_extra);
   SCVAE_ARG(!a->training || p->grads);
   SCVAE_ARG(!(a->training && a->deterministic_z));
+  SCVAE_ARG(a->row_offset >= 0 &&
+            (a->global_cells <= 0 || a->row_offset + a->cells <= a->global_cells));
+  p->drop_seed = a->dropout_seed;
+  p->drop_rows = RowMap();
+  if (a->global_cells > a->cells) {   // a shard of a data-parallel minibatch
+    p->drop_rows.cells = a->cells;
+    p->drop_rows.global_cells = a->global_cells;
+    p->drop_rows.offset = a->row_offset;
+  }
   if (p->cfg.model_type == SCVAE_MODEL_GMVAE) {
     SCVAE_ARG(!a->deterministic_z);
     return scvae::gmvae_step(p, a, (hipStream_t)stream);

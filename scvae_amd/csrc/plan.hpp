@@ -143,6 +143,7 @@ struct scvae_plan {
   float *zcat = nullptr, *dzcat = nullptr;  // [rows, L + E]: decoder input [z | extra] and its gradient
   int use_fused = 1;          // fused decoder head kernel (0 = unfused GEMM + likelihood path)
   uint64_t drop_seed = 0;     // dropout: this step's mask seed (scvae_step_args.dropout_seed)
+  RowMap drop_rows;           // ... and this rank's rows within the global minibatch
   scvae_sync_fn sync = nullptr;
   void* sync_user = nullptr;
   // data parallel: when the backward reaches this layer's weight gradient (the last large GEMM of

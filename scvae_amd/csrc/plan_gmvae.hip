@@ -238,7 +238,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       // every pass drops its own elements of [x | one-hot]: K separate inputs, one GEMM
       TRY(tile_onehot(s, a->x, d.in_drop, K, B, F));
       TRY(dropout_apply(s, d.in_drop, F + K, d.in_drop, F + K, KB, F + K, d.keep, p->drop_seed,
-                        d.site, 0));
+                        d.site, 0, p->drop_rows));
       TRY(dense_affine(p, s, d, d.in_drop, F + K, KB, K, true, training));
     } else if (i == 0) {
       // x*W[:F] + b once, then + W[F+k] per pass

@@ -138,6 +138,14 @@ class GradientSynchroniser:
         return scalars
 
     def broadcast_state(self, src=0):
+        """Weights, Adam slots, moving statistics and the Adam step count of
+        rank ``src`` on every rank (the step count sets lr_t: replicas with
+        different counts would silently diverge)."""
         for tensor in (self.engine.params, self.engine.adam_m,
                        self.engine.adam_v, self.engine.moving):
             dist.broadcast(tensor, src=src, group=self.group)
+        step_count = torch.tensor([float(self.engine.adam_t)],
+                                  dtype=torch.float64,
+                                  device=self.engine.params.device)
+        dist.broadcast(step_count, src=src, group=self.group)
+        self.engine.adam_t = int(step_count.item())

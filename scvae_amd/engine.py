@@ -308,7 +308,8 @@ class Engine:
     def step(self, x, t, eps=None, row_const=None, training=False,
              n_iw=1, n_mc=1, warm_up_weight=1.0, deterministic_z=False,
              global_cells=None, outputs=None, scalars=None,
-             decoder_extra=None, dropout_seed=None, count_sum=None):
+             decoder_extra=None, dropout_seed=None, count_sum=None,
+             row_offset=0):
         """One graph execution (no host synchronisation).  ``outputs`` maps
         optional output names of ``scvae_step_args`` to preallocated tensors.
         ``dropout_seed``: seed of this training step's dropout masks (default:
@@ -342,6 +343,8 @@ class Engine:
             a.dropout_seed = int(dropout_seed) & 0xFFFFFFFFFFFFFFFF
         a.cells = cells
         a.global_cells = global_cells if global_cells else cells
+        # data parallel: this rank's first cell within the global minibatch
+        a.row_offset = int(row_offset)
         a.n_iw, a.n_mc = n_iw, n_mc
         a.training = 1 if training else 0
         a.deterministic_z = 1 if deterministic_z else 0

@@ -49,6 +49,12 @@ class DeviceCSR:
     @classmethod
     def from_scipy(cls, matrix, device):
         matrix = matrix.tocsr()
+        if not matrix.has_canonical_format:
+            # duplicate (row, column) entries are summed, as ``.toarray()`` of
+            # the reference's minibatch fetch does (va:997-998); the densify
+            # kernel and the lgamma row term take one entry per position
+            matrix = matrix.copy()
+            matrix.sum_duplicates()
         matrix.sort_indices()
         return cls(matrix.indptr.astype(numpy.int64),
                    matrix.indices.astype(numpy.int32),

@@ -31,6 +31,13 @@ from scvae_amd.utilities import (
     capitalise_string, format_duration, format_time)
 
 
+def _rank_zero_value(value, device):
+    """Rank 0's ``value`` (a number) on every rank."""
+    holder = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    torch.distributed.broadcast(holder, src=0)
+    return float(holder.item())
+
+
 def _distributed():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
@@ -283,6 +290,8 @@ class ModelBase:
         if (master and reset_training
                 and os.path.exists(permanent_log_directory)):
             mu.clear_log_directory(permanent_log_directory)
+        if world > 1:   # nobody reads the directories before rank 0 is done with them
+            torch.distributed.barrier()
 
         metadata_log = {
             "epochs trained": None,
@@ -330,6 +339,12 @@ class ModelBase:
             model_string=model_string, epoch_start=epoch_start,
             number_of_epochs=number_of_epochs, data_string=data_string)
 
+        if world > 1:
+            # one decision for all ranks (a rank that disagreed would leave the
+            # collectives of the others hanging)
+            epoch_start = int(_rank_zero_value(epoch_start,
+                                               self.engine.device))
+
         if epoch_start >= number_of_epochs:
             say(training_string)
             return 0
@@ -345,6 +360,8 @@ class ModelBase:
             say("Log directory copied ({}).".format(
                 format_duration(time() - copying_time_start)))
             say()
+        if world > 1:
+            torch.distributed.barrier()
 
         minibatch_size = self._training_minibatch_size(
             minibatch_size, "training")
@@ -423,7 +440,10 @@ class ModelBase:
                 format_duration(time() - initialising_time_start)))
             say()
         if sync is not None:
+            # rank 0's weights, Adam slots *and* step count / epoch (a rank that
+            # saw a stale checkpoint must not keep its own)
             sync.broadcast_state(0)
+            epoch_start = int(_rank_zero_value(epoch_start, engine.device))
 
         metadata_log["epochs trained"] = (epoch_start, number_of_epochs)
         say(training_string)
@@ -443,6 +463,8 @@ class ModelBase:
             int(numpy.prod(self._eps_shape(samples, max(local_batch, 1)))),
             device=device)
         step = int(epoch_start * steps_per_epoch)
+        engine.reserve(max(local_batch, 1), samples)
+        engine.scalars.zero_()   # incl. the sticky non-finite-step counter [7]
 
         from scvae_amd.minibatch import philox_normal
 
@@ -494,8 +516,10 @@ class ModelBase:
                     n_mc=n_mc, warm_up_weight=warm_up_weight,
                     global_cells=global_cells, decoder_extra=de,
                     count_sum=cs,
-                    dropout_seed=((self.noise_seed * 1000003 + rank) << 40)
-                    + step + 1)
+                    # (the masks are keyed by the global row: the same for any
+                    # sharding, like the noise)
+                    dropout_seed=((self.noise_seed * 1000003) << 40)
+                    + step + 1, row_offset=lo)
                 if sync is not None:
                     sync.all_reduce_gradients()
                 engine.adam_step(learning_rate)
@@ -504,12 +528,16 @@ class ModelBase:
                     local = scalars.clone()
                     if sync is not None:
                         sync.all_reduce_scalars(local)
-                    minibatch_loss = float(local[0].item())
+                    local = local.cpu()
+                    minibatch_loss = float(local[0])
+                    # [7]: steps since the start of train() whose ELBO was not
+                    # finite (sticky device-side counter, summed over the ranks)
+                    non_finite_steps = float(local[7])
                     step_duration = time() - step_time_start
                     say("Step {:d} ({}): {:.5g}.".format(
                         int(step + 1), format_duration(step_duration),
                         minibatch_loss))
-                    if numpy.isnan(minibatch_loss):
+                    if numpy.isnan(minibatch_loss) or non_finite_steps > 0:
                         raise ArithmeticError(
                             "Aborting. The ELBO for the last batch became "
                             "indefinite.")
@@ -517,6 +545,12 @@ class ModelBase:
 
             say()
             torch.cuda.synchronize(device)
+            non_finite = engine.scalars[7:8].clone()
+            if sync is not None:
+                sync.all_reduce_scalars(non_finite)
+            if float(non_finite.item()) > 0:   # any step of the epoch, any rank
+                raise ArithmeticError(
+                    "Aborting. The ELBO for a batch became indefinite.")
             epoch_duration = time() - epoch_time_start
             say("Epoch {} ({}):".format(
                 epoch + 1, format_duration(epoch_duration)))
@@ -902,12 +936,13 @@ class ModelBase:
         if "reconstructed" in output_versions:
             # the reference's "15 GB dense reconstructed test set"
             # (docs/guide.rst:61) stays in HBM until the single copy below
-            outputs["p_x_mean"] = torch.empty(
-                n_examples_eval, n_features_eval, device=device)
-            outputs["p_x_stddev"] = torch.empty(
-                n_examples_eval, n_features_eval, device=device)
-            outputs["stddev_of_p_x_given_z_mean"] = torch.empty(
-                n_examples_eval, n_features_eval, device=device)
+            # (zeros, not empty: with several ranks each one fills the rows of
+            # its own minibatches and the all-reduce(sum) below assembles the rest)
+            allocate = torch.zeros if world > 1 else torch.empty
+            for key in ("p_x_mean", "p_x_stddev",
+                        "stddev_of_p_x_given_z_mean"):
+                outputs[key] = allocate(
+                    n_examples_eval, n_features_eval, device=device)
         if use_deterministic_z:
             n_iw = n_mc = 1
         else:

@@ -114,8 +114,11 @@ def get_checkpoint_state(log_directory):
     index = os.path.join(log_directory, CHECKPOINT_INDEX)
     if not os.path.exists(index):
         return None
-    with open(index) as f:
-        name = json.load(f).get("model_checkpoint_path")
+    try:
+        with open(index) as f:
+            name = json.load(f).get("model_checkpoint_path")
+    except ValueError:   # a truncated index counts as no checkpoint
+        return None
     if not name:
         return None
     path = os.path.join(log_directory, os.path.basename(name))
@@ -132,9 +135,15 @@ def save_checkpoint(state, log_directory, epoch):
     import torch
     os.makedirs(log_directory, exist_ok=True)
     name = "{}-{}.pt".format(CHECKPOINT_PREFIX, epoch)
-    torch.save(state, os.path.join(log_directory, name))
-    with open(os.path.join(log_directory, CHECKPOINT_INDEX), "w") as f:
+    # write-then-rename, the state before the index that points at it: an
+    # interrupted save leaves the previous checkpoint and its index intact
+    path = os.path.join(log_directory, name)
+    torch.save(state, path + ".tmp")
+    os.replace(path + ".tmp", path)
+    index = os.path.join(log_directory, CHECKPOINT_INDEX)
+    with open(index + ".tmp", "w") as f:
         json.dump({"model_checkpoint_path": name}, f)
+    os.replace(index + ".tmp", index)
     remove_old_checkpoints(log_directory)  # Saver(max_to_keep=1)
     return os.path.join(log_directory, name)
 
@@ -172,8 +181,10 @@ class CheckpointWriter:
 
 def load_checkpoint(checkpoint_path):
     import torch
+    # the state is tensors plus one int: nothing that needs unpickling of
+    # arbitrary objects
     return torch.load(checkpoint_path, map_location="cpu",
-                      weights_only=False)
+                      weights_only=True)
 
 
 def copy_model_directory(checkpoint_path, output_directory):
@@ -200,7 +211,8 @@ def remove_old_checkpoints(log_directory):
         return
     keep = os.path.basename(latest)
     for entry in os.listdir(log_directory):
-        if (entry.startswith(CHECKPOINT_PREFIX + "-") and entry != keep):
+        if (entry.startswith(CHECKPOINT_PREFIX + "-") and entry != keep
+                and not entry.endswith(".tmp")):
             os.remove(os.path.join(log_directory, entry))
 
 

@@ -175,13 +175,26 @@ def test_random_streams_match_the_numpy_restatement(cuda_device):
         assert np.array_equal(out.cpu().numpy(), want), (rows, cols, site)
     for rows, cols, offset, seed, stream_id in [
             (50, 25, 0, 1, 0), (33, 7, 1000, 0xDEADBEEF12, 41),
-            (8, 100, 2 ** 33, 5, 2)]:
+            (8, 100, 2 ** 33, 5, 2),
+            # 64-bit stream ids: the host uses the high bits as domain separators
+            # (evaluation passes (1 << 40) + ..., model.sample() (1 << 41) + j)
+            (16, 25, 0, 1, (1 << 40) + 3), (16, 25, 0, 1, (1 << 41) + 3)]:
         out = torch.empty(rows, cols, device=cuda_device)
         _lib.check(lib.scvae_philox_normal(
             _p(out), rows, cols, offset, seed, stream_id, _stream()), "philox")
         torch.cuda.synchronize()
         want = philox.standard_normal(rows, cols, offset, seed, stream_id)
         assert np.abs(out.cpu().numpy() - want).max() < 2e-5
+    # streams that differ only above bit 31 are different streams
+    draws = []
+    for stream_id in (3, (1 << 40) + 3, (1 << 41) + 3):
+        out = torch.empty(16, 25, device=cuda_device)
+        _lib.check(lib.scvae_philox_normal(
+            _p(out), 16, 25, 0, 1, stream_id, _stream()), "philox")
+        draws.append(out.cpu())
+    assert not torch.equal(draws[0], draws[1])
+    assert not torch.equal(draws[0], draws[2])
+    assert not torch.equal(draws[1], draws[2])
 
 
 def test_csr_densify(cuda_device):
