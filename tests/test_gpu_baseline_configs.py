@@ -73,6 +73,28 @@ def _bn_bias(name):
         "ENCODER/" in name or "DECODER/" in name or "LAYER_" in name)
 
 
+def _check_optimiser(eng, dev_grads, params, new_params, skip):
+    """clip + Adam (va:2742-2759).  An Adam step from zero slots moves an
+    element by ``lr * g / (|g| + 3.2e-7)``: where |g| is within the gradient
+    tolerance of that epsilon, the step is not determined by a gradient that
+    is only known to 2e-4 of the tensor's maximum.  So the kernel is held to
+    the oracle's optimiser *fed with the device's gradients* (per element,
+    fp32 rounding), and the end-to-end weights to the oracle's in the median."""
+    want = om.clip_and_adam(dict(params), dev_grads, om.adam_state(params),
+                            LEARNING_RATE)
+    for name, p in eng.named_parameters().items():
+        if skip(name):
+            continue
+        close_elementwise(p, want[name], rtol=1e-6, atol=1e-8,
+                          what="Adam kernel " + name)
+        diff = (p.cpu().double() - new_params[name]).abs()
+        stats = "{}: max {:.3e} median {:.3e} mean {:.3e} (lr {:.0e})".format(
+            name, diff.max().item(), diff.median().item(), diff.mean().item(),
+            LEARNING_RATE)
+        assert diff.max().item() <= 2.001 * LEARNING_RATE, stats
+        assert diff.median().item() <= 1e-2 * LEARNING_RATE, stats
+
+
 @pytest.mark.parametrize("config,likelihood,features,latent,cells", [
     ("cfg2", "negative binomial", 32738, 25, 100),
     ("cfg3", "zero-inflated negative binomial", 32738, 100, 100),
@@ -103,6 +125,8 @@ def test_vae_training_step_at_baseline_shape(cuda_device, config, likelihood,
                   training=True, warm_up_weight=warm_up,
                   outputs={"log_p_x_given_z": ll, "kl_neurons": klz,
                            "q_z_mean": qz}).cpu().numpy()
+    dev_grads = {k: v.detach().cpu().double()
+                 for k, v in eng.named_gradients().items()}
     eng.adam_step(LEARNING_RATE)
     torch.cuda.synchronize()
     assert np.isfinite(sc[:4]).all()
@@ -124,15 +148,12 @@ def test_vae_training_step_at_baseline_shape(cuda_device, config, likelihood,
                       what="kl per latent unit")
     close_elementwise(qz, out["q_z_mean"], rtol=1e-4, atol=1e-5,
                       what="q_z_mean")
-    for name, g in eng.named_gradients().items():
+    for name, g in dev_grads.items():
         if _bn_bias(name):
             assert g.abs().max().item() == 0.0, name
             continue
         close_maxnorm(g, grads[name], rtol=2e-4, what="grad " + name)
-    for name, p in eng.named_parameters().items():
-        if _bn_bias(name):
-            continue
-        close_maxnorm(p, new_params[name], rtol=2e-4, what="param " + name)
+    _check_optimiser(eng, dev_grads, params, new_params, _bn_bias)
     for name, m in eng.named_moving_statistics().items():
         close_elementwise(m, new_moving[name], rtol=1e-5, atol=1e-7,
                           what="moving " + name)
@@ -165,6 +186,8 @@ def test_gmvae_training_step_at_baseline_shape(cuda_device, config,
                   training=True, warm_up_weight=warm_up,
                   outputs={"log_p_x_given_z": ll, "q_y_logits": logits,
                            "q_z_mean": zmean}).cpu().numpy()
+    dev_grads = {k: v.detach().cpu().double()
+                 for k, v in eng.named_gradients().items()}
     eng.adam_step(LEARNING_RATE)
     torch.cuda.synchronize()
     assert np.isfinite(sc[:5]).all()
@@ -188,23 +211,23 @@ def test_gmvae_training_step_at_baseline_shape(cuda_device, config,
                       what="q_y_logits")
     close_elementwise(zmean, out["z_mean"], rtol=1e-4, atol=1e-5,
                       what="z_mean")
-    for name, g in eng.named_gradients().items():
+    for name, g in dev_grads.items():
         if _bn_bias(name):
             assert g.abs().max().item() == 0.0, name
             continue
-        got, want = g.cpu(), grads[name]
+        got, want = g, grads[name]
         if name == "Z/Q/ENCODER/LAYER_1/DENSE/weights":
             # the one-hot rows W[F+k] are cancelled by the per-pass batch norm
             assert got[F:].abs().max().item() < 1e-5
             got, want = got[:F], want[:F]
-        close_maxnorm(got, want, rtol=5e-4, what="grad " + name)
-    for name, p in eng.named_parameters().items():
-        if _bn_bias(name):
-            continue
-        got, want = p.cpu(), new_params[name]
-        if name == "Z/Q/ENCODER/LAYER_1/DENSE/weights":
-            got, want = got[:F], want[:F]
-        close_maxnorm(got, want, rtol=3e-4, what="param " + name)
+        # q(y|x): d/dlogit_k = y_k (dy_k - sum_j y_j dy_j) with dy_k = -ll_k / B
+        # takes differences (of order 1..10) of per-cluster log-likelihoods of
+        # order 2e4, whose fp32 ulp is 2e-3: that conditioning -- the
+        # reference's fp32 graph has it too -- shows at the 1e-3 level
+        rtol = 2e-3 if name.startswith("Y/") else 5e-4
+        close_maxnorm(got, want, rtol=rtol, what="grad " + name)
+    # (rows W[F+k] of the first q(z|x,y) layer: zero gradient, see above)
+    _check_optimiser(eng, dev_grads, params, new_params, _bn_bias)
     for name, m in eng.named_moving_statistics().items():
         close_elementwise(m, new_moving[name], rtol=2e-5, atol=1e-7,
                           what="moving " + name)
