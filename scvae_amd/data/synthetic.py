@@ -50,13 +50,18 @@ def create_development_data_set(n_examples=10000, n_features=25, scale=10,
             keep = random_state.binomial(1, dropout[i, j])
             values[i, j] = keep * value
 
+    feature_ids = numpy.array(
+        ["feature {}".format(j + 1) for j in range(n_features)])
     return {
         "values": values,
         "labels": labels,
         "example names": numpy.array(
             ["example {}".format(i + 1) for i in range(n_examples)]),
-        "feature names": numpy.array(
-            ["feature {}".format(j + 1) for j in range(n_features)]),
+        "feature names": feature_ids,
+        # feature ids grouped five at a time under "feature A" .. "feature E"
+        "feature mapping": {
+            "feature " + letter: group.tolist() for letter, group in
+            zip("ABCDE", numpy.split(feature_ids, 5))},
     }
 
 

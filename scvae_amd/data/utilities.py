@@ -17,7 +17,9 @@ def build_directory_path(base_directory, data_set, splitting_method=None,
     """``<base>/<data set>/<no_split|split-<method>_<fraction>>/<preprocessing>``."""
     if splitting_method:
         if splitting_method == "default":
-            splitting_method = "random"
+            splitting_method = (
+                getattr(data_set, "default_splitting_method", None)
+                or "random")
         if splitting_method == "indices":
             splitting_directory = "split-indices"
         else:
@@ -29,6 +31,17 @@ def build_directory_path(base_directory, data_set, splitting_method=None,
     parts = []
     if getattr(data_set, "features_mapped", False):
         parts.append("features_mapped")
+    # (feature selection / example filters are not built -- SURVEY.md section 2
+    # OUT OF SCOPE -- but a data set object that carries them still gets the
+    # reference's directory name)
+    for kind in ("feature_selection", "example_filter"):
+        method = getattr(data_set, kind + "_method", None)
+        if method:
+            part = normalise_string(method)
+            for parameter in getattr(data_set, kind + "_parameters",
+                                     None) or ():
+                part += "_" + normalise_string(str(parameter))
+            parts.append(part)
     if preprocessing and data_set.preprocessing_methods:
         parts.extend(map(normalise_string, data_set.preprocessing_methods))
     if preprocessing and data_set.noisy_preprocessing_methods:

@@ -94,15 +94,6 @@ def step_fixture(kind, name, likelihood, F, L, H, B, K=1, S=1, bn=True,
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
 
 
-def development_data_set():
-    from scvae_amd.data.synthetic import create_development_data_set
-    d = create_development_data_set()
-    v = d["values"]
-    np.savez(os.path.join(HERE, "development_data_set.npz"),
-             first_rows=v[:8], row_sums=v.sum(axis=1)[:256],
-             column_sums=v.sum(axis=0), total=v.sum(),
-             nonzeros=np.count_nonzero(v), labels_head=d["labels"][:32])
-
 
 if __name__ == "__main__":
     likelihood_kat()
@@ -116,5 +107,4 @@ if __name__ == "__main__":
                  (10, 8), 13, K=3, seed=3)
     step_fixture("gmvae", "gmvae_step_zip", "zero-inflated poisson", 29, 3,
                  (8,), 9, K=2, S=2, seed=4)
-    development_data_set()
     print("fixtures written to", HERE)
