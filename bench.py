@@ -339,7 +339,8 @@ class Workload:
                           stream_id=self.step_counter)
         self.step_counter += 1
         self.engine.step(self.x, self.x, eps=self.eps, row_const=self.row_const,
-                         training=True, global_cells=GB, row_offset=rank * B)
+                         training=True, global_cells=GB, row_offset=rank * B,
+                         x_counts=self.matrix.integer_counts)
         if self.sync is not None:
             self.sync.all_reduce_gradients()
         self.engine.adam_step(1e-4)
@@ -512,6 +513,11 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            # x W1 and x^T dA of the input layer: exact hi/lo bf16 cut of the integer
+            # counts times an exact three-term bf16 split of the fp32 operand, fp32
+            # accumulation (count_gemm.hip); everything else fp32 MFMA / VALU
+            "encoder_input_arith": ("bf16x3-exact" if matrix.integer_counts
+                                    else "f32"),
             "data": "synthetic",
             "config": {
                 "workload": describe(args.cells, F, args.likelihood, gm, K, L),

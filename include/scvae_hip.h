@@ -129,6 +129,10 @@ int scvae_plan_set_sync(scvae_plan* plan, scvae_sync_fn fn, void* user);
  * 0: separate GEMM and likelihood kernels (same results; kept for A/B tests and for the
  * evaluate-time statistics, which need the materialised pre-activations) */
 int scvae_plan_set_fused(scvae_plan* plan, int32_t enabled);
+/* The exact bf16-split kernels for products with a count matrix (default on; 0: those products
+ * take the fp32 MFMA kernels even when scvae_step_args.x_counts is set -- for A/B measurements
+ * and the parity test between the two) */
+int scvae_plan_set_count_gemm(scvae_plan* plan, int32_t enabled);
 
 /* One graph execution = session.run(...) in the reference loops
  * (train step va:1026-1029 / gm:1094-1097; evaluation va:1124-1135, 1983-2014).
@@ -182,6 +186,11 @@ typedef struct scvae_step_args {
    * global_cells cells (0 on a single GPU).  The dropout masks are a function of the global
    * row, so a sharded step draws exactly the masks of the single-process step */
   int64_t row_offset;
+  /* != 0: the caller vouches that x holds integers in [0, 65536) (a count matrix; see
+   * scvae_check_counts).  The products x W and x^T dA of the layer that sees x then run on the
+   * exact bf16-split kernels (count_gemm.hip: fp32-accurate, 16x the fp32 matrix rate) instead of
+   * the fp32 MFMA kernels; 0 (preprocessed / dropped-out / unknown x): fp32 MFMA */
+  int32_t x_counts;
 } scvae_step_args;
 int scvae_plan_step(scvae_plan* plan, const scvae_step_args* args, void* stream);
 /* Decoder only, is_training = False: p_x_mean[rows, F] = mean of p(x|z) for given latent values
@@ -204,6 +213,20 @@ int scvae_gemm(int32_t trans_a, int32_t trans_b, const float* A, const float* B,
                int64_t ldb, int64_t ldc, int32_t relu, int32_t accumulate, void* workspace,
                int64_t workspace_bytes, void* stream);
 int64_t scvae_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+/* The same dense layer when its input is the count matrix itself (mu:53-59 on
+ * x_train[idx].toarray(), va:997-998), x integers in [0, 65536):
+ *   mode 0: C[rows, N] = act(x[rows, cols] other[cols, N] + bias)   (x W + b)
+ *   mode 1: C[cols, N] = x[rows, cols]^T other[rows, N]             (dW = x^T dA)
+ * exact hi/lo bf16 cut of x times an exact three-term bf16 split of `other`, fp32 accumulation
+ * on the bf16 matrix cores; N <= 128.  workspace: scvae_count_gemm_workspace_bytes (16-byte
+ * aligned).  The precondition on x is the caller's (scvae_check_counts). */
+int scvae_count_gemm(int32_t mode, const float* x, int64_t ldx, int64_t rows, int64_t cols,
+                     const float* other, int64_t ld_other, int64_t N, const float* bias,
+                     int32_t relu, float* C, int64_t ldc, void* workspace, int64_t workspace_bytes,
+                     void* stream);
+int64_t scvae_count_gemm_workspace_bytes(int32_t mode, int64_t rows, int64_t cols, int64_t N);
+/* *bad (device int32) = 1 unless every one of the n values is an integer in [0, 65536) */
+int scvae_check_counts(const float* values, int64_t n, int32_t* bad, void* stream);
 /* p(x|z).log_prob(t) summed over F (va:2583-2590); pre = heads' pre-activations [rows,F] */
 int scvae_loglik_fwd(int32_t kind, const float* t, const float* const* pre, const float* row_const,
                      float* ll, int64_t rows, int64_t cells, int64_t F, void* stream);

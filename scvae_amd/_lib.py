@@ -77,6 +77,7 @@ class StepArgs(Structure):
         ("dropout_seed", c_uint64),
         ("count_sum", c_void_p),
         ("row_offset", c_int64),
+        ("x_counts", c_int32),
     ]
 
 
@@ -104,6 +105,14 @@ SIGNATURES = {
         c_int64]),
     "scvae_plan_set_sync": (c_int32, [c_void_p, SYNC_FN, c_void_p]),
     "scvae_plan_set_fused": (c_int32, [c_void_p, c_int32]),
+    "scvae_plan_set_count_gemm": (c_int32, [c_void_p, c_int32]),
+    "scvae_count_gemm": (c_int32, [
+        c_int32, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64,
+        c_int64, c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int64,
+        c_void_p]),
+    "scvae_count_gemm_workspace_bytes": (c_int64, [c_int32, c_int64, c_int64,
+                                                   c_int64]),
+    "scvae_check_counts": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p]),
     "scvae_plan_step": (c_int32, [c_void_p, POINTER(StepArgs), c_void_p]),
     "scvae_adam_clip_step": (c_int32, [
         c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float,

@@ -1,0 +1,612 @@
+// The two large products of the encoder's input layer when x is a COUNT matrix
+// (scvae/models/utilities.py:53-59 on `x_train[idx].toarray()`, va:997-998):
+//
+//     forward   a[B,N]  = x[B,F] W[F,N] + b          (MODE 0; contraction over the genes)
+//     backward  dW[F,N] = x[B,F]^T dA[B,N]           (MODE 1; contraction over the cells)
+//
+// x holds integers below 65 536 (UMI counts), i.e. at most 16 significant bits: x = hi + lo with
+// hi = the fp32 bit pattern truncated to its upper 16 bits and lo = x - hi, BOTH exactly
+// representable in bf16 (lo == 0 for every count below 256, the bulk of a count matrix).  The
+// fp32 operand on the other side (W or dA) is split exactly into three bf16 terms
+// w = w1 + w2 + w3 (3 x 8 = 24 significant bits, round-to-nearest remainders).  Every product
+// hi*w_i / lo*w_i is then exact in the matrix core's fp32 accumulator, so the result is the fp32
+// sum of the exact products -- the quality of the fp32 MFMA path -- at 3 (or 6, where a tile
+// holds counts >= 256) bf16 MFMAs per 16 k, 16x the fp32 matrix rate: these two GEMMs become
+// HBM-bound reads of x instead of MFMA-bound.  Arithmetic type of the path stays fp32 ("dtype"
+// f32; bench.py reports "encoder_input_arith": "bf16x3-exact").
+//
+// The caller guarantees the precondition (DeviceCSR verifies integrality and range once, at
+// upload: scvae_csr_check_counts); anything else takes the fp32 MFMA kernels of gemm.hip.
+//
+// Structure (both modes): a workgroup = 8 waves, each owning 64 x-side rows (MODE 0: cells,
+// MODE 1: genes) x all N <= 128 columns (2 x 4 accumulator tiles of v_mfma_f32_32x32x16_bf16).
+// The x-side fragments come straight from global memory into the operand layout (MODE 0: a lane
+// reads 16 consecutive genes of its cell = one 128-byte line per pair of lanes; MODE 1: a lane
+// reads one gene down 16 cells, every load instruction covering two 128-byte row segments), are
+// cut into hi / lo with three VALU instructions per pair, and meet the other operand -- split and
+// transposed to k-contiguous bf16 once per launch by split3_transpose_kernel -- in LDS (80-byte
+// rows: conflict-free ds_read_b128 fragments).  Split-K over the grid, slabs reduced in a fixed
+// order by gemm.hip's reduction kernel (deterministic).
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace scvae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int CG_NP = 128;            // columns, padded
+constexpr int CG_BK = 32;             // k per chunk (two MFMA k-steps)
+constexpr int CG_ROW = 80;            // LDS bytes per (term, column) row: 64 + 16 pad
+constexpr int CG_WAVES = 8;
+constexpr int CG_TM = 64;             // x-side rows per wave (two 32-row tiles)
+constexpr int CG_BM = CG_WAVES * CG_TM;
+constexpr int CG_KPAD = 64;           // the split operand is zero-padded to a multiple of this
+
+static inline int cg_kpad(int K) { return (K + CG_KPAD - 1) / CG_KPAD * CG_KPAD; }
+
+__device__ __forceinline__ unsigned bf16_rne_bits(float v) {
+  // round-to-nearest-even to bf16, returned in the low 16 bits (finite inputs)
+  const unsigned u = __float_as_uint(v);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// S[R][C] (row-major, pitch ld) -> T[3][CG_NP][Rpad] bf16 with T[t][c][r] = term t of S[r][c];
+// zero for c >= C or r >= R.  One thread: one column, 8 consecutive rows (one 16-byte store
+// per term).
+__global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __restrict__ S, int R,
+                                                               int C, int ld,
+                                                               uint16_t* __restrict__ T,
+                                                               int Rpad) {
+  const int c = threadIdx.x & (CG_NP - 1);
+  const int r0 = (blockIdx.x * 2 + (threadIdx.x >> 7)) * 8;
+  if (r0 >= Rpad) return;
+  unsigned t1[8], t2[8], t3[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int r = r0 + j;
+    const float w = (c < C && r < R) ? S[(size_t)r * ld + c] : 0.f;
+    const unsigned b1 = bf16_rne_bits(w);
+    const float r1 = w - __uint_as_float(b1 << 16);          // exact
+    const unsigned b2 = bf16_rne_bits(r1);
+    const float r2 = r1 - __uint_as_float(b2 << 16);         // exact, <= 8 significant bits
+    const unsigned b3 = bf16_rne_bits(r2);
+    t1[j] = b1; t2[j] = b2; t3[j] = b3;
+  }
+  const size_t plane = (size_t)CG_NP * Rpad;
+  uint16_t* dst = T + (size_t)c * Rpad + r0;
+  auto pack = [](const unsigned* t) {
+    u32x4 v;
+    v.x = t[0] | (t[1] << 16); v.y = t[2] | (t[3] << 16);
+    v.z = t[4] | (t[5] << 16); v.w = t[6] | (t[7] << 16);
+    return v;
+  };
+  *reinterpret_cast<u32x4*>(dst) = pack(t1);
+  *reinterpret_cast<u32x4*>(dst + plane) = pack(t2);
+  *reinterpret_cast<u32x4*>(dst + 2 * plane) = pack(t3);
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// MODE 0: out[m, n] = sum_k X[m, k] Wt(k, n)      m: cells (M = B),  k: genes (K = F)
+// MODE 1: out[m, n] = sum_k X[k, m] dAt(k, n)     m: genes (M = F),  k: cells (K = B)
+// out: slabs [gridDim.y][M][N], or (direct) C itself with pitch ldo, bias and activation applied
+// NT: 32-column tiles in use (N <= 32 NT).  Rows / genes past M are clamped to M - 1 (loaded,
+// multiplied, never stored) and K here is a multiple of the chunk (the K % 32 leftover terms are
+// added in fp32 by the reduction kernel), so the loop has no per-lane predicates.
+template <int MODE, int NT>
+__global__ __launch_bounds__(512) void count_gemm_kernel(
+    const float* __restrict__ X, int ldx, int M, int K, const uint16_t* __restrict__ T, int Kpad,
+    int N, int k_chunk, float* __restrict__ out, int ldo, const float* __restrict__ bias,
+    int act, int direct) {
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[2][3 * CG_NP * CG_ROW];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kg = lane >> 5;
+  const int m_w = blockIdx.x * CG_BM + w * CG_TM;       // first x-side row of this wave
+  const int k_begin = blockIdx.y * k_chunk;
+  const int k_end = min(K, k_begin + k_chunk);
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][q][i] = 0.f;
+
+  // ---- x-side loads: raw[t][q], q = 8 s + j  <->  k = kc + 16 kg + 8 s + j ----
+  float raw[2][16];
+  // MODE 0: per-lane row pointers (+ uniform k offset); MODE 1: uniform row pointer (+ per-lane
+  // 32-bit element offset: gene + 16 kg rows)
+  const float* xrow[2];
+  unsigned xoff[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int m = min(m_w + 32 * t + li, M - 1);
+    xrow[t] = X + (size_t)m * ldx + 16 * kg;
+    xoff[t] = (unsigned)(16 * kg) * (unsigned)ldx + (unsigned)m;
+  }
+  auto load_x = [&](int kc) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (MODE == 0) {
+        const float* src = xrow[t] + kc;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const f32x4u x4 = *reinterpret_cast<const f32x4u*>(src + 4 * v);
+          raw[t][4 * v] = x4.x; raw[t][4 * v + 1] = x4.y;
+          raw[t][4 * v + 2] = x4.z; raw[t][4 * v + 3] = x4.w;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float* srow = X + (size_t)(kc + q) * ldx;      // uniform: scalar base
+          raw[t][q] = srow[xoff[t]];
+        }
+      }
+    }
+  };
+
+  // ---- split operand: global -> registers -> LDS (3 x 16 bytes per thread and chunk) ----
+  u32x4 breg[3];
+  auto load_b = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int p = tid + 512 * i;                 // 1536 pieces: (term, column, quarter)
+      const int row = p >> 2, part = p & 3;        // row = term * 128 + column
+      if ((row & (CG_NP - 1)) < NT * 32)
+        breg[i] = *reinterpret_cast<const u32x4*>(T + (size_t)row * Kpad + kc + part * 8);
+    }
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int p = tid + 512 * i;
+      const int row = p >> 2, part = p & 3;
+      if ((row & (CG_NP - 1)) < NT * 32)
+        *reinterpret_cast<u32x4*>(&Bs[buf][row * CG_ROW + part * 16]) = breg[i];
+    }
+  };
+
+  if (k_begin < k_end) {
+    load_x(k_begin);
+    load_b(k_begin);
+    store_b(0);
+  }
+  __syncthreads();
+
+  // B fragment (term, tile q, k-step s) of the current buffer
+  const int frag_off = li * CG_ROW + 32 * kg;
+  auto bfrag = [&](const unsigned char* bcur, int term, int q, int s) {
+    return as_bf16x8(*reinterpret_cast<const u32x4*>(
+        bcur + (term * CG_NP + q * 32) * CG_ROW + frag_off + 16 * s));
+  };
+
+  int buf = 0;
+  for (int kc = k_begin; kc < k_end; kc += CG_BK) {
+    // ---- cut the counts of this chunk into hi / lo bf16 fragments ----
+    u32x4 ahi[2][2];
+    unsigned low_bits = 0u;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        unsigned h[4];
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          const unsigned u0 = __float_as_uint(raw[t][8 * s + 2 * pr]);
+          const unsigned u1 = __float_as_uint(raw[t][8 * s + 2 * pr + 1]);
+          low_bits |= u0 | u1;
+          h[pr] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);        // upper halves
+        }
+        ahi[t][s] = u32x4{h[0], h[1], h[2], h[3]};
+      }
+    // more than 8 significant bits anywhere in this wave's 64 x 32 block of x? (wave-uniform)
+    const bool need_lo =
+        __builtin_amdgcn_readfirstlane(__any((int)((low_bits & 0xFFFFu) != 0u)));
+    u32x4 alo[2][2];
+    if (need_lo) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          unsigned l[4];
+#pragma unroll
+          for (int pr = 0; pr < 4; ++pr) {
+            const float x0 = raw[t][8 * s + 2 * pr], x1 = raw[t][8 * s + 2 * pr + 1];
+            const float l0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u);
+            const float l1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
+            l[pr] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+          }
+          alo[t][s] = u32x4{l[0], l[1], l[2], l[3]};
+        }
+    }
+
+    // ---- next chunk in flight under the MFMAs ----
+    const bool has_next = kc + CG_BK < k_end;
+    if (has_next) {
+      load_x(kc + CG_BK);
+      load_b(kc + CG_BK);
+    }
+
+    // ---- MFMAs: per (k-step, term) the NT fragments of the split operand, then 2 NT MFMAs;
+    //      smallest term first (fp32 accumulation) ----
+    const unsigned char* bcur = Bs[buf];
+#pragma unroll
+    for (int step = 0; step < 6; ++step) {
+      const int s = step / 3, term = 2 - step % 3;
+      bf16x8 fr[NT];
+#pragma unroll
+      for (int q = 0; q < NT; ++q) fr[q] = bfrag(bcur, term, q, s);
+      if (need_lo) {
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+          acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(alo[0][s]), fr[q],
+                                                              acc[0][q], 0, 0, 0);
+          acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(alo[1][s]), fr[q],
+                                                              acc[1][q], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NT; ++q) {
+        acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ahi[0][s]), fr[q],
+                                                            acc[0][q], 0, 0, 0);
+        acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ahi[1][s]), fr[q],
+                                                            acc[1][q], 0, 0, 0);
+      }
+    }
+    if (has_next) store_b(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
+  float* dst = direct ? out : out + (size_t)blockIdx.y * M * ldo;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const int col = q * 32 + li;
+      if (col >= N) continue;
+      const float bv = (direct && bias != nullptr) ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m_w + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (m < M) {
+          float v = acc[t][q][r] + bv;
+          if (direct && act == ACT_RELU) v = fmaxf(v, 0.f);
+          dst[(size_t)m * ldo + col] = v;
+        }
+      }
+    }
+}
+
+// ---- forward (MODE 0) with the x tile staged through LDS ----
+// Reading x straight into the operand layout (a lane = one cell, 64 contiguous bytes) touches 32
+// cache lines per load instruction and a quarter of each: measured 3.5 TB/s on its own.  Here a
+// workgroup (8 waves, 256 cells) reads its [256, 32] tile of x with fully coalesced 16-byte
+// loads (8 lanes per 128-byte row segment), cuts it into hi / lo bf16 in registers and parks it
+// in LDS (80-byte rows, the layout of the split operand); the MFMA fragments of both operands
+// are then conflict-free ds_read_b128.  Wave w: cells 64 (w & 3) .. +63 (two 32-row tiles),
+// column tiles NQ (w >> 2) .. + NQ - 1.  The lo plane is written only by waves whose cells need
+// it (more than 8 significant bits) or whose earlier lo data has to be cleared; it is read when
+// any wave of the workgroup flagged the chunk.
+constexpr int CF_BM = 256;
+constexpr int CF_A_BYTES = CF_BM * CG_ROW;            // one plane of one buffer
+
+static size_t cf_lds_bytes(int NQ) {
+  return 4 * (size_t)CF_A_BYTES + 2 * (size_t)(3 * 64 * NQ * CG_ROW) + 2 * 8 * sizeof(int);
+}
+
+template <int NQ>
+__global__ __launch_bounds__(512) void count_gemm_fwd_kernel(
+    const float* __restrict__ X, int ldx, int M, int K, const uint16_t* __restrict__ T, int Kpad,
+    int N, int k_chunk, float* __restrict__ out, int ldo, const float* __restrict__ bias,
+    int act, int direct) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cf_smem[];
+  constexpr int NCOL = 64 * NQ;                         // columns staged per term
+  constexpr int B_BYTES = 3 * NCOL * CG_ROW;
+  unsigned char* Ahi = cf_smem;                         // [2][256][80]
+  unsigned char* Alo = Ahi + 2 * CF_A_BYTES;            // [2][256][80]
+  unsigned char* Bsm = Alo + 2 * CF_A_BYTES;            // [2][3][NCOL][80]
+  int* lo_flag = reinterpret_cast<int*>(Bsm + 2 * B_BYTES);   // [2][8]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kg = lane >> 5;
+  const int rg = w & 3, q0 = (w >> 2) * NQ;
+  const int m0 = blockIdx.x * CF_BM;
+  const int k_begin = blockIdx.y * k_chunk;
+  const int k_end = min(K, k_begin + k_chunk);
+
+  f32x16 acc[2][NQ];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][q][i] = 0.f;
+
+  // zero both lo planes once (a wave only ever rewrites its own rows)
+  for (int i = tid; i < 2 * CF_A_BYTES / 16; i += 512)
+    reinterpret_cast<u32x4*>(Alo)[i] = u32x4{0u, 0u, 0u, 0u};
+
+  // ---- staging: thread -> 4 pieces (row (tid >> 3) + 64 i, floats 4 (tid & 7) .. + 3) ----
+  const int part = tid & 7;
+  const float* xsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = min(m0 + (tid >> 3) + 64 * i, M - 1);
+    xsrc[i] = X + (size_t)m * ldx + 4 * part;
+  }
+  const int a_off = (tid >> 3) * CG_ROW + part * 8;     // + i * 64 rows
+  f32x4u raw[4];
+  u32x4 breg[3];
+  auto load_tiles = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) raw[i] = *reinterpret_cast<const f32x4u*>(xsrc[i] + kc);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int p = tid + 512 * i;                      // (term, column, quarter)
+      const int row = p >> 2, prt = p & 3;              // row = term * 128 + column
+      if ((row & (CG_NP - 1)) < NCOL)
+        breg[i] = *reinterpret_cast<const u32x4*>(T + (size_t)row * Kpad + kc + prt * 8);
+    }
+  };
+  bool dirty[2] = {false, false};                       // this wave's lo rows of buffer b are set
+  auto store_tiles = [&](int buf) {
+    unsigned low = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned u0 = __float_as_uint(raw[i].x), u1 = __float_as_uint(raw[i].y);
+      const unsigned u2 = __float_as_uint(raw[i].z), u3 = __float_as_uint(raw[i].w);
+      low |= u0 | u1 | u2 | u3;
+      uint2 h;
+      h.x = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+      h.y = __builtin_amdgcn_perm(u3, u2, 0x07060302u);
+      *reinterpret_cast<uint2*>(Ahi + buf * CF_A_BYTES + a_off + i * 64 * CG_ROW) = h;
+    }
+    const bool need = __builtin_amdgcn_readfirstlane(__any((int)((low & 0xFFFFu) != 0u)));
+    if (need || dirty[buf]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float l0 = raw[i].x - __uint_as_float(__float_as_uint(raw[i].x) & 0xFFFF0000u);
+        const float l1 = raw[i].y - __uint_as_float(__float_as_uint(raw[i].y) & 0xFFFF0000u);
+        const float l2 = raw[i].z - __uint_as_float(__float_as_uint(raw[i].z) & 0xFFFF0000u);
+        const float l3 = raw[i].w - __uint_as_float(__float_as_uint(raw[i].w) & 0xFFFF0000u);
+        uint2 l;
+        l.x = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+        l.y = __builtin_amdgcn_perm(__float_as_uint(l3), __float_as_uint(l2), 0x07060302u);
+        *reinterpret_cast<uint2*>(Alo + buf * CF_A_BYTES + a_off + i * 64 * CG_ROW) = l;
+      }
+    }
+    dirty[buf] = need;
+    if (lane == 0) lo_flag[buf * 8 + w] = need ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int p = tid + 512 * i;
+      const int row = p >> 2, prt = p & 3;
+      const int term = row >> 7, col = row & (CG_NP - 1);
+      if (col < NCOL)
+        *reinterpret_cast<u32x4*>(Bsm + buf * B_BYTES + (term * NCOL + col) * CG_ROW + prt * 16) =
+            breg[i];
+    }
+  };
+
+  __syncthreads();                                      // lo planes zeroed
+  if (k_begin < k_end) {
+    load_tiles(k_begin);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  const int a_frag = (64 * rg + li) * CG_ROW + 32 * kg;      // + 32 rows * t, + 16 s
+  const int b_frag = (q0 * 32 + li) * CG_ROW + 32 * kg;      // + term * NCOL rows, + 32 rows * q
+  int buf = 0;
+  for (int kc = k_begin; kc < k_end; kc += CG_BK) {
+    const bool has_next = kc + CG_BK < k_end;
+    if (has_next) load_tiles(kc + CG_BK);               // in flight under the MFMAs
+
+    const bool need_lo =
+        __builtin_amdgcn_readfirstlane(__any(lo_flag[buf * 8 + (lane & 7)]));
+    const unsigned char* ah = Ahi + buf * CF_A_BYTES + a_frag;
+    const unsigned char* al = Alo + buf * CF_A_BYTES + a_frag;
+    const unsigned char* bb = Bsm + buf * B_BYTES + b_frag;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 fh[2], fl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        fh[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(ah + t * 32 * CG_ROW + 16 * s));
+      if (need_lo) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          fl[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(al + t * 32 * CG_ROW + 16 * s));
+      }
+#pragma unroll
+      for (int term = 2; term >= 0; --term) {           // smallest term first
+        bf16x8 fb[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          fb[q] = as_bf16x8(*reinterpret_cast<const u32x4*>(
+              bb + (term * NCOL + q * 32) * CG_ROW + 16 * s));
+        if (need_lo) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[0], fb[q], acc[0][q], 0, 0, 0);
+            acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[1], fb[q], acc[1][q], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[0], fb[q], acc[0][q], 0, 0, 0);
+          acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[1], fb[q], acc[1][q], 0, 0, 0);
+        }
+      }
+    }
+    if (has_next) store_tiles(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  float* dst = direct ? out : out + (size_t)blockIdx.y * M * ldo;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int col = (q0 + q) * 32 + li;
+      if (col >= N) continue;
+      const float bv = (direct && bias != nullptr) ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 64 * rg + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (m < M) {
+          float v = acc[t][q][r] + bv;
+          if (direct && act == ACT_RELU) v = fmaxf(v, 0.f);
+          dst[(size_t)m * ldo + col] = v;
+        }
+      }
+    }
+}
+
+// fixed-order sum of the split-K slabs, + the K % 32 leftover terms of the contraction (plain
+// fp32 fma on the original operands: k_main <= k < K), + bias, activation
+__global__ __launch_bounds__(256) void count_gemm_reduce_kernel(
+    const float* __restrict__ slabs, const float* __restrict__ bias, float* __restrict__ C, int M,
+    int N, int ldc, int splits, int act, int mode, const float* __restrict__ X, int ldx,
+    const float* __restrict__ other, int ld_other, int k_main, int K) {
+  const size_t total = (size_t)M * N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / N), col = (int)(i % N);
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * total + i];
+    for (int k = k_main; k < K; ++k) {
+      const float xv = mode == 0 ? X[(size_t)row * ldx + k] : X[(size_t)k * ldx + row];
+      s = fmaf(xv, other[(size_t)k * ld_other + col], s);
+    }
+    if (bias) s += bias[col];
+    if (act == ACT_RELU) s = fmaxf(s, 0.f);
+    C[(size_t)row * ldc + col] = s;
+  }
+}
+
+static int cg_splits(int mode, int M, int K) {
+  const int bm = mode == 0 ? CF_BM : CG_BM;
+  const long blocks = (M + bm - 1) / bm;
+  long want = (256 + blocks - 1) / blocks;           // one workgroup per CU in total
+  const long max_by_k = K / 256 > 0 ? K / 256 : 1;   // at least 8 chunks per split
+  long s = want < max_by_k ? want : max_by_k;
+  if (s < 1) s = 1;
+  if (s > 128) s = 128;
+  return (int)s;
+}
+
+bool count_gemm_supported(int N) { return N >= 1 && N <= CG_NP; }
+
+// mode 0: x [rows, cols] (pitch ldx) times other [cols, N]   -> C [rows, N]
+// mode 1: x^T                        times other [rows, N]   -> C [cols, N]
+size_t count_gemm_workspace_bytes(int mode, int rows, int cols, int N) {
+  if (!count_gemm_supported(N)) return 0;
+  const int M = mode == 0 ? rows : cols, K = mode == 0 ? cols : rows;
+  const size_t t_bytes = (size_t)3 * CG_NP * cg_kpad(K) * sizeof(uint16_t);
+  const int splits = cg_splits(mode, M, K / CG_BK * CG_BK);
+  return (t_bytes + 255) / 256 * 256 + (size_t)splits * M * N * sizeof(float);
+}
+
+int count_gemm(hipStream_t stream, int mode, const float* x, int ldx, int rows, int cols,
+               const float* other, int ld_other, int N, const float* bias, int act, float* C,
+               int ldc, void* workspace, size_t workspace_bytes) {
+  SCVAE_ARG(x && other && C && workspace);
+  SCVAE_ARG(mode == 0 || mode == 1);
+  SCVAE_ARG(count_gemm_supported(N) && ld_other >= N && ldc >= N && ldx >= cols);
+  if (rows == 0 || cols == 0) return 0;
+  SCVAE_ARG(workspace_bytes >= count_gemm_workspace_bytes(mode, rows, cols, N));
+  SCVAE_ARG(((uintptr_t)workspace & 15) == 0);
+  const int M = mode == 0 ? rows : cols, K = mode == 0 ? cols : rows;
+  const int k_main = K / CG_BK * CG_BK;      // whole chunks: matrix cores; the rest: reduction
+  const int Kpad = cg_kpad(K);
+  uint16_t* T = reinterpret_cast<uint16_t*>(workspace);
+  const size_t t_bytes = ((size_t)3 * CG_NP * Kpad * sizeof(uint16_t) + 255) / 256 * 256;
+  float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + t_bytes);
+  int splits = 0;
+  if (k_main > 0) {
+    hipLaunchKernelGGL(split3_transpose_kernel, dim3((Kpad / 8 + 1) / 2), dim3(256), 0, stream,
+                       other, K, N, ld_other, T, Kpad);
+    SCVAE_LAUNCH_CHECK("split3_transpose_kernel");
+    splits = cg_splits(mode, M, k_main);
+    int k_chunk = k_main;
+    if (splits > 1) {
+      k_chunk = (k_main + splits - 1) / splits;
+      k_chunk = (k_chunk + CG_BK - 1) / CG_BK * CG_BK;
+      splits = (k_main + k_chunk - 1) / k_chunk;
+    }
+    // a single split with no leftover terms writes C directly (bias and activation included)
+    const bool direct = splits == 1 && k_main == K;
+    float* dst = direct ? C : slabs;
+    const int ldo = direct ? ldc : N;
+    const int NT = (N + 31) / 32;
+    const float* kbias = direct ? bias : nullptr;
+    const int kact = direct ? act : (int)ACT_NONE, kdirect = direct ? 1 : 0;
+    if (mode == 0) {
+      const dim3 grid((M + CF_BM - 1) / CF_BM, splits);
+      const int NQ = NT > 2 ? 2 : 1;
+      const size_t lds = cf_lds_bytes(NQ);
+#define SCVAE_CF(NQ_)                                                                             \
+  do {                                                                                            \
+    auto kfn = count_gemm_fwd_kernel<NQ_>;                                                        \
+    SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, stream, x, ldx, M, k_main, T, Kpad, N, k_chunk, \
+                       dst, ldo, kbias, kact, kdirect);                                           \
+  } while (0)
+      if (NQ == 2) SCVAE_CF(2); else SCVAE_CF(1);
+#undef SCVAE_CF
+    } else {
+      const dim3 grid((M + CG_BM - 1) / CG_BM, splits);
+#define SCVAE_CG(NT_)                                                                             \
+  hipLaunchKernelGGL((count_gemm_kernel<1, NT_>), grid, dim3(512), 0, stream, x, ldx, M, k_main,  \
+                     T, Kpad, N, k_chunk, dst, ldo, kbias, kact, kdirect)
+      switch (NT) { case 1: SCVAE_CG(1); break; case 2: SCVAE_CG(2); break;
+                    case 3: SCVAE_CG(3); break; default: SCVAE_CG(4); }
+#undef SCVAE_CG
+    }
+    SCVAE_LAUNCH_CHECK("count_gemm_kernel");
+    if (direct) return 0;
+  }
+  const size_t total = (size_t)M * N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(count_gemm_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slabs, bias, C,
+                     M, N, ldc, splits, act, mode, x, ldx, other, ld_other, k_main, K);
+  SCVAE_LAUNCH_CHECK("count_gemm_reduce_kernel");
+  return 0;
+}
+
+// ---- precondition check: every value an integer in [0, 65536) ----
+__global__ __launch_bounds__(256) void check_counts_kernel(const float* __restrict__ v, size_t n,
+                                                           int* __restrict__ bad) {
+  int local = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const float x = v[i];
+    if (!(x >= 0.f && x < 65536.f && x == __builtin_truncf(x))) local = 1;
+  }
+  if (__any(local) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
+}
+
+int check_counts(hipStream_t stream, const float* values, size_t n, int* bad) {
+  SCVAE_ARG(bad && (values || n == 0));
+  SCVAE_HIP(hipMemsetAsync(bad, 0, sizeof(int), stream));
+  if (n == 0) return 0;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(check_counts_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, values, n,
+                     bad);
+  SCVAE_LAUNCH_CHECK("check_counts_kernel");
+  return 0;
+}
+
+}  // namespace scvae

@@ -17,6 +17,18 @@ int gemm(hipStream_t stream, bool ta, bool tb, const float* A, const float* B, c
          float* C, int M, int N, int K, int lda, int ldb, int ldc, int act, bool accumulate,
          float* workspace, size_t workspace_bytes);
 
+// ---- count_gemm.hip: the encoder input layer's two large products on a count matrix ----
+// (x integers in [0, 65536): exact bf16 hi/lo cut of x times an exact three-term bf16 split of
+// the fp32 operand, fp32 accumulation)
+// mode 0: C[rows, N] = x[rows, cols] other[cols, N] + bias;  mode 1: C[cols, N] = x^T other[rows, N]
+bool count_gemm_supported(int N);
+size_t count_gemm_workspace_bytes(int mode, int rows, int cols, int N);
+int count_gemm(hipStream_t stream, int mode, const float* x, int ldx, int rows, int cols,
+               const float* other, int ld_other, int N, const float* bias, int act, float* C,
+               int ldc, void* workspace, size_t workspace_bytes);
+// *bad = 1 unless every value is an integer in [0, 65536) (the precondition of count_gemm)
+int check_counts(hipStream_t stream, const float* values, size_t n, int* bad);
+
 // ---- elementwise.hip ----
 struct HeadPtrs {
   float* p[3];

@@ -123,6 +123,11 @@ static size_t carve(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_
     const size_t FC = F * (size_t)(c.k_max + 1);
     track(R, FC, h1); track(h1, FC, R); track(R, h1, FC);
   }
+  {   // products with the count matrix x itself (count_gemm.hip): the layer that sees x
+    const int n_x = p->enc.empty() ? (int)Lz : p->enc[0].n_out;
+    const size_t w = plan_x_gemm_workspace_bytes((int)B, (int)F, n_x);
+    if (w > gws) gws = w;
+  }
   float* gemm_ws = gws ? b.floats(gws / sizeof(float)) : nullptr;
   size_t pmax = col_sum_partial_floats((int)(F > hmax ? F : hmax));
   if (c.k_max > 0) pmax = col_sum_partial_floats((int)(F * (size_t)(c.k_max + 1)));
@@ -166,6 +171,29 @@ float dropout_keep(const scvae_model_config& c, int which) {
   return (k > 0.f && k < 1.f) ? k : 0.f;   // p in {0, 1, False}: no dropout (mu:45)
 }
 
+size_t plan_x_gemm_workspace_bytes(int cells, int features, int n_out) {
+  if (!count_gemm_supported(n_out)) return 0;
+  const size_t f = count_gemm_workspace_bytes(0, cells, features, n_out);
+  const size_t b = count_gemm_workspace_bytes(1, cells, features, n_out);
+  return f > b ? f : b;
+}
+
+int plan_gemm(scvae_plan* p, hipStream_t s, bool ta, bool tb, const float* A, const float* B,
+              const float* bias, float* C, int M, int N, int K, int lda, int ldb, int ldc, int act,
+              bool accumulate) {
+  if (p->x_counts && p->use_count_gemm && A == p->step_x && !tb && !accumulate &&
+      count_gemm_supported(N)) {
+    // x [rows, cols]: forward (x W) contracts over the columns, x^T dA over the rows
+    const int mode = ta ? 1 : 0;
+    const int rows = ta ? K : M, cols = ta ? M : K;
+    if (count_gemm_workspace_bytes(mode, rows, cols, N) <= p->gemm_ws_bytes)
+      return count_gemm(s, mode, A, lda, rows, cols, B, ldb, N, bias, act, C, ldc, p->gemm_ws,
+                        p->gemm_ws_bytes);
+  }
+  return gemm(s, ta, tb, A, B, bias, C, M, N, K, lda, ldb, ldc, act, accumulate, p->gemm_ws,
+              p->gemm_ws_bytes);
+}
+
 int dense_input(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_in, int rows,
                 bool training, const float** in_out, int* ld_out) {
   *in_out = in; *ld_out = ld_in;
@@ -196,11 +224,11 @@ int dense_affine(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld
   const float* W = p->params + d.w;
   const float* bias = p->params + d.b;
   if (!d.bn) {
-    return gemm(s, false, false, in, W, bias, d.h, rows, d.n_out, d.n_in, ld_in, d.n_out, d.n_out,
-                relu ? ACT_RELU : ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes);
+    return plan_gemm(p, s, false, false, in, W, bias, d.h, rows, d.n_out, d.n_in, ld_in, d.n_out,
+                     d.n_out, relu ? ACT_RELU : ACT_NONE, false);
   }
-  int rc = gemm(s, false, false, in, W, bias, d.a, rows, d.n_out, d.n_in, ld_in, d.n_out, d.n_out,
-                ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes);
+  int rc = plan_gemm(p, s, false, false, in, W, bias, d.a, rows, d.n_out, d.n_in, ld_in, d.n_out,
+                     d.n_out, ACT_NONE, false);
   if (rc) return rc;
   const int N = d.n_out;
   if (training) {
@@ -281,8 +309,8 @@ int dense_backward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int 
       return -2;
     }
   }
-  if ((rc = gemm(s, true, false, in, da, nullptr, p->grads + d.w, d.n_in, N, rows, ld_in, N, N,
-                 ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+  if ((rc = plan_gemm(p, s, true, false, in, da, nullptr, p->grads + d.w, d.n_in, N, rows, ld_in, N,
+                      N, ACT_NONE, false)))
     return rc;
   // bias of a batch-normalised layer: the batch mean is subtracted again, its gradient is
   // identically zero (the reference computes rounding noise there); the slot was zeroed at bind
@@ -424,16 +452,16 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const float* h_ls = h;
   int ld_mu = ld, ld_ls = ld;
   if ((rc = dense_input(p, s, mu, h, ld, B, training, &h_mu, &ld_mu))) return rc;
-  if ((rc = gemm(s, false, false, h_mu, p->params + mu.w, p->params + mu.b, p->mu_pre, B, L,
-                 mu.n_in, ld_mu, L, L, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+  if ((rc = plan_gemm(p, s, false, false, h_mu, p->params + mu.w, p->params + mu.b, p->mu_pre, B, L,
+                      mu.n_in, ld_mu, L, L, ACT_NONE, false)))
     return rc;
   const bool mc_kl = (c.latent_mode & 1) != 0;      // va:2633-2640
   const bool unit_var = (c.latent_mode & 2) != 0;   // du:323-337
   const float* ls_pre = unit_var ? nullptr : p->ls_pre;
   if (!unit_var) {
     if ((rc = dense_input(p, s, ls, h, ld, B, training, &h_ls, &ld_ls))) return rc;
-    if ((rc = gemm(s, false, false, h_ls, p->params + ls.w, p->params + ls.b, p->ls_pre, B, L,
-                   ls.n_in, ld_ls, L, L, ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+    if ((rc = plan_gemm(p, s, false, false, h_ls, p->params + ls.w, p->params + ls.b, p->ls_pre, B,
+                        L, ls.n_in, ld_ls, L, L, ACT_NONE, false)))
       return rc;
   }
   if ((rc = gauss_latent_fwd(s, p->mu_pre, ls_pre, a->eps, p->z, p->kl_elem, p->kl_cell,
@@ -600,8 +628,8 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     const float* hq = q == 0 ? h_mu : h_ls;        // the (dropped-out) input of that layer
     const int ldq = q == 0 ? ld_mu : ld_ls;
     const bool drop = hd.keep > 0.f;
-    if ((rc = gemm(s, true, false, hq, dpre, nullptr, p->grads + hd.w, hd.n_in, L, B, ldq, L, L,
-                   ACT_NONE, false, p->gemm_ws, p->gemm_ws_bytes)))
+    if ((rc = plan_gemm(p, s, true, false, hq, dpre, nullptr, p->grads + hd.w, hd.n_in, L, B, ldq,
+                        L, L, ACT_NONE, false)))
       return rc;
     if ((rc = col_sum(s, dpre, L, B, L, p->grads + hd.b, 1.f, 0, p->partial))) return rc;
     if (need_dh) {
@@ -739,6 +767,12 @@ int scvae_plan_set_fused(scvae_plan* p, int32_t enabled) {
   return 0;
 }
 
+int scvae_plan_set_count_gemm(scvae_plan* p, int32_t enabled) {
+  SCVAE_ARG(p);
+  p->use_count_gemm = enabled ? 1 : 0;
+  return 0;
+}
+
 int scvae_plan_set_sync(scvae_plan* p, scvae_sync_fn fn, void* user) {
   SCVAE_ARG(p);
   p->sync = fn; p->sync_user = user;
@@ -803,6 +837,8 @@ int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
   SCVAE_ARG(!(a->training && a->deterministic_z));
   SCVAE_ARG(a->row_offset >= 0 &&
             (a->global_cells <= 0 || a->row_offset + a->cells <= a->global_cells));
+  p->step_x = a->x;
+  p->x_counts = a->x_counts != 0;
   p->drop_seed = a->dropout_seed;
   p->drop_rows = RowMap();
   if (a->global_cells > a->cells) {   // a shard of a data-parallel minibatch
@@ -831,6 +867,23 @@ int scvae_gemm(int32_t ta, int32_t tb, const float* A, const float* B, const flo
   return scvae::gemm((hipStream_t)stream, ta != 0, tb != 0, A, B, bias, C, (int)M, (int)N, (int)K,
                      (int)lda, (int)ldb, (int)ldc, relu ? scvae::ACT_RELU : scvae::ACT_NONE,
                      accumulate != 0, (float*)workspace, (size_t)workspace_bytes);
+}
+int scvae_count_gemm(int32_t mode, const float* x, int64_t ldx, int64_t rows, int64_t cols,
+                     const float* other, int64_t ld_other, int64_t N, const float* bias,
+                     int32_t relu, float* C, int64_t ldc, void* workspace, int64_t workspace_bytes,
+                     void* stream) {
+  SCVAE_ARG(workspace_bytes >= 0);
+  return scvae::count_gemm((hipStream_t)stream, mode, x, (int)ldx, (int)rows, (int)cols, other,
+                           (int)ld_other, (int)N, bias, relu ? scvae::ACT_RELU : scvae::ACT_NONE,
+                           C, (int)ldc, workspace, (size_t)workspace_bytes);
+}
+int64_t scvae_count_gemm_workspace_bytes(int32_t mode, int64_t rows, int64_t cols, int64_t N) {
+  if (!scvae::count_gemm_supported((int)N)) return -1;
+  return (int64_t)scvae::count_gemm_workspace_bytes(mode, (int)rows, (int)cols, (int)N);
+}
+int scvae_check_counts(const float* values, int64_t n, int32_t* bad, void* stream) {
+  SCVAE_ARG(n >= 0);
+  return scvae::check_counts((hipStream_t)stream, values, (size_t)n, bad);
 }
 int64_t scvae_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   return (int64_t)scvae::gemm_workspace_bytes((int)M, (int)N, (int)K);

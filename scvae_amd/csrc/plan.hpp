@@ -142,6 +142,9 @@ struct scvae_plan {
   size_t gw_rows = 0;         //  the constant -1/(MC*B) is only rewritten when it changes)
   float *zcat = nullptr, *dzcat = nullptr;  // [rows, L + E]: decoder input [z | extra] and its gradient
   int use_fused = 1;          // fused decoder head kernel (0 = unfused GEMM + likelihood path)
+  int use_count_gemm = 1;     // exact bf16-split kernels for products with a count matrix x
+  const float* step_x = nullptr;   // this step's x and whether the caller vouches that it holds
+  bool x_counts = false;           //  integers in [0, 65536) (scvae_step_args.x_counts)
   uint64_t drop_seed = 0;     // dropout: this step's mask seed (scvae_step_args.dropout_seed)
   RowMap drop_rows;           // ... and this rank's rows within the global minibatch
   scvae_sync_fn sync = nullptr;
@@ -181,6 +184,12 @@ int dense_input_backward(scvae_plan* p, hipStream_t s, const Dense& d, const flo
                          int rows, bool accumulate);
 float dropout_keep(const scvae_model_config& c, int which);
 int fill(hipStream_t s, float* dst, float v, size_t n);
+// gemm() of kernels.hpp on the plan's workspace; products whose A operand is this step's count
+// matrix x (x W, x^T dA) take count_gemm.hip's exact bf16-split kernels
+int plan_gemm(scvae_plan* p, hipStream_t s, bool ta, bool tb, const float* A, const float* B,
+              const float* bias, float* C, int M, int N, int K, int lda, int ldb, int ldc, int act,
+              bool accumulate);
+size_t plan_x_gemm_workspace_bytes(int cells, int features, int n_out);
 HeadParams head_params(scvae_plan* p);
 int heads_forward(scvae_plan* p, hipStream_t s, const float* dch, int ld, int R, bool training,
                   const float* (&head_in)[4]);

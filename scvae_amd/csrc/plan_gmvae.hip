@@ -146,6 +146,14 @@ size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t
     const size_t FC = F * (size_t)(c.k_max + 1);
     track(R, FC, h1); track(h1, FC, R); track(R, h1, FC);
   }
+  {   // products with the count matrix x itself (count_gemm.hip): q(y|x) and q(z|x,y) layer 1
+    size_t w = plan_x_gemm_workspace_bytes((int)B, (int)F, (int)h1z);
+    if (!p->yenc.empty()) {
+      const size_t wy = plan_x_gemm_workspace_bytes((int)B, (int)F, p->yenc[0].n_out);
+      if (wy > w) w = wy;
+    }
+    if (w > gws) gws = w;
+  }
   float* gemm_ws = gws ? b.floats(gws / sizeof(float)) : nullptr;
   size_t pmax = col_sum_partial_floats((int)(F > hmax ? F : hmax));
   if (c.k_max > 0) pmax = col_sum_partial_floats((int)(F * (size_t)(c.k_max + 1)));
@@ -206,7 +214,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   p->drop_seed = a->dropout_seed;
 #define GEMM(...)                                                              \
   do {                                                                         \
-    if ((rc = gemm(s, __VA_ARGS__, p->gemm_ws, p->gemm_ws_bytes))) return rc;  \
+    if ((rc = plan_gemm(p, s, __VA_ARGS__))) return rc;                        \
   } while (0)
 #define TRY(call)                  \
   do {                             \

@@ -295,6 +295,12 @@ class Engine:
         _lib.check(self.lib.scvae_plan_set_fused(
             self.handle, 1 if enabled else 0), "scvae_plan_set_fused")
 
+    def set_count_gemm(self, enabled):
+        """Allow (default) or forbid the exact bf16-split kernels for the
+        products with a count matrix (``step(..., x_counts=True)``)."""
+        _lib.check(self.lib.scvae_plan_set_count_gemm(
+            self.handle, 1 if enabled else 0), "scvae_plan_set_count_gemm")
+
     def set_sync(self, callback):
         """Install the data-parallel collective hook (see scvae_sync_fn)."""
         if callback is None:
@@ -309,7 +315,7 @@ class Engine:
              n_iw=1, n_mc=1, warm_up_weight=1.0, deterministic_z=False,
              global_cells=None, outputs=None, scalars=None,
              decoder_extra=None, dropout_seed=None, count_sum=None,
-             row_offset=0):
+             row_offset=0, x_counts=False):
         """One graph execution (no host synchronisation).  ``outputs`` maps
         optional output names of ``scvae_step_args`` to preallocated tensors.
         ``dropout_seed``: seed of this training step's dropout masks (default:
@@ -345,6 +351,10 @@ class Engine:
         a.global_cells = global_cells if global_cells else cells
         # data parallel: this rank's first cell within the global minibatch
         a.row_offset = int(row_offset)
+        # the caller vouches that x holds integer counts below 65 536
+        # (DeviceCSR.integer_counts): the input layer's two large products take
+        # the exact bf16-split kernels instead of the fp32 MFMA kernels
+        a.x_counts = 1 if x_counts else 0
         a.n_iw, a.n_mc = n_iw, n_mc
         a.training = 1 if training else 0
         a.deterministic_z = 1 if deterministic_z else 0

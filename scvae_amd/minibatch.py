@@ -37,6 +37,16 @@ class DeviceCSR:
             device=self.device, dtype=torch.float32).contiguous()
         if self.indptr.numel() != self.shape[0] + 1:
             raise ValueError("indptr does not match the number of rows.")
+        # precondition of the exact bf16-split input-layer kernels
+        # (count_gemm.hip): every value an integer in [0, 65536), verified here
+        # once -- preprocessed / noisy matrices fail it and keep the fp32 path
+        self.integer_counts = False
+        if self.values.numel():
+            bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+            _lib.check(self.lib.scvae_check_counts(
+                _ptr(self.values), self.values.numel(), _ptr(bad),
+                current_stream_handle(self.device)), "scvae_check_counts")
+            self.integer_counts = int(bad.item()) == 0
         # data-only term of the count likelihoods: sum_f lgamma(1 + t[b, f])
         self.row_lgamma1p = torch.zeros(
             max(self.shape[0], 1), dtype=torch.float32, device=self.device)

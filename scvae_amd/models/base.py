@@ -515,7 +515,7 @@ class ModelBase:
                     xb, tb, eps=eps, row_const=rc, training=True, n_iw=n_iw,
                     n_mc=n_mc, warm_up_weight=warm_up_weight,
                     global_cells=global_cells, decoder_extra=de,
-                    count_sum=cs,
+                    count_sum=cs, x_counts=x_train.integer_counts,
                     # (the masks are keyed by the global row: the same for any
                     # sharding, like the noise)
                     dropout_seed=((self.noise_seed * 1000003) << 40)
@@ -794,7 +794,7 @@ class ModelBase:
             engine.step(xb, tb, eps=eps, row_const=rc, training=False,
                         n_iw=n_iw, n_mc=n_mc, deterministic_z=deterministic_z,
                         outputs=out, scalars=scalars[j], decoder_extra=de,
-                        count_sum=cs)
+                        count_sum=cs, x_counts=x.integer_counts)
         if sync is not None:
             for tensor in [scalars, kl_neurons, latent] + [
                     v for v in extra.values() if torch.is_tensor(v)]:

@@ -14,7 +14,9 @@ the regime of the small-batch kernels (``dd_reduce_split_kernel``, 128-slab
 split-K); the GMVAE batches keep the fp64 oracle (K passes of the decoder with
 autograd) within seconds.  The count matrix is the benchmark's generator
 (``synthetic_count_matrix``, ~5 % nonzeros) through the production minibatch
-path (device CSR gather + densify + the lgamma row term).
+path (device CSR gather + densify + the lgamma row term), with the input
+layer's two large products on the exact bf16-split kernels (``x_counts``), as
+``model.train`` and ``bench.py`` run them.
 
 Follows va:2560-2734 (VAE loss), gm:3223-3434 (GMVAE loss), va:2736-2770
 (clip + Adam).
@@ -122,7 +124,7 @@ def test_vae_training_step_at_baseline_shape(cuda_device, config, likelihood,
     qz = torch.zeros(B, L, device=cuda_device)
     warm_up = 0.7
     sc = eng.step(x, x, eps=eps.float().to(cuda_device), row_const=row_const,
-                  training=True, warm_up_weight=warm_up,
+                  training=True, warm_up_weight=warm_up, x_counts=True,
                   outputs={"log_p_x_given_z": ll, "kl_neurons": klz,
                            "q_z_mean": qz}).cpu().numpy()
     dev_grads = {k: v.detach().cpu().double()
@@ -183,7 +185,7 @@ def test_gmvae_training_step_at_baseline_shape(cuda_device, config,
     zmean = torch.zeros(B, L, device=cuda_device)
     warm_up = 0.6
     sc = eng.step(x, x, eps=eps.float().to(cuda_device), row_const=row_const,
-                  training=True, warm_up_weight=warm_up,
+                  training=True, warm_up_weight=warm_up, x_counts=True,
                   outputs={"log_p_x_given_z": ll, "q_y_logits": logits,
                            "q_z_mean": zmean}).cpu().numpy()
     dev_grads = {k: v.detach().cpu().double()

@@ -92,6 +92,19 @@ def main():
     print("encoder-1 dW         : {:9.1f} us  {:6.1f} TFLOP/s".format(
         us, 2.0 * R * F * H / us / 1e6))
 
+    # the same two products on the exact bf16-split kernels (count_gemm.hip): HBM-bound
+    # reads of x, priced against the 8 TB/s roof
+    for mode, other, out, label in ((0, W1, y, "forward"), (1, dy, dW1, "dW     ")):
+        cbytes = lib.scvae_count_gemm_workspace_bytes(mode, R, F, H)
+        cws = torch.empty(cbytes + 16, dtype=torch.uint8, device=dev)
+        bias = b1.data_ptr() if mode == 0 else None
+        us = timeit(lambda: _lib.check(lib.scvae_count_gemm(
+            mode, x.data_ptr(), F, R, F, other.data_ptr(), H, H, bias, 0,
+            out.data_ptr(), H, cws.data_ptr(), cbytes, stream), "count_gemm"))
+        print("encoder-1 {} bf16x3-exact: {:9.1f} us  {:6.2f} TB/s of x "
+              "({:.1f}% of 8 TB/s)".format(label, us, 4.0 * R * F / us / 1e6,
+                                           4.0 * R * F / us / 1e6 / 8.0 * 100))
+
 
 if __name__ == "__main__":
     main()
