@@ -129,9 +129,10 @@ int scvae_plan_set_sync(scvae_plan* plan, scvae_sync_fn fn, void* user);
  * 0: separate GEMM and likelihood kernels (same results; kept for A/B tests and for the
  * evaluate-time statistics, which need the materialised pre-activations) */
 int scvae_plan_set_fused(scvae_plan* plan, int32_t enabled);
-/* The exact bf16-split kernels for products with a count matrix (default on; 0: those products
- * take the fp32 MFMA kernels even when scvae_step_args.x_counts is set -- for A/B measurements
- * and the parity test between the two) */
+/* The exact bf16-split kernels for products with a count matrix: 1 (default) where they pay
+ * (minibatches from a few hundred cells upwards, see plan_gemm), 2 always, 0 never -- those
+ * products then take the fp32 MFMA kernels even when scvae_step_args.x_counts is set (A/B
+ * measurements, the parity test between the two) */
 int scvae_plan_set_count_gemm(scvae_plan* plan, int32_t enabled);
 
 /* One graph execution = session.run(...) in the reference loops

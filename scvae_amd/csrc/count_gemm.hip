@@ -18,15 +18,17 @@
 // The caller guarantees the precondition (DeviceCSR verifies integrality and range once, at
 // upload: scvae_csr_check_counts); anything else takes the fp32 MFMA kernels of gemm.hip.
 //
-// Structure (both modes): a workgroup = 8 waves, each owning 64 x-side rows (MODE 0: cells,
-// MODE 1: genes) x all N <= 128 columns (2 x 4 accumulator tiles of v_mfma_f32_32x32x16_bf16).
-// The x-side fragments come straight from global memory into the operand layout (MODE 0: a lane
-// reads 16 consecutive genes of its cell = one 128-byte line per pair of lanes; MODE 1: a lane
-// reads one gene down 16 cells, every load instruction covering two 128-byte row segments), are
-// cut into hi / lo with three VALU instructions per pair, and meet the other operand -- split and
-// transposed to k-contiguous bf16 once per launch by split3_transpose_kernel -- in LDS (80-byte
-// rows: conflict-free ds_read_b128 fragments).  Split-K over the grid, slabs reduced in a fixed
-// order by gemm.hip's reduction kernel (deterministic).
+// Structure: the x-side operand of both products is cut into hi / lo in registers (two or three
+// VALU instructions per pair); the other operand is split and transposed to k-contiguous bf16
+// once per launch (split3_transpose_kernel) and reaches the MFMAs through LDS rows padded by 16
+// bytes (conflict-free ds_read_b128 fragments).  A wave owns 64 x-side rows (two 32-row tiles of
+// v_mfma_f32_32x32x16_bf16) times up to four 32-column tiles.  Forward: the [256, 32] tile of x is
+// read with coalesced 16-byte loads and parked in LDS as bf16 (count_gemm_fwd_kernel); weight
+// gradient: a lane reads its gene down the cells straight into the operand layout
+// (count_gemm_dw_kernel).  Both request x two chunks ahead.  Split-K over the grid, slabs summed
+// in a fixed order (deterministic); the K % chunk leftover terms are added there in fp32.
+#include <type_traits>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -40,12 +42,11 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int CG_NP = 128;            // columns, padded
 constexpr int CG_BK = 32;             // k per chunk (two MFMA k-steps)
 constexpr int CG_ROW = 80;            // LDS bytes per (term, column) row: 64 + 16 pad
-constexpr int CG_WAVES = 8;
 constexpr int CG_TM = 64;             // x-side rows per wave (two 32-row tiles)
-constexpr int CG_BM = CG_WAVES * CG_TM;
 constexpr int CG_KPAD = 64;           // the split operand is zero-padded to a multiple of this
 
 static inline int cg_kpad(int K) { return (K + CG_KPAD - 1) / CG_KPAD * CG_KPAD; }
+static inline int cg_bk(int mode) { return mode == 0 ? 32 : 16; }   // chunk of the mode's kernel
 
 __device__ __forceinline__ unsigned bf16_rne_bits(float v) {
   // round-to-nearest-even to bf16, returned in the low 16 bits (finite inputs)
@@ -90,22 +91,25 @@ __global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __re
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-// MODE 0: out[m, n] = sum_k X[m, k] Wt(k, n)      m: cells (M = B),  k: genes (K = F)
-// MODE 1: out[m, n] = sum_k X[k, m] dAt(k, n)     m: genes (M = F),  k: cells (K = B)
-// out: slabs [gridDim.y][M][N], or (direct) C itself with pitch ldo, bias and activation applied
-// NT: 32-column tiles in use (N <= 32 NT).  Rows / genes past M are clamped to M - 1 (loaded,
-// multiplied, never stored) and K here is a multiple of the chunk (the K % 32 leftover terms are
-// added in fp32 by the reduction kernel), so the loop has no per-lane predicates.
-template <int MODE, int NT>
-__global__ __launch_bounds__(512) void count_gemm_kernel(
+// ---- weight gradient (MODE 1): dW[F, N] = x^T dA ----
+// A lane owns one gene and reads it down the cells of the chunk: every load instruction covers
+// two 128-byte row segments of x (fully coalesced; 5.9 TB/s on its own).  256-thread workgroups
+// (4 waves x 64 genes), two per CU, so that one workgroup's wait for HBM is the other's MFMA
+// phase; chunks of 16 cells (one MFMA k-step), x requested two chunks ahead (static register
+// slots), the split dA operand through LDS (48-byte rows: conflict-free ds_read_b128).
+constexpr int CD_BK = 16;
+constexpr int CD_ROW = 48;            // LDS bytes per (term, column) row: 32 + 16 pad
+constexpr int CD_BM = 256;            // genes per workgroup
+
+template <int NT, bool USE_STEADY = false>
+__global__ __launch_bounds__(256, 2) void count_gemm_dw_kernel(
     const float* __restrict__ X, int ldx, int M, int K, const uint16_t* __restrict__ T, int Kpad,
-    int N, int k_chunk, float* __restrict__ out, int ldo, const float* __restrict__ bias,
-    int act, int direct) {
-  __shared__ __attribute__((aligned(16))) unsigned char Bs[2][3 * CG_NP * CG_ROW];
+    int N, int k_chunk, float* __restrict__ out, int ldo) {
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[2][3 * CG_NP * CD_ROW];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, kg = lane >> 5;
-  const int m_w = blockIdx.x * CG_BM + w * CG_TM;       // first x-side row of this wave
+  const int m_w = blockIdx.x * CD_BM + w * CG_TM;       // first gene of this wave
   const int k_begin = blockIdx.y * k_chunk;
   const int k_end = min(K, k_begin + k_chunk);
 
@@ -117,46 +121,28 @@ __global__ __launch_bounds__(512) void count_gemm_kernel(
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][q][i] = 0.f;
 
-  // ---- x-side loads: raw[t][q], q = 8 s + j  <->  k = kc + 16 kg + 8 s + j ----
-  float raw[2][16];
-  // MODE 0: per-lane row pointers (+ uniform k offset); MODE 1: uniform row pointer (+ per-lane
-  // 32-bit element offset: gene + 16 kg rows)
-  const float* xrow[2];
+  // raw[slot][t][j]  <->  cell kc + 8 kg + j of gene tile t; uniform row pointer + per-lane
+  // 32-bit element offset (gene + 8 kg rows)
+  float raw[2][2][8];
   unsigned xoff[2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int m = min(m_w + 32 * t + li, M - 1);
-    xrow[t] = X + (size_t)m * ldx + 16 * kg;
-    xoff[t] = (unsigned)(16 * kg) * (unsigned)ldx + (unsigned)m;
-  }
-  auto load_x = [&](int kc) {
+  for (int t = 0; t < 2; ++t)
+    xoff[t] = (unsigned)(8 * kg) * (unsigned)ldx + (unsigned)min(m_w + 32 * t + li, M - 1);
+  u32x4 breg[3];
+  auto load_x = [&](int kc, auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      if (MODE == 0) {
-        const float* src = xrow[t] + kc;
+    for (int j = 0; j < 8; ++j) {
+      const float* srow = X + (size_t)(kc + j) * ldx;            // uniform: scalar base
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const f32x4u x4 = *reinterpret_cast<const f32x4u*>(src + 4 * v);
-          raw[t][4 * v] = x4.x; raw[t][4 * v + 1] = x4.y;
-          raw[t][4 * v + 2] = x4.z; raw[t][4 * v + 3] = x4.w;
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const float* srow = X + (size_t)(kc + q) * ldx;      // uniform: scalar base
-          raw[t][q] = srow[xoff[t]];
-        }
-      }
+      for (int t = 0; t < 2; ++t) raw[SLOT][t][j] = srow[xoff[t]];
     }
   };
-
-  // ---- split operand: global -> registers -> LDS (3 x 16 bytes per thread and chunk) ----
-  u32x4 breg[3];
   auto load_b = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int p = tid + 512 * i;                 // 1536 pieces: (term, column, quarter)
-      const int row = p >> 2, part = p & 3;        // row = term * 128 + column
+      const int p = tid + 256 * i;                 // 768 pieces: (term, column, half)
+      const int row = p >> 1, part = p & 1;        // row = term * 128 + column
       if ((row & (CG_NP - 1)) < NT * 32)
         breg[i] = *reinterpret_cast<const u32x4*>(T + (size_t)row * Kpad + kc + part * 8);
     }
@@ -164,122 +150,119 @@ __global__ __launch_bounds__(512) void count_gemm_kernel(
   auto store_b = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int p = tid + 512 * i;
-      const int row = p >> 2, part = p & 3;
+      const int p = tid + 256 * i;
+      const int row = p >> 1, part = p & 1;
       if ((row & (CG_NP - 1)) < NT * 32)
-        *reinterpret_cast<u32x4*>(&Bs[buf][row * CG_ROW + part * 16]) = breg[i];
+        *reinterpret_cast<u32x4*>(&Bs[buf][row * CD_ROW + part * 16]) = breg[i];
     }
   };
 
   if (k_begin < k_end) {
-    load_x(k_begin);
+    load_x(k_begin, std::integral_constant<int, 0>{});
+    if (k_begin + CD_BK < k_end) load_x(k_begin + CD_BK, std::integral_constant<int, 1>{});
     load_b(k_begin);
     store_b(0);
   }
   __syncthreads();
 
-  // B fragment (term, tile q, k-step s) of the current buffer
-  const int frag_off = li * CG_ROW + 32 * kg;
-  auto bfrag = [&](const unsigned char* bcur, int term, int q, int s) {
-    return as_bf16x8(*reinterpret_cast<const u32x4*>(
-        bcur + (term * CG_NP + q * 32) * CG_ROW + frag_off + 16 * s));
-  };
-
-  int buf = 0;
-  for (int kc = k_begin; kc < k_end; kc += CG_BK) {
+  const int frag_off = li * CD_ROW + 16 * kg;
+  // STEADY (compile time): chunks j + 1 and j + 2 exist -- requests and hand-over unconditional
+  // (see count_gemm_fwd_kernel).  Measured on this kernel the unconditional loop is SLOWER (178 vs
+  // 155 us at 4096 x 32 738: both x chunks then really stay in flight, the kernel sits at 256
+  // VGPRs and the deeper queue does not pay), so USE_STEADY defaults to off here.
+  auto chunk = [&](int kc, auto buf_tag, auto steady_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;        // LDS buffer and x slot of this chunk
+    constexpr bool STEADY = decltype(steady_tag)::value;
     // ---- cut the counts of this chunk into hi / lo bf16 fragments ----
-    u32x4 ahi[2][2];
+    u32x4 ahi[2], alo[2];
     unsigned low_bits = 0u;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+      unsigned h[4];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        unsigned h[4];
-#pragma unroll
-        for (int pr = 0; pr < 4; ++pr) {
-          const unsigned u0 = __float_as_uint(raw[t][8 * s + 2 * pr]);
-          const unsigned u1 = __float_as_uint(raw[t][8 * s + 2 * pr + 1]);
-          low_bits |= u0 | u1;
-          h[pr] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);        // upper halves
-        }
-        ahi[t][s] = u32x4{h[0], h[1], h[2], h[3]};
+      for (int pr = 0; pr < 4; ++pr) {
+        const unsigned u0 = __float_as_uint(raw[BUF][t][2 * pr]);
+        const unsigned u1 = __float_as_uint(raw[BUF][t][2 * pr + 1]);
+        low_bits |= u0 | u1;
+        h[pr] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);          // upper halves
       }
-    // more than 8 significant bits anywhere in this wave's 64 x 32 block of x? (wave-uniform)
+      ahi[t] = u32x4{h[0], h[1], h[2], h[3]};
+    }
     const bool need_lo =
         __builtin_amdgcn_readfirstlane(__any((int)((low_bits & 0xFFFFu) != 0u)));
-    u32x4 alo[2][2];
     if (need_lo) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t) {
+        unsigned l[4];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          unsigned l[4];
-#pragma unroll
-          for (int pr = 0; pr < 4; ++pr) {
-            const float x0 = raw[t][8 * s + 2 * pr], x1 = raw[t][8 * s + 2 * pr + 1];
-            const float l0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u);
-            const float l1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
-            l[pr] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
-          }
-          alo[t][s] = u32x4{l[0], l[1], l[2], l[3]};
+        for (int pr = 0; pr < 4; ++pr) {
+          const float x0 = raw[BUF][t][2 * pr], x1 = raw[BUF][t][2 * pr + 1];
+          const float l0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u);
+          const float l1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
+          l[pr] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
         }
+        alo[t] = u32x4{l[0], l[1], l[2], l[3]};
+      }
     }
+    // ---- requests: x two chunks ahead (the slot just converted), dA one chunk ahead ----
+    if (STEADY || kc + 2 * CD_BK < k_end) load_x(kc + 2 * CD_BK, buf_tag);
+    const bool has_next = STEADY || kc + CD_BK < k_end;
+    if (has_next) load_b(kc + CD_BK);
 
-    // ---- next chunk in flight under the MFMAs ----
-    const bool has_next = kc + CG_BK < k_end;
-    if (has_next) {
-      load_x(kc + CG_BK);
-      load_b(kc + CG_BK);
-    }
-
-    // ---- MFMAs: per (k-step, term) the NT fragments of the split operand, then 2 NT MFMAs;
-    //      smallest term first (fp32 accumulation) ----
-    const unsigned char* bcur = Bs[buf];
+    const unsigned char* bcur = Bs[BUF] + frag_off;
 #pragma unroll
-    for (int step = 0; step < 6; ++step) {
-      const int s = step / 3, term = 2 - step % 3;
+    for (int term = 2; term >= 0; --term) {              // smallest term first
       bf16x8 fr[NT];
 #pragma unroll
-      for (int q = 0; q < NT; ++q) fr[q] = bfrag(bcur, term, q, s);
+      for (int q = 0; q < NT; ++q)
+        fr[q] = as_bf16x8(*reinterpret_cast<const u32x4*>(
+            bcur + (term * CG_NP + q * 32) * CD_ROW));
       if (need_lo) {
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
-          acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(alo[0][s]), fr[q],
-                                                              acc[0][q], 0, 0, 0);
-          acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(alo[1][s]), fr[q],
-                                                              acc[1][q], 0, 0, 0);
+          acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(alo[0]), fr[q], acc[0][q],
+                                                              0, 0, 0);
+          acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(alo[1]), fr[q], acc[1][q],
+                                                              0, 0, 0);
         }
       }
 #pragma unroll
       for (int q = 0; q < NT; ++q) {
-        acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ahi[0][s]), fr[q],
-                                                            acc[0][q], 0, 0, 0);
-        acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ahi[1][s]), fr[q],
-                                                            acc[1][q], 0, 0, 0);
+        acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ahi[0]), fr[q], acc[0][q], 0,
+                                                            0, 0);
+        acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ahi[1]), fr[q], acc[1][q], 0,
+                                                            0, 0);
       }
     }
-    if (has_next) store_b(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
+    if (has_next) store_b(BUF ^ 1);
+    lds_barrier();       // (LDS only: the x requests stay in flight across it)
+  };
+  {
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    int kc = k_begin;
+    if (USE_STEADY)
+    for (; kc + 3 * CD_BK < k_end; kc += 2 * CD_BK) {   // chunks j, j + 1 with j + 3 in range
+      chunk(kc, B0{}, std::true_type{});
+      chunk(kc + CD_BK, B1{}, std::true_type{});
+    }
+    for (; kc < k_end; kc += 2 * CD_BK) {               // the last one to three chunks
+      chunk(kc, B0{}, std::false_type{});
+      if (kc + CD_BK < k_end) chunk(kc + CD_BK, B1{}, std::false_type{});
+    }
   }
 
-  // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
-  float* dst = direct ? out : out + (size_t)blockIdx.y * M * ldo;
+  float* dst = out + (size_t)blockIdx.y * M * ldo;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
       const int col = q * 32 + li;
       if (col >= N) continue;
-      const float bv = (direct && bias != nullptr) ? bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m_w + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kg;
-        if (m < M) {
-          float v = acc[t][q][r] + bv;
-          if (direct && act == ACT_RELU) v = fmaxf(v, 0.f);
-          dst[(size_t)m * ldo + col] = v;
-        }
+        if (m < M) dst[(size_t)m * ldo + col] = acc[t][q][r];
       }
     }
 }
@@ -342,26 +325,29 @@ __global__ __launch_bounds__(512) void count_gemm_fwd_kernel(
     xsrc[i] = X + (size_t)m * ldx + 4 * part;
   }
   const int a_off = (tid >> 3) * CG_ROW + part * 8;     // + i * 64 rows
-  f32x4u raw[4];
-  u32x4 breg[3];
-  auto load_tiles = [&](int kc) {
+  // two chunks of staging registers: chunk c + 2 is requested while chunk c is multiplied and
+  // chunk c + 1 (requested one iteration earlier) is converted and parked -- a full iteration
+  // plus the MFMA phase of latency tolerance with a single workgroup per CU
+  f32x4u raw[2][4];
+  u32x4 breg[2][3];
+  auto load_tiles = [&](int kc, int slot) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) raw[i] = *reinterpret_cast<const f32x4u*>(xsrc[i] + kc);
+    for (int i = 0; i < 4; ++i) raw[slot][i] = *reinterpret_cast<const f32x4u*>(xsrc[i] + kc);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int p = tid + 512 * i;                      // (term, column, quarter)
       const int row = p >> 2, prt = p & 3;              // row = term * 128 + column
       if ((row & (CG_NP - 1)) < NCOL)
-        breg[i] = *reinterpret_cast<const u32x4*>(T + (size_t)row * Kpad + kc + prt * 8);
+        breg[slot][i] = *reinterpret_cast<const u32x4*>(T + (size_t)row * Kpad + kc + prt * 8);
     }
   };
-  bool dirty[2] = {false, false};                       // this wave's lo rows of buffer b are set
-  auto store_tiles = [&](int buf) {
+  bool dirty0 = false, dirty1 = false;                  // this wave's lo rows of buffer b are set
+  auto store_tiles = [&](int buf, int slot) {
     unsigned low = 0u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const unsigned u0 = __float_as_uint(raw[i].x), u1 = __float_as_uint(raw[i].y);
-      const unsigned u2 = __float_as_uint(raw[i].z), u3 = __float_as_uint(raw[i].w);
+      const unsigned u0 = __float_as_uint(raw[slot][i].x), u1 = __float_as_uint(raw[slot][i].y);
+      const unsigned u2 = __float_as_uint(raw[slot][i].z), u3 = __float_as_uint(raw[slot][i].w);
       low |= u0 | u1 | u2 | u3;
       uint2 h;
       h.x = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
@@ -369,20 +355,20 @@ __global__ __launch_bounds__(512) void count_gemm_fwd_kernel(
       *reinterpret_cast<uint2*>(Ahi + buf * CF_A_BYTES + a_off + i * 64 * CG_ROW) = h;
     }
     const bool need = __builtin_amdgcn_readfirstlane(__any((int)((low & 0xFFFFu) != 0u)));
-    if (need || dirty[buf]) {
+    if (need || (buf ? dirty1 : dirty0)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float l0 = raw[i].x - __uint_as_float(__float_as_uint(raw[i].x) & 0xFFFF0000u);
-        const float l1 = raw[i].y - __uint_as_float(__float_as_uint(raw[i].y) & 0xFFFF0000u);
-        const float l2 = raw[i].z - __uint_as_float(__float_as_uint(raw[i].z) & 0xFFFF0000u);
-        const float l3 = raw[i].w - __uint_as_float(__float_as_uint(raw[i].w) & 0xFFFF0000u);
+        const float l0 = raw[slot][i].x - __uint_as_float(__float_as_uint(raw[slot][i].x) & 0xFFFF0000u);
+        const float l1 = raw[slot][i].y - __uint_as_float(__float_as_uint(raw[slot][i].y) & 0xFFFF0000u);
+        const float l2 = raw[slot][i].z - __uint_as_float(__float_as_uint(raw[slot][i].z) & 0xFFFF0000u);
+        const float l3 = raw[slot][i].w - __uint_as_float(__float_as_uint(raw[slot][i].w) & 0xFFFF0000u);
         uint2 l;
         l.x = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
         l.y = __builtin_amdgcn_perm(__float_as_uint(l3), __float_as_uint(l2), 0x07060302u);
         *reinterpret_cast<uint2*>(Alo + buf * CF_A_BYTES + a_off + i * 64 * CG_ROW) = l;
       }
     }
-    dirty[buf] = need;
+    if (buf) dirty1 = need; else dirty0 = need;
     if (lane == 0) lo_flag[buf * 8 + w] = need ? 1 : 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -391,29 +377,37 @@ __global__ __launch_bounds__(512) void count_gemm_fwd_kernel(
       const int term = row >> 7, col = row & (CG_NP - 1);
       if (col < NCOL)
         *reinterpret_cast<u32x4*>(Bsm + buf * B_BYTES + (term * NCOL + col) * CG_ROW + prt * 16) =
-            breg[i];
+            breg[slot][i];
     }
   };
 
   __syncthreads();                                      // lo planes zeroed
   if (k_begin < k_end) {
-    load_tiles(k_begin);
-    store_tiles(0);
+    load_tiles(k_begin, 0);
+    if (k_begin + CG_BK < k_end) load_tiles(k_begin + CG_BK, 1);
+    store_tiles(0, 0);
   }
   __syncthreads();
 
   const int a_frag = (64 * rg + li) * CG_ROW + 32 * kg;      // + 32 rows * t, + 16 s
   const int b_frag = (q0 * 32 + li) * CG_ROW + 32 * kg;      // + term * NCOL rows, + 32 rows * q
-  int buf = 0;
-  for (int kc = k_begin; kc < k_end; kc += CG_BK) {
-    const bool has_next = kc + CG_BK < k_end;
-    if (has_next) load_tiles(kc + CG_BK);               // in flight under the MFMAs
+  // one chunk; BUF (compile time: the staging registers are indexed statically) = LDS buffer and
+  // staging slot of chunk j = j & 1
+  // STEADY (compile time): chunks j + 1 and j + 2 exist, so the request and the hand-over are
+  // unconditional -- with conditions the compiler cannot pair them up and waits for every
+  // outstanding load at the loop header, which cancels the second chunk of latency tolerance
+  auto chunk = [&](int kc, auto buf_tag, auto steady_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    constexpr bool STEADY = decltype(steady_tag)::value;
+    // chunk j + 2 -> staging slot BUF (chunk j left it for LDS before this iteration)
+    if (STEADY || kc + 2 * CG_BK < k_end) load_tiles(kc + 2 * CG_BK, BUF);
+    __builtin_amdgcn_sched_barrier(0);
 
     const bool need_lo =
-        __builtin_amdgcn_readfirstlane(__any(lo_flag[buf * 8 + (lane & 7)]));
-    const unsigned char* ah = Ahi + buf * CF_A_BYTES + a_frag;
-    const unsigned char* al = Alo + buf * CF_A_BYTES + a_frag;
-    const unsigned char* bb = Bsm + buf * B_BYTES + b_frag;
+        __builtin_amdgcn_readfirstlane(__any(lo_flag[BUF * 8 + (lane & 7)]));
+    const unsigned char* ah = Ahi + BUF * CF_A_BYTES + a_frag;
+    const unsigned char* al = Alo + BUF * CF_A_BYTES + a_frag;
+    const unsigned char* bb = Bsm + BUF * B_BYTES + b_frag;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 fh[2], fl[2];
@@ -446,9 +440,24 @@ __global__ __launch_bounds__(512) void count_gemm_fwd_kernel(
         }
       }
     }
-    if (has_next) store_tiles(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
+    // chunk j + 1 (requested one iteration ago, staging slot BUF ^ 1) -> LDS buffer BUF ^ 1
+    // (scheduling fence: the conversion and its wait for the loads stay below the MFMAs)
+    __builtin_amdgcn_sched_barrier(0);
+    if (STEADY || kc + CG_BK < k_end) store_tiles(BUF ^ 1, BUF ^ 1);
+    lds_barrier();       // (LDS only: the requests for chunk j + 2 stay in flight across it)
+  };
+  {
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    int kc = k_begin;
+    for (; kc + 3 * CG_BK < k_end; kc += 2 * CG_BK) {   // chunks j, j + 1 with j + 3 in range
+      chunk(kc, B0{}, std::true_type{});
+      chunk(kc + CG_BK, B1{}, std::true_type{});
+    }
+    for (; kc < k_end; kc += 2 * CG_BK) {               // the last one to three chunks
+      chunk(kc, B0{}, std::false_type{});
+      if (kc + CG_BK < k_end) chunk(kc + CG_BK, B1{}, std::false_type{});
+    }
   }
 
   float* dst = direct ? out : out + (size_t)blockIdx.y * M * ldo;
@@ -494,9 +503,10 @@ __global__ __launch_bounds__(256) void count_gemm_reduce_kernel(
 }
 
 static int cg_splits(int mode, int M, int K) {
-  const int bm = mode == 0 ? CF_BM : CG_BM;
+  const int bm = mode == 0 ? CF_BM : CD_BM;
   const long blocks = (M + bm - 1) / bm;
-  long want = (256 + blocks - 1) / blocks;           // one workgroup per CU in total
+  const long target = mode == 0 ? 256 : 512;         // workgroups per CU: forward 1, dW 2
+  long want = (target + blocks - 1) / blocks;
   const long max_by_k = K / 256 > 0 ? K / 256 : 1;   // at least 8 chunks per split
   long s = want < max_by_k ? want : max_by_k;
   if (s < 1) s = 1;
@@ -512,7 +522,7 @@ size_t count_gemm_workspace_bytes(int mode, int rows, int cols, int N) {
   if (!count_gemm_supported(N)) return 0;
   const int M = mode == 0 ? rows : cols, K = mode == 0 ? cols : rows;
   const size_t t_bytes = (size_t)3 * CG_NP * cg_kpad(K) * sizeof(uint16_t);
-  const int splits = cg_splits(mode, M, K / CG_BK * CG_BK);
+  const int splits = cg_splits(mode, M, K / cg_bk(mode) * cg_bk(mode));
   return (t_bytes + 255) / 256 * 256 + (size_t)splits * M * N * sizeof(float);
 }
 
@@ -526,7 +536,8 @@ int count_gemm(hipStream_t stream, int mode, const float* x, int ldx, int rows, 
   SCVAE_ARG(workspace_bytes >= count_gemm_workspace_bytes(mode, rows, cols, N));
   SCVAE_ARG(((uintptr_t)workspace & 15) == 0);
   const int M = mode == 0 ? rows : cols, K = mode == 0 ? cols : rows;
-  const int k_main = K / CG_BK * CG_BK;      // whole chunks: matrix cores; the rest: reduction
+  const int bk = cg_bk(mode);
+  const int k_main = K / bk * bk;            // whole chunks: matrix cores; the rest: reduction
   const int Kpad = cg_kpad(K);
   uint16_t* T = reinterpret_cast<uint16_t*>(workspace);
   const size_t t_bytes = ((size_t)3 * CG_NP * Kpad * sizeof(uint16_t) + 255) / 256 * 256;
@@ -540,11 +551,11 @@ int count_gemm(hipStream_t stream, int mode, const float* x, int ldx, int rows, 
     int k_chunk = k_main;
     if (splits > 1) {
       k_chunk = (k_main + splits - 1) / splits;
-      k_chunk = (k_chunk + CG_BK - 1) / CG_BK * CG_BK;
+      k_chunk = (k_chunk + bk - 1) / bk * bk;
       splits = (k_main + k_chunk - 1) / k_chunk;
     }
     // a single split with no leftover terms writes C directly (bias and activation included)
-    const bool direct = splits == 1 && k_main == K;
+    const bool direct = mode == 0 && splits == 1 && k_main == K;
     float* dst = direct ? C : slabs;
     const int ldo = direct ? ldc : N;
     const int NT = (N + 31) / 32;
@@ -565,13 +576,13 @@ int count_gemm(hipStream_t stream, int mode, const float* x, int ldx, int rows, 
       if (NQ == 2) SCVAE_CF(2); else SCVAE_CF(1);
 #undef SCVAE_CF
     } else {
-      const dim3 grid((M + CG_BM - 1) / CG_BM, splits);
-#define SCVAE_CG(NT_)                                                                             \
-  hipLaunchKernelGGL((count_gemm_kernel<1, NT_>), grid, dim3(512), 0, stream, x, ldx, M, k_main,  \
-                     T, Kpad, N, k_chunk, dst, ldo, kbias, kact, kdirect)
-      switch (NT) { case 1: SCVAE_CG(1); break; case 2: SCVAE_CG(2); break;
-                    case 3: SCVAE_CG(3); break; default: SCVAE_CG(4); }
-#undef SCVAE_CG
+      const dim3 grid((M + CD_BM - 1) / CD_BM, splits);
+#define SCVAE_CD(NT_)                                                                             \
+  hipLaunchKernelGGL((count_gemm_dw_kernel<NT_>), grid, dim3(256), 0, stream, x, ldx, M, k_main,  \
+                     T, Kpad, N, k_chunk, dst, ldo)
+      switch (NT) { case 1: SCVAE_CD(1); break; case 2: SCVAE_CD(2); break;
+                    case 3: SCVAE_CD(3); break; default: SCVAE_CD(4); }
+#undef SCVAE_CD
     }
     SCVAE_LAUNCH_CHECK("count_gemm_kernel");
     if (direct) return 0;

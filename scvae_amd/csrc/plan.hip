@@ -186,7 +186,12 @@ int plan_gemm(scvae_plan* p, hipStream_t s, bool ta, bool tb, const float* A, co
     // x [rows, cols]: forward (x W) contracts over the columns, x^T dA over the rows
     const int mode = ta ? 1 : 0;
     const int rows = ta ? K : M, cols = ta ? M : K;
-    if (count_gemm_workspace_bytes(mode, rows, cols, N) <= p->gemm_ws_bytes)
+    // the split kernels carry a fixed cost (the split / transpose of the fp32 operand, the
+    // slab reduction): measured against the fp32 MFMA kernels at 32 738 genes they win from
+    // ~600 cells (forward) / ~300 cells (weight gradient) upwards
+    const bool pays = p->use_count_gemm >= 2 ||
+                      ((double)rows * cols >= (mode == 0 ? 768.0 : 384.0) * 32768.0);
+    if (pays && count_gemm_workspace_bytes(mode, rows, cols, N) <= p->gemm_ws_bytes)
       return count_gemm(s, mode, A, lda, rows, cols, B, ldb, N, bias, act, C, ldc, p->gemm_ws,
                         p->gemm_ws_bytes);
   }
@@ -769,7 +774,8 @@ int scvae_plan_set_fused(scvae_plan* p, int32_t enabled) {
 
 int scvae_plan_set_count_gemm(scvae_plan* p, int32_t enabled) {
   SCVAE_ARG(p);
-  p->use_count_gemm = enabled ? 1 : 0;
+  SCVAE_ARG(enabled >= 0 && enabled <= 2);
+  p->use_count_gemm = enabled;
   return 0;
 }
 

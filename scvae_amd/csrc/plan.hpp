@@ -142,7 +142,8 @@ struct scvae_plan {
   size_t gw_rows = 0;         //  the constant -1/(MC*B) is only rewritten when it changes)
   float *zcat = nullptr, *dzcat = nullptr;  // [rows, L + E]: decoder input [z | extra] and its gradient
   int use_fused = 1;          // fused decoder head kernel (0 = unfused GEMM + likelihood path)
-  int use_count_gemm = 1;     // exact bf16-split kernels for products with a count matrix x
+  int use_count_gemm = 1;     // exact bf16-split kernels for products with a count matrix x:
+                              // 0 never, 1 where they pay (plan_gemm), 2 always
   const float* step_x = nullptr;   // this step's x and whether the caller vouches that it holds
   bool x_counts = false;           //  integers in [0, 65536) (scvae_step_args.x_counts)
   uint64_t drop_seed = 0;     // dropout: this step's mask seed (scvae_step_args.dropout_seed)

@@ -295,11 +295,13 @@ class Engine:
         _lib.check(self.lib.scvae_plan_set_fused(
             self.handle, 1 if enabled else 0), "scvae_plan_set_fused")
 
-    def set_count_gemm(self, enabled):
-        """Allow (default) or forbid the exact bf16-split kernels for the
-        products with a count matrix (``step(..., x_counts=True)``)."""
-        _lib.check(self.lib.scvae_plan_set_count_gemm(
-            self.handle, 1 if enabled else 0), "scvae_plan_set_count_gemm")
+    def set_count_gemm(self, enabled, always=False):
+        """The exact bf16-split kernels for the products with a count matrix
+        (``step(..., x_counts=True)``): where they pay (default: minibatches
+        from a few hundred cells upwards), ``always``, or never."""
+        mode = (2 if always else 1) if enabled else 0
+        _lib.check(self.lib.scvae_plan_set_count_gemm(self.handle, mode),
+                   "scvae_plan_set_count_gemm")
 
     def set_sync(self, callback):
         """Install the data-parallel collective hook (see scvae_sync_fn)."""

@@ -110,6 +110,7 @@ def test_vae_training_step_at_baseline_shape(cuda_device, config, likelihood,
     B, F, L = cells, features, latent
     eng = Engine(F, L, H, likelihood, batch_norm=True, device=cuda_device,
                  seed=0)
+    eng.set_count_gemm(True, always=True)   # (also at B = 100, below the auto threshold)
     _perturb(eng, 1)
     x, row_const = _minibatch(cuda_device, B, F, seed=60)
     rng = np.random.default_rng(7)
@@ -171,6 +172,7 @@ def test_gmvae_training_step_at_baseline_shape(cuda_device, config,
     B, F, L, K = 16, features, 100, 20
     eng = Engine(F, L, H, likelihood, batch_norm=True, model_type="GMVAE",
                  n_clusters=K, device=cuda_device, seed=0)
+    eng.set_count_gemm(True, always=True)
     _perturb(eng, 2)
     x, row_const = _minibatch(cuda_device, B, F, seed=61)
     rng = np.random.default_rng(8)

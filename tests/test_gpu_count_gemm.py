@@ -198,7 +198,7 @@ def test_training_step_with_and_without_the_count_kernels(cuda_device,
     rows = B if model_type == "VAE" else K * B
     results = []
     for enabled in (True, False):
-        eng.set_count_gemm(enabled)
+        eng.set_count_gemm(enabled, always=True)   # (B = 200 is below the auto threshold)
         ll = torch.zeros(rows, device=cuda_device)
         scalars = eng.step(x, x, eps=eps, training=True, x_counts=True,
                            outputs={"log_p_x_given_z": ll}).clone()
