@@ -16,8 +16,13 @@ per optimiser step there is
   ``[sum dA | sum dA*xhat]`` in the backward pass, so that the result equals
   single-process batch norm over the whole minibatch (sync batch norm).
 
-The collective logic is backend-agnostic: ``tests/test_dataparallel_cpu.py``
-drives it with ``gloo`` and the oracle as compute stand-in.
+Tests: ``tests/test_dataparallel_cpu.py`` (gloo, world size 2, no GPU) covers
+``shard_bounds``, ``merge_batch_norm_statistics`` and the same sequence of
+collectives with plain fp64 torch as the compute stand-in;
+``GradientSynchroniser`` itself is driven by ``tests/test_gpu_dataparallel.py``
+(two ranks on one GPU with the real kernels, gloo moving the bytes, and a
+single-rank RCCL group).  RCCL between several physical GPUs is only run by the
+driver's scaling benchmark.
 """
 
 import ctypes

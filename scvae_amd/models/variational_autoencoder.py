@@ -29,13 +29,17 @@ class VariationalAutoencoder(ModelBase):
             encoder (the decoder uses them in reverse order).
         reconstruction_distribution (str, optional): Name of the likelihood
             (``poisson``, ``negative binomial``, ``zero-inflated poisson``,
-            ``zero-inflated negative binomial``).
+            ``zero-inflated negative binomial``, ``constrained poisson``,
+            ``bernoulli``).
         number_of_reconstruction_classes (int, optional): Piecewise
-            categorical classes (``-k``); only 0 is built here.
-        latent_distribution (str, optional): ``gaussian``.
+            categorical classes (``-k``): counts below k are classes of an
+            extra ``P_K`` head (Poisson / negative binomial base, va:2507-2532).
+        latent_distribution (str, optional): ``gaussian`` or
+            ``unit-variance gaussian``.
         minibatch_normalisation (bool, optional): Batch normalisation of the
             hidden layers.
-        batch_correction, number_of_batches: not built (must be falsy).
+        batch_correction (bool, optional), number_of_batches (int): one-hot
+            batch indices appended to the decoder input (va:2407-2441).
         number_of_warm_up_epochs (int, optional): Linear KL warm-up.
         log_directory (str, optional): Where checkpoints and scalars go.
         kwargs: ``parameterise_latent_posterior``, ``analytical_kl_term``,

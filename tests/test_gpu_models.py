@@ -340,3 +340,46 @@ def test_sample_from_trained_model(tmp_path, cuda_device, capsys, model_type):
         z = torch.from_numpy(np.asarray(latent["z"].values, np.float32))
         again = model.engine.decode(z.to(cuda_device)).cpu().numpy()
         assert np.allclose(again, reconstruction.values, rtol=1e-5, atol=1e-6)
+
+
+def test_initial_values_are_the_tf_contrib_defaults(cuda_device):
+    """Row a17: ``tf.contrib.layers.fully_connected``
+    initialises weights Glorot-uniform -- U(-l, l) with l = sqrt(6 / (n_in +
+    n_out)) -- and biases to zero; ``batch_norm(center=True, scale=False)``
+    creates beta = 0, moving_mean = 0, moving_variance = 1; Adam slots start
+    at zero (mu:53-70, va:2742)."""
+    import math
+    from scvae_amd.engine import Engine
+    for model_type in ("VAE", "GMVAE"):
+        eng = Engine(3000, 12, (64, 48), "zero-inflated negative binomial",
+                     batch_norm=True, model_type=model_type, n_clusters=5,
+                     device=cuda_device, seed=7)
+        for name, p in eng.named_parameters().items():
+            if name.endswith("weights"):
+                n_in, n_out = p.shape
+                limit = math.sqrt(6.0 / (n_in + n_out))
+                assert p.abs().max().item() <= limit * (1 + 1e-6), name
+                if p.numel() >= 2000:
+                    # a uniform law on (-l, l): mean 0, variance l^2 / 3, and
+                    # the extremes come close to the bound
+                    assert abs(p.mean().item()) < 4 * limit / math.sqrt(
+                        3 * p.numel()), name
+                    assert abs(p.var().item() / (limit ** 2 / 3) - 1) < 0.1, name
+                    assert p.abs().max().item() > 0.97 * limit, name
+            else:   # biases, beta (and the learnable prior logits): zeros
+                assert p.abs().max().item() == 0.0, name
+        for name, m in eng.named_moving_statistics().items():
+            want = 1.0 if name.endswith("moving_variance") else 0.0
+            assert torch.all(m == want), name
+        assert eng.adam_m.abs().max().item() == 0.0
+        assert eng.adam_v.abs().max().item() == 0.0
+        assert eng.adam_t == 0
+        # the same seed gives the same weights, another seed does not
+        again = Engine(3000, 12, (64, 48), "zero-inflated negative binomial",
+                       batch_norm=True, model_type=model_type, n_clusters=5,
+                       device=cuda_device, seed=7)
+        other = Engine(3000, 12, (64, 48), "zero-inflated negative binomial",
+                       batch_norm=True, model_type=model_type, n_clusters=5,
+                       device=cuda_device, seed=8)
+        assert torch.equal(again.params, eng.params)
+        assert not torch.equal(other.params, eng.params)
