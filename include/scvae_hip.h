@@ -134,6 +134,12 @@ int scvae_plan_set_fused(scvae_plan* plan, int32_t enabled);
  * products then take the fp32 MFMA kernels even when scvae_step_args.x_counts is set (A/B
  * measurements, the parity test between the two) */
 int scvae_plan_set_count_gemm(scvae_plan* plan, int32_t enabled);
+/* One-launch batch norm (statistics + normalise, backward sums + gradient in a single
+ * column-parallel kernel each) for single-group layers: 1 (default) for minibatches of up to 1024
+ * rows, where it pays; 2 whenever it applies (<= 8192 rows); 0 never -- always the chunked
+ * statistics / finalize / apply kernels (the two implementations are compared in
+ * tests/test_gpu_vae_step.py) */
+int scvae_plan_set_bn_one_launch(scvae_plan* plan, int32_t enabled);
 
 /* One graph execution = session.run(...) in the reference loops
  * (train step va:1026-1029 / gm:1094-1097; evaluation va:1124-1135, 1983-2014).

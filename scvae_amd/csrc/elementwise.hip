@@ -1021,6 +1021,195 @@ int bn_bwd_apply(hipStream_t stream, const float* dh, int lddh, const float* h, 
   return 0;
 }
 
+// ---- one-launch batch norm for tensors of a few thousand rows (column-parallel) ----
+// The statistics of batch norm are per column, so a workgroup that owns FOUR columns and ALL rows
+// needs nobody else: it loads its [rows, 4] slab once (one float4 per row and thread, kept in
+// registers), reduces it twice (mean, centred second moment), and writes the normalised
+// activations -- statistics + finalize + apply in one launch instead of three (forward), and the
+// backward sums + dbeta + moving-average update + gradient in one instead of three.  N / 4
+// workgroups of 1024 threads, up to BNC_RPT rows per thread.  Fixed reduction order
+// (wave shuffles, then the 16 wave sums in sequence): deterministic.  Used for small minibatches
+// (bn_cols_pays) when there is one group, no data-parallel exchange between the statistics and
+// their use, and the layout is 16-byte friendly; everything else takes the chunked kernels above.
+constexpr int BNC_RPT = 8;
+constexpr int BNC_THREADS = 1024;
+
+__device__ __forceinline__ float4 bnc_block_sum(float4 v, float4* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    v.x += __shfl_xor(v.x, off, WAVE); v.y += __shfl_xor(v.y, off, WAVE);
+    v.z += __shfl_xor(v.z, off, WAVE); v.w += __shfl_xor(v.w, off, WAVE);
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float4 s = red[0];
+#pragma unroll
+  for (int i = 1; i < BNC_THREADS / 64; ++i) {
+    s.x += red[i].x; s.y += red[i].y; s.z += red[i].z; s.w += red[i].w;
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(BNC_THREADS) void bn_fwd_cols_kernel(
+    const float* __restrict__ a, int lda, int R, int N, const float* __restrict__ beta, int relu,
+    float* __restrict__ h, int ldh, float* __restrict__ mean, float* __restrict__ var) {
+  __shared__ float4 red[BNC_THREADS / 64];
+  const int c = blockIdx.x * 4;
+  float4 v[BNC_RPT];
+  float4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < BNC_RPT; ++i) {
+    const int r = threadIdx.x + BNC_THREADS * i;
+    v[i] = r < R ? *reinterpret_cast<const float4*>(a + (size_t)r * lda + c)
+                 : float4{0.f, 0.f, 0.f, 0.f};
+    s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w;
+  }
+  s = bnc_block_sum(s, red);
+  const float inv = 1.f / (float)R;
+  const float4 mu = {s.x * inv, s.y * inv, s.z * inv, s.w * inv};
+  float4 q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < BNC_RPT; ++i) {
+    if (threadIdx.x + BNC_THREADS * i < R) {
+      const float dx = v[i].x - mu.x, dy = v[i].y - mu.y, dz = v[i].z - mu.z, dw = v[i].w - mu.w;
+      q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y);
+      q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
+    }
+  }
+  q = bnc_block_sum(q, red);
+  const float4 vr = {q.x * inv, q.y * inv, q.z * inv, q.w * inv};
+  if (threadIdx.x == 0) {
+    *reinterpret_cast<float4*>(mean + c) = mu;
+    *reinterpret_cast<float4*>(var + c) = vr;
+  }
+  const float4 is = {rsqrtf(vr.x + BN_EPSILON), rsqrtf(vr.y + BN_EPSILON),
+                     rsqrtf(vr.z + BN_EPSILON), rsqrtf(vr.w + BN_EPSILON)};
+  const float4 be = *reinterpret_cast<const float4*>(beta + c);
+#pragma unroll
+  for (int i = 0; i < BNC_RPT; ++i) {
+    const int r = threadIdx.x + BNC_THREADS * i;
+    if (r < R) {
+      float4 o = {(v[i].x - mu.x) * is.x + be.x, (v[i].y - mu.y) * is.y + be.y,
+                  (v[i].z - mu.z) * is.z + be.z, (v[i].w - mu.w) * is.w + be.w};
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      *reinterpret_cast<float4*>(h + (size_t)r * ldh + c) = o;
+    }
+  }
+}
+
+static bool bnc_aligned(const void* p, int ld) { return ((uintptr_t)p & 15) == 0 && (ld & 3) == 0; }
+
+bool bn_cols_supported(int rows, int N) {
+  return rows >= 1 && rows <= BNC_RPT * BNC_THREADS && N >= 4 && (N & 3) == 0;
+}
+// ... and where it pays: the 16-byte-per-row column slabs stream badly, so beyond ~1000 rows the
+// chunked kernels win (4096 rows: 13 vs 14 us forward but 32 vs 16 us backward); below, the step
+// is a chain of dependent latencies and one launch replaces three
+bool bn_cols_pays(int rows) { return rows <= 1024; }
+
+int bn_fwd_cols(hipStream_t stream, const float* a, int lda, int rows, int N, const float* beta,
+                int relu, float* h, int ldh, float* mean, float* var) {
+  SCVAE_ARG(a && beta && h && mean && var && bn_cols_supported(rows, N));
+  SCVAE_ARG(bnc_aligned(a, lda) && bnc_aligned(h, ldh) && bnc_aligned(beta, 4) &&
+            bnc_aligned(mean, 4) && bnc_aligned(var, 4));
+  hipLaunchKernelGGL(bn_fwd_cols_kernel, dim3(N / 4), dim3(BNC_THREADS), 0, stream, a, lda, rows, N,
+                     beta, relu, h, ldh, mean, var);
+  SCVAE_LAUNCH_CHECK("bn_fwd_cols_kernel");
+  return 0;
+}
+
+// backward: g = dh * (h > 0) [relu]; s1 = sum g; s2 = sum g xhat; dbeta = s1;
+// da = istd * (g - s1 / R - xhat * s2 / R); moving statistics <- batch statistics (UPDATE_OPS)
+__global__ __launch_bounds__(BNC_THREADS) void bn_bwd_cols_kernel(
+    const float* __restrict__ dh, int lddh, const float* __restrict__ h, int ldh,
+    const float* __restrict__ a, int lda, const float* __restrict__ mean,
+    const float* __restrict__ var, int R, int N, int relu, float* __restrict__ da, int ldda,
+    float* __restrict__ s1_out, float* __restrict__ s2_out, float* __restrict__ dbeta,
+    float* __restrict__ moving_mean, float* __restrict__ moving_var, float bessel) {
+  __shared__ float4 red[BNC_THREADS / 64];
+  const int c = blockIdx.x * 4;
+  const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+  const float4 vr = *reinterpret_cast<const float4*>(var + c);
+  const float4 is = {rsqrtf(vr.x + BN_EPSILON), rsqrtf(vr.y + BN_EPSILON),
+                     rsqrtf(vr.z + BN_EPSILON), rsqrtf(vr.w + BN_EPSILON)};
+  float4 g[BNC_RPT], xh[BNC_RPT];
+  float4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < BNC_RPT; ++i) {
+    const int r = threadIdx.x + BNC_THREADS * i;
+    g[i] = float4{0.f, 0.f, 0.f, 0.f};
+    xh[i] = float4{0.f, 0.f, 0.f, 0.f};
+    if (r < R) {
+      float4 d = *reinterpret_cast<const float4*>(dh + (size_t)r * lddh + c);
+      if (relu) {
+        const float4 hv = *reinterpret_cast<const float4*>(h + (size_t)r * ldh + c);
+        if (!(hv.x > 0.f)) d.x = 0.f;
+        if (!(hv.y > 0.f)) d.y = 0.f;
+        if (!(hv.z > 0.f)) d.z = 0.f;
+        if (!(hv.w > 0.f)) d.w = 0.f;
+      }
+      const float4 av = *reinterpret_cast<const float4*>(a + (size_t)r * lda + c);
+      g[i] = d;
+      xh[i] = float4{(av.x - mu.x) * is.x, (av.y - mu.y) * is.y, (av.z - mu.z) * is.z,
+                     (av.w - mu.w) * is.w};
+      t1.x += d.x; t1.y += d.y; t1.z += d.z; t1.w += d.w;
+      t2.x = fmaf(d.x, xh[i].x, t2.x); t2.y = fmaf(d.y, xh[i].y, t2.y);
+      t2.z = fmaf(d.z, xh[i].z, t2.z); t2.w = fmaf(d.w, xh[i].w, t2.w);
+    }
+  }
+  t1 = bnc_block_sum(t1, red);
+  t2 = bnc_block_sum(t2, red);
+  const float inv = 1.f / (float)R;
+  if (threadIdx.x == 0) {
+    *reinterpret_cast<float4*>(s1_out + c) = t1;
+    *reinterpret_cast<float4*>(s2_out + c) = t2;
+    if (dbeta != nullptr) *reinterpret_cast<float4*>(dbeta + c) = t1;
+    if (moving_mean != nullptr) {
+      float4 mm = *reinterpret_cast<float4*>(moving_mean + c);
+      float4 mv = *reinterpret_cast<float4*>(moving_var + c);
+      mm.x -= (mm.x - mu.x) * BN_UPDATE_RATE; mm.y -= (mm.y - mu.y) * BN_UPDATE_RATE;
+      mm.z -= (mm.z - mu.z) * BN_UPDATE_RATE; mm.w -= (mm.w - mu.w) * BN_UPDATE_RATE;
+      mv.x -= (mv.x - vr.x * bessel) * BN_UPDATE_RATE; mv.y -= (mv.y - vr.y * bessel) * BN_UPDATE_RATE;
+      mv.z -= (mv.z - vr.z * bessel) * BN_UPDATE_RATE; mv.w -= (mv.w - vr.w * bessel) * BN_UPDATE_RATE;
+      *reinterpret_cast<float4*>(moving_mean + c) = mm;
+      *reinterpret_cast<float4*>(moving_var + c) = mv;
+    }
+  }
+  const float4 m1 = {t1.x * inv, t1.y * inv, t1.z * inv, t1.w * inv};
+  const float4 m2 = {t2.x * inv, t2.y * inv, t2.z * inv, t2.w * inv};
+#pragma unroll
+  for (int i = 0; i < BNC_RPT; ++i) {
+    const int r = threadIdx.x + BNC_THREADS * i;
+    if (r < R) {
+      const float4 o = {is.x * (g[i].x - m1.x - xh[i].x * m2.x), is.y * (g[i].y - m1.y - xh[i].y * m2.y),
+                        is.z * (g[i].z - m1.z - xh[i].z * m2.z), is.w * (g[i].w - m1.w - xh[i].w * m2.w)};
+      *reinterpret_cast<float4*>(da + (size_t)r * ldda + c) = o;
+    }
+  }
+}
+
+int bn_bwd_cols(hipStream_t stream, const float* dh, int lddh, const float* h, int ldh,
+                const float* a, int lda, const float* mean, const float* var, int rows, int N,
+                int relu, float* da, int ldda, float* s1, float* s2, float* dbeta,
+                float* moving_mean, float* moving_var) {
+  SCVAE_ARG(dh && h && a && mean && var && da && s1 && s2 && bn_cols_supported(rows, N));
+  SCVAE_ARG((moving_mean == nullptr) == (moving_var == nullptr));
+  SCVAE_ARG(bnc_aligned(dh, lddh) && bnc_aligned(h, ldh) && bnc_aligned(a, lda) &&
+            bnc_aligned(da, ldda) && bnc_aligned(mean, 4) && bnc_aligned(var, 4) &&
+            bnc_aligned(s1, 4) && bnc_aligned(s2, 4) && (!dbeta || bnc_aligned(dbeta, 4)) &&
+            (!moving_mean || (bnc_aligned(moving_mean, 4) && bnc_aligned(moving_var, 4))));
+  const float bessel = (float)rows / (float)(rows > 1 ? rows - 1 : 1);
+  hipLaunchKernelGGL(bn_bwd_cols_kernel, dim3(N / 4), dim3(BNC_THREADS), 0, stream, dh, lddh, h, ldh,
+                     a, lda, mean, var, rows, N, relu, da, ldda, s1, s2, dbeta, moving_mean,
+                     moving_var, bessel);
+  SCVAE_LAUNCH_CHECK("bn_bwd_cols_kernel");
+  return 0;
+}
+
+bool bn_cols_layout_ok(const void* p, int ld) { return bnc_aligned(p, ld); }
+
 // Chan et al. merge of per-rank (count, mean, biased var): gathered = [ranks][mean(n)|var(n)]
 __global__ void bn_merge_kernel(const float* __restrict__ gathered,
                                 const int64_t* __restrict__ counts, int ranks, int n,

@@ -107,6 +107,17 @@ int bn_bwd_apply(hipStream_t stream, const float* dh, int lddh, const float* h, 
                  float* da, int ldda);
 int bn_merge(hipStream_t stream, const float* gathered, const int64_t* counts, int ranks, int n,
              float* out);
+// one-launch (column-parallel) batch norm of a single group of <= 8192 rows, N % 4 == 0, 16-byte
+// aligned rows: statistics + normalise (+ relu) / backward sums + dbeta + moving averages + da
+bool bn_cols_supported(int rows, int N);
+bool bn_cols_pays(int rows);
+bool bn_cols_layout_ok(const void* p, int ld);
+int bn_fwd_cols(hipStream_t stream, const float* a, int lda, int rows, int N, const float* beta,
+                int relu, float* h, int ldh, float* mean, float* var);
+int bn_bwd_cols(hipStream_t stream, const float* dh, int lddh, const float* h, int ldh,
+                const float* a, int lda, const float* mean, const float* var, int rows, int N,
+                int relu, float* da, int ldda, float* s1, float* s2, float* dbeta,
+                float* moving_mean, float* moving_var);
 // out[r, :] = [z[r, :L] | extra[r % cells, :E]];  slice: out[r, :L] = in[r, :L] of [rows, ld]
 int concat_extra(hipStream_t stream, const float* z, int L, const float* extra, int E, size_t rows,
                  size_t cells, float* out);

@@ -240,6 +240,11 @@ int dense_affine(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld
     const int rpg = rows / groups;
     float* mean = d.stats;
     float* var = d.stats + (size_t)groups * N;
+    // one group, nothing to exchange between the statistics and their use: one launch
+    if (groups == 1 && !p->sync && p->use_bn_cols && bn_cols_supported(rows, N) &&
+        (p->use_bn_cols >= 2 || bn_cols_pays(rows)) && bn_cols_layout_ok(d.a, N) && bn_cols_layout_ok(d.h, N) &&
+        bn_cols_layout_ok(p->params + d.beta, 4) && bn_cols_layout_ok(mean, N))
+      return bn_fwd_cols(s, d.a, N, rows, N, p->params + d.beta, relu ? 1 : 0, d.h, N, mean, var);
     if ((rc = bn_stats(s, d.a, N, rpg, groups, N, mean, var, p->partial))) return rc;
     if (p->sync) {
       // statistics of the global minibatch (sync batch norm); groups == 1 on this path
@@ -272,6 +277,19 @@ int dense_backward_activation(scvae_plan* p, hipStream_t s, Dense& d, int rows, 
     float* var = d.stats + (size_t)groups * N;
     float* s1 = d.stats + 2 * (size_t)groups * N;
     float* s2 = d.stats + 3 * (size_t)groups * N;
+    if (groups == 1 && !p->sync && p->use_bn_cols && bn_cols_supported(rows, N) &&
+        (p->use_bn_cols >= 2 || bn_cols_pays(rows)) && global_rows_per_group == rows && bn_cols_layout_ok(dh, N) && bn_cols_layout_ok(d.h, N) &&
+        bn_cols_layout_ok(d.a, N) && bn_cols_layout_ok(scratch, N) && bn_cols_layout_ok(mean, N) &&
+        bn_cols_layout_ok(p->grads + d.beta, 4) && bn_cols_layout_ok(p->moving + d.mov_mean, 4) &&
+        bn_cols_layout_ok(p->moving + d.mov_var, 4)) {
+      // sums + dbeta + moving averages + da in one launch
+      if ((rc = bn_bwd_cols(s, dh, N, d.h, N, d.a, N, mean, var, rows, N, relu ? 1 : 0, scratch, N,
+                            s1, s2, p->grads + d.beta, p->moving + d.mov_mean,
+                            p->moving + d.mov_var)))
+        return rc;
+      *da_out = scratch;
+      return 0;
+    }
     // the statistics launch also writes dbeta (sum over this rank's rows of dA, taken before s1
     // becomes a global sum) and updates the layer's moving averages from the (possibly synced)
     // batch statistics of the forward pass
@@ -769,6 +787,12 @@ int scvae_plan_bind(scvae_plan* p, float* params, float* grads, float* moving, v
 int scvae_plan_set_fused(scvae_plan* p, int32_t enabled) {
   SCVAE_ARG(p);
   p->use_fused = enabled ? 1 : 0;
+  return 0;
+}
+
+int scvae_plan_set_bn_one_launch(scvae_plan* p, int32_t enabled) {
+  SCVAE_ARG(p && enabled >= 0 && enabled <= 2);
+  p->use_bn_cols = enabled;
   return 0;
 }
 

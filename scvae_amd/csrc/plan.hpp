@@ -144,6 +144,7 @@ struct scvae_plan {
   int use_fused = 1;          // fused decoder head kernel (0 = unfused GEMM + likelihood path)
   int use_count_gemm = 1;     // exact bf16-split kernels for products with a count matrix x:
                               // 0 never, 1 where they pay (plan_gemm), 2 always
+  int use_bn_cols = 1;        // one-launch batch norm for single-group layers (bn_*_cols)
   const float* step_x = nullptr;   // this step's x and whether the caller vouches that it holds
   bool x_counts = false;           //  integers in [0, 65536) (scvae_step_args.x_counts)
   uint64_t drop_seed = 0;     // dropout: this step's mask seed (scvae_step_args.dropout_seed)

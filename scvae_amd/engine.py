@@ -303,6 +303,14 @@ class Engine:
         _lib.check(self.lib.scvae_plan_set_count_gemm(self.handle, mode),
                    "scvae_plan_set_count_gemm")
 
+    def set_bn_one_launch(self, enabled, always=False):
+        """One-launch batch norm for single-group layers: for minibatches of
+        up to 1024 rows (default), whenever it applies (``always``), or never
+        (the chunked statistics / finalize / apply kernels)."""
+        mode = (2 if always else 1) if enabled else 0
+        _lib.check(self.lib.scvae_plan_set_bn_one_launch(self.handle, mode),
+                   "scvae_plan_set_bn_one_launch")
+
     def set_sync(self, callback):
         """Install the data-parallel collective hook (see scvae_sync_fn)."""
         if callback is None:

@@ -219,3 +219,30 @@ def test_linear_factor_architectures(cuda_device, inference, generative):
               for k, v in eng.named_moving_statistics().items()}
     _close(eng.decode(z.float().to(cuda_device)).cpu(),
            om.decode_mean(cfg, params, moving, z), rtol=2e-4, what="decode")
+
+
+@pytest.mark.parametrize("B,H", [(37, (24, 20)), (4096, (100, 100)),
+                                 (5000, (64, 32)), (8192, (100,))])
+def test_one_launch_batch_norm_matches_the_chunked_kernels(cuda_device, B, H):
+    """Single-group layers normalise in one column-parallel launch
+    (``bn_fwd_cols`` / ``bn_bwd_cols``); the chunked statistics / finalize /
+    apply kernels (other shapes, the GMVAE's grouped layers, data parallel)
+    give the same step: scalars, gradients, moving statistics."""
+    from scvae_amd.engine import Engine
+    F, L = 300, 8
+    rng = np.random.default_rng(B)
+    x = torch.from_numpy(_counts(rng, B, F)).float().to(cuda_device)
+    eps = torch.from_numpy(rng.standard_normal((1, B, L))).float().to(
+        cuda_device)
+    results = []
+    for one_launch in (True, False):
+        eng = Engine(F, L, H, "negative binomial", batch_norm=True,
+                     device=cuda_device, seed=4)
+        eng.set_bn_one_launch(one_launch, always=True)
+        scalars = eng.step(x, x, eps=eps, training=True).clone()
+        torch.cuda.synchronize()
+        results.append((scalars.cpu(), eng.grads.clone().cpu(),
+                        eng.moving.clone().cpu()))
+    for a, b in zip(*results):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-9
