@@ -92,12 +92,14 @@ typedef struct scvae_plan scvae_plan; /* opaque */
  * kind 0: all-reduce(sum) `count` floats in place at `buf`;
  * kind 1: merge batch-norm statistics: buf = [mean(n) | var(n)] of `local_rows`
  *         rows -> global mean/var over all ranks, in place (count = 2n);
- * kind 2: notification: the `count` gradient floats at `buf` (a suffix of the
+ * kind 2: notification: the `count` gradient floats at `buf` (a range of the
  *         bound gradient buffer) are final although the step is still running;
  *         the caller may start their all-reduce(sum) asynchronously so that it
- *         overlaps the last large GEMM of the backward pass, and must complete
- *         it (and reduce the rest of the buffer) before the optimiser step.
- *         May be ignored (return 0).
+ *         overlaps the rest of the backward pass, and must complete it (and
+ *         reduce the rest of the buffer) before the optimiser step.  The VAE step
+ *         announces the likelihood heads right after their kernel and the hidden
+ *         layers when it reaches the first encoder layer.  May be ignored
+ *         (return 0).
  * Kinds 0 and 1 must enqueue on the plan's stream.  NULL = single process. */
 typedef int (*scvae_sync_fn)(void* user, float* buf, int64_t count, int32_t kind,
                              int64_t local_rows);

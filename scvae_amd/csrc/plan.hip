@@ -46,6 +46,7 @@ static int build_vae(scvae_plan* p) {
     p->dec.push_back(L.dense(scope, n_in, h, bn));
     n_in = h;
   }
+  p->heads_start = L.n_params;   // the likelihood heads are the tail of the parameter buffer
   for (int j = 0; j < p->P; ++j) {
     snprintf(scope, sizeof scope, "X_TILDE/%s", head_names(c.likelihood, j));
     p->heads[j] = L.dense(scope, n_in, c.feature_size, false);
@@ -326,8 +327,9 @@ int dense_backward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int 
                                       global_rows_per_group, &da)))
     return rc;
   if (p->sync && p->early_reduce_layer == &d) {
+    // everything between ENCODER/1 and the likelihood heads (announced after the head kernel)
     if (p->sync(p->sync_user, p->grads + p->early_reduce_start,
-                (int64_t)(p->layout.n_params - p->early_reduce_start), 2, 0)) {
+                (int64_t)(p->heads_start - p->early_reduce_start), 2, 0)) {
       set_error("gradient all-reduce hook failed");
       return -2;
     }
@@ -612,6 +614,15 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                       n_iw == 1 ? p->ll : nullptr, R, B, F);
     if (rc) return rc;
     if ((rc = heads_backward(p, s, head_in, R, head_drop, dcur, dalt))) return rc;
+  }
+  if (p->sync && p->early_reduce_layer != nullptr) {
+    // data parallel: the gradients of the likelihood heads -- two thirds of the buffer -- are
+    // final; their all-reduce may run under the whole backward pass of the hidden layers
+    if (p->sync(p->sync_user, p->grads + p->heads_start,
+                (int64_t)(p->layout.n_params - p->heads_start), 2, 0)) {
+      set_error("gradient all-reduce hook failed");
+      return -2;
+    }
   }
   if (n_iw == 1)
     if ((rc = vae_elbo(s, p->ll, p->kl_cell, mc_kl, n_iw, n_mc, B, w, row_scale, a->scalars, nullptr)))

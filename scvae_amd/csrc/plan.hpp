@@ -156,6 +156,9 @@ struct scvae_plan {
   // hook (kind 2) so that its all-reduce overlaps that GEMM
   const Dense* early_reduce_layer = nullptr;
   size_t early_reduce_start = 0;
+  // ... in two pieces: [heads_start, end) right after the likelihood-head kernel (the largest
+  // block, final first), [early_reduce_start, heads_start) at ENCODER/1's weight gradient
+  size_t heads_start = 0;
   // GMVAE graph (gm:2788-3221)
   std::vector<Dense> yenc, zenc, xdec;
   Dense ylogits, qmean, qscale, pmean, pscale;

@@ -8,9 +8,11 @@ per optimiser step there is
 
 * one all-reduce(sum) of the flat fp32 gradient buffer (each rank's gradient is
   already scaled by 1/global_batch, so the sum is the single-process gradient;
-  clipping to [-1, 1] happens after it, as in va:2751-2755), issued in two
-  pieces: everything but the first encoder layer as soon as it is final (it
-  overlaps that layer's weight-gradient GEMM), the rest after the step, and
+  clipping to [-1, 1] happens after it, as in va:2751-2755), issued in three
+  pieces: the likelihood heads (two thirds of the buffer) right after their
+  kernel, the hidden layers when the backward pass reaches the first encoder
+  layer -- both asynchronously, under the rest of the backward pass -- and the
+  first encoder layer after the step, and
 * per batch-norm layer one all-gather of ``[mean | var]`` in the forward pass
   (merged with the parallel-variance formula) and one all-reduce of
   ``[sum dA | sum dA*xhat]`` in the backward pass, so that the result equals
@@ -55,12 +57,23 @@ def merge_batch_norm_statistics(gathered, counts):
 class GradientSynchroniser:
     """Collectives of one data-parallel rank, bound to an ``Engine``."""
 
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, gradient_group=None):
         from scvae_amd import _lib
         self.engine = engine
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # The asynchronous gradient all-reduces get a communicator of their own: collectives
+        # of one communicator execute in issue order on its stream, so on a shared one the
+        # small, latency-critical batch-norm exchanges of the backward pass would queue
+        # behind the 26 MB gradient bucket issued just before them.  (Collective call: every
+        # rank constructs its synchroniser at the same point.)
+        if gradient_group is None and self.world_size > 1:
+            ranks = (dist.get_process_group_ranks(group) if group is not None
+                     else list(range(self.world_size)))
+            gradient_group = dist.new_group(ranks=ranks,
+                                            backend=dist.get_backend(group))
+        self.gradient_group = gradient_group if gradient_group is not None else group
         self.lib = _lib.load()
         self._check = _lib.check
         self._gathered = None
@@ -85,7 +98,7 @@ class GradientSynchroniser:
                 if offset < 0 or offset + count > grads.numel():
                     raise RuntimeError("gradient range is outside the buffer")
                 work = dist.all_reduce(grads[offset:offset + count],
-                                       group=self.group, async_op=True)
+                                       group=self.gradient_group, async_op=True)
                 self._pending.append((offset, count, work))
                 return 0
             view = self._view(address, count)
@@ -130,10 +143,11 @@ class GradientSynchroniser:
         position = 0
         for offset, count, _ in sorted(self._pending, key=lambda p: p[0]):
             if offset > position:
-                dist.all_reduce(grads[position:offset], group=self.group)
+                dist.all_reduce(grads[position:offset],
+                                group=self.gradient_group)
             position = max(position, offset + count)
         if position < grads.numel():
-            dist.all_reduce(grads[position:], group=self.group)
+            dist.all_reduce(grads[position:], group=self.gradient_group)
         for _, _, work in self._pending:
             work.wait()
         self._pending = []

@@ -132,8 +132,12 @@ def _two_rank_worker(rank, port, model_type, result_path):
         sync.broadcast_state(0)
         lo, hi = shard_bounds(B, 2, rank)
         scalars = step(eng, lo, hi, global_cells=B)
-        # the VAE step announces everything but ENCODER/1 for an early all-reduce
-        assert len(sync._pending) == (1 if model_type == "VAE" else 0)
+        # the VAE step announces the likelihood heads, then the hidden layers, for an
+        # early all-reduce (everything but ENCODER/1)
+        assert len(sync._pending) == (2 if model_type == "VAE" else 0)
+        if model_type == "VAE":
+            (o1, c1, _), (o2, c2, _) = sorted(sync._pending, key=lambda p: p[0])
+            assert o1 + c1 == o2 and o2 + c2 == eng.grads.numel()
         sync.all_reduce_gradients()
         assert not sync._pending
         sync.all_reduce_scalars(scalars)
