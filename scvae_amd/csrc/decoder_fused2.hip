@@ -124,29 +124,54 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) accW[j][i] = 0.f;
 
-  float dv[DLOADS];            // next d tile, in flight from the MFMA slot to the hand-over
+  // next d tile, in flight from the MFMA slot to the hand-over.  H % 4 == 0 (the usual case: rows
+  // of d are 16-byte multiples, a 32-row tile is one contiguous block): two 16-byte loads per
+  // thread and one row / column split per load instead of seven scalar loads with one each.
+  constexpr int DREGS = DLOADS > 8 ? DLOADS : 8;
+  float dv[DREGS];
   float tv[4] = {0.f, 0.f, 0.f, 0.f}, up[2] = {0.f, 0.f};   // in flight until the VALU slot
+  const bool h4 = (H & 3) == 0;
 
   // `tq` is an opaque copy of the thread's index within its half: the per-thread addresses are
   // re-derived in every slot instead of living in (spilled) registers across the whole loop.
   auto load_d = [&](int m0, int tq) {
-    const float* dbase = d + (size_t)m0 * H + tq;
     const int n_valid = (m0 < R) ? min(R - m0, BM) * H : 0;
+    if (h4) {
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const float* dbase = d + (size_t)m0 * H + 4 * tq;
 #pragma unroll
-    for (int i = 0; i < DLOADS; ++i) {
-      // (the first loads of a full tile need no predicate: BM * H >= 64 * (i + 1) * 8 ...)
-      dv[i] = (i * NH + tq < n_valid) ? dbase[i * NH] : 0.f;
+      for (int i = 0; i < 2; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (4 * (i * NH + tq) < n_valid) v = *reinterpret_cast<const f32x4*>(dbase + 4 * i * NH);
+        dv[4 * i] = v.x; dv[4 * i + 1] = v.y; dv[4 * i + 2] = v.z; dv[4 * i + 3] = v.w;
+      }
+    } else {
+      const float* dbase = d + (size_t)m0 * H + tq;
+#pragma unroll
+      for (int i = 0; i < DLOADS; ++i) dv[i] = (i * NH + tq < n_valid) ? dbase[i * NH] : 0.f;
     }
   };
   auto store_d = [&](int m0, int buf, int tq) {
     float* dst = dsh + (size_t)buf * DBUF;
     const int n_d = BM * H;
+    if (h4) {
 #pragma unroll
-    for (int i = 0; i < DLOADS; ++i) {
-      const int e = i * NH + tq;
-      if (e < n_d) {
-        const int r = __umulhi((unsigned)e, magic_h), h = e - r * H;
-        dst[r * LDD + h] = dv[i];
+      for (int i = 0; i < 2; ++i) {
+        const int e = 4 * (i * NH + tq);
+        if (e < n_d) {
+          const int r = __umulhi((unsigned)e, magic_h), h = e - r * H;
+          float* q = dst + r * LDD + h;
+          q[0] = dv[4 * i]; q[1] = dv[4 * i + 1]; q[2] = dv[4 * i + 2]; q[3] = dv[4 * i + 3];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < DLOADS; ++i) {
+        const int e = i * NH + tq;
+        if (e < n_d) {
+          const int r = __umulhi((unsigned)e, magic_h), h = e - r * H;
+          dst[r * LDD + h] = dv[i];
+        }
       }
     }
     if (tq < BM) dst[tq * LDD + H] = (m0 + tq < R) ? 1.f : 0.f;
@@ -264,7 +289,7 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
       // the d loads have landed by now: consume the wait here, before the dd stores are issued,
       // so that the hand-over does not wait for the stores
 #pragma unroll
-      for (int i = 0; i < DLOADS; ++i) asm volatile("" : "+v"(dv[i]));
+      for (int i = 0; i < DREGS; ++i) asm volatile("" : "+v"(dv[i]));
       // (non-temporal stores: 839 MB of dd slabs per launch that are read exactly once, by
       //  dd_reduce_kernel -- written through, they do not linger as dirty lines in the 256 MB
       //  infinity cache and get evicted in the middle of that reduce: 151 -> 123 us)
