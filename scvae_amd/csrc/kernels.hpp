@@ -126,6 +126,39 @@ int relu_bwd(hipStream_t stream, const float* dh, const float* h, float* da, siz
 int col_sum(hipStream_t stream, const float* a, int lda, int rows, int N, float* out, float scale,
             int accumulate, float* partial);
 
+// ---- midchain.hip: the hidden layers, posterior heads and latent stage of a small VAE step
+//      in one workgroup (two launches instead of ~27) ----
+struct MidLayer {
+  const float* W;        // [n_in, n_out]
+  const float* b;        // [n_out]
+  const float* beta;     // [n_out]
+  float* mov_mean;       // [n_out]
+  float* mov_var;
+  float* a;              // [rows, n_out] pre-normalisation output
+  float* h;              // [rows, n_out] layer output
+  float* stats;          // [mean | var | s1 | s2]
+  float* dW;
+  float* db;
+  float* dbeta;
+  int n_in, n_out;
+};
+constexpr int MID_MAX_LAYERS = 8;
+struct MidChainArgs {
+  int cells, samples, latent, n_enc, n_dec, training, deterministic;
+  float kl_coeff;                       // d(-ELBO_w) / d KL_cell
+  MidLayer enc[MID_MAX_LAYERS], dec[MID_MAX_LAYERS], mu, ls;
+  const float* eps;
+  float *mu_pre, *ls_pre, *z, *kl_elem, *kl_cell;
+  float *dz, *dmu, *dls;
+  float* da0;                           // out: gradient w.r.t. the input layer's pre-activation
+  float* buf[3];                        // [rows, <=128] scratch; buf[0] holds dd on entry (backward)
+  unsigned* bar;                        // grid-barrier counter (never reset)
+  unsigned bar_base;                    // its value when this launch starts
+};
+unsigned vae_mid_barrier_advance(const MidChainArgs& args, bool backward);
+int vae_mid_forward(hipStream_t stream, const MidChainArgs& args);
+int vae_mid_backward(hipStream_t stream, const MidChainArgs& args);
+
 // ---- decoder_fused.hip ----
 struct HeadParams {
   const float* W[3];

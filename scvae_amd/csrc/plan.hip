@@ -99,6 +99,8 @@ static size_t carve(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_
   };
   for (auto& d : p->enc) layer_ws(d, B);
   for (auto& d : p->dec) layer_ws(d, R);
+  float* mid_bar = b.floats(64);
+  if (!dry) p->mid_bar = reinterpret_cast<unsigned*>(mid_bar);
   float* mu_pre = b.floats(B * Lz);
   float* ls_pre = b.floats(B * Lz);
   float* kl_elem = b.floats(B * Lz);
@@ -449,6 +451,61 @@ HeadParams head_params(scvae_plan* p) {
   return hp;
 }
 
+// ---- small minibatches: the chain between the input layer and the likelihood heads in one
+//      workgroup (midchain.hip) ----
+static bool mid_chain_ok(const scvae_plan* p, int B, int S, bool training) {
+  const scvae_model_config& c = p->cfg;
+  if (!p->use_mid_chain || p->sync) return false;
+  if (!c.batch_norm || p->enc.empty() || p->dec.empty()) return false;
+  if (c.latent_mode != 0 || c.decoder_extra != 0) return false;
+  if ((int64_t)B * S > 128 || c.latent_size > 128) return false;
+  if (p->enc.size() > (size_t)MID_MAX_LAYERS || p->dec.size() > (size_t)MID_MAX_LAYERS) return false;
+  for (const auto& d : p->enc) if (d.n_out > 128) return false;
+  for (const auto& d : p->dec) if (d.n_out > 128) return false;
+  if (training)   // every parameter layer of the chain would need its own dropped-out input
+    for (int i = 0; i < 3; ++i) if (dropout_keep(c, i) > 0.f) return false;
+  return true;
+}
+
+static MidLayer mid_layer(const scvae_plan* p, const Dense& d) {
+  MidLayer m;
+  m.W = p->params + d.w;
+  m.b = p->params + d.b;
+  m.beta = d.bn ? p->params + d.beta : nullptr;
+  m.mov_mean = d.bn ? p->moving + d.mov_mean : nullptr;
+  m.mov_var = d.bn ? p->moving + d.mov_var : nullptr;
+  m.a = d.a; m.h = d.h; m.stats = d.stats;
+  m.dW = p->grads ? p->grads + d.w : nullptr;
+  m.db = p->grads ? p->grads + d.b : nullptr;
+  m.dbeta = (p->grads && d.bn) ? p->grads + d.beta : nullptr;
+  m.n_in = d.n_in; m.n_out = d.n_out;
+  return m;
+}
+
+static MidChainArgs mid_chain_args(const scvae_plan* p, const scvae_step_args* a, int B, int S,
+                                   bool training, float kl_coeff) {
+  MidChainArgs q;
+  memset(&q, 0, sizeof q);
+  q.cells = B; q.samples = S; q.latent = p->cfg.latent_size;
+  q.n_enc = (int)p->enc.size(); q.n_dec = (int)p->dec.size();
+  q.training = training ? 1 : 0;
+  q.deterministic = a->deterministic_z ? 1 : 0;
+  q.kl_coeff = kl_coeff;
+  for (int i = 0; i < q.n_enc; ++i) q.enc[i] = mid_layer(p, p->enc[i]);
+  for (int i = 0; i < q.n_dec; ++i) q.dec[i] = mid_layer(p, p->dec[i]);
+  q.mu = mid_layer(p, p->mu);
+  q.ls = mid_layer(p, p->ls);
+  q.eps = a->eps;
+  q.mu_pre = p->mu_pre; q.ls_pre = p->ls_pre; q.z = p->z;
+  q.kl_elem = p->kl_elem; q.kl_cell = p->kl_cell;
+  q.dz = p->dz; q.dmu = p->dmu; q.dls = p->dls;
+  q.da0 = p->dbuf[2];
+  for (int i = 0; i < 3; ++i) q.buf[i] = p->dbuf[i];
+  q.bar = p->mid_bar;
+  q.bar_base = p->mid_bar_count;
+  return q;
+}
+
 static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const scvae_model_config& c = p->cfg;
   const int B = (int)a->cells;
@@ -464,11 +521,24 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   p->drop_seed = a->dropout_seed;
 
   // ---------------- forward ----------------
+  const bool mid = mid_chain_ok(p, B, S, training);
   const float* h = a->x;
   int ld = F;
+  if (mid) {
+    // the input-layer product, then everything up to the decoder's output in one workgroup
+    Dense& d0 = p->enc[0];
+    if ((rc = plan_gemm(p, s, false, false, a->x, p->params + d0.w, p->params + d0.b, d0.a, B,
+                        d0.n_out, d0.n_in, F, d0.n_out, d0.n_out, ACT_NONE, false)))
+      return rc;
+    const MidChainArgs q = mid_chain_args(p, a, B, S, training, 0.f);
+    if ((rc = vae_mid_forward(s, q))) return rc;
+    p->mid_bar_count += vae_mid_barrier_advance(q, false);
+    h = p->enc.back().h; ld = p->enc.back().n_out;
+  } else {
   for (auto& d : p->enc) {
     if ((rc = dense_forward(p, s, d, h, ld, B, 1, true, training))) return rc;
     h = d.h; ld = d.n_out;
+  }
   }
   Dense& mu = p->mu;
   Dense& ls = p->ls;
@@ -476,13 +546,14 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const float* h_mu = h;
   const float* h_ls = h;
   int ld_mu = ld, ld_ls = ld;
+  const bool mc_kl = (c.latent_mode & 1) != 0;      // va:2633-2640
+  const bool unit_var = (c.latent_mode & 2) != 0;   // du:323-337
+  const float* ls_pre = unit_var ? nullptr : p->ls_pre;
+  if (!mid) {
   if ((rc = dense_input(p, s, mu, h, ld, B, training, &h_mu, &ld_mu))) return rc;
   if ((rc = plan_gemm(p, s, false, false, h_mu, p->params + mu.w, p->params + mu.b, p->mu_pre, B, L,
                       mu.n_in, ld_mu, L, L, ACT_NONE, false)))
     return rc;
-  const bool mc_kl = (c.latent_mode & 1) != 0;      // va:2633-2640
-  const bool unit_var = (c.latent_mode & 2) != 0;   // du:323-337
-  const float* ls_pre = unit_var ? nullptr : p->ls_pre;
   if (!unit_var) {
     if ((rc = dense_input(p, s, ls, h, ld, B, training, &h_ls, &ld_ls))) return rc;
     if ((rc = plan_gemm(p, s, false, false, h_ls, p->params + ls.w, p->params + ls.b, p->ls_pre, B,
@@ -492,6 +563,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   if ((rc = gauss_latent_fwd(s, p->mu_pre, ls_pre, a->eps, p->z, p->kl_elem, p->kl_cell,
                              mc_kl ? p->kl_cell : nullptr, S, B, L, a->deterministic_z)))
     return rc;
+  }
   if (a->kl_neurons)
     if ((rc = col_sum(s, p->kl_elem, L, B, L, a->kl_neurons, 1.f / (float)GB, 0, p->partial))) return rc;
   if (a->q_z_mean)
@@ -506,9 +578,13 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   const float* dch = dec_in;
   ld = L + E;
+  if (mid) {
+    dch = p->dec.back().h; ld = p->dec.back().n_out;
+  } else {
   for (auto& d : p->dec) {
     if ((rc = dense_forward(p, s, d, dch, ld, R, 1, true, training))) return rc;
     dch = d.h; ld = d.n_out;
+  }
   }
   HeadPtrs pre;
   for (int j = 0; j < 3; ++j) pre.p[j] = p->pre[j];
@@ -630,6 +706,16 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   if (a->log_p_x_given_z)
     if ((rc = copy(s, p->ll, a->log_p_x_given_z, (size_t)R))) return rc;
 
+  if (mid) {
+    // hidden layers, latent stage and posterior heads backwards in one workgroup; what is left
+    // is the input layer's weight gradient x^T dA
+    const MidChainArgs q = mid_chain_args(p, a, B, S, true, w / (float)GB);
+    if ((rc = vae_mid_backward(s, q))) return rc;
+    p->mid_bar_count += vae_mid_barrier_advance(q, true);
+    Dense& d0 = p->enc[0];
+    return plan_gemm(p, s, true, false, a->x, p->dbuf[2], nullptr, p->grads + d0.w, d0.n_in,
+                     d0.n_out, B, F, d0.n_out, d0.n_out, ACT_NONE, false);
+  }
   const int64_t GR = GB * S;  // global decoder rows
   // decoder layers, last to first; the first decoder layer's input is z
   for (int i = (int)p->dec.size() - 1; i >= 0; --i) {
@@ -784,6 +870,10 @@ int scvae_plan_bind(scvae_plan* p, float* params, float* grads, float* moving, v
   p->max_cells = max_cells; p->max_samples = max_samples;
   if (gm) scvae::carve_gmvae(p, workspace, (size_t)workspace_bytes, max_cells, max_samples, false);
   else scvae::carve(p, workspace, (size_t)workspace_bytes, max_cells, max_samples, false);
+  if (p->mid_bar) {
+    SCVAE_HIP(hipMemset(p->mid_bar, 0, 64 * sizeof(float)));
+    p->mid_bar_count = 0;
+  }
   if (grads) {
     // bias gradients of batch-normalised layers are identically zero and never written
     for (auto* layers : {&p->enc, &p->dec, &p->yenc, &p->zenc, &p->xdec})
@@ -798,6 +888,12 @@ int scvae_plan_bind(scvae_plan* p, float* params, float* grads, float* moving, v
 int scvae_plan_set_fused(scvae_plan* p, int32_t enabled) {
   SCVAE_ARG(p);
   p->use_fused = enabled ? 1 : 0;
+  return 0;
+}
+
+int scvae_plan_set_mid_chain(scvae_plan* p, int32_t enabled) {
+  SCVAE_ARG(p);
+  p->use_mid_chain = enabled ? 1 : 0;
   return 0;
 }
 

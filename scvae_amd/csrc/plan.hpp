@@ -145,6 +145,9 @@ struct scvae_plan {
   int use_count_gemm = 1;     // exact bf16-split kernels for products with a count matrix x:
                               // 0 never, 1 where they pay (plan_gemm), 2 always
   int use_bn_cols = 1;        // one-launch batch norm for single-group layers (bn_*_cols)
+  unsigned* mid_bar = nullptr;   // midchain.hip's grid-barrier counter (workspace, zeroed at bind)
+  unsigned mid_bar_count = 0;    // its value once every launch enqueued so far has run
+  int use_mid_chain = 1;      // small VAE steps: hidden layers + heads + latent in two launches
   const float* step_x = nullptr;   // this step's x and whether the caller vouches that it holds
   bool x_counts = false;           //  integers in [0, 65536) (scvae_step_args.x_counts)
   uint64_t drop_seed = 0;     // dropout: this step's mask seed (scvae_step_args.dropout_seed)

@@ -303,6 +303,12 @@ class Engine:
         _lib.check(self.lib.scvae_plan_set_count_gemm(self.handle, mode),
                    "scvae_plan_set_count_gemm")
 
+    def set_mid_chain(self, enabled):
+        """Small VAE minibatches: hidden layers + posterior heads + latent stage
+        in one workgroup (default) or as the chain of launches."""
+        _lib.check(self.lib.scvae_plan_set_mid_chain(
+            self.handle, 1 if enabled else 0), "scvae_plan_set_mid_chain")
+
     def set_bn_one_launch(self, enabled, always=False):
         """One-launch batch norm for single-group layers: for minibatches of
         up to 1024 rows (default), whenever it applies (``always``), or never

@@ -246,3 +246,47 @@ def test_one_launch_batch_norm_matches_the_chunked_kernels(cuda_device, B, H):
     for a, b in zip(*results):
         scale = b.abs().max().item()
         assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-9
+
+
+@pytest.mark.parametrize("B,H,L,n_iw", [(100, (100, 100), 25, 1),
+                                         (37, (24, 20), 7, 1),
+                                         (128, (128,), 128, 1),
+                                         (19, (16, 12, 8), 5, 3)])
+def test_mid_chain_matches_the_launch_chain(cuda_device, B, H, L, n_iw):
+    """Small minibatches run the hidden layers, posterior heads and latent stage
+    in one workgroup (``midchain.hip``, 2 launches instead of ~27).  Same step as
+    the chain of launches: scalars, per-cell outputs, every gradient, the moving
+    statistics; training and evaluation."""
+    from scvae_amd.engine import Engine
+    F = 400
+    rng = np.random.default_rng(B + L)
+    x = torch.from_numpy(_counts(rng, B, F)).float().to(cuda_device)
+    eps = torch.from_numpy(rng.standard_normal((n_iw, B, L))).float().to(
+        cuda_device)
+    results = []
+    for mid in (True, False):
+        eng = Engine(F, L, H, "negative binomial", batch_norm=True,
+                     device=cuda_device, seed=4)
+        g = torch.Generator().manual_seed(9)
+        for name, p in eng.named_parameters().items():
+            if not name.endswith("weights"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+        eng.set_mid_chain(mid)
+        ll = torch.zeros(n_iw * B, device=cuda_device)
+        qz = torch.zeros(B, L, device=cuda_device)
+        klz = torch.zeros(L, device=cuda_device)
+        outs = {"log_p_x_given_z": ll, "q_z_mean": qz, "kl_neurons": klz}
+        scalars = eng.step(x, x, eps=eps, training=True, n_iw=n_iw,
+                           warm_up_weight=0.7, outputs=outs).clone()
+        torch.cuda.synchronize()
+        train = [scalars.cpu(), ll.cpu().clone(), qz.cpu().clone(),
+                 klz.cpu().clone(), eng.grads.clone().cpu(),
+                 eng.moving.clone().cpu()]
+        ev = eng.step(x, x, eps=eps, training=False, n_iw=n_iw,
+                      outputs=outs).clone()
+        det = eng.step(x, x, training=False, deterministic_z=True).clone()
+        torch.cuda.synchronize()
+        results.append(train + [ev.cpu(), ll.cpu().clone(), det.cpu()])
+    for a, b in zip(*results):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-9
