@@ -251,12 +251,15 @@ def test_one_launch_batch_norm_matches_the_chunked_kernels(cuda_device, B, H):
 @pytest.mark.parametrize("B,H,L,n_iw", [(100, (100, 100), 25, 1),
                                          (37, (24, 20), 7, 1),
                                          (128, (128,), 128, 1),
-                                         (19, (16, 12, 8), 5, 3)])
+                                         (19, (16, 12, 8), 5, 3),
+                                         (64, (50, 30), 10, 2)])
 def test_mid_chain_matches_the_launch_chain(cuda_device, B, H, L, n_iw):
     """Small minibatches run the hidden layers, posterior heads and latent stage
-    in one workgroup (``midchain.hip``, 2 launches instead of ~27).  Same step as
-    the chain of launches: scalars, per-cell outputs, every gradient, the moving
-    statistics; training and evaluation."""
+    in two cooperative launches (``midchain.hip``: sixteen workgroups, a grid
+    barrier per layer; instead of ~27 launches).  Same step as the chain of
+    launches: scalars, per-cell outputs, every gradient, the moving statistics;
+    training and evaluation.  (Widths off the float4 path, ragged strips, three
+    layers, importance samples.)"""
     from scvae_amd.engine import Engine
     F = 400
     rng = np.random.default_rng(B + L)
@@ -287,6 +290,20 @@ def test_mid_chain_matches_the_launch_chain(cuda_device, B, H, L, n_iw):
         det = eng.step(x, x, training=False, deterministic_z=True).clone()
         torch.cuda.synchronize()
         results.append(train + [ev.cpu(), ll.cpu().clone(), det.cpu()])
+        if mid:
+            # many launches on the same barrier counter, and bitwise repeatable
+            moving = eng.moving.clone()
+            again = []
+            for _ in range(2):
+                eng.moving.copy_(moving)
+                for _ in range(25):
+                    s25 = eng.step(x, x, eps=eps, training=True, n_iw=n_iw,
+                                   warm_up_weight=0.7).clone()
+                torch.cuda.synchronize()
+                again.append((s25.cpu(), eng.grads.clone().cpu(),
+                              eng.moving.clone().cpu()))
+            for u, v in zip(*again):
+                assert torch.equal(u, v)
     for a, b in zip(*results):
         scale = b.abs().max().item()
         assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-9
