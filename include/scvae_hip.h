@@ -144,7 +144,8 @@ int scvae_plan_set_count_gemm(scvae_plan* plan, int32_t enabled);
 int scvae_plan_set_bn_one_launch(scvae_plan* plan, int32_t enabled);
 /* Small VAE minibatches (cells x samples <= 128, widths <= 128, batch norm, analytic KL, no
  * dropout / decoder extras, single process): the hidden layers, posterior heads and latent stage
- * of a step run in ONE workgroup, forwards and backwards (2 launches instead of ~27; midchain.hip).
+ * of a step run as TWO cooperative launches (forwards, backwards: sixteen workgroups with a grid
+ * barrier per layer, instead of ~27 launches; midchain.hip).
  * Default on; 0 keeps the chain of launches (the two are compared in tests/test_gpu_vae_step.py) */
 int scvae_plan_set_mid_chain(scvae_plan* plan, int32_t enabled);
 

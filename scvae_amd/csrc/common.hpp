@@ -202,6 +202,54 @@ __device__ __forceinline__ void lgamma_digamma_diff(float r, float t, float& A, 
 __device__ __forceinline__ float lgamma1p(float t) {
   return t == 0.f ? 0.f : lgammaf(1.f + t);
 }
+// ---- batch-norm arithmetic of the chunked kernels (elementwise.hip).
+// Written out operation by operation (no contraction left to the compiler) so that two kernels
+// using the same helper give the same bits whatever surrounds the call.
+#pragma clang fp contract(off)
+__device__ __forceinline__ float bn_normalise(float a, float mu, float istd, float beta) {
+  return fmaf(a - mu, istd, beta);
+}
+// merge of chunk statistics: sum of n * mean, then sum of M2 + n * (mean - mu)^2
+__device__ __forceinline__ float bn_merge_mean(float acc, float n, float chunk_mean) {
+  return fmaf(n, chunk_mean, acc);
+}
+__device__ __forceinline__ float bn_merge_m2(float acc, float n, float chunk_mean, float chunk_m2,
+                                             float mu) {
+  const float d = chunk_mean - mu;
+  return acc + fmaf(n * d, d, chunk_m2);
+}
+// dA = istd (g - s1 / count - xhat s2 / count)
+__device__ __forceinline__ float bn_input_gradient(float g, float xh, float s1, float s2,
+                                                   float inv_count, float istd) {
+  const float t = g - s1 * inv_count;
+  return istd * (t - (xh * s2) * inv_count);
+}
+// moving <- moving - (moving - batch) * rate
+__device__ __forceinline__ float bn_moving_update(float moving, float batch) {
+  const float d = moving - batch;
+  return moving - d * BN_UPDATE_RATE;
+}
+#pragma clang fp contract(fast)
+
+// All workgroups of a launch arrive; writes made before are visible to every workgroup after.
+// `bar` is a counter that is never reset; `target` = its value once all workgroups of this
+// barrier have arrived (the host advances the base by workgroups x barriers per launch; the
+// comparison is wrap-safe).  Only for launches whose workgroups are all co-resident (<= one per
+// CU); should the others never arrive -- tens of seconds -- the launch aborts loudly rather than
+// hang the queue.
+__device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned target) {
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while ((int)(__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins == (1u << 28)) __builtin_trap();
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
 #endif  // __HIPCC__
 
 }  // namespace scvae

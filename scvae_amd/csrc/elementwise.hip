@@ -774,7 +774,7 @@ __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(
   if (c < N)
     for (int z = zl; z < chunks; z += 16) {
       const int n = min(R, (z + 1) * chunk) - z * chunk;
-      acc += (float)n * partial[(((size_t)z * G + g) * 2) * N + c];
+      acc = bn_merge_mean(acc, (float)n, partial[(((size_t)z * G + g) * 2) * N + c]);
     }
   red[zl][cl] = acc;
   __syncthreads();
@@ -788,8 +788,7 @@ __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(
     for (int z = zl; z < chunks; z += 16) {
       const int n = min(R, (z + 1) * chunk) - z * chunk;
       const float* pz = partial + (((size_t)z * G + g) * 2) * N;
-      const float d = pz[c] - mu;
-      acc += pz[N + c] + (float)n * d * d;
+      acc = bn_merge_m2(acc, (float)n, pz[c], pz[N + c], mu);
     }
   red[zl][cl] = acc;
   __syncthreads();
@@ -843,7 +842,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const int g = (int)(row / R);
     const float mu = mean[(size_t)g * stat_stride + c];
     const float istd = rsqrtf(var[(size_t)g * stat_stride + c] + BN_EPSILON);
-    float v = (a[row * lda + c] - mu) * istd + beta[c];
+    float v = bn_normalise(a[row * lda + c], mu, istd, beta[c]);
     if (relu) v = fmaxf(v, 0.f);
     h[row * ldh + c] = v;
   }
@@ -954,8 +953,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_stats_finalize_kernel(
   if (moving_mean != nullptr && writer) {
     float mm = moving_mean[c], mv = moving_var[c];
     for (int q = 0; q < G; ++q) {
-      mm -= (mm - mean[(size_t)q * N + c]) * BN_UPDATE_RATE;
-      mv -= (mv - var[(size_t)q * N + c] * bessel) * BN_UPDATE_RATE;
+      mm = bn_moving_update(mm, mean[(size_t)q * N + c]);
+      mv = bn_moving_update(mv, var[(size_t)q * N + c] * bessel);
     }
     moving_mean[c] = mm;
     moving_var[c] = mv;
@@ -1001,8 +1000,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     float d = dh[row * lddh + c];
     if (relu && !(h[row * ldh + c] > 0.f)) d = 0.f;
     const float xh = (a[row * lda + c] - mu) * istd;
-    da[row * ldda + c] =
-        istd * (d - s1[(size_t)g * N + c] * inv_count - xh * s2[(size_t)g * N + c] * inv_count);
+    da[row * ldda + c] = bn_input_gradient(d, xh, s1[(size_t)g * N + c], s2[(size_t)g * N + c],
+                                           inv_count, istd);
   }
 }
 

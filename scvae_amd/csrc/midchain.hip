@@ -75,25 +75,6 @@ __device__ __forceinline__ Ctx make_ctx(float* smem) {
   return x;
 }
 
-// All workgroups of the launch arrive; writes made before are visible to every workgroup after.
-// `target` = the counter value once all of them have arrived (the counter is never reset: the
-// host advances the base by MC_WGS x barriers per launch; the comparison is wrap-safe).
-__device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned target) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    // (sixteen workgroups are always co-resident on this part; should the others never arrive
-    //  -- tens of seconds -- abort the launch loudly rather than hang the queue)
-    unsigned spins = 0;
-    while ((int)(__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins == (1u << 28)) __builtin_trap();
-    }
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-
 // The memory matrix Mx[nr][nc] (row pitch ld) into LDS as As[r][c].  Two halves so that a stage can put its loads in flight early
 // (before the grid barrier when the data does not depend on the stage before): mat_issue starts
 // the loads of the first pass (the whole matrix unless it is wider than 32 columns AND not

@@ -305,7 +305,7 @@ class Engine:
 
     def set_mid_chain(self, enabled):
         """Small VAE minibatches: hidden layers + posterior heads + latent stage
-        in one workgroup (default) or as the chain of launches."""
+        in two cooperative launches (default) or as the chain of launches."""
         _lib.check(self.lib.scvae_plan_set_mid_chain(
             self.handle, 1 if enabled else 0), "scvae_plan_set_mid_chain")
 
