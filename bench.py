@@ -313,7 +313,16 @@ class Workload:
             from scvae_amd.dataparallel import GradientSynchroniser
             self.sync = GradientSynchroniser(self.engine)
             self.sync.broadcast_state(0)
-        self.x = torch.empty(batch, F, device=device)
+        # integer count matrices: the minibatch is densified as uint16 where the
+        # plan takes it (half the bytes for the kernels that stream it;
+        # bit-identical step), fp32 otherwise
+        self.u16 = bool(matrix.integer_counts
+                        and self.engine.accepts_counts_u16(batch, True))
+        if self.u16:
+            self.x = torch.empty(batch, matrix.u16_pitch, dtype=torch.uint16,
+                                 device=device)
+        else:
+            self.x = torch.empty(batch, F, device=device)
         self.row_const = torch.empty(batch, device=device)
         self.eps = torch.empty(self.K, batch, latent, device=device)
         self.generator = torch.Generator(device=device).manual_seed(2)
@@ -333,7 +342,12 @@ class Workload:
             self.cursor = 0
         rows = self.perm[self.cursor + rank * B: self.cursor + (rank + 1) * B]
         self.cursor += GB
-        self.matrix.gather_dense(rows, out=self.x, row_const_out=self.row_const)
+        if self.u16:
+            self.matrix.gather_counts_u16(rows, out=self.x,
+                                          row_const_out=self.row_const)
+        else:
+            self.matrix.gather_dense(rows, out=self.x,
+                                     row_const_out=self.row_const)
         for k in range(self.K):
             philox_normal(self.eps[k], row_offset=k * GB + rank * B, seed=1,
                           stream_id=self.step_counter)
@@ -518,6 +532,9 @@ def main():
             # accumulation (count_gemm.hip); everything else fp32 MFMA / VALU
             "encoder_input_arith": ("bf16x3-exact" if matrix.integer_counts
                                     else "f32"),
+            # storage of the dense minibatch between the CSR gather and its three
+            # readers (integer counts: uint16, exact; the arithmetic stays fp32)
+            "minibatch_storage": "u16" if work.u16 else "f32",
             "data": "synthetic",
             "config": {
                 "workload": describe(args.cells, F, args.likelihood, gm, K, L),

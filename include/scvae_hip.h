@@ -206,8 +206,22 @@ typedef struct scvae_step_args {
    * exact bf16-split kernels (count_gemm.hip: fp32-accurate, 16x the fp32 matrix rate) instead of
    * the fp32 MFMA kernels; 0 (preprocessed / dropped-out / unknown x): fp32 MFMA */
   int32_t x_counts;
+  /* Optional: the minibatch as uint16 counts [cells, F] with row pitch counts_ld (a multiple of 8,
+   * 16-byte aligned base; scvae_csr_densify_u16).  When given, it IS x and t of this step (x and t
+   * may be NULL) and x_counts is implied: the three kernels that stream the minibatch (x W, x^T dA,
+   * the fused likelihood heads) read half the bytes; same arithmetic on the same values, so the
+   * step is bit-identical to the fp32 batch.  Only where scvae_plan_accepts_counts_u16 says so;
+   * anything else is refused with an error. */
+  const uint16_t* counts_u16;
+  int64_t counts_ld;
 } scvae_step_args;
 int scvae_plan_step(scvae_plan* plan, const scvae_step_args* args, void* stream);
+/* 1 if a step of `cells` cells (training or not) of this plan can take its minibatch as uint16
+ * counts: a VAE plan on the fused likelihood kernels (no -k / constrained Poisson, no dropout on
+ * the input layer or the likelihood heads while training, no evaluation statistics requested),
+ * the layer that sees x at most 128 units wide, the count kernels enabled, and a minibatch large
+ * enough for them to pay (the threshold of scvae_plan_set_count_gemm).  0 otherwise. */
+int scvae_plan_accepts_counts_u16(const scvae_plan* plan, int64_t cells, int32_t training);
 /* Decoder only, is_training = False: p_x_mean[rows, F] = mean of p(x|z) for given latent values
  * z[rows, L] -- `session.run(self.p_x_mean, feed_dict={self.z: z, self.is_training: False})`
  * in model.sample() (va:1680-1715; gm:2055-2079, where the one-hot y selects the fed z).
@@ -239,6 +253,12 @@ int scvae_count_gemm(int32_t mode, const float* x, int64_t ldx, int64_t rows, in
                      const float* other, int64_t ld_other, int64_t N, const float* bias,
                      int32_t relu, float* C, int64_t ldc, void* workspace, int64_t workspace_bytes,
                      void* stream);
+/* scvae_count_gemm with x as uint16 counts (row pitch ldx even, x 4-byte aligned): the same
+ * arithmetic on the same values -- bit-identical results */
+int scvae_count_gemm_u16(int32_t mode, const uint16_t* x, int64_t ldx, int64_t rows, int64_t cols,
+                         const float* other, int64_t ld_other, int64_t N, const float* bias,
+                         int32_t relu, float* C, int64_t ldc, void* workspace,
+                         int64_t workspace_bytes, void* stream);
 int64_t scvae_count_gemm_workspace_bytes(int32_t mode, int64_t rows, int64_t cols, int64_t N);
 /* *bad (device int32) = 1 unless every one of the n values is an integer in [0, 65536) */
 int scvae_check_counts(const float* values, int64_t n, int32_t* bad, void* stream);
@@ -287,6 +307,13 @@ int scvae_dropout_apply(const float* in, float* out, int64_t rows, int64_t cols,
 /* minibatch fetch x_train[idx].toarray() (va:985-998) from a device-resident CSR matrix */
 int scvae_csr_densify(const int64_t* indptr, const int32_t* indices, const float* values,
                       const int64_t* rows, int64_t n, int64_t F, float* out, void* stream);
+/* the same minibatch as uint16 counts (precondition: integer counts below 65 536, see
+ * scvae_check_counts) with row pitch ld -- a multiple of 8, ld >= F, ld * 2 <= 152 KiB; out
+ * 16-byte aligned; the pad columns are zeroed.  Half the bytes for the kernels that stream the
+ * minibatch: scvae_step_args.counts_u16 */
+int scvae_csr_densify_u16(const int64_t* indptr, const int32_t* indices, const float* values,
+                          const int64_t* rows, int64_t n, int64_t F, uint16_t* out, int64_t ld,
+                          void* stream);
 int scvae_csr_row_lgamma1p(const int64_t* indptr, const float* values, int64_t n_rows, float* out,
                            void* stream);
 int scvae_gather_rows(const float* src, const int64_t* rows, int64_t n, float* out, void* stream);

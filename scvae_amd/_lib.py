@@ -78,6 +78,8 @@ class StepArgs(Structure):
         ("count_sum", c_void_p),
         ("row_offset", c_int64),
         ("x_counts", c_int32),
+        ("counts_u16", c_void_p),
+        ("counts_ld", c_int64),
     ]
 
 
@@ -112,6 +114,14 @@ SIGNATURES = {
         c_int32, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64,
         c_int64, c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int64,
         c_void_p]),
+    "scvae_plan_accepts_counts_u16": (c_int32, [c_void_p, c_int64, c_int32]),
+    "scvae_count_gemm_u16": (c_int32, [
+        c_int32, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64,
+        c_int64, c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int64,
+        c_void_p]),
+    "scvae_csr_densify_u16": (c_int32, [
+        c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
+        c_int64, c_void_p]),
     "scvae_count_gemm_workspace_bytes": (c_int64, [c_int32, c_int64, c_int64,
                                                    c_int64]),
     "scvae_check_counts": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p]),

@@ -45,6 +45,11 @@ constexpr int CG_ROW = 80;            // LDS bytes per (term, column) row: 64 + 
 constexpr int CG_TM = 64;             // x-side rows per wave (two 32-row tiles)
 constexpr int CG_KPAD = 64;           // the split operand is zero-padded to a multiple of this
 
+// The count matrix arrives as fp32 (any caller) or as uint16 (the minibatch densified for these
+// kernels: half the bytes of the HBM-bound reads); a count converts exactly, the cut into hi / lo
+// is the same arithmetic on the same fp32 value.
+template <typename XT> __device__ __forceinline__ float count_to_f32(XT v) { return (float)v; }
+
 static inline int cg_kpad(int K) { return (K + CG_KPAD - 1) / CG_KPAD * CG_KPAD; }
 static inline int cg_bk(int mode) { return mode == 0 ? 32 : 16; }   // chunk of the mode's kernel
 
@@ -101,9 +106,9 @@ constexpr int CD_BK = 16;
 constexpr int CD_ROW = 48;            // LDS bytes per (term, column) row: 32 + 16 pad
 constexpr int CD_BM = 256;            // genes per workgroup
 
-template <int NT, bool USE_STEADY = false>
+template <int NT, typename XT, bool USE_STEADY = false>
 __global__ __launch_bounds__(256, 2) void count_gemm_dw_kernel(
-    const float* __restrict__ X, int ldx, int M, int K, const uint16_t* __restrict__ T, int Kpad,
+    const XT* __restrict__ X, int ldx, int M, int K, const uint16_t* __restrict__ T, int Kpad,
     int N, int k_chunk, float* __restrict__ out, int ldo) {
   __shared__ __attribute__((aligned(16))) unsigned char Bs[2][3 * CG_NP * CD_ROW];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void count_gemm_dw_kernel(
 
   // raw[slot][t][j]  <->  cell kc + 8 kg + j of gene tile t; uniform row pointer + per-lane
   // 32-bit element offset (gene + 8 kg rows)
-  float raw[2][2][8];
+  XT raw[2][2][8];
   unsigned xoff[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void count_gemm_dw_kernel(
     constexpr int SLOT = decltype(slot_tag)::value;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float* srow = X + (size_t)(kc + j) * ldx;            // uniform: scalar base
+      const XT* srow = X + (size_t)(kc + j) * ldx;               // uniform: scalar base
 #pragma unroll
       for (int t = 0; t < 2; ++t) raw[SLOT][t][j] = srow[xoff[t]];
     }
@@ -181,8 +186,8 @@ __global__ __launch_bounds__(256, 2) void count_gemm_dw_kernel(
       unsigned h[4];
 #pragma unroll
       for (int pr = 0; pr < 4; ++pr) {
-        const unsigned u0 = __float_as_uint(raw[BUF][t][2 * pr]);
-        const unsigned u1 = __float_as_uint(raw[BUF][t][2 * pr + 1]);
+        const unsigned u0 = __float_as_uint(count_to_f32(raw[BUF][t][2 * pr]));
+        const unsigned u1 = __float_as_uint(count_to_f32(raw[BUF][t][2 * pr + 1]));
         low_bits |= u0 | u1;
         h[pr] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);          // upper halves
       }
@@ -196,7 +201,8 @@ __global__ __launch_bounds__(256, 2) void count_gemm_dw_kernel(
         unsigned l[4];
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
-          const float x0 = raw[BUF][t][2 * pr], x1 = raw[BUF][t][2 * pr + 1];
+          const float x0 = count_to_f32(raw[BUF][t][2 * pr]);
+          const float x1 = count_to_f32(raw[BUF][t][2 * pr + 1]);
           const float l0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u);
           const float l1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
           l[pr] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
@@ -284,9 +290,9 @@ static size_t cf_lds_bytes(int NQ) {
   return 4 * (size_t)CF_A_BYTES + 2 * (size_t)(3 * 64 * NQ * CG_ROW) + 2 * 8 * sizeof(int);
 }
 
-template <int NQ>
+template <int NQ, typename XT>
 __global__ __launch_bounds__(512) void count_gemm_fwd_kernel(
-    const float* __restrict__ X, int ldx, int M, int K, const uint16_t* __restrict__ T, int Kpad,
+    const XT* __restrict__ X, int ldx, int M, int K, const uint16_t* __restrict__ T, int Kpad,
     int N, int k_chunk, float* __restrict__ out, int ldo, const float* __restrict__ bias,
     int act, int direct) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cf_smem[];
@@ -316,23 +322,29 @@ __global__ __launch_bounds__(512) void count_gemm_fwd_kernel(
   for (int i = tid; i < 2 * CF_A_BYTES / 16; i += 512)
     reinterpret_cast<u32x4*>(Alo)[i] = u32x4{0u, 0u, 0u, 0u};
 
-  // ---- staging: thread -> 4 pieces (row (tid >> 3) + 64 i, floats 4 (tid & 7) .. + 3) ----
-  const int part = tid & 7;
-  const float* xsrc[4];
+  // ---- staging: 16-byte pieces of the [256, 32] tile; fp32: 8 per row, thread -> 4 pieces (row
+  // (tid >> 3) + 64 i, floats 4 (tid & 7) .. + 3); uint16: 4 per row, thread -> 2 pieces (row
+  // (tid >> 2) + 128 i, counts 8 (tid & 3) .. + 7) ----
+  constexpr int EPP = 16 / (int)sizeof(XT);             // elements per piece
+  constexpr int PPR = CG_BK / EPP;                      // pieces per row
+  constexpr int RPP = 512 / PPR;                        // rows per pass
+  constexpr int PCS = CF_BM / RPP;                      // pieces per thread
+  const int part = tid & (PPR - 1);
+  const XT* xsrc[PCS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = min(m0 + (tid >> 3) + 64 * i, M - 1);
-    xsrc[i] = X + (size_t)m * ldx + 4 * part;
+  for (int i = 0; i < PCS; ++i) {
+    const int m = min(m0 + tid / PPR + RPP * i, M - 1);
+    xsrc[i] = X + (size_t)m * ldx + EPP * part;
   }
-  const int a_off = (tid >> 3) * CG_ROW + part * 8;     // + i * 64 rows
+  const int a_off = (tid / PPR) * CG_ROW + part * (2 * EPP);   // + i * RPP rows
   // two chunks of staging registers: chunk c + 2 is requested while chunk c is multiplied and
   // chunk c + 1 (requested one iteration earlier) is converted and parked -- a full iteration
   // plus the MFMA phase of latency tolerance with a single workgroup per CU
-  f32x4u raw[2][4];
+  f32x4u raw[2][PCS];
   u32x4 breg[2][3];
   auto load_tiles = [&](int kc, int slot) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) raw[slot][i] = *reinterpret_cast<const f32x4u*>(xsrc[i] + kc);
+    for (int i = 0; i < PCS; ++i) raw[slot][i] = *reinterpret_cast<const f32x4u*>(xsrc[i] + kc);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int p = tid + 512 * i;                      // (term, column, quarter)
@@ -344,28 +356,49 @@ __global__ __launch_bounds__(512) void count_gemm_fwd_kernel(
   bool dirty0 = false, dirty1 = false;                  // this wave's lo rows of buffer b are set
   auto store_tiles = [&](int buf, int slot) {
     unsigned low = 0u;
+    // the piece's counts as fp32 bit patterns (uint16: two per loaded dword)
+    auto bits_of = [&](int i, unsigned* u) {
+      if constexpr (sizeof(XT) == 4) {
+        u[0] = __float_as_uint(raw[slot][i].x); u[1] = __float_as_uint(raw[slot][i].y);
+        u[2] = __float_as_uint(raw[slot][i].z); u[3] = __float_as_uint(raw[slot][i].w);
+      } else {
+        const unsigned w[4] = {__float_as_uint(raw[slot][i].x), __float_as_uint(raw[slot][i].y),
+                               __float_as_uint(raw[slot][i].z), __float_as_uint(raw[slot][i].w)};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned u0 = __float_as_uint(raw[slot][i].x), u1 = __float_as_uint(raw[slot][i].y);
-      const unsigned u2 = __float_as_uint(raw[slot][i].z), u3 = __float_as_uint(raw[slot][i].w);
-      low |= u0 | u1 | u2 | u3;
-      uint2 h;
-      h.x = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-      h.y = __builtin_amdgcn_perm(u3, u2, 0x07060302u);
-      *reinterpret_cast<uint2*>(Ahi + buf * CF_A_BYTES + a_off + i * 64 * CG_ROW) = h;
+        for (int j = 0; j < 4; ++j) {
+          u[2 * j] = __float_as_uint((float)(w[j] & 0xFFFFu));
+          u[2 * j + 1] = __float_as_uint((float)(w[j] >> 16));
+        }
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < PCS; ++i) {
+      unsigned u[EPP], h[EPP / 2];
+      bits_of(i, u);
+#pragma unroll
+      for (int j = 0; j < EPP / 2; ++j) {
+        low |= u[2 * j] | u[2 * j + 1];
+        h[j] = __builtin_amdgcn_perm(u[2 * j + 1], u[2 * j], 0x07060302u);     // upper halves
+      }
+      unsigned char* dst = Ahi + buf * CF_A_BYTES + a_off + i * RPP * CG_ROW;
+      if constexpr (EPP == 4) *reinterpret_cast<uint2*>(dst) = uint2{h[0], h[1]};
+      else *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
     }
     const bool need = __builtin_amdgcn_readfirstlane(__any((int)((low & 0xFFFFu) != 0u)));
     if (need || (buf ? dirty1 : dirty0)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float l0 = raw[slot][i].x - __uint_as_float(__float_as_uint(raw[slot][i].x) & 0xFFFF0000u);
-        const float l1 = raw[slot][i].y - __uint_as_float(__float_as_uint(raw[slot][i].y) & 0xFFFF0000u);
-        const float l2 = raw[slot][i].z - __uint_as_float(__float_as_uint(raw[slot][i].z) & 0xFFFF0000u);
-        const float l3 = raw[slot][i].w - __uint_as_float(__float_as_uint(raw[slot][i].w) & 0xFFFF0000u);
-        uint2 l;
-        l.x = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
-        l.y = __builtin_amdgcn_perm(__float_as_uint(l3), __float_as_uint(l2), 0x07060302u);
-        *reinterpret_cast<uint2*>(Alo + buf * CF_A_BYTES + a_off + i * 64 * CG_ROW) = l;
+      for (int i = 0; i < PCS; ++i) {
+        unsigned u[EPP], l[EPP / 2];
+        bits_of(i, u);
+#pragma unroll
+        for (int j = 0; j < EPP / 2; ++j) {
+          const float l0 = __uint_as_float(u[2 * j]) - __uint_as_float(u[2 * j] & 0xFFFF0000u);
+          const float l1 = __uint_as_float(u[2 * j + 1]) - __uint_as_float(u[2 * j + 1] & 0xFFFF0000u);
+          l[j] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+        }
+        unsigned char* dst = Alo + buf * CF_A_BYTES + a_off + i * RPP * CG_ROW;
+        if constexpr (EPP == 4) *reinterpret_cast<uint2*>(dst) = uint2{l[0], l[1]};
+        else *reinterpret_cast<u32x4*>(dst) = u32x4{l[0], l[1], l[2], l[3]};
       }
     }
     if (buf) dirty1 = need; else dirty0 = need;
@@ -482,9 +515,10 @@ __global__ __launch_bounds__(512) void count_gemm_fwd_kernel(
 
 // fixed-order sum of the split-K slabs, + the K % 32 leftover terms of the contraction (plain
 // fp32 fma on the original operands: k_main <= k < K), + bias, activation
+template <typename XT>
 __global__ __launch_bounds__(256) void count_gemm_reduce_kernel(
     const float* __restrict__ slabs, const float* __restrict__ bias, float* __restrict__ C, int M,
-    int N, int ldc, int splits, int act, int mode, const float* __restrict__ X, int ldx,
+    int N, int ldc, int splits, int act, int mode, const XT* __restrict__ X, int ldx,
     const float* __restrict__ other, int ld_other, int k_main, int K) {
   const size_t total = (size_t)M * N;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -493,7 +527,7 @@ __global__ __launch_bounds__(256) void count_gemm_reduce_kernel(
     float s = 0.f;
     for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * total + i];
     for (int k = k_main; k < K; ++k) {
-      const float xv = mode == 0 ? X[(size_t)row * ldx + k] : X[(size_t)k * ldx + row];
+      const float xv = count_to_f32(mode == 0 ? X[(size_t)row * ldx + k] : X[(size_t)k * ldx + row]);
       s = fmaf(xv, other[(size_t)k * ld_other + col], s);
     }
     if (bias) s += bias[col];
@@ -526,12 +560,15 @@ size_t count_gemm_workspace_bytes(int mode, int rows, int cols, int N) {
   return (t_bytes + 255) / 256 * 256 + (size_t)splits * M * N * sizeof(float);
 }
 
-int count_gemm(hipStream_t stream, int mode, const float* x, int ldx, int rows, int cols,
-               const float* other, int ld_other, int N, const float* bias, int act, float* C,
-               int ldc, void* workspace, size_t workspace_bytes) {
+template <typename XT>
+static int count_gemm_impl(hipStream_t stream, int mode, const XT* x, int ldx, int rows, int cols,
+                           const float* other, int ld_other, int N, const float* bias, int act,
+                           float* C, int ldc, void* workspace, size_t workspace_bytes) {
   SCVAE_ARG(x && other && C && workspace);
   SCVAE_ARG(mode == 0 || mode == 1);
   SCVAE_ARG(count_gemm_supported(N) && ld_other >= N && ldc >= N && ldx >= cols);
+  // 16-byte loads of a row need 4-byte aligned rows
+  SCVAE_ARG(sizeof(XT) == 4 || ((ldx & 1) == 0 && ((uintptr_t)x & 3) == 0));
   if (rows == 0 || cols == 0) return 0;
   SCVAE_ARG(workspace_bytes >= count_gemm_workspace_bytes(mode, rows, cols, N));
   SCVAE_ARG(((uintptr_t)workspace & 15) == 0);
@@ -567,7 +604,7 @@ int count_gemm(hipStream_t stream, int mode, const float* x, int ldx, int rows, 
       const size_t lds = cf_lds_bytes(NQ);
 #define SCVAE_CF(NQ_)                                                                             \
   do {                                                                                            \
-    auto kfn = count_gemm_fwd_kernel<NQ_>;                                                        \
+    auto kfn = count_gemm_fwd_kernel<NQ_, XT>;                                                    \
     SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, stream, x, ldx, M, k_main, T, Kpad, N, k_chunk, \
@@ -578,8 +615,8 @@ int count_gemm(hipStream_t stream, int mode, const float* x, int ldx, int rows, 
     } else {
       const dim3 grid((M + CD_BM - 1) / CD_BM, splits);
 #define SCVAE_CD(NT_)                                                                             \
-  hipLaunchKernelGGL((count_gemm_dw_kernel<NT_>), grid, dim3(256), 0, stream, x, ldx, M, k_main,  \
-                     T, Kpad, N, k_chunk, dst, ldo)
+  hipLaunchKernelGGL((count_gemm_dw_kernel<NT_, XT>), grid, dim3(256), 0, stream, x, ldx, M,      \
+                     k_main, T, Kpad, N, k_chunk, dst, ldo)
       switch (NT) { case 1: SCVAE_CD(1); break; case 2: SCVAE_CD(2); break;
                     case 3: SCVAE_CD(3); break; default: SCVAE_CD(4); }
 #undef SCVAE_CD
@@ -590,10 +627,24 @@ int count_gemm(hipStream_t stream, int mode, const float* x, int ldx, int rows, 
   const size_t total = (size_t)M * N;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(count_gemm_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slabs, bias, C,
-                     M, N, ldc, splits, act, mode, x, ldx, other, ld_other, k_main, K);
+  hipLaunchKernelGGL(count_gemm_reduce_kernel<XT>, dim3(blocks), dim3(256), 0, stream, slabs, bias,
+                     C, M, N, ldc, splits, act, mode, x, ldx, other, ld_other, k_main, K);
   SCVAE_LAUNCH_CHECK("count_gemm_reduce_kernel");
   return 0;
+}
+
+int count_gemm(hipStream_t stream, int mode, const float* x, int ldx, int rows, int cols,
+               const float* other, int ld_other, int N, const float* bias, int act, float* C,
+               int ldc, void* workspace, size_t workspace_bytes) {
+  return count_gemm_impl<float>(stream, mode, x, ldx, rows, cols, other, ld_other, N, bias, act, C,
+                                ldc, workspace, workspace_bytes);
+}
+
+int count_gemm_u16(hipStream_t stream, int mode, const uint16_t* x, int ldx, int rows, int cols,
+                   const float* other, int ld_other, int N, const float* bias, int act, float* C,
+                   int ldc, void* workspace, size_t workspace_bytes) {
+  return count_gemm_impl<uint16_t>(stream, mode, x, ldx, rows, cols, other, ld_other, N, bias, act,
+                                   C, ldc, workspace, workspace_bytes);
 }
 
 // ---- precondition check: every value an integer in [0, 65536) ----

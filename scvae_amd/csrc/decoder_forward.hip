@@ -78,7 +78,7 @@ __device__ __forceinline__ float select16(const float (&v)[16], const IndexMasks
 
 template <int KIND, int KS4>
 __global__ __launch_bounds__(512) void decoder_forward_kernel(
-    const float* __restrict__ d, int R, int H, HeadParams hp, int F, const float* __restrict__ t,
+    const float* __restrict__ d, int R, int H, HeadParams hp, int F, Targets tg,
     int B, int inline_lgamma, float* __restrict__ ll_part) {
   using Traits = LikelihoodTraits<KIND>;
   constexpr int P = Traits::P;
@@ -155,23 +155,41 @@ __global__ __launch_bounds__(512) void decoder_forward_kernel(
     const int m0 = tile * BM;
     const int row = m0 + li;
     const bool row_ok = row < R;
-    const float* trow = t + (size_t)((row_ok ? row : R - 1) % B) * F;
+    const size_t trow_off = (size_t)((row_ok ? row : R - 1) % B) * tg.ld;
     float lane_sum = 0.f;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       // ---- t of this lane's 16 elements: genes cbase + 8*(i>>2) + (i&3), row li ----
       const int cbase = c0 + cb * 32 + 4 * kh;
       float tv[16];
+      if (tg.u16) {        // the uint16 minibatch: four counts per 8-byte load (pitch % 8 == 0)
+        const uint16_t* trow = static_cast<const uint16_t*>(tg.p) + trow_off;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int c = cbase + 8 * g;
-        if (c + 3 < F) {   // one 16-byte load (global loads need only 4-byte alignment)
-          typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-          const f32x4u v = *reinterpret_cast<const f32x4u*>(trow + c);
-          tv[4 * g] = v.x; tv[4 * g + 1] = v.y; tv[4 * g + 2] = v.z; tv[4 * g + 3] = v.w;
-        } else {
+        for (int g = 0; g < 4; ++g) {
+          const int c = cbase + 8 * g;
+          if (c + 3 < F) {
+            typedef unsigned u32x2u __attribute__((ext_vector_type(2), aligned(4)));
+            const u32x2u v = *reinterpret_cast<const u32x2u*>(trow + c);
+            tv[4 * g] = (float)(v.x & 0xFFFFu); tv[4 * g + 1] = (float)(v.x >> 16);
+            tv[4 * g + 2] = (float)(v.y & 0xFFFFu); tv[4 * g + 3] = (float)(v.y >> 16);
+          } else {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) tv[4 * g + u] = (c + u < F) ? trow[c + u] : 0.f;
+            for (int u = 0; u < 4; ++u) tv[4 * g + u] = (c + u < F) ? (float)trow[c + u] : 0.f;
+          }
+        }
+      } else {
+        const float* trow = static_cast<const float*>(tg.p) + trow_off;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = cbase + 8 * g;
+          if (c + 3 < F) {   // one 16-byte load (global loads need only 4-byte alignment)
+            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            const f32x4u v = *reinterpret_cast<const f32x4u*>(trow + c);
+            tv[4 * g] = v.x; tv[4 * g + 1] = v.y; tv[4 * g + 2] = v.z; tv[4 * g + 3] = v.w;
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) tv[4 * g + u] = (c + u < F) ? trow[c + u] : 0.f;
+          }
         }
       }
       // ---- pre_j^T[gene, row] = sum_pos Ws_j[pos, gene] * d[row, pos] ----
@@ -242,7 +260,7 @@ __global__ __launch_bounds__(512) void decoder_forward_kernel(
 }
 
 int decoder_forward_launch(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
-                           int F, const float* t, int B, int inline_lgamma, float* ll_part) {
+                           int F, Targets t, int B, int inline_lgamma, float* ll_part) {
   const int P = likelihood_heads(kind);
   const size_t lds = fw_lds_bytes(P, H);
   const int strips = (F + FW_BN - 1) / FW_BN;

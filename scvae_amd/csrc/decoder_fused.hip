@@ -80,7 +80,7 @@ size_t decoder_fused_lds_bytes(int P, int H, bool train) {
 template <int KIND, bool TRAIN, int BM>
 __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
     const float* __restrict__ d, int R, int H, unsigned magic_h, HeadParams hp, int F,
-    const float* __restrict__ t, int B, const float* __restrict__ gw, int inline_lgamma,
+    Targets tg, int B, const float* __restrict__ gw, int inline_lgamma,
     float* __restrict__ ll_part, float* __restrict__ dd_part, int d_buffers) {
   using Traits = LikelihoodTraits<KIND>;
   constexpr int P = Traits::P;
@@ -166,14 +166,15 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
   };
   // element owner: rows er0 + 16 i, columns ec and ec + 32 (one 128-byte row segment per half
   // wave: coalesced HBM loads, conflict-free LDS accesses with the odd stride)
-  auto load_t = [&](int m0, int tq) {
+  auto load_t_from = [&](auto* t, int m0, int tq) {
     const int ec = tq & 31, er0 = tq >> 5;
+    const int ldt = tg.ld;
     if (m0 + BM <= R && c0 + BN <= F && R == B) {   // full tile, no row wrap: no predicates
-      const float* tp = t + (size_t)(m0 + er0) * F + c0 + ec;
+      auto* tp = t + (size_t)(m0 + er0) * ldt + c0 + ec;
 #pragma unroll
       for (int ri = 0; ri < RI; ++ri) {
-        tv[2 * ri] = tp[(size_t)(16 * ri) * F];
-        tv[2 * ri + 1] = tp[(size_t)(16 * ri) * F + 32];
+        tv[2 * ri] = target_raw(tp[(size_t)(16 * ri) * ldt]);
+        tv[2 * ri + 1] = target_raw(tp[(size_t)(16 * ri) * ldt + 32]);
         if (TRAIN) up[ri] = gw[m0 + er0 + 16 * ri];
       }
     } else {
@@ -182,14 +183,20 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
         const int grow = m0 + er0 + 16 * ri;
         const bool rok = grow < R;
         up[ri] = (TRAIN && rok) ? gw[grow] : 0.f;
-        const float* trow = t + (size_t)(rok ? grow % B : 0) * F + c0;
+        auto* trow = t + (size_t)(rok ? grow % B : 0) * ldt + c0;
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci) {
           const int c = ec + 32 * ci;
-          tv[2 * ri + ci] = (rok && c0 + c < F) ? trow[c] : 0.f;
+          tv[2 * ri + ci] = (rok && c0 + c < F) ? target_raw(trow[c]) : 0.f;
         }
       }
     }
+  };
+  // (fp32 batch or the uint16 minibatch: one uniform branch around the loads; the values stay
+  //  raw until they are used)
+  auto load_t = [&](int m0, int tq) {
+    if (tg.u16) load_t_from(static_cast<const uint16_t*>(tg.p), m0, tq);
+    else load_t_from(static_cast<const float*>(tg.p), m0, tq);
   };
 
   load_d(0, tid);
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void decoder_head_kernel(
           const int ri = e >> 1, ci = e & 1;
           const int row = er0 + 16 * ri, c = ec + 32 * ci;
           const bool ok = FULL || ((m0 + row < R) && (c0 + c < F));
-          const float tval = tv[e];
+          const float tval = target_value(tv[e], tg.u16);
           float a[P], g[P], lp, r, rgate;
   #pragma unroll
           for (int j = 0; j < P; ++j) a[j] = Gs[(j * BM + row) * LD + c];
@@ -527,7 +534,7 @@ int decoder_fused_variant(int P, int H) {
 
 template <bool TRAIN>
 static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
-                          int F, const float* t, int B, const float* gw, int inline_lgamma,
+                          int F, Targets t, int B, const float* gw, int inline_lgamma,
                           float* ll_part, float* dd_part) {
   const int P = likelihood_heads(kind);
   if (decoder_fused_variant(P, H) == 2)
@@ -559,9 +566,9 @@ static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int
 
 // Forward only (is_training=False / importance-weight pass): ll[rows]
 int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
-                          int F, const float* t, int B, const float* row_const, float* ll,
+                          int F, Targets t, int B, const float* row_const, float* ll,
                           float* workspace) {
-  SCVAE_ARG(d && t && ll && workspace && decoder_fused_supported(H));
+  SCVAE_ARG(d && t.p && ll && workspace && decoder_fused_supported(H));
   if (rows == 0) return 0;
   const int strips = (F + DF_BN - 1) / DF_BN;
   float* ll_part = workspace;
@@ -586,9 +593,9 @@ int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int
 
 // Forward + backward: ll[rows], dW_j, db_j (in hp), dd[rows, H]
 int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
-                        int F, const float* t, int B, const float* gw, const float* row_const,
+                        int F, Targets t, int B, const float* gw, const float* row_const,
                         float* ll, float* dd, float* workspace, bool kernel_only) {
-  SCVAE_ARG(d && t && gw && ll && dd && workspace && decoder_fused_supported(H));
+  SCVAE_ARG(d && t.p && gw && ll && dd && workspace && decoder_fused_supported(H));
   if (rows == 0) return 0;
   const int strips = (F + DF_BN - 1) / DF_BN;
   float* ll_part = workspace;

@@ -69,7 +69,7 @@ __device__ __forceinline__ void lds_wave_fence() {
 template <int KIND, bool TRAIN>
 __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
     const float* __restrict__ d, int R, int H, unsigned magic_h, HeadParams hp, int F,
-    const float* __restrict__ t, int B, const float* __restrict__ gw, int inline_lgamma,
+    Targets tg, int B, const float* __restrict__ gw, int inline_lgamma,
     float* __restrict__ ll_part, float* __restrict__ dd_part) {
   using Traits = LikelihoodTraits<KIND>;
   constexpr int P = Traits::P;
@@ -229,12 +229,15 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
       load_d(m0 + 2 * BM, tq);
       if (live) {
         const int ec = tq & 31, er0 = tq >> 5;
+        // (fp32 batch or the uint16 minibatch: one uniform branch around the loads)
+        auto load_t = [&](auto* t) {
+        const int ldt = tg.ld;
         if (m0 + BM <= R && c0 + BN <= F && R == B) {   // full tile, no row wrap: no predicates
-          const float* tp = t + (size_t)(m0 + er0) * F + c0 + ec;
-          tv[0] = tp[0];
-          tv[1] = tp[32];
-          tv[2] = tp[(size_t)16 * F];
-          tv[3] = tp[(size_t)16 * F + 32];
+          auto* tp = t + (size_t)(m0 + er0) * ldt + c0 + ec;
+          tv[0] = target_raw(tp[0]);
+          tv[1] = target_raw(tp[32]);
+          tv[2] = target_raw(tp[(size_t)16 * ldt]);
+          tv[3] = target_raw(tp[(size_t)16 * ldt + 32]);
           if (TRAIN) {
             up[0] = gw[m0 + er0];
             up[1] = gw[m0 + er0 + 16];
@@ -245,14 +248,17 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
             const int grow = m0 + er0 + 16 * ri;
             const bool rok = grow < R;
             up[ri] = (TRAIN && rok) ? gw[grow] : 0.f;
-            const float* trow = t + (size_t)(rok ? grow % B : 0) * F + c0;
+            auto* trow = t + (size_t)(rok ? grow % B : 0) * ldt + c0;
 #pragma unroll
             for (int ci = 0; ci < 2; ++ci) {
               const int c = ec + 32 * ci;
-              tv[ri * 2 + ci] = (rok && c0 + c < F) ? trow[c] : 0.f;
+              tv[ri * 2 + ci] = (rok && c0 + c < F) ? target_raw(trow[c]) : 0.f;
             }
           }
         }
+        };
+        if (tg.u16) load_t(static_cast<const uint16_t*>(tg.p));
+        else load_t(static_cast<const float*>(tg.p));
       }
       if (hw < 4) {
         // ---- GEMM3: dd[row, h] = sum_j sum_col G_j[row, col] W_j[h, col] ----
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
         const int ri = e >> 1, ci = e & 1;
         const int row = er0 + 16 * ri, c = ec + 32 * ci;
         const bool ok = FULL || ((m0 + row < R) && (c0 + c < F));
-        const float tval = tv[e];
+        const float tval = target_value(tv[e], tg.u16);
         float a[P], g[P], lp, r, rgate;
 #pragma unroll
         for (int j = 0; j < P; ++j) a[j] = Gs[(j * BM + row) * LD + c];
@@ -453,7 +459,7 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
 
 template <bool TRAIN>
 static int launch_decoder2(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
-                           int F, const float* t, int B, const float* gw, int inline_lgamma,
+                           int F, Targets t, int B, const float* gw, int inline_lgamma,
                            float* ll_part, float* dd_part) {
   const int P = likelihood_heads(kind);
   const size_t lds = decoder_fused2_lds_bytes(P, H);
@@ -480,7 +486,7 @@ static int launch_decoder2(hipStream_t s, int kind, const float* d, int rows, in
 }
 
 int decoder_fused2_launch(hipStream_t s, bool train, int kind, const float* d, int rows, int H,
-                          HeadParams hp, int F, const float* t, int B, const float* gw,
+                          HeadParams hp, int F, Targets t, int B, const float* gw,
                           int inline_lgamma, float* ll_part, float* dd_part) {
   return train ? launch_decoder2<true>(s, kind, d, rows, H, hp, F, t, B, gw, inline_lgamma, ll_part,
                                        dd_part)

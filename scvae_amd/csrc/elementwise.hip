@@ -1503,6 +1503,55 @@ int csr_densify(hipStream_t stream, const int64_t* indptr, const int32_t* indice
   return 0;
 }
 
+// The minibatch as uint16 counts for the kernels that stream it (count_gemm.hip, the fused
+// likelihood heads): half the bytes of the fp32 batch.  Precondition: integer counts below
+// 65 536 (DeviceCSR.integer_counts).  Row pitch ldo: a multiple of 8 (16-byte rows), the pad
+// columns F .. ldo - 1 are zeroed.  The row is assembled in LDS and streamed out once.
+__global__ __launch_bounds__(1024) void csr_densify_u16_kernel(
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const float* __restrict__ values, const int64_t* __restrict__ rows, int F,
+    uint16_t* __restrict__ out, int ldo) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t row16[];
+  const int b = blockIdx.x;
+  const int64_t r = rows[b];
+  const int64_t lo = indptr[r], hi = indptr[r + 1];
+  const int n8 = ldo / 8;
+  uint4* rowv = reinterpret_cast<uint4*>(row16);
+  for (int i = threadIdx.x; i < n8; i += 1024) rowv[i] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  for (int64_t j = lo + threadIdx.x; j < hi; j += 1024) {
+    const int32_t c = indices[j];
+    if (c >= 0 && c < F) row16[c] = (uint16_t)(int)values[j];
+  }
+  __syncthreads();
+  typedef unsigned u32x4nt __attribute__((ext_vector_type(4)));
+  u32x4nt* orow = reinterpret_cast<u32x4nt*>(out + (size_t)b * ldo);
+  for (int i = threadIdx.x; i < n8; i += 1024) {
+    const uint4 v = rowv[i];
+    const u32x4nt q = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(q, orow + i);
+  }
+}
+
+bool csr_densify_u16_supported(int F, int ldo) {
+  return F > 0 && ldo >= F && (ldo & 7) == 0 && (size_t)ldo * 2 <= 152 * 1024;
+}
+
+int csr_densify_u16(hipStream_t stream, const int64_t* indptr, const int32_t* indices,
+                    const float* values, const int64_t* rows, int B, int F, uint16_t* out,
+                    int ldo) {
+  SCVAE_ARG(indptr && indices && values && rows && out);
+  SCVAE_ARG(csr_densify_u16_supported(F, ldo) && ((uintptr_t)out & 15) == 0);
+  if (B == 0) return 0;
+  const size_t lds = (size_t)ldo * 2;
+  SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(csr_densify_u16_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(csr_densify_u16_kernel, dim3(B), dim3(1024), lds, stream, indptr, indices,
+                     values, rows, F, out, ldo);
+  SCVAE_LAUNCH_CHECK("csr_densify_u16_kernel");
+  return 0;
+}
+
 // out[r] = sum_j lgamma(1 + values[j]) over the nonzeros of row r (one wave per row)
 __global__ __launch_bounds__(256) void csr_row_lgamma1p_kernel(const int64_t* __restrict__ indptr,
                                                                const float* __restrict__ values,

@@ -26,6 +26,10 @@ size_t count_gemm_workspace_bytes(int mode, int rows, int cols, int N);
 int count_gemm(hipStream_t stream, int mode, const float* x, int ldx, int rows, int cols,
                const float* other, int ld_other, int N, const float* bias, int act, float* C,
                int ldc, void* workspace, size_t workspace_bytes);
+// the same with x as uint16 counts (row pitch ldx even, base 4-byte aligned)
+int count_gemm_u16(hipStream_t stream, int mode, const uint16_t* x, int ldx, int rows, int cols,
+               const float* other, int ld_other, int N, const float* bias, int act, float* C,
+               int ldc, void* workspace, size_t workspace_bytes);
 // *bad = 1 unless every value is an integer in [0, 65536) (the precondition of count_gemm)
 int check_counts(hipStream_t stream, const float* values, size_t n, int* bad);
 
@@ -160,6 +164,24 @@ int vae_mid_forward(hipStream_t stream, const MidChainArgs& args);
 int vae_mid_backward(hipStream_t stream, const MidChainArgs& args);
 
 // ---- decoder_fused.hip ----
+// where a fused likelihood kernel reads its targets t[row % B, gene] from: fp32 [B, F] (pitch F)
+// or the uint16 minibatch of scvae_csr_densify_u16 (pitch ld; integer counts convert exactly)
+struct Targets {
+  const void* p;
+  int ld;
+  int u16;
+};
+inline Targets targets_f32(const float* t, int F) { return Targets{t, F, 0}; }
+inline Targets targets_u16(const uint16_t* t, int ld) { return Targets{t, ld, 1}; }
+#ifdef __HIPCC__
+// a target as loaded (kept raw while the load is in flight: no instruction touches it) and as
+// the fp32 value the likelihood uses
+__device__ __forceinline__ float target_raw(float v) { return v; }
+__device__ __forceinline__ float target_raw(uint16_t v) { return __uint_as_float((unsigned)v); }
+__device__ __forceinline__ float target_value(float raw, int u16) {
+  return u16 ? (float)__float_as_uint(raw) : raw;
+}
+#endif
 struct HeadParams {
   const float* W[3];
   const float* b[3];
@@ -173,19 +195,19 @@ int decoder_fused_variant(int P, int H);   // 1: decoder_head_kernel, 2: decoder
 bool decoder_fused2_supported(int P, int H);
 size_t decoder_fused2_lds_bytes(int P, int H);
 int decoder_fused2_launch(hipStream_t s, bool train, int kind, const float* d, int rows, int H,
-                          HeadParams hp, int F, const float* t, int B, const float* gw,
+                          HeadParams hp, int F, Targets t, int B, const float* gw,
                           int inline_lgamma, float* ll_part, float* dd_part);
 int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
-                          int F, const float* t, int B, const float* row_const, float* ll,
+                          int F, Targets t, int B, const float* row_const, float* ll,
                           float* workspace);
 int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
-                        int F, const float* t, int B, const float* gw, const float* row_const,
+                        int F, Targets t, int B, const float* gw, const float* row_const,
                         float* ll, float* dd, float* workspace, bool kernel_only = false);
 
 // forward-only variant with the pre-activations in registers (decoder_forward.hip)
 bool decoder_forward_supported(int P, int H);
 int decoder_forward_launch(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
-                           int F, const float* t, int B, int inline_lgamma, float* ll_part);
+                           int F, Targets t, int B, int inline_lgamma, float* ll_part);
 
 // ---- gmvae_kernels.hip ----
 int add_group_rows(hipStream_t s, const float* a0, const float* rows, float* out, int K, int B,
@@ -234,6 +256,10 @@ int adam_clip_step(hipStream_t stream, float* theta, float* grad, float* m, floa
 // CSR row gather + densify (va:985-998)
 int csr_densify(hipStream_t stream, const int64_t* indptr, const int32_t* indices,
                 const float* values, const int64_t* rows, int B, int F, float* out, int ldo);
+bool csr_densify_u16_supported(int F, int ldo);
+int csr_densify_u16(hipStream_t stream, const int64_t* indptr, const int32_t* indices,
+                    const float* values, const int64_t* rows, int B, int F, uint16_t* out,
+                    int ldo);
 int csr_row_lgamma1p(hipStream_t stream, const int64_t* indptr, const float* values, int64_t n_rows,
                      float* out);
 int gather_rows_f32(hipStream_t stream, const float* src, const int64_t* rows, int B, float* out);

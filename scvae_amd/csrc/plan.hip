@@ -184,6 +184,18 @@ size_t plan_x_gemm_workspace_bytes(int cells, int features, int n_out) {
 int plan_gemm(scvae_plan* p, hipStream_t s, bool ta, bool tb, const float* A, const float* B,
               const float* bias, float* C, int M, int N, int K, int lda, int ldb, int ldc, int act,
               bool accumulate) {
+  if (p->x_u16 && A == p->step_x) {
+    // the uint16 minibatch: only the count kernels read it
+    const int mode = ta ? 1 : 0;
+    const int rows = ta ? K : M, cols = ta ? M : K;
+    if (tb || accumulate || !count_gemm_supported(N) ||
+        count_gemm_workspace_bytes(mode, rows, cols, N) > p->gemm_ws_bytes) {
+      set_error("the uint16 minibatch reached a product the count kernels do not cover");
+      return -1;
+    }
+    return count_gemm_u16(s, mode, p->step_u16, p->step_u16_ld, rows, cols, B, ldb, N, bias, act,
+                          C, ldc, p->gemm_ws, p->gemm_ws_bytes);
+  }
   if (p->x_counts && p->use_count_gemm && A == p->step_x && !tb && !accumulate &&
       count_gemm_supported(N)) {
     // x [rows, cols]: forward (x W) contracts over the columns, x^T dA over the rows
@@ -206,6 +218,10 @@ int dense_input(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_
                 bool training, const float** in_out, int* ld_out) {
   *in_out = in; *ld_out = ld_in;
   if (!training || d.keep <= 0.f) return 0;
+  if (p->x_u16 && in == p->step_x) {
+    set_error("dropout on the input layer needs the fp32 minibatch");
+    return -1;
+  }
   int rc = dropout_apply(s, in, ld_in, d.in_drop, d.n_in, rows, d.n_in, d.keep, p->drop_seed,
                          d.site, 0, p->drop_rows);
   if (rc) return rc;
@@ -522,12 +538,12 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
 
   // ---------------- forward ----------------
   const bool mid = mid_chain_ok(p, B, S, training);
-  const float* h = a->x;
+  const float* h = p->step_x;   // (the fp32 batch, or the token of the uint16 one: plan_gemm)
   int ld = F;
   if (mid) {
     // the input-layer product, then everything up to the decoder's output in one workgroup
     Dense& d0 = p->enc[0];
-    if ((rc = plan_gemm(p, s, false, false, a->x, p->params + d0.w, p->params + d0.b, d0.a, B,
+    if ((rc = plan_gemm(p, s, false, false, p->step_x, p->params + d0.w, p->params + d0.b, d0.a, B,
                         d0.n_out, d0.n_in, F, d0.n_out, d0.n_out, ACT_NONE, false)))
       return rc;
     const MidChainArgs q = mid_chain_args(p, a, B, S, training, 0.f);
@@ -602,6 +618,12 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
                      !a->p_x_mean && KM == 0 && !head_drop && c.likelihood <= LK_ZINB;
+  if (p->x_u16 && !fused) {
+    set_error("the uint16 minibatch needs the fused likelihood kernels (no -k / constrained "
+              "Poisson, head dropout or evaluation statistics)");
+    return -1;
+  }
+  const Targets tg = p->x_u16 ? targets_u16(p->step_u16, p->step_u16_ld) : targets_f32(a->t, F);
   const HeadParams hp = head_params(p);
   const float* head_in[4] = {dch, dch, dch, dch};   // [3]: the P_K head
   if (!fused)
@@ -609,7 +631,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   // per-row log-likelihood, forward only
   auto loglik_forward = [&]() -> int {
     if (fused)
-      return decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, a->t, B, a->row_const, p->ll,
+      return decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, tg, B, a->row_const, p->ll,
                                    p->fused_ws);
     if (KM > 0)
       return loglik_cat_fwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->ll, R, B, F);
@@ -675,7 +697,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   if (fused) {
     // heads forward + likelihood + dW_j, db_j, dd in one kernel
-    if ((rc = decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, a->t, B, p->gw,
+    if ((rc = decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, tg, B, p->gw,
                                   a->row_const, p->ll, dcur, p->fused_ws)))
       return rc;
   } else {
@@ -713,7 +735,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     if ((rc = vae_mid_backward(s, q))) return rc;
     p->mid_bar_count += vae_mid_barrier_advance(q, true);
     Dense& d0 = p->enc[0];
-    return plan_gemm(p, s, true, false, a->x, p->dbuf[2], nullptr, p->grads + d0.w, d0.n_in,
+    return plan_gemm(p, s, true, false, p->step_x, p->dbuf[2], nullptr, p->grads + d0.w, d0.n_in,
                      d0.n_out, B, F, d0.n_out, d0.n_out, ACT_NONE, false);
   }
   const int64_t GR = GB * S;  // global decoder rows
@@ -763,7 +785,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   for (int i = (int)p->enc.size() - 1; i >= 0; --i) {
     Dense& d = p->enc[i];
-    const float* in = i > 0 ? p->enc[i - 1].h : a->x;
+    const float* in = i > 0 ? p->enc[i - 1].h : p->step_x;
     const int ld_in = d.n_in;
     float* d_in = i > 0 ? dh_alt : nullptr;
     float* scratch = p->dbuf[2];
@@ -961,11 +983,39 @@ int scvae_plan_decode(scvae_plan* p, const float* z, int64_t rows, float* p_x_me
   return px_statistics(s, c.likelihood, pre, F, 1, R, F, nullptr, 0, 0, p_x_mean, p->mov, p->vom);
 }
 
+int scvae_plan_accepts_counts_u16(const scvae_plan* p, int64_t cells, int32_t training) {
+  if (!p || cells <= 0) return 0;
+  const scvae_model_config& c = p->cfg;
+  if (c.model_type == SCVAE_MODEL_GMVAE) return 0;
+  if (!p->use_count_gemm || !p->use_fused || !p->fused_ws) return 0;
+  if (c.likelihood > scvae::LK_ZINB || c.k_max > 0) return 0;
+  if (!scvae::decoder_fused_supported(p->heads[0].n_in)) return 0;
+  const int n_x = p->enc.empty() ? c.latent_size : p->enc[0].n_out;
+  if (!scvae::count_gemm_supported(n_x)) return 0;
+  if (training) {
+    if (p->heads[0].keep > 0.f) return 0;
+    if (!p->enc.empty() ? p->enc[0].keep > 0.f : (p->mu.keep > 0.f || p->ls.keep > 0.f)) return 0;
+  }
+  // both products on the count kernels by the plan's own rule (plan_gemm)
+  if (p->use_count_gemm < 2 && (double)cells * c.feature_size < 768.0 * 32768.0) return 0;
+  return 1;
+}
+
 int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
   SCVAE_ARG(p && a);
   SCVAE_ARG(p->params && p->ws);
-  SCVAE_ARG(a->x && a->t && a->scalars);
+  const bool u16 = a->counts_u16 != nullptr;
+  SCVAE_ARG((u16 || (a->x && a->t)) && a->scalars);
   SCVAE_ARG(a->cells > 0 && a->cells <= p->max_cells);
+  if (u16) {
+    if (!scvae_plan_accepts_counts_u16(p, a->cells, a->training)) {
+      scvae::set_error("this plan / step does not take a uint16 minibatch "
+                       "(scvae_plan_accepts_counts_u16)");
+      return -1;
+    }
+    SCVAE_ARG(a->counts_ld >= p->cfg.feature_size && (a->counts_ld & 7) == 0 &&
+              ((uintptr_t)a->counts_u16 & 15) == 0);
+  }
   SCVAE_ARG(a->n_iw > 0 && a->n_mc > 0);
   SCVAE_ARG(a->deterministic_z || (int64_t)a->n_iw * a->n_mc <= p->max_samples);
   SCVAE_ARG(a->deterministic_z || a->eps);
@@ -974,8 +1024,13 @@ int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
   SCVAE_ARG(!(a->training && a->deterministic_z));
   SCVAE_ARG(a->row_offset >= 0 &&
             (a->global_cells <= 0 || a->row_offset + a->cells <= a->global_cells));
-  p->step_x = a->x;
-  p->x_counts = a->x_counts != 0;
+  p->x_u16 = u16;
+  p->step_u16 = a->counts_u16;
+  p->step_u16_ld = (int)a->counts_ld;
+  // (the uint16 batch travels through the layers as an opaque token; only plan_gemm, which
+  //  hands it to the count kernels, and the fused likelihood launch look behind it)
+  p->step_x = u16 ? reinterpret_cast<const float*>(a->counts_u16) : a->x;
+  p->x_counts = u16 || a->x_counts != 0;
   p->drop_seed = a->dropout_seed;
   p->drop_rows = RowMap();
   if (a->global_cells > a->cells) {   // a shard of a data-parallel minibatch
@@ -1069,11 +1124,13 @@ int scvae_decoder_fused(int32_t kind, int32_t train, const float* d, int64_t row
   }
   if (train) {
     SCVAE_ARG(dW && db);
-    return scvae::decoder_fused_train((hipStream_t)stream, kind, d, (int)rows, (int)H, hp, (int)F, t,
+    return scvae::decoder_fused_train((hipStream_t)stream, kind, d, (int)rows, (int)H, hp, (int)F,
+                                      scvae::targets_f32(t, (int)F),
                                       (int)cells, gw, row_const, ll, dd, (float*)workspace,
                                       (train & 2) != 0);
   }
-  return scvae::decoder_fused_forward((hipStream_t)stream, kind, d, (int)rows, (int)H, hp, (int)F, t,
+  return scvae::decoder_fused_forward((hipStream_t)stream, kind, d, (int)rows, (int)H, hp, (int)F,
+                                      scvae::targets_f32(t, (int)F),
                                       (int)cells, row_const, ll, (float*)workspace);
 }
 int scvae_likelihood_elementwise(int32_t kind, const float* t, const float* const* pre,
@@ -1097,6 +1154,24 @@ int scvae_dropout_apply(const float* in, float* out, int64_t rows, int64_t cols,
   return scvae::dropout_apply((hipStream_t)stream, in, (int)cols, out, (int)cols, rows, (int)cols,
                               keep, seed, (uint32_t)site, accumulate);
 }
+int scvae_csr_densify_u16(const int64_t* indptr, const int32_t* indices, const float* values,
+                          const int64_t* rows, int64_t n, int64_t F, uint16_t* out, int64_t ld,
+                          void* stream) {
+  return scvae::csr_densify_u16((hipStream_t)stream, indptr, indices, values, rows, (int)n, (int)F,
+                                out, (int)ld);
+}
+
+int scvae_count_gemm_u16(int32_t mode, const uint16_t* x, int64_t ldx, int64_t rows, int64_t cols,
+                         const float* other, int64_t ld_other, int64_t N, const float* bias,
+                         int32_t relu, float* C, int64_t ldc, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
+  SCVAE_ARG(workspace_bytes >= 0);
+  return scvae::count_gemm_u16((hipStream_t)stream, mode, x, (int)ldx, (int)rows, (int)cols, other,
+                               (int)ld_other, (int)N, bias,
+                               relu ? scvae::ACT_RELU : scvae::ACT_NONE, C, (int)ldc, workspace,
+                               (size_t)workspace_bytes);
+}
+
 int scvae_csr_densify(const int64_t* indptr, const int32_t* indices, const float* values,
                       const int64_t* rows, int64_t n, int64_t F, float* out, void* stream) {
   return scvae::csr_densify((hipStream_t)stream, indptr, indices, values, rows, (int)n, (int)F, out,

@@ -147,6 +147,9 @@ struct scvae_plan {
   int use_bn_cols = 1;        // one-launch batch norm for single-group layers (bn_*_cols)
   unsigned* mid_bar = nullptr;   // midchain.hip's grid-barrier counter (workspace, zeroed at bind)
   unsigned mid_bar_count = 0;    // its value once every launch enqueued so far has run
+  bool x_u16 = false;            // this step's minibatch is the uint16 count matrix below
+  const uint16_t* step_u16 = nullptr;
+  int step_u16_ld = 0;
   int use_mid_chain = 1;      // small VAE steps: hidden layers + heads + latent in two launches
   const float* step_x = nullptr;   // this step's x and whether the caller vouches that it holds
   bool x_counts = false;           //  integers in [0, 65536) (scvae_step_args.x_counts)

@@ -385,7 +385,8 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const int use_free_nats = c.free_nats_proportion != 0.f;
   if (!training) {
     if (fused)
-      TRY(decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, a->t, B, a->row_const, p->ll,
+      TRY(decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, targets_f32(a->t, F), B,
+                                a->row_const, p->ll,
                                 p->fused_ws));
     else if (KM > 0)
       TRY(loglik_cat_fwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->ll, R, B, F));
@@ -407,7 +408,8 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   float* dalt = p->dbuf[1];
   float* scratch = p->dbuf[2];
   if (fused) {
-    TRY(decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, a->t, B, p->gw, a->row_const,
+    TRY(decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, targets_f32(a->t, F), B, p->gw,
+                            a->row_const,
                             p->ll, dcur, p->fused_ws));
   } else if (KM > 0) {
     TRY(loglik_cat_bwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->gw, p->ll, R, B, F));

@@ -317,6 +317,13 @@ class Engine:
         _lib.check(self.lib.scvae_plan_set_bn_one_launch(self.handle, mode),
                    "scvae_plan_set_bn_one_launch")
 
+    def accepts_counts_u16(self, cells, training):
+        """Whether a step of ``cells`` cells may take its minibatch as uint16
+        counts (half the bytes for the three kernels that stream it)."""
+        self.reserve(int(cells), 1)
+        return bool(self.lib.scvae_plan_accepts_counts_u16(
+            self.handle, int(cells), 1 if training else 0))
+
     def set_sync(self, callback):
         """Install the data-parallel collective hook (see scvae_sync_fn)."""
         if callback is None:
@@ -341,8 +348,16 @@ class Engine:
         samples = 1 if deterministic_z else n_iw * n_mc
         self.reserve(cells, samples)
         a = _lib.StepArgs()
-        a.x = x.data_ptr()
-        a.t = t.data_ptr()
+        if x.dtype == torch.uint16:
+            # the minibatch as uint16 counts (DeviceCSR.gather_counts_u16): it
+            # is x and t of the step; see accepts_counts_u16()
+            if t is not x or x.dim() != 2 or x.stride(1) != 1:
+                raise ValueError("a uint16 minibatch is both x and t")
+            a.counts_u16 = x.data_ptr()
+            a.counts_ld = x.stride(0)
+        else:
+            a.x = x.data_ptr()
+            a.t = t.data_ptr()
         a.row_const = row_const.data_ptr() if row_const is not None else None
         if self.decoder_extra:
             if (decoder_extra is None or tuple(decoder_extra.shape)

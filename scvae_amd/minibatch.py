@@ -94,6 +94,32 @@ class DeviceCSR:
         return out
 
 
+    @property
+    def u16_pitch(self):
+        """Row pitch (elements) of the uint16 minibatch: whole 128-byte lines."""
+        return (self.shape[1] + 63) // 64 * 64
+
+    def gather_counts_u16(self, rows, out=None, row_const_out=None):
+        """The minibatch as uint16 counts ``[len(rows), u16_pitch]`` (columns past
+        F zeroed) for the kernels that stream it -- integer count matrices only
+        (``integer_counts``).  Pass it to ``Engine.step`` as both x and t."""
+        if not self.integer_counts:
+            raise ValueError("not an integer count matrix below 65 536")
+        n, F, ld = int(rows.numel()), self.shape[1], self.u16_pitch
+        if out is None:
+            out = torch.empty((n, ld), dtype=torch.uint16, device=self.device)
+        stream = current_stream_handle(self.device)
+        _lib.check(self.lib.scvae_csr_densify_u16(
+            _ptr(self.indptr), _ptr(self.indices), _ptr(self.values),
+            _ptr(rows), n, F, _ptr(out), out.stride(0), stream),
+            "scvae_csr_densify_u16")
+        if row_const_out is not None:
+            _lib.check(self.lib.scvae_gather_rows(
+                _ptr(self.row_lgamma1p), _ptr(rows), n, _ptr(row_const_out),
+                stream), "scvae_gather_rows")
+        return out
+
+
 def philox_normal(out, row_offset, seed, stream_id):
     """Fill ``out`` ([rows, cols], fp32, device) with N(0,1) draws keyed by
     (seed, stream_id, row_offset + row, col)."""

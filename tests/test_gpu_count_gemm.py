@@ -222,3 +222,79 @@ def test_training_step_with_and_without_the_count_kernels(cuda_device,
     torch.cuda.synchronize()
     assert torch.equal(eng.grads, g_f)
     assert np.array_equal(plain.cpu().numpy()[:5], s_f[:5])
+
+
+@pytest.mark.parametrize("likelihood", ["negative binomial",
+                                        "zero-inflated negative binomial",
+                                        "poisson"])
+def test_uint16_minibatch_is_the_fp32_step_bit_for_bit(cuda_device, likelihood):
+    """The minibatch densified as uint16 counts (``scvae_csr_densify_u16``,
+    ``scvae_step_args.counts_u16``): the input layer's two products and the
+    fused likelihood heads read half the bytes and do the same arithmetic on
+    the same values -- scalars, per-cell log-likelihood, every gradient and the
+    moving statistics carry identical bits; training and evaluation."""
+    import scipy.sparse as sp
+    from scvae_amd.engine import Engine
+    from scvae_amd.minibatch import DeviceCSR
+    F, L, H, B = 2101, 10, (100, 100), 300     # F: odd pitch for the fp32 batch
+    rng = np.random.default_rng(17)
+    counts = sp.csr_matrix(_counts(rng, 700, F, 0.05))
+    csr = DeviceCSR.from_scipy(counts, cuda_device)
+    assert csr.integer_counts
+    rows = torch.from_numpy(rng.permutation(700)[:B]).to(cuda_device)
+    x32 = csr.gather_dense(rows)
+    rc16 = torch.zeros(B, device=cuda_device)
+    x16 = csr.gather_counts_u16(rows, row_const_out=rc16)
+    assert x16.dtype == torch.uint16 and x16.shape == (B, csr.u16_pitch)
+    assert torch.equal(x16[:, :F].to(torch.float32), x32)
+    assert int(x16[:, F:].to(torch.int32).abs().sum()) == 0
+    eps = torch.from_numpy(rng.standard_normal((2, B, L)).astype(np.float32)
+                           ).to(cuda_device)
+    results = []
+    for u16 in (False, True):
+        eng = Engine(F, L, H, likelihood, batch_norm=True, device=cuda_device,
+                     seed=1)
+        eng.set_count_gemm(True, always=True)
+        assert eng.accepts_counts_u16(B, True) and eng.accepts_counts_u16(B, False)
+        x = x16 if u16 else x32
+        out = []
+        for _ in range(2):
+            ll = torch.zeros(2 * B, device=cuda_device)
+            s = eng.step(x, x, eps=eps, training=True, n_iw=2, row_const=rc16,
+                         x_counts=True, outputs={"log_p_x_given_z": ll}).clone()
+            eng.adam_step(1e-3)
+            out += [s, ll.clone()]
+        ev = eng.step(x, x, eps=eps, training=False, n_iw=2, row_const=rc16,
+                      x_counts=True).clone()
+        det = eng.step(x, x, training=False, deterministic_z=True,
+                       row_const=rc16, x_counts=True).clone()
+        torch.cuda.synchronize()
+        results.append([t.cpu() for t in out + [ev, det, eng.grads, eng.moving,
+                                                eng.params]])
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+
+
+def test_uint16_minibatch_is_refused_where_it_does_not_apply(cuda_device):
+    from scvae_amd.engine import Engine
+    F, L, B = 600, 6, 64
+    x16 = torch.zeros(B, 640, dtype=torch.uint16, device=cuda_device)
+    eps = torch.zeros(1, B, L, device=cuda_device)
+    # a GMVAE plan, and a VAE whose minibatch is too small for the count kernels
+    gm = Engine(F, L, (32,), "negative binomial", batch_norm=True,
+                model_type="GMVAE", n_clusters=3, device=cuda_device, seed=1)
+    assert not gm.accepts_counts_u16(B, True)
+    vae = Engine(F, L, (32,), "negative binomial", batch_norm=True,
+                 device=cuda_device, seed=1)
+    assert not vae.accepts_counts_u16(B, True)
+    with pytest.raises(RuntimeError):
+        vae.step(x16, x16, eps=eps, training=True)
+    vae.set_count_gemm(True, always=True)
+    assert vae.accepts_counts_u16(B, True)
+    # dropout on the input layer reads the fp32 batch
+    drop = Engine(F, L, (32,), "negative binomial", batch_norm=True,
+                  dropout_keep_probabilities=(0, 0.9, 0, 0), device=cuda_device,
+                  seed=1)
+    drop.set_count_gemm(True, always=True)
+    assert not drop.accepts_counts_u16(B, True)
+    assert drop.accepts_counts_u16(B, False)
