@@ -464,6 +464,16 @@ class ModelBase:
             device=device)
         step = int(epoch_start * steps_per_epoch)
         engine.reserve(max(local_batch, 1), samples)
+        # an integer count matrix that is both input and target: the minibatch
+        # is densified as uint16 where the plan takes it (half the bytes for the
+        # three kernels that stream it; the step is bit-identical)
+        u16_buffer = None
+        if (x_train is t_train and getattr(x_train, "integer_counts", False)
+                and hasattr(x_train, "gather_counts_u16")
+                and engine.accepts_counts_u16(max(local_batch, 1), True)):
+            u16_buffer = torch.empty(
+                max(local_batch, 1), x_train.u16_pitch, dtype=torch.uint16,
+                device=device)
         engine.scalars.zero_()   # incl. the sticky non-finite-step counter [7]
 
         from scvae_amd.minibatch import philox_normal
@@ -501,9 +511,14 @@ class ModelBase:
                 xb = x_buffer[:cells]
                 tb = t_buffer[:cells]
                 rc = row_const[:cells]
-                t_train.gather_dense(rows, out=tb, row_const_out=rc)
-                if x_train is not t_train:
-                    x_train.gather_dense(rows, out=xb)
+                if (u16_buffer is not None
+                        and engine.accepts_counts_u16(cells, True)):
+                    xb = tb = x_train.gather_counts_u16(
+                        rows, out=u16_buffer[:cells], row_const_out=rc)
+                else:
+                    t_train.gather_dense(rows, out=tb, row_const_out=rc)
+                    if x_train is not t_train:
+                        x_train.gather_dense(rows, out=xb)
                 eps = eps_buffer[:int(numpy.prod(
                     self._eps_shape(samples, cells)))]
                 self._draw_noise(eps, samples, cells, global_cells, lo, step)

@@ -170,6 +170,40 @@ def test_training_loop_matches_oracle(tmp_path, cuda_device):
     assert abs(got - expected) <= 1e-4 * abs(expected)
 
 
+def test_training_loop_on_the_uint16_minibatch(tmp_path, cuda_device):
+    """``model.train`` densifies an integer count matrix as uint16 where the
+    plan takes it (``Engine.accepts_counts_u16``; forced here -- the data set is
+    far below the size where the count kernels pay): same weights, same
+    learning curves as the fp32 minibatch on the fp32 MFMA kernels, to fp32
+    rounding (bit-identity against the fp32 batch on the same kernels:
+    tests/test_gpu_count_gemm.py)."""
+    from scvae_amd.models import VariationalAutoencoder
+    from scvae_amd.models.utilities import load_learning_curves
+    n, F, L, B = 70, 40, 3, 32          # two full minibatches and a short one
+    data = _data(n, F, labels=False)
+    results = []
+    for force in (True, False):
+        model = VariationalAutoencoder(
+            feature_size=F, latent_size=L, hidden_sizes=[10, 10],
+            reconstruction_distribution="negative binomial",
+            log_directory=str(tmp_path / ("u16" if force else "f32")),
+            device=cuda_device)
+        model.engine.set_count_gemm(True, always=force)
+        assert model.engine.accepts_counts_u16(B, True) == force
+        np.random.seed(11)
+        model.train(data, None, number_of_epochs=2, minibatch_size=B,
+                    learning_rate=1e-3)
+        curves = load_learning_curves(model)["training"]
+        results.append((model.engine.params.clone().cpu(),
+                        model.engine.moving.clone().cpu(),
+                        torch.tensor(curves["lower_bound"])))
+    # (the fp32 run takes the fp32 MFMA kernels for the input layer: equal to
+    #  rounding, not to the bit)
+    for a, b in zip(*results):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 1e-5 * scale + 1e-9
+
+
 def test_cli_train_and_evaluate(tmp_path, cuda_device, capsys):
     from scvae_amd import cli
     arguments = ["synthetic_1k", "-M", str(tmp_path), "-r",
