@@ -196,7 +196,7 @@ def cpu_baseline(matrix, batch):
 # ----------------------------------------------------------------------------
 # roofline of the dominant kernel
 # ----------------------------------------------------------------------------
-def _measured_traffic(rows, F, H, kernel):
+def _measured_traffic(rows, F, H, kernel, targets="f32"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3
     PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section);
     only reported when the profiled kernel and shapes are the benchmarked ones."""
@@ -210,16 +210,18 @@ def _measured_traffic(rows, F, H, kernel):
         except (OSError, ValueError):
             continue
         if (pmc.get("kernel") == "scvae::" + kernel and pmc.get("rows") == rows
-                and pmc.get("features") == F and pmc.get("hidden") == H):
+                and pmc.get("features") == F and pmc.get("hidden") == H
+                and pmc.get("targets", "f32") == targets):
             return pmc["traffic_bytes_per_launch"]
     return None
 
 
-def time_dominant_kernel(engine, rows, launches=10):
+def time_dominant_kernel(engine, rows, launches=10, u16=False):
     """Average duration (HIP events on the launch stream) of the dominant
     kernel of the step -- the fused decoder-head kernel -- run standalone on
     the step's own shapes (main kernel only, without its two small reductions,
-    so that the figure matches rocprofv3's per-kernel average)."""
+    so that the figure matches rocprofv3's per-kernel average).  ``u16``: the
+    targets as the uint16 minibatch, as the step launches it."""
     import torch
     from scvae_amd import _lib
     lib = engine.lib
@@ -249,7 +251,20 @@ def time_dominant_kernel(engine, rows, launches=10):
     aW, ab, adW, adb = arr(W), arr(b), arr(dW), arr(db)
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
+    if u16:
+        ld = (F + 63) // 64 * 64
+        t16 = torch.zeros(rows, ld, dtype=torch.int32, device=dev)
+        t16[:, :F] = t.to(torch.int32)
+        t16 = t16.to(torch.uint16)
+
     def launch():
+        if u16:
+            _lib.check(lib.scvae_decoder_fused_u16(
+                kind, 3, d.data_ptr(), rows, H, aW, ab, adW, adb, F,
+                t16.data_ptr(), ld, rows, gw.data_ptr(), rc.data_ptr(),
+                ll.data_ptr(), dd.data_ptr(), ws.data_ptr(), stream),
+                "scvae_decoder_fused_u16")
+            return
         _lib.check(lib.scvae_decoder_fused(
             kind, 3, d.data_ptr(), rows, H, aW, ab, adW, adb, F, t.data_ptr(),
             rows, gw.data_ptr(), rc.data_ptr(), ll.data_ptr(), dd.data_ptr(),
@@ -279,7 +294,8 @@ def time_dominant_kernel(engine, rows, launches=10):
         "peak": PEAK_FP32_MFMA_TFLOPS,
         "unit": "TFLOP/s",
         "frac": flops / seconds / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-        "traffic": _measured_traffic(rows, F, H, kernel),
+        "traffic": _measured_traffic(rows, F, H, kernel, "u16" if u16 else "f32"),
+        "targets": "u16" if u16 else "f32",
         "launch_us": seconds * 1e6,
         "algorithmic_flop_per_launch": flops,
     }
@@ -557,7 +573,7 @@ def main():
         if gm:   # informational run: per-cell flops of the VAE formula do not apply
             result["train_flop_per_cell"] = None
             result["step_mfma_frac"] = None
-        result["roofline"] = time_dominant_kernel(engine, B * K)
+        result["roofline"] = time_dominant_kernel(engine, B * K, u16=work.u16)
         headline = (not gm and args.likelihood == LIKELIHOOD and L == LATENT)
         if world == 1 and headline and not args.no_other_workloads:
             result["other_workloads"] = other_workloads(matrix, device, barrier)

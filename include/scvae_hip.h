@@ -285,6 +285,13 @@ int scvae_decoder_fused(int32_t kind, int32_t train, const float* d, int64_t row
                         float* const* db, int64_t F, const float* t, int64_t cells,
                         const float* gw, const float* row_const, float* ll, float* dd,
                         void* workspace, void* stream);
+/* the same with the targets as the uint16 minibatch of scvae_csr_densify_u16 (row pitch ldt, a
+ * multiple of 8; t 16-byte aligned): what a step given scvae_step_args.counts_u16 launches */
+int scvae_decoder_fused_u16(int32_t kind, int32_t train, const float* d, int64_t rows, int64_t H,
+                            const float* const* W, const float* const* b, float* const* dW,
+                            float* const* db, int64_t F, const uint16_t* t, int64_t ldt,
+                            int64_t cells, const float* gw, const float* row_const, float* ll,
+                            float* dd, void* workspace, void* stream);
 /* element-wise .log_prob(t) / .mean() / .variance() of the DISTRIBUTIONS registry classes
  * (scvae/distributions/utilities.py:206-305, zero_inflated.py:180-199); pre = head
  * pre-activations (n elements each); log_prob and/or (mean, variance) may be NULL */

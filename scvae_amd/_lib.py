@@ -151,6 +151,11 @@ SIGNATURES = {
         POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int64,
         c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
         c_void_p]),
+    "scvae_decoder_fused_u16": (c_int32, [
+        c_int32, c_int32, c_void_p, c_int64, c_int64, POINTER(c_void_p),
+        POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int64,
+        c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+        c_void_p, c_void_p]),
     "scvae_likelihood_elementwise": (c_int32, [
         c_int32, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p,
         c_int64, c_void_p]),

@@ -1107,11 +1107,11 @@ int32_t scvae_decoder_fused_variant(int32_t kind, int64_t H) {
   if (kind < 0 || kind > 3 || !scvae::decoder_fused_supported((int)H)) return 0;
   return scvae::decoder_fused_variant(scvae::likelihood_heads(kind), (int)H);
 }
-int scvae_decoder_fused(int32_t kind, int32_t train, const float* d, int64_t rows, int64_t H,
-                        const float* const* W, const float* const* b, float* const* dW,
-                        float* const* db, int64_t F, const float* t, int64_t cells,
-                        const float* gw, const float* row_const, float* ll, float* dd,
-                        void* workspace, void* stream) {
+static int decoder_fused_entry(int32_t kind, int32_t train, const float* d, int64_t rows, int64_t H,
+                               const float* const* W, const float* const* b, float* const* dW,
+                               float* const* db, int64_t F, scvae::Targets t, int64_t cells,
+                               const float* gw, const float* row_const, float* ll, float* dd,
+                               void* workspace, void* stream) {
   SCVAE_ARG(kind >= 0 && kind <= 3 && W && b);
   SCVAE_ARG(scvae::decoder_fused_supported((int)H));
   scvae::HeadParams hp;
@@ -1125,13 +1125,30 @@ int scvae_decoder_fused(int32_t kind, int32_t train, const float* d, int64_t row
   if (train) {
     SCVAE_ARG(dW && db);
     return scvae::decoder_fused_train((hipStream_t)stream, kind, d, (int)rows, (int)H, hp, (int)F,
-                                      scvae::targets_f32(t, (int)F),
-                                      (int)cells, gw, row_const, ll, dd, (float*)workspace,
+                                      t, (int)cells, gw, row_const, ll, dd, (float*)workspace,
                                       (train & 2) != 0);
   }
   return scvae::decoder_fused_forward((hipStream_t)stream, kind, d, (int)rows, (int)H, hp, (int)F,
-                                      scvae::targets_f32(t, (int)F),
-                                      (int)cells, row_const, ll, (float*)workspace);
+                                      t, (int)cells, row_const, ll, (float*)workspace);
+}
+int scvae_decoder_fused(int32_t kind, int32_t train, const float* d, int64_t rows, int64_t H,
+                        const float* const* W, const float* const* b, float* const* dW,
+                        float* const* db, int64_t F, const float* t, int64_t cells,
+                        const float* gw, const float* row_const, float* ll, float* dd,
+                        void* workspace, void* stream) {
+  return decoder_fused_entry(kind, train, d, rows, H, W, b, dW, db, F,
+                             scvae::targets_f32(t, (int)F), cells, gw, row_const, ll, dd,
+                             workspace, stream);
+}
+int scvae_decoder_fused_u16(int32_t kind, int32_t train, const float* d, int64_t rows, int64_t H,
+                            const float* const* W, const float* const* b, float* const* dW,
+                            float* const* db, int64_t F, const uint16_t* t, int64_t ldt,
+                            int64_t cells, const float* gw, const float* row_const, float* ll,
+                            float* dd, void* workspace, void* stream) {
+  SCVAE_ARG(t && ldt >= F && (ldt & 7) == 0 && ((uintptr_t)t & 15) == 0);
+  return decoder_fused_entry(kind, train, d, rows, H, W, b, dW, db, F,
+                             scvae::targets_u16(t, (int)ldt), cells, gw, row_const, ll, dd,
+                             workspace, stream);
 }
 int scvae_likelihood_elementwise(int32_t kind, const float* t, const float* const* pre,
                                  float* log_prob, float* mean, float* variance, int64_t n,
