@@ -314,6 +314,14 @@ int scvae_dropout_apply(const float* in, float* out, int64_t rows, int64_t cols,
 /* minibatch fetch x_train[idx].toarray() (va:985-998) from a device-resident CSR matrix */
 int scvae_csr_densify(const int64_t* indptr, const int32_t* indices, const float* values,
                       const int64_t* rows, int64_t n, int64_t F, float* out, void* stream);
+/* One launch for the whole minibatch fetch: the dense rows as fp32 (as_u16 = 0: out float
+ * [n, ld], ld >= F) or as uint16 counts (as_u16 = 1: see scvae_csr_densify_u16) and, when
+ * row_values_out is given, row_values_out[i] = row_values[rows[i]] -- the per-cell lgamma term
+ * of scvae_csr_row_lgamma1p that the step takes as row_const */
+int scvae_csr_minibatch(const int64_t* indptr, const int32_t* indices, const float* values,
+                        const int64_t* rows, int64_t n, int64_t F, void* out, int64_t ld,
+                        int32_t as_u16, const float* row_values, float* row_values_out,
+                        void* stream);
 /* the same minibatch as uint16 counts (precondition: integer counts below 65 536, see
  * scvae_check_counts) with row pitch ld -- a multiple of 8, ld >= F, ld * 2 <= 152 KiB; out
  * 16-byte aligned; the pad columns are zeroed.  Half the bytes for the kernels that stream the

@@ -119,6 +119,9 @@ SIGNATURES = {
         c_int32, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64,
         c_int64, c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int64,
         c_void_p]),
+    "scvae_csr_minibatch": (c_int32, [
+        c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
+        c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "scvae_csr_densify_u16": (c_int32, [
         c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
         c_int64, c_void_p]),

@@ -1426,9 +1426,12 @@ __global__ __launch_bounds__(256) void csr_densify_kernel(const int64_t* __restr
                                                           const int32_t* __restrict__ indices,
                                                           const float* __restrict__ values,
                                                           const int64_t* __restrict__ rows, int F,
-                                                          float* __restrict__ out, int ldo) {
+                                                          float* __restrict__ out, int ldo,
+                                                          const float* __restrict__ row_values,
+                                                          float* __restrict__ row_values_out) {
   const int b = blockIdx.x;
   const int64_t r = rows[b];
+  if (row_values_out != nullptr && threadIdx.x == 0) row_values_out[b] = row_values[r];
   const int64_t lo = indptr[r], hi = indptr[r + 1];
   float* orow = out + (size_t)b * ldo;
   // head elements up to the first 16-byte boundary, float4 body, scalar tail
@@ -1455,10 +1458,13 @@ __global__ __launch_bounds__(256) void csr_densify_kernel(const int64_t* __restr
 __global__ __launch_bounds__(1024) void csr_densify_lds_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
     const float* __restrict__ values, const int64_t* __restrict__ rows, int F,
-    float* __restrict__ out, int ldo) {
+    float* __restrict__ out, int ldo, const float* __restrict__ row_values,
+    float* __restrict__ row_values_out) {
   extern __shared__ __attribute__((aligned(16))) float row[];
   const int b = blockIdx.x;
   const int64_t r = rows[b];
+  // (a per-row value of the matrix gathered on the way: the lgamma term of the likelihoods)
+  if (row_values_out != nullptr && threadIdx.x == 0) row_values_out[b] = row_values[r];
   const int64_t lo = indptr[r], hi = indptr[r + 1];
   const int n4 = (F + 3) / 4;
   float4* row4 = reinterpret_cast<float4*>(row);
@@ -1485,20 +1491,22 @@ __global__ __launch_bounds__(1024) void csr_densify_lds_kernel(
 }
 
 int csr_densify(hipStream_t stream, const int64_t* indptr, const int32_t* indices,
-                const float* values, const int64_t* rows, int B, int F, float* out, int ldo) {
+                const float* values, const int64_t* rows, int B, int F, float* out, int ldo,
+                const float* row_values, float* row_values_out) {
   SCVAE_ARG(indptr && indices && values && rows && out && F > 0 && ldo >= F);
+  SCVAE_ARG(row_values_out == nullptr || row_values != nullptr);
   if (B == 0) return 0;
   const size_t lds = ((size_t)F + 3) / 4 * 16;
   if (lds <= 152 * 1024) {
     SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(csr_densify_lds_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(csr_densify_lds_kernel, dim3(B), dim3(1024), lds, stream, indptr, indices,
-                       values, rows, F, out, ldo);
+                       values, rows, F, out, ldo, row_values, row_values_out);
     SCVAE_LAUNCH_CHECK("csr_densify_lds_kernel");
     return 0;
   }
   hipLaunchKernelGGL(csr_densify_kernel, dim3(B), dim3(256), 0, stream, indptr, indices, values,
-                     rows, F, out, ldo);
+                     rows, F, out, ldo, row_values, row_values_out);
   SCVAE_LAUNCH_CHECK("csr_densify_kernel");
   return 0;
 }
@@ -1510,10 +1518,12 @@ int csr_densify(hipStream_t stream, const int64_t* indptr, const int32_t* indice
 __global__ __launch_bounds__(1024) void csr_densify_u16_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
     const float* __restrict__ values, const int64_t* __restrict__ rows, int F,
-    uint16_t* __restrict__ out, int ldo) {
+    uint16_t* __restrict__ out, int ldo, const float* __restrict__ row_values,
+    float* __restrict__ row_values_out) {
   extern __shared__ __attribute__((aligned(16))) uint16_t row16[];
   const int b = blockIdx.x;
   const int64_t r = rows[b];
+  if (row_values_out != nullptr && threadIdx.x == 0) row_values_out[b] = row_values[r];
   const int64_t lo = indptr[r], hi = indptr[r + 1];
   const int n8 = ldo / 8;
   uint4* rowv = reinterpret_cast<uint4*>(row16);
@@ -1539,15 +1549,16 @@ bool csr_densify_u16_supported(int F, int ldo) {
 
 int csr_densify_u16(hipStream_t stream, const int64_t* indptr, const int32_t* indices,
                     const float* values, const int64_t* rows, int B, int F, uint16_t* out,
-                    int ldo) {
+                    int ldo, const float* row_values, float* row_values_out) {
   SCVAE_ARG(indptr && indices && values && rows && out);
+  SCVAE_ARG(row_values_out == nullptr || row_values != nullptr);
   SCVAE_ARG(csr_densify_u16_supported(F, ldo) && ((uintptr_t)out & 15) == 0);
   if (B == 0) return 0;
   const size_t lds = (size_t)ldo * 2;
   SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(csr_densify_u16_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(csr_densify_u16_kernel, dim3(B), dim3(1024), lds, stream, indptr, indices,
-                     values, rows, F, out, ldo);
+                     values, rows, F, out, ldo, row_values, row_values_out);
   SCVAE_LAUNCH_CHECK("csr_densify_u16_kernel");
   return 0;
 }

@@ -255,11 +255,12 @@ int adam_clip_step(hipStream_t stream, float* theta, float* grad, float* m, floa
 
 // CSR row gather + densify (va:985-998)
 int csr_densify(hipStream_t stream, const int64_t* indptr, const int32_t* indices,
-                const float* values, const int64_t* rows, int B, int F, float* out, int ldo);
+                const float* values, const int64_t* rows, int B, int F, float* out, int ldo,
+                const float* row_values = nullptr, float* row_values_out = nullptr);
 bool csr_densify_u16_supported(int F, int ldo);
 int csr_densify_u16(hipStream_t stream, const int64_t* indptr, const int32_t* indices,
                     const float* values, const int64_t* rows, int B, int F, uint16_t* out,
-                    int ldo);
+                    int ldo, const float* row_values = nullptr, float* row_values_out = nullptr);
 int csr_row_lgamma1p(hipStream_t stream, const int64_t* indptr, const float* values, int64_t n_rows,
                      float* out);
 int gather_rows_f32(hipStream_t stream, const float* src, const int64_t* rows, int B, float* out);

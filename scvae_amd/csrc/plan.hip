@@ -1171,6 +1171,19 @@ int scvae_dropout_apply(const float* in, float* out, int64_t rows, int64_t cols,
   return scvae::dropout_apply((hipStream_t)stream, in, (int)cols, out, (int)cols, rows, (int)cols,
                               keep, seed, (uint32_t)site, accumulate);
 }
+int scvae_csr_minibatch(const int64_t* indptr, const int32_t* indices, const float* values,
+                        const int64_t* rows, int64_t n, int64_t F, void* out, int64_t ld,
+                        int32_t as_u16, const float* row_values, float* row_values_out,
+                        void* stream) {
+  SCVAE_ARG(as_u16 == 0 || as_u16 == 1);
+  if (as_u16)
+    return scvae::csr_densify_u16((hipStream_t)stream, indptr, indices, values, rows, (int)n,
+                                  (int)F, static_cast<uint16_t*>(out), (int)ld, row_values,
+                                  row_values_out);
+  return scvae::csr_densify((hipStream_t)stream, indptr, indices, values, rows, (int)n, (int)F,
+                            static_cast<float*>(out), (int)ld, row_values, row_values_out);
+}
+
 int scvae_csr_densify_u16(const int64_t* indptr, const int32_t* indices, const float* values,
                           const int64_t* rows, int64_t n, int64_t F, uint16_t* out, int64_t ld,
                           void* stream) {

@@ -84,13 +84,12 @@ class DeviceCSR:
         if out is None:
             out = torch.empty((n, F), dtype=torch.float32, device=self.device)
         stream = current_stream_handle(self.device)
-        _lib.check(self.lib.scvae_csr_densify(
+        _lib.check(self.lib.scvae_csr_minibatch(
             _ptr(self.indptr), _ptr(self.indices), _ptr(self.values),
-            _ptr(rows), n, F, _ptr(out), stream), "scvae_csr_densify")
-        if row_const_out is not None:
-            _lib.check(self.lib.scvae_gather_rows(
-                _ptr(self.row_lgamma1p), _ptr(rows), n, _ptr(row_const_out),
-                stream), "scvae_gather_rows")
+            _ptr(rows), n, F, _ptr(out), out.stride(0), 0,
+            _ptr(self.row_lgamma1p),
+            _ptr(row_const_out) if row_const_out is not None else None,
+            stream), "scvae_csr_minibatch")
         return out
 
 
@@ -109,14 +108,12 @@ class DeviceCSR:
         if out is None:
             out = torch.empty((n, ld), dtype=torch.uint16, device=self.device)
         stream = current_stream_handle(self.device)
-        _lib.check(self.lib.scvae_csr_densify_u16(
+        _lib.check(self.lib.scvae_csr_minibatch(
             _ptr(self.indptr), _ptr(self.indices), _ptr(self.values),
-            _ptr(rows), n, F, _ptr(out), out.stride(0), stream),
-            "scvae_csr_densify_u16")
-        if row_const_out is not None:
-            _lib.check(self.lib.scvae_gather_rows(
-                _ptr(self.row_lgamma1p), _ptr(rows), n, _ptr(row_const_out),
-                stream), "scvae_gather_rows")
+            _ptr(rows), n, F, _ptr(out), out.stride(0), 1,
+            _ptr(self.row_lgamma1p),
+            _ptr(row_const_out) if row_const_out is not None else None,
+            stream), "scvae_csr_minibatch")
         return out
 
 
