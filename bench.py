@@ -351,7 +351,7 @@ class Workload:
                                    generator=self.generator, device=self.device)
 
     def one_step(self):
-        from scvae_amd.minibatch import philox_normal
+        from scvae_amd.minibatch import philox_normal_blocks
         n, B, GB, rank = self.matrix.number_of_rows, self.B, self.GB, self.rank
         if self.cursor + GB > n:
             self.perm = self._permutation()
@@ -364,9 +364,8 @@ class Workload:
         else:
             self.matrix.gather_dense(rows, out=self.x,
                                      row_const_out=self.row_const)
-        for k in range(self.K):
-            philox_normal(self.eps[k], row_offset=k * GB + rank * B, seed=1,
-                          stream_id=self.step_counter)
+        philox_normal_blocks(self.eps, block_stride=GB, row_offset=rank * B,
+                             seed=1, stream_id=self.step_counter)
         self.step_counter += 1
         self.engine.step(self.x, self.x, eps=self.eps, row_const=self.row_const,
                          training=True, global_cells=GB, row_offset=rank * B,

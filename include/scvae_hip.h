@@ -336,6 +336,12 @@ int scvae_gather_rows(const float* src, const int64_t* rows, int64_t n, float* o
  * key = (seed_lo, seed_hi ^ stream_id_hi), counter = (row_lo, row_hi, col / 4, stream_id_lo) */
 int scvae_philox_normal(float* out, int64_t rows, int64_t cols, int64_t row_offset, uint64_t seed,
                         uint64_t stream_id, void* stream);
+/* the same for out[blocks][block_rows][cols] in one launch: row r of block g is row
+ * `g * block_stride + row_offset + r` of the noise field -- the stacked passes (GMVAE clusters,
+ * importance / Monte-Carlo samples) of a rank's shard of a global minibatch of block_stride cells */
+int scvae_philox_normal_blocks(float* out, int64_t blocks, int64_t block_rows, int64_t cols,
+                               int64_t block_stride, int64_t row_offset, uint64_t seed,
+                               uint64_t stream_id, void* stream);
 /* batch-norm statistic merge for the data-parallel hook: gathered = [ranks][mean(n)|var(n)],
  * counts = rows per rank (DEVICE int64 array) -> out [mean(n)|var(n)] */
 int scvae_bn_merge(const float* gathered, const int64_t* counts, int64_t ranks, int64_t n,

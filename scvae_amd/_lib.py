@@ -174,6 +174,9 @@ SIGNATURES = {
         c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "scvae_philox_normal": (c_int32, [
         c_void_p, c_int64, c_int64, c_int64, c_uint64, c_uint64, c_void_p]),
+    "scvae_philox_normal_blocks": (c_int32, [
+        c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_uint64,
+        c_uint64, c_void_p]),
     "scvae_dropout_apply": (c_int32, [
         c_void_p, c_void_p, c_int64, c_int64, c_float, c_uint64, c_int32,
         c_int32, c_void_p]),

@@ -1615,8 +1615,12 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
 
 // thread per (row, group of 4 columns): counter = (row_lo, row_hi, col_group, stream_id),
 // key = seed.  u = ((x >> 8) + 0.5) * 2^-24; Box-Muller on (u0,u1) and (u2,u3).
+// Rows may come in blocks (the stacked passes of a sharded minibatch): row r of the buffer is
+// row `(r / block_rows) * block_stride + row_offset + r % block_rows` of the noise field.
 __global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, int64_t rows,
                                                             int cols, int64_t row_offset,
+                                                            int64_t block_rows,
+                                                            int64_t block_stride,
                                                             uint32_t seed_lo, uint32_t seed_hi,
                                                             uint32_t stream_id) {
   const int groups = (cols + 3) / 4;
@@ -1625,7 +1629,8 @@ __global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ 
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = i / groups;
     const int cg = (int)(i % groups);
-    const uint64_t grow = (uint64_t)(row + row_offset);
+    const uint64_t grow =
+        (uint64_t)((row / block_rows) * block_stride + row_offset + row % block_rows);
     uint32_t c[4] = {(uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)cg, stream_id};
     uint32_t k0 = seed_lo, k1 = seed_hi;
 #pragma unroll
@@ -1651,14 +1656,16 @@ __global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ 
 }
 
 int philox_normal(hipStream_t stream, float* out, int64_t rows, int cols, int64_t row_offset,
-                  uint64_t seed, uint64_t stream_id) {
+                  uint64_t seed, uint64_t stream_id, int64_t block_rows, int64_t block_stride) {
   SCVAE_ARG(out && rows >= 0 && cols > 0);
   if (rows == 0) return 0;
+  if (block_rows <= 0) { block_rows = rows; block_stride = 0; }   // one block: rows as they are
+  SCVAE_ARG(block_stride >= 0);
   const int64_t total = rows * ((cols + 3) / 4);
   int64_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, out, rows,
-                     cols, row_offset, (uint32_t)seed,
+                     cols, row_offset, block_rows, block_stride, (uint32_t)seed,
                      // the high half of the 64-bit stream id goes into the key (callers use the
                      // high bits as domain separators: evaluation passes, model.sample())
                      (uint32_t)(seed >> 32) ^ (uint32_t)(stream_id >> 32), (uint32_t)stream_id);

@@ -268,7 +268,8 @@ int gather_rows_f32(hipStream_t stream, const float* src, const int64_t* rows, i
 // counter-based standard-normal draws (Philox4x32-10 + Box-Muller), keyed by
 // (seed, stream id, global row, column): identical for any sharding of the rows
 int philox_normal(hipStream_t stream, float* out, int64_t rows, int cols, int64_t row_offset,
-                  uint64_t seed, uint64_t stream_id);
+                  uint64_t seed, uint64_t stream_id, int64_t block_rows = 0,
+                  int64_t block_stride = 0);
 // Local row -> row of the global minibatch (data parallel).  A buffer of `rows` rows stacks
 // rows / cells passes (samples, GMVAE clusters) of this rank's `cells` cells, which are cells
 // offset .. offset + cells - 1 of the global_cells cells of the step: local row p*cells + b is

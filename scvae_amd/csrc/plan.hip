@@ -1223,5 +1223,12 @@ int scvae_philox_normal(float* out, int64_t rows, int64_t cols, int64_t row_offs
   return scvae::philox_normal((hipStream_t)stream, out, rows, (int)cols, row_offset, seed,
                               stream_id);
 }
+int scvae_philox_normal_blocks(float* out, int64_t blocks, int64_t block_rows, int64_t cols,
+                               int64_t block_stride, int64_t row_offset, uint64_t seed,
+                               uint64_t stream_id, void* stream) {
+  SCVAE_ARG(blocks >= 0 && block_rows >= 0);
+  return scvae::philox_normal((hipStream_t)stream, out, blocks * block_rows, (int)cols, row_offset,
+                              seed, stream_id, block_rows, block_stride);
+}
 
 }  // extern "C"

@@ -129,6 +129,23 @@ def philox_normal(out, row_offset, seed, stream_id):
     return out
 
 
+def philox_normal_blocks(out, block_stride, row_offset, seed, stream_id):
+    """``out`` [blocks, rows, cols] in ONE launch: block g, row r gets the draw
+    of row ``g * block_stride + row_offset + r`` -- the stacked passes (GMVAE
+    clusters, importance / Monte-Carlo samples) of a rank's shard of a global
+    minibatch of ``block_stride`` cells; equal to ``philox_normal`` block by
+    block."""
+    lib = _lib.load()
+    blocks, rows, cols = out.shape
+    if not out.is_contiguous():
+        raise ValueError("contiguous [blocks, rows, cols] expected")
+    _lib.check(lib.scvae_philox_normal_blocks(
+        _ptr(out), blocks, rows, cols, int(block_stride), int(row_offset),
+        int(seed), int(stream_id), current_stream_handle(out.device)),
+        "scvae_philox_normal_blocks")
+    return out
+
+
 def synthetic_count_matrix(n_cells, n_features, density=0.05, n_clusters=8,
                            seed=60, device="cuda:0", chunk=2048):
     """Synthetic cell x gene counts of a named shape, generated on the GPU.

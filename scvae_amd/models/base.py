@@ -748,12 +748,10 @@ class ModelBase:
         """Fill ``eps`` ([S, cells, L]) so that global row g of sample s gets
         the draw keyed by (noise_seed, step, s*global_cells + g): the same for
         any sharding of the rows."""
-        from scvae_amd.minibatch import philox_normal
-        L = self.latent_size
-        view = eps.view(samples, cells, L)
-        for s in range(samples):
-            philox_normal(view[s], row_offset=s * global_cells + row_offset,
-                          seed=self.noise_seed, stream_id=step)
+        from scvae_amd.minibatch import philox_normal_blocks
+        philox_normal_blocks(eps.view(samples, cells, self.latent_size),
+                             block_stride=global_cells, row_offset=row_offset,
+                             seed=self.noise_seed, stream_id=step)
 
     # -- evaluation pass shared by train (epoch end) and evaluate --------------
     def _evaluation_pass(self, x, t, data_set, minibatch_size, n_iw, n_mc,

@@ -386,12 +386,11 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
 
     def _draw_noise(self, eps, samples, cells, global_cells, row_offset,
                     step):
-        from scvae_amd.minibatch import philox_normal
+        from scvae_amd.minibatch import philox_normal_blocks
         K, L = self.n_clusters, self.latent_size
-        view = eps.view(K * samples, cells, L)
-        for ks in range(K * samples):
-            philox_normal(view[ks], row_offset=ks * global_cells + row_offset,
-                          seed=self.noise_seed, stream_id=step)
+        philox_normal_blocks(eps.view(K * samples, cells, L),
+                             block_stride=global_cells, row_offset=row_offset,
+                             seed=self.noise_seed, stream_id=step)
 
     def _loss_tags(self):
         return [(0, "lower_bound", "ELBO"),

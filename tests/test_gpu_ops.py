@@ -134,6 +134,22 @@ def test_loglik_forward_backward(cuda_device, name):
                                g[bad][:5], g_ref[bad][:5])
 
 
+def test_philox_normal_blocks_equals_block_by_block(cuda_device):
+    """The stacked passes of a shard in one launch (``philox_normal_blocks``)
+    are the per-block launches, bit for bit."""
+    from scvae_amd.minibatch import philox_normal, philox_normal_blocks
+    blocks, rows, cols, stride, offset = 5, 37, 11, 100, 23
+    got = torch.full((blocks, rows, cols), float("nan"), device=cuda_device)
+    philox_normal_blocks(got, block_stride=stride, row_offset=offset, seed=99,
+                         stream_id=(3 << 40) + 5)
+    want = torch.empty_like(got)
+    for g in range(blocks):
+        philox_normal(want[g], row_offset=g * stride + offset, seed=99,
+                      stream_id=(3 << 40) + 5)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+
+
 def test_philox_normal_is_sharding_invariant(cuda_device):
     from scvae_amd import _lib
     lib = _lib.load()
