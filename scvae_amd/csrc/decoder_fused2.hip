@@ -26,6 +26,29 @@
 namespace scvae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+// Quarter Q (elements 4Q .. 4Q + 3) of a 16-register accumulator tuple as a 4-register one and
+// back, as whole-vector shuffles: the tuple stays a tuple for the register allocator (element-wise
+// extract / insert made it split the accumulators' live ranges and copy all 32 registers at the
+// head of every tile).
+template <int Q>
+__device__ __forceinline__ f32x4m quarter_of(const f32x16& v) {
+  return __builtin_shufflevector(v, v, 4 * Q, 4 * Q + 1, 4 * Q + 2, 4 * Q + 3);
+}
+template <int Q>
+__device__ __forceinline__ f32x16 with_quarter(const f32x16& v, const f32x4m& c) {
+  const f32x16 w = __builtin_shufflevector(c, c, 0, 1, 2, 3, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                           -1, -1);
+  if constexpr (Q == 0)
+    return __builtin_shufflevector(v, w, 16, 17, 18, 19, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+  else if constexpr (Q == 1)
+    return __builtin_shufflevector(v, w, 0, 1, 2, 3, 16, 17, 18, 19, 8, 9, 10, 11, 12, 13, 14, 15);
+  else if constexpr (Q == 2)
+    return __builtin_shufflevector(v, w, 0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 12, 13, 14, 15);
+  else
+    return __builtin_shufflevector(v, w, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19);
+}
 
 constexpr int D2_THREADS = 1024;  // 16 waves: 4 per SIMD
 constexpr int D2_HALF = 512;
@@ -117,7 +140,33 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
   }
 
   // dW tile of this wave: rows h0..h0+31 (incl. the ones-row h == H -> db), columns n0..n0+31
-  const int g2_h0 = (hw >> 1) * 32, g2_n0 = (hw & 1) * 32;
+  // ---- which matrix jobs this wave runs (hw = wave within its half; SIMD = hw & 3) ----
+  // Default: GEMM2 tile (h-tile hw >> 1, column tile hw & 1) on every wave, GEMM3 h-tile hw on
+  // waves 0-3, GEMM1 job hw - 4 on waves 4-7: 178 MFMA-equivalents per SIMD and tile when H pads
+  // to 128.  When the h remainder (rows 96 .. H of dW incl. the ones-row, columns 96 .. H - 1 of
+  // dd) fits a 16-wide tile (96 < H <= 111, e.g. the default 100) it runs on
+  // v_mfma_f32_16x16x4_f32 tiles instead of a mostly empty 32-wide one, and the jobs are dealt
+  // so that every SIMD carries 160-164 instead of 178 (32x32x2 equivalents per tile, P = 2):
+  //   SIMD 0: w0 GEMM3 h0 + GEMM2 (0,0)    w4 GEMM3 remainder + GEMM2 (0,1)
+  //   SIMD 1: w1 GEMM3 h1 + GEMM2 (1,0)    w5 GEMM1 job 0    + GEMM2 remainder, columns 0-31
+  //   SIMD 2: w2 GEMM3 h2 + GEMM2 (1,1)    w6 GEMM1 job 1    + GEMM2 remainder, columns 32-63
+  //   SIMD 3: w3 GEMM1 job 2 + GEMM2 (2,0) w7 GEMM1 job 3    + GEMM2 (2,1)
+  const bool rem16 = TRAIN && P <= 2 && H > 96 && H <= 111;
+  int g2_h0 = (hw >> 1) * 32, g2_n0 = (hw & 1) * 32;
+  bool g2_rem = false;
+  int g3_h0 = hw * 32;
+  bool g3_full = hw < 4 && hw * 32 < H, g3_rem = false;
+  int g1_job = hw - 4;                       // GEMM1: head g1_job >> 1, column tile g1_job & 1
+  if (rem16) {
+    const int ht = (0x20002110 >> (4 * hw)) & 15;     // h-tile of the full GEMM2 tile (w5, w6: -)
+    const int nt = (0xD4 >> hw) & 1;                  // column tile: w2, w4, w6, w7 -> 1
+    g2_rem = hw == 5 || hw == 6;
+    g2_h0 = g2_rem ? 96 : ht * 32;
+    g2_n0 = nt * 32;
+    g3_full = hw < 3;
+    g3_rem = hw == 4;
+    g1_job = hw == 5 ? 0 : hw == 6 ? 1 : hw == 3 ? 2 : hw == 7 ? 3 : -1;
+  }
   f32x16 accW[P];
 #pragma unroll
   for (int j = 0; j < P; ++j)
@@ -185,10 +234,7 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
   store_d(half * BM, 0, th);
   __syncthreads();
 
-  f32x16 accX;   // GEMM3 (waves 0-3) / GEMM1 (waves 4-7) accumulator, held until the hand-over
-  const int g1_job = hw - 4;                 // GEMM1: head g1_job >> 1, column tile g1_job & 1
   const bool g1_wave = g1_job >= 0 && g1_job < 2 * P;
-  const bool g3_wave = hw < 4 && hw * 32 < H;
 
   // Slot schedule (one workgroup barrier after every slot; the slot order is static so that the
   // register allocator sees the short live ranges of accX / dv / tv):
@@ -204,6 +250,16 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
     const int mp = m0 - 2 * BM;              // tile k-1
     const bool live = m0 < R;
     const bool live_prev = (k >= 1) && (mp < R);
+    // GEMM3 / GEMM1 accumulator of this tile, held until the hand-over (declared per tile: a
+    // value carried round the loop would be copied through every path that does not set it)
+    f32x16 accX;
+    // (the dW accumulators as whole register tuples at the head of every tile: without this use
+    //  the allocator keeps them as 32 scattered registers between tiles and copies them into the
+    //  MFMA tuples and back, 64 moves per wave and tile)
+    if (TRAIN) {
+#pragma unroll
+      for (int j = 0; j < P; ++j) asm volatile("" : "+v"(accW[j]));
+    }
     {
       // ============ MFMA slot: GEMM2 + GEMM3 of tile k-1, GEMM1 of tile k ============
       __builtin_amdgcn_s_setprio(3);   // MFMA waves first; the other half's VALU work fills the gaps
@@ -212,7 +268,33 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
       const float* dprev = dsh + (size_t)((k - 1) & 1) * DBUF;
       const float* dcur = dsh + (size_t)(k & 1) * DBUF;
       // ---- GEMM2: dW_j[h, col] += sum_row d[row, h] G_j[row, col]; row h == H gives db_j ----
-      if (TRAIN && live_prev && g2_h0 <= H) {
+      if (TRAIN && live_prev && g2_rem) {
+        // h rows 96 .. 111 (96 .. H live) x 32 columns as two 16x16 tiles, four rows per step.
+        // (The four k-lanes of the 16x16x4 operands may take any four rows as long as A and B
+        //  agree: lane group k4 walks rows 8 k4 .. 8 k4 + 7, which spreads the banks.)
+        const int i16 = tq & 15, k4 = (tq >> 4) & 3;
+        const float* ap = dprev + 8 * k4 * LDD + 96 + i16;            // A[i=h][k=row]
+        const float* bp = Gs + 8 * k4 * LD + g2_n0 + i16;             // B[k=row][n=col]
+        // the four 16x16 accumulators (head j, column half nt) are quarters 2 j + nt of accW[0]
+        // (accW[1] is idle on these waves): updated in place so that the two kinds of GEMM2
+        // waves share the accumulator registers
+#pragma unroll
+        for (int kk = 0; kk < BM / 4; ++kk) {
+          const float a = ap[kk * LDD];
+          const float* b = bp + kk * LD;
+#define SCVAE_G2R(Q_, J_, NT_)                                                                    \
+  accW[0] = with_quarter<Q_>(                                                                     \
+      accW[0], __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[(J_ * BM) * LD + 16 * NT_],              \
+                                                    quarter_of<Q_>(accW[0]), 0, 0, 0))
+          SCVAE_G2R(0, 0, 0);
+          SCVAE_G2R(1, 0, 1);
+          if constexpr (P == 2) {
+            SCVAE_G2R(2, 1, 0);
+            SCVAE_G2R(3, 1, 1);
+          }
+#undef SCVAE_G2R
+        }
+      } else if (TRAIN && live_prev && g2_h0 <= H) {
         const float* ap = dprev + kh * LDD + g2_h0 + li;              // A[i=h][k=row]
         const float* bp = Gs + kh * LD + g2_n0 + li;                  // B[k=row][n=col]
 #pragma unroll 8
@@ -260,10 +342,31 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
         if (tg.u16) load_t(static_cast<const uint16_t*>(tg.p));
         else load_t(static_cast<const float*>(tg.p));
       }
-      if (hw < 4) {
+      if (g3_rem) {
+        // ---- GEMM3, columns h = 96 .. 111 (96 .. H - 1 live): two 16-row tiles, four gene
+        //      columns per step ----
+        if (TRAIN && live_prev) {
+          const int i16 = tq & 15, k4 = (tq >> 4) & 3;
+          f32x4m x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < P; ++j) {
+            // (lane group k4 walks gene columns 16 k4 .. 16 k4 + 15: conflict-free with the
+            //  odd row stride)
+            const float* ap = Gs + (j * BM + i16) * LD + 16 * k4;     // A[i=row][k=col]
+            const float* bp = Ws + (j * H + 96 + i16) * LD + 16 * k4; // B[k=col][n=h]
+#pragma unroll 8
+            for (int kk = 0; kk < BN / 4; ++kk) {
+              const float b = bp[kk];
+              x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk], b, x0, 0, 0, 0);
+              x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * LD + kk], b, x1, 0, 0, 0);
+            }
+          }
+          accX = with_quarter<1>(with_quarter<0>(accX, x0), x1);
+        }
+      } else if (g1_job < 0) {
         // ---- GEMM3: dd[row, h] = sum_j sum_col G_j[row, col] W_j[h, col] ----
-        if (TRAIN && live_prev && g3_wave) {
-          const int h0 = hw * 32;
+        if (TRAIN && live_prev && g3_full) {
+          const int h0 = g3_h0;
 #pragma unroll
           for (int i = 0; i < 16; ++i) accX[i] = 0.f;
 #pragma unroll
@@ -299,8 +402,28 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
       // (non-temporal stores: 839 MB of dd slabs per launch that are read exactly once, by
       //  dd_reduce_kernel -- written through, they do not linger as dirty lines in the 256 MB
       //  infinity cache and get evicted in the middle of that reduce: 151 -> 123 us)
-      if (TRAIN && live_prev && g3_wave) {
-        const int h = hw * 32 + li;
+      if (TRAIN && live_prev && g3_rem) {
+        const int i16 = tq & 15, k4 = (tq >> 4) & 3;
+        const int h = 96 + i16;
+        if (h < H) {
+          float* dst = dd_part + ((size_t)blockIdx.x * R + mp + 4 * k4) * H + h;
+          if (mp + BM <= R) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                __builtin_nontemporal_store(accX[4 * rt + r], dst + (16 * rt + r) * H);
+          } else {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (mp + 16 * rt + 4 * k4 + r < R)
+                  __builtin_nontemporal_store(accX[4 * rt + r], dst + (16 * rt + r) * H);
+          }
+        }
+      } else if (TRAIN && live_prev && g3_full) {
+        const int h = g3_h0 + li;
         if (h < H) {
           float* dst = dd_part + ((size_t)blockIdx.x * R + mp + 4 * kh) * H + h;
           if (mp + BM <= R) {
@@ -441,7 +564,22 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
       for (int r = 0; r < 16; ++r) park[(j * 16 + r) * 64 + lane] = accW[j][r];
   }
   __syncthreads();
-  if (half == 0 && g2_h0 <= H) {
+  if (half == 0 && g2_rem) {
+    const int i16 = lane & 15, k4 = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = accW[0][4 * ((2 * j + nt) & 3) + r] + park[(4 * ((2 * j + nt) & 3) + r) * 64 + lane];
+          const int h = 96 + 4 * k4 + r, c = c0 + g2_n0 + 16 * nt + i16;
+          if (c < F) {
+            if (h < H) hp.dW[j][(size_t)h * F + c] = v;
+            else if (h == H) hp.db[j][c] = v;
+          }
+        }
+  } else if (half == 0 && g2_h0 <= H) {
     const int c = c0 + g2_n0 + li;
 #pragma unroll
     for (int j = 0; j < P; ++j)
