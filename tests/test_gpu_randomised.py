@@ -80,6 +80,54 @@ def test_fused_equals_unfused_on_random_models(cuda_device, seed):
             name, c)
 
 
+@pytest.mark.parametrize("H,B,likelihood", [
+    (100, 1000, "negative binomial"),      # ragged last tile on the dealt schedule
+    (110, 777, "zero-inflated poisson"),   # the widest remainder (rows 96 .. 110)
+    (98, 513, "poisson"),                  # one head; remainder rows 96 .. 98
+    (112, 600, "negative binomial"),       # just outside: the padded 32-wide tile
+    (96, 600, "negative binomial"),        # no remainder at all
+    (100, 511, "negative binomial"),       # below the row threshold: default schedule
+])
+def test_head_kernel_schedules_against_the_unfused_path(cuda_device, H, B,
+                                                        likelihood):
+    """The likelihood-head kernel runs the h remainder of its two backward
+    products (rows 96 .. H of dW incl. the bias row, columns 96 .. H - 1 of dd)
+    on 16-wide MFMA tiles with the jobs re-dealt over the waves when
+    96 < H <= 111 and there are >= 512 rows; all schedules against the unfused
+    GEMM + likelihood kernels, ragged row counts included."""
+    from scvae_amd.engine import Engine
+    F, L = 333, 6
+    rng = np.random.default_rng(H * 1000 + B)
+    eng = Engine(F, L, (H,), likelihood, batch_norm=True, device=cuda_device,
+                 seed=2)
+    g = torch.Generator().manual_seed(3)
+    for name, p in eng.named_parameters().items():
+        if not name.endswith("weights"):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    x = torch.from_numpy((rng.poisson(3.0, (B, F))
+                          * (rng.random((B, F)) < 0.2)).astype(np.float32)
+                         ).to(cuda_device)
+    eps = torch.from_numpy(rng.standard_normal((1, B, L)).astype(np.float32)
+                           ).to(cuda_device)
+    results = []
+    for fused in (True, False):
+        eng.set_fused(fused)
+        ll = torch.zeros(B, device=cuda_device)
+        scalars = eng.step(x, x, eps=eps, training=True,
+                           outputs={"log_p_x_given_z": ll}).clone()
+        torch.cuda.synchronize()
+        results.append((scalars.cpu().numpy(), ll.cpu().numpy(),
+                        eng.grads.clone().cpu().numpy()))
+    eng.set_fused(True)
+    (s_f, ll_f, g_f), (s_u, ll_u, g_u) = results
+    assert abs(s_f[0] - s_u[0]) <= 2e-5 * abs(s_u[0]) + 1e-6
+    assert np.abs(ll_f - ll_u).max() <= 2e-5 * np.abs(ll_u).max() + 1e-5
+    for name, (offset, shape) in eng.param_table.items():
+        n = int(np.prod(shape))
+        a, b = g_f[offset:offset + n], g_u[offset:offset + n]
+        assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max() + 1e-7, name
+
+
 def _oracle_case(seed):
     rng = np.random.default_rng(5000 + seed)
     likelihood = LIKELIHOODS[int(rng.integers(0, 4))]
