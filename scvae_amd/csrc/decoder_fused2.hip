@@ -89,7 +89,7 @@ __device__ __forceinline__ void lds_wave_fence() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-template <int KIND, bool TRAIN>
+template <int KIND, bool TRAIN, bool REM = false>
 __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
     const float* __restrict__ d, int R, int H, unsigned magic_h, HeadParams hp, int F,
     Targets tg, int B, const float* __restrict__ gw, int inline_lgamma,
@@ -151,9 +151,14 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
   //   SIMD 1: w1 GEMM3 h1 + GEMM2 (1,0)    w5 GEMM1 job 0    + GEMM2 remainder, columns 0-31
   //   SIMD 2: w2 GEMM3 h2 + GEMM2 (1,1)    w6 GEMM1 job 1    + GEMM2 remainder, columns 32-63
   //   SIMD 3: w3 GEMM1 job 2 + GEMM2 (2,0) w7 GEMM1 job 3    + GEMM2 (2,1)
-  // (from a few hundred rows on: with the four tiles of a 100-cell minibatch the dealt schedule
-  //  is 9 us slower than the default one -- 104 against 95 us)
-  const bool rem16 = TRAIN && P <= 2 && H > 96 && H <= 111 && R >= 512;
+  // REM is chosen by the launcher: 96 < H <= 111, at most two heads, from a few hundred rows on
+  // (with the four tiles of a 100-cell minibatch the dealt schedule is 9 us slower: 104 against
+  // 95 us).  In a REM kernel EVERY GEMM2 tile runs as 16x16x4 sub-tiles (same MFMA time and LDS
+  // reads as 32x32x2), so that the dW accumulators have one shape and one definition site: with
+  // two MFMA shapes writing them the register allocator kept a second copy of all 32 across the
+  // tile loop.
+  constexpr bool rem16 = REM;
+  static_assert(!REM || (TRAIN && P <= 2), "remainder schedule: training kernels, two heads");
   int g2_h0 = (hw >> 1) * 32, g2_n0 = (hw & 1) * 32;
   bool g2_rem = false;
   int g3_h0 = hw * 32;
@@ -169,11 +174,16 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
     g3_rem = hw == 4;
     g1_job = hw == 5 ? 0 : hw == 6 ? 1 : hw == 3 ? 2 : hw == 7 ? 3 : -1;
   }
-  f32x16 accW[P];
+  f32x16 accW[P];            // default schedule: one 32x32 tile per head
+  f32x4m accQ[P][4];         // REM: its four 16x16 sub-tiles [2 hi + cj] (remainder job: hi = 0)
 #pragma unroll
   for (int j = 0; j < P; ++j)
 #pragma unroll
     for (int i = 0; i < 16; ++i) accW[j][i] = 0.f;
+#pragma unroll
+  for (int j = 0; j < P; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) accQ[j][q] = f32x4m{0.f, 0.f, 0.f, 0.f};
 
   // next d tile, in flight from the MFMA slot to the hand-over.  H % 4 == 0 (the usual case: rows
   // of d are 16-byte multiples, a 32-row tile is one contiguous block): two 16-byte loads per
@@ -255,13 +265,6 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
     // GEMM3 / GEMM1 accumulator of this tile, held until the hand-over (declared per tile: a
     // value carried round the loop would be copied through every path that does not set it)
     f32x16 accX;
-    // (the dW accumulators as whole register tuples at the head of every tile: without this use
-    //  the allocator keeps them as 32 scattered registers between tiles and copies them into the
-    //  MFMA tuples and back, 64 moves per wave and tile)
-    if (TRAIN) {
-#pragma unroll
-      for (int j = 0; j < P; ++j) asm volatile("" : "+v"(accW[j]));
-    }
     {
       // ============ MFMA slot: GEMM2 + GEMM3 of tile k-1, GEMM1 of tile k ============
       __builtin_amdgcn_s_setprio(3);   // MFMA waves first; the other half's VALU work fills the gaps
@@ -270,31 +273,39 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
       const float* dprev = dsh + (size_t)((k - 1) & 1) * DBUF;
       const float* dcur = dsh + (size_t)(k & 1) * DBUF;
       // ---- GEMM2: dW_j[h, col] += sum_row d[row, h] G_j[row, col]; row h == H gives db_j ----
-      if (TRAIN && live_prev && g2_rem) {
-        // h rows 96 .. 111 (96 .. H live) x 32 columns as two 16x16 tiles, four rows per step.
+      if constexpr (REM) {
+        // every job as 16x16 sub-tiles (hi, cj) of its h rows x 32 columns, four rows per step:
+        // a full job has two h sub-tiles, the remainder job (rows 96 .. 111, 96 .. H live) one.
         // (The four k-lanes of the 16x16x4 operands may take any four rows as long as A and B
         //  agree: lane group k4 walks rows 8 k4 .. 8 k4 + 7, which spreads the banks.)
-        const int i16 = tq & 15, k4 = (tq >> 4) & 3;
-        const float* ap = dprev + 8 * k4 * LDD + 96 + i16;            // A[i=h][k=row]
-        const float* bp = Gs + 8 * k4 * LD + g2_n0 + i16;             // B[k=row][n=col]
-        // the four 16x16 accumulators (head j, column half nt) are quarters 2 j + nt of accW[0]
-        // (accW[1] is idle on these waves): updated in place so that the two kinds of GEMM2
-        // waves share the accumulator registers
+        if (live_prev) {
+          const int i16 = tq & 15, k4 = (tq >> 4) & 3;
+          const float* ap = dprev + 8 * k4 * LDD + g2_h0 + i16;       // A[i=h][k=row]
+          const float* bp = Gs + 8 * k4 * LD + g2_n0 + i16;           // B[k=row][n=col]
+          // h sub-tile 0 on every wave, then h sub-tile 1 where the job has one: each
+          // accumulator is written in exactly one place (the B operands are read twice)
 #pragma unroll
-        for (int kk = 0; kk < BM / 4; ++kk) {
-          const float a = ap[kk * LDD];
-          const float* b = bp + kk * LD;
-#define SCVAE_G2R(Q_, J_, NT_)                                                                    \
-  accW[0] = with_quarter<Q_>(                                                                     \
-      accW[0], __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[(J_ * BM) * LD + 16 * NT_],              \
-                                                    quarter_of<Q_>(accW[0]), 0, 0, 0))
-          SCVAE_G2R(0, 0, 0);
-          SCVAE_G2R(1, 0, 1);
-          if constexpr (P == 2) {
-            SCVAE_G2R(2, 1, 0);
-            SCVAE_G2R(3, 1, 1);
+          for (int kk = 0; kk < BM / 4; ++kk) {
+            const float a0 = ap[kk * LDD];
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+              const float b0 = bp[(j * BM + kk) * LD], b1 = bp[(j * BM + kk) * LD + 16];
+              accQ[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, accQ[j][0], 0, 0, 0);
+              accQ[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, accQ[j][1], 0, 0, 0);
+            }
           }
-#undef SCVAE_G2R
+          if (!g2_rem) {
+#pragma unroll
+            for (int kk = 0; kk < BM / 4; ++kk) {
+              const float a1 = ap[kk * LDD + 16];
+#pragma unroll
+              for (int j = 0; j < P; ++j) {
+                const float b0 = bp[(j * BM + kk) * LD], b1 = bp[(j * BM + kk) * LD + 16];
+                accQ[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, accQ[j][2], 0, 0, 0);
+                accQ[j][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, accQ[j][3], 0, 0, 0);
+              }
+            }
+          }
         }
       } else if (TRAIN && live_prev && g2_h0 <= H) {
         const float* ap = dprev + kh * LDD + g2_h0 + li;              // A[i=h][k=row]
@@ -563,24 +574,27 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
 #pragma unroll
     for (int j = 0; j < P; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) park[(j * 16 + r) * 64 + lane] = accW[j][r];
+      for (int r = 0; r < 16; ++r)
+        park[(j * 16 + r) * 64 + lane] = REM ? accQ[j][r >> 2][r & 3] : accW[j][r];
   }
   __syncthreads();
-  if (half == 0 && g2_rem) {
+  if (REM && half == 0) {
     const int i16 = lane & 15, k4 = lane >> 4;
 #pragma unroll
     for (int j = 0; j < P; ++j)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int q = 0; q < 4; ++q) {
+        if (g2_rem && q >= 2) continue;          // (the remainder job has one h sub-tile)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = accW[0][4 * ((2 * j + nt) & 3) + r] + park[(4 * ((2 * j + nt) & 3) + r) * 64 + lane];
-          const int h = 96 + 4 * k4 + r, c = c0 + g2_n0 + 16 * nt + i16;
+          const float v = accQ[j][q][r] + park[(j * 16 + 4 * q + r) * 64 + lane];
+          const int h = g2_h0 + 16 * (q >> 1) + 4 * k4 + r, c = c0 + g2_n0 + 16 * (q & 1) + i16;
           if (c < F) {
             if (h < H) hp.dW[j][(size_t)h * F + c] = v;
             else if (h == H) hp.db[j][c] = v;
           }
         }
+      }
   } else if (half == 0 && g2_h0 <= H) {
     const int c = c0 + g2_n0 + li;
 #pragma unroll
@@ -607,12 +621,18 @@ static int launch_decoder2(hipStream_t s, int kind, const float* d, int rows, in
   const unsigned magic_h = (unsigned)(0x100000000ull / (unsigned)H) + 1u;
 #define SCVAE_D2(K_)                                                                              \
   do {                                                                                            \
-    auto kfn = decoder_head2_kernel<K_, TRAIN>;                                                   \
+    void (*kfn)(const float*, int, int, unsigned, HeadParams, int, Targets, int, const float*,    \
+                int, float*, float*) = decoder_head2_kernel<K_, TRAIN, false>;                    \
+    if constexpr (TRAIN && LikelihoodTraits<K_>::P <= 2) {                                        \
+      if (rem) kfn = decoder_head2_kernel<K_, TRAIN, true>;                                       \
+    }                                                                                             \
     SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
     hipLaunchKernelGGL(kfn, dim3(strips), dim3(D2_THREADS), lds, s, d, rows, H, magic_h, hp, F,   \
                        t, B, gw, inline_lgamma, ll_part, dd_part);                                \
   } while (0)
+  // the schedule with the 16-wide h remainder (see the kernel): where it applies and pays
+  const bool rem = TRAIN && P <= 2 && H > 96 && H <= 111 && rows >= 512;
   switch (kind) {
     case LK_POISSON: SCVAE_D2(LK_POISSON); break;
     case LK_NB: SCVAE_D2(LK_NB); break;
