@@ -778,6 +778,15 @@ class ModelBase:
                 int(numpy.prod(self._eps_shape(
                     samples, min(minibatch_size, n)))), device=device)
         all_rows = torch.arange(n, device=device, dtype=torch.int64)
+        # plain passes (no reconstruction statistics requested) over an integer
+        # count matrix take the uint16 minibatch where the plan allows it
+        u16_buffer = None
+        if (not outputs and x is t and getattr(x, "integer_counts", False)
+                and hasattr(x, "gather_counts_u16")
+                and engine.accepts_counts_u16(min(minibatch_size, n), False)):
+            u16_buffer = torch.empty(
+                min(minibatch_size, n), x.u16_pitch, dtype=torch.uint16,
+                device=device)
         self._evaluation_counter = getattr(
             self, "_evaluation_counter", 0) + 1
         for j, i in enumerate(starts):
@@ -786,9 +795,14 @@ class ModelBase:
             rows = all_rows[i:i + minibatch_size]
             cells = int(rows.numel())
             xb, tb, rc = x_buffer[:cells], t_buffer[:cells], row_const[:cells]
-            t.gather_dense(rows, out=tb, row_const_out=rc)
-            if x is not t:
-                x.gather_dense(rows, out=xb)
+            if (u16_buffer is not None
+                    and engine.accepts_counts_u16(cells, False)):
+                xb = tb = x.gather_counts_u16(
+                    rows, out=u16_buffer[:cells], row_const_out=rc)
+            else:
+                t.gather_dense(rows, out=tb, row_const_out=rc)
+                if x is not t:
+                    x.gather_dense(rows, out=xb)
             eps = None
             if not deterministic_z:
                 eps = eps_buffer[:int(numpy.prod(
