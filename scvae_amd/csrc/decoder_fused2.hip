@@ -374,7 +374,14 @@ __global__ __launch_bounds__(D2_THREADS) void decoder_head2_kernel(
               x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * LD + kk], b, x1, 0, 0, 0);
             }
           }
-          accX = with_quarter<1>(with_quarter<0>(accX, x0), x1);
+          {   // accX[0..3] = x0, accX[4..7] = x1, the rest unused on this wave
+            const f32x16 t0 = __builtin_shufflevector(x0, x0, 0, 1, 2, 3, -1, -1, -1, -1, -1, -1, -1,
+                                                      -1, -1, -1, -1, -1);
+            const f32x16 t1 = __builtin_shufflevector(x1, x1, 0, 1, 2, 3, -1, -1, -1, -1, -1, -1, -1,
+                                                      -1, -1, -1, -1, -1);
+            accX = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 16, 17, 18, 19, -1, -1, -1, -1, -1,
+                                           -1, -1, -1);
+          }
         }
       } else if (g1_job < 0) {
         // ---- GEMM3: dd[row, h] = sum_j sum_col G_j[row, col] W_j[h, col] ----
