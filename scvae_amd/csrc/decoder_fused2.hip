@@ -13,6 +13,11 @@
 // SIMD): the matrix cores do not wait for the likelihood math any more.  The only synchronisation
 // is one workgroup barrier per slot; the d tile is double buffered.
 //
+// Two job tables for the matrix work of a half (see the kernel): the default one, and -- REM
+// instantiations, chosen by the launcher for 96 < H <= 111 from 512 rows on -- one in which the h
+// remainder of the two backward products runs on 16-wide MFMA tiles and the jobs are dealt
+// evenly over the SIMDs.
+//
 // The t > 0 corrections of the negative-binomial kinds (lgamma / digamma differences; 5 % of a
 // count matrix) are compacted per wave with ballots into a wave-private LDS queue, so that the
 // expensive code runs once per wave on dense lanes instead of four times on sparse lanes; no
@@ -27,28 +32,6 @@ namespace scvae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4m __attribute__((ext_vector_type(4)));
-
-// Quarter Q (elements 4Q .. 4Q + 3) of a 16-register accumulator tuple as a 4-register one and
-// back, as whole-vector shuffles: the tuple stays a tuple for the register allocator (element-wise
-// extract / insert made it split the accumulators' live ranges and copy all 32 registers at the
-// head of every tile).
-template <int Q>
-__device__ __forceinline__ f32x4m quarter_of(const f32x16& v) {
-  return __builtin_shufflevector(v, v, 4 * Q, 4 * Q + 1, 4 * Q + 2, 4 * Q + 3);
-}
-template <int Q>
-__device__ __forceinline__ f32x16 with_quarter(const f32x16& v, const f32x4m& c) {
-  const f32x16 w = __builtin_shufflevector(c, c, 0, 1, 2, 3, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
-                                           -1, -1);
-  if constexpr (Q == 0)
-    return __builtin_shufflevector(v, w, 16, 17, 18, 19, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-  else if constexpr (Q == 1)
-    return __builtin_shufflevector(v, w, 0, 1, 2, 3, 16, 17, 18, 19, 8, 9, 10, 11, 12, 13, 14, 15);
-  else if constexpr (Q == 2)
-    return __builtin_shufflevector(v, w, 0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 12, 13, 14, 15);
-  else
-    return __builtin_shufflevector(v, w, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19);
-}
 
 constexpr int D2_THREADS = 1024;  // 16 waves: 4 per SIMD
 constexpr int D2_HALF = 512;
