@@ -10,6 +10,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))   # the tests' shared helpers (_parity)
 from oracle import models as om  # noqa: E402
 
 spec = importlib.util.spec_from_file_location(
