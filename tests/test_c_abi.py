@@ -109,3 +109,38 @@ def test_engine_refuses_to_run_without_gpu():
     from scvae_amd.engine import Engine
     with pytest.raises(_lib.HipLibraryError, match="no CPU path"):
         Engine(10, 2, [4], "poisson")
+
+
+def _c_layout(struct, fields, tmp_path):
+    """sizeof / offsetof of ``struct`` as the C compiler lays it out from the header."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    source = tmp_path / "layout.c"
+    lines = ['#include <stddef.h>', '#include <stdio.h>',
+             '#include "scvae_hip.h"', 'int main(void) {',
+             '  printf("%zu\\n", sizeof({}));'.format(struct)]
+    for name in fields:
+        lines.append('  printf("%zu\\n", offsetof({}, {}));'.format(struct, name))
+    lines += ['  return 0;', '}']
+    source.write_text("\n".join(lines))
+    binary = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"),
+                    str(source), "-o", str(binary)], check=True)
+    out = subprocess.run([str(binary)], check=True, capture_output=True,
+                         text=True).stdout.split()
+    return int(out[0]), [int(v) for v in out[1:]]
+
+
+@pytest.mark.parametrize("struct,ctype", [("scvae_step_args", "StepArgs"),
+                                          ("scvae_model_config", "ModelConfig")])
+def test_ctypes_structures_have_the_layout_of_the_header(tmp_path, struct, ctype):
+    """The ctypes mirrors of the C structs (``scvae_amd/_lib.py``) against the
+    layout a C compiler gives ``include/scvae_hip.h``: same size, same field
+    order, same offsets -- the binding a maintainer of the reference would add
+    passes these structs by pointer."""
+    from scvae_amd import _lib
+    mirror = getattr(_lib, ctype)
+    names = [f[0] for f in mirror._fields_]
+    size, offsets = _c_layout(struct, names, tmp_path)
+    assert ctypes.sizeof(mirror) == size
+    assert [getattr(mirror, n).offset for n in names] == offsets
