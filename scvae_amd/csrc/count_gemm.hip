@@ -106,7 +106,7 @@ constexpr int CD_BK = 16;
 constexpr int CD_ROW = 48;            // LDS bytes per (term, column) row: 32 + 16 pad
 constexpr int CD_BM = 256;            // genes per workgroup
 
-template <int NT, typename XT, bool USE_STEADY = false>
+template <int NT, typename XT, bool PAIR = false, bool USE_STEADY = false>
 __global__ __launch_bounds__(256, 2) void count_gemm_dw_kernel(
     const XT* __restrict__ X, int ldx, int M, int K, const uint16_t* __restrict__ T, int Kpad,
     int N, int k_chunk, float* __restrict__ out, int ldo) {
@@ -128,19 +128,36 @@ __global__ __launch_bounds__(256, 2) void count_gemm_dw_kernel(
 
   // raw[slot][t][j]  <->  cell kc + 8 kg + j of gene tile t; uniform row pointer + per-lane
   // 32-bit element offset (gene + 8 kg rows)
-  XT raw[2][2][8];
+  // PAIR (uint16 counts, M even): a lane reads genes 2 li and 2 li + 1 of the wave's 64 with one
+  // 4-byte load -- gene tile 0 takes the even genes, tile 1 the odd ones -- half the load
+  // instructions of the lane-per-gene pattern for the same bytes.
+  static_assert(!PAIR || sizeof(XT) == 2, "gene pairs: uint16 counts");
+  XT raw[2][2][PAIR ? 1 : 8];
+  unsigned rawp[2][PAIR ? 8 : 1];
   unsigned xoff[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
-    xoff[t] = (unsigned)(8 * kg) * (unsigned)ldx + (unsigned)min(m_w + 32 * t + li, M - 1);
+    xoff[t] = (unsigned)(8 * kg) * (unsigned)ldx +
+              (PAIR ? (unsigned)min(m_w + 2 * li, M - 2)
+                    : (unsigned)min(m_w + 32 * t + li, M - 1));
+  // the count of gene tile t, cell j of the slot, as fp32
+  auto value = [&](auto slot_tag, int t, int j) -> float {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    if constexpr (PAIR) return (float)(t == 0 ? (rawp[SLOT][j] & 0xFFFFu) : (rawp[SLOT][j] >> 16));
+    else return count_to_f32(raw[SLOT][t][j]);
+  };
   u32x4 breg[3];
   auto load_x = [&](int kc, auto slot_tag) {
     constexpr int SLOT = decltype(slot_tag)::value;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const XT* srow = X + (size_t)(kc + j) * ldx;               // uniform: scalar base
+      if constexpr (PAIR) {
+        rawp[SLOT][j] = *reinterpret_cast<const unsigned*>(srow + xoff[0]);
+      } else {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) raw[SLOT][t][j] = srow[xoff[t]];
+        for (int t = 0; t < 2; ++t) raw[SLOT][t][j] = srow[xoff[t]];
+      }
     }
   };
   auto load_b = [&](int kc) {
@@ -186,8 +203,8 @@ __global__ __launch_bounds__(256, 2) void count_gemm_dw_kernel(
       unsigned h[4];
 #pragma unroll
       for (int pr = 0; pr < 4; ++pr) {
-        const unsigned u0 = __float_as_uint(count_to_f32(raw[BUF][t][2 * pr]));
-        const unsigned u1 = __float_as_uint(count_to_f32(raw[BUF][t][2 * pr + 1]));
+        const unsigned u0 = __float_as_uint(value(buf_tag, t, 2 * pr));
+        const unsigned u1 = __float_as_uint(value(buf_tag, t, 2 * pr + 1));
         low_bits |= u0 | u1;
         h[pr] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);          // upper halves
       }
@@ -201,8 +218,8 @@ __global__ __launch_bounds__(256, 2) void count_gemm_dw_kernel(
         unsigned l[4];
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
-          const float x0 = count_to_f32(raw[BUF][t][2 * pr]);
-          const float x1 = count_to_f32(raw[BUF][t][2 * pr + 1]);
+          const float x0 = value(buf_tag, t, 2 * pr);
+          const float x1 = value(buf_tag, t, 2 * pr + 1);
           const float l0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u);
           const float l1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
           l[pr] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
@@ -267,7 +284,8 @@ __global__ __launch_bounds__(256, 2) void count_gemm_dw_kernel(
       if (col >= N) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m_w + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * kg;         // row of the gene tile
+        const int m = PAIR ? m_w + 2 * i + t : m_w + 32 * t + i;
         if (m < M) dst[(size_t)m * ldo + col] = acc[t][q][r];
       }
     }
@@ -615,8 +633,17 @@ static int count_gemm_impl(hipStream_t stream, int mode, const XT* x, int ldx, i
     } else {
       const dim3 grid((M + CD_BM - 1) / CD_BM, splits);
 #define SCVAE_CD(NT_)                                                                             \
-  hipLaunchKernelGGL((count_gemm_dw_kernel<NT_, XT>), grid, dim3(256), 0, stream, x, ldx, M,      \
-                     k_main, T, Kpad, N, k_chunk, dst, ldo)
+  do {                                                                                            \
+    if constexpr (sizeof(XT) == 2) {                                                              \
+      if ((M & 1) == 0) {   /* gene pairs per lane (4-byte loads) */                               \
+        hipLaunchKernelGGL((count_gemm_dw_kernel<NT_, XT, true>), grid, dim3(256), 0, stream, x,  \
+                           ldx, M, k_main, T, Kpad, N, k_chunk, dst, ldo);                        \
+        break;                                                                                    \
+      }                                                                                           \
+    }                                                                                             \
+    hipLaunchKernelGGL((count_gemm_dw_kernel<NT_, XT, false>), grid, dim3(256), 0, stream, x,     \
+                       ldx, M, k_main, T, Kpad, N, k_chunk, dst, ldo);                            \
+  } while (0)
       switch (NT) { case 1: SCVAE_CD(1); break; case 2: SCVAE_CD(2); break;
                     case 3: SCVAE_CD(3); break; default: SCVAE_CD(4); }
 #undef SCVAE_CD
