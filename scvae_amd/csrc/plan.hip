@@ -176,9 +176,15 @@ float dropout_keep(const scvae_model_config& c, int which) {
 
 size_t plan_x_gemm_workspace_bytes(int cells, int features, int n_out) {
   if (!count_gemm_supported(n_out)) return 0;
-  const size_t f = count_gemm_workspace_bytes(0, cells, features, n_out);
-  const size_t b = count_gemm_workspace_bytes(1, cells, features, n_out);
-  return f > b ? f : b;
+  // The plan runs any minibatch of 1 .. cells rows (the tail of an epoch).  The forward product's
+  // need is not monotone in the rows -- fewer row tiles take more split-K slabs -- so reserve
+  // the maximum over the row-tile counts (the largest row count of each is the worst of it).
+  size_t need = count_gemm_workspace_bytes(1, cells, features, n_out);
+  for (int r = cells; r > 0; r = (r - 1) / 256 * 256) {
+    const size_t f = count_gemm_workspace_bytes(0, r, features, n_out);
+    if (f > need) need = f;
+  }
+  return need;
 }
 
 int plan_gemm(scvae_plan* p, hipStream_t s, bool ta, bool tb, const float* A, const float* B,
@@ -998,6 +1004,10 @@ int scvae_plan_accepts_counts_u16(const scvae_plan* p, int64_t cells, int32_t tr
   }
   // both products on the count kernels by the plan's own rule (plan_gemm)
   if (p->use_count_gemm < 2 && (double)cells * c.feature_size < 768.0 * 32768.0) return 0;
+  // ... and inside the workspace the plan reserved for them (plan_gemm would refuse the step)
+  for (int mode = 0; mode < 2; ++mode)
+    if (scvae::count_gemm_workspace_bytes(mode, (int)cells, c.feature_size, n_x) > p->gemm_ws_bytes)
+      return 0;
   return 1;
 }
 

@@ -298,3 +298,38 @@ def test_uint16_minibatch_is_refused_where_it_does_not_apply(cuda_device):
     drop.set_count_gemm(True, always=True)
     assert not drop.accepts_counts_u16(B, True)
     assert drop.accepts_counts_u16(B, False)
+
+
+def test_tail_minibatch_fits_the_reserved_count_workspace(cuda_device):
+    """A plan bound for 1300 cells runs every smaller minibatch on the uint16
+    path: the forward count kernel takes MORE split-K slabs for fewer row
+    tiles (1259..1280 rows need more workspace than 1300), which the plan's
+    reservation must cover (round-2 advisor finding)."""
+    from scvae_amd import _lib
+    from scvae_amd.engine import Engine
+    from scvae_amd.minibatch import synthetic_count_matrix
+    lib = _lib.load()
+    F, L, H, BMAX = 20000, 8, (100,), 1300
+    need = [lib.scvae_count_gemm_workspace_bytes(0, r, F, 100)
+            for r in (BMAX, 1280, 1270)]
+    assert max(need[1:]) > need[0]          # the non-monotone case is real
+    matrix, _ = synthetic_count_matrix(BMAX, F, density=0.05, seed=9,
+                                       device=cuda_device)
+    eng = Engine(F, L, H, "negative binomial", batch_norm=True,
+                 device=cuda_device, seed=1)
+    eng.set_count_gemm(True, always=True)   # (also below the size where they pay)
+    eng.reserve(BMAX, 1)
+    for cells in (BMAX, 1280, 1270, 1024, 800):
+        assert eng.accepts_counts_u16(cells, True)
+        rows = torch.arange(cells, device=cuda_device)
+        rc = torch.zeros(cells, device=cuda_device)
+        x16 = matrix.gather_counts_u16(rows, row_const_out=rc)
+        x32 = matrix.gather_dense(rows)
+        eps = torch.randn(1, cells, L, device=cuda_device)
+        s16 = eng.step(x16, x16, eps=eps, row_const=rc, training=True,
+                       x_counts=True).clone()
+        g16 = eng.grads.clone()
+        s32 = eng.step(x32, x32, eps=eps, row_const=rc, training=True,
+                       x_counts=True).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(s16, s32) and torch.equal(g16, eng.grads)
