@@ -280,6 +280,18 @@ int64_t scvae_decoder_fused_workspace_bytes(int64_t rows, int64_t H, int64_t F);
  * 2 = decoder_head2_kernel (two pipelined halves), 1 = decoder_head_kernel, 0 = unsupported H
  * (the step then uses the unfused GEMM + likelihood kernels) */
 int32_t scvae_decoder_fused_variant(int32_t kind, int64_t H);
+/* Arithmetic of the three products (va:2466-2489 and their backward) inside the fused TRAINING
+ * kernel: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32), 1 = the bf16 matrix cores in the
+ * exact nine-term form -- every fp32 operand cut exactly into three bf16 terms, all nine
+ * products of a pair (each exact in fp32) accumulated in fp32 -- where that kernel applies (one
+ * or two heads, hidden width within its LDS budget; otherwise the fp32 kernel runs).
+ * Process-wide; the initial value comes from SCVAE_HEAD_ARITH=fp32|bf16x9.
+ * scvae_decoder_train_kernel: which kernel a training launch takes under the current setting:
+ * 1 / 2 = scvae_decoder_fused_variant's fp32 schedules, 3 = decoder_head3_kernel (bf16x9),
+ * 0 = unsupported H. */
+int32_t scvae_decoder_head_arith(void);
+int scvae_set_decoder_head_arith(int32_t mode);
+int32_t scvae_decoder_train_kernel(int32_t kind, int64_t H);
 int scvae_decoder_fused(int32_t kind, int32_t train, const float* d, int64_t rows, int64_t H,
                         const float* const* W, const float* const* b, float* const* dW,
                         float* const* db, int64_t F, const float* t, int64_t cells,

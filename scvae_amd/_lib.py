@@ -146,6 +146,9 @@ SIGNATURES = {
     "scvae_decoder_fused_workspace_bytes": (c_int64, [c_int64, c_int64,
                                                       c_int64]),
     "scvae_decoder_fused_variant": (c_int32, [c_int32, c_int64]),
+    "scvae_decoder_head_arith": (c_int32, []),
+    "scvae_set_decoder_head_arith": (c_int32, [c_int32]),
+    "scvae_decoder_train_kernel": (c_int32, [c_int32, c_int64]),
     "scvae_plan_prior_offset": (c_int64, [c_void_p]),
     "scvae_plan_decode": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p,
                                     c_void_p]),

@@ -513,6 +513,7 @@ size_t decoder_fused_workspace_floats(int rows, int H, int F, bool train) {
   const size_t strips = (size_t)(F + DF_BN - 1) / DF_BN;
   size_t n = strips * rows;                       // ll_part
   if (train) n += strips * (size_t)rows * H + 64; // dd_part (16-byte aligned start)
+  if (train) n += decoder_fused3_workspace_floats(rows) + 64;   // bf16 planes of d (bf16x9 kernel)
   return n + 64;
 }
 
@@ -532,11 +533,34 @@ int decoder_fused_variant(int P, int H) {
   return (decoder_variant() == 2 && decoder_fused2_supported(P, H)) ? 2 : 1;
 }
 
+// Arithmetic of the three products of the TRAINING kernel: 0 = fp32 MFMA (decoder_fused.hip /
+// decoder_fused2.hip), 1 = the exact nine-term bf16 split (decoder_fused3.hip) where that kernel
+// applies (one / two heads, its LDS budget).  Process-wide; SCVAE_HEAD_ARITH=fp32|bf16x9 sets the
+// initial value.
+static int g_head_arith = -1;
+int decoder_head_arith() {
+  if (g_head_arith < 0) {
+    const char* e = getenv("SCVAE_HEAD_ARITH");
+    g_head_arith = (e && (e[0] == 'b' || e[0] == '1')) ? 1 : 0;
+  }
+  return g_head_arith;
+}
+void set_decoder_head_arith(int mode) { g_head_arith = mode ? 1 : 0; }
+int decoder_train_kernel(int P, int H) {
+  if (decoder_head_arith() == 1 && decoder_fused3_supported(P, H)) return 3;
+  return decoder_fused_variant(P, H);
+}
+
 template <bool TRAIN>
 static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                           int F, Targets t, int B, const float* gw, int inline_lgamma,
-                          float* ll_part, float* dd_part) {
+                          float* ll_part, float* dd_part, float* planes = nullptr) {
   const int P = likelihood_heads(kind);
+  if (TRAIN && planes && decoder_train_kernel(P, H) == 3) {
+    static const int dbg = [] { const char* e = getenv("SCVAE_D3_DEBUG"); return e ? atoi(e) : 0; }();
+    return decoder_fused3_launch(s, kind, d, rows, H, hp, F, t, B, gw, inline_lgamma | (dbg << 8),
+                                 ll_part, dd_part, planes);
+  }
   if (decoder_fused_variant(P, H) == 2)
     return decoder_fused2_launch(s, TRAIN, kind, d, rows, H, hp, F, t, B, gw, inline_lgamma, ll_part,
                                  dd_part);
@@ -601,8 +625,9 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
   float* ll_part = workspace;
   size_t off = ((size_t)strips * rows + 63) / 64 * 64;
   float* dd_part = workspace + off;
+  float* planes = dd_part + ((size_t)strips * rows * H + 63) / 64 * 64;
   int rc = launch_decoder<true>(s, kind, d, rows, H, hp, F, t, B, gw, row_const ? 0 : 1, ll_part,
-                                dd_part);
+                                dd_part, planes);
   if (rc) return rc;
   if (kernel_only) return 0;  // profiling aid: leave the per-strip partials unreduced
   hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 15) / 16), dim3(1024), 0, s, ll_part,

@@ -1,0 +1,579 @@
+// Fused decoder output layer on the bf16 matrix cores in the exact-product nine-term form
+// ("bf16x9"): the same maths, inputs, outputs and per-strip partial buffers as decoder_fused.hip /
+// decoder_fused2.hip (X_TILDE heads va:2466-2489, activation + clip + TFP log_prob du:206-305,
+// sum over the genes va:2583-2590, and their backward), with the three products
+//
+//     GEMM1  pre_j[row, gene] = sum_h d[row, h] W_j[h, gene] + b_j[gene]
+//     GEMM2  dW_j[h, gene]   += sum_row d[row, h] G_j[row, gene]         (row h == H: db_j)
+//     GEMM3  dd[row, h]       = sum_j sum_gene G_j[row, gene] W_j[h, gene]
+//
+// evaluated as follows.  An fp32 value is cut EXACTLY into three bf16 terms x = x1 + x2 + x3
+// (8 + 8 + 8 significant bits, by truncation: x1 = the upper 16 bits of x, x2 = those of x - x1,
+// x3 = the rest); a product x y is the sum of the nine products x_a y_b, each of which is exact
+// in fp32 (8 x 8 bits), and the matrix core accumulates them in fp32: the result is an fp32 sum
+// of exact products -- the error class of an fp32 FMA chain, not of a bf16 GEMM.  Nine
+// v_mfma_f32_*_bf16 per 16 k cost 9 x 32 cycles against 8 x 64 for v_mfma_f32_32x32x2_f32:
+// 0.56 of the matrix time of the fp32 kernels.  Reported by bench.py as
+// "decoder_head_arith": "bf16x9-exact" with the roofline priced at 2500 / 9 TFLOP/s.
+//
+// Organisation (one workgroup = 8 waves = one 64-gene strip, walking over 64-row tiles):
+//   * d reaches the kernel already cut into bf16 planes, in both operand orientations
+//     (split3_hidden_kernel: dA [3][rows][128] for GEMM1, dT [3][128][rows] for GEMM2; column /
+//     row H holds ones, so b_j and db_j fall out of the same MFMAs); every operand fragment of d
+//     is ONE 16-byte load from L2 straight into the registers that feed the MFMAs -- d never
+//     passes through LDS;
+//   * the strip's weights are cut once per workgroup and stay in LDS as [head][plane][h][gene]
+//     bf16 (144-byte rows: conflict-free ds_read_b128 fragments for GEMM3); GEMM1 reads the same
+//     image through ds_read_b64_tr_b16, the hardware transpose read, which hands a lane four
+//     consecutive h of its gene;
+//   * phase A (all waves): wave (gene block of 16, row half of 32) computes the TRANSPOSED head
+//     tile pre_j^T[gene, row] with v_mfma_f32_16x16x32_bf16: a lane then holds four consecutive
+//     genes of one row for every head, the likelihood and its gradient run on the accumulator
+//     registers (no LDS round trip of the pre-activations), the t > 0 corrections of the
+//     negative-binomial kinds as a per-lane walk over the lane's non-zeros; G_j is cut into
+//     planes and stored to LDS once, row-major;
+//   * phase B (all waves): GEMM3 from LDS (ds_read_b128 of G and W) while the dT fragments of
+//     GEMM2 are in flight, then GEMM2 (G through the transpose read); dW accumulators persist
+//     in registers over the whole launch;
+//   * two workgroup barriers per 64 rows.
+#include <type_traits>
+
+#include "common.hpp"
+#include "kernels.hpp"
+#include "likelihood.hpp"
+
+namespace scvae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int D3_THREADS = 512;
+constexpr int D3_BN = 64;           // genes per strip
+constexpr int D3_BM = 64;           // rows per tile
+constexpr int D3_ROWB = 144;        // bytes per LDS row: 64 bf16 + 16 bytes of padding
+constexpr int D3_KP = 128;          // padded hidden width of the planes of d
+constexpr int D3_GPLANE = D3_BM * D3_ROWB;   // bytes of one [64 rows][64 genes] plane of G
+
+__host__ __device__ inline int d3_hp1(int H) { return (H + 1 + 15) / 16 * 16; }
+
+size_t decoder_fused3_lds_bytes(int P, int H) {
+  return (size_t)P * 3 * d3_hp1(H) * D3_ROWB + (size_t)P * 3 * D3_GPLANE + 4 * D3_BM * sizeof(float);
+}
+bool decoder_fused3_supported(int P, int H) {
+  return P <= 2 && H >= 2 && H <= 126 && decoder_fused3_lds_bytes(P, H) <= 160 * 1024;
+}
+// planes of d: dA [3][Rpad][128] then dT [3][128][Rpad], bf16
+size_t decoder_fused3_workspace_floats(int rows) {
+  const size_t rpad = (size_t)(rows + D3_BM - 1) / D3_BM * D3_BM;
+  return 2 * 3 * rpad * D3_KP * sizeof(uint16_t) / sizeof(float) + 64;
+}
+
+// x = b1 + b2 + b3 exactly, each term's upper 16 bits a bf16 value (lower 16 bits zero)
+__device__ __forceinline__ void split3_trunc(float x, unsigned& b1, unsigned& b2, unsigned& b3) {
+  b1 = __float_as_uint(x) & 0xFFFF0000u;
+  const float r1 = x - __uint_as_float(b1);
+  b2 = __float_as_uint(r1) & 0xFFFF0000u;
+  b3 = __float_as_uint(r1 - __uint_as_float(b2));
+}
+// (upper half of hi) << 16 | upper half of lo
+__device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) {
+  return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+
+// d [R, H] fp32 -> the bf16 planes of [d | 1 | 0...] (column H = 1: bias / db; zero beyond and
+// for rows >= R), laid out FRAGMENT-MAJOR, so that the operand fragment of a wave is one
+// contiguous KiB (64 lanes x 16 bytes, eight full cache lines):
+//   dA[pl][rb][ks][lane][8]   GEMM1's B operand (16x16x32): row 16 rb + (lane & 15),
+//                             k = 32 ks + 8 (lane >> 4) + e                  (rb < Rpad / 16)
+//   dT[pl][ht][kg][lane][8]   GEMM2's A operand (32x32x16): h = 32 ht + (lane & 31),
+//                             row 16 kg + 8 (lane >> 5) + e                  (kg < Rpad / 16)
+// One thread = one lane slot of a fragment, all three planes.  blockIdx.y: 0 = dA, 1 = dT.
+__global__ __launch_bounds__(256) void split3_hidden_kernel(const float* __restrict__ d, int R,
+                                                            int H, int Rpad,
+                                                            uint16_t* __restrict__ dA,
+                                                            uint16_t* __restrict__ dT) {
+  const int slot = blockIdx.x * 256 + threadIdx.x;       // < Rpad * 16
+  if (slot >= Rpad * 16) return;
+  const int lane = slot & 63, frag = slot >> 6;
+  const int nb = Rpad / 16;
+  unsigned t1[8], t2[8], t3[8];
+  auto value = [&](int r, int k) {
+    if (r >= R) return 0.f;
+    return k < H ? d[(size_t)r * H + k] : (k == H ? 1.f : 0.f);
+  };
+  if (blockIdx.y == 0) {
+    const int rb = frag >> 2, ks = frag & 3;
+    const int row = 16 * rb + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split3_trunc(value(row, k0 + e), t1[e], t2[e], t3[e]);
+  } else {
+    const int ht = frag / nb, kg = frag % nb;
+    const int h = 32 * ht + (lane & 31), r0 = 16 * kg + 8 * (lane >> 5);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split3_trunc(value(r0 + e, h), t1[e], t2[e], t3[e]);
+  }
+  auto pack = [](const unsigned* t) {
+    u32x4 v;
+    v.x = pack_hi16(t[0], t[1]); v.y = pack_hi16(t[2], t[3]);
+    v.z = pack_hi16(t[4], t[5]); v.w = pack_hi16(t[6], t[7]);
+    return v;
+  };
+  const size_t plane = (size_t)D3_KP * Rpad;
+  uint16_t* dst = (blockIdx.y == 0 ? dA : dT) + (size_t)slot * 8;
+  *reinterpret_cast<u32x4*>(dst) = pack(t1);
+  *reinterpret_cast<u32x4*>(dst + plane) = pack(t2);
+  *reinterpret_cast<u32x4*>(dst + 2 * plane) = pack(t3);
+}
+
+// ---- LDS / global operand fragments ----
+__device__ __forceinline__ bf16x8 lds_b128(const char* p) {
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+}
+// transpose read: the 16 lanes of a group pass the addresses of a [4 rows][16 columns] block
+// (lane i: row i >> 2, columns 4 (i & 3) ..) and lane i receives column i of the four rows
+__device__ __forceinline__ s16x4 lds_tr(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ bf16x8 lds_tr8(const char* p) {    // rows 0-3 and rows 4-7
+  const s16x4 lo = lds_tr(p), hi = lds_tr(p + 4 * D3_ROWB);
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ bf16x8 global_b128(const uint16_t* p) {
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+}
+
+// one of 8 registers by a per-lane index (3 lane masks of the index bits; inline asm: written as
+// C++ selects the compiler turns the tree into a dynamically indexed array = scratch)
+struct IndexMasks3 { unsigned long long m[3]; };
+__device__ __forceinline__ IndexMasks3 index_masks3(int idx) {
+  IndexMasks3 k;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) k.m[b] = __builtin_amdgcn_ballot_w64((idx >> b) & 1);
+  return k;
+}
+__device__ __forceinline__ float cnd3(float lo, float hi, unsigned long long mask) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(lo), "v"(hi), "s"(mask));
+  return r;
+}
+__device__ __forceinline__ float select8(const float (&v)[8], const IndexMasks3& k) {
+  float a[4], b[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = cnd3(v[2 * i], v[2 * i + 1], k.m[0]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) b[i] = cnd3(a[2 * i], a[2 * i + 1], k.m[1]);
+  return cnd3(b[0], b[1], k.m[2]);
+}
+
+template <int KIND, int KS1>
+__global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
+    const uint16_t* __restrict__ dA, const uint16_t* __restrict__ dT, int R, int Rpad, int H,
+    HeadParams hp, int F, Targets tg, int B, const float* __restrict__ gw, int inline_lgamma,
+    float* __restrict__ ll_part, float* __restrict__ dd_part) {
+  using Traits = LikelihoodTraits<KIND>;
+  constexpr int P = Traits::P;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int HP1 = d3_hp1(H);
+  const int WPLANE = HP1 * D3_ROWB;                 // bytes of one [HP1][64] plane of W
+  char* Wl = smem;                                  // [P][3][HP1][72] bf16
+  char* Gl = smem + (size_t)P * 3 * WPLANE;         // [P][3][64][72] bf16
+  float* llbuf = reinterpret_cast<float*>(Gl + (size_t)P * 3 * D3_GPLANE);   // [4][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int dbg = inline_lgamma >> 8;
+  inline_lgamma &= 1;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, i16 = lane & 15, li = lane & 31, kh = lane >> 5;
+  const int c0 = blockIdx.x * D3_BN;
+
+  // ---- LDS: zero everything (padding and over-read regions must hold finite values), then the
+  //      strip's weights and biases, cut into planes ----
+  {
+    const int n16 = (int)(((size_t)P * 3 * WPLANE + (size_t)P * 3 * D3_GPLANE + 4 * D3_BM * 4) / 16);
+    u32x4* z = reinterpret_cast<u32x4*>(smem);
+    for (int i = tid; i < n16; i += D3_THREADS) z[i] = u32x4{0u, 0u, 0u, 0u};
+  }
+  __syncthreads();
+  {
+    const int g = tid & 63;
+    const bool col_ok = c0 + g < F;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const float* Wj = hp.W[j] + c0 + g;
+      for (int h = tid >> 6; h <= H; h += D3_THREADS / 64) {
+        float v = 0.f;
+        if (col_ok) v = h < H ? Wj[(size_t)h * F] : hp.b[j][c0 + g];
+        unsigned b1, b2, b3;
+        split3_trunc(v, b1, b2, b3);
+        char* dst = Wl + (size_t)(j * 3) * WPLANE + h * D3_ROWB + 2 * g;
+        *reinterpret_cast<uint16_t*>(dst) = (uint16_t)(b1 >> 16);
+        *reinterpret_cast<uint16_t*>(dst + WPLANE) = (uint16_t)(b2 >> 16);
+        *reinterpret_cast<uint16_t*>(dst + 2 * WPLANE) = (uint16_t)(b3 >> 16);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- wave roles ----
+  const int gp = w & 1, rq = w >> 1;        // phase A: genes 32 gp .., rows 16 rq .. of the tile
+  const int ht = w & 3, hi2 = w >> 2;       // phase B: h tile; gene tile (GEMM2) / row tile (GEMM3)
+  const int n_ht3 = (H + 31) / 32, n_ht2 = (H + 1 + 31) / 32;
+  const int nb16 = Rpad / 16;               // 16-row blocks of the planes of d
+
+  // per-lane byte offsets
+  const int trw = (8 * q + (i16 >> 2)) * D3_ROWB + 2 * (32 * gp + 4 * (i16 & 3));   // W, GEMM1
+  const int gst = (16 * rq + i16) * D3_ROWB + 2 * (32 * gp + 4 * q);                // G store
+  const int g3a = (32 * hi2 + li) * D3_ROWB + 16 * kh;                              // G, GEMM3 A
+  const int g3b = (32 * ht + li) * D3_ROWB + 16 * kh;                               // W, GEMM3 B
+  const int g2b = (8 * (q >> 1) + (i16 >> 2)) * D3_ROWB +
+                  2 * (32 * hi2 + 16 * (q & 1) + 4 * (i16 & 3));                    // G, GEMM2 B
+
+  f32x16 accW[P];                           // dW tile (h tile ht, gene tile hi2) of every head
+#pragma unroll
+  for (int j = 0; j < P; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accW[j][i] = 0.f;
+
+  const int n_tiles = (R + D3_BM - 1) / D3_BM;
+  const size_t dplane = (size_t)Rpad * D3_KP;
+
+  // targets / upstream of a tile, in flight from the previous phase B (returned by value: an
+  // array written through a reference capture ends up in scratch memory)
+  struct TileIn { f32x4m t0, t1; float up0; };
+  auto load_t = [&](int m0) {
+    TileIn in;
+    f32x4m tv[2];
+    const int row = m0 + 16 * rq + i16;
+    const bool rok = row < R;
+    in.up0 = rok ? gw[row] : 0.f;
+    const size_t trow = (size_t)((rok ? row : R - 1) % B) * tg.ld;
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      const int c = c0 + 32 * gp + 16 * sb + 4 * q;
+      f32x4m v = {0.f, 0.f, 0.f, 0.f};
+      if (tg.u16) {     // pitch % 8 == 0, padding columns zero: one 8-byte load
+        const uint16_t* tp = static_cast<const uint16_t*>(tg.p) + trow + c;
+        const u32x2 u = *reinterpret_cast<const u32x2*>(tp);
+        v.x = __uint_as_float(u.x); v.y = __uint_as_float(u.y);
+      } else {
+        const float* tp = static_cast<const float*>(tg.p) + trow + c;
+        if (c + 3 < F) {
+          const f32x4u u = *reinterpret_cast<const f32x4u*>(tp);
+          v.x = u.x; v.y = u.y; v.z = u.z; v.w = u.w;
+        } else {
+          v.x = (c < F) ? tp[0] : 0.f;
+          v.y = (c + 1 < F) ? tp[1] : 0.f;
+          v.z = (c + 2 < F) ? tp[2] : 0.f;
+        }
+      }
+      tv[sb] = v;
+    }
+    in.t0 = tv[0]; in.t1 = tv[1];
+    return in;
+  };
+  TileIn nxt = load_t(0);
+  // d fragments of GEMM1 (B[k = h][n = row]): 3 planes per k-step, one contiguous KiB each,
+  // requested one k-step ahead of the MFMAs that use them (k-step 0 of a tile during the
+  // previous phase B)
+  auto load_d1 = [&](int m0, int ks, bf16x8 (&dst)[3]) {
+    const uint16_t* dbase = dA + ((size_t)(m0 / 16 + rq) * 4 + ks) * 512 + lane * 8;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) dst[pl] = global_b128(dbase + pl * dplane);
+  };
+  bf16x8 bfr0[3];
+  load_d1(0, 0, bfr0);
+
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    const int m0 = tile * D3_BM;
+    const f32x4m traw[2] = {nxt.t0, nxt.t1};
+    const float up = nxt.up0;
+    // =================== phase A: GEMM1 (transposed) + likelihood + G -> LDS ===================
+    f32x4m acc1[P][2];
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) acc1[j][sb] = f32x4m{0.f, 0.f, 0.f, 0.f};
+    {
+      // W fragments (transpose reads) and d fragments one k-step ahead of the MFMAs
+      bf16x8 afr[2][P][2][3], bfr[2][3];
+      auto load_w = [&](int ks, bf16x8 (&dst)[P][2][3]) {
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+#pragma unroll
+          for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+              dst[j][sb][pl] = lds_tr8(Wl + (size_t)(j * 3 + pl) * WPLANE + trw + 32 * sb +
+                                       32 * ks * D3_ROWB);
+      };
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bfr[0][pl] = bfr0[pl];
+      load_w(0, afr[0]);
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) {
+        if (dbg & 8) break;
+        if (ks + 1 < KS1) {
+          load_d1(m0, ks + 1, bfr[(ks + 1) & 1]);
+          load_w(ks + 1, afr[(ks + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // small terms first; the four accumulators (head x gene block) are independent chains
+#pragma unroll
+        for (int a = 2; a >= 0; --a)
+#pragma unroll
+          for (int b = 2; b >= 0; --b)
+#pragma unroll
+            for (int j = 0; j < P; ++j)
+#pragma unroll
+              for (int sb = 0; sb < 2; ++sb)
+                acc1[j][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    afr[ks & 1][j][sb][a], bfr[ks & 1][b], acc1[j][sb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- likelihood of this lane's 2 x 4 elements: row 16 rq + i16, genes
+    //      32 gp + 16 sb + 4 q + e ----
+    float G[P][8], tval[8];
+    float lsum = 0.f;
+    unsigned nz = 0;
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      if (tg.u16) {
+        const unsigned v0 = __float_as_uint(traw[sb][0]), v1 = __float_as_uint(traw[sb][1]);
+        tval[4 * sb] = (float)(v0 & 0xFFFFu); tval[4 * sb + 1] = (float)(v0 >> 16);
+        tval[4 * sb + 2] = (float)(v1 & 0xFFFFu); tval[4 * sb + 3] = (float)(v1 >> 16);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tval[4 * sb + e] = traw[sb][e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a[P], g[P], lp, r, rgate;
+#pragma unroll
+        for (int j = 0; j < P; ++j) a[j] = acc1[j][sb][e];
+        if (dbg & 1) {
+          lp = a[0];
+#pragma unroll
+          for (int j = 0; j < P; ++j) g[j] = a[j];
+        } else {
+          lik_dense<KIND, true>(tval[4 * sb + e], a, lp, g, r, rgate);
+        }
+        const bool ok = c0 + 32 * gp + 16 * sb + 4 * q + e < F;
+        lsum += ok ? lp : 0.f;
+#pragma unroll
+        for (int j = 0; j < P; ++j) G[j][4 * sb + e] = up * g[j];
+        nz |= (ok && tval[4 * sb + e] > 0.f) ? (1u << (4 * sb + e)) : 0u;
+      }
+    }
+    // ---- t > 0: + lgamma(r+t) - lgamma(r) [- lgamma(1+t)], and the digamma term of dlog r ----
+    if (dbg & 2) nz = 0;
+    if (Traits::HAS_R || inline_lgamma) {
+      float lr[8];
+      if (Traits::HAS_R) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lr[i] = acc1[P - 1][i >> 2][i & 3];
+      }
+      while (__builtin_amdgcn_ballot_w64(nz != 0) != 0) {
+        const bool on = nz != 0;
+        const int idx = on ? __builtin_ctz(nz) : 0;
+        nz &= nz - 1;
+        const IndexMasks3 km = index_masks3(idx);
+        const float tt = select8(tval, km);
+        float corr = 0.f;
+        if (Traits::HAS_R) {
+          const float lrv = select8(lr, km);
+          const float r = __expf(fminf(fmaxf(lrv, -10.f), 10.f));
+          const float rgate = (lrv >= -10.f && lrv <= 10.f) ? 1.f : 0.f;
+          const bool small = !on || (tt <= 8.f && tt == __builtin_rintf(tt));
+          float A, D;
+          if (__builtin_amdgcn_ballot_w64(!small) == 0)
+            lgamma_digamma_diff_small<true>(r, on ? tt : 0.f, A, D);
+          else
+            lgamma_digamma_diff_general<true>(r, on ? tt : 1.f, A, D);
+          corr = A;
+          const float delta = on ? up * rgate * r * D : 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) G[P - 1][e] += (idx == e) ? delta : 0.f;
+        }
+        if (inline_lgamma) corr -= lgamma1p(tt);
+        lsum += on ? corr : 0.f;
+      }
+    }
+    // ---- row sums over this wave's 32 genes -> llbuf[gp][row] ----
+    {
+      float sm = lsum;
+      sm += __shfl_xor(sm, 16, WAVE);
+      sm += __shfl_xor(sm, 32, WAVE);
+      if (q == 0) llbuf[gp * D3_BM + 16 * rq + i16] = sm;
+    }
+    // ---- G_j -> three bf16 planes, row-major [row][gene], 8 bytes (4 genes) per store ----
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        unsigned b1[4], b2[4], b3[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split3_trunc(G[j][4 * sb + e], b1[e], b2[e], b3[e]);
+        char* dst = Gl + (size_t)(j * 3) * D3_GPLANE + gst + 32 * sb;
+        *reinterpret_cast<u32x2*>(dst) = u32x2{pack_hi16(b1[0], b1[1]), pack_hi16(b1[2], b1[3])};
+        *reinterpret_cast<u32x2*>(dst + D3_GPLANE) =
+            u32x2{pack_hi16(b2[0], b2[1]), pack_hi16(b2[2], b2[3])};
+        *reinterpret_cast<u32x2*>(dst + 2 * D3_GPLANE) =
+            u32x2{pack_hi16(b3[0], b3[1]), pack_hi16(b3[2], b3[3])};
+      }
+    lds_barrier();
+
+    // =================== phase B: GEMM3 (LDS operands), then GEMM2 ===================
+    // per-row log-likelihood of the strip: the four gene blocks summed in a fixed order
+    if (tid < D3_BM && m0 + tid < R)
+      ll_part[(size_t)blockIdx.x * R + m0 + tid] = llbuf[tid] + llbuf[D3_BM + tid];
+    // GEMM2's d fragments (A[i = h][k = row]) come from L2 one k-step ahead; k-step 0 is
+    // requested here and lands under GEMM3
+    auto load_a2 = [&](int ks, bf16x8 (&dst)[3]) {
+      const uint16_t* tb = dT + ((size_t)ht * nb16 + m0 / 16 + ks) * 512 + lane * 8;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) dst[pl] = global_b128(tb + pl * dplane);
+    };
+    bf16x8 a2[2][3];
+    if (ht < n_ht2) load_a2(0, a2[0]);
+    // next tile's targets
+    if (tile + 1 < n_tiles) nxt = load_t(m0 + D3_BM);
+    if (ht < n_ht3 && !(dbg & 4)) {
+      // ---- GEMM3: dd[row, h] = sum_j sum_gene G_j[row, gene] W_j[h, gene] ----
+      f32x16 acc3;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc3[i] = 0.f;
+      bf16x8 af[2][3], bf[2][3];
+      auto load_3 = [&](int st, bf16x8 (&a)[3], bf16x8 (&b)[3]) {   // step = head * 4 + k-step
+        const int j = st >> 2, ks = st & 3;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          a[pl] = lds_b128(Gl + (size_t)(j * 3 + pl) * D3_GPLANE + g3a + 32 * ks);
+          b[pl] = lds_b128(Wl + (size_t)(j * 3 + pl) * WPLANE + g3b + 32 * ks);
+        }
+      };
+      load_3(0, af[0], bf[0]);
+#pragma unroll
+      for (int st = 0; st < 4 * P; ++st) {
+        if (st + 1 < 4 * P) load_3(st + 1, af[(st + 1) & 1], bf[(st + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 2; a >= 0; --a)
+#pragma unroll
+          for (int b = 2; b >= 0; --b)
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st & 1][a], bf[st & 1][b], acc3, 0,
+                                                           0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int h = 32 * ht + li;
+      if (h < H && !(dbg & 16)) {
+        float* dst = dd_part + ((size_t)blockIdx.x * R + m0 + 32 * hi2 + 4 * kh) * H + h;
+        if (m0 + D3_BM <= R) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            __builtin_nontemporal_store(acc3[i], dst + ((i & 3) + 8 * (i >> 2)) * H);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int ro = (i & 3) + 8 * (i >> 2);
+            if (m0 + 32 * hi2 + 4 * kh + ro < R) __builtin_nontemporal_store(acc3[i], dst + ro * H);
+          }
+        }
+      }
+    }
+    // the next tile's d fragments of GEMM1: in flight under GEMM2 and the barrier
+    if (tile + 1 < n_tiles) load_d1(m0 + D3_BM, 0, bfr0);
+    if (ht < n_ht2 && !(dbg & 4)) {
+      // ---- GEMM2: dW_j[h, gene] += sum_row d[row, h] G_j[row, gene] ----
+      bf16x8 bf[2][3];
+      auto load_2 = [&](int st, bf16x8 (&b)[3]) {                    // step = k-step * P + head
+        const int ks = st / P, j = st % P;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          b[pl] = lds_tr8(Gl + (size_t)(j * 3 + pl) * D3_GPLANE + g2b + 16 * ks * D3_ROWB);
+      };
+      load_2(0, bf[0]);
+#pragma unroll
+      for (int st = 0; st < 4 * P; ++st) {
+        if (st + 1 < 4 * P) load_2(st + 1, bf[(st + 1) & 1]);
+        if (st % P == 0 && st / P + 1 < 4) load_a2(st / P + 1, a2[(st / P + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const int ks = st / P, j = st % P;
+#pragma unroll
+        for (int a = 2; a >= 0; --a)
+#pragma unroll
+          for (int b = 2; b >= 0; --b)
+            accW[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks & 1][a], bf[st & 1][b], accW[j], 0,
+                                                              0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    lds_barrier();
+  }
+
+  // ---- dW / db of the strip ----
+  if (ht < n_ht2) {
+    const int c = c0 + 32 * hi2 + li;
+    if (c < F) {
+#pragma unroll
+      for (int j = 0; j < P; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int h = 32 * ht + (i & 3) + 8 * (i >> 2) + 4 * kh;
+          if (h < H) hp.dW[j][(size_t)h * F + c] = accW[j][i];
+          else if (h == H) hp.db[j][c] = accW[j][i];
+        }
+    }
+  }
+}
+
+int decoder_fused3_launch(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
+                          int F, Targets t, int B, const float* gw, int inline_lgamma,
+                          float* ll_part, float* dd_part, float* planes) {
+  const int P = likelihood_heads(kind);
+  SCVAE_ARG(decoder_fused3_supported(P, H) && planes);
+  const int Rpad = (rows + D3_BM - 1) / D3_BM * D3_BM;
+  uint16_t* dA = reinterpret_cast<uint16_t*>(planes);
+  uint16_t* dT = dA + (size_t)3 * Rpad * D3_KP;
+  {
+    hipLaunchKernelGGL(split3_hidden_kernel, dim3((Rpad * 16 + 255) / 256, 2), dim3(256), 0, s, d,
+                       rows, H, Rpad, dA, dT);
+    SCVAE_LAUNCH_CHECK("split3_hidden_kernel");
+  }
+  const size_t lds = decoder_fused3_lds_bytes(P, H);
+  const int strips = (F + D3_BN - 1) / D3_BN;
+  const int ks1 = (d3_hp1(H) + 31) / 32;
+#define SCVAE_D3K(K_, KS_)                                                                        \
+  do {                                                                                            \
+    auto kfn = decoder_head3_kernel<K_, KS_>;                                                     \
+    SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
+    hipLaunchKernelGGL(kfn, dim3(strips), dim3(D3_THREADS), lds, s, dA, dT, rows, Rpad, H, hp, F, \
+                       t, B, gw, inline_lgamma, ll_part, dd_part);                                \
+  } while (0)
+#define SCVAE_D3(K_)                                                                              \
+  switch (ks1) {                                                                                  \
+    case 1: SCVAE_D3K(K_, 1); break;                                                              \
+    case 2: SCVAE_D3K(K_, 2); break;                                                              \
+    case 3: SCVAE_D3K(K_, 3); break;                                                              \
+    default: SCVAE_D3K(K_, 4); break;                                                             \
+  }
+  switch (kind) {
+    case LK_POISSON: SCVAE_D3(LK_POISSON); break;
+    case LK_NB: SCVAE_D3(LK_NB); break;
+    case LK_ZIP: SCVAE_D3(LK_ZIP); break;
+    default: set_error("decoder_head3_kernel: likelihood kind %d", kind); return -1;
+  }
+#undef SCVAE_D3
+#undef SCVAE_D3K
+  SCVAE_LAUNCH_CHECK("decoder_head3_kernel");
+  return 0;
+}
+
+}  // namespace scvae

@@ -204,6 +204,17 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
                         int F, Targets t, int B, const float* gw, const float* row_const,
                         float* ll, float* dd, float* workspace, bool kernel_only = false);
 
+// training kernel on the bf16 matrix cores, exact nine-term split (decoder_fused3.hip)
+bool decoder_fused3_supported(int P, int H);
+size_t decoder_fused3_lds_bytes(int P, int H);
+size_t decoder_fused3_workspace_floats(int rows);
+int decoder_fused3_launch(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
+                          int F, Targets t, int B, const float* gw, int inline_lgamma,
+                          float* ll_part, float* dd_part, float* planes);
+int decoder_head_arith();              // 0: fp32 MFMA, 1: bf16x9 where decoder_fused3 applies
+void set_decoder_head_arith(int mode);
+int decoder_train_kernel(int P, int H);   // 1 / 2: the fp32 schedules, 3: decoder_head3_kernel
+
 // forward-only variant with the pre-activations in registers (decoder_forward.hip)
 bool decoder_forward_supported(int P, int H);
 int decoder_forward_launch(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,

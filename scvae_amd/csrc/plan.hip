@@ -1117,6 +1117,16 @@ int32_t scvae_decoder_fused_variant(int32_t kind, int64_t H) {
   if (kind < 0 || kind > 3 || !scvae::decoder_fused_supported((int)H)) return 0;
   return scvae::decoder_fused_variant(scvae::likelihood_heads(kind), (int)H);
 }
+int32_t scvae_decoder_head_arith(void) { return scvae::decoder_head_arith(); }
+int scvae_set_decoder_head_arith(int32_t mode) {
+  SCVAE_ARG(mode == 0 || mode == 1);
+  scvae::set_decoder_head_arith(mode);
+  return 0;
+}
+int32_t scvae_decoder_train_kernel(int32_t kind, int64_t H) {
+  if (kind < 0 || kind > 3 || !scvae::decoder_fused_supported((int)H)) return 0;
+  return scvae::decoder_train_kernel(scvae::likelihood_heads(kind), (int)H);
+}
 static int decoder_fused_entry(int32_t kind, int32_t train, const float* d, int64_t rows, int64_t H,
                                const float* const* W, const float* const* b, float* const* dW,
                                float* const* db, int64_t F, scvae::Targets t, int64_t cells,

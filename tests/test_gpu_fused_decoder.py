@@ -13,6 +13,19 @@ from oracle import likelihoods as lk
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["fp32", "bf16x9"], autouse=True)
+def head_arith(request):
+    """Every case on both training kernels: the fp32 matrix cores and the exact
+    nine-term bf16 split (decoder_head3_kernel, where it applies)."""
+    from scvae_amd import _lib
+    lib = _lib.load()
+    before = lib.scvae_decoder_head_arith()
+    _lib.check(lib.scvae_set_decoder_head_arith(
+        1 if request.param == "bf16x9" else 0), "scvae_set_decoder_head_arith")
+    yield request.param
+    lib.scvae_set_decoder_head_arith(before)
+
+
 def _run(device, name, rows, cells, F, H, density, seed=0, row_const=True):
     from scvae_amd import _lib
     lib = _lib.load()
