@@ -41,6 +41,8 @@ N_CELLS, N_FEATURES = 68579, 32738
 HIDDEN, LATENT = (100, 100), 25
 LIKELIHOOD = "negative binomial"
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense (MI355X_MICROARCH.md); the exact nine-term split of an
+                                # fp32 product costs nine bf16 MFMAs: 2500 / 9 = 277.8 TFLOP/s
 PEAK_HBM_GBS = 8000.0
 MIN_WARM_SECONDS = 1.0          # real steps before the timed window, whatever --warmup says
 
@@ -216,12 +218,14 @@ def _measured_traffic(rows, F, H, kernel, targets="f32"):
     return None
 
 
-def time_dominant_kernel(engine, rows, launches=10, u16=False):
+def time_dominant_kernel(engine, rows, launches=10, u16=False, arith=None):
     """Average duration (HIP events on the launch stream) of the dominant
     kernel of the step -- the fused decoder-head kernel -- run standalone on
-    the step's own shapes (main kernel only, without its two small reductions,
+    the step's own shapes (main kernel only, without its small reductions,
     so that the figure matches rocprofv3's per-kernel average).  ``u16``: the
-    targets as the uint16 minibatch, as the step launches it."""
+    targets as the uint16 minibatch, as the step launches it.  ``arith``: 0 =
+    the fp32-MFMA kernel, 1 = the exact nine-term bf16 kernel, None = whatever
+    the step runs (the process-wide setting)."""
     import torch
     from scvae_amd import _lib
     lib = engine.lib
@@ -269,31 +273,48 @@ def time_dominant_kernel(engine, rows, launches=10, u16=False):
             kind, 3, d.data_ptr(), rows, H, aW, ab, adW, adb, F, t.data_ptr(),
             rows, gw.data_ptr(), rc.data_ptr(), ll.data_ptr(), dd.data_ptr(),
             ws.data_ptr(), stream), "scvae_decoder_fused")
-    for _ in range(3):
-        launch()
-    torch.cuda.synchronize(dev)
-    start, stop = torch.cuda.Event(True), torch.cuda.Event(True)
-    start.record()
-    for _ in range(launches):
-        launch()
-    stop.record()
-    torch.cuda.synchronize(dev)
+    setting = lib.scvae_decoder_head_arith()
+    if arith is not None:
+        lib.scvae_set_decoder_head_arith(arith)
+    try:
+        which = lib.scvae_decoder_train_kernel(kind, H)
+        for _ in range(3):
+            launch()
+        torch.cuda.synchronize(dev)
+        start, stop = torch.cuda.Event(True), torch.cuda.Event(True)
+        start.record()
+        for _ in range(launches):
+            launch()
+        stop.record()
+        torch.cuda.synchronize(dev)
+    finally:
+        lib.scvae_set_decoder_head_arith(setting)
     seconds = start.elapsed_time(stop) / 1e3 / launches
     # algorithmic flops of the decoder heads: forward + dW + dX, 2 flop / MAC
     flops = 2.0 * rows * F * P * 3 * H
-    if lib.scvae_decoder_fused_variant(kind, H) == 2:
-        kernel = "decoder_head2_kernel<{}, true>".format(kind)
+    # the instantiation as rocprofv3 prints it
+    if which == 3:
+        kernel = "decoder_head3_kernel<{}, {}>".format(kind, ((H + 1 + 15) // 16 * 16 + 31) // 32)
+        peak, arith_name = PEAK_BF16_MFMA_TFLOPS / 9.0, "bf16x9-exact"
+    elif which == 2:
+        rem = P <= 2 and 96 < H <= 111 and rows >= 512
+        kernel = "decoder_head2_kernel<{}, true, {}>".format(kind, "true" if rem else "false")
+        peak, arith_name = PEAK_FP32_MFMA_TFLOPS, "f32"
     else:
-        kernel = "decoder_head_kernel<{}, true, {}>".format(
-            kind, 32 if P >= 3 else 64)
+        kernel = "decoder_head_kernel<{}, true, {}>".format(kind, 32 if P >= 3 else 64)
+        peak, arith_name = PEAK_FP32_MFMA_TFLOPS, "f32"
     return {
         "kernel": "{} (X_TILDE heads + likelihood + dW/db/dd, "
                   "[rows,{}]x[{},{}]x{} heads)".format(kernel, H, H, F, P),
+        "arith": arith_name,
         "bound": "mfma",
         "achieved": flops / seconds / 1e12,
-        "peak": PEAK_FP32_MFMA_TFLOPS,
+        "peak": peak,
         "unit": "TFLOP/s",
-        "frac": flops / seconds / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+        "frac": flops / seconds / 1e12 / peak,
+        # the same launch against the fp32 matrix cores' peak (what an fp32-in / fp32-out
+        # product can reach without the split): comparable across the two kernels
+        "frac_of_fp32_mfma_peak": flops / seconds / 1e12 / PEAK_FP32_MFMA_TFLOPS,
         "traffic": _measured_traffic(rows, F, H, kernel, "u16" if u16 else "f32"),
         "targets": "u16" if u16 else "f32",
         "launch_us": seconds * 1e6,
@@ -542,6 +563,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            # (decoder_head_arith, below: the heads' products as exact nine-term bf16 splits
+            #  with fp32 accumulation where that kernel applies)
             # x W1 and x^T dA of the input layer: exact hi/lo bf16 cut of the integer
             # counts times an exact three-term bf16 split of the fp32 operand, fp32
             # accumulation (count_gemm.hip); everything else fp32 MFMA / VALU
@@ -573,6 +596,12 @@ def main():
             result["train_flop_per_cell"] = None
             result["step_mfma_frac"] = None
         result["roofline"] = time_dominant_kernel(engine, B * K, u16=work.u16)
+        # arithmetic of the decoder heads' three products in the training kernel
+        result["decoder_head_arith"] = result["roofline"]["arith"]
+        if result["roofline"]["arith"] != "f32":
+            # the fp32-MFMA kernel on the same shapes, for comparison (not what the step ran)
+            result["roofline_fp32_kernel"] = time_dominant_kernel(
+                engine, B * K, u16=work.u16, arith=0)
         headline = (not gm and args.likelihood == LIKELIHOOD and L == LATENT)
         if world == 1 and headline and not args.no_other_workloads:
             result["other_workloads"] = other_workloads(matrix, device, barrier)

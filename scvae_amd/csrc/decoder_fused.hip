@@ -535,13 +535,13 @@ int decoder_fused_variant(int P, int H) {
 
 // Arithmetic of the three products of the TRAINING kernel: 0 = fp32 MFMA (decoder_fused.hip /
 // decoder_fused2.hip), 1 = the exact nine-term bf16 split (decoder_fused3.hip) where that kernel
-// applies (one / two heads, its LDS budget).  Process-wide; SCVAE_HEAD_ARITH=fp32|bf16x9 sets the
-// initial value.
+// applies (one / two heads, its LDS budget).  Process-wide; default bf16x9, SCVAE_HEAD_ARITH=fp32
+// starts a process on the fp32 kernels.
 static int g_head_arith = -1;
 int decoder_head_arith() {
   if (g_head_arith < 0) {
     const char* e = getenv("SCVAE_HEAD_ARITH");
-    g_head_arith = (e && (e[0] == 'b' || e[0] == '1')) ? 1 : 0;
+    g_head_arith = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : 1;   // default: bf16x9
   }
   return g_head_arith;
 }
