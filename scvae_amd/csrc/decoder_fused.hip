@@ -507,6 +507,91 @@ __global__ __launch_bounds__(256) void dd_reduce_scalar_kernel(const float* __re
   }
 }
 
+// The same sums for the h-major slabs [strips][H][R] of decoder_head3_kernel (dd_part[z][h][r]):
+// a thread owns four consecutive rows of one h (16-byte loads along the rows) and writes them to
+// the row-major dd[r][h]; `split`: 16 thread groups per 16 columns, every 16th slab each (small
+// batches, as dd_reduce_split_kernel).
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void dd_reduce_t_kernel(const float* __restrict__ dd_part,
+                                                          int strips, int R, int H,
+                                                          float* __restrict__ dd) {
+  __shared__ float4 red[16][16];
+  const size_t n4 = (size_t)R * H / 4;       // R % 4 == 0
+  const float4* p4 = reinterpret_cast<const float4*>(dd_part);
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  auto emit = [&](size_t i, float4 t) {
+    const int r4 = R / 4;
+    const int h = (int)(i / r4), r0 = (int)(i % r4) * 4;
+    dd[(size_t)r0 * H + h] = t.x;
+    dd[(size_t)(r0 + 1) * H + h] = t.y;
+    dd[(size_t)(r0 + 2) * H + h] = t.z;
+    dd[(size_t)(r0 + 3) * H + h] = t.w;
+  };
+  if (SPLIT) {
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * 16 + cl;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+      int z = g;
+      for (; z + 7 * 16 < strips; z += 8 * 16) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p4[(size_t)(z + u * 16) * n4 + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+      }
+      for (; z < strips; z += 16) {
+        const float4 v = p4[(size_t)z * n4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && i < n4) {
+      float4 t = red[0][cl];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) {
+        const float4 v = red[k][cl];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+      emit(i, t);
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (size_t)gridDim.x * blockDim.x) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      int z = 0;
+      for (; z + 8 <= strips; z += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const f32x4 q = __builtin_nontemporal_load(
+              reinterpret_cast<const f32x4*>(p4 + (size_t)(z + u) * n4 + i));
+          v[u] = make_float4(q.x, q.y, q.z, q.w);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+      }
+      for (; z < strips; ++z) {
+        const float4 v = p4[(size_t)z * n4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      emit(i, s);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void dd_reduce_t_scalar_kernel(const float* __restrict__ dd_part,
+                                                                 int strips, int R, int H,
+                                                                 float* __restrict__ dd) {
+  const size_t n = (size_t)R * H;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < strips; ++z) s += dd_part[(size_t)z * n + i];
+    dd[(i % R) * H + i / R] = s;
+  }
+}
+
 bool decoder_fused_supported(int H) { return H >= 2 && H <= 126 && (H % 2) == 0; }
 
 size_t decoder_fused_workspace_floats(int rows, int H, int F, bool train) {
@@ -634,6 +719,25 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
                      strips, rows, row_const, B, ll);
   SCVAE_LAUNCH_CHECK("ll_reduce_kernel");
   const size_t n = (size_t)rows * H;
+  if (decoder_train_kernel(likelihood_heads(kind), H) == 3) {
+    // h-major slabs of decoder_head3_kernel
+    if (rows % 4 == 0 && n / 4 <= DD_SPLIT_MAX) {
+      hipLaunchKernelGGL(dd_reduce_t_kernel<true>, dim3((unsigned)((n / 4 + 15) / 16)), dim3(256),
+                         0, s, dd_part, strips, rows, H, dd);
+    } else if (rows % 4 == 0) {
+      size_t blocks = (n / 4 + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(dd_reduce_t_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s,
+                         dd_part, strips, rows, H, dd);
+    } else {
+      size_t blocks = (n + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(dd_reduce_t_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                         dd_part, strips, rows, H, dd);
+    }
+    SCVAE_LAUNCH_CHECK("dd_reduce_t_kernel");
+    return 0;
+  }
   if (n % 4 == 0 && n / 4 <= DD_SPLIT_MAX) {
     hipLaunchKernelGGL(dd_reduce_split_kernel, dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0,
                        s, dd_part, strips, n, dd);

@@ -467,23 +467,21 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
         for (int a = 2; a >= 0; --a)
 #pragma unroll
           for (int b = 2; b >= 0; --b)
-            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st & 1][a], bf[st & 1][b], acc3, 0,
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[st & 1][b], af[st & 1][a], acc3, 0,
                                                            0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      const int h = 32 * ht + li;
-      if (h < H && !(dbg & 16)) {
-        float* dst = dd_part + ((size_t)blockIdx.x * R + m0 + 32 * hi2 + 4 * kh) * H + h;
-        if (m0 + D3_BM <= R) {
+      // (computed transposed, dd^T[h, row], and stored to an h-major slab [strip][H][R]: a
+      //  store instruction then writes 32 consecutive rows of one h -- whole 128-byte lines --
+      //  where a row-major slab takes 100-float rows in partial lines.  Non-temporal: the slabs
+      //  are read exactly once, by dd_reduce_t_kernel)
+      const int row = m0 + 32 * hi2 + li;
+      if (row < R && !(dbg & 16)) {
+        float* dst = dd_part + ((size_t)blockIdx.x * H + 32 * ht + 4 * kh) * R + row;
 #pragma unroll
-          for (int i = 0; i < 16; ++i)
-            __builtin_nontemporal_store(acc3[i], dst + ((i & 3) + 8 * (i >> 2)) * H);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int ro = (i & 3) + 8 * (i >> 2);
-            if (m0 + 32 * hi2 + 4 * kh + ro < R) __builtin_nontemporal_store(acc3[i], dst + ro * H);
-          }
+        for (int i = 0; i < 16; ++i) {
+          const int ho = (i & 3) + 8 * (i >> 2);
+          if (32 * ht + 4 * kh + ho < H) __builtin_nontemporal_store(acc3[i], dst + (size_t)ho * R);
         }
       }
     }
