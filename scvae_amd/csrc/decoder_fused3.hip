@@ -322,7 +322,6 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
           load_d1(m0, ks + 1, bfr[(ks + 1) & 1]);
           load_w(ks + 1, afr[(ks + 1) & 1]);
         }
-        __builtin_amdgcn_sched_barrier(0);
         // small terms first; the four accumulators (head x gene block) are independent chains
 #pragma unroll
         for (int a = 2; a >= 0; --a)
@@ -334,7 +333,6 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
               for (int sb = 0; sb < 2; ++sb)
                 acc1[j][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     afr[ks & 1][j][sb][a], bfr[ks & 1][b], acc1[j][sb], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // ---- likelihood of this lane's 2 x 4 elements: row 16 rq + i16, genes
@@ -462,14 +460,12 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
 #pragma unroll
       for (int st = 0; st < 4 * P; ++st) {
         if (st + 1 < 4 * P) load_3(st + 1, af[(st + 1) & 1], bf[(st + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 2; a >= 0; --a)
 #pragma unroll
           for (int b = 2; b >= 0; --b)
             acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[st & 1][b], af[st & 1][a], acc3, 0,
                                                            0, 0);
-        __builtin_amdgcn_sched_barrier(0);
       }
       // (computed transposed, dd^T[h, row], and stored to an h-major slab [strip][H][R]: a
       //  store instruction then writes 32 consecutive rows of one h -- whole 128-byte lines --
@@ -501,7 +497,6 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
       for (int st = 0; st < 4 * P; ++st) {
         if (st + 1 < 4 * P) load_2(st + 1, bf[(st + 1) & 1]);
         if (st % P == 0 && st / P + 1 < 4) load_a2(st / P + 1, a2[(st / P + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
         const int ks = st / P, j = st % P;
 #pragma unroll
         for (int a = 2; a >= 0; --a)
@@ -509,7 +504,6 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
           for (int b = 2; b >= 0; --b)
             accW[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks & 1][a], bf[st & 1][b], accW[j], 0,
                                                               0, 0);
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
     lds_barrier();

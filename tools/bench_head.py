@@ -20,7 +20,8 @@ kind, heads = _lib.LIKELIHOOD_KINDS[name]
 P = len(heads)
 g = torch.Generator(device=dev).manual_seed(5)
 d = torch.relu(torch.randn(rows, H, device=dev, generator=g))
-W = [torch.randn(H, F, device=dev, generator=g) * 0.1 for _ in range(P)]
+WS = float(os.environ.get("WSCALE", "0.1"))
+W = [torch.randn(H, F, device=dev, generator=g) * WS for _ in range(P)]
 b = [torch.randn(F, device=dev, generator=g) * 0.1 for _ in range(P)]
 t = torch.poisson(torch.full((rows, F), 2.0, device=dev), generator=g)
 t = t * (torch.rand(rows, F, device=dev, generator=g) < 0.05)
