@@ -53,7 +53,11 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096,
-                    help="cells per GPU per step (weak scaling)")
+                    help="cells per GPU per step (weak scaling) / cells per step over all "
+                         "GPUs (strong scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch cells per GPU; strong: --batch cells in total, "
+                         "split evenly over the ranks")
     ap.add_argument("--cells", type=int, default=N_CELLS)
     ap.add_argument("--features", type=int, default=N_FEATURES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -371,7 +375,7 @@ class Workload:
         return self.torch.randperm(self.matrix.number_of_rows,
                                    generator=self.generator, device=self.device)
 
-    def one_step(self):
+    def one_step(self, comm_events=None):
         from scvae_amd.minibatch import philox_normal_blocks
         n, B, GB, rank = self.matrix.number_of_rows, self.B, self.GB, self.rank
         if self.cursor + GB > n:
@@ -392,7 +396,7 @@ class Workload:
                          training=True, global_cells=GB, row_offset=rank * B,
                          x_counts=self.matrix.integer_counts)
         if self.sync is not None:
-            self.sync.all_reduce_gradients()
+            self.sync.all_reduce_gradients(events=comm_events)
         self.engine.adam_step(1e-4)
 
     def run(self, steps, warmup, barrier, min_warm_seconds=MIN_WARM_SECONDS):
@@ -421,15 +425,20 @@ class Workload:
             warm_steps += 8
             barrier()
         events = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        # (data parallel) events around the waits for the gradient all-reduce: what the
+        # step did not hide of the communication
+        comm = ([(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                 for _ in range(steps)] if self.sync is not None else None)
         barrier()
         t0 = time.perf_counter()
         events[0].record()
         for i in range(steps):
-            self.one_step()
+            self.one_step(comm[i] if comm else None)
             events[i + 1].record()
         barrier()
         elapsed = time.perf_counter() - t0
         per_step = [events[i].elapsed_time(events[i + 1]) for i in range(steps)]
+        self.exposed_comm_ms = ([a.elapsed_time(b) for a, b in comm] if comm else [])
         return elapsed, per_step, warm_steps
 
 
@@ -522,6 +531,11 @@ def main():
     matrix, _ = synthetic_count_matrix(
         args.cells, args.features, density=0.05, seed=60, device=device)
     F, B, L = args.features, args.batch, args.latent
+    if args.scaling == "strong":
+        if B % world:
+            raise SystemExit("--scaling strong: --batch {} does not split over {} ranks"
+                             .format(B, world))
+        B //= world
     gm = args.model == "gmvae"
     K = args.clusters if gm else 1
     work = Workload(matrix, device, B, args.likelihood, L, model=args.model,
@@ -539,6 +553,18 @@ def main():
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    # per-rank figures: median step time and the communication the step did not hide
+    rank_ms = [statistics.median(per_step)]
+    rank_comm = [statistics.median(work.exposed_comm_ms) if work.exposed_comm_ms else 0.0]
+    if world > 1:
+        # (gloo -- the 1-GPU debugging set-up -- gathers host tensors only)
+        mine = torch.tensor([rank_ms[0], rank_comm[0]], dtype=torch.float64,
+                            device=device if backend == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(t[0]) for t in every]
+        rank_comm = [float(t[1]) for t in every]
 
     engine = work.engine
     scalars = engine.scalars.clone()
@@ -560,7 +586,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             # (decoder_head_arith, below: the heads' products as exact nine-term bf16 splits
@@ -583,6 +609,11 @@ def main():
             "collective_backend": ("rccl (torch 'nccl')" if backend == "nccl"
                                    else backend),
             "ranks_in_communicator": ranks_seen,
+            "rank_step_ms_median": rank_ms,
+            # per rank, median over the timed steps: time between the first and the last wait
+            # for the gradient all-reduce (three pieces, two of them issued under the backward
+            # pass) -- the part of the collective the step did not hide
+            "rank_exposed_allreduce_ms_median": rank_comm,
             "warm_steps_before_timing": warm_steps,
             "step_ms_min": min(per_step),
             "step_ms_median": statistics.median(per_step),
@@ -610,6 +641,8 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
+        from scvae_amd.dataparallel import release_gradient_groups
+        release_gradient_groups()
         dist.destroy_process_group()
 
 

@@ -54,6 +54,39 @@ def merge_batch_norm_statistics(gathered, counts):
     return mean, m2 / total
 
 
+# One gradient communicator per (backend, ranks) and process: ``dist.new_group`` is a collective
+# that allocates an RCCL communicator which is never freed, and ``model.train`` builds a new
+# synchroniser on every call.
+_GRADIENT_GROUPS = {}
+
+
+def gradient_group_for(group=None):
+    """The communicator the asynchronous gradient all-reduces run on -- distinct
+    from ``group``, created once per process and set of ranks.  COLLECTIVE over
+    the default group on first use (``dist.new_group`` must be entered by every
+    process of the default group, members or not): construct synchronisers at
+    the same point on every rank, or create the group up front and pass it as
+    ``gradient_group``."""
+    ranks = tuple(dist.get_process_group_ranks(group) if group is not None
+                  else range(dist.get_world_size()))
+    key = (dist.get_backend(group), ranks)
+    if key not in _GRADIENT_GROUPS:
+        _GRADIENT_GROUPS[key] = dist.new_group(ranks=list(ranks),
+                                               backend=key[0])
+    return _GRADIENT_GROUPS[key]
+
+
+def release_gradient_groups():
+    """Destroy the cached gradient communicators (before
+    ``dist.destroy_process_group()`` at the end of a job)."""
+    for g in _GRADIENT_GROUPS.values():
+        try:
+            dist.destroy_process_group(g)
+        except Exception:   # the default group is already gone
+            pass
+    _GRADIENT_GROUPS.clear()
+
+
 class GradientSynchroniser:
     """Collectives of one data-parallel rank, bound to an ``Engine``."""
 
@@ -69,10 +102,7 @@ class GradientSynchroniser:
         # behind the 26 MB gradient bucket issued just before them.  (Collective call: every
         # rank constructs its synchroniser at the same point.)
         if gradient_group is None and self.world_size > 1:
-            ranks = (dist.get_process_group_ranks(group) if group is not None
-                     else list(range(self.world_size)))
-            gradient_group = dist.new_group(ranks=ranks,
-                                            backend=dist.get_backend(group))
+            gradient_group = gradient_group_for(group)
         self.gradient_group = gradient_group if gradient_group is not None else group
         self.lib = _lib.load()
         self._check = _lib.check
@@ -136,10 +166,15 @@ class GradientSynchroniser:
             print("[scvae_amd] sync hook failed:", repr(error), flush=True)
             return 1
 
-    def all_reduce_gradients(self):
+    def all_reduce_gradients(self, events=None):
         """Sum the gradient buffer over the ranks: the ranges announced early by
-        the step (hook kind 2) are already in flight, the rest is reduced here."""
+        the step (hook kind 2) are already in flight, the rest is reduced here.
+        ``events``: an optional pair of CUDA events recorded on the compute stream
+        before the first and after the last wait -- the time between them is the
+        communication the step did not hide."""
         grads = self.engine.grads
+        if events is not None:
+            events[0].record()
         position = 0
         for offset, count, _ in sorted(self._pending, key=lambda p: p[0]):
             if offset > position:
@@ -151,6 +186,8 @@ class GradientSynchroniser:
         for _, _, work in self._pending:
             work.wait()
         self._pending = []
+        if events is not None:
+            events[1].record()
 
     def all_reduce_scalars(self, scalars):
         dist.all_reduce(scalars, group=self.group)

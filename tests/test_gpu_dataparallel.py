@@ -269,3 +269,34 @@ def test_model_train_two_ranks_equals_single_process(cuda_device, tmp_path):
     # the reconstructed data set: rows filled by the other rank included
     assert worst_mean <= 5e-3, worst_mean
     assert worst_stddev <= 5e-3, worst_stddev
+
+
+def test_bench_with_eight_ranks_on_one_gpu():
+    """``bench.py --gpus 8`` as the driver's scaling run starts it -- rendezvous
+    on 127.0.0.1, the two communicators, shard arithmetic at N = 8 (4096 / 8 rows
+    per rank, strong scaling), sync batch norm, the three-piece gradient
+    all-reduce, the per-rank report -- with gloo moving the bytes and all eight
+    ranks on the one GPU of the test box.  Plumbing only: nothing is timed."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCVAE_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run(
+        [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8",
+         "--scaling", "strong", "--batch", "4096", "--cells", "8192",
+         "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+         "--no-other-workloads"],
+        env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 8 and r["ranks_in_communicator"] == 8
+    assert r["scaling"] == "strong"
+    assert r["config"]["global_batch"] == 4096
+    assert r["config"]["cells_per_gpu_per_step"] == 512
+    assert len(r["rank_step_ms_median"]) == 8
+    assert len(r["rank_exposed_allreduce_ms_median"]) == 8
+    assert r["value"] > 0 and r["last_lower_bound"] < 0
