@@ -349,6 +349,8 @@ class Workload:
                              model_type="GMVAE" if self.gm else "VAE",
                              n_clusters=self.K, device=device, seed=0)
         self.engine.reserve(batch, 1)
+        if os.environ.get("SCVAE_BENCH_COUNT_ALWAYS"):
+            self.engine.set_count_gemm(True, always=True)
         self.sync = None
         if data_parallel:
             from scvae_amd.dataparallel import GradientSynchroniser

@@ -992,22 +992,42 @@ int scvae_plan_decode(scvae_plan* p, const float* z, int64_t rows, float* p_x_me
 int scvae_plan_accepts_counts_u16(const scvae_plan* p, int64_t cells, int32_t training) {
   if (!p || cells <= 0) return 0;
   const scvae_model_config& c = p->cfg;
-  if (c.model_type == SCVAE_MODEL_GMVAE) return 0;
+  const bool gm = c.model_type == SCVAE_MODEL_GMVAE;
   if (!p->use_count_gemm || !p->use_fused || !p->fused_ws) return 0;
   if (c.likelihood > scvae::LK_ZINB || c.k_max > 0) return 0;
   if (!scvae::decoder_fused_supported(p->heads[0].n_in)) return 0;
-  const int n_x = p->enc.empty() ? c.latent_size : p->enc[0].n_out;
-  if (!scvae::count_gemm_supported(n_x)) return 0;
+  // the layers that see x: the VAE's first encoder layer (or the posterior heads of a model
+  // without hidden layers); the GMVAE's first q(y|x) and q(z|x,y) layers
+  int n_x[2] = {0, 0};
+  if (gm) {
+    if (p->zenc.empty()) return 0;
+    n_x[0] = p->zenc[0].n_out;
+    n_x[1] = p->yenc.empty() ? c.n_clusters : p->yenc[0].n_out;
+  } else {
+    n_x[0] = n_x[1] = p->enc.empty() ? c.latent_size : p->enc[0].n_out;
+  }
+  for (int i = 0; i < 2; ++i)
+    if (!scvae::count_gemm_supported(n_x[i])) return 0;
   if (training) {
     if (p->heads[0].keep > 0.f) return 0;
-    if (!p->enc.empty() ? p->enc[0].keep > 0.f : (p->mu.keep > 0.f || p->ls.keep > 0.f)) return 0;
+    if (gm) {
+      if (p->zenc[0].keep > 0.f) return 0;
+      if (!p->yenc.empty() ? p->yenc[0].keep > 0.f : p->ylogits.keep > 0.f) return 0;
+    } else if (!p->enc.empty() ? p->enc[0].keep > 0.f : (p->mu.keep > 0.f || p->ls.keep > 0.f)) {
+      return 0;
+    }
   }
-  // both products on the count kernels by the plan's own rule (plan_gemm)
-  if (p->use_count_gemm < 2 && (double)cells * c.feature_size < 768.0 * 32768.0) return 0;
+  // both products on the count kernels by the plan's own rule (plan_gemm); the GMVAE, whose K
+  // decoder passes re-read the targets, from the size where the weight-gradient kernel pays
+  if (p->use_count_gemm < 2 &&
+      (double)cells * c.feature_size < (gm ? 384.0 : 768.0) * 32768.0)
+    return 0;
   // ... and inside the workspace the plan reserved for them (plan_gemm would refuse the step)
   for (int mode = 0; mode < 2; ++mode)
-    if (scvae::count_gemm_workspace_bytes(mode, (int)cells, c.feature_size, n_x) > p->gemm_ws_bytes)
-      return 0;
+    for (int i = 0; i < 2; ++i)
+      if (scvae::count_gemm_workspace_bytes(mode, (int)cells, c.feature_size, n_x[i]) >
+          p->gemm_ws_bytes)
+        return 0;
   return 1;
 }
 

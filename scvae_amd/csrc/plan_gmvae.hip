@@ -222,7 +222,8 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   } while (0)
 
   // ---------------- q(y|x) (gm:3050-3092) ----------------
-  const float* h = a->x;
+  // (the fp32 batch, or the token of the uint16 one: plan_gemm hands that to the count kernels)
+  const float* h = p->step_x;
   int ld = F;
   for (auto& d : p->yenc) {
     TRY(dense_forward(p, s, d, h, ld, B, 1, true, training));
@@ -238,12 +239,16 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   if (a->q_y_logits) TRY(copy(s, p->logits, a->q_y_logits, (size_t)B * K));
 
   // ---------------- q(z|x,y=k), all k (gm:2936-3007) ----------------
-  const float* hz = a->x;
+  const float* hz = p->step_x;
   int ldz = F;
   for (size_t i = 0; i < p->zenc.size(); ++i) {
     Dense& d = p->zenc[i];
     if (i == 0 && training && d.keep > 0.f) {
       // every pass drops its own elements of [x | one-hot]: K separate inputs, one GEMM
+      if (p->x_u16) {
+        set_error("dropout on the input layer needs the fp32 minibatch");
+        return -1;
+      }
       TRY(tile_onehot(s, a->x, d.in_drop, K, B, F));
       TRY(dropout_apply(s, d.in_drop, F + K, d.in_drop, F + K, KB, F + K, d.keep, p->drop_seed,
                         d.site, 0, p->drop_rows));
@@ -251,7 +256,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     } else if (i == 0) {
       // x*W[:F] + b once, then + W[F+k] per pass
       const float* W = p->params + d.w;
-      GEMM(false, false, a->x, W, p->params + d.b, p->a0, B, d.n_out, F, F, d.n_out, d.n_out,
+      GEMM(false, false, p->step_x, W, p->params + d.b, p->a0, B, d.n_out, F, F, d.n_out, d.n_out,
            ACT_NONE, false);
       float* target = d.bn ? d.a : d.h;
       TRY(add_group_rows(s, p->a0, W + (size_t)F * d.n_out, target, K, B, d.n_out, d.bn ? 0 : 1));
@@ -344,6 +349,14 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
                      !a->p_x_mean && KM == 0 && !head_drop && c.likelihood <= LK_ZINB;
+  if (p->x_u16 && !fused) {
+    set_error("the uint16 minibatch needs the fused likelihood kernels (no -k / constrained "
+              "Poisson, head dropout or evaluation statistics)");
+    return -1;
+  }
+  // the K stacked passes read the same targets (row r uses t[r % B]): as uint16 they are half
+  // the bytes of every pass
+  const Targets tg = p->x_u16 ? targets_u16(p->step_u16, p->step_u16_ld) : targets_f32(a->t, F);
   const HeadParams hp = head_params(p);
   const float* head_in[4] = {dch, dch, dch, dch};   // [3]: the P_K head
   if (!fused) TRY(heads_forward(p, s, dch, ld, R, training, head_in));
@@ -385,8 +398,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const int use_free_nats = c.free_nats_proportion != 0.f;
   if (!training) {
     if (fused)
-      TRY(decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, targets_f32(a->t, F), B,
-                                a->row_const, p->ll,
+      TRY(decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, tg, B, a->row_const, p->ll,
                                 p->fused_ws));
     else if (KM > 0)
       TRY(loglik_cat_fwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->ll, R, B, F));
@@ -408,9 +420,8 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   float* dalt = p->dbuf[1];
   float* scratch = p->dbuf[2];
   if (fused) {
-    TRY(decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, targets_f32(a->t, F), B, p->gw,
-                            a->row_const,
-                            p->ll, dcur, p->fused_ws));
+    TRY(decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, tg, B, p->gw, a->row_const, p->ll,
+                            dcur, p->fused_ws));
   } else if (KM > 0) {
     TRY(loglik_cat_bwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->gw, p->ll, R, B, F));
   } else if (cpoisson) {
@@ -499,7 +510,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
         TRY(group_col_sum(s, da, N, B, K, N, 1.f, dW + (size_t)F * N, p->partial));
         // data rows: dW[:F] = x^T (sum_k dA[k])
         TRY(sum_groups(s, da, nullptr, 0, K, B, N, p->sum_scratch));
-        GEMM(true, false, a->x, p->sum_scratch, nullptr, dW, F, N, B, F, N, N, ACT_NONE, false);
+        GEMM(true, false, p->step_x, p->sum_scratch, nullptr, dW, F, N, B, F, N, N, ACT_NONE, false);
       }
     }
   }
@@ -524,7 +535,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   for (int i = (int)p->yenc.size() - 1; i >= 0; --i) {
     Dense& d = p->yenc[i];
-    const float* in = i > 0 ? p->yenc[i - 1].h : a->x;
+    const float* in = i > 0 ? p->yenc[i - 1].h : p->step_x;
     float* d_in = i > 0 ? dh_alt : nullptr;
     TRY(dense_backward(p, s, d, in, d.n_in, B, 1, true, dh, scratch, d_in, false, GB));
     if (i > 0) { float* t = dh; dh = dh_alt; dh_alt = t; }

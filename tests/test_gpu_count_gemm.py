@@ -333,3 +333,47 @@ def test_tail_minibatch_fits_the_reserved_count_workspace(cuda_device):
                        x_counts=True).clone()
         torch.cuda.synchronize()
         assert torch.equal(s16, s32) and torch.equal(g16, eng.grads)
+
+
+@pytest.mark.parametrize("likelihood", ["negative binomial",
+                                        "zero-inflated negative binomial"])
+def test_uint16_minibatch_gmvae_is_the_fp32_step_bit_for_bit(cuda_device,
+                                                            likelihood):
+    """GMVAE: the K stacked decoder passes read their targets from the uint16
+    minibatch and both layers that see x (q(y|x), q(z|x,y): x W[:F] once) take
+    the uint16 count kernels -- same bits as the fp32 batch; training (with the
+    optimiser in between) and evaluation."""
+    import scipy.sparse as sp
+    from scvae_amd.engine import Engine
+    from scvae_amd.minibatch import DeviceCSR
+    F, L, H, B, K = 2101, 10, (100, 100), 160, 4
+    rng = np.random.default_rng(23)
+    counts = sp.csr_matrix(_counts(rng, 400, F, 0.05))
+    csr = DeviceCSR.from_scipy(counts, cuda_device)
+    rows = torch.from_numpy(rng.permutation(400)[:B]).to(cuda_device)
+    x32 = csr.gather_dense(rows)
+    rc = torch.zeros(B, device=cuda_device)
+    x16 = csr.gather_counts_u16(rows, row_const_out=rc)
+    eps = torch.from_numpy(rng.standard_normal((K, 1, B, L)).astype(np.float32)
+                           ).to(cuda_device)
+    results = []
+    for u16 in (False, True):
+        eng = Engine(F, L, H, likelihood, batch_norm=True, model_type="GMVAE",
+                     n_clusters=K, device=cuda_device, seed=1)
+        eng.set_count_gemm(True, always=True)
+        assert eng.accepts_counts_u16(B, True) and eng.accepts_counts_u16(B, False)
+        x = x16 if u16 else x32
+        out = []
+        for _ in range(2):
+            ll = torch.zeros(K * B, device=cuda_device)
+            s = eng.step(x, x, eps=eps, training=True, row_const=rc,
+                         x_counts=True, outputs={"log_p_x_given_z": ll}).clone()
+            eng.adam_step(1e-3)
+            out += [s, ll.clone()]
+        ev = eng.step(x, x, eps=eps, training=False, row_const=rc,
+                      x_counts=True).clone()
+        torch.cuda.synchronize()
+        results.append([t.cpu() for t in out + [ev, eng.grads, eng.moving,
+                                                eng.params]])
+    for i, (a, b) in enumerate(zip(*results)):
+        assert torch.equal(a, b), i
