@@ -595,7 +595,9 @@ __global__ __launch_bounds__(256) void dd_reduce_t_scalar_kernel(const float* __
 bool decoder_fused_supported(int H) { return H >= 2 && H <= 126 && (H % 2) == 0; }
 
 size_t decoder_fused_workspace_floats(int rows, int H, int F, bool train) {
-  const size_t strips = (size_t)(F + DF_BN - 1) / DF_BN;
+  // (the bf16x9 kernel takes 32-gene strips for three heads: size for the narrowest strip)
+  const int bn = (train && decoder_fused3_supported(3, H)) ? decoder_fused3_strip_genes(3) : DF_BN;
+  const size_t strips = (size_t)(F + bn - 1) / bn;
   size_t n = strips * rows;                       // ll_part
   if (train) n += strips * (size_t)rows * H + 64; // dd_part (16-byte aligned start)
   if (train) n += decoder_fused3_workspace_floats(rows) + 64;   // bf16 planes of d (bf16x9 kernel)
@@ -706,7 +708,9 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
                         float* ll, float* dd, float* workspace, bool kernel_only) {
   SCVAE_ARG(d && t.p && gw && ll && dd && workspace && decoder_fused_supported(H));
   if (rows == 0) return 0;
-  const int strips = (F + DF_BN - 1) / DF_BN;
+  const int heads = likelihood_heads(kind);
+  const int bn = decoder_train_kernel(heads, H) == 3 ? decoder_fused3_strip_genes(heads) : DF_BN;
+  const int strips = (F + bn - 1) / bn;
   float* ll_part = workspace;
   size_t off = ((size_t)strips * rows + 63) / 64 * 64;
   float* dd_part = workspace + off;

@@ -54,19 +54,24 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 constexpr int D3_THREADS = 512;
-constexpr int D3_BN = 64;           // genes per strip
 constexpr int D3_BM = 64;           // rows per tile
-constexpr int D3_ROWB = 144;        // bytes per LDS row: 64 bf16 + 16 bytes of padding
 constexpr int D3_KP = 128;          // padded hidden width of the planes of d
-constexpr int D3_GPLANE = D3_BM * D3_ROWB;   // bytes of one [64 rows][64 genes] plane of G
+// genes per strip (= per workgroup): 64 for one / two heads; 32 for three heads, whose weight
+// planes (9 x 112 rows) would not fit LDS next to the G tile at 64
+__host__ __device__ constexpr int d3_bn(int P) { return P >= 3 ? 32 : 64; }
+// bytes per LDS row: the strip's genes as bf16 + 16 bytes of padding (144 / 80: odd multiples of
+// 16 bytes, conflict-free ds_read_b128 fragments)
+__host__ __device__ constexpr int d3_rowb(int P) { return 2 * d3_bn(P) + 16; }
 
 __host__ __device__ inline int d3_hp1(int H) { return (H + 1 + 15) / 16 * 16; }
 
+int decoder_fused3_strip_genes(int P) { return d3_bn(P); }
 size_t decoder_fused3_lds_bytes(int P, int H) {
-  return (size_t)P * 3 * d3_hp1(H) * D3_ROWB + (size_t)P * 3 * D3_GPLANE + 4 * D3_BM * sizeof(float);
+  return (size_t)P * 3 * d3_hp1(H) * d3_rowb(P) + (size_t)P * 3 * D3_BM * d3_rowb(P) +
+         2 * D3_BM * sizeof(float);
 }
 bool decoder_fused3_supported(int P, int H) {
-  return P <= 2 && H >= 2 && H <= 126 && decoder_fused3_lds_bytes(P, H) <= 160 * 1024;
+  return P <= 3 && H >= 2 && H <= 126 && decoder_fused3_lds_bytes(P, H) <= 160 * 1024;
 }
 // planes of d: dA [3][Rpad][128] then dT [3][128][Rpad], bf16
 size_t decoder_fused3_workspace_floats(int rows) {
@@ -141,15 +146,16 @@ __device__ __forceinline__ s16x4 lds_tr(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (__attribute__((address_space(3))) s16x4*)(p));
 }
+template <int ROWB>
 __device__ __forceinline__ bf16x8 lds_tr8(const char* p) {    // rows 0-3 and rows 4-7
-  const s16x4 lo = lds_tr(p), hi = lds_tr(p + 4 * D3_ROWB);
+  const s16x4 lo = lds_tr(p), hi = lds_tr(p + 4 * ROWB);
   return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 __device__ __forceinline__ bf16x8 global_b128(const uint16_t* p) {
   return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
 }
 
-// one of 8 registers by a per-lane index (3 lane masks of the index bits; inline asm: written as
+// one of N registers by a per-lane index (lane masks of the index bits; inline asm: written as
 // C++ selects the compiler turns the tree into a dynamically indexed array = scratch)
 struct IndexMasks3 { unsigned long long m[3]; };
 __device__ __forceinline__ IndexMasks3 index_masks3(int idx) {
@@ -163,13 +169,16 @@ __device__ __forceinline__ float cnd3(float lo, float hi, unsigned long long mas
   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(lo), "v"(hi), "s"(mask));
   return r;
 }
-__device__ __forceinline__ float select8(const float (&v)[8], const IndexMasks3& k) {
+__device__ __forceinline__ float select_n(const float (&v)[8], const IndexMasks3& k) {
   float a[4], b[2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) a[i] = cnd3(v[2 * i], v[2 * i + 1], k.m[0]);
 #pragma unroll
   for (int i = 0; i < 2; ++i) b[i] = cnd3(a[2 * i], a[2 * i + 1], k.m[1]);
   return cnd3(b[0], b[1], k.m[2]);
+}
+__device__ __forceinline__ float select_n(const float (&v)[4], const IndexMasks3& k) {
+  return cnd3(cnd3(v[0], v[1], k.m[0]), cnd3(v[2], v[3], k.m[0]), k.m[1]);
 }
 
 template <int KIND, int KS1>
@@ -179,39 +188,44 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     float* __restrict__ ll_part, float* __restrict__ dd_part) {
   using Traits = LikelihoodTraits<KIND>;
   constexpr int P = Traits::P;
+  constexpr int BN = d3_bn(P), ROWB = d3_rowb(P);
+  constexpr int GPLANE = D3_BM * ROWB;      // bytes of one [64 rows][BN genes] plane of G
+  constexpr int NSB = BN / 32;              // 16-gene blocks of a wave in phase A (2 / 1)
+  constexpr int NE = 4 * NSB;               // elements of a lane
+  constexpr bool KSPLIT = P >= 3;           // GEMM2 splits the tile's rows between wave pairs
+  constexpr int KS2 = KSPLIT ? 2 : 4;       // 16-row k-steps of GEMM2 per wave
+  constexpr int KS3 = BN / 16;              // 16-gene k-steps of GEMM3 per head
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int HP1 = d3_hp1(H);
-  const int WPLANE = HP1 * D3_ROWB;                 // bytes of one [HP1][64] plane of W
-  char* Wl = smem;                                  // [P][3][HP1][72] bf16
-  char* Gl = smem + (size_t)P * 3 * WPLANE;         // [P][3][64][72] bf16
-  float* llbuf = reinterpret_cast<float*>(Gl + (size_t)P * 3 * D3_GPLANE);   // [4][64]
+  const int WPLANE = HP1 * ROWB;                    // bytes of one [HP1][BN] plane of W
+  char* Wl = smem;                                  // [P][3][HP1][BN + 8] bf16
+  char* Gl = smem + (size_t)P * 3 * WPLANE;         // [P][3][64][BN + 8] bf16
+  float* llbuf = reinterpret_cast<float*>(Gl + (size_t)P * 3 * GPLANE);   // [2][64]
   const int tid = threadIdx.x, lane = tid & 63;
-  const int dbg = inline_lgamma >> 8;
-  inline_lgamma &= 1;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, i16 = lane & 15, li = lane & 31, kh = lane >> 5;
-  const int c0 = blockIdx.x * D3_BN;
+  const int c0 = blockIdx.x * BN;
 
   // ---- LDS: zero everything (padding and over-read regions must hold finite values), then the
   //      strip's weights and biases, cut into planes ----
   {
-    const int n16 = (int)(((size_t)P * 3 * WPLANE + (size_t)P * 3 * D3_GPLANE + 4 * D3_BM * 4) / 16);
+    const int n16 = (int)(((size_t)P * 3 * WPLANE + (size_t)P * 3 * GPLANE + 2 * D3_BM * 4) / 16);
     u32x4* z = reinterpret_cast<u32x4*>(smem);
     for (int i = tid; i < n16; i += D3_THREADS) z[i] = u32x4{0u, 0u, 0u, 0u};
   }
   __syncthreads();
   {
-    const int g = tid & 63;
+    const int g = tid & (BN - 1);
     const bool col_ok = c0 + g < F;
 #pragma unroll
     for (int j = 0; j < P; ++j) {
       const float* Wj = hp.W[j] + c0 + g;
-      for (int h = tid >> 6; h <= H; h += D3_THREADS / 64) {
+      for (int h = tid / BN; h <= H; h += D3_THREADS / BN) {
         float v = 0.f;
         if (col_ok) v = h < H ? Wj[(size_t)h * F] : hp.b[j][c0 + g];
         unsigned b1, b2, b3;
         split3_trunc(v, b1, b2, b3);
-        char* dst = Wl + (size_t)(j * 3) * WPLANE + h * D3_ROWB + 2 * g;
+        char* dst = Wl + (size_t)(j * 3) * WPLANE + h * ROWB + 2 * g;
         *reinterpret_cast<uint16_t*>(dst) = (uint16_t)(b1 >> 16);
         *reinterpret_cast<uint16_t*>(dst + WPLANE) = (uint16_t)(b2 >> 16);
         *reinterpret_cast<uint16_t*>(dst + 2 * WPLANE) = (uint16_t)(b3 >> 16);
@@ -221,20 +235,23 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
   __syncthreads();
 
   // ---- wave roles ----
-  const int gp = w & 1, rq = w >> 1;        // phase A: genes 32 gp .., rows 16 rq .. of the tile
-  const int ht = w & 3, hi2 = w >> 2;       // phase B: h tile; gene tile (GEMM2) / row tile (GEMM3)
+  const int gp = w & 1, rq = w >> 1;        // phase A: genes 16 NSB gp .., rows 16 rq .. of the tile
+  const int ht = w & 3, hi2 = w >> 2;       // phase B: h tile; GEMM3: row tile hi2; GEMM2: gene
+                                            // tile hi2 (all 64 rows), or -- three heads -- rows
+                                            // 32 hi2 .. (all 32 genes)
   const int n_ht3 = (H + 31) / 32, n_ht2 = (H + 1 + 31) / 32;
   const int nb16 = Rpad / 16;               // 16-row blocks of the planes of d
 
   // per-lane byte offsets
-  const int trw = (8 * q + (i16 >> 2)) * D3_ROWB + 2 * (32 * gp + 4 * (i16 & 3));   // W, GEMM1
-  const int gst = (16 * rq + i16) * D3_ROWB + 2 * (32 * gp + 4 * q);                // G store
-  const int g3a = (32 * hi2 + li) * D3_ROWB + 16 * kh;                              // G, GEMM3 A
-  const int g3b = (32 * ht + li) * D3_ROWB + 16 * kh;                               // W, GEMM3 B
-  const int g2b = (8 * (q >> 1) + (i16 >> 2)) * D3_ROWB +
-                  2 * (32 * hi2 + 16 * (q & 1) + 4 * (i16 & 3));                    // G, GEMM2 B
+  const int gbase = 16 * NSB * gp;
+  const int trw = (8 * q + (i16 >> 2)) * ROWB + 2 * (gbase + 4 * (i16 & 3));        // W, GEMM1
+  const int gst = (16 * rq + i16) * ROWB + 2 * (gbase + 4 * q);                     // G store
+  const int g3a = (32 * hi2 + li) * ROWB + 16 * kh;                                 // G, GEMM3 A
+  const int g3b = (32 * ht + li) * ROWB + 16 * kh;                                  // W, GEMM3 B
+  const int g2b = ((KSPLIT ? 32 * hi2 : 0) + 8 * (q >> 1) + (i16 >> 2)) * ROWB +
+                  2 * ((KSPLIT ? 0 : 32 * hi2) + 16 * (q & 1) + 4 * (i16 & 3));     // G, GEMM2 B
 
-  f32x16 accW[P];                           // dW tile (h tile ht, gene tile hi2) of every head
+  f32x16 accW[P];                           // dW tile (h tile ht [, gene tile hi2]) of every head
 #pragma unroll
   for (int j = 0; j < P; ++j)
 #pragma unroll
@@ -245,17 +262,17 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
 
   // targets / upstream of a tile, in flight from the previous phase B (returned by value: an
   // array written through a reference capture ends up in scratch memory)
-  struct TileIn { f32x4m t0, t1; float up0; };
+  struct TileIn { f32x4m t[NSB]; float up0; };
   auto load_t = [&](int m0) {
     TileIn in;
-    f32x4m tv[2];
     const int row = m0 + 16 * rq + i16;
     const bool rok = row < R;
     in.up0 = rok ? gw[row] : 0.f;
-    const size_t trow = (size_t)((rok ? row : R - 1) % B) * tg.ld;
+    const int rc = rok ? row : R - 1;
+    const size_t trow = (size_t)(R == B ? rc : rc % B) * tg.ld;
 #pragma unroll
-    for (int sb = 0; sb < 2; ++sb) {
-      const int c = c0 + 32 * gp + 16 * sb + 4 * q;
+    for (int sb = 0; sb < NSB; ++sb) {
+      const int c = c0 + gbase + 16 * sb + 4 * q;
       f32x4m v = {0.f, 0.f, 0.f, 0.f};
       if (tg.u16) {     // pitch % 8 == 0, padding columns zero: one 8-byte load
         const uint16_t* tp = static_cast<const uint16_t*>(tg.p) + trow + c;
@@ -272,9 +289,8 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
           v.z = (c + 2 < F) ? tp[2] : 0.f;
         }
       }
-      tv[sb] = v;
+      in.t[sb] = v;
     }
-    in.t0 = tv[0]; in.t1 = tv[1];
     return in;
   };
   TileIn nxt = load_t(0);
@@ -291,38 +307,37 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
 
   for (int tile = 0; tile < n_tiles; ++tile) {
     const int m0 = tile * D3_BM;
-    const f32x4m traw[2] = {nxt.t0, nxt.t1};
-    const float up = nxt.up0;
+    const TileIn cur = nxt;
+    const float up = cur.up0;
     // =================== phase A: GEMM1 (transposed) + likelihood + G -> LDS ===================
-    f32x4m acc1[P][2];
+    f32x4m acc1[P][NSB];
 #pragma unroll
     for (int j = 0; j < P; ++j)
 #pragma unroll
-      for (int sb = 0; sb < 2; ++sb) acc1[j][sb] = f32x4m{0.f, 0.f, 0.f, 0.f};
+      for (int sb = 0; sb < NSB; ++sb) acc1[j][sb] = f32x4m{0.f, 0.f, 0.f, 0.f};
     {
       // W fragments (transpose reads) and d fragments one k-step ahead of the MFMAs
-      bf16x8 afr[2][P][2][3], bfr[2][3];
-      auto load_w = [&](int ks, bf16x8 (&dst)[P][2][3]) {
+      bf16x8 afr[2][P][NSB][3], bfr[2][3];
+      auto load_w = [&](int ks, bf16x8 (&dst)[P][NSB][3]) {
 #pragma unroll
         for (int j = 0; j < P; ++j)
 #pragma unroll
-          for (int sb = 0; sb < 2; ++sb)
+          for (int sb = 0; sb < NSB; ++sb)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-              dst[j][sb][pl] = lds_tr8(Wl + (size_t)(j * 3 + pl) * WPLANE + trw + 32 * sb +
-                                       32 * ks * D3_ROWB);
+              dst[j][sb][pl] = lds_tr8<ROWB>(Wl + (size_t)(j * 3 + pl) * WPLANE + trw + 32 * sb +
+                                             32 * ks * ROWB);
       };
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) bfr[0][pl] = bfr0[pl];
       load_w(0, afr[0]);
 #pragma unroll
       for (int ks = 0; ks < KS1; ++ks) {
-        if (dbg & 8) break;
         if (ks + 1 < KS1) {
           load_d1(m0, ks + 1, bfr[(ks + 1) & 1]);
           load_w(ks + 1, afr[(ks + 1) & 1]);
         }
-        // small terms first; the four accumulators (head x gene block) are independent chains
+        // small terms first; the accumulators (head x gene block) are independent chains
 #pragma unroll
         for (int a = 2; a >= 0; --a)
 #pragma unroll
@@ -330,62 +345,56 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
 #pragma unroll
             for (int j = 0; j < P; ++j)
 #pragma unroll
-              for (int sb = 0; sb < 2; ++sb)
+              for (int sb = 0; sb < NSB; ++sb)
                 acc1[j][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     afr[ks & 1][j][sb][a], bfr[ks & 1][b], acc1[j][sb], 0, 0, 0);
       }
     }
-    // ---- likelihood of this lane's 2 x 4 elements: row 16 rq + i16, genes
-    //      32 gp + 16 sb + 4 q + e ----
-    float G[P][8], tval[8];
+    // ---- likelihood of this lane's NSB x 4 elements: row 16 rq + i16, genes
+    //      16 NSB gp + 16 sb + 4 q + e ----
+    float G[P][NE], tval[NE];
     float lsum = 0.f;
     unsigned nz = 0;
 #pragma unroll
-    for (int sb = 0; sb < 2; ++sb) {
+    for (int sb = 0; sb < NSB; ++sb) {
       if (tg.u16) {
-        const unsigned v0 = __float_as_uint(traw[sb][0]), v1 = __float_as_uint(traw[sb][1]);
+        const unsigned v0 = __float_as_uint(cur.t[sb][0]), v1 = __float_as_uint(cur.t[sb][1]);
         tval[4 * sb] = (float)(v0 & 0xFFFFu); tval[4 * sb + 1] = (float)(v0 >> 16);
         tval[4 * sb + 2] = (float)(v1 & 0xFFFFu); tval[4 * sb + 3] = (float)(v1 >> 16);
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) tval[4 * sb + e] = traw[sb][e];
+        for (int e = 0; e < 4; ++e) tval[4 * sb + e] = cur.t[sb][e];
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float a[P], g[P], lp, r, rgate;
 #pragma unroll
         for (int j = 0; j < P; ++j) a[j] = acc1[j][sb][e];
-        if (dbg & 1) {
-          lp = a[0];
-#pragma unroll
-          for (int j = 0; j < P; ++j) g[j] = a[j];
-        } else {
-          lik_dense<KIND, true>(tval[4 * sb + e], a, lp, g, r, rgate);
-        }
-        const bool ok = c0 + 32 * gp + 16 * sb + 4 * q + e < F;
+        lik_dense<KIND, true>(tval[4 * sb + e], a, lp, g, r, rgate);
+        const bool ok = c0 + gbase + 16 * sb + 4 * q + e < F;
         lsum += ok ? lp : 0.f;
 #pragma unroll
         for (int j = 0; j < P; ++j) G[j][4 * sb + e] = up * g[j];
         nz |= (ok && tval[4 * sb + e] > 0.f) ? (1u << (4 * sb + e)) : 0u;
       }
     }
-    // ---- t > 0: + lgamma(r+t) - lgamma(r) [- lgamma(1+t)], and the digamma term of dlog r ----
-    if (dbg & 2) nz = 0;
+    // ---- t > 0: + lgamma(r+t) - lgamma(r) [- lgamma(1+t)], and the digamma term of dlog r:
+    //      a per-lane walk over the lane's non-zero elements ----
     if (Traits::HAS_R || inline_lgamma) {
-      float lr[8];
+      float lr[NE];
       if (Traits::HAS_R) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) lr[i] = acc1[P - 1][i >> 2][i & 3];
+        for (int i = 0; i < NE; ++i) lr[i] = acc1[P - 1][i >> 2][i & 3];
       }
       while (__builtin_amdgcn_ballot_w64(nz != 0) != 0) {
         const bool on = nz != 0;
         const int idx = on ? __builtin_ctz(nz) : 0;
         nz &= nz - 1;
         const IndexMasks3 km = index_masks3(idx);
-        const float tt = select8(tval, km);
+        const float tt = select_n(tval, km);
         float corr = 0.f;
         if (Traits::HAS_R) {
-          const float lrv = select8(lr, km);
+          const float lrv = select_n(lr, km);
           const float r = __expf(fminf(fmaxf(lrv, -10.f), 10.f));
           const float rgate = (lrv >= -10.f && lrv <= 10.f) ? 1.f : 0.f;
           const bool small = !on || (tt <= 8.f && tt == __builtin_rintf(tt));
@@ -395,15 +404,17 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
           else
             lgamma_digamma_diff_general<true>(r, on ? tt : 1.f, A, D);
           corr = A;
+          // (zero-inflated: at t > 0 the gradient of the base distribution passes unscaled,
+          //  zero_inflated.py:194-199 -- the same insertion)
           const float delta = on ? up * rgate * r * D : 0.f;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) G[P - 1][e] += (idx == e) ? delta : 0.f;
+          for (int e = 0; e < NE; ++e) G[P - 1][e] += (idx == e) ? delta : 0.f;
         }
         if (inline_lgamma) corr -= lgamma1p(tt);
         lsum += on ? corr : 0.f;
       }
     }
-    // ---- row sums over this wave's 32 genes -> llbuf[gp][row] ----
+    // ---- row sums over this wave's genes -> llbuf[gp][row] ----
     {
       float sm = lsum;
       sm += __shfl_xor(sm, 16, WAVE);
@@ -414,27 +425,28 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
 #pragma unroll
     for (int j = 0; j < P; ++j)
 #pragma unroll
-      for (int sb = 0; sb < 2; ++sb) {
+      for (int sb = 0; sb < NSB; ++sb) {
         unsigned b1[4], b2[4], b3[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) split3_trunc(G[j][4 * sb + e], b1[e], b2[e], b3[e]);
-        char* dst = Gl + (size_t)(j * 3) * D3_GPLANE + gst + 32 * sb;
+        char* dst = Gl + (size_t)(j * 3) * GPLANE + gst + 32 * sb;
         *reinterpret_cast<u32x2*>(dst) = u32x2{pack_hi16(b1[0], b1[1]), pack_hi16(b1[2], b1[3])};
-        *reinterpret_cast<u32x2*>(dst + D3_GPLANE) =
+        *reinterpret_cast<u32x2*>(dst + GPLANE) =
             u32x2{pack_hi16(b2[0], b2[1]), pack_hi16(b2[2], b2[3])};
-        *reinterpret_cast<u32x2*>(dst + 2 * D3_GPLANE) =
+        *reinterpret_cast<u32x2*>(dst + 2 * GPLANE) =
             u32x2{pack_hi16(b3[0], b3[1]), pack_hi16(b3[2], b3[3])};
       }
     lds_barrier();
 
     // =================== phase B: GEMM3 (LDS operands), then GEMM2 ===================
-    // per-row log-likelihood of the strip: the four gene blocks summed in a fixed order
+    // per-row log-likelihood of the strip: the two gene blocks summed in a fixed order
     if (tid < D3_BM && m0 + tid < R)
       ll_part[(size_t)blockIdx.x * R + m0 + tid] = llbuf[tid] + llbuf[D3_BM + tid];
     // GEMM2's d fragments (A[i = h][k = row]) come from L2 one k-step ahead; k-step 0 is
     // requested here and lands under GEMM3
     auto load_a2 = [&](int ks, bf16x8 (&dst)[3]) {
-      const uint16_t* tb = dT + ((size_t)ht * nb16 + m0 / 16 + ks) * 512 + lane * 8;
+      const uint16_t* tb =
+          dT + ((size_t)ht * nb16 + m0 / 16 + (KSPLIT ? 2 * hi2 : 0) + ks) * 512 + lane * 8;
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) dst[pl] = global_b128(tb + pl * dplane);
     };
@@ -442,24 +454,24 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     if (ht < n_ht2) load_a2(0, a2[0]);
     // next tile's targets
     if (tile + 1 < n_tiles) nxt = load_t(m0 + D3_BM);
-    if (ht < n_ht3 && !(dbg & 4)) {
+    if (ht < n_ht3) {
       // ---- GEMM3: dd[row, h] = sum_j sum_gene G_j[row, gene] W_j[h, gene] ----
       f32x16 acc3;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc3[i] = 0.f;
       bf16x8 af[2][3], bf[2][3];
-      auto load_3 = [&](int st, bf16x8 (&a)[3], bf16x8 (&b)[3]) {   // step = head * 4 + k-step
-        const int j = st >> 2, ks = st & 3;
+      auto load_3 = [&](int st, bf16x8 (&a)[3], bf16x8 (&b)[3]) {   // step = head * KS3 + k-step
+        const int j = st / KS3, ks = st % KS3;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-          a[pl] = lds_b128(Gl + (size_t)(j * 3 + pl) * D3_GPLANE + g3a + 32 * ks);
+          a[pl] = lds_b128(Gl + (size_t)(j * 3 + pl) * GPLANE + g3a + 32 * ks);
           b[pl] = lds_b128(Wl + (size_t)(j * 3 + pl) * WPLANE + g3b + 32 * ks);
         }
       };
       load_3(0, af[0], bf[0]);
 #pragma unroll
-      for (int st = 0; st < 4 * P; ++st) {
-        if (st + 1 < 4 * P) load_3(st + 1, af[(st + 1) & 1], bf[(st + 1) & 1]);
+      for (int st = 0; st < KS3 * P; ++st) {
+        if (st + 1 < KS3 * P) load_3(st + 1, af[(st + 1) & 1], bf[(st + 1) & 1]);
 #pragma unroll
         for (int a = 2; a >= 0; --a)
 #pragma unroll
@@ -472,7 +484,7 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
       //  where a row-major slab takes 100-float rows in partial lines.  Non-temporal: the slabs
       //  are read exactly once, by dd_reduce_t_kernel)
       const int row = m0 + 32 * hi2 + li;
-      if (row < R && !(dbg & 16)) {
+      if (row < R) {
         float* dst = dd_part + ((size_t)blockIdx.x * H + 32 * ht + 4 * kh) * R + row;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -483,35 +495,53 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     }
     // the next tile's d fragments of GEMM1: in flight under GEMM2 and the barrier
     if (tile + 1 < n_tiles) load_d1(m0 + D3_BM, 0, bfr0);
-    if (ht < n_ht2 && !(dbg & 4)) {
+    if (ht < n_ht2) {
       // ---- GEMM2: dW_j[h, gene] += sum_row d[row, h] G_j[row, gene] ----
       bf16x8 bf[2][3];
       auto load_2 = [&](int st, bf16x8 (&b)[3]) {                    // step = k-step * P + head
         const int ks = st / P, j = st % P;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-          b[pl] = lds_tr8(Gl + (size_t)(j * 3 + pl) * D3_GPLANE + g2b + 16 * ks * D3_ROWB);
+          b[pl] = lds_tr8<ROWB>(Gl + (size_t)(j * 3 + pl) * GPLANE + g2b + 16 * ks * ROWB);
       };
       load_2(0, bf[0]);
 #pragma unroll
-      for (int st = 0; st < 4 * P; ++st) {
-        if (st + 1 < 4 * P) load_2(st + 1, bf[(st + 1) & 1]);
-        if (st % P == 0 && st / P + 1 < 4) load_a2(st / P + 1, a2[(st / P + 1) & 1]);
+      for (int st = 0; st < KS2 * P; ++st) {
+        if (st + 1 < KS2 * P) load_2(st + 1, bf[(st + 1) & 1]);
+        if (st % P == 0 && st / P + 1 < KS2) load_a2(st / P + 1, a2[(st / P + 1) & 1]);
         const int ks = st / P, j = st % P;
 #pragma unroll
         for (int a = 2; a >= 0; --a)
 #pragma unroll
           for (int b = 2; b >= 0; --b)
-            accW[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks & 1][a], bf[st & 1][b], accW[j], 0,
-                                                              0, 0);
+            accW[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks & 1][a], bf[st & 1][b], accW[j],
+                                                              0, 0, 0);
       }
     }
     lds_barrier();
   }
 
   // ---- dW / db of the strip ----
-  if (ht < n_ht2) {
-    const int c = c0 + 32 * hi2 + li;
+  if (KSPLIT) {
+    // the two waves of an h tile hold partial sums over the two row halves: waves 4-7 park
+    // theirs in LDS (the weights are no longer needed), waves 0-3 add and write
+    float* park = reinterpret_cast<float*>(smem) + (size_t)ht * P * 16 * 64;
+    if (hi2 == 1 && ht < n_ht2) {
+#pragma unroll
+      for (int j = 0; j < P; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) park[(j * 16 + i) * 64 + lane] = accW[j][i];
+    }
+    __syncthreads();
+    if (hi2 == 0 && ht < n_ht2) {
+#pragma unroll
+      for (int j = 0; j < P; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accW[j][i] += park[(j * 16 + i) * 64 + lane];
+    }
+  }
+  if (ht < n_ht2 && (!KSPLIT || hi2 == 0)) {
+    const int c = c0 + (KSPLIT ? 0 : 32 * hi2) + li;
     if (c < F) {
 #pragma unroll
       for (int j = 0; j < P; ++j)
@@ -539,7 +569,7 @@ int decoder_fused3_launch(hipStream_t s, int kind, const float* d, int rows, int
     SCVAE_LAUNCH_CHECK("split3_hidden_kernel");
   }
   const size_t lds = decoder_fused3_lds_bytes(P, H);
-  const int strips = (F + D3_BN - 1) / D3_BN;
+  const int strips = (F + d3_bn(P) - 1) / d3_bn(P);
   const int ks1 = (d3_hp1(H) + 31) / 32;
 #define SCVAE_D3K(K_, KS_)                                                                        \
   do {                                                                                            \
@@ -560,6 +590,7 @@ int decoder_fused3_launch(hipStream_t s, int kind, const float* d, int rows, int
     case LK_POISSON: SCVAE_D3(LK_POISSON); break;
     case LK_NB: SCVAE_D3(LK_NB); break;
     case LK_ZIP: SCVAE_D3(LK_ZIP); break;
+    case LK_ZINB: SCVAE_D3(LK_ZINB); break;
     default: set_error("decoder_head3_kernel: likelihood kind %d", kind); return -1;
   }
 #undef SCVAE_D3

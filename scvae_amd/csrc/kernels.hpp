@@ -207,6 +207,7 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
 // training kernel on the bf16 matrix cores, exact nine-term split (decoder_fused3.hip)
 bool decoder_fused3_supported(int P, int H);
 size_t decoder_fused3_lds_bytes(int P, int H);
+int decoder_fused3_strip_genes(int P);   // genes per workgroup (= per slab of ll_part / dd_part)
 size_t decoder_fused3_workspace_floats(int rows);
 int decoder_fused3_launch(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                           int F, Targets t, int B, const float* gw, int inline_lgamma,
