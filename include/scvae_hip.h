@@ -9,7 +9,8 @@
  *  - plain pointers and sizes only; every buffer is a DEVICE pointer owned by
  *    the caller (the library never allocates device memory), row-major fp32
  *    unless stated otherwise;
- *  - asynchronous on the given hipStream_t (as void*), no internal sync;
+ *  - asynchronous on the given hipStream_t (as void*), no internal sync (the set-up calls
+ *    without a stream argument -- scvae_plan_create / _bind -- excepted);
  *  - return 0 on success, -1 bad argument, -2 HIP error; the text is returned
  *    by scvae_last_error() (per host thread);
  *  - one host thread per plan.
@@ -124,6 +125,10 @@ int64_t scvae_plan_prior_offset(const scvae_plan* plan);
 int scvae_plan_moving_info(const scvae_plan* plan, int64_t index, char* name, int64_t* offset,
                            int64_t* size);
 int64_t scvae_plan_workspace_bytes(const scvae_plan* plan, int64_t max_cells, int64_t max_samples);
+/* Set-up call (once per plan and workspace size), NOT on the step path: it has no stream argument
+ * and clears a few words of the gradient buffer and the workspace with blocking hipMemset calls
+ * (the gradient slots of the batch-normalised layers' biases, which no kernel ever writes, and the
+ * barrier counter of the mid-chain kernels), i.e. it synchronises with the device. */
 int scvae_plan_bind(scvae_plan* plan, float* params, float* grads, float* moving, void* workspace,
                     int64_t workspace_bytes, int64_t max_cells, int64_t max_samples);
 int scvae_plan_set_sync(scvae_plan* plan, scvae_sync_fn fn, void* user);

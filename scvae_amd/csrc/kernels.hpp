@@ -160,6 +160,7 @@ struct MidChainArgs {
   unsigned bar_base;                    // its value when this launch starts
 };
 unsigned vae_mid_barrier_advance(const MidChainArgs& args, bool backward);
+bool vae_mid_chain_resident();   // all workgroups of the two kernels co-resident on this device
 int vae_mid_forward(hipStream_t stream, const MidChainArgs& args);
 int vae_mid_backward(hipStream_t stream, const MidChainArgs& args);
 

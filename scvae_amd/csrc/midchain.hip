@@ -704,15 +704,43 @@ unsigned vae_mid_barrier_advance(const MidChainArgs& q, bool backward) {
   return (unsigned)(MC_WGS * barriers);
 }
 
+// Per launch: the dynamic-LDS limit is an attribute of the function ON THE CURRENT DEVICE (a
+// process that builds engines on several GPUs must set it on each), and the hand-rolled grid
+// barrier needs every workgroup of the launch resident at once: checked against the occupancy
+// query (cached per device) instead of being assumed.
 static int mid_launch_setup() {
-  static bool done = false;
-  if (done) return 0;
   SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vae_mid_forward_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)MC_LDS_BYTES));
   SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vae_mid_backward_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)MC_LDS_BYTES));
-  done = true;
   return 0;
+}
+
+// 1 if all MC_WGS workgroups of both kernels can be co-resident on the current device (one
+// workgroup per CU suffices: MC_WGS <= number of CUs and at least one block fits a CU).  The
+// plan disables the mid chain otherwise (scvae_plan_bind).  Note that the barrier counter's base
+// is a launch argument advanced by the host: a step that uses these kernels cannot be replayed
+// from a captured HIP graph.
+bool vae_mid_chain_resident() {
+  static thread_local int cached_device = -1;
+  static thread_local bool cached = false;
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return false;
+  if (device == cached_device) return cached;
+  bool ok = false;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && mid_launch_setup() == 0) {
+    int fwd = 0, bwd = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fwd, vae_mid_forward_kernel, MC_THREADS,
+                                                     MC_LDS_BYTES) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&bwd, vae_mid_backward_kernel, MC_THREADS,
+                                                     MC_LDS_BYTES) == hipSuccess)
+      ok = (long)fwd * prop.multiProcessorCount >= MC_WGS &&
+           (long)bwd * prop.multiProcessorCount >= MC_WGS;
+  }
+  cached_device = device;
+  cached = ok;
+  return ok;
 }
 
 int vae_mid_forward(hipStream_t stream, const MidChainArgs& args) {

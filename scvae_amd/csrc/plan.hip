@@ -478,6 +478,7 @@ HeadParams head_params(scvae_plan* p) {
 static bool mid_chain_ok(const scvae_plan* p, int B, int S, bool training) {
   const scvae_model_config& c = p->cfg;
   if (!p->use_mid_chain || p->sync) return false;
+  if (!vae_mid_chain_resident()) return false;   // (the grid barrier needs co-resident workgroups)
   if (!c.batch_norm || p->enc.empty() || p->dec.empty()) return false;
   if (c.latent_mode != 0 || c.decoder_extra != 0) return false;
   if ((int64_t)B * S > 128 || c.latent_size > 128) return false;

@@ -138,11 +138,26 @@ def save_checkpoint(state, log_directory, epoch):
     # write-then-rename, the state before the index that points at it: an
     # interrupted save leaves the previous checkpoint and its index intact
     path = os.path.join(log_directory, name)
-    torch.save(state, path + ".tmp")
+    # temporaries of an earlier, interrupted save are full-size state files: drop them
+    for stale in os.listdir(log_directory):
+        if stale.endswith(".tmp") and stale.startswith(
+                (CHECKPOINT_PREFIX, CHECKPOINT_INDEX)):
+            try:
+                os.remove(os.path.join(log_directory, stale))
+            except OSError:
+                pass
+    # (flushed to the device before the rename: after a power loss the index must
+    #  not point at a truncated state file)
+    with open(path + ".tmp", "wb") as f:
+        torch.save(state, f)
+        f.flush()
+        os.fsync(f.fileno())
     os.replace(path + ".tmp", path)
     index = os.path.join(log_directory, CHECKPOINT_INDEX)
     with open(index + ".tmp", "w") as f:
         json.dump({"model_checkpoint_path": name}, f)
+        f.flush()
+        os.fsync(f.fileno())
     os.replace(index + ".tmp", index)
     remove_old_checkpoints(log_directory)  # Saver(max_to_keep=1)
     return os.path.join(log_directory, name)
