@@ -285,6 +285,7 @@ int decoder_forward_launch(hipStream_t s, int kind, const float* d, int rows, in
     case LK_NB: SCVAE_FWK(LK_NB); break;
     case LK_ZIP: SCVAE_FWK(LK_ZIP); break;
     case LK_ZINB: SCVAE_FWK(LK_ZINB); break;
+    case LK_BERNOULLI: SCVAE_FWK(LK_BERNOULLI); break;   // du:194-204; targets binarised by the caller
     default: set_error("unknown likelihood kind %d", kind); return -1;
   }
 #undef SCVAE_FWK

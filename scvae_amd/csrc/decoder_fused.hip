@@ -668,6 +668,7 @@ static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int
     case LK_NB: SCVAE_DF(LK_NB); break;
     case LK_ZIP: SCVAE_DF(LK_ZIP); break;
     case LK_ZINB: SCVAE_DF(LK_ZINB); break;
+    case LK_BERNOULLI: SCVAE_DF(LK_BERNOULLI); break;   // du:194-204; targets binarised by the caller
     default: set_error("unknown likelihood kind %d", kind); return -1;
   }
 #undef SCVAE_DF
@@ -683,6 +684,9 @@ int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int
   if (rows == 0) return 0;
   const int strips = (F + DF_BN - 1) / DF_BN;
   float* ll_part = workspace;
+  // (the data-only term lgamma(1 + t) of the count likelihoods: the caller's row constant, or
+  //  evaluated inline; the Bernoulli likelihood has none)
+  const int inline_lgamma = (row_const || kind == LK_BERNOULLI) ? 0 : 1;
   // the register-resident forward kernel (decoder_forward.hip) where its LDS budget allows;
   // SCVAE_DECODER_FORWARD=0 keeps the forward instantiation of the training kernels (A/B runs)
   static const bool use_forward = [] {
@@ -691,10 +695,10 @@ int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int
   }();
   int rc;
   if (use_forward && decoder_forward_supported(likelihood_heads(kind), H))
-    rc = decoder_forward_launch(s, kind, d, rows, H, hp, F, t, B, row_const ? 0 : 1, ll_part);
+    rc = decoder_forward_launch(s, kind, d, rows, H, hp, F, t, B, inline_lgamma, ll_part);
   else
-    rc = launch_decoder<false>(s, kind, d, rows, H, hp, F, t, B, nullptr, row_const ? 0 : 1,
-                               ll_part, nullptr);
+    rc = launch_decoder<false>(s, kind, d, rows, H, hp, F, t, B, nullptr, inline_lgamma, ll_part,
+                               nullptr);
   if (rc) return rc;
   hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 15) / 16), dim3(1024), 0, s, ll_part, strips,
                      rows, row_const, B, ll);
@@ -715,8 +719,9 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
   size_t off = ((size_t)strips * rows + 63) / 64 * 64;
   float* dd_part = workspace + off;
   float* planes = dd_part + ((size_t)strips * rows * H + 63) / 64 * 64;
-  int rc = launch_decoder<true>(s, kind, d, rows, H, hp, F, t, B, gw, row_const ? 0 : 1, ll_part,
-                                dd_part, planes);
+  int rc = launch_decoder<true>(s, kind, d, rows, H, hp, F, t, B, gw,
+                                (row_const || kind == LK_BERNOULLI) ? 0 : 1, ll_part, dd_part,
+                                planes);
   if (rc) return rc;
   if (kernel_only) return 0;  // profiling aid: leave the per-strip partials unreduced
   hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 15) / 16), dim3(1024), 0, s, ll_part,

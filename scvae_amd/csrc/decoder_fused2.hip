@@ -628,6 +628,7 @@ static int launch_decoder2(hipStream_t s, int kind, const float* d, int rows, in
     case LK_NB: SCVAE_D2(LK_NB); break;
     case LK_ZIP: SCVAE_D2(LK_ZIP); break;
     case LK_ZINB: SCVAE_D2(LK_ZINB); break;
+    case LK_BERNOULLI: SCVAE_D2(LK_BERNOULLI); break;   // du:194-204; targets binarised by the caller
     default: set_error("unknown likelihood kind %d", kind); return -1;
   }
 #undef SCVAE_D2

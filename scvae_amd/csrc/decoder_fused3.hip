@@ -591,6 +591,7 @@ int decoder_fused3_launch(hipStream_t s, int kind, const float* d, int rows, int
     case LK_NB: SCVAE_D3(LK_NB); break;
     case LK_ZIP: SCVAE_D3(LK_ZIP); break;
     case LK_ZINB: SCVAE_D3(LK_ZINB); break;
+    case LK_BERNOULLI: SCVAE_D3(LK_BERNOULLI); break;   // du:194-204; targets binarised by the caller
     default: set_error("decoder_head3_kernel: likelihood kind %d", kind); return -1;
   }
 #undef SCVAE_D3

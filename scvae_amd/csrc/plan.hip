@@ -624,7 +624,8 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     return -1;
   }
   const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
-                     !a->p_x_mean && KM == 0 && !head_drop && c.likelihood <= LK_ZINB;
+                     !a->p_x_mean && KM == 0 && !head_drop &&
+                     (c.likelihood <= LK_ZINB || c.likelihood == LK_BERNOULLI);
   if (p->x_u16 && !fused) {
     set_error("the uint16 minibatch needs the fused likelihood kernels (no -k / constrained "
               "Poisson, head dropout or evaluation statistics)");
@@ -1135,7 +1136,9 @@ int64_t scvae_decoder_fused_workspace_bytes(int64_t rows, int64_t H, int64_t F) 
                    sizeof(float));
 }
 int32_t scvae_decoder_fused_variant(int32_t kind, int64_t H) {
-  if (kind < 0 || kind > 3 || !scvae::decoder_fused_supported((int)H)) return 0;
+  if (kind < 0 || (kind > 3 && kind != scvae::LK_BERNOULLI) ||
+      !scvae::decoder_fused_supported((int)H))
+    return 0;
   return scvae::decoder_fused_variant(scvae::likelihood_heads(kind), (int)H);
 }
 int32_t scvae_decoder_head_arith(void) { return scvae::decoder_head_arith(); }
@@ -1145,7 +1148,9 @@ int scvae_set_decoder_head_arith(int32_t mode) {
   return 0;
 }
 int32_t scvae_decoder_train_kernel(int32_t kind, int64_t H) {
-  if (kind < 0 || kind > 3 || !scvae::decoder_fused_supported((int)H)) return 0;
+  if (kind < 0 || (kind > 3 && kind != scvae::LK_BERNOULLI) ||
+      !scvae::decoder_fused_supported((int)H))
+    return 0;
   return scvae::decoder_train_kernel(scvae::likelihood_heads(kind), (int)H);
 }
 static int decoder_fused_entry(int32_t kind, int32_t train, const float* d, int64_t rows, int64_t H,
@@ -1153,7 +1158,7 @@ static int decoder_fused_entry(int32_t kind, int32_t train, const float* d, int6
                                float* const* db, int64_t F, scvae::Targets t, int64_t cells,
                                const float* gw, const float* row_const, float* ll, float* dd,
                                void* workspace, void* stream) {
-  SCVAE_ARG(kind >= 0 && kind <= 3 && W && b);
+  SCVAE_ARG(((kind >= 0 && kind <= 3) || kind == scvae::LK_BERNOULLI) && W && b);
   SCVAE_ARG(scvae::decoder_fused_supported((int)H));
   scvae::HeadParams hp;
   for (int j = 0; j < 3; ++j) {

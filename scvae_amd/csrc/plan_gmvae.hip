@@ -348,7 +348,8 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     return -1;
   }
   const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
-                     !a->p_x_mean && KM == 0 && !head_drop && c.likelihood <= LK_ZINB;
+                     !a->p_x_mean && KM == 0 && !head_drop &&
+                     (c.likelihood <= LK_ZINB || c.likelihood == LK_BERNOULLI);
   if (p->x_u16 && !fused) {
     set_error("the uint16 minibatch needs the fused likelihood kernels (no -k / constrained "
               "Poisson, head dropout or evaluation statistics)");

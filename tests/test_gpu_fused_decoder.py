@@ -105,6 +105,55 @@ def test_dense_counts_overflow_the_queue(cuda_device):
     _run(cuda_device, "zero-inflated negative binomial", 64, 64, 128, 32, 1.0)
 
 
+def test_bernoulli_heads(cuda_device):
+    """du:194-204 in the fused kernels: Bernoulli(logits) on binarised targets
+    (no data-only term, no t > 0 correction); training and forward-only."""
+    import oracle.likelihoods  # noqa: F401  (the fp64 reference of _run)
+    for rows, F, H in ((70, 150, 20), (130, 200, 100), (64, 64, 32)):
+        _run_binarised(cuda_device, rows, F, H)
+
+
+def _run_binarised(device, rows, F, H):
+    from scvae_amd import _lib
+    lib = _lib.load()
+    kind, heads = _lib.LIKELIHOOD_KINDS["bernoulli"]
+    rng = np.random.default_rng(rows + F)
+    d = np.maximum(rng.normal(0, 1, (rows, H)), 0)
+    W = rng.normal(0, 0.3, (H, F))
+    b = rng.normal(0, 0.3, F)
+    t = (rng.random((rows, F)) < 0.2).astype(np.float64)
+    gw = rng.normal(0, 1, rows)
+    T = torch.from_numpy
+    dt, Wt, bt = (T(a).requires_grad_(True) for a in (d, W, b))
+    pre = dt @ Wt + bt
+    ll_ref = torch.distributions.Bernoulli(logits=pre).log_prob(T(t)).sum(dim=1)
+    (ll_ref * T(gw)).sum().backward()
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().to(device)
+    dd_, td, gwd, Wd, bd = f32(d), f32(t), f32(gw), f32(W), f32(b)
+    dWd, dbd = torch.full_like(Wd, 7.0), torch.full_like(bd, 7.0)
+    ll = torch.full((rows,), 7.0, device=device)
+    dd = torch.full((rows, H), 7.0, device=device)
+    ws = torch.empty(lib.scvae_decoder_fused_workspace_bytes(rows, H, F),
+                     dtype=torch.uint8, device=device)
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[x.data_ptr() for x in ts])
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for train in (0, 1):
+        _lib.check(lib.scvae_decoder_fused(
+            kind, train, dd_.data_ptr(), rows, H, arr([Wd]), arr([bd]),
+            arr([dWd]), arr([dbd]), F, td.data_ptr(), rows, gwd.data_ptr(), None,
+            ll.data_ptr(), dd.data_ptr(), ws.data_ptr(), stream),
+            "scvae_decoder_fused")
+        torch.cuda.synchronize()
+        want = ll_ref.detach().numpy()
+        got = ll.cpu().double().numpy()
+        assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max() + 1e-4
+    for got, want, what in ((dd, dt.grad, "dd"), (dWd, Wt.grad, "dW"),
+                            (dbd, bt.grad, "db")):
+        want = want.numpy()
+        err = np.abs(got.cpu().double().numpy() - want).max()
+        assert err <= 3e-5 * (np.abs(want).max() + 1e-12), (what, err)
+
+
 def test_repeated_targets_and_inline_lgamma(cuda_device):
     # rows = samples x cells (importance samples / GMVAE passes): row r uses t[r % cells]
     _run(cuda_device, "negative binomial", 96, 32, 100, 24, 0.3)
