@@ -147,6 +147,12 @@ int scvae_plan_set_count_gemm(scvae_plan* plan, int32_t enabled);
  * statistics / finalize / apply kernels (the two implementations are compared in
  * tests/test_gpu_vae_step.py) */
 int scvae_plan_set_bn_one_launch(scvae_plan* plan, int32_t enabled);
+/* Large VAE training minibatches (more than 128 rows, batch norm, no dropout, no data-parallel
+ * hook): 1 (default) = every hidden layer and the posterior heads as ONE launch per layer and
+ * direction -- a workgroup owns a 64-row tile, merges the batch-norm chunk statistics of the layer
+ * below, normalises its rows of it, multiplies (mu:38-76), and leaves the chunk statistics of its
+ * own output (tilechain.hip); 0 = the chain of GEMM / statistics / merge / normalise launches. */
+int scvae_plan_set_tile_chain(scvae_plan* plan, int32_t enabled);
 /* Small VAE minibatches (cells x samples <= 128, widths <= 128, batch norm, analytic KL, no
  * dropout / decoder extras, single process): the hidden layers, posterior heads and latent stage
  * of a step run as TWO cooperative launches (forwards, backwards: sixteen workgroups with a grid

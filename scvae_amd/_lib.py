@@ -110,6 +110,7 @@ SIGNATURES = {
     "scvae_plan_set_count_gemm": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_set_bn_one_launch": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_set_mid_chain": (c_int32, [c_void_p, c_int32]),
+    "scvae_plan_set_tile_chain": (c_int32, [c_void_p, c_int32]),
     "scvae_count_gemm": (c_int32, [
         c_int32, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64,
         c_int64, c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int64,

@@ -825,6 +825,20 @@ int bn_stats(hipStream_t stream, const float* a, int lda, int rows_per_group, in
   return 0;
 }
 
+// the chunk statistics alone (one group): merged by the consumer (tilechain.hip)
+int bn_stats_partial(hipStream_t stream, const float* a, int lda, int rows, int N, float* partial,
+                     int* chunk_out, int* chunks_out) {
+  SCVAE_ARG(a && partial && rows > 0 && N > 0 && chunk_out && chunks_out);
+  int chunk;
+  const int chunks = bn_chunks(rows, &chunk);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((N + 63) / 64, 1, chunks), dim3(1024), 0, stream,
+                     a, lda, rows, N, chunk, partial);
+  SCVAE_LAUNCH_CHECK("bn_stats_partial_kernel");
+  *chunk_out = chunk;
+  *chunks_out = chunks;
+  return 0;
+}
+
 // h = [relu]((a - mean) * rsqrt(var + eps) + beta); stat_stride = N for per-group batch
 // statistics, 0 for the moving statistics shared by all groups (is_training=False).
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ a, int lda,

@@ -97,6 +97,8 @@ size_t bn_partial_floats(int groups, int N);
 size_t col_sum_partial_floats(int N);
 int bn_stats(hipStream_t stream, const float* a, int lda, int rows_per_group, int groups, int N,
              float* mean, float* var, float* partial);
+int bn_stats_partial(hipStream_t stream, const float* a, int lda, int rows, int N, float* partial,
+                     int* chunk_out, int* chunks_out);
 int bn_apply(hipStream_t stream, const float* a, int lda, const float* mean, const float* var,
              int stat_stride, const float* beta, float* h, int ldh, int rows_per_group, int groups,
              int N, int relu);
@@ -163,6 +165,75 @@ unsigned vae_mid_barrier_advance(const MidChainArgs& args, bool backward);
 bool vae_mid_chain_resident();   // all workgroups of the two kernels co-resident on this device
 int vae_mid_forward(hipStream_t stream, const MidChainArgs& args);
 int vae_mid_backward(hipStream_t stream, const MidChainArgs& args);
+
+// ---- tilechain.hip: the hidden layers of a large training minibatch, one launch per layer and
+//      direction (64-row tiles; batch-norm statistics merged by the consuming kernel) ----
+struct TileBN {
+  const float* a = nullptr;   // [rows, n] pre-normalisation output of the layer (nullptr: none)
+  float* h = nullptr;         // [rows, n] normalised (+ relu) output
+  const float* beta = nullptr;
+  float* mean = nullptr;      // [n] batch statistics of the forward pass
+  float* var = nullptr;
+  const float* part = nullptr;   // forward: chunk (mean, M2); backward: chunk (sum dxh, sum dxh xh)
+  int chunks = 0, chunk = 0;
+  float* part_out = nullptr;  // backward epilogue: where the chunk sums of THIS layer go
+  float* s1 = nullptr;        // backward: merged sums, dbeta, moving statistics (tile 0 writes)
+  float* s2 = nullptr;
+  float* dbeta = nullptr;
+  float* mov_mean = nullptr;
+  float* mov_var = nullptr;
+};
+
+struct TileFwdArgs {
+  int rows = 0, K = 0;
+  const float* x = nullptr;   // plain input [rows, K] (pitch ldx) when bn.a == nullptr
+  int ldx = 0;
+  TileBN bn;                  // the layer below, normalisation pending
+  struct Out {
+    const float* W = nullptr;   // [K, N]
+    const float* b = nullptr;
+    float* out = nullptr;       // [rows, N]
+    float* part = nullptr;      // chunk statistics of `out` (one chunk per tile), or nullptr
+    int N = 0;
+  } o[2];
+  int n_out = 0;
+};
+
+struct TileBwdArgs {
+  int rows = 0;
+  float inv_count = 0.f, bessel = 1.f;
+  // the gradients arriving from above: for a batch-normalised layer ONE, w.r.t. its output h
+  // (bn.a != nullptr: dA is formed here); for plain layers (the posterior heads) one or two,
+  // w.r.t. their pre-activations
+  int n_up = 0;
+  struct Up {
+    const float* g = nullptr;   // [rows, N]
+    const float* W = nullptr;   // [K, N]
+    float* dW_slab = nullptr;   // [G][K][N]
+    float* db_slab = nullptr;   // [G][N] (plain layers; nullptr: no bias gradient)
+    float* dA_out = nullptr;    // [rows, N]: dA written out (the layer that sees x: its dW is the
+                                // count kernels' job), nullptr otherwise
+    int N = 0;
+  } up[2];
+  TileBN bn;                  // this layer's batch norm (n_up == 1)
+  const float* in = nullptr;  // [rows, K] the layer's input (nullptr: no dW / d_in here)
+  int K = 0;
+  float* d_in = nullptr;      // [rows, K] gradient w.r.t. the input (nullptr: not needed)
+  TileBN below;               // the batch-normalised layer that produced `in` (a != nullptr):
+                              // its chunk sums are formed from d_in (written to below.part_out)
+};
+
+// out[i] = sum_g slabs[g][i], fixed order; up to four (slabs, n, out) jobs in one launch
+struct SlabJobs {
+  int n_jobs = 0, G = 0;
+  struct Job { const float* slabs; float* out; int n; } job[4];
+};
+size_t tile_chain_part_floats(int rows);     // chunk statistics / sums of one layer
+size_t tile_chain_slab_floats(int rows);     // dW (+ db) slabs of one weight matrix
+int tile_forward(hipStream_t s, const TileFwdArgs& q);
+int tile_backward(hipStream_t s, const TileBwdArgs& q);
+int tile_backward_stats(hipStream_t s, const float* dh, const TileBN& bn, int rows, int N);
+int tile_slab_reduce(hipStream_t s, const SlabJobs& q);
 
 // ---- decoder_fused.hip ----
 // where a fused likelihood kernel reads its targets t[row % B, gene] from: fp32 [B, F] (pitch F)

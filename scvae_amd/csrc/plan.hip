@@ -101,6 +101,15 @@ static size_t carve(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_
   for (auto& d : p->dec) layer_ws(d, R);
   float* mid_bar = b.floats(64);
   if (!dry) p->mid_bar = reinterpret_cast<unsigned*>(mid_bar);
+  {   // tilechain.hip (sized by the decoder's rows, the larger count)
+    float* q[6];
+    for (int i = 0; i < 4; ++i) q[i] = b.floats(tile_chain_part_floats((int)R));
+    for (int i = 4; i < 6; ++i) q[i] = b.floats(tile_chain_slab_floats((int)R));
+    if (!dry) {
+      p->tc_part[0] = q[0]; p->tc_part[1] = q[1]; p->tc_spart[0] = q[2]; p->tc_spart[1] = q[3];
+      p->tc_slab[0] = q[4]; p->tc_slab[1] = q[5];
+    }
+  }
   float* mu_pre = b.floats(B * Lz);
   float* ls_pre = b.floats(B * Lz);
   float* kl_elem = b.floats(B * Lz);
@@ -473,6 +482,33 @@ HeadParams head_params(scvae_plan* p) {
   return hp;
 }
 
+// ---- large training minibatches: one launch per hidden layer and direction (tilechain.hip) ----
+static bool tile_chain_ok(const scvae_plan* p, int B, int S, bool training) {
+  const scvae_model_config& c = p->cfg;
+  static const bool env_on = [] { const char* e = getenv("SCVAE_TILE_CHAIN"); return !(e && e[0] == '0'); }();
+  if (!env_on || !p->use_tile_chain || p->sync || !training) return false;
+  if (!c.batch_norm || p->enc.empty() || p->dec.empty()) return false;
+  if (c.latent_mode != 0 || c.decoder_extra != 0 || c.latent_size > 128) return false;
+  if ((int64_t)B * S <= 128) return false;      // (the mid-chain kernels' regime)
+  for (const auto& d : p->enc) if (d.n_out > 128 || !d.bn) return false;
+  for (const auto& d : p->dec) if (d.n_out > 128 || !d.bn) return false;
+  for (int i = 0; i < 3; ++i) if (dropout_keep(c, i) > 0.f) return false;
+  return p->tc_part[0] != nullptr;
+}
+// the batch norm of layer d as the tile kernels see it
+static TileBN tile_bn(scvae_plan* p, Dense& d, const float* part, int chunks, int chunk,
+                      float* part_out) {
+  TileBN t;
+  const int N = d.n_out;
+  t.a = d.a; t.h = d.h; t.beta = p->params + d.beta;
+  t.mean = d.stats; t.var = d.stats + N;
+  t.s1 = d.stats + 2 * (size_t)N; t.s2 = d.stats + 3 * (size_t)N;
+  t.part = part; t.chunks = chunks; t.chunk = chunk; t.part_out = part_out;
+  t.dbeta = p->grads ? p->grads + d.beta : nullptr;
+  t.mov_mean = p->moving + d.mov_mean; t.mov_var = p->moving + d.mov_var;
+  return t;
+}
+
 // ---- small minibatches: the chain between the input layer and the likelihood heads in one
 //      workgroup (midchain.hip) ----
 static bool mid_chain_ok(const scvae_plan* p, int B, int S, bool training) {
@@ -545,6 +581,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
 
   // ---------------- forward ----------------
   const bool mid = mid_chain_ok(p, B, S, training);
+  const bool tile = !mid && tile_chain_ok(p, B, S, training);
   const float* h = p->step_x;   // (the fp32 batch, or the token of the uint16 one: plan_gemm)
   int ld = F;
   if (mid) {
@@ -556,6 +593,41 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     const MidChainArgs q = mid_chain_args(p, a, B, S, training, 0.f);
     if ((rc = vae_mid_forward(s, q))) return rc;
     p->mid_bar_count += vae_mid_barrier_advance(q, false);
+    h = p->enc.back().h; ld = p->enc.back().n_out;
+  } else if (tile) {
+    // the input layer's product, its chunk statistics, then one launch per layer: the consumer
+    // of a layer merges its statistics and normalises its own rows of it
+    Dense& d0 = p->enc[0];
+    if ((rc = plan_gemm(p, s, false, false, p->step_x, p->params + d0.w, p->params + d0.b, d0.a, B,
+                        d0.n_out, d0.n_in, F, d0.n_out, d0.n_out, ACT_NONE, false)))
+      return rc;
+    int chunk = 0, chunks = 0;
+    if ((rc = bn_stats_partial(s, d0.a, d0.n_out, B, d0.n_out, p->tc_part[0], &chunk, &chunks)))
+      return rc;
+    int cur = 0;
+    for (size_t i = 1; i < p->enc.size(); ++i) {
+      Dense& d = p->enc[i];
+      TileFwdArgs q;
+      q.rows = B; q.K = d.n_in;
+      q.bn = tile_bn(p, p->enc[i - 1], p->tc_part[cur], chunks, chunk, nullptr);
+      q.n_out = 1;
+      q.o[0].W = p->params + d.w; q.o[0].b = p->params + d.b; q.o[0].out = d.a;
+      q.o[0].part = p->tc_part[cur ^ 1]; q.o[0].N = d.n_out;
+      if ((rc = tile_forward(s, q))) return rc;
+      cur ^= 1; chunk = 64; chunks = (B + 63) / 64;
+    }
+    {   // the two posterior heads on the normalised output of the last encoder layer
+      Dense& last = p->enc.back();
+      TileFwdArgs q;
+      q.rows = B; q.K = last.n_out;
+      q.bn = tile_bn(p, last, p->tc_part[cur], chunks, chunk, nullptr);
+      q.n_out = 2;
+      q.o[0].W = p->params + p->mu.w; q.o[0].b = p->params + p->mu.b; q.o[0].out = p->mu_pre;
+      q.o[0].N = L;
+      q.o[1].W = p->params + p->ls.w; q.o[1].b = p->params + p->ls.b; q.o[1].out = p->ls_pre;
+      q.o[1].N = L;
+      if ((rc = tile_forward(s, q))) return rc;
+    }
     h = p->enc.back().h; ld = p->enc.back().n_out;
   } else {
   for (auto& d : p->enc) {
@@ -572,7 +644,11 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const bool mc_kl = (c.latent_mode & 1) != 0;      // va:2633-2640
   const bool unit_var = (c.latent_mode & 2) != 0;   // du:323-337
   const float* ls_pre = unit_var ? nullptr : p->ls_pre;
-  if (!mid) {
+  if (tile) {
+    if ((rc = gauss_latent_fwd(s, p->mu_pre, ls_pre, a->eps, p->z, p->kl_elem, p->kl_cell,
+                               mc_kl ? p->kl_cell : nullptr, S, B, L, a->deterministic_z)))
+      return rc;
+  } else if (!mid) {
   if ((rc = dense_input(p, s, mu, h, ld, B, training, &h_mu, &ld_mu))) return rc;
   if ((rc = plan_gemm(p, s, false, false, h_mu, p->params + mu.w, p->params + mu.b, p->mu_pre, B, L,
                       mu.n_in, ld_mu, L, L, ACT_NONE, false)))
@@ -602,6 +678,26 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const float* dch = dec_in;
   ld = L + E;
   if (mid) {
+    dch = p->dec.back().h; ld = p->dec.back().n_out;
+  } else if (tile) {
+    int cur = 0;
+    for (size_t i = 0; i <= p->dec.size(); ++i) {
+      TileFwdArgs q;
+      q.rows = R;
+      if (i == 0) { q.x = dec_in; q.ldx = L; q.K = L; }
+      else {
+        q.K = p->dec[i - 1].n_out;
+        q.bn = tile_bn(p, p->dec[i - 1], p->tc_part[cur], (R + 63) / 64, 64, nullptr);
+      }
+      if (i < p->dec.size()) {
+        Dense& d = p->dec[i];
+        q.n_out = 1;
+        q.o[0].W = p->params + d.w; q.o[0].b = p->params + d.b; q.o[0].out = d.a;
+        q.o[0].part = p->tc_part[i == 0 ? cur : cur ^ 1]; q.o[0].N = d.n_out;
+      }   // (i == size: the last layer's normalisation alone -> its h feeds the likelihood heads)
+      if ((rc = tile_forward(s, q))) return rc;
+      if (i > 0) cur ^= 1;
+    }
     dch = p->dec.back().h; ld = p->dec.back().n_out;
   } else {
   for (auto& d : p->dec) {
@@ -747,6 +843,84 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                      d0.n_out, B, F, d0.n_out, d0.n_out, ACT_NONE, false);
   }
   const int64_t GR = GB * S;  // global decoder rows
+  if (tile) {
+    // one launch per layer (+ the fixed-order reduce of its dW slabs): the layer's batch-norm
+    // sums are merged by its own kernel, which also leaves the chunk sums of the layer below
+    auto bessel = [](int64_t n) { return (float)n / (float)(n > 1 ? n - 1 : 1); };
+    int sp = 0;
+    {
+      Dense& top = p->dec.back();
+      if ((rc = tile_backward_stats(s, dcur, tile_bn(p, top, nullptr, 0, 0, p->tc_spart[sp]), R,
+                                    top.n_out)))
+        return rc;
+    }
+    auto layer_backward = [&](Dense& d, Dense* below, const float* in, int rows, int64_t grows,
+                              const float* dh_in, float* d_in, float* dA_out) -> int {
+      TileBwdArgs q;
+      const int G = (rows + 63) / 64;
+      q.rows = rows; q.inv_count = 1.f / (float)grows; q.bessel = bessel(grows);
+      q.n_up = 1;
+      q.up[0].g = dh_in; q.up[0].W = p->params + d.w; q.up[0].N = d.n_out;
+      q.up[0].dW_slab = p->tc_slab[0]; q.up[0].dA_out = dA_out;
+      q.bn = tile_bn(p, d, p->tc_spart[sp], G, 64, nullptr);
+      q.in = in; q.K = in ? d.n_in : 0; q.d_in = d_in;
+      if (below) q.below = tile_bn(p, *below, nullptr, 0, 0, p->tc_spart[sp ^ 1]);
+      int r = tile_backward(s, q);
+      if (r || !in) return r;
+      SlabJobs j;
+      j.n_jobs = 1; j.G = G;
+      j.job[0] = {p->tc_slab[0], p->grads + d.w, d.n_in * d.n_out};
+      sp ^= 1;
+      return tile_slab_reduce(s, j);
+    };
+    for (int i = (int)p->dec.size() - 1; i >= 0; --i) {
+      Dense& d = p->dec[i];
+      const float* in = i > 0 ? p->dec[i - 1].h : dec_in;
+      float* d_in = i > 0 ? dalt : p->dz;
+      if ((rc = layer_backward(d, i > 0 ? &p->dec[i - 1] : nullptr, in, R, GR, dcur, d_in, nullptr)))
+        return rc;
+      if (i > 0) { float* t = dcur; dcur = dalt; dalt = t; }
+    }
+    if ((rc = gauss_latent_bwd(s, p->mu_pre, ls_pre, a->eps, p->dz, w / (float)GB, nullptr, p->dmu,
+                               p->dls, S, B, L)))
+      return rc;
+    float* dh = p->dbuf[0];
+    float* dh_alt = p->dbuf[1];
+    {   // the two posterior heads: dW, db of both, dh of the last encoder layer and its chunk sums
+      Dense& last = p->enc.back();
+      const int G = (B + 63) / 64, K = last.n_out;
+      TileBwdArgs q;
+      q.rows = B; q.n_up = 2;
+      for (int u = 0; u < 2; ++u) {
+        Dense& hd = u == 0 ? p->mu : p->ls;
+        q.up[u].g = u == 0 ? p->dmu : p->dls;
+        q.up[u].W = p->params + hd.w; q.up[u].N = L;
+        q.up[u].dW_slab = p->tc_slab[u];
+        q.up[u].db_slab = p->tc_slab[u] + (size_t)G * 128 * 128;
+      }
+      q.in = last.h; q.K = K; q.d_in = dh;
+      q.below = tile_bn(p, last, nullptr, 0, 0, p->tc_spart[sp]);
+      if ((rc = tile_backward(s, q))) return rc;
+      SlabJobs j;
+      j.n_jobs = 4; j.G = G;
+      j.job[0] = {p->tc_slab[0], p->grads + p->mu.w, K * L};
+      j.job[1] = {p->tc_slab[1], p->grads + p->ls.w, K * L};
+      j.job[2] = {q.up[0].db_slab, p->grads + p->mu.b, L};
+      j.job[3] = {q.up[1].db_slab, p->grads + p->ls.b, L};
+      if ((rc = tile_slab_reduce(s, j))) return rc;
+    }
+    for (int i = (int)p->enc.size() - 1; i >= 1; --i) {
+      if ((rc = layer_backward(p->enc[i], &p->enc[i - 1], p->enc[i - 1].h, B, GB, dh, dh_alt,
+                               nullptr)))
+        return rc;
+      float* t = dh; dh = dh_alt; dh_alt = t;
+    }
+    // the layer that sees x: its dA here, its weight gradient x^T dA on the count kernels
+    Dense& d0 = p->enc[0];
+    if ((rc = layer_backward(d0, nullptr, nullptr, B, GB, dh, nullptr, p->dbuf[2]))) return rc;
+    return plan_gemm(p, s, true, false, p->step_x, p->dbuf[2], nullptr, p->grads + d0.w, d0.n_in,
+                     d0.n_out, B, F, d0.n_out, d0.n_out, ACT_NONE, false);
+  }
   // decoder layers, last to first; the first decoder layer's input is z
   for (int i = (int)p->dec.size() - 1; i >= 0; --i) {
     Dense& d = p->dec[i];
@@ -921,6 +1095,11 @@ int scvae_plan_set_fused(scvae_plan* p, int32_t enabled) {
   return 0;
 }
 
+int scvae_plan_set_tile_chain(scvae_plan* p, int32_t enabled) {
+  SCVAE_ARG(p);
+  p->use_tile_chain = enabled ? 1 : 0;
+  return 0;
+}
 int scvae_plan_set_mid_chain(scvae_plan* p, int32_t enabled) {
   SCVAE_ARG(p);
   p->use_mid_chain = enabled ? 1 : 0;

@@ -1,0 +1,616 @@
+// The hidden layers of a LARGE training minibatch with fewer launches (round 3).
+//
+// dense_layer with batch normalisation (mu:38-76: fully_connected -> batch_norm(center=True,
+// scale=False) -> relu) is, launch by launch, GEMM | chunk statistics | merge | normalise going
+// forward and statistics | merge | dA | dX GEMM | dW GEMM | split-K reduce going back: ten
+// launches per layer of ~5 us each on [4096, 100] tensors, none of them bound by anything but its
+// own dependent memory round trips.  The statistics of a layer need all rows, so the layer cannot
+// be one kernel without a grid barrier -- but the work can be cut at the OTHER side of the
+// statistics: a workgroup owns a 64-row tile through
+//
+//   forward  (tile_fwd_kernel):  merge the chunk statistics of the layer below (every workgroup
+//            the same fixed-order merge: identical bits), normalise + relu its own tile of that
+//            layer (written out once, as h, for the backward pass), product with this layer's
+//            weights on the fp32 matrix cores, bias, the tile's own chunk statistics;
+//   backward (tile_bwd_kernel):  merge the layer's two column sums, dA of the tile
+//            (bn_input_gradient), dX = dA W^T, this tile's slab of dW = in^T dA, and the chunk
+//            sums the layer BELOW needs for its own batch-norm backward.
+//
+// One launch per layer and direction (+ one fixed-order reduce of the dW slabs), kernel
+// boundaries where the statistics need all rows, no atomics, no grid barrier.  The posterior heads
+// (two weight matrices on the same input) ride in the same kernels.  Used by the VAE plan for
+// training minibatches of more than 128 rows without dropout or a data-parallel hook; everything
+// else keeps the launch chain (plan.hip) or the two mid-chain kernels (midchain.hip).
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace scvae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TC_ROWS = 64;      // rows per tile
+constexpr int TC_MAXN = 128;     // widest layer
+constexpr int TC_LD = 129;       // LDS row stride (odd)
+constexpr int TC_THREADS = 512;   // 8 waves, two per SIMD: at one per SIMD every LDS / memory latency is exposed
+constexpr int TC_RG = TC_THREADS / 128;   // row groups: thread = (column tid & 127, row group tid >> 7)
+
+size_t tile_chain_part_floats(int rows) {
+  return (size_t)((rows + TC_ROWS - 1) / TC_ROWS) * 2 * TC_MAXN;
+}
+size_t tile_chain_slab_floats(int rows) {
+  return (size_t)((rows + TC_ROWS - 1) / TC_ROWS) * (TC_MAXN + 1) * TC_MAXN;
+}
+
+// C[64, N] (+)= A[64, K] B[K, N] on the fp32 matrix cores; A in LDS [64][TC_LD], B in LDS
+// [K][TC_LD] (k padded to even with zeros by the caller); wave w (of 8): row tile w & 1, column
+// tile w >> 1.
+__device__ __forceinline__ void tile_mma(const float* As, const float* Bs, int K2, int N, int w,
+                                         int lane, f32x16& acc) {
+  const int li = lane & 31, kh = lane >> 5;
+  const int rt = w & 1, ct = w >> 1;
+  if (32 * ct >= N) return;
+  const float* ap = As + (32 * rt + li) * TC_LD + kh;
+  const float* bp = Bs + kh * TC_LD + 32 * ct + li;
+#pragma unroll 8
+  for (int k = 0; k < K2; k += 2)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bp[k * TC_LD], acc, 0, 0, 0);
+}
+// the accumulator of tile_mma -> LDS tile [64][TC_LD]
+__device__ __forceinline__ void tile_store(float* Os, int N, int w, int lane, const f32x16& acc) {
+  const int li = lane & 31, kh = lane >> 5;
+  const int rt = w & 1, ct = w >> 1;
+  if (32 * ct >= N) return;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    Os[(32 * rt + (i & 3) + 8 * (i >> 2) + 4 * kh) * TC_LD + 32 * ct + li] = acc[i];
+}
+
+typedef float f32x4t __attribute__((ext_vector_type(4)));
+
+// A contiguous block of n floats (a [rows, nc] tile whose pitch is nc: every tensor of the
+// chain) on its way into an LDS tile [..][TC_LD]: `load` requests it with 16-byte loads, all of a
+// thread's requests in flight together; `store` lands it later (element e -> row e / nc, column
+// e % nc), so that several blocks travel at once and a kernel pays one memory round trip for its
+// inputs instead of one per block.
+template <int NV>
+struct TilePre {
+  float v[NV];
+  // request rows rl, rl + TC_RG, ... (NV of them) of column c = tid & 127 of a [nr, nc] block of
+  // pitch nc (n = nr * nc floats)
+  __device__ __forceinline__ void load(const float* __restrict__ src, int n, int tid, int nc) {
+    const int c = tid & 127, rl = tid >> 7;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = (rl + TC_RG * u) * nc + c;
+      v[u] = (c < nc && e < n) ? src[e] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ dst, int cols_pad, int rows_pad,
+                                        int tid) const {
+    const int c = tid & 127, rl = tid >> 7;
+    if (c >= cols_pad) return;
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+      if (rl + TC_RG * u < rows_pad) dst[(rl + TC_RG * u) * TC_LD + c] = v[u];
+  }
+};
+// a linear block of n floats (the chunk statistics): 16-byte loads
+template <int NV>
+struct LinePre {
+  f32x4t v[NV];
+  __device__ __forceinline__ void load(const float* __restrict__ src, int n, int tid) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = 4 * (tid + TC_THREADS * u);
+      f32x4t x = {0.f, 0.f, 0.f, 0.f};
+      if (e + 3 < n) {
+        x = *reinterpret_cast<const f32x4t*>(src + e);
+      } else if (e < n) {
+        x.x = src[e];
+        if (e + 1 < n) x.y = src[e + 1];
+        if (e + 2 < n) x.z = src[e + 2];
+      }
+      v[u] = x;
+    }
+  }
+  __device__ __forceinline__ void store_linear(float* __restrict__ dst, int n, int tid) const {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = 4 * (tid + TC_THREADS * u);
+      if (e + 3 < n) {
+        dst[e] = v[u].x; dst[e + 1] = v[u].y; dst[e + 2] = v[u].z; dst[e + 3] = v[u].w;
+      } else if (e < n) {
+        dst[e] = v[u].x;
+        if (e + 1 < n) dst[e + 1] = v[u].y;
+        if (e + 2 < n) dst[e + 2] = v[u].z;
+      }
+    }
+  }
+};
+__global__ __launch_bounds__(TC_THREADS) void tile_fwd_kernel(TileFwdArgs q) {
+  extern __shared__ __attribute__((aligned(16))) float tsm[];
+  float* As = tsm;                               // [64][TC_LD]
+  float* Bs = As + TC_ROWS * TC_LD;              // [K2][TC_LD], then the output tile
+  float* st = Bs + TC_MAXN * TC_LD;              // [3][128]: mean, istd, beta
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.x, r0 = g * TC_ROWS;
+  const int nr = min(TC_ROWS, q.rows - r0);
+  const int K = q.K, K2 = (K + 1) & ~1;
+  // ---- every input of the kernel is requested up front: the first weight matrix, the input
+  //      tile, the chunk statistics of the layer below ----
+  TilePre<128 / TC_RG> pw;              // [K, N] weights (<= 128 x 128)
+  TilePre<TC_ROWS / TC_RG> pa;          // [64, K] input tile
+  const int n_w0 = q.n_out > 0 ? K * q.o[0].N : 0;
+  pw.load(q.n_out > 0 ? q.o[0].W : q.x, n_w0, tid, q.n_out > 0 ? q.o[0].N : 1);
+  const float* src_a = q.bn.a ? q.bn.a + (size_t)r0 * K : q.x + (size_t)r0 * q.ldx;
+  pa.load(src_a, nr * K, tid, K);
+  if (q.bn.a) {
+    // (the chunk statistics pass through LDS, 64 chunks at a time: a thread walking its column's
+    //  chunks in global memory pays a round trip per chunk.  Two passes -- mean, then M2 about it
+    //  -- in chunk order: fixed, so every workgroup of the launch arrives at the same bits)
+    const int chunks = q.bn.chunks, chunk = q.bn.chunk;
+    float mean = 0.f, m2 = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int z0 = 0; z0 < chunks; z0 += 64) {
+        const int zn = min(64, chunks - z0);
+        if (pass == 0 || chunks > 64) {     // (a single block stays in LDS for the second pass)
+          LinePre<8> pp;
+          pp.load(q.bn.part + (size_t)z0 * 2 * K, zn * 2 * K, tid);
+          lds_barrier();
+          pp.store_linear(Bs, zn * 2 * K, tid);
+          lds_barrier();
+        }
+        {
+          // thread (column c, group zg) takes the chunks z = zg mod TC_RG; the groups' partial
+          // sums are combined in group order: a fixed order, the same bits in every workgroup
+          const int c = tid & 127, zg = tid >> 7;
+          const float n_full = (float)chunk;
+          const float n_last = (float)(q.rows - (chunks - 1) * chunk);
+          float part_sum = 0.f;
+          if (c < K) {
+#pragma unroll 4
+            for (int z = zg; z < 64; z += TC_RG) {
+              const bool on = z < zn;
+              const float n = on ? (z0 + z == chunks - 1 ? n_last : n_full) : 0.f;
+              const float* pz = Bs + (on ? z : 0) * 2 * K;
+              if (pass == 0) part_sum = bn_merge_mean(part_sum, n, pz[c]);
+              else part_sum = on ? bn_merge_m2(part_sum, n, pz[c], pz[K + c], st[c]) : part_sum;
+            }
+          }
+          lds_barrier();
+          st[(1 + zg) * TC_MAXN + c] = part_sum;
+          lds_barrier();
+          if (tid < K) {
+            float total = st[TC_MAXN + tid];
+#pragma unroll
+            for (int j = 1; j < TC_RG; ++j) total += st[(1 + j) * TC_MAXN + tid];
+            if (pass == 0) mean += total; else m2 += total;
+          }
+        }
+      }
+      if (pass == 0) {
+        // (the mean of the whole minibatch, broadcast to the column's other threads through st)
+        mean /= (float)q.rows;
+        lds_barrier();
+        if (tid < K) st[tid] = mean;
+        lds_barrier();
+      }
+    }
+    if (tid < K) {
+      const float var = m2 / (float)q.rows;
+      st[tid] = mean;
+      st[TC_MAXN + tid] = rsqrtf(var + BN_EPSILON);
+      st[2 * TC_MAXN + tid] = q.bn.beta[tid];
+      if (g == 0) { q.bn.mean[tid] = mean; q.bn.var[tid] = var; }
+    }
+  }
+  lds_barrier();        // (As zeroed, statistics in st, Bs free)
+  pa.store(As, (K + 31) & ~31, TC_ROWS, tid);
+  if (q.bn.a) {
+    lds_barrier();
+    const int c = tid & 127, rl = tid >> 7;
+    if (c < K) {
+#pragma unroll 4
+      for (int r = rl; r < nr; r += TC_RG) {
+        float v = bn_normalise(As[r * TC_LD + c], st[c], st[TC_MAXN + c], st[2 * TC_MAXN + c]);
+        v = fmaxf(v, 0.f);
+        As[r * TC_LD + c] = v;
+        q.bn.h[(size_t)(r0 + r) * K + c] = v;
+      }
+    }
+  }
+  // ---- products ----
+  for (int o = 0; o < q.n_out; ++o) {
+    const TileFwdArgs::Out& out = q.o[o];
+    const int N = out.N;
+    if (o > 0) pw.load(out.W, K * N, tid, N);
+    lds_barrier();     // (As written / the previous output tile consumed)
+    pw.store(Bs, (N + 31) & ~31, K2, tid);
+    lds_barrier();
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    tile_mma(As, Bs, K2, N, w, lane, acc);
+    lds_barrier();     // (all waves done with Bs)
+    tile_store(Bs, N, w, lane, acc);
+    lds_barrier();
+    // bias, store, chunk statistics of the tile (two-pass, as bn_stats_partial_kernel)
+    {
+      const int c = tid & 127, rl = tid >> 7;
+      const float bv = c < N ? out.b[c] : 0.f;
+      for (int r = rl; r < nr; r += TC_RG)
+        if (c < N) {
+          const float v = Bs[r * TC_LD + c] + bv;
+          Bs[r * TC_LD + c] = v;
+          out.out[(size_t)(r0 + r) * N + c] = v;
+        }
+    }
+    if (out.part) {
+      // chunk statistics of the tile, two-pass (mean, then M2 about it); two threads per column
+      lds_barrier();
+      const int c = tid & 127, rl = tid >> 7;
+      float sum = 0.f;
+      if (c < N) {
+#pragma unroll 8
+        for (int r = rl; r < TC_ROWS; r += TC_RG) sum += (r < nr) ? Bs[r * TC_LD + c] : 0.f;
+      }
+      st[rl * TC_MAXN + c] = sum;
+      lds_barrier();
+      float tot = st[c];
+#pragma unroll
+      for (int j = 1; j < TC_RG; ++j) tot += st[j * TC_MAXN + c];
+      const float mu = tot / (float)nr;
+      float m2 = 0.f;
+      if (c < N) {
+#pragma unroll 8
+        for (int r = rl; r < TC_ROWS; r += TC_RG) {
+          const float d = Bs[r * TC_LD + c] - mu;
+          m2 = fmaf(d, (r < nr) ? d : 0.f, m2);
+        }
+      }
+      lds_barrier();
+      st[rl * TC_MAXN + c] = m2;
+      lds_barrier();
+      if (rl == 0 && c < N) {
+        float t2 = st[c];
+#pragma unroll
+        for (int j = 1; j < TC_RG; ++j) t2 += st[j * TC_MAXN + c];
+        out.part[((size_t)g * 2) * N + c] = mu;
+        out.part[((size_t)g * 2 + 1) * N + c] = t2;
+      }
+    }
+  }
+}
+
+static constexpr size_t TC_FWD_LDS =
+    (size_t)(TC_ROWS * TC_LD + TC_MAXN * TC_LD + (1 + TC_RG) * TC_MAXN) * 4;
+
+int tile_forward(hipStream_t s, const TileFwdArgs& q) {
+  SCVAE_ARG(q.rows > 0 && q.K > 0 && q.K <= TC_MAXN && q.n_out >= 0 && q.n_out <= 2);
+  SCVAE_ARG(q.bn.a || (q.x && q.ldx == q.K));      // (tiles are contiguous blocks)
+  for (int o = 0; o < q.n_out; ++o) SCVAE_ARG(q.o[o].N > 0 && q.o[o].N <= TC_MAXN);
+  SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_fwd_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)TC_FWD_LDS));
+  hipLaunchKernelGGL(tile_fwd_kernel, dim3((q.rows + TC_ROWS - 1) / TC_ROWS), dim3(TC_THREADS),
+                     TC_FWD_LDS, s, q);
+  SCVAE_LAUNCH_CHECK("tile_fwd_kernel");
+  return 0;
+}
+
+// ------------------------------- backward ---------------------------------------------------
+__global__ __launch_bounds__(TC_THREADS) void tile_bwd_kernel(TileBwdArgs q) {
+  extern __shared__ __attribute__((aligned(16))) float tsm[];
+  float* As = tsm;                               // h tile, then the input tile, then d_in [64][TC_LD]
+  float* Ds = As + TC_ROWS * TC_LD;              // dA tiles [n_up][64][TC_LD]
+  float* Ws = Ds + 2 * TC_ROWS * TC_LD;          // a tile, then half of W: [64][TC_LD]
+  float* st = Ws + TC_ROWS * TC_LD;              // [2 TC_RG][128]: mean, istd, s1, s2 / partial sums
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int g = blockIdx.x, r0 = g * TC_ROWS;
+  const int nr = min(TC_ROWS, q.rows - r0);
+  const int K = q.K;
+  const bool bn = q.bn.a != nullptr;
+  // ---- every input tile is requested up front ----
+  TilePre<TC_ROWS / TC_RG> pg[2], ph, pa, pin, pw0;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    pg[u].load(u < q.n_up ? q.up[u].g + (size_t)r0 * q.up[u].N : q.up[0].g,
+               u < q.n_up ? nr * q.up[u].N : 0, tid, u < q.n_up ? q.up[u].N : 1);
+  {
+    const int N0 = q.up[0].N;
+    ph.load(bn ? q.bn.h + (size_t)r0 * N0 : q.up[0].g, bn ? nr * N0 : 0, tid, N0);
+    pa.load(bn ? q.bn.a + (size_t)r0 * N0 : q.up[0].g, bn ? nr * N0 : 0, tid, N0);
+    pin.load(q.in ? q.in + (size_t)r0 * K : q.up[0].g, q.in ? nr * K : 0, tid, q.in ? K : 1);
+    pw0.load(q.up[0].W, q.d_in ? min(64, K) * N0 : 0, tid, N0);
+  }
+  TilePre<TC_ROWS / TC_RG> pb;   // the pre-normalisation tile of the layer below (its chunk sums)
+  pb.load(q.below.a ? q.below.a + (size_t)r0 * K : q.up[0].g, q.below.a ? nr * K : 0, tid,
+          q.below.a ? K : 1);
+  // ---- this layer's batch norm: merged sums (fixed order), dbeta, moving averages ----
+  if (bn) {
+    const int N = q.up[0].N;
+    float t1 = 0.f, t2 = 0.f;
+    for (int z0 = 0; z0 < q.bn.chunks; z0 += 64) {     // (through LDS, as in the forward kernel)
+      const int zn = min(64, q.bn.chunks - z0);
+      {
+        LinePre<8> pp;
+        pp.load(q.bn.part + (size_t)z0 * 2 * N, zn * 2 * N, tid);
+        lds_barrier();
+        pp.store_linear(Ds, zn * 2 * N, tid);
+        lds_barrier();
+      }
+      {
+        // thread (column c, group zg): chunks z = zg mod TC_RG; groups combined in a fixed order
+        const int c = tid & 127, zg = tid >> 7;
+        float p1 = 0.f, p2 = 0.f;
+        if (c < N) {
+#pragma unroll 4
+          for (int z = zg; z < 64; z += TC_RG) {
+            const bool on = z < zn;
+            const int zz = on ? z : 0;
+            p1 += on ? Ds[zz * 2 * N + c] : 0.f;
+            p2 += on ? Ds[(zz * 2 + 1) * N + c] : 0.f;
+          }
+        }
+        lds_barrier();
+        st[zg * TC_MAXN + c] = p1;
+        st[(TC_RG + zg) * TC_MAXN + c] = p2;
+        lds_barrier();
+        if (tid < N) {
+#pragma unroll
+          for (int j = 0; j < TC_RG; ++j) {
+            t1 += st[j * TC_MAXN + tid];
+            t2 += st[(TC_RG + j) * TC_MAXN + tid];
+          }
+        }
+      }
+    }
+    lds_barrier();
+    if (tid < N) {
+      const float mean = q.bn.mean[tid], var = q.bn.var[tid];
+      st[tid] = mean;
+      st[TC_MAXN + tid] = rsqrtf(var + BN_EPSILON);
+      st[2 * TC_MAXN + tid] = t1;
+      st[3 * TC_MAXN + tid] = t2;
+      if (g == 0) {
+        q.bn.s1[tid] = t1;
+        q.bn.s2[tid] = t2;
+        q.bn.dbeta[tid] = t1;
+        // UPDATE_OPS (va:2763-2768): moving <- moving - (moving - batch) * rate, Bessel-corrected
+        q.bn.mov_mean[tid] = bn_moving_update(q.bn.mov_mean[tid], mean);
+        q.bn.mov_var[tid] = bn_moving_update(q.bn.mov_var[tid], var * q.bessel);
+      }
+    }
+    lds_barrier();
+  }
+  // ---- dA tiles ----
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (u < q.n_up) pg[u].store(Ds + u * TC_ROWS * TC_LD, (q.up[u].N + 31) & ~31, TC_ROWS, tid);
+  if (bn) {
+    const int N = q.up[0].N;
+    ph.store(As, N, TC_ROWS, tid);
+    pa.store(Ws, N, TC_ROWS, tid);
+  }
+  lds_barrier();
+  for (int u = 0; u < q.n_up; ++u) {
+    const TileBwdArgs::Up& up = q.up[u];
+    const int N = up.N;
+    float* D = Ds + u * TC_ROWS * TC_LD;
+    const int c = tid & 127, rl = tid >> 7;
+    if (c < N && (bn || up.dA_out)) {
+#pragma unroll 4
+      for (int r = rl; r < nr; r += TC_RG) {
+        float v = D[r * TC_LD + c];
+        if (bn) {
+          if (!(As[r * TC_LD + c] > 0.f)) v = 0.f;
+          const float xh = (Ws[r * TC_LD + c] - st[c]) * st[TC_MAXN + c];
+          v = bn_input_gradient(v, xh, st[2 * TC_MAXN + c], st[3 * TC_MAXN + c], q.inv_count,
+                                st[TC_MAXN + c]);
+          D[r * TC_LD + c] = v;
+        }
+        if (up.dA_out) up.dA_out[(size_t)(r0 + r) * N + c] = v;
+      }
+    }
+  }
+  if (!q.in) return;      // (uniform: the layer that sees x stops here)
+  lds_barrier();        // (the dA transform is done with As and Ws)
+  pin.store(As, (K + 31) & ~31, TC_ROWS, tid);
+  lds_barrier();
+  // ---- dW slabs: dW_u[k, n] (this tile) = sum_row in[row, k] dA_u[row, n]; bias: column sums ----
+  for (int u = 0; u < q.n_up; ++u) {
+    const TileBwdArgs::Up& up = q.up[u];
+    const int N = up.N;
+    const float* D = Ds + u * TC_ROWS * TC_LD;
+    float* slab = up.dW_slab + (size_t)g * K * N;
+    const int kts = (K + 31) / 32, nts = (N + 31) / 32;
+    for (int t = w; t < kts * nts; t += TC_THREADS / 64) {
+      const int kt = t / nts, nt = t % nts;
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const float* ap = As + kh * TC_LD + 32 * kt + li;     // A[i = k][kk = row]
+      const float* bp = D + kh * TC_LD + 32 * nt + li;      // B[kk = row][n]
+#pragma unroll 8
+      for (int r = 0; r < TC_ROWS; r += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[r * TC_LD], bp[r * TC_LD], acc, 0, 0, 0);
+      const int n = 32 * nt + li;
+      if (n < N) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int k = 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * kh;
+          if (k < K) slab[(size_t)k * N + n] = acc[i];
+        }
+      }
+    }
+    if (up.db_slab && tid < N) {
+      float sum = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < TC_ROWS; ++r) sum += D[r * TC_LD + tid];   // (rows >= nr hold zeros)
+      up.db_slab[(size_t)g * N + tid] = sum;
+    }
+  }
+  if (!q.d_in) return;
+  // ---- d_in[row, k] = sum_u sum_n dA_u[row, n] W_u[k, n]; the weights pass through LDS in
+  //      halves of 64 input units (column tiles 0-1, then 2-3) ----
+  f32x16 acc;               // wave w: row tile w & 1, column tile w >> 1 (of the input width)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int u = 0; u < q.n_up; ++u) {
+    const TileBwdArgs::Up& up = q.up[u];
+    const int N = up.N, N2 = (N + 1) & ~1;
+    const float* D = Ds + u * TC_ROWS * TC_LD;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      if (64 * v >= K) continue;
+      const int kn = min(64, K - 64 * v);
+      if (u > 0 || v > 0) pw0.load(up.W + (size_t)64 * v * N, kn * N, tid, N);
+      lds_barrier();      // (Ws free)
+      pw0.store(Ws, N2, 64, tid);
+      lds_barrier();
+      const int rt = w & 1, kt = w >> 1;
+      if ((kt >> 1) == v && 32 * kt < K) {
+        const float* ap = D + (32 * rt + li) * TC_LD + kh;              // A[i = row][kk = n]
+        const float* bp = Ws + (32 * (kt & 1) + li) * TC_LD + kh;       // B[kk = n][j = k] = W[k][n]
+#pragma unroll 8
+        for (int n = 0; n < N2; n += 2)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[n], bp[n], acc, 0, 0, 0);
+      }
+    }
+  }
+  lds_barrier();
+  float* Xs = Ds;                         // the d_in tile and the layer below's a tile take the
+  float* Ab = Ds + TC_ROWS * TC_LD;       // place of the dA tiles; As still holds `in` (= its h)
+  tile_store(Xs, K, w, lane, acc);
+  if (q.below.a) pb.store(Ab, K, TC_ROWS, tid);
+  lds_barrier();
+  const int c = tid & 127, rl = tid >> 7;
+  if (c < K) {
+#pragma unroll 4
+    for (int r = rl; r < nr; r += TC_RG) q.d_in[(size_t)(r0 + r) * K + c] = Xs[r * TC_LD + c];
+  }
+  // ---- the chunk sums the layer below needs for its own batch-norm backward:
+  //      dxh = d_in * (h > 0), xh = (a - mean) * istd; two threads per column ----
+  if (q.below.a) {
+    float a1 = 0.f, a2 = 0.f;
+    if (c < K) {
+      const float mu = q.below.mean[c];
+      const float istd = rsqrtf(q.below.var[c] + BN_EPSILON);
+#pragma unroll 8
+      for (int r = rl; r < TC_ROWS; r += TC_RG) {
+        float d = Xs[r * TC_LD + c];
+        if (!(r < nr && As[r * TC_LD + c] > 0.f)) d = 0.f;
+        const float xh = (Ab[r * TC_LD + c] - mu) * istd;
+        a1 += d;
+        a2 = fmaf(d, r < nr ? xh : 0.f, a2);
+      }
+    }
+    lds_barrier();
+    st[rl * TC_MAXN + c] = a1;
+    st[(TC_RG + rl) * TC_MAXN + c] = a2;
+    lds_barrier();
+    if (rl == 0 && c < K) {
+      float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < TC_RG; ++j) {
+        u1 += st[j * TC_MAXN + c];
+        u2 += st[(TC_RG + j) * TC_MAXN + c];
+      }
+      q.below.part_out[((size_t)g * 2) * K + c] = u1;
+      q.below.part_out[((size_t)g * 2 + 1) * K + c] = u2;
+    }
+  }
+}
+
+static constexpr size_t TC_BWD_LDS =
+    (size_t)(4 * TC_ROWS * TC_LD + 2 * TC_RG * TC_MAXN) * 4;
+
+int tile_backward(hipStream_t s, const TileBwdArgs& q) {
+  SCVAE_ARG(q.rows > 0 && q.n_up >= 1 && q.n_up <= 2 && q.K >= 0 && q.K <= TC_MAXN);
+  SCVAE_ARG(!q.bn.a || q.n_up == 1);
+  for (int u = 0; u < q.n_up; ++u) SCVAE_ARG(q.up[u].N > 0 && q.up[u].N <= TC_MAXN);
+  SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bwd_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)TC_BWD_LDS));
+  hipLaunchKernelGGL(tile_bwd_kernel, dim3((q.rows + TC_ROWS - 1) / TC_ROWS), dim3(TC_THREADS),
+                     TC_BWD_LDS, s, q);
+  SCVAE_LAUNCH_CHECK("tile_bwd_kernel");
+  return 0;
+}
+
+// chunk sums of the TOP batch-normalised layer of a chain from its output gradient dh
+__global__ __launch_bounds__(256) void tile_bwd_stats_kernel(const float* __restrict__ dh,
+                                                                    TileBN bn, int rows, int N) {
+  __shared__ float red[2][256];
+  const int g = blockIdx.x, r0 = g * TC_ROWS;
+  const int nr = min(TC_ROWS, rows - r0);
+  const int c = threadIdx.x & 127, rl = threadIdx.x >> 7;
+  float a1 = 0.f, a2 = 0.f;
+  if (c < N) {
+    const float mu = bn.mean[c];
+    const float istd = rsqrtf(bn.var[c] + BN_EPSILON);
+    // (eight rows' loads in flight: a load-use-per-iteration loop pays a round trip per row)
+    for (int r = rl; r < TC_ROWS; r += 16) {
+      float dv[8], hv[8], av[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int rr = r + 2 * u;
+        const size_t e = (size_t)(r0 + (rr < nr ? rr : 0)) * N + c;
+        dv[u] = dh[e]; hv[u] = bn.h[e]; av[u] = bn.a[e];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int rr = r + 2 * u;
+        float d = dv[u];
+        if (!(rr < nr && hv[u] > 0.f)) d = 0.f;
+        const float xh = (av[u] - mu) * istd;
+        a1 += d;
+        a2 = fmaf(d, xh, a2);
+      }
+    }
+  }
+  red[0][threadIdx.x] = a1;
+  red[1][threadIdx.x] = a2;
+  lds_barrier();
+  if (rl == 0 && c < N) {
+    bn.part_out[((size_t)g * 2) * N + c] = red[0][c] + red[0][128 + c];
+    bn.part_out[((size_t)g * 2 + 1) * N + c] = red[1][c] + red[1][128 + c];
+  }
+}
+
+int tile_backward_stats(hipStream_t s, const float* dh, const TileBN& bn, int rows, int N) {
+  SCVAE_ARG(dh && bn.a && bn.h && bn.mean && bn.var && bn.part_out && N > 0 && N <= TC_MAXN);
+  hipLaunchKernelGGL(tile_bwd_stats_kernel, dim3((rows + TC_ROWS - 1) / TC_ROWS), dim3(256),
+                     0, s, dh, bn, rows, N);
+  SCVAE_LAUNCH_CHECK("tile_bwd_stats_kernel");
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void tile_slab_reduce_kernel(SlabJobs q) {
+  const SlabJobs::Job jb = q.job[blockIdx.y];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += gridDim.x * blockDim.x) {
+    float s0 = 0.f;
+    int g = 0;
+    for (; g + 8 <= q.G; g += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = jb.slabs[(size_t)(g + u) * jb.n + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s0 += v[u];
+    }
+    for (; g < q.G; ++g) s0 += jb.slabs[(size_t)g * jb.n + i];
+    jb.out[i] = s0;
+  }
+}
+int tile_slab_reduce(hipStream_t s, const SlabJobs& q) {
+  SCVAE_ARG(q.n_jobs >= 1 && q.n_jobs <= 4 && q.G >= 1);
+  int n_max = 0;
+  for (int j = 0; j < q.n_jobs; ++j) n_max = q.job[j].n > n_max ? q.job[j].n : n_max;
+  hipLaunchKernelGGL(tile_slab_reduce_kernel, dim3((n_max + 255) / 256, q.n_jobs), dim3(256), 0, s,
+                     q);
+  SCVAE_LAUNCH_CHECK("tile_slab_reduce_kernel");
+  return 0;
+}
+
+}  // namespace scvae

@@ -309,6 +309,12 @@ class Engine:
         _lib.check(self.lib.scvae_plan_set_mid_chain(
             self.handle, 1 if enabled else 0), "scvae_plan_set_mid_chain")
 
+    def set_tile_chain(self, enabled):
+        """Large VAE training minibatches: one launch per hidden layer and
+        direction (default) or the chain of GEMM / batch-norm launches."""
+        _lib.check(self.lib.scvae_plan_set_tile_chain(
+            self.handle, 1 if enabled else 0), "scvae_plan_set_tile_chain")
+
     def set_bn_one_launch(self, enabled, always=False):
         """One-launch batch norm for single-group layers: for minibatches of
         up to 1024 rows (default), whenever it applies (``always``), or never

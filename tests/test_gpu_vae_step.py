@@ -307,3 +307,63 @@ def test_mid_chain_matches_the_launch_chain(cuda_device, B, H, L, n_iw):
     for a, b in zip(*results):
         scale = b.abs().max().item()
         assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-9
+
+
+@pytest.mark.parametrize("B,H,L,n_iw,n_mc", [(4096, (100, 100), 25, 1, 1),
+                                              (300, (100, 100), 25, 1, 1),
+                                              (129, (24, 20), 7, 1, 1),
+                                              (1000, (128,), 128, 1, 1),
+                                              (333, (16, 12, 8), 5, 1, 1),
+                                              (200, (50, 30), 10, 2, 1),
+                                              (150, (64, 64), 9, 1, 3)])
+def test_tile_chain_matches_the_launch_chain(cuda_device, B, H, L, n_iw, n_mc):
+    """Large training minibatches run every hidden layer and the posterior heads
+    as one launch per layer and direction (``tilechain.hip``: 64-row tiles, the
+    consumer of a layer merges its batch-norm chunk statistics; instead of ~10
+    launches per layer).  Same step as the chain of launches: scalars, per-cell
+    outputs, every gradient, the moving statistics -- and bitwise repeatable.
+    (Ragged last tiles, odd widths, one / three layers, importance and
+    Monte-Carlo samples.)"""
+    from scvae_amd.engine import Engine
+    F = 400
+    S = n_iw * n_mc
+    rng = np.random.default_rng(B + L)
+    x = torch.from_numpy(_counts(rng, B, F)).float().to(cuda_device)
+    eps = torch.from_numpy(rng.standard_normal((S, B, L))).float().to(
+        cuda_device)
+    results = []
+    for tile in (True, False):
+        eng = Engine(F, L, H, "negative binomial", batch_norm=True,
+                     device=cuda_device, seed=4)
+        g = torch.Generator().manual_seed(9)
+        for name, p in eng.named_parameters().items():
+            if not name.endswith("weights"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+        for name, m in eng.named_moving_statistics().items():
+            m.copy_(torch.rand(m.shape, generator=g) + 0.5)
+        eng.set_tile_chain(tile)
+        ll = torch.zeros(S * B, device=cuda_device)
+        qz = torch.zeros(B, L, device=cuda_device)
+        klz = torch.zeros(L, device=cuda_device)
+        outs = {"log_p_x_given_z": ll, "q_z_mean": qz, "kl_neurons": klz}
+        moving0 = eng.moving.clone()
+        scalars = eng.step(x, x, eps=eps, training=True, n_iw=n_iw, n_mc=n_mc,
+                           warm_up_weight=0.7, outputs=outs).clone()
+        torch.cuda.synchronize()
+        train = [scalars.cpu(), ll.cpu().clone(), qz.cpu().clone(),
+                 klz.cpu().clone(), eng.grads.clone().cpu(),
+                 eng.moving.clone().cpu()]
+        results.append(train)
+        if tile:
+            eng.moving.copy_(moving0)
+            again = eng.step(x, x, eps=eps, training=True, n_iw=n_iw,
+                             n_mc=n_mc, warm_up_weight=0.7, outputs=outs).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(again.cpu(), train[0])
+            assert torch.equal(eng.grads.cpu(), train[4])
+            assert torch.equal(eng.moving.cpu(), train[5])
+    names = ["scalars", "ll", "q_z_mean", "kl_neurons", "grads", "moving"]
+    for name, a, b in zip(names, *results):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-9, (
+            name, (a - b).abs().max().item(), scale)
