@@ -361,45 +361,72 @@ class Workload:
         # bit-identical step), fp32 otherwise
         self.u16 = bool(matrix.integer_counts
                         and self.engine.accepts_counts_u16(batch, True))
+        # two sets of minibatch buffers: a step carries the fetch and the noise of
+        # the NEXT one (scvae_side_work: they run on the plan's second stream under
+        # the step's backward pass), so that one reads set i while set i ^ 1 fills
         if self.u16:
-            self.x = torch.empty(batch, matrix.u16_pitch, dtype=torch.uint16,
-                                 device=device)
+            self.x = [torch.empty(batch, matrix.u16_pitch, dtype=torch.uint16,
+                                  device=device) for _ in range(2)]
         else:
-            self.x = torch.empty(batch, F, device=device)
-        self.row_const = torch.empty(batch, device=device)
-        self.eps = torch.empty(self.K, batch, latent, device=device)
+            self.x = [torch.empty(batch, F, device=device) for _ in range(2)]
+        self.row_const = [torch.empty(batch, device=device) for _ in range(2)]
+        self.eps = [torch.empty(self.K, batch, latent, device=device)
+                    for _ in range(2)]
         self.generator = torch.Generator(device=device).manual_seed(2)
         self.perm = self._permutation()
         self.cursor = 0
         self.step_counter = 0
+        self.slot = 0
+        self.primed = False
 
     def _permutation(self):
         return self.torch.randperm(self.matrix.number_of_rows,
                                    generator=self.generator, device=self.device)
 
-    def one_step(self, comm_events=None):
-        from scvae_amd.minibatch import philox_normal_blocks
+    def _next_rows(self):
         n, B, GB, rank = self.matrix.number_of_rows, self.B, self.GB, self.rank
         if self.cursor + GB > n:
             self.perm = self._permutation()
             self.cursor = 0
         rows = self.perm[self.cursor + rank * B: self.cursor + (rank + 1) * B]
         self.cursor += GB
-        if self.u16:
-            self.matrix.gather_counts_u16(rows, out=self.x,
-                                          row_const_out=self.row_const)
-        else:
-            self.matrix.gather_dense(rows, out=self.x,
-                                     row_const_out=self.row_const)
-        philox_normal_blocks(self.eps, block_stride=GB, row_offset=rank * B,
-                             seed=1, stream_id=self.step_counter)
+        return rows
+
+    def _noise(self, slot, step):
+        return dict(out=self.eps[slot], block_stride=self.GB,
+                    row_offset=self.rank * self.B, seed=1, stream_id=step)
+
+    def one_step(self, comm_events=None):
+        """One training step: this step's minibatch and noise are in buffer set
+        ``slot`` (fetched by the step before; by hand for the very first one);
+        the step carries the fetch + noise of the next minibatch and -- single
+        process -- its own clip + Adam update; under data parallel the
+        all-reduce comes first and Adam is a launch of its own."""
+        from scvae_amd.minibatch import philox_normal_blocks
+        B, GB, rank = self.B, self.GB, self.rank
+        cur = self.slot
+        if not self.primed:
+            self.matrix.request(self._next_rows(), self.x[cur],
+                                self.row_const[cur]).issue()
+            philox_normal_blocks(self.eps[cur], block_stride=GB,
+                                 row_offset=rank * B, seed=1,
+                                 stream_id=self.step_counter)
+            self.primed = True
+        nxt = cur ^ 1
+        request = self.matrix.request(self._next_rows(), self.x[nxt],
+                                      self.row_const[nxt])
         self.step_counter += 1
-        self.engine.step(self.x, self.x, eps=self.eps, row_const=self.row_const,
-                         training=True, global_cells=GB, row_offset=rank * B,
-                         x_counts=self.matrix.integer_counts)
+        self.engine.step(self.x[cur], self.x[cur], eps=self.eps[cur],
+                         row_const=self.row_const[cur], training=True,
+                         global_cells=GB, row_offset=rank * B,
+                         x_counts=self.matrix.integer_counts,
+                         learning_rate=1e-4 if self.sync is None else None,
+                         next_minibatch=request,
+                         next_noise=self._noise(nxt, self.step_counter))
         if self.sync is not None:
             self.sync.all_reduce_gradients(events=comm_events)
-        self.engine.adam_step(1e-4)
+            self.engine.adam_step(1e-4)
+        self.slot = nxt
 
     def run(self, steps, warmup, barrier, min_warm_seconds=MIN_WARM_SECONDS):
         """Warm up (>= warmup steps and >= min_warm_seconds of real steps; the

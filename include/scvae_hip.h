@@ -175,6 +175,50 @@ int scvae_plan_set_mid_chain(scvae_plan* plan, int32_t enabled);
  * finite: a caller that keeps passing the same buffer gets a sticky counter of non-finite
  * steps.  (The reference tests the loss at the steps it prints, va:1034-1044; with the counter
  * the same test at the same steps also catches a non-finite loss of any step in between.) */
+/* ---- work a step carries along (optional: scvae_step_args.side) ----
+ * The reference's loop is fetch -> session.run(optimiser) -> fetch -> ... (va:985-1013): four
+ * calls per step through this ABI (minibatch, noise, step, optimiser).  A step may carry its own
+ * optimiser update and the fetch + noise of the NEXT minibatch: one call, everything ordered on
+ * the caller's stream when scvae_plan_step returns (no host synchronisation); the results are
+ * those of calling scvae_adam_clip_step, scvae_csr_minibatch and scvae_philox_normal_blocks right
+ * after the step.  The buffers written here must not be inputs of the step that carries them
+ * (double-buffer the minibatch and the noise): the library may run this work on a second stream
+ * of its own beside the step's backward pass (off by default -- measured on MI355X it does not
+ * pay, see plan.hip -- SCVAE_SIDE_STREAM=1). */
+typedef struct scvae_side_work {
+  /* clip + Adam (scvae_adam_clip_step on the plan's whole parameter buffer with this step's
+   * gradients); adam_m == NULL: none.  Training steps only; refused while a data-parallel hook is
+   * set (the all-reduce comes between the step and the update). */
+  float* adam_m;
+  float* adam_v;
+  float adam_grad_scale;
+  float adam_lr_t;
+  float adam_beta1;
+  float adam_beta2;
+  float adam_epsilon;
+  /* the next minibatch: the arguments of scvae_csr_minibatch; fetch_out == NULL: none */
+  int32_t fetch_as_u16;
+  const int64_t* fetch_indptr;
+  const int32_t* fetch_indices;
+  const float* fetch_values;
+  const int64_t* fetch_rows;
+  int64_t fetch_n;
+  int64_t fetch_features;
+  void* fetch_out;
+  int64_t fetch_ld;
+  const float* fetch_row_values;
+  float* fetch_row_values_out;
+  /* the next step's noise: the arguments of scvae_philox_normal_blocks; noise_out == NULL: none */
+  float* noise_out;
+  int64_t noise_blocks;
+  int64_t noise_block_rows;
+  int64_t noise_cols;
+  int64_t noise_block_stride;
+  int64_t noise_row_offset;
+  uint64_t noise_seed;
+  uint64_t noise_stream_id;
+} scvae_side_work;
+
 typedef struct scvae_step_args {
   const float* x;
   const float* t;
@@ -225,6 +269,8 @@ typedef struct scvae_step_args {
    * anything else is refused with an error. */
   const uint16_t* counts_u16;
   int64_t counts_ld;
+  /* optional: optimiser update of this step / fetch and noise of the next one (see above) */
+  const scvae_side_work* side;
 } scvae_step_args;
 int scvae_plan_step(scvae_plan* plan, const scvae_step_args* args, void* stream);
 /* 1 if a step of `cells` cells (training or not) of this plan can take its minibatch as uint16

@@ -11,7 +11,9 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int32, c_int64,
                     c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBRARY_PATH = os.path.join(_HERE, "csrc", "libscvae_hip.so")
+#: (SCVAE_HIP_LIBRARY: an A/B build of the same library, tools/ab_variants.sh)
+LIBRARY_PATH = os.environ.get("SCVAE_HIP_LIBRARY") or os.path.join(
+    _HERE, "csrc", "libscvae_hip.so")
 
 MAX_HIDDEN = 8
 NAME_MAX = 96
@@ -80,6 +82,40 @@ class StepArgs(Structure):
         ("x_counts", c_int32),
         ("counts_u16", c_void_p),
         ("counts_ld", c_int64),
+        ("side", c_void_p),
+    ]
+
+
+class SideWork(Structure):
+    """``scvae_side_work``: the optimiser update of a training step and the
+    fetch / noise of the next minibatch, carried by the step."""
+    _fields_ = [
+        ("adam_m", c_void_p),
+        ("adam_v", c_void_p),
+        ("adam_grad_scale", c_float),
+        ("adam_lr_t", c_float),
+        ("adam_beta1", c_float),
+        ("adam_beta2", c_float),
+        ("adam_epsilon", c_float),
+        ("fetch_as_u16", c_int32),
+        ("fetch_indptr", c_void_p),
+        ("fetch_indices", c_void_p),
+        ("fetch_values", c_void_p),
+        ("fetch_rows", c_void_p),
+        ("fetch_n", c_int64),
+        ("fetch_features", c_int64),
+        ("fetch_out", c_void_p),
+        ("fetch_ld", c_int64),
+        ("fetch_row_values", c_void_p),
+        ("fetch_row_values_out", c_void_p),
+        ("noise_out", c_void_p),
+        ("noise_blocks", c_int64),
+        ("noise_block_rows", c_int64),
+        ("noise_cols", c_int64),
+        ("noise_block_stride", c_int64),
+        ("noise_row_offset", c_int64),
+        ("noise_seed", c_uint64),
+        ("noise_stream_id", c_uint64),
     ]
 
 

@@ -150,6 +150,15 @@ struct scvae_plan {
   bool x_u16 = false;            // this step's minibatch is the uint16 count matrix below
   const uint16_t* step_u16 = nullptr;
   int step_u16_ld = 0;
+  // scvae_step_args.side: the plan's second stream, forked where the likelihood heads' gradients
+  // are final and joined before the step ends
+  const scvae_side_work* side = nullptr;
+  hipStream_t side_stream = nullptr;
+  hipEvent_t side_fork = nullptr, side_join = nullptr;
+  bool side_forked = false;
+  bool side_jobs_done = false;  // fetch + noise issued
+  size_t side_adam_from = 0;    // parameters [side_adam_from, n) were updated on the second stream
+  ~scvae_plan();
   int use_mid_chain = 1;      // small VAE steps: hidden layers + heads + latent in two launches
   int use_tile_chain = 1;     // large VAE training steps: one launch per hidden layer and direction
   float* tc_part[2] = {nullptr, nullptr};    // tilechain.hip: chunk statistics (forward), ping-pong
@@ -214,5 +223,7 @@ int copy(hipStream_t s, const float* src, float* dst, size_t n);
 int build_gmvae(scvae_plan* p);
 size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t samples, bool dry);
 int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s);
+int plan_side_fork(scvae_plan* p, hipStream_t s, int point);   // scvae_step_args.side (plan.hip)
+int plan_side_finish(scvae_plan* p, hipStream_t s);
 }  // namespace scvae
 

@@ -447,6 +447,8 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
 
   // ---------------- backward: heads + decoder ----------------
   if (!fused) TRY(heads_backward(p, s, head_in, R, head_drop, dcur, dalt));
+  // the next minibatch and its noise (scvae_step_args.side) under the rest of the backward pass
+  TRY(plan_side_fork(p, s, 1));
   const int64_t GSB = GB * S;  // global rows per group (pass) in the decoder
   for (int i = (int)p->xdec.size() - 1; i >= 0; --i) {
     Dense& d = p->xdec[i];

@@ -344,12 +344,22 @@ class Engine:
              n_iw=1, n_mc=1, warm_up_weight=1.0, deterministic_z=False,
              global_cells=None, outputs=None, scalars=None,
              decoder_extra=None, dropout_seed=None, count_sum=None,
-             row_offset=0, x_counts=False):
+             row_offset=0, x_counts=False, learning_rate=None,
+             grad_scale=1.0, next_minibatch=None, next_noise=None):
         """One graph execution (no host synchronisation).  ``outputs`` maps
         optional output names of ``scvae_step_args`` to preallocated tensors.
         ``dropout_seed``: seed of this training step's dropout masks (default:
         a counter of the training steps taken).  Returns the device tensor of
-        scalars."""
+        scalars.
+
+        Work the step may carry (``scvae_side_work``; results as if issued
+        right after the step, but run on the plan's second stream under the
+        backward pass of the hidden layers): ``learning_rate`` -- the clip +
+        Adam update of this training step (instead of ``adam_step``; single
+        process only); ``next_minibatch`` -- a ``DeviceCSR.request(...)`` for
+        the following step's minibatch (into buffers this step does not read);
+        ``next_noise`` -- ``dict(out=, block_stride=, row_offset=, seed=,
+        stream_id=)`` for its noise (``philox_normal_blocks`` arguments)."""
         cells = x.shape[0]
         samples = 1 if deterministic_z else n_iw * n_mc
         self.reserve(cells, samples)
@@ -401,6 +411,34 @@ class Engine:
         if outputs:
             for key, tensor in outputs.items():
                 setattr(a, key, tensor.data_ptr())
+        side = None
+        if (learning_rate is not None or next_minibatch is not None
+                or next_noise is not None):
+            side = _lib.SideWork()
+            if learning_rate is not None:
+                if not training:
+                    raise ValueError("learning_rate: training steps only")
+                side.adam_m = self.adam_m.data_ptr()
+                side.adam_v = self.adam_v.data_ptr()
+                side.adam_grad_scale = float(grad_scale)
+                side.adam_lr_t = self._next_adam_lr_t(learning_rate)
+                side.adam_beta1 = ADAM_BETA1
+                side.adam_beta2 = ADAM_BETA2
+                side.adam_epsilon = ADAM_EPSILON
+            if next_minibatch is not None:
+                next_minibatch.fill(side)
+            if next_noise is not None:
+                out = next_noise["out"]
+                if out.dim() != 3 or not out.is_contiguous():
+                    raise ValueError("contiguous [blocks, rows, cols] expected")
+                side.noise_out = out.data_ptr()
+                (side.noise_blocks, side.noise_block_rows,
+                 side.noise_cols) = out.shape
+                side.noise_block_stride = int(next_noise["block_stride"])
+                side.noise_row_offset = int(next_noise.get("row_offset", 0))
+                side.noise_seed = int(next_noise["seed"])
+                side.noise_stream_id = int(next_noise["stream_id"])
+            a.side = ctypes.addressof(side)
         _lib.check(self.lib.scvae_plan_step(
             self.handle, ctypes.byref(a), current_stream_handle(self.device)),
             "scvae_plan_step")
@@ -432,12 +470,16 @@ class Engine:
             current_stream_handle(self.device)), "scvae_plan_decode")
         return out
 
-    def adam_step(self, learning_rate, grad_scale=1.0):
-        """clip-by-value(+-1) + ``tf.train.AdamOptimizer`` update (va:2742-2759)."""
+    def _next_adam_lr_t(self, learning_rate):
+        """``lr_t`` of the next optimiser step (tf.train.AdamOptimizer)."""
         self.adam_t += 1
         t = self.adam_t
-        lr_t = (learning_rate * math.sqrt(1.0 - ADAM_BETA2 ** t)
+        return (learning_rate * math.sqrt(1.0 - ADAM_BETA2 ** t)
                 / (1.0 - ADAM_BETA1 ** t))
+
+    def adam_step(self, learning_rate, grad_scale=1.0):
+        """clip-by-value(+-1) + ``tf.train.AdamOptimizer`` update (va:2742-2759)."""
+        lr_t = self._next_adam_lr_t(learning_rate)
         _lib.check(self.lib.scvae_adam_clip_step(
             _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m),
             _ptr(self.adam_v), self.params.numel(), float(grad_scale),

@@ -93,6 +93,11 @@ class DeviceCSR:
         return out
 
 
+    def request(self, rows, out, row_const_out=None):
+        """A fetch of ``rows`` into ``out`` (fp32 ``[n, F]`` or uint16
+        ``[n, u16_pitch]``) to hand to ``Engine.step(next_minibatch=...)``."""
+        return MinibatchRequest(self, rows, out, row_const_out)
+
     @property
     def u16_pitch(self):
         """Row pitch (elements) of the uint16 minibatch: whole 128-byte lines."""
@@ -115,6 +120,47 @@ class DeviceCSR:
             _ptr(row_const_out) if row_const_out is not None else None,
             stream), "scvae_csr_minibatch")
         return out
+
+
+class MinibatchRequest:
+    """The arguments of one minibatch fetch (``scvae_csr_minibatch``), to be
+    carried by the step before it (``Engine.step(next_minibatch=...)``: the
+    densify then runs under that step's backward pass) or issued directly
+    (``issue()``).  Holds references to every tensor involved."""
+
+    def __init__(self, matrix, rows, out, row_const_out=None):
+        if out.dtype not in (torch.uint16, torch.float32):
+            raise ValueError("uint16 or float32 minibatch buffer expected")
+        if out.dtype == torch.uint16 and not matrix.integer_counts:
+            raise ValueError("not an integer count matrix below 65 536")
+        if out.dim() != 2 or out.stride(1) != 1 or out.shape[0] < rows.numel():
+            raise ValueError("row-major [>= len(rows), >= F] buffer expected")
+        self.matrix, self.rows, self.out = matrix, rows, out
+        self.row_const_out = row_const_out
+
+    def fill(self, side):
+        m = self.matrix
+        side.fetch_as_u16 = 1 if self.out.dtype == torch.uint16 else 0
+        side.fetch_indptr = m.indptr.data_ptr()
+        side.fetch_indices = m.indices.data_ptr()
+        side.fetch_values = m.values.data_ptr()
+        side.fetch_rows = self.rows.data_ptr()
+        side.fetch_n = int(self.rows.numel())
+        side.fetch_features = m.shape[1]
+        side.fetch_out = self.out.data_ptr()
+        side.fetch_ld = self.out.stride(0)
+        side.fetch_row_values = m.row_lgamma1p.data_ptr()
+        side.fetch_row_values_out = (
+            self.row_const_out.data_ptr()
+            if self.row_const_out is not None else None)
+
+    def issue(self):
+        if self.out.dtype == torch.uint16:
+            self.matrix.gather_counts_u16(self.rows, out=self.out,
+                                          row_const_out=self.row_const_out)
+        else:
+            self.matrix.gather_dense(self.rows, out=self.out,
+                                     row_const_out=self.row_const_out)
 
 
 def philox_normal(out, row_offset, seed, stream_id):

@@ -455,25 +455,47 @@ class ModelBase:
         samples = n_iw * n_mc
 
         local_batch = minibatch_size // world if world > 1 else minibatch_size
-        x_buffer = torch.empty(max(local_batch, 1), F, device=device)
-        t_buffer = (x_buffer if x_train is t_train
-                    else torch.empty_like(x_buffer))
-        row_const = torch.empty(max(local_batch, 1), device=device)
-        eps_buffer = torch.empty(
+        # two sets of minibatch buffers: a step carries the fetch and the noise
+        # of the NEXT minibatch and -- single process -- its own optimiser update
+        # (``Engine.step(learning_rate=, next_minibatch=, next_noise=)``: one
+        # call per step), so set i is read while set i ^ 1 fills
+        same_matrix = x_train is t_train
+        x_buffers = [torch.empty(max(local_batch, 1), F, device=device)
+                     for _ in range(2)]
+        t_buffers = (x_buffers if same_matrix
+                     else [torch.empty_like(b) for b in x_buffers])
+        row_consts = [torch.empty(max(local_batch, 1), device=device)
+                      for _ in range(2)]
+        eps_buffers = [torch.empty(
             int(numpy.prod(self._eps_shape(samples, max(local_batch, 1)))),
-            device=device)
+            device=device) for _ in range(2)]
         step = int(epoch_start * steps_per_epoch)
         engine.reserve(max(local_batch, 1), samples)
         # an integer count matrix that is both input and target: the minibatch
         # is densified as uint16 where the plan takes it (half the bytes for the
         # three kernels that stream it; the step is bit-identical)
-        u16_buffer = None
-        if (x_train is t_train and getattr(x_train, "integer_counts", False)
+        u16_buffers = None
+        if (same_matrix and getattr(x_train, "integer_counts", False)
                 and hasattr(x_train, "gather_counts_u16")
                 and engine.accepts_counts_u16(max(local_batch, 1), True)):
-            u16_buffer = torch.empty(
+            u16_buffers = [torch.empty(
                 max(local_batch, 1), x_train.u16_pitch, dtype=torch.uint16,
-                device=device)
+                device=device) for _ in range(2)]
+
+        def minibatch_buffers(slot, cells):
+            """(x, t, row constant, fetch request or None) of a minibatch of
+            ``cells`` cells in buffer set ``slot``."""
+            rc = row_consts[slot][:cells]
+            if (u16_buffers is not None
+                    and engine.accepts_counts_u16(cells, True)):
+                xb = tb = u16_buffers[slot][:cells]
+            else:
+                xb, tb = x_buffers[slot][:cells], t_buffers[slot][:cells]
+            return xb, tb, rc
+
+        def noise_buffer(slot, cells):
+            return eps_buffers[slot][:int(numpy.prod(
+                self._eps_shape(samples, cells)))]
         engine.scalars.zero_()   # incl. the sticky non-finite-step counter [7]
 
         from scvae_amd.minibatch import philox_normal
@@ -495,8 +517,10 @@ class ModelBase:
             else:
                 shuffled_indices = torch.from_numpy(shuffled).to(device)
 
+            # this epoch's minibatches: (rows of this rank, global cells, first
+            # global row of this rank)
+            batches = []
             for i in range(0, n_examples_train, minibatch_size):
-                step_time_start = time()
                 rows = shuffled_indices[i:(i + minibatch_size)]
                 global_cells = int(rows.numel())
                 lo = 0
@@ -507,21 +531,33 @@ class ModelBase:
                     per_rank = global_cells // world
                     lo = rank * per_rank
                     rows = rows[lo:lo + per_rank]
+                batches.append((rows, global_cells, lo))
+
+            slot, carried = 0, False
+            for index, (rows, global_cells, lo) in enumerate(batches):
+                step_time_start = time()
                 cells = int(rows.numel())
-                xb = x_buffer[:cells]
-                tb = t_buffer[:cells]
-                rc = row_const[:cells]
-                if (u16_buffer is not None
-                        and engine.accepts_counts_u16(cells, True)):
-                    xb = tb = x_train.gather_counts_u16(
-                        rows, out=u16_buffer[:cells], row_const_out=rc)
-                else:
-                    t_train.gather_dense(rows, out=tb, row_const_out=rc)
-                    if x_train is not t_train:
+                xb, tb, rc = minibatch_buffers(slot, cells)
+                eps = noise_buffer(slot, cells)
+                if not carried:   # (the previous step brought this minibatch)
+                    if xb is tb:
+                        t_train.request(rows, tb, rc).issue()
+                    else:
+                        t_train.gather_dense(rows, out=tb, row_const_out=rc)
                         x_train.gather_dense(rows, out=xb)
-                eps = eps_buffer[:int(numpy.prod(
-                    self._eps_shape(samples, cells)))]
-                self._draw_noise(eps, samples, cells, global_cells, lo, step)
+                    self._draw_noise(eps, samples, cells, global_cells, lo, step)
+                # what this step carries for the next one
+                next_minibatch = next_noise = None
+                carried = False
+                if same_matrix and index + 1 < len(batches):
+                    n_rows, n_global, n_lo = batches[index + 1]
+                    n_cells = int(n_rows.numel())
+                    n_xb, _, n_rc = minibatch_buffers(slot ^ 1, n_cells)
+                    next_minibatch = t_train.request(n_rows, n_xb, n_rc)
+                    next_noise = self._noise_request(
+                        noise_buffer(slot ^ 1, n_cells), samples, n_cells,
+                        n_global, n_lo, step + 1)
+                    carried = True
                 de = (t_train.decoder_extra.index_select(0, rows)
                       if t_train.decoder_extra is not None else None)
                 cs = (t_train.count_sum.index_select(0, rows)
@@ -534,10 +570,15 @@ class ModelBase:
                     # (the masks are keyed by the global row: the same for any
                     # sharding, like the noise)
                     dropout_seed=((self.noise_seed * 1000003) << 40)
-                    + step + 1, row_offset=lo)
+                    + step + 1, row_offset=lo,
+                    # single process: clip + Adam ride with the step; data
+                    # parallel: the gradient all-reduce comes first
+                    learning_rate=learning_rate if sync is None else None,
+                    next_minibatch=next_minibatch, next_noise=next_noise)
                 if sync is not None:
                     sync.all_reduce_gradients()
-                engine.adam_step(learning_rate)
+                    engine.adam_step(learning_rate)
+                slot ^= 1
 
                 if (step + 1 - steps_per_epoch * epoch) in output_at_step:
                     local = scalars.clone()
@@ -743,15 +784,22 @@ class ModelBase:
         return 0
 
     # -- noise -----------------------------------------------------------------
+    def _noise_request(self, eps, samples, cells, global_cells, row_offset,
+                       step):
+        """The ``philox_normal_blocks`` arguments that fill ``eps`` (shape
+        ``_eps_shape``: stacked passes of ``cells`` rows) so that global row g
+        of pass s gets the draw keyed by (noise_seed, step, s*global_cells +
+        g): the same for any sharding of the rows."""
+        blocks = int(numpy.prod(self._eps_shape(samples, cells)[:-2]))
+        return dict(out=eps.view(blocks, cells, self.latent_size),
+                    block_stride=global_cells, row_offset=row_offset,
+                    seed=self.noise_seed, stream_id=step)
+
     def _draw_noise(self, eps, samples, cells, global_cells, row_offset,
                     step):
-        """Fill ``eps`` ([S, cells, L]) so that global row g of sample s gets
-        the draw keyed by (noise_seed, step, s*global_cells + g): the same for
-        any sharding of the rows."""
         from scvae_amd.minibatch import philox_normal_blocks
-        philox_normal_blocks(eps.view(samples, cells, self.latent_size),
-                             block_stride=global_cells, row_offset=row_offset,
-                             seed=self.noise_seed, stream_id=step)
+        philox_normal_blocks(**self._noise_request(
+            eps, samples, cells, global_cells, row_offset, step))
 
     # -- evaluation pass shared by train (epoch end) and evaluate --------------
     def _evaluation_pass(self, x, t, data_set, minibatch_size, n_iw, n_mc,

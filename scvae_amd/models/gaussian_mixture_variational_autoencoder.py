@@ -384,14 +384,6 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
     def _eps_shape(self, samples, cells):
         return (self.n_clusters, samples, cells, self.latent_size)
 
-    def _draw_noise(self, eps, samples, cells, global_cells, row_offset,
-                    step):
-        from scvae_amd.minibatch import philox_normal_blocks
-        K, L = self.n_clusters, self.latent_size
-        philox_normal_blocks(eps.view(K * samples, cells, L),
-                             block_stride=global_cells, row_offset=row_offset,
-                             seed=self.noise_seed, stream_id=step)
-
     def _loss_tags(self):
         return [(0, "lower_bound", "ELBO"),
                 (2, "reconstruction_error", "ENRE"),

@@ -132,6 +132,7 @@ def _c_layout(struct, fields, tmp_path):
 
 
 @pytest.mark.parametrize("struct,ctype", [("scvae_step_args", "StepArgs"),
+                                          ("scvae_side_work", "SideWork"),
                                           ("scvae_model_config", "ModelConfig")])
 def test_ctypes_structures_have_the_layout_of_the_header(tmp_path, struct, ctype):
     """The ctypes mirrors of the C structs (``scvae_amd/_lib.py``) against the
