@@ -207,30 +207,44 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
   const int c0 = blockIdx.x * BN;
 
   // ---- LDS: zero everything (padding and over-read regions must hold finite values), then the
-  //      strip's weights and biases, cut into planes ----
+  //      strip's weights and biases, cut into planes.  ALL of a thread's weight loads -- its rows
+  //      of every head -- are requested first, from clamped, always valid addresses, and land
+  //      under the zero fill: as a plain loop this fill was one dependent global-memory round trip
+  //      per weight row, 12 us per workgroup -- a third of the kernel at a 100-cell minibatch ----
+  constexpr int HSTEP = D3_THREADS / BN;
+  constexpr int NV = (126 + HSTEP) / HSTEP;            // rows 0 .. H <= 126 of a thread
   {
-    const int n16 = (int)(((size_t)P * 3 * WPLANE + (size_t)P * 3 * GPLANE + 2 * D3_BM * 4) / 16);
-    u32x4* z = reinterpret_cast<u32x4*>(smem);
-    for (int i = tid; i < n16; i += D3_THREADS) z[i] = u32x4{0u, 0u, 0u, 0u};
-  }
-  __syncthreads();
-  {
-    const int g = tid & (BN - 1);
+    const int g = tid & (BN - 1), h0 = tid / BN;
     const bool col_ok = c0 + g < F;
+    const int gc = min(c0 + g, F - 1);
+    float v[P][NV];
 #pragma unroll
-    for (int j = 0; j < P; ++j) {
-      const float* Wj = hp.W[j] + c0 + g;
-      for (int h = tid / BN; h <= H; h += D3_THREADS / BN) {
-        float v = 0.f;
-        if (col_ok) v = h < H ? Wj[(size_t)h * F] : hp.b[j][c0 + g];
-        unsigned b1, b2, b3;
-        split3_trunc(v, b1, b2, b3);
-        char* dst = Wl + (size_t)(j * 3) * WPLANE + h * ROWB + 2 * g;
-        *reinterpret_cast<uint16_t*>(dst) = (uint16_t)(b1 >> 16);
-        *reinterpret_cast<uint16_t*>(dst + WPLANE) = (uint16_t)(b2 >> 16);
-        *reinterpret_cast<uint16_t*>(dst + 2 * WPLANE) = (uint16_t)(b3 >> 16);
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const int h = h0 + u * HSTEP;
+        v[j][u] = h < H ? hp.W[j][(size_t)h * F + gc] : hp.b[j][gc];
       }
+    {
+      const int n16 = (int)(((size_t)P * 3 * WPLANE + (size_t)P * 3 * GPLANE + 2 * D3_BM * 4) / 16);
+      u32x4* z = reinterpret_cast<u32x4*>(smem);
+      for (int i = tid; i < n16; i += D3_THREADS) z[i] = u32x4{0u, 0u, 0u, 0u};
     }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const int h = h0 + u * HSTEP;
+        if (h <= H) {
+          unsigned b1, b2, b3;
+          split3_trunc(col_ok ? v[j][u] : 0.f, b1, b2, b3);
+          char* dst = Wl + (size_t)(j * 3) * WPLANE + h * ROWB + 2 * g;
+          *reinterpret_cast<uint16_t*>(dst) = (uint16_t)(b1 >> 16);
+          *reinterpret_cast<uint16_t*>(dst + WPLANE) = (uint16_t)(b2 >> 16);
+          *reinterpret_cast<uint16_t*>(dst + 2 * WPLANE) = (uint16_t)(b3 >> 16);
+        }
+      }
   }
   __syncthreads();
 
