@@ -94,31 +94,27 @@ __global__ __launch_bounds__(512) void decoder_forward_kernel(
 
   // ---- strip weights (rows 0..H-1), biases (row H), zeros (rows H+1..HK-1) -> LDS, once ----
   {
-    const int c = tid & (BN - 1);
+    // (all of a thread's loads in flight together, from clamped -- always valid -- addresses: a
+    //  loop with one load per trip pays a global-memory round trip per weight row)
+    const int c = tid & (BN - 1), p0 = tid >> 6;
     const bool col_ok = c0 + c < F;
-    const int rows_per_pass = NW;                      // NW * 64 threads = NW rows of 64 genes
+    const int cc = min(c0 + c, F - 1);
+    constexpr int NV = HK / NW;                        // rows p0 + NW u < HK of this thread
+    float v[P][NV];
 #pragma unroll
-    for (int j = 0; j < P; ++j) {
-      const float* Wj = hp.W[j] + c0 + c;
-      float* dst = Ws + (size_t)j * HK * LD + c;
-      int pos = tid >> 6;
-      for (; pos + 7 * rows_per_pass < H; pos += 8 * rows_per_pass) {   // 8 loads in flight
-        float v[8];
+    for (int j = 0; j < P; ++j)
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          v[u] = col_ok ? Wj[(size_t)(pos + u * rows_per_pass) * F] : 0.f;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) dst[(size_t)(pos + u * rows_per_pass) * LD] = v[u];
+      for (int u = 0; u < NV; ++u) {
+        const int pos = p0 + u * NW;
+        v[j][u] = pos < H ? hp.W[j][(size_t)pos * F + cc] : hp.b[j][cc];
       }
-      for (; pos < HK; pos += rows_per_pass) {
-        float v = 0.f;
-        if (col_ok) {
-          if (pos < H) v = Wj[(size_t)pos * F];
-          else if (pos == H) v = hp.b[j][c0 + c];
-        }
-        dst[(size_t)pos * LD] = v;
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const int pos = p0 + u * NW;
+        Ws[((size_t)j * HK + pos) * LD + c] = (col_ok && pos <= H) ? v[j][u] : 0.f;
       }
-    }
   }
   __syncthreads();
 
