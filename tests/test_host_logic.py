@@ -415,3 +415,43 @@ def test_preprocessing_methods():
         np.log1p(training.values.toarray()))
     data.binarise()
     assert set(np.unique(data.binarised_values.toarray())) <= {0.0, 1.0}
+
+
+def test_minibatch_request_checks_and_fills_the_side_work_struct():
+    """``DeviceCSR.request`` (the fetch a step carries for the next one): buffer
+    checks on the host, and the ``scvae_side_work`` fields it fills -- no GPU
+    needed (a stand-in for the device matrix, CPU tensors)."""
+    import torch
+    from scvae_amd import _lib
+    from scvae_amd.minibatch import MinibatchRequest
+
+    class Matrix:
+        shape = (50, 12)
+        integer_counts = True
+        indptr = torch.zeros(51, dtype=torch.int64)
+        indices = torch.zeros(4, dtype=torch.int32)
+        values = torch.zeros(4)
+        row_lgamma1p = torch.zeros(50)
+
+    rows = torch.arange(8)
+    out = torch.zeros(8, 16, dtype=torch.uint16)
+    rc = torch.zeros(8)
+    request = MinibatchRequest(Matrix, rows, out, rc)
+    side = _lib.SideWork()
+    request.fill(side)
+    assert side.fetch_as_u16 == 1 and side.fetch_n == 8
+    assert side.fetch_features == 12 and side.fetch_ld == 16
+    assert side.fetch_out == out.data_ptr() and side.fetch_rows == rows.data_ptr()
+    assert side.fetch_row_values_out == rc.data_ptr()
+    assert side.adam_m is None and side.noise_out is None
+    fp32 = MinibatchRequest(Matrix, rows, torch.zeros(8, 12))
+    fp32.fill(side)
+    assert side.fetch_as_u16 == 0 and side.fetch_ld == 12
+    assert side.fetch_row_values_out is None
+    with pytest.raises(ValueError):      # too few rows in the buffer
+        MinibatchRequest(Matrix, rows, torch.zeros(4, 12))
+    with pytest.raises(ValueError):      # neither uint16 nor fp32
+        MinibatchRequest(Matrix, rows, torch.zeros(8, 12, dtype=torch.float64))
+    Matrix.integer_counts = False
+    with pytest.raises(ValueError):      # uint16 needs an integer count matrix
+        MinibatchRequest(Matrix, rows, out)
