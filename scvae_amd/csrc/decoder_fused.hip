@@ -507,25 +507,29 @@ __global__ __launch_bounds__(256) void dd_reduce_scalar_kernel(const float* __re
   }
 }
 
-// The same sums for the h-major slabs [strips][H][R] of decoder_head3_kernel (dd_part[z][h][r]):
-// a thread owns four consecutive rows of one h (16-byte loads along the rows) and writes them to
-// the row-major dd[r][h]; `split`: 16 thread groups per 16 columns, every 16th slab each (small
-// batches, as dd_reduce_split_kernel).
+// The same sums for the slabs of decoder_head3_kernel, dd_part[z][H / 4][R][4] (four consecutive
+// h of a row are one 16-byte piece): a thread owns one piece and writes it to the row-major
+// dd[r][h]; `split`: 16 thread groups per 16 pieces, every 16th slab each (small batches, as
+// dd_reduce_split_kernel).
 template <bool SPLIT>
-__global__ __launch_bounds__(256) void dd_reduce_t_kernel(const float* __restrict__ dd_part,
+__global__ __launch_bounds__(256) void dd_reduce_q_kernel(const float* __restrict__ dd_part,
                                                           int strips, int R, int H,
                                                           float* __restrict__ dd) {
   __shared__ float4 red[16][16];
-  const size_t n4 = (size_t)R * H / 4;       // R % 4 == 0
+  const size_t n4 = (size_t)((H + 3) >> 2) * R;
   const float4* p4 = reinterpret_cast<const float4*>(dd_part);
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   auto emit = [&](size_t i, float4 t) {
-    const int r4 = R / 4;
-    const int h = (int)(i / r4), r0 = (int)(i % r4) * 4;
-    dd[(size_t)r0 * H + h] = t.x;
-    dd[(size_t)(r0 + 1) * H + h] = t.y;
-    dd[(size_t)(r0 + 2) * H + h] = t.z;
-    dd[(size_t)(r0 + 3) * H + h] = t.w;
+    const int hq = (int)(i / R), r = (int)(i % R);
+    float* out = dd + (size_t)r * H + 4 * hq;
+    if ((H & 3) == 0) {
+      *reinterpret_cast<float4*>(out) = t;
+    } else {
+      out[0] = t.x;
+      if (4 * hq + 1 < H) out[1] = t.y;
+      if (4 * hq + 2 < H) out[2] = t.z;
+      if (4 * hq + 3 < H) out[3] = t.w;
+    }
   };
   if (SPLIT) {
     const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
@@ -580,17 +584,6 @@ __global__ __launch_bounds__(256) void dd_reduce_t_kernel(const float* __restric
     }
   }
 }
-__global__ __launch_bounds__(256) void dd_reduce_t_scalar_kernel(const float* __restrict__ dd_part,
-                                                                 int strips, int R, int H,
-                                                                 float* __restrict__ dd) {
-  const size_t n = (size_t)R * H;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (size_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int z = 0; z < strips; ++z) s += dd_part[(size_t)z * n + i];
-    dd[(i % R) * H + i / R] = s;
-  }
-}
 
 bool decoder_fused_supported(int H) { return H >= 2 && H <= 126 && (H % 2) == 0; }
 
@@ -599,7 +592,7 @@ size_t decoder_fused_workspace_floats(int rows, int H, int F, bool train) {
   const int bn = (train && decoder_fused3_supported(3, H)) ? decoder_fused3_strip_genes(3) : DF_BN;
   const size_t strips = (size_t)(F + bn - 1) / bn;
   size_t n = strips * rows;                       // ll_part
-  if (train) n += strips * (size_t)rows * H + 64; // dd_part (16-byte aligned start)
+  if (train) n += strips * (size_t)rows * ((H + 3) / 4 * 4) + 64; // dd_part (16-byte aligned start; H in quads)
   if (train) n += decoder_fused3_workspace_floats(rows) + 64;   // bf16 planes of d (bf16x9 kernel)
   return n + 64;
 }
@@ -718,7 +711,7 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
   float* ll_part = workspace;
   size_t off = ((size_t)strips * rows + 63) / 64 * 64;
   float* dd_part = workspace + off;
-  float* planes = dd_part + ((size_t)strips * rows * H + 63) / 64 * 64;
+  float* planes = dd_part + ((size_t)strips * rows * ((H + 3) / 4 * 4) + 63) / 64 * 64;
   int rc = launch_decoder<true>(s, kind, d, rows, H, hp, F, t, B, gw,
                                 (row_const || kind == LK_BERNOULLI) ? 0 : 1, ll_part, dd_part,
                                 planes);
@@ -729,22 +722,18 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
   SCVAE_LAUNCH_CHECK("ll_reduce_kernel");
   const size_t n = (size_t)rows * H;
   if (decoder_train_kernel(likelihood_heads(kind), H) == 3) {
-    // h-major slabs of decoder_head3_kernel
-    if (rows % 4 == 0 && n / 4 <= DD_SPLIT_MAX) {
-      hipLaunchKernelGGL(dd_reduce_t_kernel<true>, dim3((unsigned)((n / 4 + 15) / 16)), dim3(256),
-                         0, s, dd_part, strips, rows, H, dd);
-    } else if (rows % 4 == 0) {
-      size_t blocks = (n / 4 + 255) / 256;
-      if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(dd_reduce_t_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s,
-                         dd_part, strips, rows, H, dd);
+    // quad slabs of decoder_head3_kernel
+    const size_t n4 = (size_t)((H + 3) / 4) * rows;
+    if (n4 <= DD_SPLIT_MAX) {
+      hipLaunchKernelGGL(dd_reduce_q_kernel<true>, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0,
+                         s, dd_part, strips, rows, H, dd);
     } else {
-      size_t blocks = (n + 255) / 256;
+      size_t blocks = (n4 + 255) / 256;
       if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(dd_reduce_t_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+      hipLaunchKernelGGL(dd_reduce_q_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s,
                          dd_part, strips, rows, H, dd);
     }
-    SCVAE_LAUNCH_CHECK("dd_reduce_t_kernel");
+    SCVAE_LAUNCH_CHECK("dd_reduce_q_kernel");
     return 0;
   }
   if (n % 4 == 0 && n / 4 <= DD_SPLIT_MAX) {

@@ -493,17 +493,23 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
             acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[st & 1][b], af[st & 1][a], acc3, 0,
                                                            0, 0);
       }
-      // (computed transposed, dd^T[h, row], and stored to an h-major slab [strip][H][R]: a
-      //  store instruction then writes 32 consecutive rows of one h -- whole 128-byte lines --
-      //  where a row-major slab takes 100-float rows in partial lines.  Non-temporal: the slabs
-      //  are read exactly once, by dd_reduce_t_kernel)
+      // (computed transposed, dd^T[h, row]: a lane holds, for each of four groups, FOUR consecutive
+      //  h of one row.  The per-strip partial goes to a slab [strip][H / 4][R][4]: one 16-byte
+      //  store per group and lane, 32 consecutive rows of an h quad = 512 contiguous bytes per
+      //  half wave -- whole lines, a quarter of the store instructions of an [H][R] slab, which
+      //  in turn beat the row-major slab with its 100-float rows in partial lines.
+      //  Non-temporal: the slabs are read exactly once, by dd_reduce_q_kernel)
       const int row = m0 + 32 * hi2 + li;
       if (row < R) {
-        float* dst = dd_part + ((size_t)blockIdx.x * H + 32 * ht + 4 * kh) * R + row;
+        const int HQ = (H + 3) >> 2;
+        f32x4m* dst = reinterpret_cast<f32x4m*>(dd_part) +
+                      ((size_t)blockIdx.x * HQ + 8 * ht + kh) * R + row;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int ho = (i & 3) + 8 * (i >> 2);
-          if (32 * ht + 4 * kh + ho < H) __builtin_nontemporal_store(acc3[i], dst + (size_t)ho * R);
+        for (int c = 0; c < 4; ++c) {
+          if (4 * (8 * ht + 2 * c + kh) < H)
+            __builtin_nontemporal_store(
+                f32x4m{acc3[4 * c], acc3[4 * c + 1], acc3[4 * c + 2], acc3[4 * c + 3]},
+                dst + (size_t)2 * c * R);
         }
       }
     }
