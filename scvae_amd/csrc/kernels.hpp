@@ -223,10 +223,13 @@ struct TileBwdArgs {
                               // its chunk sums are formed from d_in (written to below.part_out)
 };
 
-// out[i] = sum_g slabs[g][i], fixed order; up to four (slabs, n, out) jobs in one launch
+// out[i] = sum_g slabs[g][i] (g < G), fixed order; up to eight (slabs, n, G, out) jobs in one
+// launch: the weight-gradient slabs of a backward pass are independent of the chain of layers, so
+// they are summed together at its end
+constexpr int TC_MAX_JOBS = 8;
 struct SlabJobs {
-  int n_jobs = 0, G = 0;
-  struct Job { const float* slabs; float* out; int n; } job[4];
+  int n_jobs = 0;
+  struct Job { const float* slabs; float* out; int n; int G; } job[TC_MAX_JOBS];
 };
 size_t tile_chain_part_floats(int rows);     // chunk statistics / sums of one layer
 size_t tile_chain_slab_floats(int rows);     // dW (+ db) slabs of one weight matrix

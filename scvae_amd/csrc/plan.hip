@@ -102,12 +102,12 @@ static size_t carve(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_
   float* mid_bar = b.floats(64);
   if (!dry) p->mid_bar = reinterpret_cast<unsigned*>(mid_bar);
   {   // tilechain.hip (sized by the decoder's rows, the larger count)
-    float* q[6];
+    float* q[4 + TC_MAX_JOBS];
     for (int i = 0; i < 4; ++i) q[i] = b.floats(tile_chain_part_floats((int)R));
-    for (int i = 4; i < 6; ++i) q[i] = b.floats(tile_chain_slab_floats((int)R));
+    for (int i = 0; i < TC_MAX_JOBS; ++i) q[4 + i] = b.floats(tile_chain_slab_floats((int)R));
     if (!dry) {
       p->tc_part[0] = q[0]; p->tc_part[1] = q[1]; p->tc_spart[0] = q[2]; p->tc_spart[1] = q[3];
-      p->tc_slab[0] = q[4]; p->tc_slab[1] = q[5];
+      for (int i = 0; i < TC_MAX_JOBS; ++i) p->tc_slab[i] = q[4 + i];
     }
   }
   float* mu_pre = b.floats(B * Lz);
@@ -948,6 +948,15 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     // sums are merged by its own kernel, which also leaves the chunk sums of the layer below
     auto bessel = [](int64_t n) { return (float)n / (float)(n > 1 ? n - 1 : 1); };
     int sp = 0;
+    // the dW / db slabs of the layers wait for ONE fixed-order reduce at the end of the pass (they
+    // are not on the chain's critical path: four launches fewer); slab buffer i <-> pending job i
+    SlabJobs pending;
+    auto flush = [&]() -> int {
+      if (pending.n_jobs == 0) return 0;
+      const int r = tile_slab_reduce(s, pending);
+      pending.n_jobs = 0;
+      return r;
+    };
     {
       Dense& top = p->dec.back();
       if ((rc = tile_backward_stats(s, dcur, tile_bn(p, top, nullptr, 0, 0, p->tc_spart[sp]), R,
@@ -960,18 +969,18 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       const int G = (rows + 63) / 64;
       q.rows = rows; q.inv_count = 1.f / (float)grows; q.bessel = bessel(grows);
       q.n_up = 1;
+      if (in && pending.n_jobs == TC_MAX_JOBS) { const int r = flush(); if (r) return r; }
+      float* slab = p->tc_slab[pending.n_jobs % TC_MAX_JOBS];
       q.up[0].g = dh_in; q.up[0].W = p->params + d.w; q.up[0].N = d.n_out;
-      q.up[0].dW_slab = p->tc_slab[0]; q.up[0].dA_out = dA_out;
+      q.up[0].dW_slab = slab; q.up[0].dA_out = dA_out;
       q.bn = tile_bn(p, d, p->tc_spart[sp], G, 64, nullptr);
       q.in = in; q.K = in ? d.n_in : 0; q.d_in = d_in;
       if (below) q.below = tile_bn(p, *below, nullptr, 0, 0, p->tc_spart[sp ^ 1]);
       int r = tile_backward(s, q);
       if (r || !in) return r;
-      SlabJobs j;
-      j.n_jobs = 1; j.G = G;
-      j.job[0] = {p->tc_slab[0], p->grads + d.w, d.n_in * d.n_out};
+      pending.job[pending.n_jobs++] = {slab, p->grads + d.w, d.n_in * d.n_out, G};
       sp ^= 1;
-      return tile_slab_reduce(s, j);
+      return 0;
     };
     for (int i = (int)p->dec.size() - 1; i >= 0; --i) {
       Dense& d = p->dec[i];
@@ -989,25 +998,28 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     {   // the two posterior heads: dW, db of both, dh of the last encoder layer and its chunk sums
       Dense& last = p->enc.back();
       const int G = (B + 63) / 64, K = last.n_out;
+      if (pending.n_jobs + 4 > TC_MAX_JOBS) { if ((rc = flush())) return rc; }
+      float* slab2[2] = {p->tc_slab[pending.n_jobs], p->tc_slab[pending.n_jobs + 1]};
       TileBwdArgs q;
       q.rows = B; q.n_up = 2;
       for (int u = 0; u < 2; ++u) {
         Dense& hd = u == 0 ? p->mu : p->ls;
         q.up[u].g = u == 0 ? p->dmu : p->dls;
         q.up[u].W = p->params + hd.w; q.up[u].N = L;
-        q.up[u].dW_slab = p->tc_slab[u];
-        q.up[u].db_slab = p->tc_slab[u] + (size_t)G * 128 * 128;
+        q.up[u].dW_slab = slab2[u];
+        q.up[u].db_slab = slab2[u] + (size_t)G * 128 * 128;
       }
       q.in = last.h; q.K = K; q.d_in = dh;
       q.below = tile_bn(p, last, nullptr, 0, 0, p->tc_spart[sp]);
       if ((rc = tile_backward(s, q))) return rc;
-      SlabJobs j;
-      j.n_jobs = 4; j.G = G;
-      j.job[0] = {p->tc_slab[0], p->grads + p->mu.w, K * L};
-      j.job[1] = {p->tc_slab[1], p->grads + p->ls.w, K * L};
-      j.job[2] = {q.up[0].db_slab, p->grads + p->mu.b, L};
-      j.job[3] = {q.up[1].db_slab, p->grads + p->ls.b, L};
-      if ((rc = tile_slab_reduce(s, j))) return rc;
+      // (jobs i and i + 1 own slab buffers i and i + 1; the two bias jobs ride in the same
+      //  buffers and only take job slots)
+      const int j0 = pending.n_jobs;
+      pending.job[j0] = {slab2[0], p->grads + p->mu.w, K * L, G};
+      pending.job[j0 + 1] = {slab2[1], p->grads + p->ls.w, K * L, G};
+      pending.job[j0 + 2] = {q.up[0].db_slab, p->grads + p->mu.b, L, G};
+      pending.job[j0 + 3] = {q.up[1].db_slab, p->grads + p->ls.b, L, G};
+      pending.n_jobs = j0 + 4;
     }
     for (int i = (int)p->enc.size() - 1; i >= 1; --i) {
       if ((rc = layer_backward(p->enc[i], &p->enc[i - 1], p->enc[i - 1].h, B, GB, dh, dh_alt,
@@ -1018,6 +1030,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     // the layer that sees x: its dA here, its weight gradient x^T dA on the count kernels
     Dense& d0 = p->enc[0];
     if ((rc = layer_backward(d0, nullptr, nullptr, B, GB, dh, nullptr, p->dbuf[2]))) return rc;
+    if ((rc = flush())) return rc;
     if ((rc = plan_side_fork(p, s, 2))) return rc;
     return plan_gemm(p, s, true, false, p->step_x, p->dbuf[2], nullptr, p->grads + d0.w, d0.n_in,
                      d0.n_out, B, F, d0.n_out, d0.n_out, ACT_NONE, false);

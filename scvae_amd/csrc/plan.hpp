@@ -163,7 +163,7 @@ struct scvae_plan {
   int use_tile_chain = 1;     // large VAE training steps: one launch per hidden layer and direction
   float* tc_part[2] = {nullptr, nullptr};    // tilechain.hip: chunk statistics (forward), ping-pong
   float* tc_spart[2] = {nullptr, nullptr};   // ... chunk sums of the batch-norm backward
-  float* tc_slab[2] = {nullptr, nullptr};    // ... dW / db slabs (two: the posterior heads)
+  float* tc_slab[TC_MAX_JOBS] = {};          // ... dW / db slabs of the layers of a backward pass
   const float* step_x = nullptr;   // this step's x and whether the caller vouches that it holds
   bool x_counts = false;           //  integers in [0, 65536) (scvae_step_args.x_counts)
   uint64_t drop_seed = 0;     // dropout: this step's mask seed (scvae_step_args.dropout_seed)

@@ -592,21 +592,24 @@ __global__ __launch_bounds__(256) void tile_slab_reduce_kernel(SlabJobs q) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += gridDim.x * blockDim.x) {
     float s0 = 0.f;
     int g = 0;
-    for (; g + 8 <= q.G; g += 8) {
+    for (; g + 8 <= jb.G; g += 8) {
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = jb.slabs[(size_t)(g + u) * jb.n + i];
 #pragma unroll
       for (int u = 0; u < 8; ++u) s0 += v[u];
     }
-    for (; g < q.G; ++g) s0 += jb.slabs[(size_t)g * jb.n + i];
+    for (; g < jb.G; ++g) s0 += jb.slabs[(size_t)g * jb.n + i];
     jb.out[i] = s0;
   }
 }
 int tile_slab_reduce(hipStream_t s, const SlabJobs& q) {
-  SCVAE_ARG(q.n_jobs >= 1 && q.n_jobs <= 4 && q.G >= 1);
+  SCVAE_ARG(q.n_jobs >= 1 && q.n_jobs <= TC_MAX_JOBS);
   int n_max = 0;
-  for (int j = 0; j < q.n_jobs; ++j) n_max = q.job[j].n > n_max ? q.job[j].n : n_max;
+  for (int j = 0; j < q.n_jobs; ++j) {
+    SCVAE_ARG(q.job[j].G >= 1 && q.job[j].slabs && q.job[j].out);
+    n_max = q.job[j].n > n_max ? q.job[j].n : n_max;
+  }
   hipLaunchKernelGGL(tile_slab_reduce_kernel, dim3((n_max + 255) / 256, q.n_jobs), dim3(256), 0, s,
                      q);
   SCVAE_LAUNCH_CHECK("tile_slab_reduce_kernel");
