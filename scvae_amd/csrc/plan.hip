@@ -1391,7 +1391,9 @@ int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
                 w->fetch_n > 0 && w->fetch_features > 0 && w->fetch_ld >= w->fetch_features &&
                 (w->fetch_as_u16 == 0 || w->fetch_as_u16 == 1) &&
                 w->fetch_out != (const void*)a->x && w->fetch_out != (const void*)a->t &&
-                w->fetch_out != (const void*)a->counts_u16);
+                w->fetch_out != (const void*)a->counts_u16 &&
+                (w->fetch_row_values_out == nullptr ||
+                 (w->fetch_row_values && w->fetch_row_values_out != a->row_const)));
     if (w->noise_out)
       SCVAE_ARG(w->noise_out != a->eps && w->noise_blocks >= 0 && w->noise_block_rows >= 0 &&
                 w->noise_cols > 0);
