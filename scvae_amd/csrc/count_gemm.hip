@@ -543,7 +543,15 @@ __global__ __launch_bounds__(256) void count_gemm_reduce_kernel(
        i += (size_t)gridDim.x * blockDim.x) {
     const int row = (int)(i / N), col = (int)(i % N);
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * total + i];
+    int z = 0;
+    for (; z + 8 <= splits; z += 8) {      // (eight slabs' loads in flight, summed in slab order)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = slabs[(size_t)(z + u) * total + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < splits; ++z) s += slabs[(size_t)z * total + i];
     for (int k = k_main; k < K; ++k) {
       const float xv = count_to_f32(mode == 0 ? X[(size_t)row * ldx + k] : X[(size_t)k * ldx + row]);
       s = fmaf(xv, other[(size_t)k * ld_other + col], s);

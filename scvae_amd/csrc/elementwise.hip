@@ -991,20 +991,54 @@ __global__ __launch_bounds__(1024) void bn_bwd_stats_finalize_kernel(
     s2[(size_t)g * N + c] = t2;
   }
   if (g != 0) return;   // (uniform per workgroup)
+  // (the loads of eight groups in flight at a time, from clamped addresses; the sums keep the
+  //  order of group_sums -- chunk lanes in sequence, groups in sequence: the same bits.  As a loop
+  //  over group_sums this tail was a dependent global-memory round trip per group: 18 us for the
+  //  GMVAE's 20 passes)
   if (dbeta != nullptr) {
     float total = t1;
-    for (int q = 1; q < G; ++q) {
-      float u1, u2;
-      group_sums(q, u1, u2);
-      total += u1;
+    const int cc = min(c, N - 1);
+    for (int q0 = 1; q0 < G; q0 += 8) {
+      float a1q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = min(q0 + u, G - 1);
+        float a1 = 0.f;
+        for (int z = zl; z < chunks; z += 16) a1 += partial[(((size_t)z * G + q) * 2) * N + cc];
+        a1q[u] = a1;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (q0 + u < G) {          // (uniform)
+          __syncthreads();
+          red1[zl][cl] = c < N ? a1q[u] : 0.f;
+          __syncthreads();
+          float u1 = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) u1 += red1[i][cl];
+          total += u1;
+        }
+      }
     }
     if (writer) dbeta[c] = total;
   }
   if (moving_mean != nullptr && writer) {
     float mm = moving_mean[c], mv = moving_var[c];
-    for (int q = 0; q < G; ++q) {
-      mm = bn_moving_update(mm, mean[(size_t)q * N + c]);
-      mv = bn_moving_update(mv, var[(size_t)q * N + c] * bessel);
+    for (int q0 = 0; q0 < G; q0 += 8) {
+      float mq[8], vq[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = min(q0 + u, G - 1);
+        mq[u] = mean[(size_t)q * N + c];
+        vq[u] = var[(size_t)q * N + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (q0 + u < G) {
+          mm = bn_moving_update(mm, mq[u]);
+          mv = bn_moving_update(mv, vq[u] * bessel);
+        }
+      }
     }
     moving_mean[c] = mm;
     moving_var[c] = mv;
