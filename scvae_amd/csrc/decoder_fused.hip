@@ -412,8 +412,17 @@ __global__ __launch_bounds__(1024) void ll_reduce_kernel(const float* __restrict
   const int rl = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int r = blockIdx.x * 16 + rl;
   float s = 0.f;
-  if (r < R)
-    for (int z = g; z < strips; z += 64) s += ll_part[(size_t)z * R + r];
+  if (r < R) {
+    int z = g;
+    for (; z + 7 * 64 < strips; z += 8 * 64) {     // (eight strips' loads in flight, same order)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ll_part[(size_t)(z + 64 * u) * R + r];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < strips; z += 64) s += ll_part[(size_t)z * R + r];
+  }
   red[g][rl] = s;
   __syncthreads();
   if (g == 0 && r < R) {

@@ -415,8 +415,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(
   const int il = threadIdx.x & 15, zl = threadIdx.x >> 4;
   const size_t i = (size_t)blockIdx.x * 16 + il;
   float s = 0.f;
-  if (i < total)
-    for (int z = zl; z < splits; z += 16) s += slabs[(size_t)z * total + i];
+  if (i < total) {
+    int z = zl;
+    for (; z + 7 * 16 < splits; z += 8 * 16) {     // (eight slabs' loads in flight, same order)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = slabs[(size_t)(z + 16 * u) * total + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < splits; z += 16) s += slabs[(size_t)z * total + i];
+  }
   red[zl][il] = s;
   __syncthreads();
   if (zl == 0 && i < total) {

@@ -325,6 +325,26 @@ __global__ __launch_bounds__(256) void gmvae_elbo_sums_kernel(const float* __res
   const float inv_s = 1.f / (float)S;
   for (int b = threadIdx.x; b < B; b += 256) {
     float rc = 0.f, kc = 0.f;
+    if (S == 1) {
+      // (the loads of eight passes in flight; same order of the sums as the general loop)
+      for (int k0 = 0; k0 < K; k0 += 8) {
+        float av[8], cv[8], yv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = min(k0 + u, K - 1);
+          av[u] = ll[(size_t)k * B + b];
+          cv[u] = klz[(size_t)k * B + b];
+          yv[u] = y[(size_t)b * K + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (k0 + u < K) {
+            rc += (0.f + av[u]) * inv_s * yv[u];
+            kc += (0.f + cv[u]) * inv_s * yv[u];
+          }
+        }
+      }
+    } else
     for (int k = 0; k < K; ++k) {
       float a = 0.f, c = 0.f;
       for (int s = 0; s < S; ++s) {
