@@ -147,6 +147,13 @@ int scvae_plan_set_count_gemm(scvae_plan* plan, int32_t enabled);
  * statistics / finalize / apply kernels (the two implementations are compared in
  * tests/test_gpu_vae_step.py) */
 int scvae_plan_set_bn_one_launch(scvae_plan* plan, int32_t enabled);
+/* Measurement aid (bench.py's `roofline`): HIP events around the likelihood-head TRAINING kernel
+ * proper -- the dominant kernel of a step; bf16x9 kernel only -- of the next n training steps, on
+ * the stream of each step.  scvae_plan_probe_heads(plan, n) arms n pairs (n = 0: off, events
+ * released); scvae_plan_probe_heads_ms waits (host) for the pairs recorded so far and writes their
+ * elapsed times in milliseconds to out[0 .. n), returning how many (or -1 / -2). */
+int scvae_plan_probe_heads(scvae_plan* plan, int32_t n);
+int scvae_plan_probe_heads_ms(scvae_plan* plan, float* out, int32_t n);
 /* Large VAE training minibatches (more than 128 rows, batch norm, no dropout, no data-parallel
  * hook): 1 (default) = every hidden layer and the posterior heads as ONE launch per layer and
  * direction -- a workgroup owns a 64-row tile, merges the batch-norm chunk statistics of the layer

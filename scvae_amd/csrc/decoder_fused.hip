@@ -640,6 +640,22 @@ int decoder_train_kernel(int P, int H) {
   return decoder_fused_variant(P, H);
 }
 
+// Measurement aid (scvae_plan_probe_heads): a pair of HIP events to record around the training
+// kernel proper -- after the pre-pass that cuts d into planes, before the reductions -- of the
+// next decoder_fused_train call on this host thread.
+static thread_local hipEvent_t g_probe[2] = {nullptr, nullptr};
+static thread_local bool g_probe_recorded = false;
+void decoder_fused_set_probe(hipEvent_t before, hipEvent_t after) {
+  g_probe[0] = before;
+  g_probe[1] = after;
+  g_probe_recorded = false;
+}
+hipEvent_t decoder_fused_probe(int which) {
+  if (which == 1 && g_probe[1]) g_probe_recorded = true;
+  return g_probe[which];
+}
+bool decoder_fused_probe_recorded() { return g_probe_recorded; }
+
 template <bool TRAIN>
 static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                           int F, Targets t, int B, const float* gw, int inline_lgamma,

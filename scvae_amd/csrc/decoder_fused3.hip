@@ -606,6 +606,7 @@ int decoder_fused3_launch(hipStream_t s, int kind, const float* d, int rows, int
     case 3: SCVAE_D3K(K_, 3); break;                                                              \
     default: SCVAE_D3K(K_, 4); break;                                                             \
   }
+  if (decoder_fused_probe(0)) SCVAE_HIP(hipEventRecord(decoder_fused_probe(0), s));
   switch (kind) {
     case LK_POISSON: SCVAE_D3(LK_POISSON); break;
     case LK_NB: SCVAE_D3(LK_NB); break;
@@ -617,6 +618,7 @@ int decoder_fused3_launch(hipStream_t s, int kind, const float* d, int rows, int
 #undef SCVAE_D3
 #undef SCVAE_D3K
   SCVAE_LAUNCH_CHECK("decoder_head3_kernel");
+  if (decoder_fused_probe(1)) SCVAE_HIP(hipEventRecord(decoder_fused_probe(1), s));
   return 0;
 }
 

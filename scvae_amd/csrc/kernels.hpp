@@ -287,6 +287,9 @@ size_t decoder_fused3_workspace_floats(int rows);
 int decoder_fused3_launch(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                           int F, Targets t, int B, const float* gw, int inline_lgamma,
                           float* ll_part, float* dd_part, float* planes);
+void decoder_fused_set_probe(hipEvent_t before, hipEvent_t after);   // (nullptr, nullptr): off
+hipEvent_t decoder_fused_probe(int which);
+bool decoder_fused_probe_recorded();   // both events of the pair went into a stream
 int decoder_head_arith();              // 0: fp32 MFMA, 1: bf16x9 where decoder_fused3 applies
 void set_decoder_head_arith(int mode);
 int decoder_train_kernel(int P, int H);   // 1 / 2: the fp32 schedules, 3: decoder_head3_kernel

@@ -1097,6 +1097,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
 
 // =============================== C ABI =====================================
 scvae_plan::~scvae_plan() {
+  for (hipEvent_t e : probe_events) (void)hipEventDestroy(e);
   if (side_stream) {
     (void)hipStreamSynchronize(side_stream);
     (void)hipStreamDestroy(side_stream);
@@ -1218,6 +1219,30 @@ int scvae_plan_set_fused(scvae_plan* p, int32_t enabled) {
   return 0;
 }
 
+int scvae_plan_probe_heads(scvae_plan* p, int32_t n) {
+  SCVAE_ARG(p && n >= 0 && n <= 4096);
+  for (hipEvent_t e : p->probe_events) (void)hipEventDestroy(e);
+  p->probe_events.clear();
+  p->probe_next = 0;
+  for (int i = 0; i < 2 * n; ++i) {
+    hipEvent_t e = nullptr;
+    SCVAE_HIP(hipEventCreate(&e));
+    p->probe_events.push_back(e);
+  }
+  return 0;
+}
+int scvae_plan_probe_heads_ms(scvae_plan* p, float* out, int32_t n) {
+  SCVAE_ARG(p && out && n >= 0);
+  int got = 0;
+  for (int i = 0; i < p->probe_next && i < n; ++i) {
+    SCVAE_HIP(hipEventSynchronize(p->probe_events[2 * (size_t)i + 1]));
+    float ms = 0.f;
+    SCVAE_HIP(hipEventElapsedTime(&ms, p->probe_events[2 * (size_t)i],
+                                  p->probe_events[2 * (size_t)i + 1]));
+    out[got++] = ms;
+  }
+  return got;
+}
 int scvae_plan_set_tile_chain(scvae_plan* p, int32_t enabled) {
   SCVAE_ARG(p);
   p->use_tile_chain = enabled ? 1 : 0;
@@ -1400,11 +1425,19 @@ int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
     p->side = w;
   }
   int rc;
+  const bool probing = a->training && 2 * (size_t)p->probe_next + 1 < p->probe_events.size();
+  if (probing)
+    scvae::decoder_fused_set_probe(p->probe_events[2 * (size_t)p->probe_next],
+                                   p->probe_events[2 * (size_t)p->probe_next + 1]);
   if (p->cfg.model_type == SCVAE_MODEL_GMVAE) {
     SCVAE_ARG(!a->deterministic_z);
     rc = scvae::gmvae_step(p, a, (hipStream_t)stream);
   } else {
     rc = scvae::vae_step(p, a, (hipStream_t)stream);
+  }
+  if (probing) {
+    if (scvae::decoder_fused_probe_recorded()) ++p->probe_next;
+    scvae::decoder_fused_set_probe(nullptr, nullptr);
   }
   if (rc) {
     // a failed step: the caller's stream still waits for what the second stream was given

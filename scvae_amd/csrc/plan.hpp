@@ -158,6 +158,10 @@ struct scvae_plan {
   bool side_forked = false;
   bool side_jobs_done = false;  // fetch + noise issued
   size_t side_adam_from = 0;    // parameters [side_adam_from, n) were updated on the second stream
+  // scvae_plan_probe_heads: event pairs around the likelihood-head training kernel of the next
+  // steps (measurement aid of bench.py)
+  std::vector<hipEvent_t> probe_events;
+  int probe_next = 0;
   ~scvae_plan();
   int use_mid_chain = 1;      // small VAE steps: hidden layers + heads + latent in two launches
   int use_tile_chain = 1;     // large VAE training steps: one launch per hidden layer and direction

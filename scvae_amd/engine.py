@@ -315,6 +315,23 @@ class Engine:
         _lib.check(self.lib.scvae_plan_set_tile_chain(
             self.handle, 1 if enabled else 0), "scvae_plan_set_tile_chain")
 
+    def probe_heads(self, n):
+        """Arm HIP event pairs around the likelihood-head training kernel of
+        the next ``n`` training steps (0: off) -- ``bench.py``'s roofline."""
+        _lib.check(self.lib.scvae_plan_probe_heads(self.handle, int(n)),
+                   "scvae_plan_probe_heads")
+        self._probe_n = int(n)
+
+    def probe_heads_ms(self):
+        """Durations (ms) of the probed kernel launches recorded so far (waits
+        for them on the host)."""
+        n = getattr(self, "_probe_n", 0)
+        out = (ctypes.c_float * max(n, 1))()
+        got = self.lib.scvae_plan_probe_heads_ms(self.handle, out, n)
+        if got < 0:
+            _lib.check(got, "scvae_plan_probe_heads_ms")
+        return [float(out[i]) for i in range(got)]
+
     def set_bn_one_launch(self, enabled, always=False):
         """One-launch batch norm for single-group layers: for minibatches of
         up to 1024 rows (default), whenever it applies (``always``), or never
