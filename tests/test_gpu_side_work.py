@@ -140,3 +140,27 @@ def test_second_stream_variant_in_a_subprocess(cuda_device):
              "carried_work or evaluation_step"], env=env, capture_output=True,
             text=True)
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_head_kernel_probe_times_the_training_steps(cuda_device):
+    """``scvae_plan_probe_heads``: one HIP-event pair per training step around
+    the likelihood-head kernel (what ``bench.py`` reports as ``roofline``):
+    as many positive durations as armed steps ran, none for evaluation steps,
+    nothing once disarmed."""
+    B, F, L = 256, 700, 6
+    matrix = _matrix(B, F, 17, cuda_device)
+    eng = _engine(cuda_device, F, L, (32, 32), "negative binomial", "VAE")
+    x = matrix.gather_dense(torch.arange(B, device=cuda_device))
+    eps = torch.randn(1, B, L, device=cuda_device)
+    eng.probe_heads(5)
+    for i in range(3):
+        eng.step(x, x, eps=eps, training=True)
+    eng.step(x, x, eps=eps, training=False)          # not probed
+    times = eng.probe_heads_ms()
+    assert len(times) == 3 and all(0.0 < t < 50.0 for t in times)
+    for i in range(4):                               # only two pairs are left
+        eng.step(x, x, eps=eps, training=True)
+    assert len(eng.probe_heads_ms()) == 5
+    eng.probe_heads(0)
+    eng.step(x, x, eps=eps, training=True)
+    assert eng.probe_heads_ms() == []
