@@ -1500,6 +1500,106 @@ int adam_clip_step(hipStream_t stream, float* theta, float* grad, float* m, floa
   return 0;
 }
 
+// ================================ Philox ===================================
+
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+// thread per (row, group of 4 columns): counter = (row_lo, row_hi, col_group, stream_id),
+// key = seed.  u = ((x >> 8) + 0.5) * 2^-24; Box-Muller on (u0,u1) and (u2,u3).
+// Rows may come in blocks (the stacked passes of a sharded minibatch): row r of the buffer is
+// row `(r / block_rows) * block_stride + row_offset + r % block_rows` of the noise field.
+// (the arguments of one noise fill; also handed to the minibatch kernels, whose trailing
+//  workgroups then draw the noise of the same step: one launch for fetch + noise)
+struct NoiseJob {
+  float* out = nullptr;     // nullptr: none
+  int64_t rows = 0;
+  int cols = 0;
+  int64_t row_offset = 0, block_rows = 1, block_stride = 0;
+  uint32_t seed_lo = 0, seed_hi = 0, stream_id = 0;
+};
+__device__ __forceinline__ void philox_fill(const NoiseJob& q, int64_t first, int64_t stride) {
+  float* __restrict__ out = q.out;
+  const int cols = q.cols;
+  const int64_t rows = q.rows, row_offset = q.row_offset, block_rows = q.block_rows,
+                block_stride = q.block_stride;
+  const uint32_t seed_lo = q.seed_lo, seed_hi = q.seed_hi, stream_id = q.stream_id;
+  const int groups = (cols + 3) / 4;
+  const int64_t total = rows * groups;
+  for (int64_t i = first; i < total; i += stride) {
+    const int64_t row = i / groups;
+    const int cg = (int)(i % groups);
+    const uint64_t grow =
+        (uint64_t)((row / block_rows) * block_stride + row_offset + row % block_rows);
+    uint32_t c[4] = {(uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)cg, stream_id};
+    uint32_t k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    float u[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[j] = ((float)(c[j] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    float n[4];
+    const float r0 = sqrtf(-2.f * logf(u[0])), r1 = sqrtf(-2.f * logf(u[2]));
+    const float th0 = 6.283185307179586f * u[1], th1 = 6.283185307179586f * u[3];
+    n[0] = r0 * cosf(th0); n[1] = r0 * sinf(th0);
+    n[2] = r1 * cosf(th1); n[3] = r1 * sinf(th1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = cg * 4 + j;
+      if (col < cols) out[row * cols + col] = n[j];
+    }
+  }
+}
+__global__ __launch_bounds__(256) void philox_normal_kernel(NoiseJob q) {
+  philox_fill(q, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+// workgroups of 1024 threads a fetch kernel appends for the noise of `q` (0: none)
+static int noise_blocks_1024(const NoiseJob& q) {
+  if (!q.out || q.rows == 0) return 0;
+  const int64_t total = q.rows * ((q.cols + 3) / 4);
+  int64_t blocks = (total + 1023) / 1024;
+  return (int)(blocks > 1024 ? 1024 : blocks);
+}
+static NoiseJob noise_job(float* out, int64_t rows, int cols, int64_t row_offset, uint64_t seed,
+                          uint64_t stream_id, int64_t block_rows, int64_t block_stride) {
+  NoiseJob q;
+  if (block_rows <= 0) { block_rows = rows > 0 ? rows : 1; block_stride = 0; }   // one block
+  q.out = out; q.rows = rows; q.cols = cols; q.row_offset = row_offset;
+  q.block_rows = block_rows; q.block_stride = block_stride;
+  q.seed_lo = (uint32_t)seed;
+  // the high half of the 64-bit stream id goes into the key (callers use the high bits as
+  // domain separators: evaluation passes, model.sample())
+  q.seed_hi = (uint32_t)(seed >> 32) ^ (uint32_t)(stream_id >> 32);
+  q.stream_id = (uint32_t)stream_id;
+  return q;
+}
+
+int philox_normal(hipStream_t stream, float* out, int64_t rows, int cols, int64_t row_offset,
+                  uint64_t seed, uint64_t stream_id, int64_t block_rows, int64_t block_stride) {
+  SCVAE_ARG(out && rows >= 0 && cols > 0);
+  if (rows == 0) return 0;
+  SCVAE_ARG(block_rows <= 0 || block_stride >= 0);
+  const NoiseJob q = noise_job(out, rows, cols, row_offset, seed, stream_id, block_rows,
+                               block_stride);
+  const int64_t total = rows * ((cols + 3) / 4);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, q);
+  SCVAE_LAUNCH_CHECK("philox_normal_kernel");
+  return 0;
+}
+
 // ============================== CSR minibatch ==============================
 
 // One workgroup per gathered row writes the whole dense row in one pass: float4 zero fill of
@@ -1543,8 +1643,13 @@ __global__ __launch_bounds__(1024) void csr_densify_lds_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
     const float* __restrict__ values, const int64_t* __restrict__ rows, int F,
     float* __restrict__ out, int ldo, const float* __restrict__ row_values,
-    float* __restrict__ row_values_out) {
+    float* __restrict__ row_values_out, int B, NoiseJob noise) {
   extern __shared__ __attribute__((aligned(16))) float row[];
+  if ((int)blockIdx.x >= B) {       // (the trailing workgroups: this step's noise)
+    philox_fill(noise, (int64_t)(blockIdx.x - B) * 1024 + threadIdx.x,
+                (int64_t)(gridDim.x - B) * 1024);
+    return;
+  }
   const int b = blockIdx.x;
   const int64_t r = rows[b];
   // (a per-row value of the matrix gathered on the way: the lgamma term of the likelihoods)
@@ -1576,22 +1681,31 @@ __global__ __launch_bounds__(1024) void csr_densify_lds_kernel(
 
 int csr_densify(hipStream_t stream, const int64_t* indptr, const int32_t* indices,
                 const float* values, const int64_t* rows, int B, int F, float* out, int ldo,
-                const float* row_values, float* row_values_out) {
+                const float* row_values, float* row_values_out, const NoiseRequest* nr) {
   SCVAE_ARG(indptr && indices && values && rows && out && F > 0 && ldo >= F);
   SCVAE_ARG(row_values_out == nullptr || row_values != nullptr);
-  if (B == 0) return 0;
+  SCVAE_ARG(!nr || !nr->out || (nr->rows >= 0 && nr->cols > 0));
+  if (B == 0) return nr && nr->out ? philox_normal(stream, nr->out, nr->rows, nr->cols, nr->row_offset, nr->seed, nr->stream_id, nr->block_rows, nr->block_stride) : 0;
+  const NoiseJob noise = (nr && nr->out)
+                             ? noise_job(nr->out, nr->rows, nr->cols, nr->row_offset, nr->seed,
+                                         nr->stream_id, nr->block_rows, nr->block_stride)
+                             : NoiseJob();
   const size_t lds = ((size_t)F + 3) / 4 * 16;
   if (lds <= 152 * 1024) {
     SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(csr_densify_lds_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(csr_densify_lds_kernel, dim3(B), dim3(1024), lds, stream, indptr, indices,
-                       values, rows, F, out, ldo, row_values, row_values_out);
+    hipLaunchKernelGGL(csr_densify_lds_kernel, dim3(B + noise_blocks_1024(noise)), dim3(1024), lds,
+                       stream, indptr, indices, values, rows, F, out, ldo, row_values,
+                       row_values_out, B, noise);
     SCVAE_LAUNCH_CHECK("csr_densify_lds_kernel");
     return 0;
   }
   hipLaunchKernelGGL(csr_densify_kernel, dim3(B), dim3(256), 0, stream, indptr, indices, values,
                      rows, F, out, ldo, row_values, row_values_out);
   SCVAE_LAUNCH_CHECK("csr_densify_kernel");
+  if (noise.out)
+    return philox_normal(stream, nr->out, nr->rows, nr->cols, nr->row_offset, nr->seed,
+                         nr->stream_id, nr->block_rows, nr->block_stride);
   return 0;
 }
 
@@ -1603,8 +1717,13 @@ __global__ __launch_bounds__(1024) void csr_densify_u16_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
     const float* __restrict__ values, const int64_t* __restrict__ rows, int F,
     uint16_t* __restrict__ out, int ldo, const float* __restrict__ row_values,
-    float* __restrict__ row_values_out) {
+    float* __restrict__ row_values_out, int B, NoiseJob noise) {
   extern __shared__ __attribute__((aligned(16))) uint16_t row16[];
+  if ((int)blockIdx.x >= B) {       // (the trailing workgroups: this step's noise)
+    philox_fill(noise, (int64_t)(blockIdx.x - B) * 1024 + threadIdx.x,
+                (int64_t)(gridDim.x - B) * 1024);
+    return;
+  }
   const int b = blockIdx.x;
   const int64_t r = rows[b];
   if (row_values_out != nullptr && threadIdx.x == 0) row_values_out[b] = row_values[r];
@@ -1633,16 +1752,23 @@ bool csr_densify_u16_supported(int F, int ldo) {
 
 int csr_densify_u16(hipStream_t stream, const int64_t* indptr, const int32_t* indices,
                     const float* values, const int64_t* rows, int B, int F, uint16_t* out,
-                    int ldo, const float* row_values, float* row_values_out) {
+                    int ldo, const float* row_values, float* row_values_out,
+                    const NoiseRequest* nr) {
   SCVAE_ARG(indptr && indices && values && rows && out);
   SCVAE_ARG(row_values_out == nullptr || row_values != nullptr);
   SCVAE_ARG(csr_densify_u16_supported(F, ldo) && ((uintptr_t)out & 15) == 0);
-  if (B == 0) return 0;
+  SCVAE_ARG(!nr || !nr->out || (nr->rows >= 0 && nr->cols > 0));
+  if (B == 0) return nr && nr->out ? philox_normal(stream, nr->out, nr->rows, nr->cols, nr->row_offset, nr->seed, nr->stream_id, nr->block_rows, nr->block_stride) : 0;
+  const NoiseJob noise = (nr && nr->out)
+                             ? noise_job(nr->out, nr->rows, nr->cols, nr->row_offset, nr->seed,
+                                         nr->stream_id, nr->block_rows, nr->block_stride)
+                             : NoiseJob();
   const size_t lds = (size_t)ldo * 2;
   SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(csr_densify_u16_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(csr_densify_u16_kernel, dim3(B), dim3(1024), lds, stream, indptr, indices,
-                     values, rows, F, out, ldo, row_values, row_values_out);
+  hipLaunchKernelGGL(csr_densify_u16_kernel, dim3(B + noise_blocks_1024(noise)), dim3(1024), lds,
+                     stream, indptr, indices, values, rows, F, out, ldo, row_values,
+                     row_values_out, B, noise);
   SCVAE_LAUNCH_CHECK("csr_densify_u16_kernel");
   return 0;
 }
@@ -1685,77 +1811,6 @@ int gather_rows_f32(hipStream_t stream, const float* src, const int64_t* rows, i
   return 0;
 }
 
-// ================================ Philox ===================================
-
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-  const uint32_t n1 = (uint32_t)p1;
-  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-  const uint32_t n3 = (uint32_t)p0;
-  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-
-// thread per (row, group of 4 columns): counter = (row_lo, row_hi, col_group, stream_id),
-// key = seed.  u = ((x >> 8) + 0.5) * 2^-24; Box-Muller on (u0,u1) and (u2,u3).
-// Rows may come in blocks (the stacked passes of a sharded minibatch): row r of the buffer is
-// row `(r / block_rows) * block_stride + row_offset + r % block_rows` of the noise field.
-__global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, int64_t rows,
-                                                            int cols, int64_t row_offset,
-                                                            int64_t block_rows,
-                                                            int64_t block_stride,
-                                                            uint32_t seed_lo, uint32_t seed_hi,
-                                                            uint32_t stream_id) {
-  const int groups = (cols + 3) / 4;
-  const int64_t total = rows * groups;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i / groups;
-    const int cg = (int)(i % groups);
-    const uint64_t grow =
-        (uint64_t)((row / block_rows) * block_stride + row_offset + row % block_rows);
-    uint32_t c[4] = {(uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)cg, stream_id};
-    uint32_t k0 = seed_lo, k1 = seed_hi;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-      philox_round(c, k0, k1);
-      k0 += 0x9E3779B9u;
-      k1 += 0xBB67AE85u;
-    }
-    float u[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) u[j] = ((float)(c[j] >> 8) + 0.5f) * 5.9604644775390625e-8f;
-    float n[4];
-    const float r0 = sqrtf(-2.f * logf(u[0])), r1 = sqrtf(-2.f * logf(u[2]));
-    const float th0 = 6.283185307179586f * u[1], th1 = 6.283185307179586f * u[3];
-    n[0] = r0 * cosf(th0); n[1] = r0 * sinf(th0);
-    n[2] = r1 * cosf(th1); n[3] = r1 * sinf(th1);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = cg * 4 + j;
-      if (col < cols) out[row * cols + col] = n[j];
-    }
-  }
-}
-
-int philox_normal(hipStream_t stream, float* out, int64_t rows, int cols, int64_t row_offset,
-                  uint64_t seed, uint64_t stream_id, int64_t block_rows, int64_t block_stride) {
-  SCVAE_ARG(out && rows >= 0 && cols > 0);
-  if (rows == 0) return 0;
-  if (block_rows <= 0) { block_rows = rows; block_stride = 0; }   // one block: rows as they are
-  SCVAE_ARG(block_stride >= 0);
-  const int64_t total = rows * ((cols + 3) / 4);
-  int64_t blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, out, rows,
-                     cols, row_offset, block_rows, block_stride, (uint32_t)seed,
-                     // the high half of the 64-bit stream id goes into the key (callers use the
-                     // high bits as domain separators: evaluation passes, model.sample())
-                     (uint32_t)(seed >> 32) ^ (uint32_t)(stream_id >> 32), (uint32_t)stream_id);
-  SCVAE_LAUNCH_CHECK("philox_normal_kernel");
-  return 0;
-}
 
 // ================================ dropout ==================================
 

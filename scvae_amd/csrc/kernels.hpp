@@ -343,14 +343,26 @@ int prior_stats(hipStream_t s, const float* Wpm, const float* bpm, const float* 
 int adam_clip_step(hipStream_t stream, float* theta, float* grad, float* m, float* v, size_t n,
                    float grad_scale, float lr_t, float beta1, float beta2, float epsilon);
 
+// the noise of the same step, drawn by trailing workgroups of the minibatch launch (the arguments
+// of philox_normal below; a step that carries both for the next one: scvae_side_work)
+struct NoiseRequest {
+  float* out = nullptr;
+  int64_t rows = 0;
+  int cols = 0;
+  int64_t row_offset = 0;
+  uint64_t seed = 0, stream_id = 0;
+  int64_t block_rows = 0, block_stride = 0;
+};
 // CSR row gather + densify (va:985-998)
 int csr_densify(hipStream_t stream, const int64_t* indptr, const int32_t* indices,
                 const float* values, const int64_t* rows, int B, int F, float* out, int ldo,
-                const float* row_values = nullptr, float* row_values_out = nullptr);
+                const float* row_values = nullptr, float* row_values_out = nullptr,
+                const NoiseRequest* noise = nullptr);
 bool csr_densify_u16_supported(int F, int ldo);
 int csr_densify_u16(hipStream_t stream, const int64_t* indptr, const int32_t* indices,
                     const float* values, const int64_t* rows, int B, int F, uint16_t* out,
-                    int ldo, const float* row_values = nullptr, float* row_values_out = nullptr);
+                    int ldo, const float* row_values = nullptr, float* row_values_out = nullptr,
+                    const NoiseRequest* noise = nullptr);
 int csr_row_lgamma1p(hipStream_t stream, const int64_t* indptr, const float* values, int64_t n_rows,
                      float* out);
 int gather_rows_f32(hipStream_t stream, const float* src, const int64_t* rows, int B, float* out);

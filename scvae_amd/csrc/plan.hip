@@ -581,24 +581,30 @@ static MidChainArgs mid_chain_args(const scvae_plan* p, const scvae_step_args* a
 // SCVAE_SIDE_STREAM=1 turns the fork on (points 1 / 2, SCVAE_SIDE_ADAM_AT = 1 | 2) for A/B runs.
 static int side_jobs(const scvae_side_work* w, hipStream_t st) {
   int rc;
+  // (fetch + noise of the same next step: one launch -- the noise is drawn by trailing
+  //  workgroups of the minibatch kernel)
+  NoiseRequest nr;
+  if (w->noise_out) {
+    nr.out = w->noise_out; nr.rows = w->noise_blocks * w->noise_block_rows;
+    nr.cols = (int)w->noise_cols; nr.row_offset = w->noise_row_offset; nr.seed = w->noise_seed;
+    nr.stream_id = w->noise_stream_id; nr.block_rows = w->noise_block_rows;
+    nr.block_stride = w->noise_block_stride;
+  }
   if (w->fetch_out) {
     if (w->fetch_as_u16)
       rc = csr_densify_u16(st, w->fetch_indptr, w->fetch_indices, w->fetch_values, w->fetch_rows,
                            (int)w->fetch_n, (int)w->fetch_features,
                            static_cast<uint16_t*>(w->fetch_out), (int)w->fetch_ld,
-                           w->fetch_row_values, w->fetch_row_values_out);
+                           w->fetch_row_values, w->fetch_row_values_out, &nr);
     else
       rc = csr_densify(st, w->fetch_indptr, w->fetch_indices, w->fetch_values, w->fetch_rows,
                        (int)w->fetch_n, (int)w->fetch_features, static_cast<float*>(w->fetch_out),
-                       (int)w->fetch_ld, w->fetch_row_values, w->fetch_row_values_out);
-    if (rc) return rc;
+                       (int)w->fetch_ld, w->fetch_row_values, w->fetch_row_values_out, &nr);
+    return rc;
   }
-  if (w->noise_out) {
-    if ((rc = philox_normal(st, w->noise_out, w->noise_blocks * w->noise_block_rows,
-                            (int)w->noise_cols, w->noise_row_offset, w->noise_seed,
-                            w->noise_stream_id, w->noise_block_rows, w->noise_block_stride)))
-      return rc;
-  }
+  if (w->noise_out)
+    return philox_normal(st, nr.out, nr.rows, nr.cols, nr.row_offset, nr.seed, nr.stream_id,
+                         nr.block_rows, nr.block_stride);
   return 0;
 }
 static int side_adam(scvae_plan* p, hipStream_t st, size_t begin, size_t end) {
