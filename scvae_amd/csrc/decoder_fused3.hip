@@ -53,6 +53,22 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
+// A/B switch (tools/ab_variants.sh): 1 = the global fragment loads of d stay where the source
+// issues them -- one k-step ahead -- (a scheduling barrier that only vector-memory reads may not
+// cross); 0 = the compiler sinks them to just before their use to save registers, and the wave
+// then waits for an L2 round trip in every k-step
+#ifndef D3_PIN_LOADS
+#define D3_PIN_LOADS 1
+#endif
+// how many k-steps ahead the fragments of d are requested (1, or 2: 24 more VGPRs and no faster)
+#ifndef D3_AHEAD
+#define D3_AHEAD 1
+#endif
+constexpr int D3_NB = D3_AHEAD + 1;      // fragment buffers
+__device__ __forceinline__ void d3_pin_loads() {
+  if (D3_PIN_LOADS) __builtin_amdgcn_sched_barrier(0x7C6);   // VMEM reads stay above, MFMAs below; the rest may cross
+}
+
 constexpr int D3_THREADS = 512;
 constexpr int D3_BM = 64;           // rows per tile
 constexpr int D3_KP = 128;          // padded hidden width of the planes of d
@@ -316,8 +332,9 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) dst[pl] = global_b128(dbase + pl * dplane);
   };
-  bf16x8 bfr0[3];
+  bf16x8 bfr0[3], bfr1[3];
   load_d1(0, 0, bfr0);
+  if (D3_AHEAD > 1 && KS1 > 1) load_d1(0, 1, bfr1);
 
   for (int tile = 0; tile < n_tiles; ++tile) {
     const int m0 = tile * D3_BM;
@@ -331,7 +348,7 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
       for (int sb = 0; sb < NSB; ++sb) acc1[j][sb] = f32x4m{0.f, 0.f, 0.f, 0.f};
     {
       // W fragments (transpose reads) and d fragments one k-step ahead of the MFMAs
-      bf16x8 afr[2][P][NSB][3], bfr[2][3];
+      bf16x8 afr[2][P][NSB][3], bfr[D3_NB][3];
       auto load_w = [&](int ks, bf16x8 (&dst)[P][NSB][3]) {
 #pragma unroll
         for (int j = 0; j < P; ++j)
@@ -344,13 +361,18 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
       };
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) bfr[0][pl] = bfr0[pl];
+      if (D3_AHEAD > 1 && KS1 > 1) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bfr[1][pl] = bfr1[pl];
+      }
       load_w(0, afr[0]);
 #pragma unroll
       for (int ks = 0; ks < KS1; ++ks) {
-        if (ks + 1 < KS1) {
-          load_d1(m0, ks + 1, bfr[(ks + 1) & 1]);
-          load_w(ks + 1, afr[(ks + 1) & 1]);
+        if (ks + D3_AHEAD < KS1) {
+          load_d1(m0, ks + D3_AHEAD, bfr[(ks + D3_AHEAD) % D3_NB]);
+          d3_pin_loads();
         }
+        if (ks + 1 < KS1) load_w(ks + 1, afr[(ks + 1) & 1]);
         // small terms first; the accumulators (head x gene block) are independent chains
 #pragma unroll
         for (int a = 2; a >= 0; --a)
@@ -361,7 +383,7 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
 #pragma unroll
               for (int sb = 0; sb < NSB; ++sb)
                 acc1[j][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    afr[ks & 1][j][sb][a], bfr[ks & 1][b], acc1[j][sb], 0, 0, 0);
+                    afr[ks & 1][j][sb][a], bfr[ks % D3_NB][b], acc1[j][sb], 0, 0, 0);
       }
     }
     // ---- likelihood of this lane's NSB x 4 elements: row 16 rq + i16, genes
@@ -464,8 +486,11 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) dst[pl] = global_b128(tb + pl * dplane);
     };
-    bf16x8 a2[2][3];
-    if (ht < n_ht2) load_a2(0, a2[0]);
+    bf16x8 a2[D3_NB][3];
+    if (ht < n_ht2) {
+      load_a2(0, a2[0]);
+      if (D3_AHEAD > 1 && KS2 > 1) load_a2(1, a2[1]);
+    }
     // next tile's targets
     if (tile + 1 < n_tiles) nxt = load_t(m0 + D3_BM);
     if (ht < n_ht3) {
@@ -514,7 +539,10 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
       }
     }
     // the next tile's d fragments of GEMM1: in flight under GEMM2 and the barrier
-    if (tile + 1 < n_tiles) load_d1(m0 + D3_BM, 0, bfr0);
+    if (tile + 1 < n_tiles) {
+      load_d1(m0 + D3_BM, 0, bfr0);
+      if (D3_AHEAD > 1 && KS1 > 1) load_d1(m0 + D3_BM, 1, bfr1);
+    }
     if (ht < n_ht2) {
       // ---- GEMM2: dW_j[h, gene] += sum_row d[row, h] G_j[row, gene] ----
       bf16x8 bf[2][3];
@@ -528,13 +556,16 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
 #pragma unroll
       for (int st = 0; st < KS2 * P; ++st) {
         if (st + 1 < KS2 * P) load_2(st + 1, bf[(st + 1) & 1]);
-        if (st % P == 0 && st / P + 1 < KS2) load_a2(st / P + 1, a2[(st / P + 1) & 1]);
+        if (st % P == 0 && st / P + D3_AHEAD < KS2) {
+          load_a2(st / P + D3_AHEAD, a2[(st / P + D3_AHEAD) % D3_NB]);
+          d3_pin_loads();
+        }
         const int ks = st / P, j = st % P;
 #pragma unroll
         for (int a = 2; a >= 0; --a)
 #pragma unroll
           for (int b = 2; b >= 0; --b)
-            accW[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks & 1][a], bf[st & 1][b], accW[j],
+            accW[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks % D3_NB][a], bf[st & 1][b], accW[j],
                                                               0, 0, 0);
       }
     }
