@@ -197,7 +197,11 @@ __device__ __forceinline__ float select_n(const float (&v)[4], const IndexMasks3
   return cnd3(cnd3(v[0], v[1], k.m[0]), cnd3(v[2], v[3], k.m[0]), k.m[1]);
 }
 
-template <int KIND, int KS1>
+// U16 (compile time): the targets are the uint16 minibatch.  As a run-time flag the two load
+// paths met in a branch, the compiler waited for the load INSIDE each arm, and the request for the
+// next tile's targets -- meant to travel under a whole phase B -- cost a full memory round trip
+// (vmcnt(0): everything in flight) per tile.
+template <int KIND, int KS1, bool U16>
 __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     const uint16_t* __restrict__ dA, const uint16_t* __restrict__ dT, int R, int Rpad, int H,
     HeadParams hp, int F, Targets tg, int B, const float* __restrict__ gw, int inline_lgamma,
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     for (int sb = 0; sb < NSB; ++sb) {
       const int c = c0 + gbase + 16 * sb + 4 * q;
       f32x4m v = {0.f, 0.f, 0.f, 0.f};
-      if (tg.u16) {     // pitch % 8 == 0, padding columns zero: one 8-byte load
+      if (U16) {        // pitch % 8 == 0, padding columns zero: one 8-byte load
         const uint16_t* tp = static_cast<const uint16_t*>(tg.p) + trow + c;
         const u32x2 u = *reinterpret_cast<const u32x2*>(tp);
         v.x = __uint_as_float(u.x); v.y = __uint_as_float(u.y);
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     unsigned nz = 0;
 #pragma unroll
     for (int sb = 0; sb < NSB; ++sb) {
-      if (tg.u16) {
+      if (U16) {
         const unsigned v0 = __float_as_uint(cur.t[sb][0]), v1 = __float_as_uint(cur.t[sb][1]);
         tval[4 * sb] = (float)(v0 & 0xFFFFu); tval[4 * sb + 1] = (float)(v0 >> 16);
         tval[4 * sb + 2] = (float)(v1 & 0xFFFFu); tval[4 * sb + 3] = (float)(v1 >> 16);
@@ -624,7 +628,7 @@ int decoder_fused3_launch(hipStream_t s, int kind, const float* d, int rows, int
   const int ks1 = (d3_hp1(H) + 31) / 32;
 #define SCVAE_D3K(K_, KS_)                                                                        \
   do {                                                                                            \
-    auto kfn = decoder_head3_kernel<K_, KS_>;                                                     \
+    auto kfn = t.u16 ? decoder_head3_kernel<K_, KS_, true> : decoder_head3_kernel<K_, KS_, false>; \
     SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
     hipLaunchKernelGGL(kfn, dim3(strips), dim3(D3_THREADS), lds, s, dA, dT, rows, Rpad, H, hp, F, \
