@@ -76,7 +76,9 @@ __device__ __forceinline__ float select16(const float (&v)[16], const IndexMasks
   return cnd(c[0], c[1], k.m[3]);
 }
 
-template <int KIND, int KS4>
+// U16 (compile time): the targets are the uint16 minibatch (as a run-time flag the two load paths
+// met in a branch and every target load was waited for inside it, before the products started)
+template <int KIND, int KS4, bool U16>
 __global__ __launch_bounds__(512) void decoder_forward_kernel(
     const float* __restrict__ d, int R, int H, HeadParams hp, int F, Targets tg,
     int B, int inline_lgamma, float* __restrict__ ll_part) {
@@ -158,20 +160,19 @@ __global__ __launch_bounds__(512) void decoder_forward_kernel(
       // ---- t of this lane's 16 elements: genes cbase + 8*(i>>2) + (i&3), row li ----
       const int cbase = c0 + cb * 32 + 4 * kh;
       float tv[16];
-      if (tg.u16) {        // the uint16 minibatch: four counts per 8-byte load (pitch % 8 == 0)
+      if (U16) {           // the uint16 minibatch: four counts per 8-byte load (pitch % 8 == 0,
+                           // pad columns zero: no per-element bound; a quad at or beyond the
+                           // pitch -- c is a multiple of 4 -- lies wholly beyond F: zeros).
+                           // Branch-free: the loads of a tile are all in flight together
         const uint16_t* trow = static_cast<const uint16_t*>(tg.p) + trow_off;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int c = cbase + 8 * g;
-          if (c + 3 < F) {
-            typedef unsigned u32x2u __attribute__((ext_vector_type(2), aligned(4)));
-            const u32x2u v = *reinterpret_cast<const u32x2u*>(trow + c);
-            tv[4 * g] = (float)(v.x & 0xFFFFu); tv[4 * g + 1] = (float)(v.x >> 16);
-            tv[4 * g + 2] = (float)(v.y & 0xFFFFu); tv[4 * g + 3] = (float)(v.y >> 16);
-          } else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) tv[4 * g + u] = (c + u < F) ? (float)trow[c + u] : 0.f;
-          }
+          typedef unsigned u32x2u __attribute__((ext_vector_type(2), aligned(4)));
+          u32x2u v = *reinterpret_cast<const u32x2u*>(trow + min(c, tg.ld - 4));
+          if (c >= tg.ld) v = u32x2u{0u, 0u};
+          tv[4 * g] = (float)(v.x & 0xFFFFu); tv[4 * g + 1] = (float)(v.x >> 16);
+          tv[4 * g + 2] = (float)(v.y & 0xFFFFu); tv[4 * g + 3] = (float)(v.y >> 16);
         }
       } else {
         const float* trow = static_cast<const float*>(tg.p) + trow_off;
@@ -262,7 +263,8 @@ int decoder_forward_launch(hipStream_t s, int kind, const float* d, int rows, in
   const int strips = (F + FW_BN - 1) / FW_BN;
 #define SCVAE_FW(K_, KS_)                                                                       \
   case KS_: {                                                                                   \
-    auto kfn = decoder_forward_kernel<K_, KS_>;                                                 \
+    auto kfn = t.u16 ? decoder_forward_kernel<K_, KS_, true>                                    \
+                     : decoder_forward_kernel<K_, KS_, false>;                                  \
     SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                          \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
     hipLaunchKernelGGL(kfn, dim3(strips), dim3(512), lds, s, d, rows, H, hp, F, t, B,           \
