@@ -268,7 +268,8 @@ typedef struct scvae_step_args {
    * exact bf16-split kernels (count_gemm.hip: fp32-accurate, 16x the fp32 matrix rate) instead of
    * the fp32 MFMA kernels; 0 (preprocessed / dropped-out / unknown x): fp32 MFMA */
   int32_t x_counts;
-  /* Optional: the minibatch as uint16 counts [cells, F] with row pitch counts_ld (a multiple of 8,
+  /* Optional: the minibatch as uint16 counts [cells, F] with row pitch counts_ld (a multiple of 8
+   * and at least F rounded up to a multiple of 64 -- whole strips of the likelihood kernels --,
    * 16-byte aligned base; scvae_csr_densify_u16).  When given, it IS x and t of this step (x and t
    * may be NULL) and x_counts is implied: the three kernels that stream the minibatch (x W, x^T dA,
    * the fused likelihood heads) read half the bytes; same arithmetic on the same values, so the
@@ -362,7 +363,8 @@ int scvae_decoder_fused(int32_t kind, int32_t train, const float* d, int64_t row
                         const float* gw, const float* row_const, float* ll, float* dd,
                         void* workspace, void* stream);
 /* the same with the targets as the uint16 minibatch of scvae_csr_densify_u16 (row pitch ldt, a
- * multiple of 8; t 16-byte aligned): what a step given scvae_step_args.counts_u16 launches */
+ * multiple of 8 and at least F rounded up to 64; t 16-byte aligned): what a step given
+ * scvae_step_args.counts_u16 launches */
 int scvae_decoder_fused_u16(int32_t kind, int32_t train, const float* d, int64_t rows, int64_t H,
                             const float* const* W, const float* const* b, float* const* dW,
                             float* const* db, int64_t F, const uint16_t* t, int64_t ldt,

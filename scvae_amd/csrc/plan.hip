@@ -1387,7 +1387,8 @@ int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
                        "(scvae_plan_accepts_counts_u16)");
       return -1;
     }
-    SCVAE_ARG(a->counts_ld >= p->cfg.feature_size && (a->counts_ld & 7) == 0 &&
+    // (whole 64-gene strips: the likelihood kernels read four counts per lane without a bound)
+    SCVAE_ARG(a->counts_ld >= (p->cfg.feature_size + 63) / 64 * 64 && (a->counts_ld & 7) == 0 &&
               ((uintptr_t)a->counts_u16 & 15) == 0);
   }
   SCVAE_ARG(a->n_iw > 0 && a->n_mc > 0);
@@ -1578,7 +1579,7 @@ int scvae_decoder_fused_u16(int32_t kind, int32_t train, const float* d, int64_t
                             float* const* db, int64_t F, const uint16_t* t, int64_t ldt,
                             int64_t cells, const float* gw, const float* row_const, float* ll,
                             float* dd, void* workspace, void* stream) {
-  SCVAE_ARG(t && ldt >= F && (ldt & 7) == 0 && ((uintptr_t)t & 15) == 0);
+  SCVAE_ARG(t && ldt >= (F + 63) / 64 * 64 && (ldt & 7) == 0 && ((uintptr_t)t & 15) == 0);
   return decoder_fused_entry(kind, train, d, rows, H, W, b, dW, db, F,
                              scvae::targets_u16(t, (int)ldt), cells, gw, row_const, ll, dd,
                              workspace, stream);
