@@ -160,17 +160,16 @@ __global__ __launch_bounds__(512) void decoder_forward_kernel(
       // ---- t of this lane's 16 elements: genes cbase + 8*(i>>2) + (i&3), row li ----
       const int cbase = c0 + cb * 32 + 4 * kh;
       float tv[16];
-      if (U16) {           // the uint16 minibatch: four counts per 8-byte load (pitch % 8 == 0,
-                           // pad columns zero: no per-element bound; a quad at or beyond the
-                           // pitch -- c is a multiple of 4 -- lies wholly beyond F: zeros).
-                           // Branch-free: the loads of a tile are all in flight together
+      if (U16) {           // the uint16 minibatch: four counts per 8-byte load (the pitch covers
+                           // whole 64-gene strips, pad columns zero: no bound, no branch, and
+                           // nothing touches the loaded value before its use -- a select on it
+                           // would end the load's flight)
         const uint16_t* trow = static_cast<const uint16_t*>(tg.p) + trow_off;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int c = cbase + 8 * g;
           typedef unsigned u32x2u __attribute__((ext_vector_type(2), aligned(4)));
-          u32x2u v = *reinterpret_cast<const u32x2u*>(trow + min(c, tg.ld - 4));
-          if (c >= tg.ld) v = u32x2u{0u, 0u};
+          const u32x2u v = *reinterpret_cast<const u32x2u*>(trow + c);
           tv[4 * g] = (float)(v.x & 0xFFFFu); tv[4 * g + 1] = (float)(v.x >> 16);
           tv[4 * g + 2] = (float)(v.y & 0xFFFFu); tv[4 * g + 3] = (float)(v.y >> 16);
         }
