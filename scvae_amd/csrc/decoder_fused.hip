@@ -663,8 +663,8 @@ static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int
   const int P = likelihood_heads(kind);
   if (TRAIN && planes && decoder_train_kernel(P, H) == 3) {
     static const int dbg = [] { const char* e = getenv("SCVAE_D3_DEBUG"); return e ? atoi(e) : 0; }();
-    return decoder_fused3_launch(s, kind, d, rows, H, hp, F, t, B, gw, inline_lgamma | (dbg << 8),
-                                 ll_part, dd_part, planes);
+    return decoder_fused3_launch(s, true, kind, d, rows, H, hp, F, t, B, gw,
+                                 inline_lgamma | (dbg << 8), ll_part, dd_part, planes);
   }
   if (decoder_fused_variant(P, H) == 2)
     return decoder_fused2_launch(s, TRAIN, kind, d, rows, H, hp, F, t, B, gw, inline_lgamma, ll_part,
@@ -700,23 +700,41 @@ int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int
                           float* workspace) {
   SCVAE_ARG(d && t.p && ll && workspace && decoder_fused_supported(H));
   if (rows == 0) return 0;
-  const int strips = (F + DF_BN - 1) / DF_BN;
+  int strips = (F + DF_BN - 1) / DF_BN;
   float* ll_part = workspace;
   // (the data-only term lgamma(1 + t) of the count likelihoods: the caller's row constant, or
   //  evaluated inline; the Bernoulli likelihood has none)
   const int inline_lgamma = (row_const || kind == LK_BERNOULLI) ? 0 : 1;
-  // the register-resident forward kernel (decoder_forward.hip) where its LDS budget allows;
-  // SCVAE_DECODER_FORWARD=0 keeps the forward instantiation of the training kernels (A/B runs)
-  static const bool use_forward = [] {
+  // Which kernel (SCVAE_DECODER_FORWARD overrides, for A/B runs):
+  //   3  the forward instantiation of the bf16x9 training kernel (decoder_fused3.hip) -- default
+  //      for one- and two-head likelihoods under the bf16x9 head arithmetic;
+  //   1  the register-resident fp32 forward kernel (decoder_forward.hip) -- default otherwise,
+  //      where its LDS budget allows;
+  //   0  the forward instantiation of the fp32 training kernels.
+  // The workspace is the one decoder_fused_workspace_floats(.., train = true) sizes (the plans
+  // and the C ABI size no other): the bf16 planes of d go behind ll_part.
+  static const int forced = [] {
     const char* e = getenv("SCVAE_DECODER_FORWARD");
-    return !(e && e[0] == '0');
+    return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : -1;
   }();
+  const int heads = likelihood_heads(kind);
+  int which = decoder_forward_supported(heads, H) ? 1 : 0;
+  if (decoder_head_arith() == 1 && heads <= 2 && decoder_fused3_supported(heads, H)) which = 3;
+  if (forced == 0) which = 0;
+  if (forced == 1 && decoder_forward_supported(heads, H)) which = 1;
   int rc;
-  if (use_forward && decoder_forward_supported(likelihood_heads(kind), H))
+  if (which == 3) {
+    const int bn = decoder_fused3_strip_genes(heads);
+    strips = (F + bn - 1) / bn;
+    float* planes = workspace + ((size_t)strips * rows + 63) / 64 * 64;
+    rc = decoder_fused3_launch(s, false, kind, d, rows, H, hp, F, t, B, nullptr, inline_lgamma,
+                               ll_part, nullptr, planes);
+  } else if (which == 1) {
     rc = decoder_forward_launch(s, kind, d, rows, H, hp, F, t, B, inline_lgamma, ll_part);
-  else
+  } else {
     rc = launch_decoder<false>(s, kind, d, rows, H, hp, F, t, B, nullptr, inline_lgamma, ll_part,
                                nullptr);
+  }
   if (rc) return rc;
   hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 15) / 16), dim3(1024), 0, s, ll_part, strips,
                      rows, row_const, B, ll);

@@ -201,7 +201,11 @@ __device__ __forceinline__ float select_n(const float (&v)[4], const IndexMasks3
 // paths met in a branch, the compiler waited for the load INSIDE each arm, and the request for the
 // next tile's targets -- meant to travel under a whole phase B -- cost a full memory round trip
 // (vmcnt(0): everything in flight) per tile.
-template <int KIND, int KS1, bool U16>
+//
+// TRAIN = false: the forward half alone (evaluation passes, the importance-weight pass): GEMM1 +
+// likelihood + row sums; no G, no phase B, one barrier per tile (the row-sum buffer alternates
+// between two places), the next tile's operands requested under the last k-step of this one.
+template <int KIND, int KS1, bool U16, bool TRAIN>
 __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     const uint16_t* __restrict__ dA, const uint16_t* __restrict__ dT, int R, int Rpad, int H,
     HeadParams hp, int F, Targets tg, int B, const float* __restrict__ gw, int inline_lgamma,
@@ -239,12 +243,16 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     const int gc = min(c0 + g, F - 1);
     float v[P][NV];
 #pragma unroll
-    for (int j = 0; j < P; ++j)
+    for (int j = 0; j < P; ++j) {
+      const float* wj = hp.W[j] + gc;
+      const float* bj = hp.b[j] + gc;
 #pragma unroll
       for (int u = 0; u < NV; ++u) {
         const int h = h0 + u * HSTEP;
-        v[j][u] = h < H ? hp.W[j][(size_t)h * F + gc] : hp.b[j][gc];
+        const float* src = h < H ? wj + (size_t)h * F : bj;
+        v[j][u] = *src;
       }
+    }
     {
       const int n16 = (int)(((size_t)P * 3 * WPLANE + (size_t)P * 3 * GPLANE + 2 * D3_BM * 4) / 16);
       u32x4* z = reinterpret_cast<u32x4*>(smem);
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     TileIn in;
     const int row = m0 + 16 * rq + i16;
     const bool rok = row < R;
-    in.up0 = rok ? gw[row] : 0.f;
+    in.up0 = (TRAIN && rok) ? gw[row] : 0.f;
     const int rc = rok ? row : R - 1;
     const size_t trow = (size_t)(R == B ? rc : rc % B) * tg.ld;
 #pragma unroll
@@ -344,6 +352,10 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     const int m0 = tile * D3_BM;
     const TileIn cur = nxt;
     const float up = cur.up0;
+    // row sums of the tile (forward only: alternating with the unused G area)
+    // (not at the start of the G area: GEMM1's last k-step reads up to 16 rows past the last
+    //  weight plane -- times zero columns of d, but a row sum's low half can be a bf16 NaN)
+    float* lb = (!TRAIN && (tile & 1)) ? reinterpret_cast<float*>(Gl + 4096) : llbuf;
     // =================== phase A: GEMM1 (transposed) + likelihood + G -> LDS ===================
     f32x4m acc1[P][NSB];
 #pragma unroll
@@ -377,6 +389,16 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
           d3_pin_loads();
         }
         if (ks + 1 < KS1) load_w(ks + 1, afr[(ks + 1) & 1]);
+        if (!TRAIN && ks == KS1 - 1) {
+          // (forward only) the next tile's targets and first d fragments: under this k-step
+          // and the likelihood.  Unconditional -- the last tile requests itself again: under
+          // a branch the compiler waits for the loads where the arms meet
+          const int mn = min(m0 + D3_BM, Rpad - D3_BM);
+          nxt = load_t(mn);
+          load_d1(mn, 0, bfr0);
+          if (D3_AHEAD > 1 && KS1 > 1) load_d1(mn, 1, bfr1);
+          d3_pin_loads();
+        }
         // small terms first; the accumulators (head x gene block) are independent chains
 #pragma unroll
         for (int a = 2; a >= 0; --a)
@@ -410,11 +432,13 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
         float a[P], g[P], lp, r, rgate;
 #pragma unroll
         for (int j = 0; j < P; ++j) a[j] = acc1[j][sb][e];
-        lik_dense<KIND, true>(tval[4 * sb + e], a, lp, g, r, rgate);
+        lik_dense<KIND, TRAIN>(tval[4 * sb + e], a, lp, g, r, rgate);
         const bool ok = c0 + gbase + 16 * sb + 4 * q + e < F;
         lsum += ok ? lp : 0.f;
+        if (TRAIN) {
 #pragma unroll
-        for (int j = 0; j < P; ++j) G[j][4 * sb + e] = up * g[j];
+          for (int j = 0; j < P; ++j) G[j][4 * sb + e] = up * g[j];
+        }
         nz |= (ok && tval[4 * sb + e] > 0.f) ? (1u << (4 * sb + e)) : 0u;
       }
     }
@@ -440,15 +464,17 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
           const bool small = !on || (tt <= 8.f && tt == __builtin_rintf(tt));
           float A, D;
           if (__builtin_amdgcn_ballot_w64(!small) == 0)
-            lgamma_digamma_diff_small<true>(r, on ? tt : 0.f, A, D);
+            lgamma_digamma_diff_small<TRAIN>(r, on ? tt : 0.f, A, D);
           else
-            lgamma_digamma_diff_general<true>(r, on ? tt : 1.f, A, D);
+            lgamma_digamma_diff_general<TRAIN>(r, on ? tt : 1.f, A, D);
           corr = A;
           // (zero-inflated: at t > 0 the gradient of the base distribution passes unscaled,
           //  zero_inflated.py:194-199 -- the same insertion)
-          const float delta = on ? up * rgate * r * D : 0.f;
+          if (TRAIN) {
+            const float delta = on ? up * rgate * r * D : 0.f;
 #pragma unroll
-          for (int e = 0; e < NE; ++e) G[P - 1][e] += (idx == e) ? delta : 0.f;
+            for (int e = 0; e < NE; ++e) G[P - 1][e] += (idx == e) ? delta : 0.f;
+          }
         }
         if (inline_lgamma) corr -= lgamma1p(tt);
         lsum += on ? corr : 0.f;
@@ -459,9 +485,10 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
       float sm = lsum;
       sm += __shfl_xor(sm, 16, WAVE);
       sm += __shfl_xor(sm, 32, WAVE);
-      if (q == 0) llbuf[gp * D3_BM + 16 * rq + i16] = sm;
+      if (q == 0) lb[gp * D3_BM + 16 * rq + i16] = sm;
     }
     // ---- G_j -> three bf16 planes, row-major [row][gene], 8 bytes (4 genes) per store ----
+    if (TRAIN) {
 #pragma unroll
     for (int j = 0; j < P; ++j)
 #pragma unroll
@@ -476,12 +503,14 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
         *reinterpret_cast<u32x2*>(dst + 2 * GPLANE) =
             u32x2{pack_hi16(b3[0], b3[1]), pack_hi16(b3[2], b3[3])};
       }
+    }
     lds_barrier();
 
     // =================== phase B: GEMM3 (LDS operands), then GEMM2 ===================
     // per-row log-likelihood of the strip: the two gene blocks summed in a fixed order
     if (tid < D3_BM && m0 + tid < R)
-      ll_part[(size_t)blockIdx.x * R + m0 + tid] = llbuf[tid] + llbuf[D3_BM + tid];
+      ll_part[(size_t)blockIdx.x * R + m0 + tid] = lb[tid] + lb[D3_BM + tid];
+    if (!TRAIN) continue;   // (the next tile writes the other row-sum buffer: no second barrier)
     // GEMM2's d fragments (A[i = h][k = row]) come from L2 one k-step ahead; k-step 0 is
     // requested here and lands under GEMM3
     auto load_a2 = [&](int ks, bf16x8 (&dst)[3]) {
@@ -576,6 +605,7 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     lds_barrier();
   }
 
+  if (!TRAIN) return;
   // ---- dW / db of the strip ----
   if (KSPLIT) {
     // the two waves of an h tile hold partial sums over the two row halves: waves 4-7 park
@@ -610,50 +640,64 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
   }
 }
 
-int decoder_fused3_launch(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
-                          int F, Targets t, int B, const float* gw, int inline_lgamma,
-                          float* ll_part, float* dd_part, float* planes) {
+int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, int rows, int H,
+                          HeadParams hp, int F, Targets t, int B, const float* gw,
+                          int inline_lgamma, float* ll_part, float* dd_part, float* planes) {
   const int P = likelihood_heads(kind);
   SCVAE_ARG(decoder_fused3_supported(P, H) && planes);
+  SCVAE_ARG(train || P <= 2);
+  // (forward only: one- and two-head likelihoods; the three-head one, on 32-gene strips, is
+  //  no faster than decoder_forward_kernel: 0.92 vs 0.94 ms at 4096 x 32 738, the same step)
   const int Rpad = (rows + D3_BM - 1) / D3_BM * D3_BM;
   uint16_t* dA = reinterpret_cast<uint16_t*>(planes);
   uint16_t* dT = dA + (size_t)3 * Rpad * D3_KP;
   {
-    hipLaunchKernelGGL(split3_hidden_kernel, dim3((Rpad * 16 + 255) / 256, 2), dim3(256), 0, s, d,
+    hipLaunchKernelGGL(split3_hidden_kernel, dim3((Rpad * 16 + 255) / 256, train ? 2 : 1), dim3(256), 0, s, d,
                        rows, H, Rpad, dA, dT);
     SCVAE_LAUNCH_CHECK("split3_hidden_kernel");
   }
   const size_t lds = decoder_fused3_lds_bytes(P, H);
   const int strips = (F + d3_bn(P) - 1) / d3_bn(P);
   const int ks1 = (d3_hp1(H) + 31) / 32;
-#define SCVAE_D3K(K_, KS_)                                                                        \
+#define SCVAE_D3K(K_, KS_, T_)                                                                   \
   do {                                                                                            \
-    auto kfn = t.u16 ? decoder_head3_kernel<K_, KS_, true> : decoder_head3_kernel<K_, KS_, false>; \
+    auto kfn = t.u16 ? decoder_head3_kernel<K_, KS_, true, T_>                                    \
+                     : decoder_head3_kernel<K_, KS_, false, T_>;                                  \
     SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
     hipLaunchKernelGGL(kfn, dim3(strips), dim3(D3_THREADS), lds, s, dA, dT, rows, Rpad, H, hp, F, \
                        t, B, gw, inline_lgamma, ll_part, dd_part);                                \
   } while (0)
-#define SCVAE_D3(K_)                                                                              \
+#define SCVAE_D3(K_, T_)                                                                          \
   switch (ks1) {                                                                                  \
-    case 1: SCVAE_D3K(K_, 1); break;                                                              \
-    case 2: SCVAE_D3K(K_, 2); break;                                                              \
-    case 3: SCVAE_D3K(K_, 3); break;                                                              \
-    default: SCVAE_D3K(K_, 4); break;                                                             \
+    case 1: SCVAE_D3K(K_, 1, T_); break;                                                          \
+    case 2: SCVAE_D3K(K_, 2, T_); break;                                                          \
+    case 3: SCVAE_D3K(K_, 3, T_); break;                                                          \
+    default: SCVAE_D3K(K_, 4, T_); break;                                                         \
   }
-  if (decoder_fused_probe(0)) SCVAE_HIP(hipEventRecord(decoder_fused_probe(0), s));
-  switch (kind) {
-    case LK_POISSON: SCVAE_D3(LK_POISSON); break;
-    case LK_NB: SCVAE_D3(LK_NB); break;
-    case LK_ZIP: SCVAE_D3(LK_ZIP); break;
-    case LK_ZINB: SCVAE_D3(LK_ZINB); break;
-    case LK_BERNOULLI: SCVAE_D3(LK_BERNOULLI); break;   // du:194-204; targets binarised by the caller
-    default: set_error("decoder_head3_kernel: likelihood kind %d", kind); return -1;
+  if (train && decoder_fused_probe(0)) SCVAE_HIP(hipEventRecord(decoder_fused_probe(0), s));
+  if (train) {
+    switch (kind) {
+      case LK_POISSON: SCVAE_D3(LK_POISSON, true); break;
+      case LK_NB: SCVAE_D3(LK_NB, true); break;
+      case LK_ZIP: SCVAE_D3(LK_ZIP, true); break;
+      case LK_ZINB: SCVAE_D3(LK_ZINB, true); break;
+      case LK_BERNOULLI: SCVAE_D3(LK_BERNOULLI, true); break;   // du:194-204; targets binarised by the caller
+      default: set_error("decoder_head3_kernel: likelihood kind %d", kind); return -1;
+    }
+  } else {
+    switch (kind) {
+      case LK_POISSON: SCVAE_D3(LK_POISSON, false); break;
+      case LK_NB: SCVAE_D3(LK_NB, false); break;
+      case LK_ZIP: SCVAE_D3(LK_ZIP, false); break;
+      case LK_BERNOULLI: SCVAE_D3(LK_BERNOULLI, false); break;
+      default: set_error("decoder_head3_kernel (forward): likelihood kind %d", kind); return -1;
+    }
   }
 #undef SCVAE_D3
 #undef SCVAE_D3K
   SCVAE_LAUNCH_CHECK("decoder_head3_kernel");
-  if (decoder_fused_probe(1)) SCVAE_HIP(hipEventRecord(decoder_fused_probe(1), s));
+  if (train && decoder_fused_probe(1)) SCVAE_HIP(hipEventRecord(decoder_fused_probe(1), s));
   return 0;
 }
 

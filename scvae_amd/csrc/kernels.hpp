@@ -284,9 +284,10 @@ bool decoder_fused3_supported(int P, int H);
 size_t decoder_fused3_lds_bytes(int P, int H);
 int decoder_fused3_strip_genes(int P);   // genes per workgroup (= per slab of ll_part / dd_part)
 size_t decoder_fused3_workspace_floats(int rows);
-int decoder_fused3_launch(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
-                          int F, Targets t, int B, const float* gw, int inline_lgamma,
-                          float* ll_part, float* dd_part, float* planes);
+// (train = false: the forward half alone, one- and two-head likelihoods; gw / dd_part unused)
+int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, int rows, int H,
+                          HeadParams hp, int F, Targets t, int B, const float* gw,
+                          int inline_lgamma, float* ll_part, float* dd_part, float* planes);
 void decoder_fused_set_probe(hipEvent_t before, hipEvent_t after);   // (nullptr, nullptr): off
 hipEvent_t decoder_fused_probe(int which);
 bool decoder_fused_probe_recorded();   // both events of the pair went into a stream
