@@ -99,6 +99,18 @@ def test_hidden_sizes(cuda_device, H):
     _run(cuda_device, "zero-inflated negative binomial", 40, 40, 90, H, 0.2)
 
 
+@pytest.mark.parametrize("name", ["poisson", "negative binomial",
+                                  "zero-inflated poisson",
+                                  "zero-inflated negative binomial"])
+@pytest.mark.parametrize("H", [40, 100])
+def test_many_row_tiles(cuda_device, name, H):
+    """Seven row tiles at hidden widths whose last contraction step reads past
+    the weight planes (H + 1 = 41 -> 48 rows of 64, 101 -> 112 of 128): what
+    lies behind them in LDS must stay harmless from the third tile on (the
+    forward instantiation of the bf16x9 kernel keeps a row-sum buffer there)."""
+    _run(cuda_device, name, 400, 400, 130, H, 0.1)
+
+
 def test_dense_counts_overflow_the_queue(cuda_device):
     # every element is nonzero: the t > 0 queue overflows and falls back inline
     _run(cuda_device, "negative binomial", 128, 128, 256, 32, 1.0)
