@@ -339,7 +339,9 @@ int scvae_loglik_bwd(int32_t kind, const float* t, float* const* pre, const floa
  * G_j = gw[row] * d log p / d pre_j.  d: [rows, H] (H even, <= 126); W_j: [H, F]; b_j: [F];
  * t: [cells, F] (row r uses t[r % cells]); ll: [rows]; dd: [rows, H].
  * train: 0 forward, 1 forward+backward, 3 forward+backward main kernel only (the per-strip
- * partial sums are left unreduced; used by bench.py to time that kernel alone). */
+ * partial sums are left unreduced; used by bench.py to time that kernel alone).
+ * workspace: scvae_decoder_fused_workspace_bytes for every value of train (the forward-only call
+ * keeps the bf16 planes of d there under the bf16x9 arithmetic), 256-byte aligned. */
 int64_t scvae_decoder_fused_workspace_bytes(int64_t rows, int64_t H, int64_t F);
 /* which schedule scvae_decoder_fused / the step launch for this likelihood and hidden size:
  * 2 = decoder_head2_kernel (two pipelined halves), 1 = decoder_head_kernel, 0 = unsupported H
@@ -348,8 +350,11 @@ int32_t scvae_decoder_fused_variant(int32_t kind, int64_t H);
 /* Arithmetic of the three products (va:2466-2489 and their backward) inside the fused TRAINING
  * kernel: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32), 1 = the bf16 matrix cores in the
  * exact nine-term form -- every fp32 operand cut exactly into three bf16 terms, all nine
- * products of a pair (each exact in fp32) accumulated in fp32 -- where that kernel applies (one
- * or two heads, hidden width within its LDS budget; otherwise the fp32 kernel runs).
+ * products of a pair (each exact in fp32) accumulated in fp32 -- where that kernel applies (up
+ * to three heads, hidden width within its LDS budget; otherwise the fp32 kernel runs).
+ * Forward-only calls (train = 0, evaluation steps) of one- and two-head likelihoods follow the
+ * same setting (the forward instantiation of the same kernel); three heads evaluate on the fp32
+ * matrix cores.
  * Process-wide; the initial value comes from SCVAE_HEAD_ARITH=fp32|bf16x9.
  * scvae_decoder_train_kernel: which kernel a training launch takes under the current setting:
  * 1 / 2 = scvae_decoder_fused_variant's fp32 schedules, 3 = decoder_head3_kernel (bf16x9),
