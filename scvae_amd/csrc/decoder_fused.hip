@@ -659,12 +659,17 @@ bool decoder_fused_probe_recorded() { return g_probe_recorded; }
 template <bool TRAIN>
 static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                           int F, Targets t, int B, const float* gw, int inline_lgamma,
-                          float* ll_part, float* dd_part, float* planes = nullptr) {
+                          float* ll_part, float* dd_part, float* planes = nullptr,
+                          const HeadDropout* drop = nullptr) {
   const int P = likelihood_heads(kind);
   if (TRAIN && planes && decoder_train_kernel(P, H) == 3) {
     static const int dbg = [] { const char* e = getenv("SCVAE_D3_DEBUG"); return e ? atoi(e) : 0; }();
     return decoder_fused3_launch(s, true, kind, d, rows, H, hp, F, t, B, gw,
-                                 inline_lgamma | (dbg << 8), ll_part, dd_part, planes);
+                                 inline_lgamma | (dbg << 8), ll_part, dd_part, planes, drop);
+  }
+  if (drop) {
+    set_error("head dropout inside the fused kernel needs the bf16x9 head kernel");
+    return -1;
   }
   if (decoder_fused_variant(P, H) == 2)
     return decoder_fused2_launch(s, TRAIN, kind, d, rows, H, hp, F, t, B, gw, inline_lgamma, ll_part,
@@ -745,7 +750,8 @@ int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int
 // Forward + backward: ll[rows], dW_j, db_j (in hp), dd[rows, H]
 int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                         int F, Targets t, int B, const float* gw, const float* row_const,
-                        float* ll, float* dd, float* workspace, bool kernel_only) {
+                        float* ll, float* dd, float* workspace, bool kernel_only,
+                        const HeadDropout* drop) {
   SCVAE_ARG(d && t.p && gw && ll && dd && workspace && decoder_fused_supported(H));
   if (rows == 0) return 0;
   const int heads = likelihood_heads(kind);
@@ -757,7 +763,7 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
   float* planes = dd_part + ((size_t)strips * rows * ((H + 3) / 4 * 4) + 63) / 64 * 64;
   int rc = launch_decoder<true>(s, kind, d, rows, H, hp, F, t, B, gw,
                                 (row_const || kind == LK_BERNOULLI) ? 0 : 1, ll_part, dd_part,
-                                planes);
+                                planes, drop);
   if (rc) return rc;
   if (kernel_only) return 0;  // profiling aid: leave the per-strip partials unreduced
   hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 15) / 16), dim3(1024), 0, s, ll_part,

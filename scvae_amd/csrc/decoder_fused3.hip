@@ -89,10 +89,13 @@ size_t decoder_fused3_lds_bytes(int P, int H) {
 bool decoder_fused3_supported(int P, int H) {
   return P <= 3 && H >= 2 && H <= 126 && decoder_fused3_lds_bytes(P, H) <= 160 * 1024;
 }
-// planes of d: dA [3][Rpad][128] then dT [3][128][Rpad], bf16
+// one plane set of d: dA [3][Rpad][128] then dT [3][128][Rpad], bf16
+__host__ __device__ inline size_t d3_set_elems(int Rpad) { return (size_t)2 * 3 * Rpad * D3_KP; }
+// three plane sets (head dropout: one dropped-out copy of d per head) + the heads' mask words
+// [3][Rpad][4]
 size_t decoder_fused3_workspace_floats(int rows) {
   const size_t rpad = (size_t)(rows + D3_BM - 1) / D3_BM * D3_BM;
-  return 2 * 3 * rpad * D3_KP * sizeof(uint16_t) / sizeof(float) + 64;
+  return 3 * d3_set_elems((int)rpad) * sizeof(uint16_t) / sizeof(float) + 3 * rpad * 4 + 64;
 }
 
 // x = b1 + b2 + b3 exactly, each term's upper 16 bits a bf16 value (lower 16 bits zero)
@@ -205,11 +208,19 @@ __device__ __forceinline__ float select_n(const float (&v)[4], const IndexMasks3
 // TRAIN = false: the forward half alone (evaluation passes, the importance-weight pass): GEMM1 +
 // likelihood + row sums; no G, no phase B, one barrier per tile (the row-sum buffer alternates
 // between two places), the next tile's operands requested under the last k-step of this one.
-template <int KIND, int KS1, bool U16, bool TRAIN>
+//
+// DROP = true (training only): dropout of the heads' input connections (mu:45-50 inside every
+// X_TILDE dense_layer, va:2475-2488): head j reads its OWN dropped-out copy of d -- plane set j,
+// d3_set_elems(Rpad) apart -- in GEMM1 and GEMM2 (contraction steps (k-step, head) instead of
+// k-steps, the fragments of d two such steps ahead), and its part of dd passes the head's mask
+// (drop_bits[j][row][4]: bit h % 32 of word h / 32) times 1 / keep before the heads are summed.
+template <int KIND, int KS1, bool U16, bool TRAIN, bool DROP>
 __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     const uint16_t* __restrict__ dA, const uint16_t* __restrict__ dT, int R, int Rpad, int H,
     HeadParams hp, int F, Targets tg, int B, const float* __restrict__ gw, int inline_lgamma,
-    float* __restrict__ ll_part, float* __restrict__ dd_part) {
+    float* __restrict__ ll_part, float* __restrict__ dd_part,
+    const uint32_t* __restrict__ drop_bits, float inv_keep) {
+  static_assert(TRAIN || !DROP, "dropout is a training-time operation");
   using Traits = LikelihoodTraits<KIND>;
   constexpr int P = Traits::P;
   constexpr int BN = d3_bn(P), ROWB = d3_rowb(P);
@@ -339,14 +350,19 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
   // d fragments of GEMM1 (B[k = h][n = row]): 3 planes per k-step, one contiguous KiB each,
   // requested one k-step ahead of the MFMAs that use them (k-step 0 of a tile during the
   // previous phase B)
-  auto load_d1 = [&](int m0, int ks, bf16x8 (&dst)[3]) {
-    const uint16_t* dbase = dA + ((size_t)(m0 / 16 + rq) * 4 + ks) * 512 + lane * 8;
+  const size_t dset = DROP ? d3_set_elems(Rpad) : 0;     // plane set of head j: + j * dset
+  auto load_d1 = [&](int m0, int ks, bf16x8 (&dst)[3], int j = 0) {
+    const uint16_t* dbase = dA + j * dset + ((size_t)(m0 / 16 + rq) * 4 + ks) * 512 + lane * 8;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) dst[pl] = global_b128(dbase + pl * dplane);
   };
+  // (DROP: contraction steps st = k-step * P + head; steps 0 and 1 of a tile travel under the
+  //  previous phase B)
+  constexpr int NST1 = KS1 * P;
   bf16x8 bfr0[3], bfr1[3];
   load_d1(0, 0, bfr0);
-  if (D3_AHEAD > 1 && KS1 > 1) load_d1(0, 1, bfr1);
+  if (DROP) { if (NST1 > 1) load_d1(0, 1 / P, bfr1, 1 % P); }
+  else if (D3_AHEAD > 1 && KS1 > 1) load_d1(0, 1, bfr1);
 
   for (int tile = 0; tile < n_tiles; ++tile) {
     const int m0 = tile * D3_BM;
@@ -362,7 +378,39 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     for (int j = 0; j < P; ++j)
 #pragma unroll
       for (int sb = 0; sb < NSB; ++sb) acc1[j][sb] = f32x4m{0.f, 0.f, 0.f, 0.f};
-    {
+    if constexpr (DROP) {
+      // one head per step: its W fragments one step ahead, its d fragments two
+      bf16x8 afr[2][NSB][3], bfr[3][3];
+      auto load_wj = [&](int st, bf16x8 (&dst)[NSB][3]) {
+        const int ks = st / P, j = st % P;
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            dst[sb][pl] = lds_tr8<ROWB>(Wl + (size_t)(j * 3 + pl) * WPLANE + trw + 32 * sb +
+                                        32 * ks * ROWB);
+      };
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) { bfr[0][pl] = bfr0[pl]; bfr[1][pl] = bfr1[pl]; }
+      load_wj(0, afr[0]);
+#pragma unroll
+      for (int st = 0; st < NST1; ++st) {
+        if (st + 2 < NST1) {
+          load_d1(m0, (st + 2) / P, bfr[(st + 2) % 3], (st + 2) % P);
+          d3_pin_loads();
+        }
+        if (st + 1 < NST1) load_wj(st + 1, afr[(st + 1) & 1]);
+        const int j = st % P;
+#pragma unroll
+        for (int a = 2; a >= 0; --a)
+#pragma unroll
+          for (int b = 2; b >= 0; --b)
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb)
+              acc1[j][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  afr[st & 1][sb][a], bfr[st % 3][b], acc1[j][sb], 0, 0, 0);
+      }
+    } else {
       // W fragments (transpose reads) and d fragments one k-step ahead of the MFMAs
       bf16x8 afr[2][P][NSB][3], bfr[D3_NB][3];
       auto load_w = [&](int ks, bf16x8 (&dst)[P][NSB][3]) {
@@ -513,24 +561,35 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     if (!TRAIN) continue;   // (the next tile writes the other row-sum buffer: no second barrier)
     // GEMM2's d fragments (A[i = h][k = row]) come from L2 one k-step ahead; k-step 0 is
     // requested here and lands under GEMM3
-    auto load_a2 = [&](int ks, bf16x8 (&dst)[3]) {
-      const uint16_t* tb =
-          dT + ((size_t)ht * nb16 + m0 / 16 + (KSPLIT ? 2 * hi2 : 0) + ks) * 512 + lane * 8;
+    auto load_a2 = [&](int ks, bf16x8 (&dst)[3], int j = 0) {
+      const uint16_t* tb = dT + j * dset +
+          ((size_t)ht * nb16 + m0 / 16 + (KSPLIT ? 2 * hi2 : 0) + ks) * 512 + lane * 8;
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) dst[pl] = global_b128(tb + pl * dplane);
     };
-    bf16x8 a2[D3_NB][3];
+    constexpr int NST2 = KS2 * P;              // (DROP: steps (k-step, head), two ahead)
+    bf16x8 a2[DROP ? 3 : D3_NB][3];
     if (ht < n_ht2) {
       load_a2(0, a2[0]);
-      if (D3_AHEAD > 1 && KS2 > 1) load_a2(1, a2[1]);
+      if (DROP) { if (NST2 > 1) load_a2(1 / P, a2[1], 1 % P); }
+      else if (D3_AHEAD > 1 && KS2 > 1) load_a2(1, a2[1]);
+    }
+    // (DROP) the heads' mask words of this lane's row and h tile, shifted to its four-h groups
+    uint32_t mw[P];
+    if (DROP) {
+#pragma unroll
+      for (int j = 0; j < P; ++j)
+        mw[j] = ht < n_ht3
+                    ? drop_bits[((size_t)j * Rpad + m0 + 32 * hi2 + li) * 4 + ht] >> (4 * kh)
+                    : 0u;
     }
     // next tile's targets
     if (tile + 1 < n_tiles) nxt = load_t(m0 + D3_BM);
     if (ht < n_ht3) {
       // ---- GEMM3: dd[row, h] = sum_j sum_gene G_j[row, gene] W_j[h, gene] ----
-      f32x16 acc3;
+      f32x16 acc3, accS;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc3[i] = 0.f;
+      for (int i = 0; i < 16; ++i) { acc3[i] = 0.f; accS[i] = 0.f; }
       bf16x8 af[2][3], bf[2][3];
       auto load_3 = [&](int st, bf16x8 (&a)[3], bf16x8 (&b)[3]) {   // step = head * KS3 + k-step
         const int j = st / KS3, ks = st % KS3;
@@ -550,7 +609,18 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
           for (int b = 2; b >= 0; --b)
             acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[st & 1][b], af[st & 1][a], acc3, 0,
                                                            0, 0);
+        if (DROP && st % KS3 == KS3 - 1) {
+          // head st / KS3 is complete: through its mask (element i = 4 c + e <-> h = 32 ht +
+          // 8 c + 4 kh + e), times 1 / keep, into the sum over the heads
+          const uint32_t m = mw[st / KS3];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            accS[i] += ((m >> (8 * (i >> 2) + (i & 3))) & 1u) ? acc3[i] * inv_keep : 0.f;
+            acc3[i] = 0.f;
+          }
+        }
       }
+      if (DROP) acc3 = accS;
       // (computed transposed, dd^T[h, row]: a lane holds, for each of four groups, FOUR consecutive
       //  h of one row.  The per-strip partial goes to a slab [strip][H / 4][R][4]: one 16-byte
       //  store per group and lane, 32 consecutive rows of an h quad = 512 contiguous bytes per
@@ -574,7 +644,8 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     // the next tile's d fragments of GEMM1: in flight under GEMM2 and the barrier
     if (tile + 1 < n_tiles) {
       load_d1(m0 + D3_BM, 0, bfr0);
-      if (D3_AHEAD > 1 && KS1 > 1) load_d1(m0 + D3_BM, 1, bfr1);
+      if (DROP) { if (NST1 > 1) load_d1(m0 + D3_BM, 1 / P, bfr1, 1 % P); }
+      else if (D3_AHEAD > 1 && KS1 > 1) load_d1(m0 + D3_BM, 1, bfr1);
     }
     if (ht < n_ht2) {
       // ---- GEMM2: dW_j[h, gene] += sum_row d[row, h] G_j[row, gene] ----
@@ -589,7 +660,12 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
 #pragma unroll
       for (int st = 0; st < KS2 * P; ++st) {
         if (st + 1 < KS2 * P) load_2(st + 1, bf[(st + 1) & 1]);
-        if (st % P == 0 && st / P + D3_AHEAD < KS2) {
+        if (DROP) {
+          if (st + 2 < NST2) {
+            load_a2((st + 2) / P, a2[(st + 2) % 3], (st + 2) % P);
+            d3_pin_loads();
+          }
+        } else if (st % P == 0 && st / P + D3_AHEAD < KS2) {
           load_a2(st / P + D3_AHEAD, a2[(st / P + D3_AHEAD) % D3_NB]);
           d3_pin_loads();
         }
@@ -598,8 +674,8 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
         for (int a = 2; a >= 0; --a)
 #pragma unroll
           for (int b = 2; b >= 0; --b)
-            accW[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks % D3_NB][a], bf[st & 1][b], accW[j],
-                                                              0, 0, 0);
+            accW[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[DROP ? st % 3 : ks % D3_NB][a],
+                                                              bf[st & 1][b], accW[j], 0, 0, 0);
       }
     }
     lds_barrier();
@@ -642,55 +718,76 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
 
 int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, int rows, int H,
                           HeadParams hp, int F, Targets t, int B, const float* gw,
-                          int inline_lgamma, float* ll_part, float* dd_part, float* planes) {
+                          int inline_lgamma, float* ll_part, float* dd_part, float* planes,
+                          const HeadDropout* drop) {
   const int P = likelihood_heads(kind);
   SCVAE_ARG(decoder_fused3_supported(P, H) && planes);
   SCVAE_ARG(train || P <= 2);
+  SCVAE_ARG(train || !drop);
   // (forward only: one- and two-head likelihoods; the three-head one, on 32-gene strips, is
   //  no faster than decoder_forward_kernel: 0.92 vs 0.94 ms at 4096 x 32 738, the same step)
   const int Rpad = (rows + D3_BM - 1) / D3_BM * D3_BM;
   uint16_t* dA = reinterpret_cast<uint16_t*>(planes);
   uint16_t* dT = dA + (size_t)3 * Rpad * D3_KP;
-  {
-    hipLaunchKernelGGL(split3_hidden_kernel, dim3((Rpad * 16 + 255) / 256, train ? 2 : 1), dim3(256), 0, s, d,
-                       rows, H, Rpad, dA, dT);
+  // (head dropout: one plane set per head, cut from that head's dropped-out copy of d, and the
+  //  heads' masks as bits behind the three sets)
+  uint32_t* bits = reinterpret_cast<uint32_t*>(dA + 3 * d3_set_elems(Rpad));
+  for (int j = 0; j < (drop ? P : 1); ++j) {
+    hipLaunchKernelGGL(split3_hidden_kernel, dim3((Rpad * 16 + 255) / 256, train ? 2 : 1),
+                       dim3(256), 0, s, drop ? drop->d[j] : d, rows, H, Rpad,
+                       dA + j * d3_set_elems(Rpad), dT + j * d3_set_elems(Rpad));
     SCVAE_LAUNCH_CHECK("split3_hidden_kernel");
+    if (drop) {
+      const int rc = dropout_mask_words(s, bits + (size_t)j * Rpad * 4, rows, Rpad, H, drop->keep,
+                                        drop->seed, drop->site[j], drop->map);
+      if (rc) return rc;
+    }
   }
+  const float inv_keep = drop ? 1.f / drop->keep : 1.f;
   const size_t lds = decoder_fused3_lds_bytes(P, H);
   const int strips = (F + d3_bn(P) - 1) / d3_bn(P);
   const int ks1 = (d3_hp1(H) + 31) / 32;
-#define SCVAE_D3K(K_, KS_, T_)                                                                   \
+#define SCVAE_D3K(K_, KS_, T_, D_)                                                               \
   do {                                                                                            \
-    auto kfn = t.u16 ? decoder_head3_kernel<K_, KS_, true, T_>                                    \
-                     : decoder_head3_kernel<K_, KS_, false, T_>;                                  \
+    auto kfn = t.u16 ? decoder_head3_kernel<K_, KS_, true, T_, D_>                                \
+                     : decoder_head3_kernel<K_, KS_, false, T_, D_>;                              \
     SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
     hipLaunchKernelGGL(kfn, dim3(strips), dim3(D3_THREADS), lds, s, dA, dT, rows, Rpad, H, hp, F, \
-                       t, B, gw, inline_lgamma, ll_part, dd_part);                                \
+                       t, B, gw, inline_lgamma, ll_part, dd_part, bits, inv_keep);                \
   } while (0)
-#define SCVAE_D3(K_, T_)                                                                          \
+#define SCVAE_D3(K_, T_, D_)                                                                      \
   switch (ks1) {                                                                                  \
-    case 1: SCVAE_D3K(K_, 1, T_); break;                                                          \
-    case 2: SCVAE_D3K(K_, 2, T_); break;                                                          \
-    case 3: SCVAE_D3K(K_, 3, T_); break;                                                          \
-    default: SCVAE_D3K(K_, 4, T_); break;                                                         \
+    case 1: SCVAE_D3K(K_, 1, T_, D_); break;                                                      \
+    case 2: SCVAE_D3K(K_, 2, T_, D_); break;                                                      \
+    case 3: SCVAE_D3K(K_, 3, T_, D_); break;                                                      \
+    default: SCVAE_D3K(K_, 4, T_, D_); break;                                                     \
   }
   if (train && decoder_fused_probe(0)) SCVAE_HIP(hipEventRecord(decoder_fused_probe(0), s));
-  if (train) {
+  if (train && drop) {
     switch (kind) {
-      case LK_POISSON: SCVAE_D3(LK_POISSON, true); break;
-      case LK_NB: SCVAE_D3(LK_NB, true); break;
-      case LK_ZIP: SCVAE_D3(LK_ZIP, true); break;
-      case LK_ZINB: SCVAE_D3(LK_ZINB, true); break;
-      case LK_BERNOULLI: SCVAE_D3(LK_BERNOULLI, true); break;   // du:194-204; targets binarised by the caller
+      case LK_POISSON: SCVAE_D3(LK_POISSON, true, true); break;
+      case LK_NB: SCVAE_D3(LK_NB, true, true); break;
+      case LK_ZIP: SCVAE_D3(LK_ZIP, true, true); break;
+      case LK_ZINB: SCVAE_D3(LK_ZINB, true, true); break;
+      case LK_BERNOULLI: SCVAE_D3(LK_BERNOULLI, true, true); break;
+      default: set_error("decoder_head3_kernel: likelihood kind %d", kind); return -1;
+    }
+  } else if (train) {
+    switch (kind) {
+      case LK_POISSON: SCVAE_D3(LK_POISSON, true, false); break;
+      case LK_NB: SCVAE_D3(LK_NB, true, false); break;
+      case LK_ZIP: SCVAE_D3(LK_ZIP, true, false); break;
+      case LK_ZINB: SCVAE_D3(LK_ZINB, true, false); break;
+      case LK_BERNOULLI: SCVAE_D3(LK_BERNOULLI, true, false); break;   // du:194-204; targets binarised by the caller
       default: set_error("decoder_head3_kernel: likelihood kind %d", kind); return -1;
     }
   } else {
     switch (kind) {
-      case LK_POISSON: SCVAE_D3(LK_POISSON, false); break;
-      case LK_NB: SCVAE_D3(LK_NB, false); break;
-      case LK_ZIP: SCVAE_D3(LK_ZIP, false); break;
-      case LK_BERNOULLI: SCVAE_D3(LK_BERNOULLI, false); break;
+      case LK_POISSON: SCVAE_D3(LK_POISSON, false, false); break;
+      case LK_NB: SCVAE_D3(LK_NB, false, false); break;
+      case LK_ZIP: SCVAE_D3(LK_ZIP, false, false); break;
+      case LK_BERNOULLI: SCVAE_D3(LK_BERNOULLI, false, false); break;
       default: set_error("decoder_head3_kernel (forward): likelihood kind %d", kind); return -1;
     }
   }

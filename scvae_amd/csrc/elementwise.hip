@@ -1875,6 +1875,51 @@ int dropout_apply(hipStream_t stream, const float* in, int ld_in, float* out, in
   return 0;
 }
 
+// The same mask as bits (the fused decoder-head kernel applies a head's mask to its part of dd):
+// thread = (row, word of 32 columns) = eight Philox blocks of four columns.
+__global__ __launch_bounds__(256) void dropout_mask_words_kernel(
+    uint32_t* __restrict__ words, int rows, int rows_pad, int cols, float keep, uint32_t seed_lo,
+    uint32_t seed_hi, uint32_t site, RowMap map) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows_pad * 4) return;
+  const int row = i >> 2, wd = i & 3;
+  uint32_t bits = 0u;
+  if (row < rows) {
+    const uint64_t grow = map.cells > 0
+        ? (uint64_t)((row / map.cells) * map.global_cells + map.offset + row % map.cells)
+        : (uint64_t)row;
+    for (int g8 = 0; g8 < 8; ++g8) {
+      const int cg = wd * 8 + g8;
+      if (cg * 4 >= cols) break;
+      uint32_t c[4] = {(uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)cg, 0x80000000u | site};
+      uint32_t k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+      for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float u = ((float)(c[j] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+        if (cg * 4 + j < cols && u < keep) bits |= 1u << (g8 * 4 + j);
+      }
+    }
+  }
+  words[i] = bits;
+}
+int dropout_mask_words(hipStream_t stream, uint32_t* words, int rows, int rows_pad, int cols,
+                       float keep, uint64_t seed, uint32_t site, RowMap map) {
+  SCVAE_ARG(words && rows >= 0 && rows_pad >= rows && cols > 0 && cols <= 128);
+  SCVAE_ARG(keep > 0.f && keep <= 1.f && site < 0x80000000u);
+  if (rows_pad == 0) return 0;
+  hipLaunchKernelGGL(dropout_mask_words_kernel, dim3((rows_pad * 4 + 255) / 256), dim3(256), 0,
+                     stream, words, rows, rows_pad, cols, keep, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), site, map);
+  SCVAE_LAUNCH_CHECK("dropout_mask_words_kernel");
+  return 0;
+}
+
 // rows of a [K, N] matrix scaled by the mask element (row k, column k): dropout of a one-hot
 // input, whose only non-zero is on the diagonal (the GMVAE's p(z|y=k) layers, gm:3024-3040)
 __global__ void dropout_scale_rows_kernel(const float* __restrict__ in, float* __restrict__ out,

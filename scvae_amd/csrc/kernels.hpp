@@ -238,6 +238,7 @@ int tile_backward(hipStream_t s, const TileBwdArgs& q);
 int tile_backward_stats(hipStream_t s, const float* dh, const TileBN& bn, int rows, int N);
 int tile_slab_reduce(hipStream_t s, const SlabJobs& q);
 
+struct HeadDropout;   // (below, with dropout_apply)
 // ---- decoder_fused.hip ----
 // where a fused likelihood kernel reads its targets t[row % B, gene] from: fp32 [B, F] (pitch F)
 // or the uint16 minibatch of scvae_csr_densify_u16 (pitch ld; integer counts convert exactly)
@@ -277,7 +278,8 @@ int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int
                           float* workspace);
 int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                         int F, Targets t, int B, const float* gw, const float* row_const,
-                        float* ll, float* dd, float* workspace, bool kernel_only = false);
+                        float* ll, float* dd, float* workspace, bool kernel_only = false,
+                        const HeadDropout* drop = nullptr);   // drop: bf16x9 kernel only
 
 // training kernel on the bf16 matrix cores, exact nine-term split (decoder_fused3.hip)
 bool decoder_fused3_supported(int P, int H);
@@ -285,9 +287,11 @@ size_t decoder_fused3_lds_bytes(int P, int H);
 int decoder_fused3_strip_genes(int P);   // genes per workgroup (= per slab of ll_part / dd_part)
 size_t decoder_fused3_workspace_floats(int rows);
 // (train = false: the forward half alone, one- and two-head likelihoods; gw / dd_part unused)
+// drop (training only): dropout of the heads' input connections inside the kernel
 int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, int rows, int H,
                           HeadParams hp, int F, Targets t, int B, const float* gw,
-                          int inline_lgamma, float* ll_part, float* dd_part, float* planes);
+                          int inline_lgamma, float* ll_part, float* dd_part, float* planes,
+                          const HeadDropout* drop = nullptr);
 void decoder_fused_set_probe(hipEvent_t before, hipEvent_t after);   // (nullptr, nullptr): off
 hipEvent_t decoder_fused_probe(int which);
 bool decoder_fused_probe_recorded();   // both events of the pair went into a stream
@@ -380,6 +384,19 @@ int philox_normal(hipStream_t stream, float* out, int64_t rows, int cols, int64_
 struct RowMap {
   int64_t cells = 0, global_cells = 0, offset = 0;
 };
+// Dropout of the likelihood heads' input connections in a training step (mu:45-50 inside each
+// X_TILDE dense_layer, va:2475-2488): every head has a mask of its own.
+struct HeadDropout {
+  const float* d[3] = {nullptr, nullptr, nullptr};   // the heads' dropped-out copies of d [rows, H]
+  float keep = 1.f;
+  uint64_t seed = 0;
+  uint32_t site[3] = {0, 0, 0};                      // mask streams of the heads (dropout_apply)
+  RowMap map;
+};
+// the mask of dropout_apply(seed, site) as bits: words[row][4], bit c % 32 of word c / 32 set iff
+// element (row, c) is kept; rows [rows, rows_pad) zero; cols <= 128
+int dropout_mask_words(hipStream_t stream, uint32_t* words, int rows, int rows_pad, int cols,
+                       float keep, uint64_t seed, uint32_t site, RowMap map = RowMap());
 // dropout (mu:45-50): out (+)= in * mask(seed, site, global row, col) / keep; forward and backward
 int dropout_apply(hipStream_t stream, const float* in, int ld_in, float* out, int ld_out,
                   int64_t rows, int cols, float keep, uint64_t seed, uint32_t site,

@@ -470,6 +470,26 @@ int heads_backward(scvae_plan* p, hipStream_t s, const float* const (&head_in)[4
   return 0;
 }
 
+// Dropout of the heads' input connections inside the fused kernel: the bf16x9 kernel reads one
+// dropped-out copy of the decoder output per head (DROP instantiation).  Not with importance
+// weights (their separate forward pass has no such instantiation) nor on the fp32 head kernels.
+bool heads_fused_dropout_ok(scvae_plan* p, int n_iw) {
+  return n_iw == 1 && decoder_train_kernel(p->P, p->heads[0].n_in) == 3;
+}
+int heads_dropout_inputs(scvae_plan* p, hipStream_t s, const float* dch, int ld, int R,
+                         HeadDropout* out) {
+  int rc, ldh = ld;
+  for (int j = 0; j < p->P; ++j) {
+    Dense& hd = p->heads[j];
+    if ((rc = dense_input(p, s, hd, dch, ld, R, true, &out->d[j], &ldh))) return rc;
+    out->site[j] = hd.site;
+  }
+  out->keep = p->heads[0].keep;
+  out->seed = p->drop_seed;
+  out->map = p->drop_rows;
+  return 0;
+}
+
 HeadParams head_params(scvae_plan* p) {
   HeadParams hp;
   for (int j = 0; j < 3; ++j) {
@@ -824,8 +844,9 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   // the fused kernel never materialises the [rows, P*F] pre-activations; the evaluate-time
   // statistics (p_x_mean, ...) need them, so that request takes the unfused path
   const int KM = c.k_max;   // piecewise categorical likelihood: unfused path
-  // dropout gives every head its own mask of the decoder output (va:2475-2488, 2507-2518):
-  // the fused kernel shares one tile of it between the heads, so that training pass is unfused
+  // dropout gives every head its own mask of the decoder output (va:2475-2488, 2507-2518): the
+  // bf16x9 kernel has an instantiation that reads one dropped-out copy per head
+  // (heads_fused_dropout_ok); otherwise that training pass is unfused
   const bool head_drop = training && p->heads[0].keep > 0.f;
   const bool cpoisson = c.likelihood == LK_CPOISSON;   // row softmax: unfused
   if (cpoisson && !a->count_sum) {
@@ -833,11 +854,12 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     return -1;
   }
   const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
-                     !a->p_x_mean && KM == 0 && !head_drop &&
+                     !a->p_x_mean && KM == 0 &&
+                     (!head_drop || heads_fused_dropout_ok(p, n_iw)) &&
                      (c.likelihood <= LK_ZINB || c.likelihood == LK_BERNOULLI);
   if (p->x_u16 && !fused) {
     set_error("the uint16 minibatch needs the fused likelihood kernels (no -k / constrained "
-              "Poisson, head dropout or evaluation statistics)");
+              "Poisson, evaluation statistics, or head dropout outside the bf16x9 kernel)");
     return -1;
   }
   const Targets tg = p->x_u16 ? targets_u16(p->step_u16, p->step_u16_ld) : targets_f32(a->t, F);
@@ -914,8 +936,12 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   if (fused) {
     // heads forward + likelihood + dW_j, db_j, dd in one kernel
+    HeadDropout hdrop;
+    if (head_drop)
+      if ((rc = heads_dropout_inputs(p, s, dch, ld, R, &hdrop))) return rc;
     if ((rc = decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, tg, B, p->gw,
-                                  a->row_const, p->ll, dcur, p->fused_ws)))
+                                  a->row_const, p->ll, dcur, p->fused_ws, false,
+                                  head_drop ? &hdrop : nullptr)))
       return rc;
   } else {
     if (KM > 0)

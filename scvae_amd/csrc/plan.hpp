@@ -219,6 +219,11 @@ int plan_gemm(scvae_plan* p, hipStream_t s, bool ta, bool tb, const float* A, co
               bool accumulate);
 size_t plan_x_gemm_workspace_bytes(int cells, int features, int n_out);
 HeadParams head_params(scvae_plan* p);
+// head dropout inside the fused decoder-head kernel (bf16x9 kernel, one likelihood pass per
+// step): may this training step take it / the heads' dropped-out inputs and mask parameters
+bool heads_fused_dropout_ok(scvae_plan* p, int n_iw);
+int heads_dropout_inputs(scvae_plan* p, hipStream_t s, const float* dch, int ld, int R,
+                         HeadDropout* out);
 int heads_forward(scvae_plan* p, hipStream_t s, const float* dch, int ld, int R, bool training,
                   const float* (&head_in)[4]);
 int heads_backward(scvae_plan* p, hipStream_t s, const float* const (&head_in)[4], int R,

@@ -340,7 +340,8 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const int h1 = p->heads[0].n_in;
   // fused heads + likelihood (+ backward) unless the evaluate-time statistics are requested
   const int KM = c.k_max, FC = F * (KM + 1);   // piecewise categorical likelihood: unfused path
-  // (dropout: every head draws its own mask of the decoder output, so that pass is unfused)
+  // (dropout: every head draws its own mask of the decoder output: the bf16x9 kernel's DROP
+  //  instantiation, or the unfused path)
   const bool head_drop = training && p->heads[0].keep > 0.f;
   const bool cpoisson = c.likelihood == LK_CPOISSON;   // row softmax: unfused
   if (cpoisson && !a->count_sum) {
@@ -348,11 +349,11 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     return -1;
   }
   const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
-                     !a->p_x_mean && KM == 0 && !head_drop &&
+                     !a->p_x_mean && KM == 0 && (!head_drop || heads_fused_dropout_ok(p, 1)) &&
                      (c.likelihood <= LK_ZINB || c.likelihood == LK_BERNOULLI);
   if (p->x_u16 && !fused) {
     set_error("the uint16 minibatch needs the fused likelihood kernels (no -k / constrained "
-              "Poisson, head dropout or evaluation statistics)");
+              "Poisson, evaluation statistics, or head dropout outside the bf16x9 kernel)");
     return -1;
   }
   // the K stacked passes read the same targets (row r uses t[r % B]): as uint16 they are half
@@ -421,8 +422,10 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   float* dalt = p->dbuf[1];
   float* scratch = p->dbuf[2];
   if (fused) {
+    HeadDropout hdrop;
+    if (head_drop) TRY(heads_dropout_inputs(p, s, dch, ld, R, &hdrop));
     TRY(decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, tg, B, p->gw, a->row_const, p->ll,
-                            dcur, p->fused_ws));
+                            dcur, p->fused_ws, false, head_drop ? &hdrop : nullptr));
   } else if (KM > 0) {
     TRY(loglik_cat_bwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->gw, p->ll, R, B, F));
   } else if (cpoisson) {

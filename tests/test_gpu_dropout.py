@@ -104,8 +104,34 @@ def _vae_masks(eng, cfg, B, R, keeps, k_max=0):
 ])
 def test_vae_train_step_matches_oracle(cuda_device, keeps, likelihood, k_max,
                                        n_iw, n_mc):
+    _vae_step_case(cuda_device, keeps, likelihood, k_max, n_iw, n_mc,
+                   96, 5, (20, 16), 31)
+
+
+@pytest.mark.parametrize("likelihood", [
+    "poisson", "negative binomial", "zero-inflated poisson",
+    "zero-inflated negative binomial"])
+@pytest.mark.parametrize("H,B", [((100, 30), 300), ((40, 24), 200)])
+def test_head_dropout_in_the_fused_kernel(cuda_device, likelihood, H, B):
+    """Hidden-layer dropout reaches the likelihood heads, each with its own mask
+    (mu:45-50 inside every X_TILDE dense_layer, va:2475-2488): with one
+    likelihood pass per step the bf16x9 head kernel takes it (one dropped-out
+    copy of the decoder output per head, the heads' parts of dd through their
+    masks).  Several row tiles, decoder widths 100 and 40, all four count
+    likelihoods, against the fp64 oracle with the same masks."""
+    from scvae_amd import _lib
+    lib = _lib.load()
+    kind, heads = _lib.LIKELIHOOD_KINDS[likelihood]
+    assert lib.scvae_decoder_train_kernel(kind, H[0]) == 3
+    _vae_step_case(cuda_device, (0.8, 0.0, 0.0), likelihood, 0, 1, 1,
+                   150, 7, H, B)
+    _vae_step_case(cuda_device, (0.6, 0.0, 0.9), likelihood, 0, 1, 2,
+                   70, 3, H, B // 2)
+
+
+def _vae_step_case(cuda_device, keeps, likelihood, k_max, n_iw, n_mc, F, L, H,
+                   B):
     from scvae_amd.engine import Engine
-    F, L, H, B = 96, 5, (20, 16), 31
     S = n_iw * n_mc
     eng = Engine(F, L, H, likelihood, device=cuda_device, k_max=k_max,
                  dropout_keep_probabilities=keeps)
