@@ -281,9 +281,11 @@ typedef struct scvae_step_args {
   const scvae_side_work* side;
 } scvae_step_args;
 int scvae_plan_step(scvae_plan* plan, const scvae_step_args* args, void* stream);
-/* 1 if a step of `cells` cells (training or not) of this plan can take its minibatch as uint16
- * counts: a VAE plan on the fused likelihood kernels (no -k / constrained Poisson, no dropout on
- * the input layer or the likelihood heads while training, no evaluation statistics requested),
+/* 1 if a step of `cells` cells of this plan can take its minibatch as uint16 counts
+ * (training: 0 = evaluation step, 1 = training step, 2 = training step without importance
+ * weighting, n_iw == 1): a plan on the fused likelihood kernels (no -k / constrained Poisson, no
+ * evaluation statistics requested; while training no dropout on the input layer, and dropout of
+ * the likelihood heads only with training == 2 under the bf16x9 head arithmetic),
  * the layer that sees x at most 128 units wide, the count kernels enabled, and a minibatch large
  * enough for them to pay (the threshold of scvae_plan_set_count_gemm).  0 otherwise. */
 int scvae_plan_accepts_counts_u16(const scvae_plan* plan, int64_t cells, int32_t training);

@@ -1379,7 +1379,11 @@ int scvae_plan_accepts_counts_u16(const scvae_plan* p, int64_t cells, int32_t tr
   for (int i = 0; i < 2; ++i)
     if (!scvae::count_gemm_supported(n_x[i])) return 0;
   if (training) {
-    if (p->heads[0].keep > 0.f) return 0;
+    // head dropout: only inside the bf16x9 head kernel, i.e. one likelihood pass per step
+    // (training == 2: the caller vouches for n_iw == 1; the GMVAE has no other kind of step)
+    if (p->heads[0].keep > 0.f &&
+        !((training == 2 || gm) && scvae::decoder_train_kernel(p->P, p->heads[0].n_in) == 3))
+      return 0;
     if (gm) {
       if (p->zenc[0].keep > 0.f) return 0;
       if (!p->yenc.empty() ? p->yenc[0].keep > 0.f : p->ylogits.keep > 0.f) return 0;
@@ -1408,7 +1412,9 @@ int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
   SCVAE_ARG((u16 || (a->x && a->t)) && a->scalars);
   SCVAE_ARG(a->cells > 0 && a->cells <= p->max_cells);
   if (u16) {
-    if (!scvae_plan_accepts_counts_u16(p, a->cells, a->training)) {
+    const bool single_pass = a->deterministic_z || a->n_iw == 1;
+    if (!scvae_plan_accepts_counts_u16(p, a->cells,
+                                       a->training ? (single_pass ? 2 : 1) : 0)) {
       scvae::set_error("this plan / step does not take a uint16 minibatch "
                        "(scvae_plan_accepts_counts_u16)");
       return -1;

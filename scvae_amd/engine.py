@@ -340,12 +340,15 @@ class Engine:
         _lib.check(self.lib.scvae_plan_set_bn_one_launch(self.handle, mode),
                    "scvae_plan_set_bn_one_launch")
 
-    def accepts_counts_u16(self, cells, training):
+    def accepts_counts_u16(self, cells, training, n_iw=None):
         """Whether a step of ``cells`` cells may take its minibatch as uint16
-        counts (half the bytes for the three kernels that stream it)."""
+        counts (half the bytes for the three kernels that stream it).
+        ``n_iw``: the importance samples of the training steps in question, if
+        known (1: head dropout does not stand in the way)."""
         self.reserve(int(cells), 1)
+        mode = 0 if not training else (2 if n_iw == 1 else 1)
         return bool(self.lib.scvae_plan_accepts_counts_u16(
-            self.handle, int(cells), 1 if training else 0))
+            self.handle, int(cells), mode))
 
     def set_sync(self, callback):
         """Install the data-parallel collective hook (see scvae_sync_fn)."""

@@ -477,7 +477,8 @@ class ModelBase:
         u16_buffers = None
         if (same_matrix and getattr(x_train, "integer_counts", False)
                 and hasattr(x_train, "gather_counts_u16")
-                and engine.accepts_counts_u16(max(local_batch, 1), True)):
+                and engine.accepts_counts_u16(max(local_batch, 1), True,
+                                              n_iw=n_iw)):
             u16_buffers = [torch.empty(
                 max(local_batch, 1), x_train.u16_pitch, dtype=torch.uint16,
                 device=device) for _ in range(2)]
@@ -487,7 +488,7 @@ class ModelBase:
             ``cells`` cells in buffer set ``slot``."""
             rc = row_consts[slot][:cells]
             if (u16_buffers is not None
-                    and engine.accepts_counts_u16(cells, True)):
+                    and engine.accepts_counts_u16(cells, True, n_iw=n_iw)):
                 xb = tb = u16_buffers[slot][:cells]
             else:
                 xb, tb = x_buffers[slot][:cells], t_buffers[slot][:cells]

@@ -275,6 +275,52 @@ def test_uint16_minibatch_is_the_fp32_step_bit_for_bit(cuda_device, likelihood):
         assert torch.equal(a, b)
 
 
+def test_uint16_minibatch_with_head_dropout(cuda_device):
+    """Hidden-layer dropout reaches the likelihood heads; in a step without
+    importance weighting the bf16x9 head kernel takes it, and with it the
+    uint16 minibatch: identical bits to the fp32 batch; with importance
+    weighting (a separate forward pass of the heads) the plan says no."""
+    import scipy.sparse as sp
+    from scvae_amd.engine import Engine
+    from scvae_amd.minibatch import DeviceCSR
+    F, L, H, B = 1500, 6, (100, 48), 200
+    rng = np.random.default_rng(23)
+    csr = DeviceCSR.from_scipy(sp.csr_matrix(_counts(rng, 400, F, 0.05)),
+                               cuda_device)
+    rows = torch.from_numpy(rng.permutation(400)[:B]).to(cuda_device)
+    x32 = csr.gather_dense(rows)
+    rc16 = torch.zeros(B, device=cuda_device)
+    x16 = csr.gather_counts_u16(rows, row_const_out=rc16)
+    eps = torch.from_numpy(rng.standard_normal((1, B, L)).astype(np.float32)
+                           ).to(cuda_device)
+    results = []
+    for u16 in (False, True):
+        eng = Engine(F, L, H, "negative binomial", batch_norm=True,
+                     device=cuda_device, seed=1,
+                     dropout_keep_probabilities=(0.8, 0.0, 0.0))
+        eng.set_count_gemm(True, always=True)
+        assert eng.accepts_counts_u16(B, True, n_iw=1)
+        assert not eng.accepts_counts_u16(B, True)
+        assert not eng.accepts_counts_u16(B, True, n_iw=2)
+        x = x16 if u16 else x32
+        out = []
+        for i in range(2):
+            ll = torch.zeros(B, device=cuda_device)
+            s = eng.step(x, x, eps=eps, training=True, row_const=rc16,
+                         x_counts=True, dropout_seed=77 + i,
+                         outputs={"log_p_x_given_z": ll}).clone()
+            eng.adam_step(1e-3)
+            out += [s, ll.clone()]
+        torch.cuda.synchronize()
+        results.append([t.cpu() for t in out + [eng.grads, eng.moving,
+                                                eng.params]])
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        eng.step(x16, x16, eps=eps.repeat(2, 1, 1), training=True, n_iw=2,
+                 row_const=rc16, x_counts=True, dropout_seed=1)
+
+
 def test_uint16_minibatch_is_refused_where_it_does_not_apply(cuda_device):
     from scvae_amd.engine import Engine
     F, L, B = 600, 6, 64
