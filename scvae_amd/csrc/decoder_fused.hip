@@ -603,6 +603,8 @@ size_t decoder_fused_workspace_floats(int rows, int H, int F, bool train) {
   size_t n = strips * rows;                       // ll_part
   if (train) n += strips * (size_t)rows * ((H + 3) / 4 * 4) + 64; // dd_part (16-byte aligned start; H in quads)
   if (train) n += decoder_fused3_workspace_floats(rows) + 64;   // bf16 planes of d (bf16x9 kernel)
+  // (constrained Poisson passes: a second [strips][rows] array, lse[rows], S[rows])
+  if (train) n += strips * (size_t)rows + 2 * (size_t)rows + 192;
   return n + 64;
 }
 
@@ -744,6 +746,103 @@ int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int
   hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 15) / 16), dim3(1024), 0, s, ll_part, strips,
                      rows, row_const, B, ll);
   SCVAE_LAUNCH_CHECK("ll_reduce_kernel");
+  return 0;
+}
+
+// lse[r] = M + log(sum_strips se[strip][r] * exp(m[strip][r] - M)), M = max_strips m[strip][r]
+// (fixed order; a strip without a valid gene carries m = -inf, se = 0)
+__global__ __launch_bounds__(256) void lse_reduce_kernel(const float* __restrict__ m_part,
+                                                         const float* __restrict__ se_part,
+                                                         int strips, int R,
+                                                         float* __restrict__ lse) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  float M = -INFINITY;
+  for (int z0 = 0; z0 < strips; z0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = m_part[(size_t)min(z0 + u, strips - 1) * R + r];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) M = fmaxf(M, v[u]);
+  }
+  float se = 0.f;
+  for (int z0 = 0; z0 < strips; z0 += 8) {
+    float v[8], e[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t i = (size_t)min(z0 + u, strips - 1) * R + r;
+      v[u] = m_part[i];
+      e[u] = se_part[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (z0 + u < strips && v[u] > -INFINITY) se += e[u] * __expf(v[u] - M);
+  }
+  lse[r] = M + __logf(se);
+}
+
+bool decoder_fused_cpoisson_supported(int H) {
+  return decoder_fused_supported(H) && decoder_head_arith() == 1 && decoder_fused3_supported(1, H);
+}
+
+// Constrained Poisson through the bf16x9 head kernel: three passes over the strip grid (an
+// element's likelihood needs the row's log-sum-exp, its gradient the row sum S; the formulas:
+// cpoisson_rows_kernel, elementwise.hip)
+int decoder_fused_cpoisson(hipStream_t s, bool train, const float* d, int rows, int H,
+                           HeadParams hp, int F, Targets t, int B, const float* gw,
+                           const float* count_sum, const float* row_const, float* ll, float* dd,
+                           float* workspace) {
+  SCVAE_ARG(d && t.p && ll && workspace && count_sum && decoder_fused_cpoisson_supported(H));
+  SCVAE_ARG(!train || (gw && dd));
+  if (rows == 0) return 0;
+  const int strips = (F + DF_BN - 1) / DF_BN;     // (one head: 64-gene strips)
+  const size_t n_part = ((size_t)strips * rows + 63) / 64 * 64;
+  float* ll_part = workspace;
+  float* dd_part = ll_part + n_part;
+  float* planes = dd_part + ((size_t)strips * rows * ((H + 3) / 4 * 4) + 63) / 64 * 64;
+  float* part2 = planes + (decoder_fused3_workspace_floats(rows) + 63) / 64 * 64;
+  float* lse = part2 + n_part;
+  float* S = lse + ((size_t)rows + 63) / 64 * 64;
+  CpRows cp;
+  cp.count_sum = count_sum;
+  cp.out2 = part2;
+  const int inline_lgamma = row_const ? 0 : 1;
+  int rc;
+  // pass 1: row maxima and sums of exponentials per strip -> log-sum-exp of every row
+  if ((rc = decoder_fused3_launch(s, false, LK_CPOISSON, d, rows, H, hp, F, t, B, nullptr, 0,
+                                  ll_part, nullptr, planes, nullptr, 1, &cp)))
+    return rc;
+  hipLaunchKernelGGL(lse_reduce_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, ll_part, part2,
+                     strips, rows, lse);
+  SCVAE_LAUNCH_CHECK("lse_reduce_kernel");
+  // pass 2: log-likelihood and S
+  cp.lse = lse;
+  if ((rc = decoder_fused3_launch(s, false, LK_CPOISSON, d, rows, H, hp, F, t, B, nullptr,
+                                  inline_lgamma, ll_part, nullptr, planes, nullptr, 2, &cp)))
+    return rc;
+  hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 15) / 16), dim3(1024), 0, s, ll_part, strips,
+                     rows, row_const, B, ll);
+  SCVAE_LAUNCH_CHECK("ll_reduce_kernel");
+  if (!train) return 0;
+  hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 15) / 16), dim3(1024), 0, s, part2, strips,
+                     rows, (const float*)nullptr, B, S);
+  SCVAE_LAUNCH_CHECK("ll_reduce_kernel");
+  // pass 3: gradients
+  cp.S = S;
+  if ((rc = decoder_fused3_launch(s, true, LK_CPOISSON, d, rows, H, hp, F, t, B, gw, 0, ll_part,
+                                  dd_part, planes, nullptr, 3, &cp)))
+    return rc;
+  const size_t n4 = (size_t)((H + 3) / 4) * rows;
+  if (n4 <= DD_SPLIT_MAX) {
+    hipLaunchKernelGGL(dd_reduce_q_kernel<true>, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s,
+                       dd_part, strips, rows, H, dd);
+  } else {
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dd_reduce_q_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, dd_part,
+                       strips, rows, H, dd);
+  }
+  SCVAE_LAUNCH_CHECK("dd_reduce_q_kernel");
   return 0;
 }
 

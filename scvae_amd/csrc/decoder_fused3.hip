@@ -214,13 +214,24 @@ __device__ __forceinline__ float select_n(const float (&v)[4], const IndexMasks3
 // d3_set_elems(Rpad) apart -- in GEMM1 and GEMM2 (contraction steps (k-step, head) instead of
 // k-steps, the fragments of d two such steps ahead), and its part of dd passes the head's mask
 // (drop_bits[j][row][4]: bit h % 32 of word h / 32) times 1 / keep before the heads are summed.
-template <int KIND, int KS1, bool U16, bool TRAIN, bool DROP>
+//
+// CP > 0 (KIND = LK_CPOISSON only): the constrained Poisson likelihood (du:218-228: lambda =
+// clip(softmax over ALL genes), rate = lambda N) in three passes over the strip grid, because an
+// element's likelihood needs the row's log-sum-exp and its gradient the row sum S = sum_f gate_f
+// (t_f - N lambda_f) (cpoisson_rows_kernel has the formulas):
+//   CP = 1 (forward): per strip and row the maximum of the logits -> ll_part, sum exp(a - max)
+//          -> cp.out2;
+//   CP = 2 (forward, given cp.lse): the strip's part of sum_f log p(t_f) -> ll_part, of S -> cp.out2;
+//   CP = 3 (training, given cp.lse and cp.S): G = gw (gate (t - N lambda) - lambda S), phase B.
+template <int KIND, int KS1, bool U16, bool TRAIN, bool DROP, int CP>
 __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     const uint16_t* __restrict__ dA, const uint16_t* __restrict__ dT, int R, int Rpad, int H,
     HeadParams hp, int F, Targets tg, int B, const float* __restrict__ gw, int inline_lgamma,
     float* __restrict__ ll_part, float* __restrict__ dd_part,
-    const uint32_t* __restrict__ drop_bits, float inv_keep) {
+    const uint32_t* __restrict__ drop_bits, float inv_keep, CpRows cp) {
   static_assert(TRAIN || !DROP, "dropout is a training-time operation");
+  static_assert((CP > 0) == (KIND == LK_CPOISSON), "CP selects the passes of LK_CPOISSON");
+  static_assert(CP == 0 || ((CP == 3) == TRAIN && !DROP), "CP 1 / 2 forward, CP 3 training");
   using Traits = LikelihoodTraits<KIND>;
   constexpr int P = Traits::P;
   constexpr int BN = d3_bn(P), ROWB = d3_rowb(P);
@@ -315,14 +326,19 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
 
   // targets / upstream of a tile, in flight from the previous phase B (returned by value: an
   // array written through a reference capture ends up in scratch memory)
-  struct TileIn { f32x4m t[NSB]; float up0; };
+  struct TileIn { f32x4m t[NSB]; float up0; float cpn, cpl, cps; };
   auto load_t = [&](int m0) {
     TileIn in;
     const int row = m0 + 16 * rq + i16;
     const bool rok = row < R;
     in.up0 = (TRAIN && rok) ? gw[row] : 0.f;
     const int rc = rok ? row : R - 1;
-    const size_t trow = (size_t)(R == B ? rc : rc % B) * tg.ld;
+    const int cell = R == B ? rc : rc % B;
+    in.cpn = in.cpl = in.cps = 0.f;
+    if (CP > 0) in.cpn = cp.count_sum[cell];
+    if (CP >= 2) in.cpl = cp.lse[rc];
+    if (CP == 3) in.cps = cp.S[rc];
+    const size_t trow = (size_t)cell * tg.ld;
 #pragma unroll
     for (int sb = 0; sb < NSB; ++sb) {
       const int c = c0 + gbase + 16 * sb + 4 * q;
@@ -372,6 +388,7 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     // (not at the start of the G area: GEMM1's last k-step reads up to 16 rows past the last
     //  weight plane -- times zero columns of d, but a row sum's low half can be a bf16 NaN)
     float* lb = (!TRAIN && (tile & 1)) ? reinterpret_cast<float*>(Gl + 4096) : llbuf;
+    float* lb2 = reinterpret_cast<float*>(Gl + ((tile & 1) ? 12288 : 8192));   // (CP 1 / 2)
     // =================== phase A: GEMM1 (transposed) + likelihood + G -> LDS ===================
     f32x4m acc1[P][NSB];
 #pragma unroll
@@ -463,8 +480,62 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     // ---- likelihood of this lane's NSB x 4 elements: row 16 rq + i16, genes
     //      16 NSB gp + 16 sb + 4 q + e ----
     float G[P][NE], tval[NE];
-    float lsum = 0.f;
+    float lsum = 0.f, lsum2 = 0.f;
     unsigned nz = 0;
+    if constexpr (CP > 0) {
+      // ---- constrained Poisson: this lane's NE logits of ONE row ----
+      const float cpn = cur.cpn, cpl = cur.cpl, cps = cur.cps;
+      float av[NE];
+      bool okv[NE];
+#pragma unroll
+      for (int sb = 0; sb < NSB; ++sb) {
+        if (U16) {
+          const unsigned v0 = __float_as_uint(cur.t[sb][0]), v1 = __float_as_uint(cur.t[sb][1]);
+          tval[4 * sb] = (float)(v0 & 0xFFFFu); tval[4 * sb + 1] = (float)(v0 >> 16);
+          tval[4 * sb + 2] = (float)(v1 & 0xFFFFu); tval[4 * sb + 3] = (float)(v1 >> 16);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tval[4 * sb + e] = cur.t[sb][e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          av[4 * sb + e] = acc1[0][sb][e];
+          okv[4 * sb + e] = c0 + gbase + 16 * sb + 4 * q + e < F;
+        }
+      }
+      if (CP == 1) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) mx = fmaxf(mx, okv[i] ? av[i] : -INFINITY);
+        float se = 0.f;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) se += okv[i] ? __expf(av[i] - mx) : 0.f;
+        float m2 = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
+        m2 = fmaxf(m2, __shfl_xor(m2, 32, WAVE));
+        se = mx > -INFINITY ? se * __expf(mx - m2) : 0.f;
+        lsum = m2;
+        lsum2 = se;     // (summed over the wave's gene groups below)
+      } else {
+        const float log_n = __logf(fmaxf(cpn, F32_TINY));
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+          const float tv = tval[i];
+          const float log_lam = av[i] - cpl;
+          const float lam = __expf(log_lam);
+          const bool gate = lam >= F32_TINY;
+          const float own = gate ? tv - cpn * lam : 0.f;
+          if (CP == 2) {
+            const float lam_c = gate ? lam : F32_TINY;
+            const float log_rate = (gate ? log_lam : LOG_F32_TINY) + log_n;
+            lsum += okv[i] ? (tv > 0.f ? tv * log_rate : 0.f) - lam_c * cpn : 0.f;
+            lsum2 += okv[i] ? own : 0.f;
+            nz |= (okv[i] && tv > 0.f) ? (1u << i) : 0u;
+          } else {
+            G[0][i] = up * (own - lam * cps);
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int sb = 0; sb < NSB; ++sb) {
       if (U16) {
@@ -490,9 +561,10 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
         nz |= (ok && tval[4 * sb + e] > 0.f) ? (1u << (4 * sb + e)) : 0u;
       }
     }
+    }
     // ---- t > 0: + lgamma(r+t) - lgamma(r) [- lgamma(1+t)], and the digamma term of dlog r:
     //      a per-lane walk over the lane's non-zero elements ----
-    if (Traits::HAS_R || inline_lgamma) {
+    if (Traits::HAS_R || (inline_lgamma && (CP == 0 || CP == 2))) {
       float lr[NE];
       if (Traits::HAS_R) {
 #pragma unroll
@@ -529,11 +601,26 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
       }
     }
     // ---- row sums over this wave's genes -> llbuf[gp][row] ----
-    {
+    if (CP == 1) {
+      // (maximum already common to the wave's gene groups; the sums of exponentials refer to it)
+      float se = lsum2;
+      se += __shfl_xor(se, 16, WAVE);
+      se += __shfl_xor(se, 32, WAVE);
+      if (q == 0) {
+        lb[gp * D3_BM + 16 * rq + i16] = lsum;
+        lb2[gp * D3_BM + 16 * rq + i16] = se;
+      }
+    } else if (CP != 3) {
       float sm = lsum;
       sm += __shfl_xor(sm, 16, WAVE);
       sm += __shfl_xor(sm, 32, WAVE);
       if (q == 0) lb[gp * D3_BM + 16 * rq + i16] = sm;
+      if (CP == 2) {
+        float s2 = lsum2;
+        s2 += __shfl_xor(s2, 16, WAVE);
+        s2 += __shfl_xor(s2, 32, WAVE);
+        if (q == 0) lb2[gp * D3_BM + 16 * rq + i16] = s2;
+      }
     }
     // ---- G_j -> three bf16 planes, row-major [row][gene], 8 bytes (4 genes) per store ----
     if (TRAIN) {
@@ -556,8 +643,22 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
 
     // =================== phase B: GEMM3 (LDS operands), then GEMM2 ===================
     // per-row log-likelihood of the strip: the two gene blocks summed in a fixed order
-    if (tid < D3_BM && m0 + tid < R)
-      ll_part[(size_t)blockIdx.x * R + m0 + tid] = lb[tid] + lb[D3_BM + tid];
+    if (CP == 1) {
+      // the two gene halves: common maximum, sums of exponentials rescaled to it
+      if (tid < D3_BM && m0 + tid < R) {
+        const float ma = lb[tid], mb = lb[D3_BM + tid];
+        const float m = fmaxf(ma, mb);
+        const float se = (ma > -INFINITY ? lb2[tid] * __expf(ma - m) : 0.f) +
+                         (mb > -INFINITY ? lb2[D3_BM + tid] * __expf(mb - m) : 0.f);
+        ll_part[(size_t)blockIdx.x * R + m0 + tid] = m;
+        cp.out2[(size_t)blockIdx.x * R + m0 + tid] = se;
+      }
+    } else if (CP != 3) {
+      if (tid < D3_BM && m0 + tid < R) {
+        ll_part[(size_t)blockIdx.x * R + m0 + tid] = lb[tid] + lb[D3_BM + tid];
+        if (CP == 2) cp.out2[(size_t)blockIdx.x * R + m0 + tid] = lb2[tid] + lb2[D3_BM + tid];
+      }
+    }
     if (!TRAIN) continue;   // (the next tile writes the other row-sum buffer: no second barrier)
     // GEMM2's d fragments (A[i = h][k = row]) come from L2 one k-step ahead; k-step 0 is
     // requested here and lands under GEMM3
@@ -719,11 +820,14 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
 int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, int rows, int H,
                           HeadParams hp, int F, Targets t, int B, const float* gw,
                           int inline_lgamma, float* ll_part, float* dd_part, float* planes,
-                          const HeadDropout* drop) {
+                          const HeadDropout* drop, int cp_pass, const CpRows* cp) {
   const int P = likelihood_heads(kind);
   SCVAE_ARG(decoder_fused3_supported(P, H) && planes);
   SCVAE_ARG(train || P <= 2);
   SCVAE_ARG(train || !drop);
+  SCVAE_ARG((kind == LK_CPOISSON) == (cp_pass >= 1 && cp_pass <= 3 && cp && cp->count_sum));
+  SCVAE_ARG(cp_pass == 0 || ((cp_pass == 3) == train && !drop));
+  const CpRows cpr = cp ? *cp : CpRows();
   // (forward only: one- and two-head likelihoods; the three-head one, on 32-gene strips, is
   //  no faster than decoder_forward_kernel: 0.92 vs 0.94 ms at 4096 x 32 738, the same step)
   const int Rpad = (rows + D3_BM - 1) / D3_BM * D3_BM;
@@ -747,15 +851,23 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
   const size_t lds = decoder_fused3_lds_bytes(P, H);
   const int strips = (F + d3_bn(P) - 1) / d3_bn(P);
   const int ks1 = (d3_hp1(H) + 31) / 32;
-#define SCVAE_D3K(K_, KS_, T_, D_)                                                               \
+#define SCVAE_D3KC(K_, KS_, T_, D_, C_)                                                          \
   do {                                                                                            \
-    auto kfn = t.u16 ? decoder_head3_kernel<K_, KS_, true, T_, D_>                                \
-                     : decoder_head3_kernel<K_, KS_, false, T_, D_>;                              \
+    auto kfn = t.u16 ? decoder_head3_kernel<K_, KS_, true, T_, D_, C_>                            \
+                     : decoder_head3_kernel<K_, KS_, false, T_, D_, C_>;                          \
     SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
     hipLaunchKernelGGL(kfn, dim3(strips), dim3(D3_THREADS), lds, s, dA, dT, rows, Rpad, H, hp, F, \
-                       t, B, gw, inline_lgamma, ll_part, dd_part, bits, inv_keep);                \
+                       t, B, gw, inline_lgamma, ll_part, dd_part, bits, inv_keep, cpr);           \
   } while (0)
+#define SCVAE_D3K(K_, KS_, T_, D_) SCVAE_D3KC(K_, KS_, T_, D_, 0)
+#define SCVAE_D3C(T_, C_)                                                                         \
+  switch (ks1) {                                                                                  \
+    case 1: SCVAE_D3KC(LK_CPOISSON, 1, T_, false, C_); break;                                     \
+    case 2: SCVAE_D3KC(LK_CPOISSON, 2, T_, false, C_); break;                                     \
+    case 3: SCVAE_D3KC(LK_CPOISSON, 3, T_, false, C_); break;                                     \
+    default: SCVAE_D3KC(LK_CPOISSON, 4, T_, false, C_); break;                                    \
+  }
 #define SCVAE_D3(K_, T_, D_)                                                                      \
   switch (ks1) {                                                                                  \
     case 1: SCVAE_D3K(K_, 1, T_, D_); break;                                                      \
@@ -764,7 +876,13 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
     default: SCVAE_D3K(K_, 4, T_, D_); break;                                                     \
   }
   if (train && decoder_fused_probe(0)) SCVAE_HIP(hipEventRecord(decoder_fused_probe(0), s));
-  if (train && drop) {
+  if (cp_pass == 1) {
+    SCVAE_D3C(false, 1);
+  } else if (cp_pass == 2) {
+    SCVAE_D3C(false, 2);
+  } else if (cp_pass == 3) {
+    SCVAE_D3C(true, 3);
+  } else if (train && drop) {
     switch (kind) {
       case LK_POISSON: SCVAE_D3(LK_POISSON, true, true); break;
       case LK_NB: SCVAE_D3(LK_NB, true, true); break;
@@ -792,6 +910,8 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
     }
   }
 #undef SCVAE_D3
+#undef SCVAE_D3C
+#undef SCVAE_D3KC
 #undef SCVAE_D3K
   SCVAE_LAUNCH_CHECK("decoder_head3_kernel");
   if (train && decoder_fused_probe(1)) SCVAE_HIP(hipEventRecord(decoder_fused_probe(1), s));

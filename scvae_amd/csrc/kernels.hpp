@@ -239,6 +239,13 @@ int tile_backward_stats(hipStream_t s, const float* dh, const TileBN& bn, int ro
 int tile_slab_reduce(hipStream_t s, const SlabJobs& q);
 
 struct HeadDropout;   // (below, with dropout_apply)
+// per-row inputs / second output of the constrained Poisson passes of decoder_head3_kernel
+struct CpRows {
+  const float* count_sum = nullptr;   // [cells]: N
+  const float* lse = nullptr;         // [rows]: log-sum-exp of the row's logits (passes 2, 3)
+  const float* S = nullptr;           // [rows]: sum_f gate_f (t_f - N lambda_f) (pass 3)
+  float* out2 = nullptr;              // [strips][rows]: pass 1 sum of exponentials, pass 2 part of S
+};
 // ---- decoder_fused.hip ----
 // where a fused likelihood kernel reads its targets t[row % B, gene] from: fp32 [B, F] (pitch F)
 // or the uint16 minibatch of scvae_csr_densify_u16 (pitch ld; integer counts convert exactly)
@@ -291,7 +298,16 @@ size_t decoder_fused3_workspace_floats(int rows);
 int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, int rows, int H,
                           HeadParams hp, int F, Targets t, int B, const float* gw,
                           int inline_lgamma, float* ll_part, float* dd_part, float* planes,
-                          const HeadDropout* drop = nullptr);
+                          const HeadDropout* drop = nullptr, int cp_pass = 0,
+                          const CpRows* cp = nullptr);
+// Constrained Poisson (du:218-228) through the bf16x9 head kernel in three passes over the strip
+// grid (row maximum / sum of exponentials | log-likelihood and S | gradients): ll[rows] and, with
+// train, dW / db (in hp) and dd[rows, H].  workspace: decoder_fused_workspace_floats(.., true).
+bool decoder_fused_cpoisson_supported(int H);
+int decoder_fused_cpoisson(hipStream_t s, bool train, const float* d, int rows, int H,
+                           HeadParams hp, int F, Targets t, int B, const float* gw,
+                           const float* count_sum, const float* row_const, float* ll, float* dd,
+                           float* workspace);
 void decoder_fused_set_probe(hipEvent_t before, hipEvent_t after);   // (nullptr, nullptr): off
 hipEvent_t decoder_fused_probe(int which);
 bool decoder_fused_probe_recorded();   // both events of the pair went into a stream

@@ -848,15 +848,17 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   // bf16x9 kernel has an instantiation that reads one dropped-out copy per head
   // (heads_fused_dropout_ok); otherwise that training pass is unfused
   const bool head_drop = training && p->heads[0].keep > 0.f;
-  const bool cpoisson = c.likelihood == LK_CPOISSON;   // row softmax: unfused
+  // row softmax: three passes of the bf16x9 head kernel (decoder_fused_cpoisson), or unfused
+  const bool cpoisson = c.likelihood == LK_CPOISSON;
   if (cpoisson && !a->count_sum) {
     set_error("the constrained Poisson likelihood needs scvae_step_args.count_sum");
     return -1;
   }
   const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
                      !a->p_x_mean && KM == 0 &&
-                     (!head_drop || heads_fused_dropout_ok(p, n_iw)) &&
-                     (c.likelihood <= LK_ZINB || c.likelihood == LK_BERNOULLI);
+                     (!head_drop || (heads_fused_dropout_ok(p, n_iw) && !cpoisson)) &&
+                     (c.likelihood <= LK_ZINB || c.likelihood == LK_BERNOULLI ||
+                      (cpoisson && decoder_fused_cpoisson_supported(h1)));
   if (p->x_u16 && !fused) {
     set_error("the uint16 minibatch needs the fused likelihood kernels (no -k / constrained "
               "Poisson, evaluation statistics, or head dropout outside the bf16x9 kernel)");
@@ -869,6 +871,9 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     if ((rc = heads_forward(p, s, dch, ld, R, training, head_in))) return rc;
   // per-row log-likelihood, forward only
   auto loglik_forward = [&]() -> int {
+    if (fused && cpoisson)
+      return decoder_fused_cpoisson(s, false, dch, R, h1, hp, F, tg, B, nullptr, a->count_sum,
+                                    a->row_const, p->ll, nullptr, p->fused_ws);
     if (fused)
       return decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, tg, B, a->row_const, p->ll,
                                    p->fused_ws);
@@ -939,10 +944,13 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     HeadDropout hdrop;
     if (head_drop)
       if ((rc = heads_dropout_inputs(p, s, dch, ld, R, &hdrop))) return rc;
-    if ((rc = decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, tg, B, p->gw,
-                                  a->row_const, p->ll, dcur, p->fused_ws, false,
-                                  head_drop ? &hdrop : nullptr)))
-      return rc;
+    if (cpoisson)
+      rc = decoder_fused_cpoisson(s, true, dch, R, h1, hp, F, tg, B, p->gw, a->count_sum,
+                                  a->row_const, p->ll, dcur, p->fused_ws);
+    else
+      rc = decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, tg, B, p->gw, a->row_const,
+                               p->ll, dcur, p->fused_ws, false, head_drop ? &hdrop : nullptr);
+    if (rc) return rc;
   } else {
     if (KM > 0)
       rc = loglik_cat_bwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->gw,

@@ -343,14 +343,17 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   // (dropout: every head draws its own mask of the decoder output: the bf16x9 kernel's DROP
   //  instantiation, or the unfused path)
   const bool head_drop = training && p->heads[0].keep > 0.f;
-  const bool cpoisson = c.likelihood == LK_CPOISSON;   // row softmax: unfused
+  // row softmax: three passes of the bf16x9 head kernel (decoder_fused_cpoisson), or unfused
+  const bool cpoisson = c.likelihood == LK_CPOISSON;
   if (cpoisson && !a->count_sum) {
     set_error("the constrained Poisson likelihood needs scvae_step_args.count_sum");
     return -1;
   }
   const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
-                     !a->p_x_mean && KM == 0 && (!head_drop || heads_fused_dropout_ok(p, 1)) &&
-                     (c.likelihood <= LK_ZINB || c.likelihood == LK_BERNOULLI);
+                     !a->p_x_mean && KM == 0 &&
+                     (!head_drop || (heads_fused_dropout_ok(p, 1) && !cpoisson)) &&
+                     (c.likelihood <= LK_ZINB || c.likelihood == LK_BERNOULLI ||
+                      (cpoisson && decoder_fused_cpoisson_supported(h1)));
   if (p->x_u16 && !fused) {
     set_error("the uint16 minibatch needs the fused likelihood kernels (no -k / constrained "
               "Poisson, evaluation statistics, or head dropout outside the bf16x9 kernel)");
@@ -399,7 +402,10 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const float thr = c.free_nats_proportion * p_y_entropy;
   const int use_free_nats = c.free_nats_proportion != 0.f;
   if (!training) {
-    if (fused)
+    if (fused && cpoisson)
+      TRY(decoder_fused_cpoisson(s, false, dch, R, h1, hp, F, tg, B, nullptr, a->count_sum,
+                                 a->row_const, p->ll, nullptr, p->fused_ws));
+    else if (fused)
       TRY(decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, tg, B, a->row_const, p->ll,
                                 p->fused_ws));
     else if (KM > 0)
@@ -424,8 +430,12 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   if (fused) {
     HeadDropout hdrop;
     if (head_drop) TRY(heads_dropout_inputs(p, s, dch, ld, R, &hdrop));
-    TRY(decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, tg, B, p->gw, a->row_const, p->ll,
-                            dcur, p->fused_ws, false, head_drop ? &hdrop : nullptr));
+    if (cpoisson)
+      TRY(decoder_fused_cpoisson(s, true, dch, R, h1, hp, F, tg, B, p->gw, a->count_sum,
+                                 a->row_const, p->ll, dcur, p->fused_ws));
+    else
+      TRY(decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, tg, B, p->gw, a->row_const,
+                              p->ll, dcur, p->fused_ws, false, head_drop ? &hdrop : nullptr));
   } else if (KM > 0) {
     TRY(loglik_cat_bwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->gw, p->ll, R, B, F));
   } else if (cpoisson) {

@@ -34,10 +34,15 @@ def _skip_bias(name):
             "ENCODER" in name or "DECODER" in name))
 
 
-@pytest.mark.parametrize("n_iw,n_mc,F", [(1, 1, 130), (2, 2, 77), (1, 1, 1100)])
-def test_vae_step_matches_oracle(cuda_device, n_iw, n_mc, F):
+@pytest.mark.parametrize("n_iw,n_mc,F,H,B", [
+    (1, 1, 130, (18, 14), 21), (2, 2, 77, (18, 14), 21),
+    (1, 1, 1100, (18, 14), 21),
+    # several row tiles and strips of the three-pass head kernel, decoder
+    # widths 100 and 40
+    (1, 1, 700, (100, 40), 300), (2, 1, 333, (40, 24), 150)])
+def test_vae_step_matches_oracle(cuda_device, n_iw, n_mc, F, H, B):
     from scvae_amd.engine import Engine
-    L, H, B = 5, (18, 14), 21
+    L = 5
     S = n_iw * n_mc
     eng = Engine(F, L, H, "constrained poisson", device=cuda_device)
     assert "X_TILDE/LAMBDA/DENSE/weights" in eng.named_parameters()
@@ -75,6 +80,20 @@ def test_vae_step_matches_oracle(cuda_device, n_iw, n_mc, F):
         if _skip_bias(name):
             continue
         _close(g.cpu(), grads[name], rtol=2e-4, what="grad " + name)
+
+    # evaluation, likelihood only (the forward passes of the fused kernel)
+    moving_now = {k: v.detach().cpu().double()
+                  for k, v in eng.named_moving_statistics().items()}
+    ll_e = torch.zeros(S * B, device=cuda_device)
+    sc = eng.step(xd, xd, eps=eps.float().to(cuda_device), training=False,
+                  n_iw=n_iw, n_mc=n_mc, count_sum=csd,
+                  outputs={"log_p_x_given_z": ll_e}).cpu().numpy()
+    out_e = om.vae_forward(cfg, params, moving_now, x, x, eps, False,
+                           count_sum=count_sum)
+    _close(sc[0], out_e["lower_bound"], what="lower_bound (evaluation)")
+    close_elementwise(ll_e, out_e["log_p_x_given_z"].reshape(-1),
+                      rtol=LL_RTOL, atol=LL_ATOL,
+                      what="per-cell ll (evaluation)")
 
     # evaluation with the reconstruction statistics (mean = variance = rate)
     moving = {k: v.detach().cpu().double()

@@ -1,6 +1,7 @@
 """A 4096-cell training step of the headline architecture with the Poisson likelihood (fused head
-kernel) and the constrained Poisson likelihood (softmax over the genes x count sum: unfused GEMMs +
-element-wise kernels), fp32 minibatch resident.  MI355X, closing build of round 3: 1.87 / 3.13 ms.
+kernel) and the constrained Poisson likelihood (softmax over the genes x count sum: three passes of the
+head kernel; before that unfused GEMMs + element-wise kernels), fp32 minibatch resident.  MI355X,
+closing build of round 3: 1.83 / 2.35 ms (unfused: 3.13).
     python tools/bench_cpoisson.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
