@@ -283,7 +283,8 @@ typedef struct scvae_step_args {
 int scvae_plan_step(scvae_plan* plan, const scvae_step_args* args, void* stream);
 /* 1 if a step of `cells` cells of this plan can take its minibatch as uint16 counts
  * (training: 0 = evaluation step, 1 = training step, 2 = training step without importance
- * weighting, n_iw == 1): a plan on the fused likelihood kernels (no -k / constrained Poisson, no
+ * weighting, n_iw == 1): a plan on the fused likelihood kernels (the four count likelihoods, or
+ * the constrained Poisson one under the bf16x9 head arithmetic; no -k, no
  * evaluation statistics requested; while training no dropout on the input layer, and dropout of
  * the likelihood heads only with training == 2 under the bf16x9 head arithmetic),
  * the layer that sees x at most 128 units wide, the count kernels enabled, and a minibatch large

@@ -1372,7 +1372,12 @@ int scvae_plan_accepts_counts_u16(const scvae_plan* p, int64_t cells, int32_t tr
   const scvae_model_config& c = p->cfg;
   const bool gm = c.model_type == SCVAE_MODEL_GMVAE;
   if (!p->use_count_gemm || !p->use_fused || !p->fused_ws) return 0;
-  if (c.likelihood > scvae::LK_ZINB || c.k_max > 0) return 0;
+  if (c.k_max > 0) return 0;
+  if (c.likelihood > scvae::LK_ZINB &&
+      !(c.likelihood == scvae::LK_CPOISSON &&
+        scvae::decoder_fused_cpoisson_supported(p->heads[0].n_in) &&
+        !(training && p->heads[0].keep > 0.f)))
+    return 0;
   if (!scvae::decoder_fused_supported(p->heads[0].n_in)) return 0;
   // the layers that see x: the VAE's first encoder layer (or the posterior heads of a model
   // without hidden layers); the GMVAE's first q(y|x) and q(z|x,y) layers

@@ -116,6 +116,48 @@ def test_vae_step_matches_oracle(cuda_device, n_iw, n_mc, F, H, B):
                  n_iw=n_iw, n_mc=n_mc)
 
 
+def test_uint16_minibatch_is_the_fp32_step_bit_for_bit(cuda_device):
+    """The constrained Poisson step on the uint16 minibatch (the three passes of
+    the head kernel read their targets as uint16, the input layer runs on the
+    count kernels): identical bits to the fp32 batch."""
+    import scipy.sparse as sp
+    from scvae_amd.engine import Engine
+    from scvae_amd.minibatch import DeviceCSR
+    F, L, H, B = 1300, 6, (100, 48), 200
+    rng = np.random.default_rng(29)
+    dense = _counts(rng, 400, F)
+    csr = DeviceCSR.from_scipy(sp.csr_matrix(dense), cuda_device)
+    rows = torch.from_numpy(rng.permutation(400)[:B]).to(cuda_device)
+    x32 = csr.gather_dense(rows)
+    rc16 = torch.zeros(B, device=cuda_device)
+    x16 = csr.gather_counts_u16(rows, row_const_out=rc16)
+    cs = x32.sum(dim=1)
+    eps = torch.from_numpy(rng.standard_normal((1, B, L)).astype(np.float32)
+                           ).to(cuda_device)
+    results = []
+    for u16 in (False, True):
+        eng = Engine(F, L, H, "constrained poisson", batch_norm=True,
+                     device=cuda_device, seed=1)
+        eng.set_count_gemm(True, always=True)
+        assert eng.accepts_counts_u16(B, True) and eng.accepts_counts_u16(B, False)
+        x = x16 if u16 else x32
+        out = []
+        for _ in range(2):
+            ll = torch.zeros(B, device=cuda_device)
+            s = eng.step(x, x, eps=eps, training=True, row_const=rc16,
+                         x_counts=True, count_sum=cs,
+                         outputs={"log_p_x_given_z": ll}).clone()
+            eng.adam_step(1e-3)
+            out += [s, ll.clone()]
+        ev = eng.step(x, x, eps=eps, training=False, row_const=rc16,
+                      x_counts=True, count_sum=cs).clone()
+        torch.cuda.synchronize()
+        results.append([t.cpu() for t in out + [ev, eng.grads, eng.moving,
+                                                eng.params]])
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+
+
 def test_gmvae_step_matches_oracle(cuda_device):
     from scvae_amd.engine import Engine
     F, L, H, B, K = 90, 4, (16,), 19, 3
