@@ -298,7 +298,7 @@ def time_dominant_kernel(engine, rows, launches=10, u16=False, arith=None):
     flops = 2.0 * rows * F * P * 3 * H
     # the instantiation as rocprofv3 prints it
     if which == 3:
-        kernel = "decoder_head3_kernel<{}, {}, {}, true>".format(
+        kernel = "decoder_head3_kernel<{}, {}, {}, true, false, 0>".format(
             kind, ((H + 1 + 15) // 16 * 16 + 31) // 32, "true" if u16 else "false")
         peak, arith_name = PEAK_BF16_MFMA_TFLOPS / 9.0, "bf16x9-exact"
     elif which == 2:
