@@ -228,8 +228,8 @@ def time_dominant_kernel(engine, rows, launches=10, u16=False, arith=None):
     the step's own shapes (main kernel only, without its small reductions,
     so that the figure matches rocprofv3's per-kernel average).  ``u16``: the
     targets as the uint16 minibatch, as the step launches it.  ``arith``: 0 =
-    the fp32-MFMA kernel, 1 = the exact nine-term bf16 kernel, None = whatever
-    the step runs (the process-wide setting)."""
+    the fp32-MFMA kernel, 1 = the exact nine-term bf16 kernel, None = what the
+    engine's plan runs (the arithmetic travels with each call)."""
     import torch
     from scvae_amd import _lib
     lib = engine.lib
@@ -258,6 +258,9 @@ def time_dominant_kernel(engine, rows, launches=10, u16=False, arith=None):
         return (ctypes.c_void_p * len(ts))(*[x.data_ptr() for x in ts])
     aW, ab, adW, adb = arr(W), arr(b), arr(dW), arr(db)
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    if arith is None:
+        arith = 1 if engine.head_arith == "bf16x9" else 0
+    flag = _lib.HEADS_BF16X9 if arith else _lib.HEADS_FP32
 
     if u16:
         ld = (F + 63) // 64 * 64
@@ -268,45 +271,41 @@ def time_dominant_kernel(engine, rows, launches=10, u16=False, arith=None):
     def launch():
         if u16:
             _lib.check(lib.scvae_decoder_fused_u16(
-                kind, 3, d.data_ptr(), rows, H, aW, ab, adW, adb, F,
+                kind, 3 | flag, d.data_ptr(), rows, H, aW, ab, adW, adb, F,
                 t16.data_ptr(), ld, rows, gw.data_ptr(), rc.data_ptr(),
                 ll.data_ptr(), dd.data_ptr(), ws.data_ptr(), stream),
                 "scvae_decoder_fused_u16")
             return
         _lib.check(lib.scvae_decoder_fused(
-            kind, 3, d.data_ptr(), rows, H, aW, ab, adW, adb, F, t.data_ptr(),
+            kind, 3 | flag, d.data_ptr(), rows, H, aW, ab, adW, adb, F, t.data_ptr(),
             rows, gw.data_ptr(), rc.data_ptr(), ll.data_ptr(), dd.data_ptr(),
             ws.data_ptr(), stream), "scvae_decoder_fused")
-    setting = lib.scvae_decoder_head_arith()
-    if arith is not None:
-        lib.scvae_set_decoder_head_arith(arith)
-    try:
-        which = lib.scvae_decoder_train_kernel(kind, H)
-        for _ in range(3):
-            launch()
-        torch.cuda.synchronize(dev)
-        start, stop = torch.cuda.Event(True), torch.cuda.Event(True)
-        start.record()
-        for _ in range(launches):
-            launch()
-        stop.record()
-        torch.cuda.synchronize(dev)
-    finally:
-        lib.scvae_set_decoder_head_arith(setting)
+    which = lib.scvae_decoder_train_kernel(kind, H, arith)
+    buf = ctypes.create_string_buffer(128)
+    _lib.check(lib.scvae_decoder_train_kernel_name(kind, H, arith, 1 if u16 else 0,
+                                                   buf, 128),
+               "scvae_decoder_train_kernel_name")
+    kernel = buf.value.decode()
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize(dev)
+    start, stop = torch.cuda.Event(True), torch.cuda.Event(True)
+    start.record()
+    for _ in range(launches):
+        launch()
+    stop.record()
+    torch.cuda.synchronize(dev)
     seconds = start.elapsed_time(stop) / 1e3 / launches
     # algorithmic flops of the decoder heads: forward + dW + dX, 2 flop / MAC
     flops = 2.0 * rows * F * P * 3 * H
     # the instantiation as rocprofv3 prints it
     if which == 3:
-        kernel = "decoder_head3_kernel<{}, {}, {}, true, false, 0>".format(
-            kind, ((H + 1 + 15) // 16 * 16 + 31) // 32, "true" if u16 else "false")
         peak, arith_name = PEAK_BF16_MFMA_TFLOPS / 9.0, "bf16x9-exact"
-    elif which == 2:
-        rem = P <= 2 and 96 < H <= 111 and rows >= 512
-        kernel = "decoder_head2_kernel<{}, true, {}>".format(kind, "true" if rem else "false")
-        peak, arith_name = PEAK_FP32_MFMA_TFLOPS, "f32"
     else:
-        kernel = "decoder_head_kernel<{}, true, {}>".format(kind, 32 if P >= 3 else 64)
+        if which == 2:
+            rem = P <= 2 and 96 < H <= 111 and rows >= 512
+            kernel = "decoder_head2_kernel<{}, true, {}>".format(
+                kind, "true" if rem else "false")
         peak, arith_name = PEAK_FP32_MFMA_TFLOPS, "f32"
     return {
         "kernel": "{} (X_TILDE heads + likelihood + dW/db/dd, "
@@ -679,6 +678,9 @@ def main():
         # arithmetic of the decoder heads' three products in the training kernel
         result["decoder_head_arith"] = result["roofline"]["arith"]
         if result["roofline"]["arith"] != "f32":
+            # (the arithmetic type the path computes in: fp32 values, fp32 accumulation; the
+            #  heads' products are issued as exact bf16 terms on the bf16 matrix cores)
+            result["dtype"] = "f32 ({} heads)".format(result["roofline"]["arith"])
             # the fp32-MFMA kernel on the same shapes, for comparison (not what the step ran)
             result["roofline_fp32_kernel"] = time_dominant_kernel(
                 engine, B * K, u16=work.u16, arith=0)

@@ -136,6 +136,11 @@ int scvae_plan_set_sync(scvae_plan* plan, scvae_sync_fn fn, void* user);
  * 0: separate GEMM and likelihood kernels (same results; kept for A/B tests and for the
  * evaluate-time statistics, which need the materialised pre-activations) */
 int scvae_plan_set_fused(scvae_plan* plan, int32_t enabled);
+/* Arithmetic of this plan's fused head kernels (see scvae_default_head_arith below): 0 fp32
+ * matrix cores, 1 the exact nine-term bf16 split.  Affects which kernels the step launches and
+ * what scvae_plan_accepts_counts_u16 answers; call it before the first step. */
+int scvae_plan_set_head_arith(scvae_plan* plan, int32_t mode);
+int32_t scvae_plan_head_arith(const scvae_plan* plan);
 /* The exact bf16-split kernels for products with a count matrix: 1 (default) where they pay
  * (minibatches from a few hundred cells upwards, see plan_gemm), 2 always, 0 never -- those
  * products then take the fp32 MFMA kernels even when scvae_step_args.x_counts is set (A/B
@@ -350,21 +355,29 @@ int64_t scvae_decoder_fused_workspace_bytes(int64_t rows, int64_t H, int64_t F);
  * 2 = decoder_head2_kernel (two pipelined halves), 1 = decoder_head_kernel, 0 = unsupported H
  * (the step then uses the unfused GEMM + likelihood kernels) */
 int32_t scvae_decoder_fused_variant(int32_t kind, int64_t H);
-/* Arithmetic of the three products (va:2466-2489 and their backward) inside the fused TRAINING
- * kernel: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32), 1 = the bf16 matrix cores in the
+/* Arithmetic of the three products (va:2466-2489 and their backward) inside the fused head
+ * kernels: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32), 1 = the bf16 matrix cores in the
  * exact nine-term form -- every fp32 operand cut exactly into three bf16 terms, all nine
  * products of a pair (each exact in fp32) accumulated in fp32 -- where that kernel applies (up
  * to three heads, hidden width within its LDS budget; otherwise the fp32 kernel runs).
  * Forward-only calls (train = 0, evaluation steps) of one- and two-head likelihoods follow the
  * same setting (the forward instantiation of the same kernel); three heads evaluate on the fp32
  * matrix cores.
- * Process-wide; the initial value comes from SCVAE_HEAD_ARITH=fp32|bf16x9.
- * scvae_decoder_train_kernel: which kernel a training launch takes under the current setting:
- * 1 / 2 = scvae_decoder_fused_variant's fp32 schedules, 3 = decoder_head3_kernel (bf16x9),
+ * There is no process-wide switch: a plan carries its arithmetic (scvae_plan_set_head_arith,
+ * below), the stand-alone entry takes it per call in `train`.  scvae_default_head_arith: what a
+ * new plan and a call without an arithmetic flag start from -- 1, or SCVAE_HEAD_ARITH=fp32|bf16x9
+ * of the environment, read once.
+ * scvae_decoder_train_kernel: which kernel a training launch takes under `arith`:
+ * 1 / 2 = scvae_decoder_fused_variant's fp32 schedules, 3 = decoder_fused3.hip (bf16x9),
  * 0 = unsupported H. */
-int32_t scvae_decoder_head_arith(void);
-int scvae_set_decoder_head_arith(int32_t mode);
-int32_t scvae_decoder_train_kernel(int32_t kind, int64_t H);
+int32_t scvae_default_head_arith(void);
+int32_t scvae_decoder_train_kernel(int32_t kind, int64_t H, int32_t arith);
+/* the instantiation of that training kernel as a profiler prints it (u16: uint16 targets) */
+int scvae_decoder_train_kernel_name(int32_t kind, int64_t H, int32_t arith, int32_t u16, char* out,
+                                    int64_t n);
+/* flags of scvae_decoder_fused's / scvae_decoder_fused_u16's `train` (or'ed to 0 / 1 / 3) */
+#define SCVAE_HEADS_FP32 0x100
+#define SCVAE_HEADS_BF16X9 0x200
 int scvae_decoder_fused(int32_t kind, int32_t train, const float* d, int64_t rows, int64_t H,
                         const float* const* W, const float* const* b, float* const* dW,
                         float* const* db, int64_t F, const float* t, int64_t cells,

@@ -19,6 +19,9 @@ MAX_HIDDEN = 8
 NAME_MAX = 96
 
 POISSON, NB, ZIP, ZINB, CONSTRAINED_POISSON, BERNOULLI = 0, 1, 2, 3, 4, 5
+#: flags of scvae_decoder_fused's ``train`` argument: the arithmetic of that call
+HEADS_FP32, HEADS_BF16X9 = 0x100, 0x200
+HEAD_ARITH_FLAGS = {"fp32": HEADS_FP32, "bf16x9": HEADS_BF16X9}
 MODEL_VAE, MODEL_GMVAE = 0, 1
 
 #: registry name -> (kind, head parameter names in registry order)
@@ -143,6 +146,8 @@ SIGNATURES = {
         c_int64]),
     "scvae_plan_set_sync": (c_int32, [c_void_p, SYNC_FN, c_void_p]),
     "scvae_plan_set_fused": (c_int32, [c_void_p, c_int32]),
+    "scvae_plan_set_head_arith": (c_int32, [c_void_p, c_int32]),
+    "scvae_plan_head_arith": (c_int32, [c_void_p]),
     "scvae_plan_set_count_gemm": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_set_bn_one_launch": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_set_mid_chain": (c_int32, [c_void_p, c_int32]),
@@ -185,9 +190,10 @@ SIGNATURES = {
     "scvae_decoder_fused_workspace_bytes": (c_int64, [c_int64, c_int64,
                                                       c_int64]),
     "scvae_decoder_fused_variant": (c_int32, [c_int32, c_int64]),
-    "scvae_decoder_head_arith": (c_int32, []),
-    "scvae_set_decoder_head_arith": (c_int32, [c_int32]),
-    "scvae_decoder_train_kernel": (c_int32, [c_int32, c_int64]),
+    "scvae_default_head_arith": (c_int32, []),
+    "scvae_decoder_train_kernel": (c_int32, [c_int32, c_int64, c_int32]),
+    "scvae_decoder_train_kernel_name": (c_int32, [c_int32, c_int64, c_int32, c_int32,
+                                                   c_char_p, c_int64]),
     "scvae_plan_prior_offset": (c_int64, [c_void_p]),
     "scvae_plan_decode": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p,
                                     c_void_p]),

@@ -103,15 +103,20 @@ __device__ __forceinline__ float fast_log1p(float x) {
   const float d = u - 1.f;
   return d == 0.f ? x : fast_log(u) * (x * fast_rcp(d));
 }
-// log(sigmoid(a)), log(sigmoid(-a)) and sigmoid(a) from one exp and one log
+// log(sigmoid(a)), log(sigmoid(-a)), sigmoid(a) and sigmoid(-a) from one exp and one log.
+// sigmoid(-a) is formed on its own, not as 1 - sigmoid(a): for a >~ 8 that difference loses
+// most of its bits (p = 0.99995 at a = 10: 1.f - p carries a relative error of 1e-3), and the
+// gradient of a saturated head is t (1 - p) - r p (tests/test_gpu_head_edges.py)
 __device__ __forceinline__ void log_sigmoid_pair(float a, float& ls_pos, float& ls_neg,
-                                                 float& sig) {
+                                                 float& sig, float& sig_neg) {
   const float e = __expf(-fabsf(a));
   const float l = fast_log1p(e);
   ls_pos = fminf(a, 0.f) - l;
   ls_neg = fminf(-a, 0.f) - l;
   const float s = fast_rcp(1.f + e);
-  sig = a >= 0.f ? s : e * s;
+  const float es = e * s;
+  sig = a >= 0.f ? s : es;
+  sig_neg = a >= 0.f ? es : s;
 }
 __device__ __forceinline__ float log_sigmoid(float a) {
   return fminf(a, 0.f) - fast_log1p(__expf(-fabsf(a)));
@@ -151,6 +156,26 @@ __device__ __forceinline__ void lgamma_digamma_diff_small(float r, float t, floa
   for (int i = 0; i < 8; ++i) {
     const float f = r + (float)i;
     const bool on = (float)i < t;
+    if (WITH_D) Q = on ? fmaf(Q, f, P) : Q;
+    P = on ? P * f : P;
+  }
+  A = fast_log(P);
+  D = WITH_D ? Q * fast_rcp(P) : 0.f;
+}
+
+// The same for a whole wave inside a non-zero walk: the product runs only as far as the largest t
+// among the lanes (the step's own comparison is the loop condition: no extra vector instruction),
+// which for count data is 2-5 steps instead of 8.  Identical bits to lgamma_digamma_diff_small
+// (a lane's skipped steps are the ones that leave its P and Q unchanged).
+template <bool WITH_D>
+__device__ __forceinline__ void lgamma_digamma_diff_small_wave(float r, float t, float& A,
+                                                               float& D) {
+  float P = 1.f, Q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const bool on = (float)i < t;
+    if (__builtin_amdgcn_ballot_w64(on) == 0) break;
+    const float f = r + (float)i;
     if (WITH_D) Q = on ? fmaf(Q, f, P) : Q;
     P = on ? P * f : P;
   }

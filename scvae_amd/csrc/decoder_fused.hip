@@ -624,21 +624,20 @@ int decoder_fused_variant(int P, int H) {
   return (decoder_variant() == 2 && decoder_fused2_supported(P, H)) ? 2 : 1;
 }
 
-// Arithmetic of the three products of the TRAINING kernel: 0 = fp32 MFMA (decoder_fused.hip /
-// decoder_fused2.hip), 1 = the exact nine-term bf16 split (decoder_fused3.hip) where that kernel
-// applies (one / two heads, its LDS budget).  Process-wide; default bf16x9, SCVAE_HEAD_ARITH=fp32
-// starts a process on the fp32 kernels.
-static int g_head_arith = -1;
-int decoder_head_arith() {
-  if (g_head_arith < 0) {
+// Arithmetic of the three products of the fused head kernels (`arith` of every entry below):
+// 0 = fp32 MFMA (decoder_fused.hip / decoder_fused2.hip), 1 = the exact nine-term bf16 split
+// (decoder_fused3.hip) where that kernel applies (its LDS budget).  A plan carries its own
+// (scvae_plan_set_head_arith); the default of a new plan and of the stand-alone entry is bf16x9,
+// or what SCVAE_HEAD_ARITH=fp32 says -- read once, never written again: no mutable process state.
+int default_head_arith() {
+  static const int v = [] {
     const char* e = getenv("SCVAE_HEAD_ARITH");
-    g_head_arith = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : 1;   // default: bf16x9
-  }
-  return g_head_arith;
+    return (e && (e[0] == 'f' || e[0] == '0')) ? 0 : 1;   // default: bf16x9
+  }();
+  return v;
 }
-void set_decoder_head_arith(int mode) { g_head_arith = mode ? 1 : 0; }
-int decoder_train_kernel(int P, int H) {
-  if (decoder_head_arith() == 1 && decoder_fused3_supported(P, H)) return 3;
+int decoder_train_kernel(int P, int H, int arith) {
+  if (arith == 1 && decoder_fused3_supported(P, H)) return 3;
   return decoder_fused_variant(P, H);
 }
 
@@ -661,10 +660,10 @@ bool decoder_fused_probe_recorded() { return g_probe_recorded; }
 template <bool TRAIN>
 static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                           int F, Targets t, int B, const float* gw, int inline_lgamma,
-                          float* ll_part, float* dd_part, float* planes = nullptr,
+                          float* ll_part, float* dd_part, int arith, float* planes = nullptr,
                           const HeadDropout* drop = nullptr) {
   const int P = likelihood_heads(kind);
-  if (TRAIN && planes && decoder_train_kernel(P, H) == 3) {
+  if (TRAIN && planes && decoder_train_kernel(P, H, arith) == 3) {
     static const int dbg = [] { const char* e = getenv("SCVAE_D3_DEBUG"); return e ? atoi(e) : 0; }();
     return decoder_fused3_launch(s, true, kind, d, rows, H, hp, F, t, B, gw,
                                  inline_lgamma | (dbg << 8), ll_part, dd_part, planes, drop);
@@ -704,7 +703,7 @@ static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int
 // Forward only (is_training=False / importance-weight pass): ll[rows]
 int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                           int F, Targets t, int B, const float* row_const, float* ll,
-                          float* workspace) {
+                          float* workspace, int arith) {
   SCVAE_ARG(d && t.p && ll && workspace && decoder_fused_supported(H));
   if (rows == 0) return 0;
   int strips = (F + DF_BN - 1) / DF_BN;
@@ -726,7 +725,7 @@ int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int
   }();
   const int heads = likelihood_heads(kind);
   int which = decoder_forward_supported(heads, H) ? 1 : 0;
-  if (decoder_head_arith() == 1 && heads <= 2 && decoder_fused3_supported(heads, H)) which = 3;
+  if (arith == 1 && heads <= 2 && decoder_fused3_supported(heads, H)) which = 3;
   if (forced == 0) which = 0;
   if (forced == 1 && decoder_forward_supported(heads, H)) which = 1;
   int rc;
@@ -740,7 +739,7 @@ int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int
     rc = decoder_forward_launch(s, kind, d, rows, H, hp, F, t, B, inline_lgamma, ll_part);
   } else {
     rc = launch_decoder<false>(s, kind, d, rows, H, hp, F, t, B, nullptr, inline_lgamma, ll_part,
-                               nullptr);
+                               nullptr, arith);
   }
   if (rc) return rc;
   hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 15) / 16), dim3(1024), 0, s, ll_part, strips,
@@ -781,8 +780,8 @@ __global__ __launch_bounds__(256) void lse_reduce_kernel(const float* __restrict
   lse[r] = M + __logf(se);
 }
 
-bool decoder_fused_cpoisson_supported(int H) {
-  return decoder_fused_supported(H) && decoder_head_arith() == 1 && decoder_fused3_supported(1, H);
+bool decoder_fused_cpoisson_supported(int H, int arith) {
+  return decoder_fused_supported(H) && arith == 1 && decoder_fused3_supported(1, H);
 }
 
 // Constrained Poisson through the bf16x9 head kernel: three passes over the strip grid (an
@@ -792,7 +791,7 @@ int decoder_fused_cpoisson(hipStream_t s, bool train, const float* d, int rows, 
                            HeadParams hp, int F, Targets t, int B, const float* gw,
                            const float* count_sum, const float* row_const, float* ll, float* dd,
                            float* workspace) {
-  SCVAE_ARG(d && t.p && ll && workspace && count_sum && decoder_fused_cpoisson_supported(H));
+  SCVAE_ARG(d && t.p && ll && workspace && count_sum && decoder_fused_cpoisson_supported(H, 1));
   SCVAE_ARG(!train || (gw && dd));
   if (rows == 0) return 0;
   const int strips = (F + DF_BN - 1) / DF_BN;     // (one head: 64-gene strips)
@@ -849,12 +848,13 @@ int decoder_fused_cpoisson(hipStream_t s, bool train, const float* d, int rows, 
 // Forward + backward: ll[rows], dW_j, db_j (in hp), dd[rows, H]
 int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                         int F, Targets t, int B, const float* gw, const float* row_const,
-                        float* ll, float* dd, float* workspace, bool kernel_only,
+                        float* ll, float* dd, float* workspace, int arith, bool kernel_only,
                         const HeadDropout* drop) {
   SCVAE_ARG(d && t.p && gw && ll && dd && workspace && decoder_fused_supported(H));
   if (rows == 0) return 0;
   const int heads = likelihood_heads(kind);
-  const int bn = decoder_train_kernel(heads, H) == 3 ? decoder_fused3_strip_genes(heads) : DF_BN;
+  const int bn = decoder_train_kernel(heads, H, arith) == 3 ? decoder_fused3_strip_genes(heads)
+                                                            : DF_BN;
   const int strips = (F + bn - 1) / bn;
   float* ll_part = workspace;
   size_t off = ((size_t)strips * rows + 63) / 64 * 64;
@@ -862,14 +862,14 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
   float* planes = dd_part + ((size_t)strips * rows * ((H + 3) / 4 * 4) + 63) / 64 * 64;
   int rc = launch_decoder<true>(s, kind, d, rows, H, hp, F, t, B, gw,
                                 (row_const || kind == LK_BERNOULLI) ? 0 : 1, ll_part, dd_part,
-                                planes, drop);
+                                arith, planes, drop);
   if (rc) return rc;
   if (kernel_only) return 0;  // profiling aid: leave the per-strip partials unreduced
   hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 15) / 16), dim3(1024), 0, s, ll_part,
                      strips, rows, row_const, B, ll);
   SCVAE_LAUNCH_CHECK("ll_reduce_kernel");
   const size_t n = (size_t)rows * H;
-  if (decoder_train_kernel(likelihood_heads(kind), H) == 3) {
+  if (decoder_train_kernel(likelihood_heads(kind), H, arith) == 3) {
     // quad slabs of decoder_head3_kernel
     const size_t n4 = (size_t)((H + 3) / 4) * rows;
     if (n4 <= DD_SPLIT_MAX) {

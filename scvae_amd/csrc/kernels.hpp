@@ -280,18 +280,21 @@ size_t decoder_fused2_lds_bytes(int P, int H);
 int decoder_fused2_launch(hipStream_t s, bool train, int kind, const float* d, int rows, int H,
                           HeadParams hp, int F, Targets t, int B, const float* gw,
                           int inline_lgamma, float* ll_part, float* dd_part);
+// arith: 0 fp32 MFMA, 1 the exact nine-term bf16 split where decoder_fused3 applies
 int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                           int F, Targets t, int B, const float* row_const, float* ll,
-                          float* workspace);
+                          float* workspace, int arith);
 int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                         int F, Targets t, int B, const float* gw, const float* row_const,
-                        float* ll, float* dd, float* workspace, bool kernel_only = false,
+                        float* ll, float* dd, float* workspace, int arith,
+                        bool kernel_only = false,
                         const HeadDropout* drop = nullptr);   // drop: bf16x9 kernel only
 
 // training kernel on the bf16 matrix cores, exact nine-term split (decoder_fused3.hip)
 bool decoder_fused3_supported(int P, int H);
 size_t decoder_fused3_lds_bytes(int P, int H);
 int decoder_fused3_strip_genes(int P);   // genes per workgroup (= per slab of ll_part / dd_part)
+int decoder_fused3_train_kernel_name(int kind, int H, bool u16, char* out, size_t n);
 size_t decoder_fused3_workspace_floats(int rows);
 // (train = false: the forward half alone, one- and two-head likelihoods; gw / dd_part unused)
 // drop (training only): dropout of the heads' input connections inside the kernel
@@ -303,7 +306,7 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
 // Constrained Poisson (du:218-228) through the bf16x9 head kernel in three passes over the strip
 // grid (row maximum / sum of exponentials | log-likelihood and S | gradients): ll[rows] and, with
 // train, dW / db (in hp) and dd[rows, H].  workspace: decoder_fused_workspace_floats(.., true).
-bool decoder_fused_cpoisson_supported(int H);
+bool decoder_fused_cpoisson_supported(int H, int arith);
 int decoder_fused_cpoisson(hipStream_t s, bool train, const float* d, int rows, int H,
                            HeadParams hp, int F, Targets t, int B, const float* gw,
                            const float* count_sum, const float* row_const, float* ll, float* dd,
@@ -311,9 +314,8 @@ int decoder_fused_cpoisson(hipStream_t s, bool train, const float* d, int rows, 
 void decoder_fused_set_probe(hipEvent_t before, hipEvent_t after);   // (nullptr, nullptr): off
 hipEvent_t decoder_fused_probe(int which);
 bool decoder_fused_probe_recorded();   // both events of the pair went into a stream
-int decoder_head_arith();              // 0: fp32 MFMA, 1: bf16x9 where decoder_fused3 applies
-void set_decoder_head_arith(int mode);
-int decoder_train_kernel(int P, int H);   // 1 / 2: the fp32 schedules, 3: decoder_head3_kernel
+int default_head_arith();   // SCVAE_HEAD_ARITH, read once: 0 fp32 MFMA, 1 (default) bf16x9
+int decoder_train_kernel(int P, int H, int arith);   // 1 / 2: the fp32 schedules, 3: decoder_fused3.hip
 
 // forward-only variant with the pre-activations in registers (decoder_forward.hip)
 bool decoder_forward_supported(int P, int H);

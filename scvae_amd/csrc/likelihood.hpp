@@ -35,10 +35,10 @@ __device__ __forceinline__ void lik_dense(float t, const float* a, float& lp, fl
                                           float& rgate) {
   if constexpr (KIND == LK_BERNOULLI) {
     // tfp.distributions.Bernoulli(logits): t log sigmoid(a) + (1 - t) log sigmoid(-a)
-    float ls_pos, ls_neg, sig;
-    log_sigmoid_pair(a[0], ls_pos, ls_neg, sig);
+    float ls_pos, ls_neg, sig, sig_neg;
+    log_sigmoid_pair(a[0], ls_pos, ls_neg, sig, sig_neg);
     lp = t * ls_pos + (1.f - t) * ls_neg;
-    if (GRAD) g[0] = t - sig;
+    if (GRAD) g[0] = t * sig_neg - (1.f - t) * sig;    // = t - sigmoid(a)
     r = 0.f; rgate = 0.f;
   } else if constexpr (KIND == LK_POISSON) {
     const float ll = fminf(fmaxf(a[0], -10.f), 10.f);
@@ -48,14 +48,14 @@ __device__ __forceinline__ void lik_dense(float t, const float* a, float& lp, fl
     r = 0.f; rgate = 0.f;
   } else if constexpr (KIND == LK_NB) {
     const float ap = fmaxf(a[0], LOGIT_OF_TINY);
-    float logp, log1mp, p;
-    log_sigmoid_pair(ap, logp, log1mp, p);
+    float logp, log1mp, p, q;                 // q = 1 - p
+    log_sigmoid_pair(ap, logp, log1mp, p, q);
     const float lr = fminf(fmaxf(a[1], -10.f), 10.f);
     r = __expf(lr);
     rgate = (a[1] >= -10.f && a[1] <= 10.f) ? 1.f : 0.f;
     lp = r * log1mp + t * logp;
     if (GRAD) {
-      g[0] = (a[0] >= LOGIT_OF_TINY) ? (t * (1.f - p) - r * p) : 0.f;
+      g[0] = (a[0] >= LOGIT_OF_TINY) ? (t * q - r * p) : 0.f;
       g[1] = rgate * r * log1mp;
     }
   } else {
@@ -68,8 +68,8 @@ __device__ __forceinline__ void lik_dense(float t, const float* a, float& lp, fl
       lik_dense<LK_NB, GRAD>(t, a + 1, lpb, gb, r, rgate);
     }
     const float api = fmaxf(a[0], LOGIT_OF_TINY);
-    float logpi, log1mpi, pi;
-    log_sigmoid_pair(api, logpi, log1mpi, pi);
+    float logpi, log1mpi, pi, qi;             // qi = 1 - pi
+    log_sigmoid_pair(api, logpi, log1mpi, pi, qi);
     const bool gate = a[0] >= LOGIT_OF_TINY;
     constexpr int NB_HEADS = (KIND == LK_ZIP) ? 1 : 2;
     if (t > 0.f) {
@@ -88,7 +88,7 @@ __device__ __forceinline__ void lik_dense(float t, const float* a, float& lp, fl
       if (GRAD) {
         const float u = __expf(u1 - y0);   // pi / (pi + (1-pi) e^lpb)
         const float w = __expf(u2 - y0);   // 1 - u
-        g[0] = gate ? (u * (1.f - pi) - w * pi) : 0.f;
+        g[0] = gate ? (u * qi - w * pi) : 0.f;
 #pragma unroll
         for (int j = 0; j < NB_HEADS; ++j) g[1 + j] = w * gb[j];
       }

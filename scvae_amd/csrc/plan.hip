@@ -474,7 +474,7 @@ int heads_backward(scvae_plan* p, hipStream_t s, const float* const (&head_in)[4
 // dropped-out copy of the decoder output per head (DROP instantiation).  Not with importance
 // weights (their separate forward pass has no such instantiation) nor on the fp32 head kernels.
 bool heads_fused_dropout_ok(scvae_plan* p, int n_iw) {
-  return n_iw == 1 && decoder_train_kernel(p->P, p->heads[0].n_in) == 3;
+  return n_iw == 1 && decoder_train_kernel(p->P, p->heads[0].n_in, p->head_arith) == 3;
 }
 int heads_dropout_inputs(scvae_plan* p, hipStream_t s, const float* dch, int ld, int R,
                          HeadDropout* out) {
@@ -858,7 +858,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                      !a->p_x_mean && KM == 0 &&
                      (!head_drop || (heads_fused_dropout_ok(p, n_iw) && !cpoisson)) &&
                      (c.likelihood <= LK_ZINB || c.likelihood == LK_BERNOULLI ||
-                      (cpoisson && decoder_fused_cpoisson_supported(h1)));
+                      (cpoisson && decoder_fused_cpoisson_supported(h1, p->head_arith)));
   if (p->x_u16 && !fused) {
     set_error("the uint16 minibatch needs the fused likelihood kernels (no -k / constrained "
               "Poisson, evaluation statistics, or head dropout outside the bf16x9 kernel)");
@@ -876,7 +876,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                                     a->row_const, p->ll, nullptr, p->fused_ws);
     if (fused)
       return decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, tg, B, a->row_const, p->ll,
-                                   p->fused_ws);
+                                   p->fused_ws, p->head_arith);
     if (KM > 0)
       return loglik_cat_fwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->ll, R, B, F);
     if (cpoisson)
@@ -949,7 +949,8 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                                   a->row_const, p->ll, dcur, p->fused_ws);
     else
       rc = decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, tg, B, p->gw, a->row_const,
-                               p->ll, dcur, p->fused_ws, false, head_drop ? &hdrop : nullptr);
+                               p->ll, dcur, p->fused_ws, p->head_arith, false,
+                               head_drop ? &hdrop : nullptr);
     if (rc) return rc;
   } else {
     if (KM > 0)
@@ -1181,6 +1182,7 @@ int scvae_plan_create(const scvae_model_config* cfg, scvae_plan** out) {
                 : (cfg->latent_mode == 0 || cfg->latent_mode == 4));
   for (int i = 0; i < 4; ++i) SCVAE_ARG(cfg->dropout_keep[i] >= 0.f && cfg->dropout_keep[i] <= 1.f);
   scvae_plan* p = new scvae_plan();
+  p->head_arith = scvae::default_head_arith();
   p->cfg = *cfg;
   p->P = scvae::likelihood_heads(cfg->likelihood);
   if (cfg->model_type == SCVAE_MODEL_GMVAE) scvae::build_gmvae(p);
@@ -1267,6 +1269,12 @@ int scvae_plan_set_fused(scvae_plan* p, int32_t enabled) {
   p->use_fused = enabled ? 1 : 0;
   return 0;
 }
+int scvae_plan_set_head_arith(scvae_plan* p, int32_t mode) {
+  SCVAE_ARG(p && (mode == 0 || mode == 1));
+  p->head_arith = mode;
+  return 0;
+}
+int32_t scvae_plan_head_arith(const scvae_plan* p) { return p ? p->head_arith : -1; }
 
 int scvae_plan_probe_heads(scvae_plan* p, int32_t n) {
   SCVAE_ARG(p && n >= 0 && n <= 4096);
@@ -1375,7 +1383,7 @@ int scvae_plan_accepts_counts_u16(const scvae_plan* p, int64_t cells, int32_t tr
   if (c.k_max > 0) return 0;
   if (c.likelihood > scvae::LK_ZINB &&
       !(c.likelihood == scvae::LK_CPOISSON &&
-        scvae::decoder_fused_cpoisson_supported(p->heads[0].n_in) &&
+        scvae::decoder_fused_cpoisson_supported(p->heads[0].n_in, p->head_arith) &&
         !(training && p->heads[0].keep > 0.f)))
     return 0;
   if (!scvae::decoder_fused_supported(p->heads[0].n_in)) return 0;
@@ -1395,7 +1403,8 @@ int scvae_plan_accepts_counts_u16(const scvae_plan* p, int64_t cells, int32_t tr
     // head dropout: only inside the bf16x9 head kernel, i.e. one likelihood pass per step
     // (training == 2: the caller vouches for n_iw == 1; the GMVAE has no other kind of step)
     if (p->heads[0].keep > 0.f &&
-        !((training == 2 || gm) && scvae::decoder_train_kernel(p->P, p->heads[0].n_in) == 3))
+        !((training == 2 || gm) &&
+          scvae::decoder_train_kernel(p->P, p->heads[0].n_in, p->head_arith) == 3))
       return 0;
     if (gm) {
       if (p->zenc[0].keep > 0.f) return 0;
@@ -1574,17 +1583,29 @@ int32_t scvae_decoder_fused_variant(int32_t kind, int64_t H) {
     return 0;
   return scvae::decoder_fused_variant(scvae::likelihood_heads(kind), (int)H);
 }
-int32_t scvae_decoder_head_arith(void) { return scvae::decoder_head_arith(); }
-int scvae_set_decoder_head_arith(int32_t mode) {
-  SCVAE_ARG(mode == 0 || mode == 1);
-  scvae::set_decoder_head_arith(mode);
+int32_t scvae_default_head_arith(void) { return scvae::default_head_arith(); }
+int scvae_decoder_train_kernel_name(int32_t kind, int64_t H, int32_t arith, int32_t u16, char* out,
+                                    int64_t n) {
+  SCVAE_ARG(out && n > 0);
+  out[0] = 0;
+  const int which = scvae_decoder_train_kernel(kind, H, arith);
+  SCVAE_ARG(which > 0);
+  const int P = scvae::likelihood_heads(kind);
+  if (which == 3) {
+    scvae::decoder_fused3_train_kernel_name(kind, (int)H, u16 != 0, out, (size_t)n);
+  } else if (which == 2) {
+    snprintf(out, (size_t)n, "decoder_head2_kernel<%d, true, %s>", kind,
+             (P <= 2 && H > 96 && H <= 111) ? "true|false" : "false");
+  } else {
+    snprintf(out, (size_t)n, "decoder_head_kernel<%d, true, %d>", kind, P >= 3 ? 32 : 64);
+  }
   return 0;
 }
-int32_t scvae_decoder_train_kernel(int32_t kind, int64_t H) {
+int32_t scvae_decoder_train_kernel(int32_t kind, int64_t H, int32_t arith) {
   if (kind < 0 || (kind > 3 && kind != scvae::LK_BERNOULLI) ||
-      !scvae::decoder_fused_supported((int)H))
+      !scvae::decoder_fused_supported((int)H) || (arith != 0 && arith != 1))
     return 0;
-  return scvae::decoder_train_kernel(scvae::likelihood_heads(kind), (int)H);
+  return scvae::decoder_train_kernel(scvae::likelihood_heads(kind), (int)H, arith);
 }
 static int decoder_fused_entry(int32_t kind, int32_t train, const float* d, int64_t rows, int64_t H,
                                const float* const* W, const float* const* b, float* const* dW,
@@ -1593,6 +1614,11 @@ static int decoder_fused_entry(int32_t kind, int32_t train, const float* d, int6
                                void* workspace, void* stream) {
   SCVAE_ARG(((kind >= 0 && kind <= 3) || kind == scvae::LK_BERNOULLI) && W && b);
   SCVAE_ARG(scvae::decoder_fused_supported((int)H));
+  // bits 8-9 of `train`: the arithmetic of this call (neither: the process default)
+  SCVAE_ARG((train & ~0x303) == 0 && (train & 0x300) != 0x300);
+  const int arith = (train & SCVAE_HEADS_FP32) ? 0
+                    : (train & SCVAE_HEADS_BF16X9) ? 1 : scvae::default_head_arith();
+  train &= 3;
   scvae::HeadParams hp;
   for (int j = 0; j < 3; ++j) {
     const bool on = j < scvae::likelihood_heads(kind);
@@ -1605,10 +1631,10 @@ static int decoder_fused_entry(int32_t kind, int32_t train, const float* d, int6
     SCVAE_ARG(dW && db);
     return scvae::decoder_fused_train((hipStream_t)stream, kind, d, (int)rows, (int)H, hp, (int)F,
                                       t, (int)cells, gw, row_const, ll, dd, (float*)workspace,
-                                      (train & 2) != 0);
+                                      arith, (train & 2) != 0);
   }
   return scvae::decoder_fused_forward((hipStream_t)stream, kind, d, (int)rows, (int)H, hp, (int)F,
-                                      t, (int)cells, row_const, ll, (float*)workspace);
+                                      t, (int)cells, row_const, ll, (float*)workspace, arith);
 }
 int scvae_decoder_fused(int32_t kind, int32_t train, const float* d, int64_t rows, int64_t H,
                         const float* const* W, const float* const* b, float* const* dW,

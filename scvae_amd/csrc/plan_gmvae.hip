@@ -353,7 +353,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                      !a->p_x_mean && KM == 0 &&
                      (!head_drop || (heads_fused_dropout_ok(p, 1) && !cpoisson)) &&
                      (c.likelihood <= LK_ZINB || c.likelihood == LK_BERNOULLI ||
-                      (cpoisson && decoder_fused_cpoisson_supported(h1)));
+                      (cpoisson && decoder_fused_cpoisson_supported(h1, p->head_arith)));
   if (p->x_u16 && !fused) {
     set_error("the uint16 minibatch needs the fused likelihood kernels (no -k / constrained "
               "Poisson, evaluation statistics, or head dropout outside the bf16x9 kernel)");
@@ -407,7 +407,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                                  a->row_const, p->ll, nullptr, p->fused_ws));
     else if (fused)
       TRY(decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, tg, B, a->row_const, p->ll,
-                                p->fused_ws));
+                                p->fused_ws, p->head_arith));
     else if (KM > 0)
       TRY(loglik_cat_fwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->ll, R, B, F));
     else if (cpoisson) {
@@ -435,7 +435,8 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                                  a->row_const, p->ll, dcur, p->fused_ws));
     else
       TRY(decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, tg, B, p->gw, a->row_const,
-                              p->ll, dcur, p->fused_ws, false, head_drop ? &hdrop : nullptr));
+                              p->ll, dcur, p->fused_ws, p->head_arith, false,
+                              head_drop ? &hdrop : nullptr));
   } else if (KM > 0) {
     TRY(loglik_cat_bwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->gw, p->ll, R, B, F));
   } else if (cpoisson) {

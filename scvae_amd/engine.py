@@ -295,6 +295,18 @@ class Engine:
         _lib.check(self.lib.scvae_plan_set_fused(
             self.handle, 1 if enabled else 0), "scvae_plan_set_fused")
 
+    def set_head_arith(self, arith):
+        """Arithmetic of this engine's fused head kernels: ``"bf16x9"`` (the
+        exact nine-term bf16 split, default) or ``"fp32"`` (fp32 matrix
+        cores).  A plan attribute: engines of one process can differ."""
+        mode = {"fp32": 0, "bf16x9": 1, 0: 0, 1: 1}[arith]
+        _lib.check(self.lib.scvae_plan_set_head_arith(self.handle, mode),
+                   "scvae_plan_set_head_arith")
+
+    @property
+    def head_arith(self):
+        return ("fp32", "bf16x9")[self.lib.scvae_plan_head_arith(self.handle)]
+
     def set_count_gemm(self, enabled, always=False):
         """The exact bf16-split kernels for the products with a count matrix
         (``step(..., x_counts=True)``): where they pay (default: minibatches

@@ -122,7 +122,7 @@ def test_head_dropout_in_the_fused_kernel(cuda_device, likelihood, H, B):
     from scvae_amd import _lib
     lib = _lib.load()
     kind, heads = _lib.LIKELIHOOD_KINDS[likelihood]
-    assert lib.scvae_decoder_train_kernel(kind, H[0]) == 3
+    assert lib.scvae_decoder_train_kernel(kind, H[0], 1) == 3
     _vae_step_case(cuda_device, (0.8, 0.0, 0.0), likelihood, 0, 1, 1,
                    150, 7, H, B)
     _vae_step_case(cuda_device, (0.6, 0.0, 0.9), likelihood, 0, 1, 2,

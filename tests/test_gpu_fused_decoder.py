@@ -13,17 +13,18 @@ from oracle import likelihoods as lk
 pytestmark = pytest.mark.gpu
 
 
+ARITH = {"flag": 0}
+
+
 @pytest.fixture(params=["fp32", "bf16x9"], autouse=True)
 def head_arith(request):
     """Every case on both training kernels: the fp32 matrix cores and the exact
-    nine-term bf16 split (decoder_head3_kernel, where it applies)."""
+    nine-term bf16 split (decoder_fused3.hip, where it applies) -- the
+    arithmetic travels with each call (``train | SCVAE_HEADS_*``)."""
     from scvae_amd import _lib
-    lib = _lib.load()
-    before = lib.scvae_decoder_head_arith()
-    _lib.check(lib.scvae_set_decoder_head_arith(
-        1 if request.param == "bf16x9" else 0), "scvae_set_decoder_head_arith")
+    ARITH["flag"] = _lib.HEAD_ARITH_FLAGS[request.param]
     yield request.param
-    lib.scvae_set_decoder_head_arith(before)
+    ARITH["flag"] = 0
 
 
 def _run(device, name, rows, cells, F, H, density, seed=0, row_const=True):
@@ -64,7 +65,7 @@ def _run(device, name, rows, cells, F, H, density, seed=0, row_const=True):
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for train in (0, 1):
         _lib.check(lib.scvae_decoder_fused(
-            kind, train, dd_.data_ptr(), rows, H, arr(Wd), arr(bd), arr(dWd),
+            kind, train | ARITH["flag"], dd_.data_ptr(), rows, H, arr(Wd), arr(bd), arr(dWd),
             arr(dbd), F, td.data_ptr(), cells, gwd.data_ptr(),
             rc.data_ptr() if rc is not None else None, ll.data_ptr(),
             dd.data_ptr(), ws.data_ptr(), stream), "scvae_decoder_fused")
@@ -151,7 +152,7 @@ def _run_binarised(device, rows, F, H):
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for train in (0, 1):
         _lib.check(lib.scvae_decoder_fused(
-            kind, train, dd_.data_ptr(), rows, H, arr([Wd]), arr([bd]),
+            kind, train | ARITH["flag"], dd_.data_ptr(), rows, H, arr([Wd]), arr([bd]),
             arr([dWd]), arr([dbd]), F, td.data_ptr(), rows, gwd.data_ptr(), None,
             ll.data_ptr(), dd.data_ptr(), ws.data_ptr(), stream),
             "scvae_decoder_fused")

@@ -37,7 +37,7 @@ arr = lambda ts: (ctypes.c_void_p * len(ts))(*[x.data_ptr() for x in ts])
 stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 results = {}
 for arith in (0, 1):
-    lib.scvae_set_decoder_head_arith(arith)
+    flag = _lib.HEADS_BF16X9 if arith else _lib.HEADS_FP32
     dW = [torch.zeros_like(w) for w in W]
     db = [torch.zeros_like(v) for v in b]
     ll = torch.zeros(rows, device=dev)
@@ -45,7 +45,7 @@ for arith in (0, 1):
 
     def launch(train):
         _lib.check(lib.scvae_decoder_fused_u16(
-            kind, train, d.data_ptr(), rows, H, arr(W), arr(b), arr(dW),
+            kind, train | flag, d.data_ptr(), rows, H, arr(W), arr(b), arr(dW),
             arr(db), F, t16.data_ptr(), ld, rows, gw.data_ptr(), rc.data_ptr(),
             ll.data_ptr(), dd.data_ptr(), ws.data_ptr(), stream), "fused")
     launch(1)
@@ -64,7 +64,7 @@ for arith in (0, 1):
     ms = e0.elapsed_time(e1) / launches
     flops = 2.0 * rows * F * P * 3 * H
     print("arith {} kernel {}: {:.3f} ms  {:.1f} TFLOP/s algorithmic".format(
-        arith, lib.scvae_decoder_train_kernel(kind, H), ms, flops / ms / 1e9))
+        arith, lib.scvae_decoder_train_kernel(kind, H, arith), ms, flops / ms / 1e9))
 a, c = results[0], results[1]
 
 
