@@ -61,6 +61,10 @@ def parse_args():
     ap.add_argument("--cells", type=int, default=N_CELLS)
     ap.add_argument("--features", type=int, default=N_FEATURES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dd-slabs", action="store_true",
+                    help="accumulate the decoder gradient dd through per-strip slabs and a "
+                         "fixed-order reduce (bit-repeatable; the library's default) instead "
+                         "of XCD-local fp32 atomics")
     ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--model", default="vae", choices=["vae", "gmvae"],
                     help="extra (non-headline) workloads for DESIGN.md")
@@ -202,6 +206,9 @@ def cpu_baseline(matrix, batch):
 # ----------------------------------------------------------------------------
 # roofline of the dominant kernel
 # ----------------------------------------------------------------------------
+DD_ATOMICS = True      # (main() clears it for --dd-slabs)
+
+
 def _measured_traffic(rows, F, H, kernel, targets="f32"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3
     PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section);
@@ -261,6 +268,8 @@ def time_dominant_kernel(engine, rows, launches=10, u16=False, arith=None):
     if arith is None:
         arith = 1 if engine.head_arith == "bf16x9" else 0
     flag = _lib.HEADS_BF16X9 if arith else _lib.HEADS_FP32
+    if DD_ATOMICS:
+        flag |= _lib.HEADS_DD_ATOMICS
 
     if u16:
         ld = (F + 63) // 64 * 64
@@ -349,6 +358,9 @@ class Workload:
                              model_type="GMVAE" if self.gm else "VAE",
                              n_clusters=self.K, device=device, seed=0)
         self.engine.reserve(batch, 1)
+        # dd = sum over the gene strips: XCD-local fp32 atomics (a plan option; run-to-run the
+        # sums differ in their last bits) unless --dd-slabs asks for the bit-repeatable path
+        self.engine.set_dd_atomics(DD_ATOMICS)
         if os.environ.get("SCVAE_BENCH_COUNT_ALWAYS"):
             self.engine.set_count_gemm(True, always=True)
         self.sync = None
@@ -527,7 +539,9 @@ def other_workloads(matrix, device, barrier):
 
 
 def main():
+    global DD_ATOMICS
     args = parse_args()
+    DD_ATOMICS = not args.dd_slabs
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(respawn_one_rank_per_gpu(args))
 
@@ -633,6 +647,9 @@ def main():
             # storage of the dense minibatch between the CSR gather and its three
             # readers (integer counts: uint16, exact; the arithmetic stays fp32)
             "minibatch_storage": "u16" if work.u16 else "f32",
+            # the decoder gradient dd = sum over the gene strips of G W^T
+            "dd_accumulation": ("xcd-local fp32 atomics (plan option; not bit-repeatable)"
+                                if DD_ATOMICS else "per-strip slabs + fixed-order reduce"),
             "data": "synthetic",
             "config": {
                 "workload": describe(args.cells, F, args.likelihood, gm, K, L),

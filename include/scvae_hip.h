@@ -141,6 +141,10 @@ int scvae_plan_set_fused(scvae_plan* plan, int32_t enabled);
  * what scvae_plan_accepts_counts_u16 answers; call it before the first step. */
 int scvae_plan_set_head_arith(scvae_plan* plan, int32_t mode);
 int32_t scvae_plan_head_arith(const scvae_plan* plan);
+/* 1: this plan's training steps accumulate the decoder gradient dd with XCD-local fp32 atomics
+ * where the head kernel has that store (SCVAE_HEADS_DD_ATOMICS below); 0 (default): per-strip
+ * slabs and a fixed-order reduce, bit-repeatable */
+int scvae_plan_set_dd_atomics(scvae_plan* plan, int32_t enabled);
 /* The exact bf16-split kernels for products with a count matrix: 1 (default) where they pay
  * (minibatches from a few hundred cells upwards, see plan_gemm), 2 always, 0 never -- those
  * products then take the fp32 MFMA kernels even when scvae_step_args.x_counts is set (A/B
@@ -378,6 +382,11 @@ int scvae_decoder_train_kernel_name(int32_t kind, int64_t H, int32_t arith, int3
 /* flags of scvae_decoder_fused's / scvae_decoder_fused_u16's `train` (or'ed to 0 / 1 / 3) */
 #define SCVAE_HEADS_FP32 0x100
 #define SCVAE_HEADS_BF16X9 0x200
+/* dd = sum over the gene strips of G W^T: with this flag the producer / consumer training kernel
+ * adds each strip's part into eight XCD-local [H][rows] accumulators with fp32 atomics (L2
+ * resident) instead of writing per-strip slabs to HBM (0.84 GB at 4096 x 32 738) -- the sums
+ * are then NOT bit-repeatable from run to run; default off */
+#define SCVAE_HEADS_DD_ATOMICS 0x400
 int scvae_decoder_fused(int32_t kind, int32_t train, const float* d, int64_t rows, int64_t H,
                         const float* const* W, const float* const* b, float* const* dW,
                         float* const* db, int64_t F, const float* t, int64_t cells,

@@ -20,7 +20,7 @@ NAME_MAX = 96
 
 POISSON, NB, ZIP, ZINB, CONSTRAINED_POISSON, BERNOULLI = 0, 1, 2, 3, 4, 5
 #: flags of scvae_decoder_fused's ``train`` argument: the arithmetic of that call
-HEADS_FP32, HEADS_BF16X9 = 0x100, 0x200
+HEADS_FP32, HEADS_BF16X9, HEADS_DD_ATOMICS = 0x100, 0x200, 0x400
 HEAD_ARITH_FLAGS = {"fp32": HEADS_FP32, "bf16x9": HEADS_BF16X9}
 MODEL_VAE, MODEL_GMVAE = 0, 1
 
@@ -148,6 +148,7 @@ SIGNATURES = {
     "scvae_plan_set_fused": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_set_head_arith": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_head_arith": (c_int32, [c_void_p]),
+    "scvae_plan_set_dd_atomics": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_set_count_gemm": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_set_bn_one_launch": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_set_mid_chain": (c_int32, [c_void_p, c_int32]),

@@ -594,14 +594,43 @@ __global__ __launch_bounds__(256) void dd_reduce_q_kernel(const float* __restric
   }
 }
 
+// dd[r][h] = sum over the eight XCD-local accumulators acc[x][h][r] of decoder_head4_kernel's
+// atomic store (fixed order: the rounding of the SUM is repeatable, that of the accumulators is
+// not).  One thread = one row and four consecutive h.
+__global__ __launch_bounds__(256) void dd_reduce_xcd_kernel(const float* __restrict__ acc, int R,
+                                                            int H, float* __restrict__ dd) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int HQ = (H + 3) >> 2;
+  if (i >= (size_t)HQ * R) return;
+  const int hq = (int)(i / R), r = (int)(i % R);
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int h = min(4 * hq + e, H - 1);
+      v[e] += acc[((size_t)x * H + h) * R + r];
+    }
+  float* out = dd + (size_t)r * H + 4 * hq;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (4 * hq + e < H) out[e] = v[e];
+}
+
 bool decoder_fused_supported(int H) { return H >= 2 && H <= 126 && (H % 2) == 0; }
+
+// the per-strip slabs of dd [strips][H / 4][rows][4] -- or, with SCVAE_HEADS_DD_ATOMICS, the eight
+// XCD-local accumulators [8][H][rows] (more than the slabs where F < 8 strips)
+static size_t dd_part_floats(size_t strips, int rows, int H) {
+  return (strips > 8 ? strips : 8) * (size_t)rows * ((H + 3) / 4 * 4);
+}
 
 size_t decoder_fused_workspace_floats(int rows, int H, int F, bool train) {
   // (the bf16x9 kernel takes 32-gene strips for three heads: size for the narrowest strip)
   const int bn = (train && decoder_fused3_supported(3, H)) ? decoder_fused3_strip_genes(3) : DF_BN;
   const size_t strips = (size_t)(F + bn - 1) / bn;
   size_t n = strips * rows;                       // ll_part
-  if (train) n += strips * (size_t)rows * ((H + 3) / 4 * 4) + 64; // dd_part (16-byte aligned start; H in quads)
+  if (train) n += dd_part_floats(strips, rows, H) + 64; // dd_part (16-byte aligned start; H in quads)
   if (train) n += decoder_fused3_workspace_floats(rows) + 64;   // bf16 planes of d (bf16x9 kernel)
   // (constrained Poisson passes: a second [strips][rows] array, lse[rows], S[rows])
   if (train) n += strips * (size_t)rows + 2 * (size_t)rows + 192;
@@ -661,12 +690,13 @@ template <bool TRAIN>
 static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                           int F, Targets t, int B, const float* gw, int inline_lgamma,
                           float* ll_part, float* dd_part, int arith, float* planes = nullptr,
-                          const HeadDropout* drop = nullptr) {
+                          const HeadDropout* drop = nullptr, int dd_mode = 0) {
   const int P = likelihood_heads(kind);
   if (TRAIN && planes && decoder_train_kernel(P, H, arith) == 3) {
     static const int dbg = [] { const char* e = getenv("SCVAE_D3_DEBUG"); return e ? atoi(e) : 0; }();
     return decoder_fused3_launch(s, true, kind, d, rows, H, hp, F, t, B, gw,
-                                 inline_lgamma | (dbg << 8), ll_part, dd_part, planes, drop);
+                                 inline_lgamma | (dbg << 8), ll_part, dd_part, planes, drop, 0,
+                                 nullptr, dd_mode);
   }
   if (drop) {
     set_error("head dropout inside the fused kernel needs the bf16x9 head kernel");
@@ -798,7 +828,7 @@ int decoder_fused_cpoisson(hipStream_t s, bool train, const float* d, int rows, 
   const size_t n_part = ((size_t)strips * rows + 63) / 64 * 64;
   float* ll_part = workspace;
   float* dd_part = ll_part + n_part;
-  float* planes = dd_part + ((size_t)strips * rows * ((H + 3) / 4 * 4) + 63) / 64 * 64;
+  float* planes = dd_part + (dd_part_floats(strips, rows, H) + 63) / 64 * 64;
   float* part2 = planes + (decoder_fused3_workspace_floats(rows) + 63) / 64 * 64;
   float* lse = part2 + n_part;
   float* S = lse + ((size_t)rows + 63) / 64 * 64;
@@ -849,7 +879,7 @@ int decoder_fused_cpoisson(hipStream_t s, bool train, const float* d, int rows, 
 int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                         int F, Targets t, int B, const float* gw, const float* row_const,
                         float* ll, float* dd, float* workspace, int arith, bool kernel_only,
-                        const HeadDropout* drop) {
+                        const HeadDropout* drop, int dd_mode) {
   SCVAE_ARG(d && t.p && gw && ll && dd && workspace && decoder_fused_supported(H));
   if (rows == 0) return 0;
   const int heads = likelihood_heads(kind);
@@ -859,16 +889,23 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
   float* ll_part = workspace;
   size_t off = ((size_t)strips * rows + 63) / 64 * 64;
   float* dd_part = workspace + off;
-  float* planes = dd_part + ((size_t)strips * rows * ((H + 3) / 4 * 4) + 63) / 64 * 64;
+  float* planes = dd_part + (dd_part_floats(strips, rows, H) + 63) / 64 * 64;
   int rc = launch_decoder<true>(s, kind, d, rows, H, hp, F, t, B, gw,
                                 (row_const || kind == LK_BERNOULLI) ? 0 : 1, ll_part, dd_part,
-                                arith, planes, drop);
+                                arith, planes, drop, dd_mode);
   if (rc) return rc;
   if (kernel_only) return 0;  // profiling aid: leave the per-strip partials unreduced
   hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 15) / 16), dim3(1024), 0, s, ll_part,
                      strips, rows, row_const, B, ll);
   SCVAE_LAUNCH_CHECK("ll_reduce_kernel");
   const size_t n = (size_t)rows * H;
+  if (decoder_train_kernel(likelihood_heads(kind), H, arith) == 3 &&
+      decoder_fused3_dd_atomics(kind, H, drop != nullptr, 0, dd_mode)) {
+    hipLaunchKernelGGL(dd_reduce_xcd_kernel, dim3((unsigned)(((size_t)((H + 3) / 4) * rows + 255) / 256)),
+                       dim3(256), 0, s, dd_part, rows, H, dd);
+    SCVAE_LAUNCH_CHECK("dd_reduce_xcd_kernel");
+    return 0;
+  }
   if (decoder_train_kernel(likelihood_heads(kind), H, arith) == 3) {
     // quad slabs of decoder_head3_kernel
     const size_t n4 = (size_t)((H + 3) / 4) * rows;

@@ -879,7 +879,7 @@ template <int KIND, int KS1, bool U16, int NPW>
 __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
     const uint16_t* __restrict__ dA, const uint16_t* __restrict__ dT, int R, int Rpad, int H,
     HeadParams hp, int F, Targets tg, int B, const float* __restrict__ gw, int inline_lgamma,
-    float* __restrict__ ll_part, float* __restrict__ dd_part) {
+    float* __restrict__ ll_part, float* __restrict__ dd_part, int dd_atomic) {
   using Traits = LikelihoodTraits<KIND>;
   constexpr int P = Traits::P;
   constexpr int NT = d4_threads(NPW);
@@ -1153,6 +1153,14 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
 
   // =========================== consumers: GEMM3 (dd) and GEMM2 (dW) ===========================
   const int ht = w - NPW;                         // h tile of this wave
+  // (dd_atomic) the accumulator copy of the XCD this workgroup actually runs on: its adds are
+  // then performed in that XCD's own L2, the only L2 that ever holds lines of that copy --
+  // correct whatever the dispatcher's block -> XCD placement is
+  unsigned xcc = 0;
+  if (dd_atomic) {
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+  }
   const int n_ht3 = (H + 31) / 32, n_ht2 = (H + 1 + 31) / 32;
   const bool do3 = ht < n_ht3, do2 = ht < n_ht2;
   const int g3a = li * ROWB + 16 * kh;                                               // G, GEMM3
@@ -1191,6 +1199,36 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
       ll_part[(size_t)blockIdx.x * R + m0 + lane] = sm;
     }
     D4_STAMP(0);
+    // (GEMM2 first: GEMM3's stores -- or atomic adds -- of this tile's part of dd then sit
+    //  right before the barrier and drain under the wait and the next tile's GEMM2)
+    if (do2 && !(dbg & 1)) {
+      // ---- GEMM2: dW_j[h, gene] += sum_row d[row, h] G_j[row, gene] ----
+      constexpr int NST = 2 * P * NGT;               // step = (k-step * P + head) * NGT + gene tile
+      bf16x8 bf[2][3];
+      auto load_2 = [&](int st, bf16x8 (&b)[3]) {
+        const int gt = st % NGT, j = (st / NGT) % P, ks = st / (NGT * P);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          b[pl] = lds_tr8<ROWB>(Gb + (size_t)(j * 3 + pl) * GPLANE + g2b + 64 * gt +
+                                16 * ks * ROWB);
+      };
+      load_2(0, bf[0]);
+#pragma unroll
+      for (int st = 0; st < NST; ++st) {
+        if (st + 1 < NST) load_2(st + 1, bf[(st + 1) & 1]);
+        const int gt = st % NGT, j = (st / NGT) % P, ks = st / (NGT * P);
+#pragma unroll
+        for (int a = 2; a >= 0; --a)
+#pragma unroll
+          for (int b = 2; b >= 0; --b)
+            accW[j][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks][a], bf[st & 1][b],
+                                                                  accW[j][gt], 0, 0, 0);
+      }
+      // the next tile's fragments (the last tile: its own again), in flight over the barrier
+      load_a2(min(m0 + D4_BM, Rpad - D4_BM));
+      d3_pin_loads();
+    }
+    D4_STAMP(2);
     if (do3 && !(dbg & 1)) {
       // ---- GEMM3: dd^T[h, row] = sum_j sum_gene W_j[h, gene] G_j[row, gene] ----
       f32x16 acc3;
@@ -1219,7 +1257,21 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
       D4_STAMP(1);
       // slab [strip][H / 4][R][4] (see decoder_head3_kernel): one 16-byte store per h quad
       const int row = (dbg & 8) ? R : m0 + li;
-      if (row < R) {
+      if (dd_atomic) {
+        // no-return fp32 adds into this XCD's [H][R] accumulator (h-major: the 32 lanes of a half
+        // wave add to 128 contiguous bytes); dd_reduce_xcd_kernel sums the eight copies
+        if (row < R) {
+          typedef __attribute__((address_space(1))) float gfloat;
+          float* base = dd_part + ((size_t)xcc * H + 32 * ht + 4 * kh) * R + row;
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (32 * ht + 8 * c + 4 * kh + e < H)
+                __builtin_amdgcn_global_atomic_fadd_f32((gfloat*)(base + (size_t)(8 * c + e) * R),
+                                                        acc3[4 * c + e]);
+        }
+      } else if (row < R) {
         const int HQ = (H + 3) >> 2;
         f32x4m* dst = reinterpret_cast<f32x4m*>(dd_part) +
                       ((size_t)blockIdx.x * HQ + 8 * ht + kh) * R + row;
@@ -1231,34 +1283,6 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
                 dst + (size_t)2 * c * R);
         }
       }
-    }
-    D4_STAMP(2);
-    if (do2 && !(dbg & 1)) {
-      // ---- GEMM2: dW_j[h, gene] += sum_row d[row, h] G_j[row, gene] ----
-      constexpr int NST = 2 * P * NGT;               // step = (k-step * P + head) * NGT + gene tile
-      bf16x8 bf[2][3];
-      auto load_2 = [&](int st, bf16x8 (&b)[3]) {
-        const int gt = st % NGT, j = (st / NGT) % P, ks = st / (NGT * P);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          b[pl] = lds_tr8<ROWB>(Gb + (size_t)(j * 3 + pl) * GPLANE + g2b + 64 * gt +
-                                16 * ks * ROWB);
-      };
-      load_2(0, bf[0]);
-#pragma unroll
-      for (int st = 0; st < NST; ++st) {
-        if (st + 1 < NST) load_2(st + 1, bf[(st + 1) & 1]);
-        const int gt = st % NGT, j = (st / NGT) % P, ks = st / (NGT * P);
-#pragma unroll
-        for (int a = 2; a >= 0; --a)
-#pragma unroll
-          for (int b = 2; b >= 0; --b)
-            accW[j][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks][a], bf[st & 1][b],
-                                                                  accW[j][gt], 0, 0, 0);
-      }
-      // the next tile's fragments (the last tile: its own again), in flight over the barrier
-      load_a2(min(m0 + D4_BM, Rpad - D4_BM));
-      d3_pin_loads();
     }
     D4_STAMP(3);
     lds_barrier();
@@ -1290,16 +1314,17 @@ extern "C" int scvae_d4_prof_dump(unsigned long long* out) {
 }
 #endif
 
-// which schedule runs a plain training launch: 4 producer / consumer waves (decoder_head4_kernel;
-// default for one and two heads), 3 all waves in one phase (decoder_head3_kernel); read once
-// (three heads stay on decoder_head3_kernel: 2.38-2.42 ms against 2.41-2.47 for the
-//  producer / consumer form at 4096 x 32 738 -- SCVAE_D3_SCHEDULE=4 forces it for A/B and tests)
+// which schedule runs a plain training launch: 4 producer / consumer waves (decoder_head4_kernel,
+// the default), 3 all waves in one phase (decoder_head3_kernel); read once
+// (SCVAE_D3_SCHEDULE=3 / 4 forces one for A/B runs and tests.  Measured at 4096 x 32 738, kernel +
+//  reduces: NB 1.49 against 1.58 ms, Poisson 0.90-0.92 against 0.90, ZINB 2.60-2.63 against 2.67)
 static int d3_schedule(int P) {
   static const int v = [] {
     const char* e = getenv("SCVAE_D3_SCHEDULE");
     return (e && (e[0] == '3' || e[0] == '4')) ? e[0] - '0' : 0;
   }();
-  return v ? v : (P >= 3 ? 3 : 4);
+  (void)P;
+  return v ? v : 4;
 }
 // producer waves per workgroup: eight (16 x 16 blocks, three waves per SIMD) for two heads, four
 // for one head (measured, 4096 x 32 738: Poisson 0.81-0.83 ms with four, 0.87-0.88 with eight;
@@ -1312,6 +1337,15 @@ static int d4_producers(int P) {
   }();
   if (P >= 3) return 4;
   return v ? v : (P == 1 ? 4 : 8);
+}
+
+// whether a training launch with these options accumulates dd with XCD-local atomics (the caller
+// then reduces eight [H][rows] copies instead of the per-strip slabs): only the producer /
+// consumer kernel has that store
+bool decoder_fused3_dd_atomics(int kind, int H, bool drop, int cp_pass, int dd_mode) {
+  const int P = likelihood_heads(kind);
+  return dd_mode && !drop && cp_pass == 0 && d3_schedule(P) == 4 &&
+         decoder_fused4_lds_bytes(P, H, d4_producers(P)) <= 160 * 1024;
 }
 
 // the training instantiation a plain launch (no dropout, no constrained-Poisson pass) takes, as
@@ -1329,7 +1363,7 @@ int decoder_fused3_train_kernel_name(int kind, int H, bool u16, char* out, size_
 int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, int rows, int H,
                           HeadParams hp, int F, Targets t, int B, const float* gw,
                           int inline_lgamma, float* ll_part, float* dd_part, float* planes,
-                          const HeadDropout* drop, int cp_pass, const CpRows* cp) {
+                          const HeadDropout* drop, int cp_pass, const CpRows* cp, int dd_mode) {
   const int P = likelihood_heads(kind);
   SCVAE_ARG(decoder_fused3_supported(P, H) && planes);
   SCVAE_ARG(train || P <= 2);
@@ -1403,6 +1437,9 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
   } else if (train && d3_schedule(P) == 4 &&
              decoder_fused4_lds_bytes(P, H, d4_producers(P)) <= 160 * 1024) {
     const int npw = d4_producers(P);
+    const int dd_atomic = dd_mode ? 1 : 0;
+    if (dd_atomic)    // eight XCD-local accumulators [8][H][rows], cleared for this launch
+      SCVAE_HIP(hipMemsetAsync(dd_part, 0, (size_t)8 * H * rows * sizeof(float), s));
     const size_t lds4 = decoder_fused4_lds_bytes(P, H, npw);
 #define SCVAE_D4N(K_, KS_, N_)                                                                    \
   do {                                                                                            \
@@ -1411,7 +1448,7 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
     SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));        \
     hipLaunchKernelGGL(kfn, dim3(strips), dim3(d4_threads(N_)), lds4, s, dA, dT, rows, Rpad, H,   \
-                       hp, F, t, B, gw, inline_lgamma, ll_part, dd_part);                         \
+                       hp, F, t, B, gw, inline_lgamma, ll_part, dd_part, dd_atomic);              \
   } while (0)
 #define SCVAE_D4K(K_, KS_)                                                                        \
   do {                                                                                            \

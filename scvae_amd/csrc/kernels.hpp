@@ -288,7 +288,8 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
                         int F, Targets t, int B, const float* gw, const float* row_const,
                         float* ll, float* dd, float* workspace, int arith,
                         bool kernel_only = false,
-                        const HeadDropout* drop = nullptr);   // drop: bf16x9 kernel only
+                        const HeadDropout* drop = nullptr,    // drop: bf16x9 kernel only
+                        int dd_mode = 0);                     // 1: XCD-local atomics for dd
 
 // training kernel on the bf16 matrix cores, exact nine-term split (decoder_fused3.hip)
 bool decoder_fused3_supported(int P, int H);
@@ -302,7 +303,11 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
                           HeadParams hp, int F, Targets t, int B, const float* gw,
                           int inline_lgamma, float* ll_part, float* dd_part, float* planes,
                           const HeadDropout* drop = nullptr, int cp_pass = 0,
-                          const CpRows* cp = nullptr);
+                          const CpRows* cp = nullptr, int dd_mode = 0);
+// dd_mode 1: the per-strip partials of dd are not written as slabs but added (fp32 atomics, not
+// bit-repeatable) into eight XCD-local [H][rows] accumulators at dd_part; only where
+// decoder_fused3_dd_atomics says so (the producer / consumer training kernel)
+bool decoder_fused3_dd_atomics(int kind, int H, bool drop, int cp_pass, int dd_mode);
 // Constrained Poisson (du:218-228) through the bf16x9 head kernel in three passes over the strip
 // grid (row maximum / sum of exponentials | log-likelihood and S | gradients): ll[rows] and, with
 // train, dW / db (in hp) and dd[rows, H].  workspace: decoder_fused_workspace_floats(.., true).

@@ -950,7 +950,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     else
       rc = decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, tg, B, p->gw, a->row_const,
                                p->ll, dcur, p->fused_ws, p->head_arith, false,
-                               head_drop ? &hdrop : nullptr);
+                               head_drop ? &hdrop : nullptr, p->dd_atomics);
     if (rc) return rc;
   } else {
     if (KM > 0)
@@ -1275,6 +1275,11 @@ int scvae_plan_set_head_arith(scvae_plan* p, int32_t mode) {
   return 0;
 }
 int32_t scvae_plan_head_arith(const scvae_plan* p) { return p ? p->head_arith : -1; }
+int scvae_plan_set_dd_atomics(scvae_plan* p, int32_t enabled) {
+  SCVAE_ARG(p);
+  p->dd_atomics = enabled ? 1 : 0;
+  return 0;
+}
 
 int scvae_plan_probe_heads(scvae_plan* p, int32_t n) {
   SCVAE_ARG(p && n >= 0 && n <= 4096);
@@ -1615,7 +1620,8 @@ static int decoder_fused_entry(int32_t kind, int32_t train, const float* d, int6
   SCVAE_ARG(((kind >= 0 && kind <= 3) || kind == scvae::LK_BERNOULLI) && W && b);
   SCVAE_ARG(scvae::decoder_fused_supported((int)H));
   // bits 8-9 of `train`: the arithmetic of this call (neither: the process default)
-  SCVAE_ARG((train & ~0x303) == 0 && (train & 0x300) != 0x300);
+  SCVAE_ARG((train & ~0x703) == 0 && (train & 0x300) != 0x300);
+  const int dd_mode = (train & SCVAE_HEADS_DD_ATOMICS) ? 1 : 0;
   const int arith = (train & SCVAE_HEADS_FP32) ? 0
                     : (train & SCVAE_HEADS_BF16X9) ? 1 : scvae::default_head_arith();
   train &= 3;
@@ -1631,7 +1637,7 @@ static int decoder_fused_entry(int32_t kind, int32_t train, const float* d, int6
     SCVAE_ARG(dW && db);
     return scvae::decoder_fused_train((hipStream_t)stream, kind, d, (int)rows, (int)H, hp, (int)F,
                                       t, (int)cells, gw, row_const, ll, dd, (float*)workspace,
-                                      arith, (train & 2) != 0);
+                                      arith, (train & 2) != 0, nullptr, dd_mode);
   }
   return scvae::decoder_fused_forward((hipStream_t)stream, kind, d, (int)rows, (int)H, hp, (int)F,
                                       t, (int)cells, row_const, ll, (float*)workspace, arith);

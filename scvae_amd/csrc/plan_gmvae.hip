@@ -436,7 +436,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     else
       TRY(decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, tg, B, p->gw, a->row_const,
                               p->ll, dcur, p->fused_ws, p->head_arith, false,
-                              head_drop ? &hdrop : nullptr));
+                              head_drop ? &hdrop : nullptr, p->dd_atomics));
   } else if (KM > 0) {
     TRY(loglik_cat_bwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->gw, p->ll, R, B, F));
   } else if (cpoisson) {

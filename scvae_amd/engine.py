@@ -303,6 +303,13 @@ class Engine:
         _lib.check(self.lib.scvae_plan_set_head_arith(self.handle, mode),
                    "scvae_plan_set_head_arith")
 
+    def set_dd_atomics(self, enabled):
+        """Accumulate the decoder gradient ``dd`` of a training step with
+        XCD-local fp32 atomics instead of per-strip slabs (faster where the
+        head kernel has that store; the sums are not bit-repeatable)."""
+        _lib.check(self.lib.scvae_plan_set_dd_atomics(
+            self.handle, 1 if enabled else 0), "scvae_plan_set_dd_atomics")
+
     @property
     def head_arith(self):
         return ("fp32", "bf16x9")[self.lib.scvae_plan_head_arith(self.handle)]

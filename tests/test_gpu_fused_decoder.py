@@ -27,7 +27,8 @@ def head_arith(request):
     ARITH["flag"] = 0
 
 
-def _run(device, name, rows, cells, F, H, density, seed=0, row_const=True):
+def _run(device, name, rows, cells, F, H, density, seed=0, row_const=True,
+         extra_flags=0):
     from scvae_amd import _lib
     lib = _lib.load()
     kind, heads = _lib.LIKELIHOOD_KINDS[name]
@@ -65,7 +66,8 @@ def _run(device, name, rows, cells, F, H, density, seed=0, row_const=True):
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for train in (0, 1):
         _lib.check(lib.scvae_decoder_fused(
-            kind, train | ARITH["flag"], dd_.data_ptr(), rows, H, arr(Wd), arr(bd), arr(dWd),
+            kind, train | ARITH["flag"] | (extra_flags if train else 0),
+            dd_.data_ptr(), rows, H, arr(Wd), arr(bd), arr(dWd),
             arr(dbd), F, td.data_ptr(), cells, gwd.data_ptr(),
             rc.data_ptr() if rc is not None else None, ll.data_ptr(),
             dd.data_ptr(), ws.data_ptr(), stream), "scvae_decoder_fused")
@@ -173,3 +175,54 @@ def test_repeated_targets_and_inline_lgamma(cuda_device):
     _run(cuda_device, "poisson", 90, 30, 77, 24, 0.3, row_const=False)
     _run(cuda_device, "zero-inflated poisson", 60, 20, 77, 24, 0.3,
          row_const=False)
+
+
+@pytest.mark.parametrize("name", list(lk.ELEMENTWISE_LIKELIHOODS))
+def test_dd_through_xcd_local_atomics(cuda_device, name, head_arith):
+    """``SCVAE_HEADS_DD_ATOMICS``: the strips' parts of ``dd`` added into eight
+    XCD-local accumulators (fp32 atomics) instead of written as slabs -- against
+    the fp64 reference like every other case (several row tiles and strips, a
+    ragged last tile), and against the slab path: the same ``ll`` / ``dW`` /
+    ``db`` bit for bit, ``dd`` to fp32 rounding of a differently ordered sum."""
+    from scvae_amd import _lib
+    _run(cuda_device, name, 300, 300, 500, 100, 0.1,
+         extra_flags=_lib.HEADS_DD_ATOMICS)
+    _run(cuda_device, name, 70, 35, 130, 20, 0.3,
+         extra_flags=_lib.HEADS_DD_ATOMICS)
+    if head_arith != "bf16x9":
+        return          # (the fp32 kernels have no such store: the flag is ignored)
+    lib = _lib.load()
+    kind, heads = _lib.LIKELIHOOD_KINDS[name]
+    P = len(heads)
+    rows, F, H = 1000, 700, 100
+    g = torch.Generator(device=cuda_device).manual_seed(11)
+    d = torch.relu(torch.randn(rows, H, device=cuda_device, generator=g))
+    W = [torch.randn(H, F, device=cuda_device, generator=g) * 0.1 for _ in range(P)]
+    b = [torch.randn(F, device=cuda_device, generator=g) * 0.1 for _ in range(P)]
+    t = torch.poisson(torch.full((rows, F), 2.0, device=cuda_device), generator=g)
+    t = t * (torch.rand(rows, F, device=cuda_device, generator=g) < 0.1)
+    gw = torch.randn(rows, device=cuda_device, generator=g)
+    rc = torch.lgamma(t + 1).sum(dim=1)
+    ws = torch.empty(lib.scvae_decoder_fused_workspace_bytes(rows, H, F),
+                     dtype=torch.uint8, device=cuda_device)
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[x.data_ptr() for x in ts])
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = {}
+    for flags in (0, _lib.HEADS_DD_ATOMICS):
+        dW = [torch.zeros_like(w) for w in W]
+        db = [torch.zeros_like(v) for v in b]
+        ll = torch.zeros(rows, device=cuda_device)
+        dd = torch.zeros(rows, H, device=cuda_device)
+        _lib.check(lib.scvae_decoder_fused(
+            kind, 1 | _lib.HEADS_BF16X9 | flags, d.data_ptr(), rows, H, arr(W),
+            arr(b), arr(dW), arr(db), F, t.data_ptr(), rows, gw.data_ptr(),
+            rc.data_ptr(), ll.data_ptr(), dd.data_ptr(), ws.data_ptr(), stream),
+            "scvae_decoder_fused")
+        torch.cuda.synchronize()
+        out[flags] = (ll, dd, dW, db)
+    a, c = out[0], out[_lib.HEADS_DD_ATOMICS]
+    assert torch.equal(a[0], c[0])
+    for j in range(P):
+        assert torch.equal(a[2][j], c[2][j]) and torch.equal(a[3][j], c[3][j])
+    err = (a[1] - c[1]).abs().max().item()
+    assert err <= 2e-6 * a[1].abs().max().item(), err

@@ -24,8 +24,7 @@ where the over-read bug of round 3 lived), for
 through the C ABI (``scvae_decoder_fused`` / ``scvae_decoder_fused_u16``), and
 for the head-dropout (DROP) and constrained-Poisson (CP 1-3) instantiations
 through a training step of the engine.  The kernel variants a process does not
-take by default (schedule 3 for one / two heads, schedule 4 for three, four /
-eight producer waves, ``decoder_head_kernel`` for two heads, the forward
+take by default (schedule 3, four / eight producer waves, ``decoder_head_kernel`` for two heads, the forward
 instantiation of the fp32 training kernels) run in subprocesses with the
 library's A/B environment switches.
 
@@ -142,7 +141,7 @@ def _columns_close(got, want, what, terms=None):
         what, i, got2[i], want2[i])
 
 
-def _check(device, name, rows, F, H, arith, u16):
+def _check(device, name, rows, F, H, arith, u16, extra_flags=0):
     from scvae_amd import _lib
     lib = _lib.load()
     kind, heads = _lib.LIKELIHOOD_KINDS[name]
@@ -163,7 +162,7 @@ def _check(device, name, rows, F, H, arith, u16):
         raise AssertionError("no draw keeps clear of the clip boundaries")
     clipped = _outside_support(name, pre)
 
-    flag = _lib.HEAD_ARITH_FLAGS[arith]      # the arithmetic travels with the call
+    flag = _lib.HEAD_ARITH_FLAGS[arith] | extra_flags   # (they travel with the call)
     if True:
         f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().to(device)
         dd_, gwd = f32(d), f32(gw)
@@ -241,9 +240,16 @@ def test_clip_regime_at_the_benchmarked_width(cuda_device, name):
     _check(cuda_device, name, 130, 140, 100, "fp32", False)
 
 
+@pytest.mark.parametrize("name", ["negative binomial",
+                                  "zero-inflated negative binomial"])
+def test_clip_regime_with_dd_through_atomics(cuda_device, name):
+    from scvae_amd import _lib
+    _check(cuda_device, name, 200, 196, 20, "bf16x9", True,
+           extra_flags=_lib.HEADS_DD_ATOMICS)
+
+
 VARIANTS = [
-    {"SCVAE_D3_SCHEDULE": "3"},              # decoder_head3_kernel for one / two heads
-    {"SCVAE_D3_SCHEDULE": "4"},              # decoder_head4_kernel for three heads
+    {"SCVAE_D3_SCHEDULE": "3"},              # decoder_head3_kernel (training instantiation)
     {"SCVAE_D4_PRODUCERS": "4"},             # four producer waves (two heads)
     {"SCVAE_D4_PRODUCERS": "8"},             # eight producer waves (one head)
     {"SCVAE_DECODER_VARIANT": "1"},          # decoder_head_kernel for one / two heads

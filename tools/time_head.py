@@ -52,9 +52,12 @@ ll = torch.zeros(rows, device=dev)
 dd = torch.zeros(rows, H, device=dev)
 
 
+FLAGS = int(os.environ.get("TIME_HEAD_FLAGS", "0"), 0)   # e.g. 0x400: dd with XCD-local atomics
+
+
 def launch(train):
     _lib.check(lib.scvae_decoder_fused_u16(
-        kind, train, d.data_ptr(), rows, H, arr(W), arr(b), arr(dW), arr(db), F, t16.data_ptr(),
+        kind, train | FLAGS, d.data_ptr(), rows, H, arr(W), arr(b), arr(dW), arr(db), F, t16.data_ptr(),
         ld, rows, gw.data_ptr(), rc.data_ptr(), ll.data_ptr(), dd.data_ptr(), ws.data_ptr(),
         stream), "fused")
 
