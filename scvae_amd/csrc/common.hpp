@@ -26,6 +26,10 @@ int check_hip(hipError_t e, const char* what);
     int _rc = ::scvae::check_hip((call), #call);                   \
     if (_rc) return _rc;                                           \
   } while (0)
+// hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), issued only when a
+// kernel needs more than any earlier launch of it in this process on this device (a driver
+// call per launch is microseconds on paths tuned to the microsecond)
+hipError_t max_dynamic_lds(const void* fn, int bytes);
 #define SCVAE_LAUNCH_CHECK(name)                                   \
   do {                                                             \
     int _rc = ::scvae::check_hip(hipGetLastError(), name);         \

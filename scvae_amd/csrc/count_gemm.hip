@@ -631,8 +631,8 @@ static int count_gemm_impl(hipStream_t stream, int mode, const XT* x, int ldx, i
 #define SCVAE_CF(NQ_)                                                                             \
   do {                                                                                            \
     auto kfn = count_gemm_fwd_kernel<NQ_, XT>;                                                    \
-    SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
+    SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(kfn), \
+                                  (int)lds));         \
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, stream, x, ldx, M, k_main, T, Kpad, N, k_chunk, \
                        dst, ldo, kbias, kact, kdirect);                                           \
   } while (0)

@@ -264,8 +264,8 @@ int decoder_forward_launch(hipStream_t s, int kind, const float* d, int rows, in
   case KS_: {                                                                                   \
     auto kfn = t.u16 ? decoder_forward_kernel<K_, KS_, true>                                    \
                      : decoder_forward_kernel<K_, KS_, false>;                                  \
-    SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                          \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
+    SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(kfn), \
+                                  (int)lds));       \
     hipLaunchKernelGGL(kfn, dim3(strips), dim3(512), lds, s, d, rows, H, hp, F, t, B,           \
                        inline_lgamma, ll_part);                                                 \
   } break

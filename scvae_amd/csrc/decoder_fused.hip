@@ -712,8 +712,8 @@ static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int
 #define SCVAE_DF(K_)                                                                              \
   do {                                                                                            \
     auto kfn = decoder_head_kernel<K_, TRAIN, (K_ == LK_ZINB ? 32 : 64)>;                         \
-    SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
+    SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(kfn), \
+                                  (int)lds));         \
     hipLaunchKernelGGL(kfn, dim3(strips), dim3(DF_THREADS), lds, s, d, rows, H, magic_h, hp, F, t, \
                        B, gw, inline_lgamma, ll_part, dd_part, df_d_buffers(P, H));               \
   } while (0)

@@ -616,8 +616,8 @@ static int launch_decoder2(hipStream_t s, int kind, const float* d, int rows, in
     if constexpr (TRAIN && LikelihoodTraits<K_>::P <= 2) {                                        \
       if (rem) kfn = decoder_head2_kernel<K_, TRAIN, true>;                                       \
     }                                                                                             \
-    SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
+    SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(kfn), \
+                                  (int)lds));         \
     hipLaunchKernelGGL(kfn, dim3(strips), dim3(D2_THREADS), lds, s, d, rows, H, magic_h, hp, F,   \
                        t, B, gw, inline_lgamma, ll_part, dd_part);                                \
   } while (0)

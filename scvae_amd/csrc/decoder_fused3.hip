@@ -852,6 +852,13 @@ size_t decoder_fused4_lds_bytes(int P, int H, int npw) {
 #ifndef D4_PROF
 #define D4_PROF 0
 #endif
+// s_setprio of the two kinds of waves (A/B: scvae_amd/csrc/build_prof.sh with EXTRA=-D...)
+#ifndef D4_PRIO_PRODUCER
+#define D4_PRIO_PRODUCER 1
+#endif
+#ifndef D4_PRIO_CONSUMER
+#define D4_PRIO_CONSUMER 0
+#endif
 #if D4_PROF
 // probe build: cycles (s_memtime) per section, summed over the tiles, of the waves of block 0
 __device__ unsigned long long d4_prof[12 * 8];
@@ -958,7 +965,7 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
     // =========================== producers: GEMM1 + likelihood + G ===========================
     // (their GEMM1 + likelihood chain is the longer of the two; measured: which producers win the
     //  arbitration changes who waits at the barrier, not the tile time)
-    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(D4_PRIO_PRODUCER);
     const int gp = w % NGP, rq = w / NGP;     // genes 16 NSB gp .., rows 16 rq .. of the tile
     const int gbase = 16 * NSB * gp;
     const int trw = (8 * q + (i16 >> 2)) * ROWB + 2 * (gbase + 4 * (i16 & 3));        // W, GEMM1
@@ -1152,6 +1159,7 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
   }
 
   // =========================== consumers: GEMM3 (dd) and GEMM2 (dW) ===========================
+  __builtin_amdgcn_s_setprio(D4_PRIO_CONSUMER);
   const int ht = w - NPW;                         // h tile of this wave
   // (dd_atomic) the accumulator copy of the XCD this workgroup actually runs on: its adds are
   // then performed in that XCD's own L2, the only L2 that ever holds lines of that copy --
@@ -1398,8 +1406,8 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
   do {                                                                                            \
     auto kfn = t.u16 ? decoder_head3_kernel<K_, KS_, true, T_, D_, C_>                            \
                      : decoder_head3_kernel<K_, KS_, false, T_, D_, C_>;                          \
-    SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
+    SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(kfn), \
+                                  (int)lds));         \
     hipLaunchKernelGGL(kfn, dim3(strips), dim3(D3_THREADS), lds, s, dA, dT, rows, Rpad, H, hp, F, \
                        t, B, gw, inline_lgamma, ll_part, dd_part, bits, inv_keep, cpr);           \
   } while (0)
@@ -1445,8 +1453,8 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
   do {                                                                                            \
     auto kfn = t.u16 ? decoder_head4_kernel<K_, KS_, true, N_>                                    \
                      : decoder_head4_kernel<K_, KS_, false, N_>;                                  \
-    SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));        \
+    SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(kfn), \
+                                  (int)lds4));        \
     hipLaunchKernelGGL(kfn, dim3(strips), dim3(d4_threads(N_)), lds4, s, dA, dT, rows, Rpad, H,   \
                        hp, F, t, B, gw, inline_lgamma, ll_part, dd_part, dd_atomic);              \
   } while (0)

@@ -172,8 +172,7 @@ static int launch_cpoisson(hipStream_t stream, const float* t, int ldt, float* p
     return -1;
   }
   auto kfn = cpoisson_rows_kernel<GRAD, RATE>;
-  SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)lds));
   hipLaunchKernelGGL(kfn, dim3(rows), dim3(1024), lds, stream, t, ldt, pre, ldp, gw, count_sum,
                      row_const, ll, B, F);
   SCVAE_LAUNCH_CHECK("cpoisson_rows_kernel");
@@ -1697,8 +1696,7 @@ int csr_densify(hipStream_t stream, const int64_t* indptr, const int32_t* indice
   const size_t lds = ((size_t)F + 3) / 4 * 16;
   if (lds <= 152 * 1024) {
     auto kfn = noise.out ? csr_densify_lds_kernel<true> : csr_densify_lds_kernel<false>;
-    SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)lds));
     hipLaunchKernelGGL(kfn, dim3(B + noise_blocks_1024(noise)), dim3(1024), lds, stream, indptr,
                        indices, values, rows, F, out, ldo, row_values, row_values_out, B, noise);
     SCVAE_LAUNCH_CHECK("csr_densify_lds_kernel");
@@ -1770,8 +1768,7 @@ int csr_densify_u16(hipStream_t stream, const int64_t* indptr, const int32_t* in
                              : NoiseJob();
   const size_t lds = (size_t)ldo * 2;
   auto kfn = noise.out ? csr_densify_u16_kernel<true> : csr_densify_u16_kernel<false>;
-  SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)lds));
   hipLaunchKernelGGL(kfn, dim3(B + noise_blocks_1024(noise)), dim3(1024), lds, stream, indptr,
                      indices, values, rows, F, out, ldo, row_values, row_values_out, B, noise);
   SCVAE_LAUNCH_CHECK("csr_densify_u16_kernel");

@@ -709,10 +709,8 @@ unsigned vae_mid_barrier_advance(const MidChainArgs& q, bool backward) {
 // barrier needs every workgroup of the launch resident at once: checked against the occupancy
 // query (cached per device) instead of being assumed.
 static int mid_launch_setup() {
-  SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vae_mid_forward_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)MC_LDS_BYTES));
-  SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vae_mid_backward_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)MC_LDS_BYTES));
+  SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(vae_mid_forward_kernel), (int)MC_LDS_BYTES));
+  SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(vae_mid_backward_kernel), (int)MC_LDS_BYTES));
   return 0;
 }
 

@@ -1,4 +1,6 @@
 // Host-side execution plan of the VAE + the exported C ABI (see plan.hpp).
+#include <mutex>
+#include <vector>
 #include "plan.hpp"
 
 namespace scvae {
@@ -17,6 +19,26 @@ int check_hip(hipError_t e, const char* what) {
 }
 const char* last_error() { return g_error; }
 
+hipError_t max_dynamic_lds(const void* fn, int bytes) {
+  // (the attribute is a maximum: it is only ever raised, so a launch that needs less than an
+  //  earlier one of the same kernel finds it large enough)
+  // (one table for the process: the attribute belongs to the function, not to a host thread)
+  struct Seen { const void* fn; int device; int bytes; };
+  static std::vector<Seen> seen;
+  static std::mutex lock;
+  std::lock_guard<std::mutex> guard(lock);
+  int device = 0;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess) return e;
+  Seen* hit = nullptr;
+  for (Seen& s : seen)
+    if (s.fn == fn && s.device == device) { hit = &s; break; }
+  if (hit && hit->bytes >= bytes) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  if (hit) hit->bytes = bytes; else seen.push_back(Seen{fn, device, bytes});
+  return hipSuccess;
+}
 }  // namespace scvae
 
 namespace scvae {
@@ -1486,17 +1508,41 @@ int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
         return -1;
       }
     }
-    if (w->fetch_out)
+    // (the outputs of the side work must not OVERLAP what this step reads -- byte ranges, not
+    //  base pointers: a slice of one tensor at another offset would race the step's reads on
+    //  the second stream)
+    auto overlaps = [](const void* p1, size_t n1, const void* p2, size_t n2) {
+      if (!p1 || !p2 || !n1 || !n2) return false;
+      const char* a1 = (const char*)p1;
+      const char* a2 = (const char*)p2;
+      return a1 < a2 + n2 && a2 < a1 + n1;
+    };
+    const size_t Fsz = (size_t)p->cfg.feature_size;
+    if (w->fetch_out) {
       SCVAE_ARG(w->fetch_indptr && w->fetch_indices && w->fetch_values && w->fetch_rows &&
                 w->fetch_n > 0 && w->fetch_features > 0 && w->fetch_ld >= w->fetch_features &&
                 (w->fetch_as_u16 == 0 || w->fetch_as_u16 == 1) &&
-                w->fetch_out != (const void*)a->x && w->fetch_out != (const void*)a->t &&
-                w->fetch_out != (const void*)a->counts_u16 &&
-                (w->fetch_row_values_out == nullptr ||
-                 (w->fetch_row_values && w->fetch_row_values_out != a->row_const)));
-    if (w->noise_out)
-      SCVAE_ARG(w->noise_out != a->eps && w->noise_blocks >= 0 && w->noise_block_rows >= 0 &&
-                w->noise_cols > 0);
+                (w->fetch_row_values_out == nullptr || w->fetch_row_values));
+      const size_t out_bytes =
+          (size_t)w->fetch_n * (size_t)w->fetch_ld * (w->fetch_as_u16 ? 2 : 4);
+      const size_t x_bytes = (size_t)a->cells * Fsz * sizeof(float);
+      SCVAE_ARG(!overlaps(w->fetch_out, out_bytes, a->x, x_bytes) &&
+                !overlaps(w->fetch_out, out_bytes, a->t, x_bytes) &&
+                !overlaps(w->fetch_out, out_bytes, a->counts_u16,
+                          (size_t)a->cells * (size_t)a->counts_ld * 2) &&
+                !overlaps(w->fetch_row_values_out, (size_t)w->fetch_n * sizeof(float),
+                          a->row_const, (size_t)a->cells * sizeof(float)));
+    }
+    if (w->noise_out) {
+      SCVAE_ARG(w->noise_blocks >= 0 && w->noise_block_rows >= 0 && w->noise_cols > 0);
+      const size_t samples = (size_t)(a->n_iw > 0 ? a->n_iw : 1) * (size_t)(a->n_mc > 0 ? a->n_mc : 1);
+      SCVAE_ARG(!overlaps(w->noise_out,
+                          ((size_t)(w->noise_blocks > 0 ? w->noise_blocks - 1 : 0) *
+                               (size_t)w->noise_block_stride +
+                           (size_t)w->noise_block_rows * (size_t)w->noise_cols) * sizeof(float),
+                          a->eps, samples * (size_t)a->cells * (size_t)p->cfg.latent_size *
+                                      sizeof(float)));
+    }
     p->side = w;
   }
   int rc;

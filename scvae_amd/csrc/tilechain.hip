@@ -290,8 +290,7 @@ int tile_forward(hipStream_t s, const TileFwdArgs& q) {
   SCVAE_ARG(q.rows > 0 && q.K > 0 && q.K <= TC_MAXN && q.n_out >= 0 && q.n_out <= 2);
   SCVAE_ARG(q.bn.a || (q.x && q.ldx == q.K));      // (tiles are contiguous blocks)
   for (int o = 0; o < q.n_out; ++o) SCVAE_ARG(q.o[o].N > 0 && q.o[o].N <= TC_MAXN);
-  SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_fwd_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)TC_FWD_LDS));
+  SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(tile_fwd_kernel), (int)TC_FWD_LDS));
   hipLaunchKernelGGL(tile_fwd_kernel, dim3((q.rows + TC_ROWS - 1) / TC_ROWS), dim3(TC_THREADS),
                      TC_FWD_LDS, s, q);
   SCVAE_LAUNCH_CHECK("tile_fwd_kernel");
@@ -531,8 +530,7 @@ int tile_backward(hipStream_t s, const TileBwdArgs& q) {
   SCVAE_ARG(q.rows > 0 && q.n_up >= 1 && q.n_up <= 2 && q.K >= 0 && q.K <= TC_MAXN);
   SCVAE_ARG(!q.bn.a || q.n_up == 1);
   for (int u = 0; u < q.n_up; ++u) SCVAE_ARG(q.up[u].N > 0 && q.up[u].N <= TC_MAXN);
-  SCVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_bwd_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)TC_BWD_LDS));
+  SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(tile_bwd_kernel), (int)TC_BWD_LDS));
   hipLaunchKernelGGL(tile_bwd_kernel, dim3((q.rows + TC_ROWS - 1) / TC_ROWS), dim3(TC_THREADS),
                      TC_BWD_LDS, s, q);
   SCVAE_LAUNCH_CHECK("tile_bwd_kernel");

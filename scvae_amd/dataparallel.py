@@ -69,17 +69,23 @@ def gradient_group_for(group=None):
     ``gradient_group``."""
     ranks = tuple(dist.get_process_group_ranks(group) if group is not None
                   else range(dist.get_world_size()))
-    key = (dist.get_backend(group), ranks)
+    # (the identity of the default process group is part of the key: after
+    #  destroy_process_group() + init_process_group() in one process -- tests, notebooks,
+    #  elastic restarts -- a communicator cached under the old world is stale)
+    world = dist.group.WORLD
+    key = (dist.get_backend(group), ranks, id(world))
+    for stale in [k for k in _GRADIENT_GROUPS if k[2] != id(world)]:
+        del _GRADIENT_GROUPS[stale]
     if key not in _GRADIENT_GROUPS:
-        _GRADIENT_GROUPS[key] = dist.new_group(ranks=list(ranks),
-                                               backend=key[0])
-    return _GRADIENT_GROUPS[key]
+        _GRADIENT_GROUPS[key] = (world, dist.new_group(ranks=list(ranks),
+                                                       backend=key[0]))
+    return _GRADIENT_GROUPS[key][1]
 
 
 def release_gradient_groups():
     """Destroy the cached gradient communicators (before
     ``dist.destroy_process_group()`` at the end of a job)."""
-    for g in _GRADIENT_GROUPS.values():
+    for _, g in _GRADIENT_GROUPS.values():
         try:
             dist.destroy_process_group(g)
         except Exception:   # the default group is already gone

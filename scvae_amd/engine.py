@@ -460,7 +460,8 @@ class Engine:
                 side.adam_m = self.adam_m.data_ptr()
                 side.adam_v = self.adam_v.data_ptr()
                 side.adam_grad_scale = float(grad_scale)
-                side.adam_lr_t = self._next_adam_lr_t(learning_rate)
+                # (adam_t advances only once the step has been accepted, below)
+                side.adam_lr_t = self._adam_lr_t(learning_rate, self.adam_t + 1)
                 side.adam_beta1 = ADAM_BETA1
                 side.adam_beta2 = ADAM_BETA2
                 side.adam_epsilon = ADAM_EPSILON
@@ -481,6 +482,8 @@ class Engine:
         _lib.check(self.lib.scvae_plan_step(
             self.handle, ctypes.byref(a), current_stream_handle(self.device)),
             "scvae_plan_step")
+        if side is not None and learning_rate is not None:
+            self.adam_t += 1      # a refused step raised above: no update, no count
         return out_scalars
 
     def dropout_mask(self, site, rows, cols, keep, dropout_seed):
@@ -509,18 +512,18 @@ class Engine:
             current_stream_handle(self.device)), "scvae_plan_decode")
         return out
 
-    def _next_adam_lr_t(self, learning_rate):
-        """``lr_t`` of the next optimiser step (tf.train.AdamOptimizer)."""
-        self.adam_t += 1
-        t = self.adam_t
+    @staticmethod
+    def _adam_lr_t(learning_rate, t):
+        """``lr_t`` of optimiser step ``t`` (tf.train.AdamOptimizer)."""
         return (learning_rate * math.sqrt(1.0 - ADAM_BETA2 ** t)
                 / (1.0 - ADAM_BETA1 ** t))
 
     def adam_step(self, learning_rate, grad_scale=1.0):
         """clip-by-value(+-1) + ``tf.train.AdamOptimizer`` update (va:2742-2759)."""
-        lr_t = self._next_adam_lr_t(learning_rate)
+        lr_t = self._adam_lr_t(learning_rate, self.adam_t + 1)
         _lib.check(self.lib.scvae_adam_clip_step(
             _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m),
             _ptr(self.adam_v), self.params.numel(), float(grad_scale),
             float(lr_t), ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON,
             current_stream_handle(self.device)), "scvae_adam_clip_step")
+        self.adam_t += 1

@@ -39,7 +39,7 @@ ll = torch.zeros(rows, device=dev)
 dd = torch.zeros(rows, H, device=dev)
 for _ in range(3):
     _lib.check(lib.scvae_decoder_fused_u16(
-        kind, 3, d.data_ptr(), rows, H, arr(W), arr(b), arr(dW), arr(db), F, t16.data_ptr(),
+        kind, 3 | int(os.environ.get("TIME_HEAD_FLAGS", "0"), 0), d.data_ptr(), rows, H, arr(W), arr(b), arr(dW), arr(db), F, t16.data_ptr(),
         ld, rows, gw.data_ptr(), rc.data_ptr(), ll.data_ptr(), dd.data_ptr(), ws.data_ptr(),
         stream), "fused")
 torch.cuda.synchronize()
