@@ -40,6 +40,7 @@ if ROOT not in sys.path:
 N_CELLS, N_FEATURES = 68579, 32738
 HIDDEN, LATENT = (100, 100), 25
 LIKELIHOOD = "negative binomial"
+PEAK_HBM_TBPS = 8.0          # MI355X_MICROARCH.md: HBM3E spec peak
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense (MI355X_MICROARCH.md); the exact nine-term split of an
                                 # fp32 product costs nine bf16 MFMAs: 2500 / 9 = 277.8 TFLOP/s
@@ -335,6 +336,48 @@ def time_dominant_kernel(engine, rows, launches=10, u16=False, arith=None):
     }
 
 
+def hbm_rooflines(work, matrix, rows):
+    """The HBM-bound stages of the step: microseconds from HIP events recorded
+    around them inside training steps of the same workload (ten steps run right
+    behind the timed ones; scvae_plan_probe_stages, medians), algorithmic bytes (what the stage must move once,
+    stated per entry), achieved rate and its fraction of the 8 TB/s HBM peak."""
+    engine = work.engine
+    F, H = engine.feature_size, engine.hidden_sizes[0]
+    ld = (F + 63) // 64 * 64 if work.u16 else F
+    xb = 2 if work.u16 else 4
+    n = engine.params.numel()
+    density = matrix.values.numel() / float(matrix.shape[0] * matrix.shape[1])
+    strips = (F + 63) // 64
+    entries = [
+        ("fetch", "csr_densify{}_kernel (minibatch fetch)".format("_u16" if work.u16 else "_lds"),
+         xb * rows * ld + 8.0 * density * rows * F,
+         "{} B x rows x ld written + 8 B per stored non-zero read".format(xb)),
+        ("count_gemm_fwd", "count_gemm_fwd_kernel + operand split + reduce (x W1 + b)",
+         xb * rows * ld + 4.0 * F * H + 4.0 * rows * H,
+         "x read once + W1 [F, H] read + [rows, H] written, fp32"),
+        ("count_gemm_dw", "count_gemm_dw_kernel + operand split + reduce (x^T dA)",
+         xb * rows * ld + 4.0 * F * H + 4.0 * rows * H,
+         "x read once + dA [rows, H] read + dW1 [F, H] written, fp32"),
+        ("dd_reduce", "dd_reduce_xcd_kernel" if DD_ATOMICS else "dd_reduce_q_kernel",
+         4.0 * rows * H * ((8 if DD_ATOMICS else strips) + 1),
+         "the partial sums read once ({}) + dd [rows, H] written".format(
+             "8 XCD-local accumulators" if DD_ATOMICS else "{} strip slabs".format(strips))),
+        ("adam", "adam_clip_kernel", 28.0 * n,
+         "28 B per parameter (theta, m, v read + written, gradient read)"),
+    ]
+    out = []
+    for key, kernel, nbytes, note in entries:
+        us = work.stage_us.get(key) or []
+        if not us:
+            continue
+        med = statistics.median(us)
+        out.append({"kernel": kernel, "algorithmic_bytes": int(nbytes), "launch_us": med,
+                    "launches_timed": len(us), "achieved": nbytes / med * 1e-6,
+                    "unit": "TB/s", "peak": PEAK_HBM_TBPS,
+                    "frac": nbytes / med * 1e-6 / PEAK_HBM_TBPS, "bytes_counted": note})
+    return out
+
+
 # ----------------------------------------------------------------------------
 # a training workload on one rank
 # ----------------------------------------------------------------------------
@@ -483,6 +526,14 @@ class Workload:
         elapsed = time.perf_counter() - t0
         self.head_kernel_ms = self.engine.probe_heads_ms()
         self.engine.probe_heads(0)
+        # ... and, in ten further steps OUTSIDE the timed region (ten more event records per step
+        # would cost the headline about half a percent), around the step's HBM-bound stages
+        self.engine.probe_stages(10)
+        for _ in range(10):
+            self.one_step()
+        barrier()
+        self.stage_us = self.engine.probe_stages_us()
+        self.engine.probe_stages(0)
         per_step = [events[i].elapsed_time(events[i + 1]) for i in range(steps)]
         self.exposed_comm_ms = ([a.elapsed_time(b) for a, b in comm] if comm else [])
         return elapsed, per_step, warm_steps
@@ -522,6 +573,13 @@ def other_workloads(matrix, device, barrier):
             "cfg2/headline model at the reference's default minibatch: " +
             describe(n, F, LIKELIHOOD, False, 1, LATENT),
             matrix, 100, LIKELIHOOD, LATENT, "vae", 200)
+    # the minibatch regimes SURVEY.md section 8d names besides 4096, and the per-rank shard of a
+    # strong-scaled 4096-cell step on eight GPUs (512)
+    for b, steps in ((512, 100), (1024, 60), (16384, 8)):
+        measure("headline_model_minibatch_{}".format(b),
+                "headline model, {} cells per step: ".format(b) +
+                describe(n, F, LIKELIHOOD, False, 1, LATENT),
+                matrix, b, LIKELIHOOD, LATENT, "vae", steps)
     measure("cfg3_zinb_vae_latent_100",
             describe(n, F, "zero-inflated negative binomial", False, 1, 100),
             matrix, 4096, "zero-inflated negative binomial", 100, "vae", 20)
@@ -702,6 +760,9 @@ def main():
             result["roofline_fp32_kernel"] = time_dominant_kernel(
                 engine, B * K, u16=work.u16, arith=0)
         headline = (not gm and args.likelihood == LIKELIHOOD and L == LATENT)
+        if rank == 0 and not gm:
+            # the HBM-bound kernels of the step (achieved bytes / peak)
+            result["roofline_hbm"] = hbm_rooflines(work, matrix, B)
         if world == 1 and headline and not args.no_other_workloads:
             result["other_workloads"] = other_workloads(matrix, device, barrier)
         if world == 1 and not args.no_cpu_baseline and headline:

@@ -163,6 +163,15 @@ int scvae_plan_set_bn_one_launch(scvae_plan* plan, int32_t enabled);
  * elapsed times in milliseconds to out[0 .. n), returning how many (or -1 / -2). */
 int scvae_plan_probe_heads(scvae_plan* plan, int32_t n);
 int scvae_plan_probe_heads_ms(scvae_plan* plan, float* out, int32_t n);
+/* The same for the HBM-bound stages of a training step: SCVAE_PROBE_STAGES event pairs per probed
+ * step, in this order: 0 fetch of the next minibatch (scvae_side_work), 1 / 2 the input layer's
+ * products x W1 + b and x^T dA on the count kernels (operand split + kernel + reduce), 3 the
+ * reduce of the decoder gradient's partial sums, 4 clip + Adam over the parameter buffer.
+ * scvae_plan_probe_stages_us writes [steps][SCVAE_PROBE_STAGES] microseconds (-1: that stage
+ * did not run in that step) and returns the number of steps recorded. */
+#define SCVAE_PROBE_STAGES 5
+int scvae_plan_probe_stages(scvae_plan* plan, int32_t n);
+int scvae_plan_probe_stages_us(scvae_plan* plan, float* out, int32_t n);
 /* Large VAE training minibatches (more than 128 rows, batch norm, no dropout, no data-parallel
  * hook): 1 (default) = every hidden layer and the posterior heads as ONE launch per layer and
  * direction -- a workgroup owns a 64-row tile, merges the batch-norm chunk statistics of the layer

@@ -145,6 +145,8 @@ SIGNATURES = {
         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
         c_int64]),
     "scvae_plan_set_sync": (c_int32, [c_void_p, SYNC_FN, c_void_p]),
+    "scvae_plan_probe_stages": (c_int32, [c_void_p, c_int32]),
+    "scvae_plan_probe_stages_us": (c_int32, [c_void_p, POINTER(c_float), c_int32]),
     "scvae_plan_set_fused": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_set_head_arith": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_head_arith": (c_int32, [c_void_p]),

@@ -673,6 +673,19 @@ int decoder_train_kernel(int P, int H, int arith) {
 // Measurement aid (scvae_plan_probe_heads): a pair of HIP events to record around the training
 // kernel proper -- after the pre-pass that cuts d into planes, before the reductions -- of the
 // next decoder_fused_train call on this host thread.
+static thread_local hipEvent_t* g_stage_events = nullptr;
+static thread_local unsigned* g_stage_recorded = nullptr;
+void stage_probe_arm(hipEvent_t* events, unsigned* recorded) {
+  g_stage_events = events;
+  g_stage_recorded = recorded;
+}
+void stage_probe(int stage, int which, hipStream_t s) {
+  if (!g_stage_events || stage < 0 || stage >= PS_COUNT) return;
+  // (a stage launched more than once per step -- the GMVAE's products with x -- times its first)
+  if (g_stage_recorded && (*g_stage_recorded >> (2 * stage + which)) & 1u) return;
+  if (hipEventRecord(g_stage_events[2 * stage + which], s) == hipSuccess && g_stage_recorded)
+    *g_stage_recorded |= 1u << (2 * stage + which);
+}
 static thread_local hipEvent_t g_probe[2] = {nullptr, nullptr};
 static thread_local bool g_probe_recorded = false;
 void decoder_fused_set_probe(hipEvent_t before, hipEvent_t after) {
@@ -899,6 +912,8 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
                      strips, rows, row_const, B, ll);
   SCVAE_LAUNCH_CHECK("ll_reduce_kernel");
   const size_t n = (size_t)rows * H;
+  stage_probe(PS_DD_REDUCE, 0, s);
+  struct EndProbe { hipStream_t s; ~EndProbe() { stage_probe(PS_DD_REDUCE, 1, s); } } end_probe{s};
   if (decoder_train_kernel(likelihood_heads(kind), H, arith) == 3 &&
       decoder_fused3_dd_atomics(kind, H, drop != nullptr, 0, dd_mode)) {
     hipLaunchKernelGGL(dd_reduce_xcd_kernel, dim3((unsigned)(((size_t)((H + 3) / 4) * rows + 255) / 256)),

@@ -316,6 +316,19 @@ int decoder_fused_cpoisson(hipStream_t s, bool train, const float* d, int rows, 
                            HeadParams hp, int F, Targets t, int B, const float* gw,
                            const float* count_sum, const float* row_const, float* ll, float* dd,
                            float* workspace);
+// Measurement aid (scvae_plan_probe_stages): HIP event pairs around the HBM-bound stages of the
+// step this host thread launches next.  stage_probe(stage, 0 / 1, stream) records the begin / end
+// event of an armed table and is a no-op otherwise.
+enum ProbeStage : int {
+  PS_FETCH = 0,      // next minibatch: CSR rows -> dense (uint16) batch (+ its noise)
+  PS_COUNT_FWD = 1,  // x W1 + b on the count kernels (split + kernel + reduce)
+  PS_COUNT_DW = 2,   // x^T dA
+  PS_DD_REDUCE = 3,  // reduce of the decoder gradient's per-strip (or per-XCD) partials
+  PS_ADAM = 4,       // clip + Adam over the whole parameter buffer
+  PS_COUNT = 5
+};
+void stage_probe_arm(hipEvent_t* events /* [PS_COUNT][2] or nullptr */, unsigned* recorded);
+void stage_probe(int stage, int which, hipStream_t s);
 void decoder_fused_set_probe(hipEvent_t before, hipEvent_t after);   // (nullptr, nullptr): off
 hipEvent_t decoder_fused_probe(int which);
 bool decoder_fused_probe_recorded();   // both events of the pair went into a stream

@@ -230,8 +230,11 @@ int plan_gemm(scvae_plan* p, hipStream_t s, bool ta, bool tb, const float* A, co
       set_error("the uint16 minibatch reached a product the count kernels do not cover");
       return -1;
     }
-    return count_gemm_u16(s, mode, p->step_u16, p->step_u16_ld, rows, cols, B, ldb, N, bias, act,
-                          C, ldc, p->gemm_ws, p->gemm_ws_bytes);
+    stage_probe(mode ? PS_COUNT_DW : PS_COUNT_FWD, 0, s);
+    const int rc = count_gemm_u16(s, mode, p->step_u16, p->step_u16_ld, rows, cols, B, ldb, N,
+                                  bias, act, C, ldc, p->gemm_ws, p->gemm_ws_bytes);
+    stage_probe(mode ? PS_COUNT_DW : PS_COUNT_FWD, 1, s);
+    return rc;
   }
   if (p->x_counts && p->use_count_gemm && A == p->step_x && !tb && !accumulate &&
       count_gemm_supported(N)) {
@@ -243,9 +246,13 @@ int plan_gemm(scvae_plan* p, hipStream_t s, bool ta, bool tb, const float* A, co
     // ~600 cells (forward) / ~300 cells (weight gradient) upwards
     const bool pays = p->use_count_gemm >= 2 ||
                       ((double)rows * cols >= (mode == 0 ? 768.0 : 384.0) * 32768.0);
-    if (pays && count_gemm_workspace_bytes(mode, rows, cols, N) <= p->gemm_ws_bytes)
-      return count_gemm(s, mode, A, lda, rows, cols, B, ldb, N, bias, act, C, ldc, p->gemm_ws,
-                        p->gemm_ws_bytes);
+    if (pays && count_gemm_workspace_bytes(mode, rows, cols, N) <= p->gemm_ws_bytes) {
+      stage_probe(mode ? PS_COUNT_DW : PS_COUNT_FWD, 0, s);
+      const int rc = count_gemm(s, mode, A, lda, rows, cols, B, ldb, N, bias, act, C, ldc,
+                                p->gemm_ws, p->gemm_ws_bytes);
+      stage_probe(mode ? PS_COUNT_DW : PS_COUNT_FWD, 1, s);
+      return rc;
+    }
   }
   return gemm(s, ta, tb, A, B, bias, C, M, N, K, lda, ldb, ldc, act, accumulate, p->gemm_ws,
               p->gemm_ws_bytes);
@@ -642,6 +649,8 @@ static int side_jobs(const scvae_side_work* w, hipStream_t st) {
     nr.block_stride = w->noise_block_stride;
   }
   if (w->fetch_out) {
+    stage_probe(PS_FETCH, 0, st);
+    struct EndProbe { hipStream_t s; ~EndProbe() { stage_probe(PS_FETCH, 1, s); } } end_probe{st};
     if (w->fetch_as_u16)
       rc = csr_densify_u16(st, w->fetch_indptr, w->fetch_indices, w->fetch_values, w->fetch_rows,
                            (int)w->fetch_n, (int)w->fetch_features,
@@ -661,9 +670,13 @@ static int side_jobs(const scvae_side_work* w, hipStream_t st) {
 static int side_adam(scvae_plan* p, hipStream_t st, size_t begin, size_t end) {
   const scvae_side_work* w = p->side;
   if (!w->adam_m || end <= begin) return 0;
-  return adam_clip_step(st, p->params + begin, p->grads + begin, w->adam_m + begin,
-                        w->adam_v + begin, end - begin, w->adam_grad_scale, w->adam_lr_t,
-                        w->adam_beta1, w->adam_beta2, w->adam_epsilon);
+  const bool whole = begin == 0 && end == p->layout.n_params;
+  if (whole) stage_probe(PS_ADAM, 0, st);
+  const int rc = adam_clip_step(st, p->params + begin, p->grads + begin, w->adam_m + begin,
+                                w->adam_v + begin, end - begin, w->adam_grad_scale, w->adam_lr_t,
+                                w->adam_beta1, w->adam_beta2, w->adam_epsilon);
+  if (whole) stage_probe(PS_ADAM, 1, st);
+  return rc;
 }
 static int side_adam_point() {
   static const int at = [] {
@@ -1170,6 +1183,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
 // =============================== C ABI =====================================
 scvae_plan::~scvae_plan() {
   for (hipEvent_t e : probe_events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : stage_events) (void)hipEventDestroy(e);
   if (side_stream) {
     (void)hipStreamSynchronize(side_stream);
     (void)hipStreamDestroy(side_stream);
@@ -1324,6 +1338,35 @@ int scvae_plan_probe_heads_ms(scvae_plan* p, float* out, int32_t n) {
     SCVAE_HIP(hipEventElapsedTime(&ms, p->probe_events[2 * (size_t)i],
                                   p->probe_events[2 * (size_t)i + 1]));
     out[got++] = ms;
+  }
+  return got;
+}
+int scvae_plan_probe_stages(scvae_plan* p, int32_t n) {
+  SCVAE_ARG(p && n >= 0 && n <= 4096);
+  for (hipEvent_t e : p->stage_events) (void)hipEventDestroy(e);
+  p->stage_events.clear();
+  p->stage_recorded.assign((size_t)n, 0u);
+  p->stage_next = 0;
+  for (int i = 0; i < 2 * scvae::PS_COUNT * n; ++i) {
+    hipEvent_t e = nullptr;
+    SCVAE_HIP(hipEventCreate(&e));
+    p->stage_events.push_back(e);
+  }
+  return 0;
+}
+int scvae_plan_probe_stages_us(scvae_plan* p, float* out, int32_t n) {
+  SCVAE_ARG(p && out && n >= 0);
+  int got = 0;
+  for (int i = 0; i < p->stage_next && i < n; ++i, ++got) {
+    for (int st = 0; st < scvae::PS_COUNT; ++st) {
+      float ms = -1.f;
+      if (((p->stage_recorded[(size_t)i] >> (2 * st)) & 3u) == 3u) {
+        hipEvent_t* ev = &p->stage_events[(size_t)(i * scvae::PS_COUNT + st) * 2];
+        SCVAE_HIP(hipEventSynchronize(ev[1]));
+        SCVAE_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+      }
+      out[(size_t)i * scvae::PS_COUNT + st] = ms < 0.f ? -1.f : ms * 1e3f;
+    }
   }
   return got;
 }
@@ -1550,6 +1593,10 @@ int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
   if (probing)
     scvae::decoder_fused_set_probe(p->probe_events[2 * (size_t)p->probe_next],
                                    p->probe_events[2 * (size_t)p->probe_next + 1]);
+  const bool staging = a->training && (size_t)p->stage_next < p->stage_recorded.size();
+  if (staging)
+    scvae::stage_probe_arm(&p->stage_events[(size_t)p->stage_next * scvae::PS_COUNT * 2],
+                           &p->stage_recorded[(size_t)p->stage_next]);
   if (p->cfg.model_type == SCVAE_MODEL_GMVAE) {
     SCVAE_ARG(!a->deterministic_z);
     rc = scvae::gmvae_step(p, a, (hipStream_t)stream);
@@ -1565,9 +1612,15 @@ int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
     if (p->side_forked && hipEventRecord(p->side_join, p->side_stream) == hipSuccess)
       (void)hipStreamWaitEvent((hipStream_t)stream, p->side_join, 0);
     p->side = nullptr;
+    if (staging) scvae::stage_probe_arm(nullptr, nullptr);
     return rc;
   }
-  return scvae::plan_side_finish(p, (hipStream_t)stream);
+  rc = scvae::plan_side_finish(p, (hipStream_t)stream);
+  if (staging) {
+    scvae::stage_probe_arm(nullptr, nullptr);
+    ++p->stage_next;
+  }
+  return rc;
 }
 
 int scvae_adam_clip_step(float* theta, float* grad, float* m, float* v, int64_t n,

@@ -166,6 +166,11 @@ struct scvae_plan {
   // steps (measurement aid of bench.py)
   std::vector<hipEvent_t> probe_events;
   int probe_next = 0;
+  // scvae_plan_probe_stages: per probed step PS_COUNT event pairs (kernels.hpp: ProbeStage) and
+  // the mask of those that were recorded
+  std::vector<hipEvent_t> stage_events;
+  std::vector<unsigned> stage_recorded;
+  int stage_next = 0;
   ~scvae_plan();
   int use_mid_chain = 1;      // small VAE steps: hidden layers + heads + latent in two launches
   int use_tile_chain = 1;     // large VAE training steps: one launch per hidden layer and direction

@@ -341,6 +341,26 @@ class Engine:
                    "scvae_plan_probe_heads")
         self._probe_n = int(n)
 
+    PROBE_STAGES = ("fetch", "count_gemm_fwd", "count_gemm_dw", "dd_reduce", "adam")
+
+    def probe_stages(self, n):
+        """Arm HIP-event pairs around the HBM-bound stages of the next ``n``
+        training steps (0: off); ``probe_stages_us`` reads them back."""
+        _lib.check(self.lib.scvae_plan_probe_stages(self.handle, int(n)),
+                   "scvae_plan_probe_stages")
+        self._stage_n = int(n)
+
+    def probe_stages_us(self):
+        """{stage: [microseconds per probed step]} (waits for the events)."""
+        n = getattr(self, "_stage_n", 0)
+        k = len(self.PROBE_STAGES)
+        out = (ctypes.c_float * (n * k))()
+        got = self.lib.scvae_plan_probe_stages_us(self.handle, out, n)
+        if got < 0:
+            _lib.check(got, "scvae_plan_probe_stages_us")
+        return {name: [out[i * k + j] for i in range(got) if out[i * k + j] >= 0]
+                for j, name in enumerate(self.PROBE_STAGES)}
+
     def probe_heads_ms(self):
         """Durations (ms) of the probed kernel launches recorded so far (waits
         for them on the host)."""
