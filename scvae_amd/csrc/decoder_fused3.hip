@@ -882,7 +882,12 @@ __device__ unsigned long long d4_prof[12 * 8];
 #define D4_PROF_END do {} while (0)
 #endif
 
-template <int KIND, int KS1, bool U16, int NPW>
+// G1LAST: where the producers' GEMM1 sits relative to the workgroup barrier -- true: at the END
+// of an iteration (for the tile after the one whose likelihood the iteration evaluates), false:
+// at its start.  Measured (4096 x 32 738, kernel + reduces, dd atomics): with four producer
+// waves the end is better (ZINB 2.35 -> 2.23 ms, Poisson 0.82 -> 0.81), with eight the start
+// (NB 1.42 against 1.50).
+template <int KIND, int KS1, bool U16, int NPW, bool G1LAST = (NPW == 4)>
 __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
     const uint16_t* __restrict__ dA, const uint16_t* __restrict__ dT, int R, int Rpad, int H,
     HeadParams hp, int F, Targets tg, int B, const float* __restrict__ gw, int inline_lgamma,
@@ -1014,8 +1019,52 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
         for (int pl = 0; pl < 3; ++pl) dfr[ks][pl] = global_b128(dbase + pl * dplane);
       }
     };
+    // GEMM1 of a tile from the fragments of d in dfr: pre_j^T[gene, row] on the accumulators
+    f32x4m acc1[P][NSB];
+    auto gemm1 = [&]() {
+#pragma unroll
+      for (int j = 0; j < P; ++j)
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) acc1[j][sb] = f32x4m{0.f, 0.f, 0.f, 0.f};
+      bf16x8 afr[2][P][NSB][3];
+      auto load_w = [&](int ks, bf16x8 (&dst)[P][NSB][3]) {
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+#pragma unroll
+          for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+              dst[j][sb][pl] = lds_tr8<ROWB>(Wl + (size_t)(j * 3 + pl) * WPLANE + trw + 32 * sb +
+                                             32 * ks * ROWB);
+      };
+      load_w(0, afr[0]);
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) {
+        if (ks + 1 < KS1) load_w(ks + 1, afr[(ks + 1) & 1]);
+        // small terms first; the accumulators (head x gene block) are independent chains
+#pragma unroll
+        for (int a = 2; a >= 0; --a)
+#pragma unroll
+          for (int b = 2; b >= 0; --b)
+#pragma unroll
+            for (int j = 0; j < P; ++j)
+#pragma unroll
+              for (int sb = 0; sb < NSB; ++sb)
+                acc1[j][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    afr[ks & 1][j][sb][a], dfr[ks][b], acc1[j][sb], 0, 0, 0);
+      }
+    };
+    // (G1LAST) the barrier sits between GEMM1 of a tile and its likelihood: when it releases, the
+    // producers are in their VALU stretch and the consumers' GEMM2 finds the matrix pipe free;
+    // the producers' GEMM1 of the NEXT tile runs at the end of the iteration, under the
+    // consumers' stores (or atomic adds) of dd, which issue no matrix instructions.
     TileIn nxt = load_t(0);
     load_d(0);
+    if (G1LAST) {
+      gemm1();
+      load_d(min(D4_BM, Rpad - D4_BM));
+      d3_pin_loads();
+    }
     D4_PROF_BEGIN;
     for (int tile = 0; tile < n_tiles; ++tile) {
       const int m0 = tile * D4_BM;
@@ -1024,48 +1073,13 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
       const float up = cur.up0;
       char* Gb = Gl + (tile & 1) * GBUF;
       float* lb = llbuf + (tile & 1) * LLN;
-      f32x4m acc1[P][NSB];
-#pragma unroll
-      for (int j = 0; j < P; ++j)
-#pragma unroll
-        for (int sb = 0; sb < NSB; ++sb) acc1[j][sb] = f32x4m{0.f, 0.f, 0.f, 0.f};
+      if (!G1LAST) gemm1();
       {
-        bf16x8 afr[2][P][NSB][3];
-        auto load_w = [&](int ks, bf16x8 (&dst)[P][NSB][3]) {
-#pragma unroll
-          for (int j = 0; j < P; ++j)
-#pragma unroll
-            for (int sb = 0; sb < NSB; ++sb)
-#pragma unroll
-              for (int pl = 0; pl < 3; ++pl)
-                dst[j][sb][pl] = lds_tr8<ROWB>(Wl + (size_t)(j * 3 + pl) * WPLANE + trw + 32 * sb +
-                                               32 * ks * ROWB);
-        };
-        load_w(0, afr[0]);
-#pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) {
-          if (ks + 1 < KS1) load_w(ks + 1, afr[(ks + 1) & 1]);
-          // small terms first; the accumulators (head x gene block) are independent chains
-#pragma unroll
-          for (int a = 2; a >= 0; --a)
-#pragma unroll
-            for (int b = 2; b >= 0; --b)
-#pragma unroll
-              for (int j = 0; j < P; ++j)
-#pragma unroll
-                for (int sb = 0; sb < NSB; ++sb)
-                  acc1[j][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                      afr[ks & 1][j][sb][a], dfr[ks][b], acc1[j][sb], 0, 0, 0);
-        }
-      }
-      D4_STAMP(0);
-      {
-        // the next tile's targets and d fragments: under the likelihood.  Unconditional (the
-        // last tile requests a valid tile again): under a branch the compiler waits for the
-        // loads where the arms meet
-        const int mn = min(m0 + D4_BM, Rpad - D4_BM);
-        nxt = load_t(mn);
-        load_d(mn);
+        // the next tile's targets (and, GEMM1 first, its fragments of d): under the likelihood.
+        // Unconditional (the last tile requests a valid tile again): under a branch the compiler
+        // waits for the loads where the arms meet
+        nxt = load_t(min(m0 + D4_BM, Rpad - D4_BM));
+        if (!G1LAST) load_d(min(m0 + D4_BM, Rpad - D4_BM));
         d3_pin_loads();
       }
       // ---- likelihood of this lane's NSB x 4 elements: row 16 rq + i16, genes
@@ -1150,6 +1164,14 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
               u32x2{pack_hi16(b3[0], b3[1]), pack_hi16(b3[2], b3[3])};
         }
       D4_STAMP(3);
+      // GEMM1 of the next tile (the last iteration: a valid tile again, unused), then the request
+      // for the fragments of the tile after it
+      if (G1LAST) {
+        gemm1();
+        load_d(min(m0 + 2 * D4_BM, Rpad - D4_BM));
+        d3_pin_loads();
+      }
+      D4_STAMP(0);
       lds_barrier();
       D4_STAMP(4);
     }
