@@ -625,13 +625,18 @@ static size_t dd_part_floats(size_t strips, int rows, int H) {
   return (strips > 8 ? strips : 8) * (size_t)rows * ((H + 3) / 4 * 4);
 }
 
+bool decoder_fused_train_supported(int P, int H, int arith) {
+  return decoder_fused_supported(H) || (arith == 1 && decoder_fused4_supported(P, H));
+}
+
 size_t decoder_fused_workspace_floats(int rows, int H, int F, bool train) {
-  // (the bf16x9 kernel takes 32-gene strips for three heads: size for the narrowest strip)
-  const int bn = (train && decoder_fused3_supported(3, H)) ? decoder_fused3_strip_genes(3) : DF_BN;
+  // (the bf16x9 kernels take 32-gene strips for three heads, and for two beyond H = 110: size for
+  //  the narrowest strip)
+  const int bn = train ? 32 : DF_BN;
   const size_t strips = (size_t)(F + bn - 1) / bn;
   size_t n = strips * rows;                       // ll_part
   if (train) n += dd_part_floats(strips, rows, H) + 64; // dd_part (16-byte aligned start; H in quads)
-  if (train) n += decoder_fused3_workspace_floats(rows) + 64;   // bf16 planes of d (bf16x9 kernel)
+  if (train) n += decoder_fused3_workspace_floats(rows, H) + 64;   // bf16 planes of d (bf16x9 kernel)
   // (constrained Poisson passes: a second [strips][rows] array, lse[rows], S[rows])
   if (train) n += strips * (size_t)rows + 2 * (size_t)rows + 192;
   return n + 64;
@@ -666,8 +671,8 @@ int default_head_arith() {
   return v;
 }
 int decoder_train_kernel(int P, int H, int arith) {
-  if (arith == 1 && decoder_fused3_supported(P, H)) return 3;
-  return decoder_fused_variant(P, H);
+  if (arith == 1 && (decoder_fused3_supported(P, H) || decoder_fused4_supported(P, H))) return 3;
+  return decoder_fused_supported(H) ? decoder_fused_variant(P, H) : 0;
 }
 
 // Measurement aid (scvae_plan_probe_heads): a pair of HIP events to record around the training
@@ -842,7 +847,7 @@ int decoder_fused_cpoisson(hipStream_t s, bool train, const float* d, int rows, 
   float* ll_part = workspace;
   float* dd_part = ll_part + n_part;
   float* planes = dd_part + (dd_part_floats(strips, rows, H) + 63) / 64 * 64;
-  float* part2 = planes + (decoder_fused3_workspace_floats(rows) + 63) / 64 * 64;
+  float* part2 = planes + (decoder_fused3_workspace_floats(rows, H) + 63) / 64 * 64;
   float* lse = part2 + n_part;
   float* S = lse + ((size_t)rows + 63) / 64 * 64;
   CpRows cp;
@@ -893,11 +898,14 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
                         int F, Targets t, int B, const float* gw, const float* row_const,
                         float* ll, float* dd, float* workspace, int arith, bool kernel_only,
                         const HeadDropout* drop, int dd_mode) {
-  SCVAE_ARG(d && t.p && gw && ll && dd && workspace && decoder_fused_supported(H));
-  if (rows == 0) return 0;
   const int heads = likelihood_heads(kind);
-  const int bn = decoder_train_kernel(heads, H, arith) == 3 ? decoder_fused3_strip_genes(heads)
-                                                            : DF_BN;
+  SCVAE_ARG(d && t.p && gw && ll && dd && workspace &&
+            decoder_fused_train_supported(heads, H, arith));
+  SCVAE_ARG(!drop || decoder_fused3_supported(heads, H));
+  if (rows == 0) return 0;
+  const int bn = decoder_train_kernel(heads, H, arith) == 3
+                     ? decoder_fused3_train_strip_genes(heads, H, drop != nullptr, 0)
+                     : DF_BN;
   const int strips = (F + bn - 1) / bn;
   float* ll_part = workspace;
   size_t off = ((size_t)strips * rows + 63) / 64 * 64;

@@ -89,12 +89,19 @@ size_t decoder_fused3_lds_bytes(int P, int H) {
 bool decoder_fused3_supported(int P, int H) {
   return P <= 3 && H >= 2 && H <= 126 && decoder_fused3_lds_bytes(P, H) <= 160 * 1024;
 }
-// one plane set of d: dA [3][Rpad][128] then dT [3][128][Rpad], bf16
-__host__ __device__ inline size_t d3_set_elems(int Rpad) { return (size_t)2 * 3 * Rpad * D3_KP; }
+// padded hidden width of the planes of d: [d | 1 | 0 ...] in whole 32-wide contraction steps;
+// 128 for every H the all-in-one-phase kernel takes, up to 288 for the producer / consumer kernel
+__host__ __device__ inline int d3_kp(int H) { return H + 1 <= D3_KP ? D3_KP : (H + 1 + 31) / 32 * 32; }
+// one plane set of d: dA [3][Rpad][KP] then dT [3][KP][Rpad], bf16
+__host__ __device__ inline size_t d3_set_elems(int Rpad, int KP = D3_KP) {
+  return (size_t)2 * 3 * Rpad * KP;
+}
 // three plane sets (head dropout: one dropped-out copy of d per head) + the heads' mask words
-// [3][Rpad][4]
-size_t decoder_fused3_workspace_floats(int rows) {
+// [3][Rpad][4]; beyond H = 126 (no dropout instantiation there) one set
+size_t decoder_fused3_workspace_floats(int rows, int H) {
   const size_t rpad = (size_t)(rows + D3_BM - 1) / D3_BM * D3_BM;
+  const int kp = d3_kp(H);
+  if (kp > D3_KP) return d3_set_elems((int)rpad, kp) * sizeof(uint16_t) / sizeof(float) + 64;
   return 3 * d3_set_elems((int)rpad) * sizeof(uint16_t) / sizeof(float) + 3 * rpad * 4 + 64;
 }
 
@@ -114,16 +121,17 @@ __device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) {
 // for rows >= R), laid out FRAGMENT-MAJOR, so that the operand fragment of a wave is one
 // contiguous KiB (64 lanes x 16 bytes, eight full cache lines):
 //   dA[pl][rb][ks][lane][8]   GEMM1's B operand (16x16x32): row 16 rb + (lane & 15),
-//                             k = 32 ks + 8 (lane >> 4) + e                  (rb < Rpad / 16)
+//                             k = 32 ks + 8 (lane >> 4) + e    (rb < Rpad / 16, ks < KP / 32)
 //   dT[pl][ht][kg][lane][8]   GEMM2's A operand (32x32x16): h = 32 ht + (lane & 31),
 //                             row 16 kg + 8 (lane >> 5) + e                  (kg < Rpad / 16)
 // One thread = one lane slot of a fragment, all three planes.  blockIdx.y: 0 = dA, 1 = dT.
 __global__ __launch_bounds__(256) void split3_hidden_kernel(const float* __restrict__ d, int R,
-                                                            int H, int Rpad,
+                                                            int H, int Rpad, int KP,
                                                             uint16_t* __restrict__ dA,
                                                             uint16_t* __restrict__ dT) {
-  const int slot = blockIdx.x * 256 + threadIdx.x;       // < Rpad * 16
-  if (slot >= Rpad * 16) return;
+  const int slot = blockIdx.x * 256 + threadIdx.x;       // < Rpad * KP / 8
+  if (slot >= Rpad * (KP / 8)) return;
+  const int ksp = KP / 32;                               // contraction steps per 16-row block
   const int lane = slot & 63, frag = slot >> 6;
   const int nb = Rpad / 16;
   unsigned t1[8], t2[8], t3[8];
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(256) void split3_hidden_kernel(const float* __restr
     return k < H ? d[(size_t)r * H + k] : (k == H ? 1.f : 0.f);
   };
   if (blockIdx.y == 0) {
-    const int rb = frag >> 2, ks = frag & 3;
+    const int rb = frag / ksp, ks = frag % ksp;
     const int row = 16 * rb + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
 #pragma unroll
     for (int e = 0; e < 8; ++e) split3_trunc(value(row, k0 + e), t1[e], t2[e], t3[e]);
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256) void split3_hidden_kernel(const float* __restr
     v.z = pack_hi16(t[4], t[5]); v.w = pack_hi16(t[6], t[7]);
     return v;
   };
-  const size_t plane = (size_t)D3_KP * Rpad;
+  const size_t plane = (size_t)KP * Rpad;
   uint16_t* dst = (blockIdx.y == 0 ? dA : dT) + (size_t)slot * 8;
   *reinterpret_cast<u32x4*>(dst) = pack(t1);
   *reinterpret_cast<u32x4*>(dst + plane) = pack(t2);
@@ -844,8 +852,9 @@ constexpr int D4_BM = 32;           // rows per tile
 
 // NPW producer waves (4 or 8) + four consumers per workgroup
 __host__ __device__ constexpr int d4_threads(int npw) { return (npw + 4) * 64; }
-size_t decoder_fused4_lds_bytes(int P, int H, int npw) {
-  return (size_t)P * 3 * d3_hp1(H) * d3_rowb(P) + (size_t)2 * P * 3 * D4_BM * d3_rowb(P) +
+size_t decoder_fused4_lds_bytes(int P, int H, int npw, int bn = 0) {
+  const int rowb = 2 * (bn ? bn : d3_bn(P)) + 16;
+  return (size_t)P * 3 * d3_hp1(H) * rowb + (size_t)2 * P * 3 * D4_BM * rowb +
          (size_t)2 * (npw / 2) * 4 * D4_BM * sizeof(float);
 }
 
@@ -887,7 +896,16 @@ __device__ unsigned long long d4_prof[12 * 8];
 // at its start.  Measured (4096 x 32 738, kernel + reduces, dd atomics): with four producer
 // waves the end is better (ZINB 2.35 -> 2.23 ms, Poisson 0.82 -> 0.81), with eight the start
 // (NB 1.42 against 1.50).
-template <int KIND, int KS1, bool U16, int NPW, bool G1LAST = (NPW == 4)>
+// KS1 = ceil((H + 1) / 32) contraction steps of GEMM1 = 32-wide h tiles of GEMM2, up to 9
+// (H <= 256): beyond four, a consumer wave owns (KS1 + 3) / 4 h tiles (ht, ht + 4, ht + 8) and the
+// producers refill their four fragment slots of d inside the loop.  BN_: genes per strip (0: the
+// default of the head count; 32 for two heads once the weight planes of 64 genes no longer fit).
+// DBP (H a multiple of 32, from 128): the bias gradients db_j = column sums of G_j are summed by
+// the PRODUCERS on their registers (one add per element and tile, a cross-lane reduce at the end)
+// instead of falling out of GEMM2's ones row -- which at these widths would be an h tile of its
+// own (the fifth at H = 128, the ninth at 256) holding nothing but that row.
+template <int KIND, int KS1, bool U16, int NPW, int BN_ = 0, bool DBP = false,
+          bool G1LAST = (NPW == 4)>
 __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
     const uint16_t* __restrict__ dA, const uint16_t* __restrict__ dT, int R, int Rpad, int H,
     HeadParams hp, int F, Targets tg, int B, const float* __restrict__ gw, int inline_lgamma,
@@ -895,7 +913,11 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
   using Traits = LikelihoodTraits<KIND>;
   constexpr int P = Traits::P;
   constexpr int NT = d4_threads(NPW);
-  constexpr int BN = d3_bn(P), ROWB = d3_rowb(P);
+  constexpr int BN = BN_ ? BN_ : d3_bn(P), ROWB = 2 * BN + 16;
+  constexpr int NT2 = DBP ? KS1 - 1 : KS1;  // 32-wide h tiles of GEMM2
+  constexpr int NHT = (NT2 + 3) / 4;        // h tiles of a consumer wave
+  static_assert(!DBP || (NPW == 4 && KS1 >= 2), "DBP: four producers");
+  constexpr int DF = KS1 < 4 ? KS1 : 4;     // fragment slots of d a producer holds
   constexpr int GPLANE = D4_BM * ROWB;      // bytes of one [32 rows][BN genes] plane of G
   constexpr int GBUF = P * 3 * GPLANE;      // one tile's G: [P][3][32][BN + 8] bf16
   constexpr int NGP = NPW / 2;              // producer waves side by side over the strip's genes
@@ -922,7 +944,7 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
 
   // ---- LDS: zero fill, then the strip's weights and biases cut into planes (as above) ----
   constexpr int HSTEP = NT / BN;
-  constexpr int NV = (126 + HSTEP) / HSTEP;
+  constexpr int NV = (32 * KS1 + HSTEP - 1) / HSTEP;    // rows 0 .. H < 32 KS1 of a thread
   {
     const int g = tid & (BN - 1), h0 = tid / BN;
     const bool col_ok = c0 + g < F;
@@ -963,7 +985,8 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
   __syncthreads();
 
   const int n_tiles = (R + D4_BM - 1) / D4_BM;
-  const size_t dplane = (size_t)Rpad * D3_KP;
+  const int KP = d3_kp(H), ksp = KP / 32;   // padded width of the planes of d, in elements / steps
+  const size_t dplane = (size_t)Rpad * KP;
   const int nb16 = Rpad / 16;
 
   if (w < NPW) {
@@ -1010,18 +1033,19 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
     // d fragments of GEMM1 (B[k = h][n = row]): 3 planes per k-step, one contiguous KiB each; a
     // whole tile's worth is requested at once, behind the previous tile's GEMM1, and lands under
     // that tile's likelihood
-    bf16x8 dfr[KS1][3];
-    auto load_d = [&](int m0) {
+    bf16x8 dfr[DF][3];
+    auto load_dk = [&](int m0, int ks, bf16x8 (&dst)[3]) {
+      const uint16_t* dbase = dA + ((size_t)(m0 / 16 + rq) * ksp + ks) * 512 + lane * 8;
 #pragma unroll
-      for (int ks = 0; ks < KS1; ++ks) {
-        const uint16_t* dbase = dA + ((size_t)(m0 / 16 + rq) * 4 + ks) * 512 + lane * 8;
+      for (int pl = 0; pl < 3; ++pl) dst[pl] = global_b128(dbase + pl * dplane);
+    };
+    auto load_d = [&](int m0) {       // the first DF steps of a tile
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) dfr[ks][pl] = global_b128(dbase + pl * dplane);
-      }
+      for (int ks = 0; ks < DF; ++ks) load_dk(m0, ks, dfr[ks]);
     };
     // GEMM1 of a tile from the fragments of d in dfr: pre_j^T[gene, row] on the accumulators
     f32x4m acc1[P][NSB];
-    auto gemm1 = [&]() {
+    auto gemm1 = [&](int mt) {      // (mt: the tile's first row -- steps beyond DF are requested here)
 #pragma unroll
       for (int j = 0; j < P; ++j)
 #pragma unroll
@@ -1051,17 +1075,26 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
 #pragma unroll
               for (int sb = 0; sb < NSB; ++sb)
                 acc1[j][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    afr[ks & 1][j][sb][a], dfr[ks][b], acc1[j][sb], 0, 0, 0);
+                    afr[ks & 1][j][sb][a], dfr[ks % DF][b], acc1[j][sb], 0, 0, 0);
+        if (ks + DF < KS1) {        // this step's slot is free: step ks + DF of the same tile
+          load_dk(mt, ks + DF, dfr[ks % DF]);
+          d3_pin_loads();
+        }
       }
     };
     // (G1LAST) the barrier sits between GEMM1 of a tile and its likelihood: when it releases, the
     // producers are in their VALU stretch and the consumers' GEMM2 finds the matrix pipe free;
     // the producers' GEMM1 of the NEXT tile runs at the end of the iteration, under the
     // consumers' stores (or atomic adds) of dd, which issue no matrix instructions.
+    float dbacc[P][NE];                 // (DBP) this lane's part of db_j: its genes, its rows
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+      for (int e = 0; e < NE; ++e) dbacc[j][e] = 0.f;
     TileIn nxt = load_t(0);
     load_d(0);
     if (G1LAST) {
-      gemm1();
+      gemm1(0);
       load_d(min(D4_BM, Rpad - D4_BM));
       d3_pin_loads();
     }
@@ -1073,7 +1106,7 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
       const float up = cur.up0;
       char* Gb = Gl + (tile & 1) * GBUF;
       float* lb = llbuf + (tile & 1) * LLN;
-      if (!G1LAST) gemm1();
+      if (!G1LAST) gemm1(m0);
       {
         // the next tile's targets (and, GEMM1 first, its fragments of d): under the likelihood.
         // Unconditional (the last tile requests a valid tile again): under a branch the compiler
@@ -1146,6 +1179,12 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
         }
       }
       D4_STAMP(2);
+      if (DBP) {
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+#pragma unroll
+          for (int e = 0; e < NE; ++e) dbacc[j][e] += G[j][e];
+      }
       // ---- this lane's part of the row sum -> lb[gp][q][row]: the consumers add the parts ----
       lb[(gp * 4 + q) * D4_BM + 16 * rq + i16] = lsum;
       // ---- G_j -> three bf16 planes, row-major [row][gene], 8 bytes (4 genes) per store ----
@@ -1167,7 +1206,7 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
       // GEMM1 of the next tile (the last iteration: a valid tile again, unused), then the request
       // for the fragments of the tile after it
       if (G1LAST) {
-        gemm1();
+        gemm1(min(m0 + D4_BM, Rpad - D4_BM));
         load_d(min(m0 + 2 * D4_BM, Rpad - D4_BM));
         d3_pin_loads();
       }
@@ -1177,6 +1216,36 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
     }
     lds_barrier();     // (the consumers' pass over the last tile)
     D4_PROF_END;
+    if (DBP) {
+      // db_j[gene] = sum over the rows: over the 16 lanes of a q group (the tile's rows of this
+      // wave), then over the row blocks rq through LDS (the G tiles are free now), fixed order
+#pragma unroll
+      for (int j = 0; j < P; ++j)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          float v = dbacc[j][e];
+#pragma unroll
+          for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, WAVE);
+          dbacc[j][e] = v;
+        }
+      float* park = reinterpret_cast<float*>(Gl);        // [gp][j][e][q]
+      if (rq == 1 && i16 == 0) {
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+#pragma unroll
+          for (int e = 0; e < NE; ++e) park[((gp * P + j) * NE + e) * 4 + q] = dbacc[j][e];
+      }
+      lds_barrier();     // (every wave of the workgroup: the consumers pass it before their dW)
+      if (rq == 0 && i16 == 0) {
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            const int c = c0 + gbase + 16 * (e >> 2) + 4 * q + (e & 3);
+            if (c < F) hp.db[j][c] = dbacc[j][e] + park[((gp * P + j) * NE + e) * 4 + q];
+          }
+      }
+    }
     return;
   }
 
@@ -1191,30 +1260,40 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7u;
   }
-  const int n_ht3 = (H + 31) / 32, n_ht2 = (H + 1 + 31) / 32;
-  const bool do3 = ht < n_ht3, do2 = ht < n_ht2;
+  const int n_ht3 = (H + 31) / 32, n_ht2 = DBP ? H / 32 : (H + 1 + 31) / 32;
+  // this wave's h tiles: ht, ht + 4, ... (NHT of them; one for H <= 126)
   const int g3a = li * ROWB + 16 * kh;                                               // G, GEMM3
   const int g3b = (32 * ht + li) * ROWB + 16 * kh;                                   // W, GEMM3
   const int g2b = (8 * (q >> 1) + (i16 >> 2)) * ROWB + 2 * (16 * (q & 1) + 4 * (i16 & 3));  // G, GEMM2
-  f32x16 accW[P][NGT];                      // dW tile (h tile ht x gene tile) of every head
+  f32x16 accW[NHT][P][NGT];                 // dW tiles (h tile x gene tile) of every head
 #pragma unroll
-  for (int j = 0; j < P; ++j)
+  for (int t = 0; t < NHT; ++t)
 #pragma unroll
-    for (int gt = 0; gt < NGT; ++gt)
+    for (int j = 0; j < P; ++j)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) accW[j][gt][i] = 0.f;
-  // GEMM2's d fragments (A[i = h][k = row]): one contiguous KiB per plane and 16-row k-step;
-  // the two k-steps of a tile are requested during the tile before
-  bf16x8 a2[2][3];
-  auto load_a2 = [&](int m0) {
+      for (int gt = 0; gt < NGT; ++gt)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const uint16_t* tb = dT + ((size_t)ht * nb16 + m0 / 16 + ks) * 512 + lane * 8;
+        for (int i = 0; i < 16; ++i) accW[t][j][gt][i] = 0.f;
+  // GEMM2's d fragments (A[i = h][k = row]): one contiguous KiB per plane and 16-row k-step; the
+  // two k-steps of (row tile, h tile) are requested while the wave works on the pair before
+  constexpr int NA2 = NHT > 1 ? 2 : 1;
+  bf16x8 a2[NA2][2][3];
+  auto load_a2k = [&](int m0, int t, int ks, bf16x8 (&dst)[3]) {
+    // (h tile clamped to the planes' last: a wave without a tile t requests a valid one, unused
+    //  -- no branch around the loads, at whose end the compiler would wait for them)
+    const int htt = min(ht + 4 * t, ksp - 1);
+    const uint16_t* tb = dT + ((size_t)htt * nb16 + m0 / 16 + ks) * 512 + lane * 8;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) a2[ks][pl] = global_b128(tb + pl * dplane);
-    }
+    for (int pl = 0; pl < 3; ++pl) dst[pl] = global_b128(tb + pl * dplane);
   };
-  if (do2) load_a2(0);
+  auto load_a2 = [&](int m0, int t, bf16x8 (&dst)[2][3]) {
+    load_a2k(m0, t, 0, dst[0]);
+    load_a2k(m0, t, 1, dst[1]);
+  };
+  // (across the barrier -- and across GEMM3, where the wave's register need peaks -- only the
+  //  first k-step of the next row tile travels; the second is requested when its GEMM2 starts,
+  //  half a GEMM2 ahead of its use)
+  if (ht < n_ht2) load_a2k(0, 0, 0, a2[0][0]);
   lds_barrier();       // (the producers' first tile)
   D4_PROF_BEGIN;
   for (int tile = 0; tile < n_tiles; ++tile) {
@@ -1231,86 +1310,105 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
     D4_STAMP(0);
     // (GEMM2 first: GEMM3's stores -- or atomic adds -- of this tile's part of dd then sit
     //  right before the barrier and drain under the wait and the next tile's GEMM2)
-    if (do2 && !(dbg & 1)) {
-      // ---- GEMM2: dW_j[h, gene] += sum_row d[row, h] G_j[row, gene] ----
-      constexpr int NST = 2 * P * NGT;               // step = (k-step * P + head) * NGT + gene tile
-      bf16x8 bf[2][3];
-      auto load_2 = [&](int st, bf16x8 (&b)[3]) {
-        const int gt = st % NGT, j = (st / NGT) % P, ks = st / (NGT * P);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          b[pl] = lds_tr8<ROWB>(Gb + (size_t)(j * 3 + pl) * GPLANE + g2b + 64 * gt +
-                                16 * ks * ROWB);
-      };
-      load_2(0, bf[0]);
+    for (int t = 0; t < NHT; ++t) {
+      if (ht + 4 * t < n_ht2 && !(dbg & 1)) {
+        // ---- GEMM2: dW_j[h, gene] += sum_row d[row, h] G_j[row, gene] ----
+        bf16x8 (&a2t)[2][3] = a2[t % NA2];
+        if (t == 0) {
+          load_a2k(m0, 0, 1, a2[0][1]);
+          d3_pin_loads();
+        }
+        if (t + 1 < NHT) {
+          load_a2(m0, t + 1, a2[(t + 1) % NA2]);
+          d3_pin_loads();
+        }
+        constexpr int NST = 2 * P * NGT;             // step = (k-step * P + head) * NGT + gene tile
+        bf16x8 bf[2][3];
+        auto load_2 = [&](int st, bf16x8 (&b)[3]) {
+          const int gt = st % NGT, j = (st / NGT) % P, ks = st / (NGT * P);
 #pragma unroll
-      for (int st = 0; st < NST; ++st) {
-        if (st + 1 < NST) load_2(st + 1, bf[(st + 1) & 1]);
-        const int gt = st % NGT, j = (st / NGT) % P, ks = st / (NGT * P);
+          for (int pl = 0; pl < 3; ++pl)
+            b[pl] = lds_tr8<ROWB>(Gb + (size_t)(j * 3 + pl) * GPLANE + g2b + 64 * gt +
+                                  16 * ks * ROWB);
+        };
+        load_2(0, bf[0]);
 #pragma unroll
-        for (int a = 2; a >= 0; --a)
+        for (int st = 0; st < NST; ++st) {
+          if (st + 1 < NST) load_2(st + 1, bf[(st + 1) & 1]);
+          const int gt = st % NGT, j = (st / NGT) % P, ks = st / (NGT * P);
 #pragma unroll
-          for (int b = 2; b >= 0; --b)
-            accW[j][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks][a], bf[st & 1][b],
-                                                                  accW[j][gt], 0, 0, 0);
+          for (int a = 2; a >= 0; --a)
+#pragma unroll
+            for (int b = 2; b >= 0; --b)
+              accW[t][j][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2t[ks][a], bf[st & 1][b],
+                                                                       accW[t][j][gt], 0, 0, 0);
+        }
       }
-      // the next tile's fragments (the last tile: its own again), in flight over the barrier
-      load_a2(min(m0 + D4_BM, Rpad - D4_BM));
+    }
+    if (ht < n_ht2 && !(dbg & 1)) {
+      // the next row tile's fragments of this wave's first h tile (the last tile: its own
+      // again), in flight over the barrier
+      load_a2k(min(m0 + D4_BM, Rpad - D4_BM), 0, 0, a2[0][0]);
       d3_pin_loads();
     }
     D4_STAMP(2);
-    if (do3 && !(dbg & 1)) {
-      // ---- GEMM3: dd^T[h, row] = sum_j sum_gene W_j[h, gene] G_j[row, gene] ----
-      f32x16 acc3;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc3[i] = 0.f;
-      bf16x8 af[2][3], bf[2][3];
-      auto load_3 = [&](int st, bf16x8 (&a)[3], bf16x8 (&b)[3]) {   // step = head * KS3 + k-step
-        const int j = st / KS3, ks = st % KS3;
+    for (int t = 0; t < NHT; ++t) {
+      if (ht + 4 * t < n_ht3 && !(dbg & 1)) {
+        // ---- GEMM3: dd^T[h, row] = sum_j sum_gene W_j[h, gene] G_j[row, gene] ----
+        const int htt = ht + 4 * t;
+        f32x16 acc3;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          a[pl] = lds_b128(Gb + (size_t)(j * 3 + pl) * GPLANE + g3a + 32 * ks);
-          b[pl] = lds_b128(Wl + (size_t)(j * 3 + pl) * WPLANE + g3b + 32 * ks);
+        for (int i = 0; i < 16; ++i) acc3[i] = 0.f;
+        bf16x8 af[2][3], bf[2][3];
+        auto load_3 = [&](int st, bf16x8 (&a)[3], bf16x8 (&b)[3]) {   // step = head * KS3 + k-step
+          const int j = st / KS3, ks = st % KS3;
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            a[pl] = lds_b128(Gb + (size_t)(j * 3 + pl) * GPLANE + g3a + 32 * ks);
+            b[pl] = lds_b128(Wl + (size_t)(j * 3 + pl) * WPLANE + g3b + 128 * t * ROWB + 32 * ks);
+          }
+        };
+        load_3(0, af[0], bf[0]);
+#pragma unroll
+        for (int st = 0; st < KS3 * P; ++st) {
+          if (st + 1 < KS3 * P) load_3(st + 1, af[(st + 1) & 1], bf[(st + 1) & 1]);
+#pragma unroll
+          for (int a = 2; a >= 0; --a)
+#pragma unroll
+            for (int b = 2; b >= 0; --b)
+              acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[st & 1][b], af[st & 1][a], acc3,
+                                                             0, 0, 0);
         }
-      };
-      load_3(0, af[0], bf[0]);
+        D4_STAMP(1);
+        const int row = (dbg & 8) ? R : m0 + li;
+        if (dd_atomic) {
+          // no-return fp32 adds into this XCD's [H][R] accumulator (h-major: the 32 lanes of a
+          // half wave add to 128 contiguous bytes); dd_reduce_xcd_kernel sums the eight copies
+          if (row < R) {
+            typedef __attribute__((address_space(1))) float gfloat;
+            float* base = dd_part + ((size_t)xcc * H + 32 * htt + 4 * kh) * R + row;
 #pragma unroll
-      for (int st = 0; st < KS3 * P; ++st) {
-        if (st + 1 < KS3 * P) load_3(st + 1, af[(st + 1) & 1], bf[(st + 1) & 1]);
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int a = 2; a >= 0; --a)
+              for (int e = 0; e < 4; ++e)
+                if (32 * htt + 8 * c + 4 * kh + e < H)
+                  __builtin_amdgcn_global_atomic_fadd_f32(
+                      (gfloat*)(base + (size_t)(8 * c + e) * R), acc3[4 * c + e]);
+          }
+        } else if (row < R) {
+          // slab [strip][H / 4][R][4] (see decoder_head3_kernel): one 16-byte store per h quad
+          const int HQ = (H + 3) >> 2;
+          f32x4m* dst = reinterpret_cast<f32x4m*>(dd_part) +
+                        ((size_t)blockIdx.x * HQ + 8 * htt + kh) * R + row;
 #pragma unroll
-          for (int b = 2; b >= 0; --b)
-            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[st & 1][b], af[st & 1][a], acc3, 0,
-                                                           0, 0);
-      }
-      D4_STAMP(1);
-      // slab [strip][H / 4][R][4] (see decoder_head3_kernel): one 16-byte store per h quad
-      const int row = (dbg & 8) ? R : m0 + li;
-      if (dd_atomic) {
-        // no-return fp32 adds into this XCD's [H][R] accumulator (h-major: the 32 lanes of a half
-        // wave add to 128 contiguous bytes); dd_reduce_xcd_kernel sums the eight copies
-        if (row < R) {
-          typedef __attribute__((address_space(1))) float gfloat;
-          float* base = dd_part + ((size_t)xcc * H + 32 * ht + 4 * kh) * R + row;
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (32 * ht + 8 * c + 4 * kh + e < H)
-                __builtin_amdgcn_global_atomic_fadd_f32((gfloat*)(base + (size_t)(8 * c + e) * R),
-                                                        acc3[4 * c + e]);
-        }
-      } else if (row < R) {
-        const int HQ = (H + 3) >> 2;
-        f32x4m* dst = reinterpret_cast<f32x4m*>(dd_part) +
-                      ((size_t)blockIdx.x * HQ + 8 * ht + kh) * R + row;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (4 * (8 * ht + 2 * c + kh) < H)
-            __builtin_nontemporal_store(
-                f32x4m{acc3[4 * c], acc3[4 * c + 1], acc3[4 * c + 2], acc3[4 * c + 3]},
-                dst + (size_t)2 * c * R);
+          for (int c = 0; c < 4; ++c) {
+            if (4 * (8 * htt + 2 * c + kh) < H)
+              __builtin_nontemporal_store(
+                  f32x4m{acc3[4 * c], acc3[4 * c + 1], acc3[4 * c + 2], acc3[4 * c + 3]},
+                  dst + (size_t)2 * c * R);
+          }
         }
       }
     }
@@ -1319,20 +1417,25 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
     D4_STAMP(4);
   }
   D4_PROF_END;
+  if (DBP) lds_barrier();     // (the producers' exchange of their db parts)
   // ---- dW / db of the strip ----
-  if (do2) {
 #pragma unroll
-    for (int gt = 0; gt < NGT; ++gt) {
-      const int c = c0 + 32 * gt + li;
-      if (c < F) {
+  for (int t = 0; t < NHT; ++t) {
+    const int htt = ht + 4 * t;
+    if (htt < n_ht2) {
 #pragma unroll
-        for (int j = 0; j < P; ++j)
+      for (int gt = 0; gt < NGT; ++gt) {
+        const int c = c0 + 32 * gt + li;
+        if (c < F) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int h = 32 * ht + (i & 3) + 8 * (i >> 2) + 4 * kh;
-            if (h < H) hp.dW[j][(size_t)h * F + c] = accW[j][gt][i];
-            else if (h == H) hp.db[j][c] = accW[j][gt][i];
-          }
+          for (int j = 0; j < P; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int h = 32 * htt + (i & 3) + 8 * (i >> 2) + 4 * kh;
+              if (h < H) hp.dW[j][(size_t)h * F + c] = accW[t][j][gt][i];
+              else if (h == H) hp.db[j][c] = accW[t][j][gt][i];
+            }
+        }
       }
     }
   }
@@ -1348,25 +1451,59 @@ extern "C" int scvae_d4_prof_dump(unsigned long long* out) {
 // the default), 3 all waves in one phase (decoder_head3_kernel); read once
 // (SCVAE_D3_SCHEDULE=3 / 4 forces one for A/B runs and tests.  Measured at 4096 x 32 738, kernel +
 //  reduces: NB 1.49 against 1.58 ms, Poisson 0.90-0.92 against 0.90, ZINB 2.60-2.63 against 2.67)
-static int d3_schedule(int P) {
+static int d3_schedule_env() {
   static const int v = [] {
     const char* e = getenv("SCVAE_D3_SCHEDULE");
     return (e && (e[0] == '3' || e[0] == '4')) ? e[0] - '0' : 0;
   }();
-  (void)P;
-  return v ? v : 4;
+  return v;
 }
 // producer waves per workgroup: eight (16 x 16 blocks, three waves per SIMD) for two heads, four
 // for one head (measured, 4096 x 32 738: Poisson 0.81-0.83 ms with four, 0.87-0.88 with eight;
 // NB 1.49-1.51 with eight, 1.58-1.61 with four); SCVAE_D4_PRODUCERS=4 / 8 overrides (A/B).
-// Three heads (32-gene strips: four 16 x 16 blocks per tile) have four.
-static int d4_producers(int P) {
+// 32-gene strips (four 16 x 16 blocks per tile) have four.
+static int d4_producers_env() {
   static const int v = [] {
     const char* e = getenv("SCVAE_D4_PRODUCERS");
     return (e && (e[0] == '4' || e[0] == '8')) ? e[0] - '0' : 0;
   }();
-  if (P >= 3) return 4;
-  return v ? v : (P == 1 ? 4 : 8);
+  return v;
+}
+// The producer / consumer kernel's geometry for P heads and decoder width H: genes per strip,
+// producer waves, contraction steps; ok = it fits (LDS: the strip's weight planes + two G tiles)
+struct D4Config { int bn, npw, ks1; size_t lds; bool ok; bool dbp; };
+static D4Config d4_config(int P, int H) {
+  D4Config c;
+  c.ks1 = (H + 1 + 31) / 32;
+  c.bn = d3_bn(P);
+  c.npw = P >= 3 ? 4 : (d4_producers_env() ? d4_producers_env() : (P == 1 ? 4 : 8));
+  c.lds = decoder_fused4_lds_bytes(P, H, c.npw, c.bn);
+  if (c.lds > 160 * 1024 && c.bn == 64 && P == 2) {
+    // two heads beyond H = 110: the planes of 64 genes no longer fit -- 32-gene strips
+    c.bn = 32; c.npw = 4;
+    c.lds = decoder_fused4_lds_bytes(P, H, c.npw, c.bn);
+  }
+  if (c.ks1 > 4 && c.npw == 8) {   // (wide decoders: four producers -- the consumers own 2-3 h tiles)
+    c.npw = 4;
+    c.lds = decoder_fused4_lds_bytes(P, H, c.npw, c.bn);
+  }
+  // (H = 128, 160, .. 256: the bias gradient by the producers, GEMM2 without the ones row's tile)
+  c.dbp = H >= 128 && H % 32 == 0;
+  c.ok = P >= 1 && P <= 3 && H >= 2 && c.ks1 <= (c.dbp ? 9 : 8) && c.lds <= 160 * 1024;
+  return c;
+}
+bool decoder_fused4_supported(int P, int H) { return d4_config(P, H).ok; }
+// which schedule runs a plain training launch: 4 producer / consumer waves (decoder_head4_kernel,
+// the default and the only one beyond H = 126), 3 all waves in one phase (decoder_head3_kernel)
+static int d3_schedule(int P, int H) {
+  if (!decoder_fused3_supported(P, H)) return 4;
+  if (!decoder_fused4_supported(P, H)) return 3;
+  return d3_schedule_env() ? d3_schedule_env() : 4;
+}
+// genes per workgroup (= per slab of ll_part / dd_part) of a TRAINING launch
+int decoder_fused3_train_strip_genes(int P, int H, bool drop, int cp_pass) {
+  if (!drop && cp_pass == 0 && d3_schedule(P, H) == 4) return d4_config(P, H).bn;
+  return d3_bn(P);
 }
 
 // whether a training launch with these options accumulates dd with XCD-local atomics (the caller
@@ -1374,20 +1511,84 @@ static int d4_producers(int P) {
 // consumer kernel has that store
 bool decoder_fused3_dd_atomics(int kind, int H, bool drop, int cp_pass, int dd_mode) {
   const int P = likelihood_heads(kind);
-  return dd_mode && !drop && cp_pass == 0 && d3_schedule(P) == 4 &&
-         decoder_fused4_lds_bytes(P, H, d4_producers(P)) <= 160 * 1024;
+  return dd_mode && !drop && cp_pass == 0 && d3_schedule(P, H) == 4;
 }
 
 // the training instantiation a plain launch (no dropout, no constrained-Poisson pass) takes, as
 // rocprofv3 prints it (bench.py matches its HIP-event timing against the kernel trace by name)
 int decoder_fused3_train_kernel_name(int kind, int H, bool u16, char* out, size_t n) {
   const int P = likelihood_heads(kind);
-  const int ks1 = min((d3_hp1(H) + 31) / 32, 4);
-  if (d3_schedule(P) == 4 && decoder_fused4_lds_bytes(P, H, d4_producers(P)) <= 160 * 1024)
-    return snprintf(out, n, "decoder_head4_kernel<%d, %d, %s, %d>", kind, ks1,
-                    u16 ? "true" : "false", d4_producers(P));
-  return snprintf(out, n, "decoder_head3_kernel<%d, %d, %s, true, false, 0>", kind, ks1,
-                  u16 ? "true" : "false");
+  if (d3_schedule(P, H) == 4) {
+    const D4Config c = d4_config(P, H);
+    return snprintf(out, n, "decoder_head4_kernel<%d, %d, %s, %d, %d, %s, %s>", kind, c.ks1,
+                    u16 ? "true" : "false", c.npw, c.bn == d3_bn(P) ? 0 : c.bn,
+                    c.dbp ? "true" : "false", c.npw == 4 ? "true" : "false");
+  }
+  return snprintf(out, n, "decoder_head3_kernel<%d, %d, %s, true, false, 0>", kind,
+                  (d3_hp1(H) + 31) / 32, u16 ? "true" : "false");
+}
+
+// ---- launch of the producer / consumer kernel: the instantiation for (kind, steps, strip, waves) ----
+struct D4Launch {
+  hipStream_t s; const uint16_t* dA; const uint16_t* dT; int rows, Rpad, H; HeadParams hp; int F;
+  Targets t; int B; const float* gw; int inline_lgamma; float* ll_part; float* dd_part;
+  int dd_atomic; int strips; size_t lds;
+};
+template <int KIND, int KS1, int NPW, int BN_, bool DBP = false>
+static int d4_launch_one(const D4Launch& a) {
+  auto kfn = a.t.u16 ? decoder_head4_kernel<KIND, KS1, true, NPW, BN_, DBP>
+                     : decoder_head4_kernel<KIND, KS1, false, NPW, BN_, DBP>;
+  SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)a.lds));
+  hipLaunchKernelGGL(kfn, dim3(a.strips), dim3(d4_threads(NPW)), a.lds, a.s, a.dA, a.dT, a.rows,
+                     a.Rpad, a.H, a.hp, a.F, a.t, a.B, a.gw, a.inline_lgamma, a.ll_part,
+                     a.dd_part, a.dd_atomic);
+  return 0;
+}
+template <int KIND, int KS1>
+static int d4_launch_steps(const D4Launch& a, const D4Config& c) {
+  constexpr int P = likelihood_heads(KIND);
+  // (the combinations d4_config can return for P heads and KS1 steps)
+  if constexpr (KS1 >= 5) {
+    if (c.dbp) {
+      if constexpr (P == 1) return d4_launch_one<KIND, KS1, 4, 0, true>(a);
+      else if constexpr (P == 2) return d4_launch_one<KIND, KS1, 4, 32, true>(a);
+      else if constexpr (KS1 == 5) return d4_launch_one<KIND, KS1, 4, 0, true>(a);
+    }
+  }
+  if constexpr (KS1 == 9) {
+    set_error("decoder_head4_kernel: nine contraction steps only at H = 256");
+    return -1;
+  } else if constexpr (P == 1) {
+    if constexpr (KS1 <= 4) { if (c.npw == 8) return d4_launch_one<KIND, KS1, 8, 0>(a); }
+    return d4_launch_one<KIND, KS1, 4, 0>(a);
+  } else if constexpr (P == 2) {
+    if constexpr (KS1 <= 4) {
+      if (c.bn == 64) return c.npw == 8 ? d4_launch_one<KIND, KS1, 8, 0>(a)
+                                        : d4_launch_one<KIND, KS1, 4, 0>(a);
+    }
+    if constexpr (KS1 >= 4) return d4_launch_one<KIND, KS1, 4, 32>(a);
+    set_error("decoder_head4_kernel: no instantiation for %d steps on %d-gene strips", KS1, c.bn);
+    return -1;
+  } else {
+    if constexpr (KS1 <= 5) return d4_launch_one<KIND, KS1, 4, 0>(a);
+    set_error("decoder_head4_kernel: three heads beyond H = 159");
+    return -1;
+  }
+}
+template <int KIND>
+static int d4_launch_kind(const D4Launch& a, const D4Config& c) {
+  switch (c.ks1) {
+    case 1: return d4_launch_steps<KIND, 1>(a, c);
+    case 2: return d4_launch_steps<KIND, 2>(a, c);
+    case 3: return d4_launch_steps<KIND, 3>(a, c);
+    case 4: return d4_launch_steps<KIND, 4>(a, c);
+    case 5: return d4_launch_steps<KIND, 5>(a, c);
+    case 6: return d4_launch_steps<KIND, 6>(a, c);
+    case 7: return d4_launch_steps<KIND, 7>(a, c);
+    case 8: return d4_launch_steps<KIND, 8>(a, c);
+    case 9: return d4_launch_steps<KIND, 9>(a, c);
+    default: set_error("decoder_head4_kernel: %d contraction steps", c.ks1); return -1;
+  }
 }
 
 int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, int rows, int H,
@@ -1395,7 +1596,8 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
                           int inline_lgamma, float* ll_part, float* dd_part, float* planes,
                           const HeadDropout* drop, int cp_pass, const CpRows* cp, int dd_mode) {
   const int P = likelihood_heads(kind);
-  SCVAE_ARG(decoder_fused3_supported(P, H) && planes);
+  const bool wide = !decoder_fused3_supported(P, H);     // (beyond H = 126: head4, training only)
+  SCVAE_ARG(planes && (!wide || (train && !drop && cp_pass == 0 && decoder_fused4_supported(P, H))));
   SCVAE_ARG(train || P <= 2);
   SCVAE_ARG(train || !drop);
   SCVAE_ARG((kind == LK_CPOISSON) == (cp_pass >= 1 && cp_pass <= 3 && cp && cp->count_sum));
@@ -1404,14 +1606,15 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
   // (forward only: one- and two-head likelihoods; the three-head one, on 32-gene strips, is
   //  no faster than decoder_forward_kernel: 0.92 vs 0.94 ms at 4096 x 32 738, the same step)
   const int Rpad = (rows + D3_BM - 1) / D3_BM * D3_BM;
+  const int KP = d3_kp(H);
   uint16_t* dA = reinterpret_cast<uint16_t*>(planes);
-  uint16_t* dT = dA + (size_t)3 * Rpad * D3_KP;
+  uint16_t* dT = dA + (size_t)3 * Rpad * KP;
   // (head dropout: one plane set per head, cut from that head's dropped-out copy of d, and the
   //  heads' masks as bits behind the three sets)
   uint32_t* bits = reinterpret_cast<uint32_t*>(dA + 3 * d3_set_elems(Rpad));
   for (int j = 0; j < (drop ? P : 1); ++j) {
-    hipLaunchKernelGGL(split3_hidden_kernel, dim3((Rpad * 16 + 255) / 256, train ? 2 : 1),
-                       dim3(256), 0, s, drop ? drop->d[j] : d, rows, H, Rpad,
+    hipLaunchKernelGGL(split3_hidden_kernel, dim3((Rpad * (KP / 8) + 255) / 256, train ? 2 : 1),
+                       dim3(256), 0, s, drop ? drop->d[j] : d, rows, H, Rpad, KP,
                        dA + j * d3_set_elems(Rpad), dT + j * d3_set_elems(Rpad));
     SCVAE_LAUNCH_CHECK("split3_hidden_kernel");
     if (drop) {
@@ -1464,49 +1667,22 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
       case LK_BERNOULLI: SCVAE_D3(LK_BERNOULLI, true, true); break;
       default: set_error("decoder_head3_kernel: likelihood kind %d", kind); return -1;
     }
-  } else if (train && d3_schedule(P) == 4 &&
-             decoder_fused4_lds_bytes(P, H, d4_producers(P)) <= 160 * 1024) {
-    const int npw = d4_producers(P);
-    const int dd_atomic = dd_mode ? 1 : 0;
-    if (dd_atomic)    // eight XCD-local accumulators [8][H][rows], cleared for this launch
+  } else if (train && d3_schedule(P, H) == 4) {
+    const D4Config c = d4_config(P, H);
+    D4Launch a{s, dA, dT, rows, Rpad, H, hp, F, t, B, gw, inline_lgamma, ll_part, dd_part,
+               dd_mode ? 1 : 0, (F + c.bn - 1) / c.bn, c.lds};
+    if (a.dd_atomic)    // eight XCD-local accumulators [8][H][rows], cleared for this launch
       SCVAE_HIP(hipMemsetAsync(dd_part, 0, (size_t)8 * H * rows * sizeof(float), s));
-    const size_t lds4 = decoder_fused4_lds_bytes(P, H, npw);
-#define SCVAE_D4N(K_, KS_, N_)                                                                    \
-  do {                                                                                            \
-    auto kfn = t.u16 ? decoder_head4_kernel<K_, KS_, true, N_>                                    \
-                     : decoder_head4_kernel<K_, KS_, false, N_>;                                  \
-    SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(kfn), \
-                                  (int)lds4));        \
-    hipLaunchKernelGGL(kfn, dim3(strips), dim3(d4_threads(N_)), lds4, s, dA, dT, rows, Rpad, H,   \
-                       hp, F, t, B, gw, inline_lgamma, ll_part, dd_part, dd_atomic);              \
-  } while (0)
-#define SCVAE_D4K(K_, KS_)                                                                        \
-  do {                                                                                            \
-    if constexpr (likelihood_heads(K_) >= 3) {                                                    \
-      SCVAE_D4N(K_, KS_, 4);                                                                      \
-    } else {                                                                                      \
-      if (npw == 8) SCVAE_D4N(K_, KS_, 8);                                                        \
-      else SCVAE_D4N(K_, KS_, 4);                                                                 \
-    }                                                                                             \
-  } while (0)
-#define SCVAE_D4(K_)                                                                              \
-  switch (ks1) {                                                                                  \
-    case 1: SCVAE_D4K(K_, 1); break;                                                              \
-    case 2: SCVAE_D4K(K_, 2); break;                                                              \
-    case 3: SCVAE_D4K(K_, 3); break;                                                              \
-    default: SCVAE_D4K(K_, 4); break;                                                             \
-  }
+    int rc;
     switch (kind) {
-      case LK_POISSON: SCVAE_D4(LK_POISSON); break;
-      case LK_NB: SCVAE_D4(LK_NB); break;
-      case LK_ZIP: SCVAE_D4(LK_ZIP); break;
-      case LK_ZINB: SCVAE_D4(LK_ZINB); break;
-      case LK_BERNOULLI: SCVAE_D4(LK_BERNOULLI); break;   // du:194-204; targets binarised by the caller
+      case LK_POISSON: rc = d4_launch_kind<LK_POISSON>(a, c); break;
+      case LK_NB: rc = d4_launch_kind<LK_NB>(a, c); break;
+      case LK_ZIP: rc = d4_launch_kind<LK_ZIP>(a, c); break;
+      case LK_ZINB: rc = d4_launch_kind<LK_ZINB>(a, c); break;
+      case LK_BERNOULLI: rc = d4_launch_kind<LK_BERNOULLI>(a, c); break;   // du:194-204; targets binarised by the caller
       default: set_error("decoder_head4_kernel: likelihood kind %d", kind); return -1;
     }
-#undef SCVAE_D4N
-#undef SCVAE_D4
-#undef SCVAE_D4K
+    if (rc) return rc;
   } else if (train) {
     switch (kind) {
       case LK_POISSON: SCVAE_D3(LK_POISSON, true, false); break;

@@ -271,7 +271,10 @@ struct HeadParams {
   float* dW[3];
   float* db[3];
 };
-bool decoder_fused_supported(int H);
+bool decoder_fused_supported(int H);                       // every fused kernel: even H <= 126
+// a TRAINING launch of the fused heads: the above, or (bf16x9) the producer / consumer kernel's
+// wider range -- H <= 256 (one / two heads), <= 159 (three), odd H included
+bool decoder_fused_train_supported(int P, int H, int arith);
 size_t decoder_fused_workspace_floats(int rows, int H, int F, bool train);
 size_t decoder_fused_lds_bytes(int P, int H, bool train);
 int decoder_fused_variant(int P, int H);   // 1: decoder_head_kernel, 2: decoder_head2_kernel
@@ -296,7 +299,12 @@ bool decoder_fused3_supported(int P, int H);
 size_t decoder_fused3_lds_bytes(int P, int H);
 int decoder_fused3_strip_genes(int P);   // genes per workgroup (= per slab of ll_part / dd_part)
 int decoder_fused3_train_kernel_name(int kind, int H, bool u16, char* out, size_t n);
-size_t decoder_fused3_workspace_floats(int rows);
+size_t decoder_fused3_workspace_floats(int rows, int H);
+// the producer / consumer training kernel (decoder_head4_kernel): any H up to 256 for one and two
+// heads, up to 159 for three (LDS), odd H included; plain training launches only
+bool decoder_fused4_supported(int P, int H);
+// genes per workgroup (= per slab of ll_part / dd_part) of a TRAINING launch
+int decoder_fused3_train_strip_genes(int P, int H, bool drop, int cp_pass);
 // (train = false: the forward half alone, one- and two-head likelihoods; gw / dd_part unused)
 // drop (training only): dropout of the heads' input connections inside the kernel
 int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, int rows, int H,

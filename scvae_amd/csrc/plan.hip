@@ -167,7 +167,9 @@ static size_t carve(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_
   if (c.k_max > 0) pmax = col_sum_partial_floats((int)(F * (size_t)(c.k_max + 1)));
   { const size_t q = bn_partial_floats(1, (int)hmax); if (q > pmax) pmax = q; }
   float* partial = b.floats(pmax);
-  float* fused_ws = decoder_fused_supported(h1)
+  // (sized whatever the plan's head arithmetic is set to later: the wide range of the bf16x9
+  //  training kernel included)
+  float* fused_ws = decoder_fused_train_supported(p->P, h1, 1)
                         ? b.floats(decoder_fused_workspace_floats((int)R, h1, (int)F, true))
                         : nullptr;
   const size_t E = (size_t)c.decoder_extra;
@@ -503,7 +505,8 @@ int heads_backward(scvae_plan* p, hipStream_t s, const float* const (&head_in)[4
 // dropped-out copy of the decoder output per head (DROP instantiation).  Not with importance
 // weights (their separate forward pass has no such instantiation) nor on the fp32 head kernels.
 bool heads_fused_dropout_ok(scvae_plan* p, int n_iw) {
-  return n_iw == 1 && decoder_train_kernel(p->P, p->heads[0].n_in, p->head_arith) == 3;
+  return n_iw == 1 && decoder_fused3_supported(p->P, p->heads[0].n_in) &&
+         decoder_train_kernel(p->P, p->heads[0].n_in, p->head_arith) == 3;
 }
 int heads_dropout_inputs(scvae_plan* p, hipStream_t s, const float* dch, int ld, int R,
                          HeadDropout* out) {
@@ -889,7 +892,13 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     set_error("the constrained Poisson likelihood needs scvae_step_args.count_sum");
     return -1;
   }
-  const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
+  // (every fused kernel takes even widths up to 126; a training step of one likelihood pass also
+  //  the bf16x9 producer / consumer kernel's wider range -- forward-only passes stay unfused there)
+  const bool fused_width =
+      decoder_fused_supported(h1) ||
+      (training && n_iw == 1 && !head_drop && !cpoisson &&
+       decoder_fused_train_supported(p->P, h1, p->head_arith));
+  const bool fused = p->use_fused && p->fused_ws && fused_width && ld == h1 &&
                      !a->p_x_mean && KM == 0 &&
                      (!head_drop || (heads_fused_dropout_ok(p, n_iw) && !cpoisson)) &&
                      (c.likelihood <= LK_ZINB || c.likelihood == LK_BERNOULLI ||
@@ -1456,7 +1465,11 @@ int scvae_plan_accepts_counts_u16(const scvae_plan* p, int64_t cells, int32_t tr
         scvae::decoder_fused_cpoisson_supported(p->heads[0].n_in, p->head_arith) &&
         !(training && p->heads[0].keep > 0.f)))
     return 0;
-  if (!scvae::decoder_fused_supported(p->heads[0].n_in)) return 0;
+  if (!scvae::decoder_fused_supported(p->heads[0].n_in) &&
+      !(training == 2 && p->heads[0].keep <= 0.f && c.likelihood <= scvae::LK_ZINB &&
+        c.model_type != SCVAE_MODEL_GMVAE &&
+        scvae::decoder_fused_train_supported(p->P, p->heads[0].n_in, p->head_arith)))
+    return 0;
   // the layers that see x: the VAE's first encoder layer (or the posterior heads of a model
   // without hidden layers); the GMVAE's first q(y|x) and q(z|x,y) layers
   int n_x[2] = {0, 0};
@@ -1677,7 +1690,7 @@ int scvae_loglik_bwd(int32_t kind, const float* t, float* const* pre, const floa
                            (int)rows, (int)cells, (int)F);
 }
 int64_t scvae_decoder_fused_workspace_bytes(int64_t rows, int64_t H, int64_t F) {
-  if (!scvae::decoder_fused_supported((int)H)) return -1;
+  if (!scvae::decoder_fused_train_supported(1, (int)H, 1)) return -1;
   return (int64_t)(scvae::decoder_fused_workspace_floats((int)rows, (int)H, (int)F, true) *
                    sizeof(float));
 }
@@ -1706,8 +1719,8 @@ int scvae_decoder_train_kernel_name(int32_t kind, int64_t H, int32_t arith, int3
   return 0;
 }
 int32_t scvae_decoder_train_kernel(int32_t kind, int64_t H, int32_t arith) {
-  if (kind < 0 || (kind > 3 && kind != scvae::LK_BERNOULLI) ||
-      !scvae::decoder_fused_supported((int)H) || (arith != 0 && arith != 1))
+  if (kind < 0 || (kind > 3 && kind != scvae::LK_BERNOULLI) || (arith != 0 && arith != 1) ||
+      !scvae::decoder_fused_train_supported(scvae::likelihood_heads(kind), (int)H, arith))
     return 0;
   return scvae::decoder_train_kernel(scvae::likelihood_heads(kind), (int)H, arith);
 }
@@ -1717,13 +1730,15 @@ static int decoder_fused_entry(int32_t kind, int32_t train, const float* d, int6
                                const float* gw, const float* row_const, float* ll, float* dd,
                                void* workspace, void* stream) {
   SCVAE_ARG(((kind >= 0 && kind <= 3) || kind == scvae::LK_BERNOULLI) && W && b);
-  SCVAE_ARG(scvae::decoder_fused_supported((int)H));
   // bits 8-9 of `train`: the arithmetic of this call (neither: the process default)
   SCVAE_ARG((train & ~0x703) == 0 && (train & 0x300) != 0x300);
   const int dd_mode = (train & SCVAE_HEADS_DD_ATOMICS) ? 1 : 0;
   const int arith = (train & SCVAE_HEADS_FP32) ? 0
                     : (train & SCVAE_HEADS_BF16X9) ? 1 : scvae::default_head_arith();
   train &= 3;
+  // (forward-only calls: even widths up to 126; training also the bf16x9 kernel's wider range)
+  SCVAE_ARG(train ? scvae::decoder_fused_train_supported(scvae::likelihood_heads(kind), (int)H, arith)
+                  : scvae::decoder_fused_supported((int)H));
   scvae::HeadParams hp;
   for (int j = 0; j < 3; ++j) {
     const bool on = j < scvae::likelihood_heads(kind);

@@ -162,7 +162,7 @@ size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t
     if (q > pmax) pmax = q;
   }
   float* partial = b.floats(pmax);
-  float* fused_ws = decoder_fused_supported(h1)
+  float* fused_ws = decoder_fused_train_supported(p->P, h1, 1)
                         ? b.floats(decoder_fused_workspace_floats((int)R, h1, (int)F, true))
                         : nullptr;
   const size_t E = (size_t)c.decoder_extra;
@@ -349,7 +349,11 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     set_error("the constrained Poisson likelihood needs scvae_step_args.count_sum");
     return -1;
   }
-  const bool fused = p->use_fused && p->fused_ws && decoder_fused_supported(h1) && ld == h1 &&
+  const bool fused_width =
+      decoder_fused_supported(h1) ||
+      (training && !head_drop && !cpoisson &&
+       decoder_fused_train_supported(p->P, h1, p->head_arith));
+  const bool fused = p->use_fused && p->fused_ws && fused_width && ld == h1 &&
                      !a->p_x_mean && KM == 0 &&
                      (!head_drop || (heads_fused_dropout_ok(p, 1) && !cpoisson)) &&
                      (c.likelihood <= LK_ZINB || c.likelihood == LK_BERNOULLI ||

@@ -103,6 +103,53 @@ def test_train_step_matches_oracle(cuda_device, likelihood, bn):
         _close(m.cpu(), new_moving[name], rtol=1e-5, what="moving " + name)
 
 
+@pytest.mark.parametrize("likelihood,H,B", [
+    ("negative binomial", (128, 128), 300),
+    ("negative binomial", (40, 200), 150),
+    ("poisson", (64, 256), 100),
+    ("zero-inflated negative binomial", (32, 129), 130),
+])
+def test_wide_decoder_trains_on_the_fused_kernel(cuda_device, likelihood, H, B):
+    """``-H`` beyond 126 (mu:81-126 takes any size): a training step of one
+    likelihood pass runs the heads on the bf16x9 producer / consumer kernel
+    (``scvae_decoder_train_kernel`` == 3), evaluation steps of the same model on
+    the unfused kernels -- both against the oracle."""
+    from scvae_amd import _lib
+    lib = _lib.load()
+    kind, _ = _lib.LIKELIHOOD_KINDS[likelihood]
+    assert lib.scvae_decoder_train_kernel(kind, H[-1], 1) == 3
+    F, L = 333, 9
+    eng, cfg, params, moving, x, eps = _setup(
+        cuda_device, likelihood, F, L, H, B, True)
+    xd = x.float().to(cuda_device)
+    epsd = eps.float().to(cuda_device)
+    ll = torch.zeros(B, device=cuda_device)
+    sc = eng.step(xd, xd, eps=epsd, training=True,
+                  outputs={"log_p_x_given_z": ll}).cpu().numpy()
+    torch.cuda.synchronize()
+    new_moving = {}
+    out, grads = om.gradients(
+        lambda p: om.vae_forward(cfg, p, moving, x, x, eps, True, 1.0, new_moving),
+        params)
+    _close(sc[0], out["lower_bound"], what="lower_bound")
+    close_elementwise(ll, out["log_p_x_given_z"].reshape(-1), rtol=LL_RTOL,
+                      atol=LL_ATOL, what="per-cell ll")
+    for name, g in eng.named_gradients().items():
+        if name.endswith("DENSE/biases") and "X_TILDE" not in name \
+                and "POSTERIOR" not in name:
+            continue
+        _close(g.cpu(), grads[name], rtol=2e-4, what="grad " + name)
+    # evaluation (forward only): the unfused kernels at this width
+    moving_now = {k: v.detach().cpu().double()
+                  for k, v in eng.named_moving_statistics().items()}
+    sc = eng.step(xd, xd, eps=epsd, training=False,
+                  outputs={"log_p_x_given_z": ll}).cpu().numpy()
+    out_e = om.vae_forward(cfg, params, moving_now, x, x, eps, False)
+    _close(sc[0], out_e["lower_bound"], what="lower_bound (evaluation)")
+    close_elementwise(ll, out_e["log_p_x_given_z"].reshape(-1), rtol=LL_RTOL,
+                      atol=LL_ATOL, what="per-cell ll (evaluation)")
+
+
 def test_importance_weighted_step(cuda_device):
     F, L, H, B = 150, 5, (16,), 19
     eng, cfg, params, moving, x, eps = _setup(
