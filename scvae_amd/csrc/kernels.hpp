@@ -176,6 +176,11 @@ struct TileBN {
   float* var = nullptr;
   const float* part = nullptr;   // forward: chunk (mean, M2); backward: chunk (sum dxh, sum dxh xh)
   int chunks = 0, chunk = 0;
+  // > 0: the rows are `groups` consecutive groups of group_tiles 64-row tiles, each normalised by
+  // its OWN batch statistics (the GMVAE's K passes through shared weights, gm:2859-2922): mean,
+  // var, s1, s2 are [groups][n]; dbeta sums the groups, the moving averages take the groups'
+  // statistics one after the other (as K executions of the layer do); chunk must be 64
+  int group_tiles = 0, groups = 1;
   float* part_out = nullptr;  // backward epilogue: where the chunk sums of THIS layer go
   float* s1 = nullptr;        // backward: merged sums, dbeta, moving statistics (tile 0 writes)
   float* s2 = nullptr;

@@ -108,6 +108,15 @@ size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t
   for (size_t i = 0; i < p->zenc.size(); ++i)
     layer_ws(p->zenc[i], KB, K, i == 0 ? F : (size_t)p->zenc[i].n_in);
   for (auto& d : p->xdec) layer_ws(d, R, K, d.n_in);
+  {   // tilechain.hip (one launch per hidden layer and direction for the K stacked passes)
+    float* q[4 + TC_MAX_JOBS];
+    for (int i = 0; i < 4; ++i) q[i] = b.floats(tile_chain_part_floats((int)R));
+    for (int i = 0; i < TC_MAX_JOBS; ++i) q[4 + i] = b.floats(tile_chain_slab_floats((int)R));
+    if (!dry) {
+      p->tc_part[0] = q[0]; p->tc_part[1] = q[1]; p->tc_spart[0] = q[2]; p->tc_spart[1] = q[3];
+      for (int i = 0; i < TC_MAX_JOBS; ++i) p->tc_slab[i] = q[4 + i];
+    }
+  }
   const size_t h1z = p->zenc.empty() ? F : (size_t)p->zenc[0].n_out;
   track(B, h1z, F); track(F, h1z, B);
   if (dropout_keep(c, 1) > 0.f) { track(KB, h1z, F + K); track(F + K, h1z, KB); }
@@ -201,6 +210,36 @@ size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t
   return b.used;
 }
 
+// ---- the K stacked passes through q(z|x,y) and p(x|z,y) with one launch per hidden layer and
+//      direction (tilechain.hip with groups: the rows of pass k are a range of 64-row tiles with
+//      their own batch statistics).  Training steps with batch normalisation, no dropout, no
+//      data-parallel hook, whole tiles per pass, layers and latent at most 128 wide. ----
+static bool gm_tile_chain_ok(const scvae_plan* p, int B, int S, bool training) {
+  const scvae_model_config& c = p->cfg;
+  static const bool env_on = [] { const char* e = getenv("SCVAE_TILE_CHAIN"); return !(e && e[0] == '0'); }();
+  if (!env_on || !p->use_tile_chain || p->sync || !training || !c.batch_norm) return false;
+  if (p->zenc.empty() || p->xdec.empty() || c.decoder_extra != 0 || c.latent_size > 128) return false;
+  if (B % 64 != 0 || ((int64_t)B * S) % 64 != 0) return false;
+  for (const auto& d : p->zenc) if (d.n_out > 128 || !d.bn) return false;
+  for (const auto& d : p->xdec) if (d.n_out > 128 || !d.bn) return false;
+  for (int i = 0; i < 4; ++i) if (dropout_keep(c, i) > 0.f) return false;
+  return p->tc_part[0] != nullptr;
+}
+// the batch norm of layer d (K groups of `group_rows` rows) as the tile kernels see it
+static TileBN gm_tile_bn(scvae_plan* p, Dense& d, int K, int group_rows, const float* part,
+                         float* part_out) {
+  TileBN t;
+  const int N = d.n_out;
+  t.a = d.a; t.h = d.h; t.beta = p->params + d.beta;
+  t.mean = d.stats; t.var = d.stats + (size_t)K * N;
+  t.s1 = d.stats + 2 * (size_t)K * N; t.s2 = d.stats + 3 * (size_t)K * N;
+  t.part = part; t.chunks = K * (group_rows / 64); t.chunk = 64; t.part_out = part_out;
+  t.group_tiles = group_rows / 64; t.groups = K;
+  t.dbeta = p->grads ? p->grads + d.beta : nullptr;
+  t.mov_mean = p->moving + d.mov_mean; t.mov_var = p->moving + d.mov_var;
+  return t;
+}
+
 int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const scvae_model_config& c = p->cfg;
   const int K = c.n_clusters, B = (int)a->cells, S = a->n_iw * a->n_mc;
@@ -239,6 +278,8 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   if (a->q_y_logits) TRY(copy(s, p->logits, a->q_y_logits, (size_t)B * K));
 
   // ---------------- q(z|x,y=k), all k (gm:2936-3007) ----------------
+  const bool tile = gm_tile_chain_ok(p, B, S, training);
+  int tcur = 0;     // (ping-pong of the tile chain's chunk statistics)
   const float* hz = p->step_x;
   int ldz = F;
   for (size_t i = 0; i < p->zenc.size(); ++i) {
@@ -276,6 +317,18 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                        p->params + d.beta, d.h, N, KB, 1, N, 1));
         }
       }
+    } else if (tile) {
+      // one launch: normalise the layer below (i >= 2; layer 1 reads the finished h of layer 0),
+      // the product with this layer's weights, the chunk statistics of its output
+      TileFwdArgs q;
+      q.rows = KB; q.K = d.n_in;
+      if (i == 1) { q.x = p->zenc[0].h; q.ldx = d.n_in; }
+      else q.bn = gm_tile_bn(p, p->zenc[i - 1], K, B, p->tc_part[tcur], nullptr);
+      q.n_out = 1;
+      q.o[0].W = p->params + d.w; q.o[0].b = p->params + d.b; q.o[0].out = d.a;
+      q.o[0].part = p->tc_part[i == 1 ? tcur : tcur ^ 1]; q.o[0].N = d.n_out;
+      TRY(tile_forward(s, q));
+      if (i > 1) tcur ^= 1;
     } else {
       TRY(dense_forward(p, s, d, hz, ldz, KB, K, true, training));
     }
@@ -288,12 +341,26 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const float* hz_m = hz;
   const float* hz_s = hz;
   int ldz_m = ldz, ldz_s = ldz;
+  if (tile) {
+    // the two posterior heads on the (here normalised) output of the last q(z|x,y) layer
+    TileFwdArgs q;
+    q.rows = KB; q.K = p->zenc.back().n_out;
+    if (p->zenc.size() == 1) { q.x = p->zenc[0].h; q.ldx = q.K; }
+    else q.bn = gm_tile_bn(p, p->zenc.back(), K, B, p->tc_part[tcur], nullptr);
+    q.n_out = 2;
+    q.o[0].W = p->params + p->qmean.w; q.o[0].b = p->params + p->qmean.b; q.o[0].out = p->qm;
+    q.o[0].N = L;
+    q.o[1].W = p->params + p->qscale.w; q.o[1].b = p->params + p->qscale.b; q.o[1].out = p->qs;
+    q.o[1].N = L;
+    TRY(tile_forward(s, q));
+  } else {
   TRY(dense_input(p, s, p->qmean, hz, ldz, KB, training, &hz_m, &ldz_m));
   TRY(dense_input(p, s, p->qscale, hz, ldz, KB, training, &hz_s, &ldz_s));
   GEMM(false, false, hz_m, p->params + p->qmean.w, p->params + p->qmean.b, p->qm, KB, L,
        p->qmean.n_in, ldz_m, L, L, ACT_NONE, false);
   GEMM(false, false, hz_s, p->params + p->qscale.w, p->params + p->qscale.b, p->qs, KB, L,
        p->qscale.n_in, ldz_s, L, L, ACT_NONE, false);
+  }
   const float* Wpm = p->params + p->pmean.w;
   const float* bpm = p->params + p->pmean.b;
   const float* Wps = p->params + p->pscale.w;
@@ -331,9 +398,31 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   const float* dch = dec_in;
   ld = L + E;
+  if (tile) {
+    int cur = 0;
+    for (size_t i = 0; i <= p->xdec.size(); ++i) {
+      TileFwdArgs q;
+      q.rows = R;
+      if (i == 0) { q.x = dec_in; q.ldx = L; q.K = L; }
+      else {
+        q.K = p->xdec[i - 1].n_out;
+        q.bn = gm_tile_bn(p, p->xdec[i - 1], K, SB, p->tc_part[cur], nullptr);
+      }
+      if (i < p->xdec.size()) {
+        Dense& d = p->xdec[i];
+        q.n_out = 1;
+        q.o[0].W = p->params + d.w; q.o[0].b = p->params + d.b; q.o[0].out = d.a;
+        q.o[0].part = p->tc_part[i == 0 ? cur : cur ^ 1]; q.o[0].N = d.n_out;
+      }   // (i == size: the last layer's normalisation alone -> its h feeds the likelihood heads)
+      TRY(tile_forward(s, q));
+      if (i > 0) cur ^= 1;
+    }
+    dch = p->xdec.back().h; ld = p->xdec.back().n_out;
+  } else {
   for (auto& d : p->xdec) {
     TRY(dense_forward(p, s, d, dch, ld, R, K, true, training));
     dch = d.h; ld = d.n_out;
+  }
   }
   HeadPtrs pre;
   for (int j = 0; j < 3; ++j) pre.p[j] = p->pre[j];
@@ -468,12 +557,56 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   // the next minibatch and its noise (scvae_step_args.side) under the rest of the backward pass
   TRY(plan_side_fork(p, s, 1));
   const int64_t GSB = GB * S;  // global rows per group (pass) in the decoder
+  // (tile chain) the dW / db slabs of the layers wait for one fixed-order reduce at the end
+  SlabJobs pending;
+  int sp = 0;
+  auto bessel = [](int64_t n) { return (float)n / (float)(n > 1 ? n - 1 : 1); };
+  auto flush = [&]() -> int {
+    if (pending.n_jobs == 0) return 0;
+    const int r = tile_slab_reduce(s, pending);
+    pending.n_jobs = 0;
+    return r;
+  };
+  // one batch-normalised layer backwards: its own sums merged per group, dA, d_in, its dW slab and
+  // the chunk sums of the layer below
+  auto tile_layer_backward = [&](Dense& d, Dense* below, const float* in, int rows, int group_rows,
+                                 int64_t grows, const float* dh_in, float* d_in) -> int {
+    TileBwdArgs q;
+    const int G = rows / 64;
+    q.rows = rows; q.inv_count = 1.f / (float)grows; q.bessel = bessel(grows);
+    q.n_up = 1;
+    if (pending.n_jobs == TC_MAX_JOBS) { const int r = flush(); if (r) return r; }
+    float* slab = p->tc_slab[pending.n_jobs % TC_MAX_JOBS];
+    q.up[0].g = dh_in; q.up[0].W = p->params + d.w; q.up[0].N = d.n_out;
+    q.up[0].dW_slab = slab;
+    q.bn = gm_tile_bn(p, d, K, group_rows, p->tc_spart[sp], nullptr);
+    q.in = in; q.K = d.n_in; q.d_in = d_in;
+    if (below) q.below = gm_tile_bn(p, *below, K, group_rows, nullptr, p->tc_spart[sp ^ 1]);
+    const int r = tile_backward(s, q);
+    if (r) return r;
+    pending.job[pending.n_jobs++] = {slab, p->grads + d.w, d.n_in * d.n_out, G};
+    sp ^= 1;
+    return 0;
+  };
+  if (tile) {
+    Dense& top = p->xdec.back();
+    TRY(tile_backward_stats(s, dcur, gm_tile_bn(p, top, K, SB, nullptr, p->tc_spart[sp]), R,
+                            top.n_out));
+    for (int i = (int)p->xdec.size() - 1; i >= 0; --i) {
+      const float* in = i > 0 ? p->xdec[i - 1].h : dec_in;
+      float* d_in = i > 0 ? dalt : p->dz;
+      TRY(tile_layer_backward(p->xdec[i], i > 0 ? &p->xdec[i - 1] : nullptr, in, R, SB, GSB, dcur,
+                              d_in));
+      if (i > 0) { float* t = dcur; dcur = dalt; dalt = t; }
+    }
+  } else {
   for (int i = (int)p->xdec.size() - 1; i >= 0; --i) {
     Dense& d = p->xdec[i];
     const float* in = i > 0 ? p->xdec[i - 1].h : dec_in;
     float* d_in = i > 0 ? dalt : (E > 0 ? p->dzcat : p->dz);
     TRY(dense_backward(p, s, d, in, d.n_in, R, K, true, dcur, scratch, d_in, false, GSB));
     if (i > 0) { float* t = dcur; dcur = dalt; dalt = t; }
+  }
   }
   if (E > 0 && !p->xdec.empty()) TRY(slice_cols(s, p->dzcat, L + E, L, (size_t)R, p->dz));
 
@@ -499,6 +632,32 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   float* dh = p->dbuf[0];
   float* dh_alt = p->dbuf[1];
+  if (tile) {
+    // the two posterior heads: dW, db of both, dh of the last q(z|x,y) layer and (where that
+    // layer belongs to the chain) its chunk sums
+    Dense& last = p->zenc.back();
+    const int G = KB / 64, Kl = last.n_out;
+    if (pending.n_jobs + 4 > TC_MAX_JOBS) TRY(flush());
+    float* slab2[2] = {p->tc_slab[pending.n_jobs], p->tc_slab[pending.n_jobs + 1]};
+    TileBwdArgs q;
+    q.rows = KB; q.n_up = 2;
+    for (int u = 0; u < 2; ++u) {
+      Dense& hd = u == 0 ? p->qmean : p->qscale;
+      q.up[u].g = u == 0 ? p->dqm : p->dqs;
+      q.up[u].W = p->params + hd.w; q.up[u].N = L;
+      q.up[u].dW_slab = slab2[u];
+      q.up[u].db_slab = slab2[u] + (size_t)G * 128 * 128;
+    }
+    q.in = last.h; q.K = Kl; q.d_in = dh;
+    if (p->zenc.size() > 1) q.below = gm_tile_bn(p, last, K, B, nullptr, p->tc_spart[sp]);
+    TRY(tile_backward(s, q));
+    const int j0 = pending.n_jobs;
+    pending.job[j0] = {slab2[0], p->grads + p->qmean.w, Kl * L, G};
+    pending.job[j0 + 1] = {slab2[1], p->grads + p->qscale.w, Kl * L, G};
+    pending.job[j0 + 2] = {q.up[0].db_slab, p->grads + p->qmean.b, L, G};
+    pending.job[j0 + 3] = {q.up[1].db_slab, p->grads + p->qscale.b, L, G};
+    pending.n_jobs = j0 + 4;
+  } else
   for (int q = 0; q < 2; ++q) {
     Dense& hd = q == 0 ? p->qmean : p->qscale;
     const float* dpre = q == 0 ? p->dqm : p->dqs;
@@ -513,7 +672,11 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   for (int i = (int)p->zenc.size() - 1; i >= 0; --i) {
     Dense& d = p->zenc[i];
-    if (i > 0) {
+    if (i > 0 && tile) {
+      TRY(tile_layer_backward(d, i > 1 ? &p->zenc[i - 1] : nullptr, p->zenc[i - 1].h, KB, B, GB,
+                              dh, dh_alt));
+      float* t = dh; dh = dh_alt; dh_alt = t;
+    } else if (i > 0) {
       TRY(dense_backward(p, s, d, p->zenc[i - 1].h, d.n_in, KB, K, true, dh, scratch, dh_alt,
                          false, GB));
       float* t = dh; dh = dh_alt; dh_alt = t;
@@ -535,6 +698,8 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       }
     }
   }
+
+  if (tile) TRY(flush());     // (the weight-gradient slabs of the chain: one fixed-order reduce)
 
   // ---------------- backward: q(y|x) ----------------
   TRY(categorical_bwd_gated(s, p->yprob, p->dy, gate, w * inv_gb, p->dlogits, B, K, prior));

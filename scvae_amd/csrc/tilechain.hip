@@ -149,14 +149,18 @@ __global__ __launch_bounds__(TC_THREADS) void tile_fwd_kernel(TileFwdArgs q) {
     // (the chunk statistics pass through LDS, 64 chunks at a time: a thread walking its column's
     //  chunks in global memory pays a round trip per chunk.  Two passes -- mean, then M2 about it
     //  -- in chunk order: fixed, so every workgroup of the launch arrives at the same bits)
-    const int chunks = q.bn.chunks, chunk = q.bn.chunk;
+    // (groups: the statistics of this tile's group alone -- its group_tiles chunks of 64 rows)
+    const int gt = q.bn.group_tiles;
+    const int grp = gt ? g / gt : 0, zfirst = grp * gt;
+    const int chunks = gt ? gt : q.bn.chunks, chunk = q.bn.chunk;
+    const int rows_g = gt ? gt * TC_ROWS : q.rows;
     float mean = 0.f, m2 = 0.f;
     for (int pass = 0; pass < 2; ++pass) {
       for (int z0 = 0; z0 < chunks; z0 += 64) {
         const int zn = min(64, chunks - z0);
         if (pass == 0 || chunks > 64) {     // (a single block stays in LDS for the second pass)
           LinePre<8> pp;
-          pp.load(q.bn.part + (size_t)z0 * 2 * K, zn * 2 * K, tid);
+          pp.load(q.bn.part + (size_t)(zfirst + z0) * 2 * K, zn * 2 * K, tid);
           lds_barrier();
           pp.store_linear(Bs, zn * 2 * K, tid);
           lds_barrier();
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(TC_THREADS) void tile_fwd_kernel(TileFwdArgs q) {
           // sums are combined in group order: a fixed order, the same bits in every workgroup
           const int c = tid & 127, zg = tid >> 7;
           const float n_full = (float)chunk;
-          const float n_last = (float)(q.rows - (chunks - 1) * chunk);
+          const float n_last = (float)(rows_g - (chunks - 1) * chunk);
           float part_sum = 0.f;
           if (c < K) {
 #pragma unroll 4
@@ -191,18 +195,18 @@ __global__ __launch_bounds__(TC_THREADS) void tile_fwd_kernel(TileFwdArgs q) {
       }
       if (pass == 0) {
         // (the mean of the whole minibatch, broadcast to the column's other threads through st)
-        mean /= (float)q.rows;
+        mean /= (float)rows_g;
         lds_barrier();
         if (tid < K) st[tid] = mean;
         lds_barrier();
       }
     }
     if (tid < K) {
-      const float var = m2 / (float)q.rows;
+      const float var = m2 / (float)rows_g;
       st[tid] = mean;
       st[TC_MAXN + tid] = rsqrtf(var + BN_EPSILON);
       st[2 * TC_MAXN + tid] = q.bn.beta[tid];
-      if (g == 0) { q.bn.mean[tid] = mean; q.bn.var[tid] = var; }
+      if (g == zfirst) { q.bn.mean[grp * K + tid] = mean; q.bn.var[grp * K + tid] = var; }
     }
   }
   lds_barrier();        // (As zeroed, statistics in st, Bs free)
@@ -328,14 +332,19 @@ __global__ __launch_bounds__(TC_THREADS) void tile_bwd_kernel(TileBwdArgs q) {
   pb.load(q.below.a ? q.below.a + (size_t)r0 * K : q.up[0].g, q.below.a ? nr * K : 0, tid,
           q.below.a ? K : 1);
   // ---- this layer's batch norm: merged sums (fixed order), dbeta, moving averages ----
+  // (groups: see TileBN -- this tile's group, its first chunk, the chunks merged here)
+  const int gt_bn = q.bn.group_tiles;
+  const int grp = gt_bn ? g / gt_bn : (q.below.group_tiles ? g / q.below.group_tiles : 0);
   if (bn) {
     const int N = q.up[0].N;
+    const int zfirst = gt_bn ? grp * gt_bn : 0;
+    const int nchunks = gt_bn ? gt_bn : q.bn.chunks;
     float t1 = 0.f, t2 = 0.f;
-    for (int z0 = 0; z0 < q.bn.chunks; z0 += 64) {     // (through LDS, as in the forward kernel)
-      const int zn = min(64, q.bn.chunks - z0);
+    for (int z0 = 0; z0 < nchunks; z0 += 64) {     // (through LDS, as in the forward kernel)
+      const int zn = min(64, nchunks - z0);
       {
         LinePre<8> pp;
-        pp.load(q.bn.part + (size_t)z0 * 2 * N, zn * 2 * N, tid);
+        pp.load(q.bn.part + (size_t)(zfirst + z0) * 2 * N, zn * 2 * N, tid);
         lds_barrier();
         pp.store_linear(Ds, zn * 2 * N, tid);
         lds_barrier();
@@ -368,14 +377,16 @@ __global__ __launch_bounds__(TC_THREADS) void tile_bwd_kernel(TileBwdArgs q) {
     }
     lds_barrier();
     if (tid < N) {
-      const float mean = q.bn.mean[tid], var = q.bn.var[tid];
+      const float mean = q.bn.mean[grp * N + tid], var = q.bn.var[grp * N + tid];
       st[tid] = mean;
       st[TC_MAXN + tid] = rsqrtf(var + BN_EPSILON);
       st[2 * TC_MAXN + tid] = t1;
       st[3 * TC_MAXN + tid] = t2;
-      if (g == 0) {
-        q.bn.s1[tid] = t1;
-        q.bn.s2[tid] = t2;
+      if (g == zfirst) {
+        q.bn.s1[grp * N + tid] = t1;
+        q.bn.s2[grp * N + tid] = t2;
+      }
+      if (g == 0 && !gt_bn) {
         q.bn.dbeta[tid] = t1;
         // UPDATE_OPS (va:2763-2768): moving <- moving - (moving - batch) * rate, Bessel-corrected
         q.bn.mov_mean[tid] = bn_moving_update(q.bn.mov_mean[tid], mean);
@@ -383,6 +394,44 @@ __global__ __launch_bounds__(TC_THREADS) void tile_bwd_kernel(TileBwdArgs q) {
       }
     }
     lds_barrier();
+    if (g == 0 && gt_bn) {
+      // the layer ran once per group on shared variables: dbeta is the sum over the groups of
+      // their s1 (all the chunks, in chunk order), the moving averages are updated group after
+      // group (gm:2859-2922: K executions of the UPDATE_OPS in pass order)
+      float tall = 0.f;
+      const int c = tid & 127, zg = tid >> 7;
+      for (int z0 = 0; z0 < q.bn.chunks; z0 += 64) {
+        const int zn = min(64, q.bn.chunks - z0);
+        LinePre<8> pp;
+        pp.load(q.bn.part + (size_t)z0 * 2 * N, zn * 2 * N, tid);
+        lds_barrier();
+        pp.store_linear(Ds, zn * 2 * N, tid);
+        lds_barrier();
+        float p1 = 0.f;
+        if (c < N) {
+#pragma unroll 4
+          for (int z = zg; z < 64; z += TC_RG) p1 += z < zn ? Ds[z * 2 * N + c] : 0.f;
+        }
+        lds_barrier();
+        st[(4 + zg) * TC_MAXN + c] = p1;
+        lds_barrier();
+        if (tid < N) {
+#pragma unroll
+          for (int j = 0; j < TC_RG; ++j) tall += st[(4 + j) * TC_MAXN + tid];
+        }
+      }
+      if (tid < N) {
+        q.bn.dbeta[tid] = tall;
+        float mm = q.bn.mov_mean[tid], mv = q.bn.mov_var[tid];
+        for (int k = 0; k < q.bn.groups; ++k) {
+          mm = bn_moving_update(mm, q.bn.mean[k * N + tid]);
+          mv = bn_moving_update(mv, q.bn.var[k * N + tid] * q.bessel);
+        }
+        q.bn.mov_mean[tid] = mm;
+        q.bn.mov_var[tid] = mv;
+      }
+      lds_barrier();
+    }
   }
   // ---- dA tiles ----
 #pragma unroll
@@ -495,8 +544,9 @@ __global__ __launch_bounds__(TC_THREADS) void tile_bwd_kernel(TileBwdArgs q) {
   if (q.below.a) {
     float a1 = 0.f, a2 = 0.f;
     if (c < K) {
-      const float mu = q.below.mean[c];
-      const float istd = rsqrtf(q.below.var[c] + BN_EPSILON);
+      const int gb = q.below.group_tiles ? g / q.below.group_tiles : 0;
+      const float mu = q.below.mean[gb * K + c];
+      const float istd = rsqrtf(q.below.var[gb * K + c] + BN_EPSILON);
 #pragma unroll 8
       for (int r = rl; r < TC_ROWS; r += TC_RG) {
         float d = Xs[r * TC_LD + c];
@@ -546,8 +596,9 @@ __global__ __launch_bounds__(256) void tile_bwd_stats_kernel(const float* __rest
   const int c = threadIdx.x & 127, rl = threadIdx.x >> 7;
   float a1 = 0.f, a2 = 0.f;
   if (c < N) {
-    const float mu = bn.mean[c];
-    const float istd = rsqrtf(bn.var[c] + BN_EPSILON);
+    const int gb = bn.group_tiles ? g / bn.group_tiles : 0;
+    const float mu = bn.mean[gb * N + c];
+    const float istd = rsqrtf(bn.var[gb * N + c] + BN_EPSILON);
     // (eight rows' loads in flight: a load-use-per-iteration loop pays a round trip per row)
     for (int r = rl; r < TC_ROWS; r += 16) {
       float dv[8], hv[8], av[8];
