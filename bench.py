@@ -292,7 +292,7 @@ def time_dominant_kernel(engine, rows, launches=10, u16=False, arith=None):
             ws.data_ptr(), stream), "scvae_decoder_fused")
     which = lib.scvae_decoder_train_kernel(kind, H, arith)
     buf = ctypes.create_string_buffer(128)
-    _lib.check(lib.scvae_decoder_train_kernel_name(kind, H, arith, 1 if u16 else 0,
+    _lib.check(lib.scvae_decoder_train_kernel_name(kind, H, rows, arith, 1 if u16 else 0,
                                                    buf, 128),
                "scvae_decoder_train_kernel_name")
     kernel = buf.value.decode()

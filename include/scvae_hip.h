@@ -385,9 +385,11 @@ int32_t scvae_decoder_fused_variant(int32_t kind, int64_t H);
  * 0 = unsupported H. */
 int32_t scvae_default_head_arith(void);
 int32_t scvae_decoder_train_kernel(int32_t kind, int64_t H, int32_t arith);
-/* the instantiation of that training kernel as a profiler prints it (u16: uint16 targets) */
-int scvae_decoder_train_kernel_name(int32_t kind, int64_t H, int32_t arith, int32_t u16, char* out,
-                                    int64_t n);
+/* the instantiation of that training kernel as a profiler prints it for a launch of `rows` rows
+ * (u16: uint16 targets; up to 128 rows the bf16x9 arithmetic runs its all-in-one-phase kernel,
+ * beyond them the producer / consumer one) */
+int scvae_decoder_train_kernel_name(int32_t kind, int64_t H, int64_t rows, int32_t arith,
+                                    int32_t u16, char* out, int64_t n);
 /* flags of scvae_decoder_fused's / scvae_decoder_fused_u16's `train` (or'ed to 0 / 1 / 3) */
 #define SCVAE_HEADS_FP32 0x100
 #define SCVAE_HEADS_BF16X9 0x200

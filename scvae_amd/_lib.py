@@ -195,7 +195,7 @@ SIGNATURES = {
     "scvae_decoder_fused_variant": (c_int32, [c_int32, c_int64]),
     "scvae_default_head_arith": (c_int32, []),
     "scvae_decoder_train_kernel": (c_int32, [c_int32, c_int64, c_int32]),
-    "scvae_decoder_train_kernel_name": (c_int32, [c_int32, c_int64, c_int32, c_int32,
+    "scvae_decoder_train_kernel_name": (c_int32, [c_int32, c_int64, c_int64, c_int32, c_int32,
                                                    c_char_p, c_int64]),
     "scvae_plan_prior_offset": (c_int64, [c_void_p]),
     "scvae_plan_decode": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p,

@@ -904,7 +904,7 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
   SCVAE_ARG(!drop || decoder_fused3_supported(heads, H));
   if (rows == 0) return 0;
   const int bn = decoder_train_kernel(heads, H, arith) == 3
-                     ? decoder_fused3_train_strip_genes(heads, H, drop != nullptr, 0)
+                     ? decoder_fused3_train_strip_genes(heads, H, rows, drop != nullptr, 0)
                      : DF_BN;
   const int strips = (F + bn - 1) / bn;
   float* ll_part = workspace;
@@ -923,7 +923,7 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
   stage_probe(PS_DD_REDUCE, 0, s);
   struct EndProbe { hipStream_t s; ~EndProbe() { stage_probe(PS_DD_REDUCE, 1, s); } } end_probe{s};
   if (decoder_train_kernel(likelihood_heads(kind), H, arith) == 3 &&
-      decoder_fused3_dd_atomics(kind, H, drop != nullptr, 0, dd_mode)) {
+      decoder_fused3_dd_atomics(kind, H, rows, drop != nullptr, 0, dd_mode)) {
     hipLaunchKernelGGL(dd_reduce_xcd_kernel, dim3((unsigned)(((size_t)((H + 3) / 4) * rows + 255) / 256)),
                        dim3(256), 0, s, dd_part, rows, H, dd);
     SCVAE_LAUNCH_CHECK("dd_reduce_xcd_kernel");

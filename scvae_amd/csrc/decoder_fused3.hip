@@ -1495,30 +1495,32 @@ static D4Config d4_config(int P, int H) {
 bool decoder_fused4_supported(int P, int H) { return d4_config(P, H).ok; }
 // which schedule runs a plain training launch: 4 producer / consumer waves (decoder_head4_kernel,
 // the default and the only one beyond H = 126), 3 all waves in one phase (decoder_head3_kernel)
-static int d3_schedule(int P, int H) {
+// Up to 128 rows (the reference's default minibatch of 100) the all-in-one-phase kernel is the
+// faster one (4 tiles: 69 against 80 us at 100 x 32 738; 512 rows: the other way round).
+static int d3_schedule(int P, int H, int rows) {
   if (!decoder_fused3_supported(P, H)) return 4;
   if (!decoder_fused4_supported(P, H)) return 3;
-  return d3_schedule_env() ? d3_schedule_env() : 4;
+  return d3_schedule_env() ? d3_schedule_env() : (rows <= 128 ? 3 : 4);
 }
 // genes per workgroup (= per slab of ll_part / dd_part) of a TRAINING launch
-int decoder_fused3_train_strip_genes(int P, int H, bool drop, int cp_pass) {
-  if (!drop && cp_pass == 0 && d3_schedule(P, H) == 4) return d4_config(P, H).bn;
+int decoder_fused3_train_strip_genes(int P, int H, int rows, bool drop, int cp_pass) {
+  if (!drop && cp_pass == 0 && d3_schedule(P, H, rows) == 4) return d4_config(P, H).bn;
   return d3_bn(P);
 }
 
 // whether a training launch with these options accumulates dd with XCD-local atomics (the caller
 // then reduces eight [H][rows] copies instead of the per-strip slabs): only the producer /
 // consumer kernel has that store
-bool decoder_fused3_dd_atomics(int kind, int H, bool drop, int cp_pass, int dd_mode) {
+bool decoder_fused3_dd_atomics(int kind, int H, int rows, bool drop, int cp_pass, int dd_mode) {
   const int P = likelihood_heads(kind);
-  return dd_mode && !drop && cp_pass == 0 && d3_schedule(P, H) == 4;
+  return dd_mode && !drop && cp_pass == 0 && d3_schedule(P, H, rows) == 4;
 }
 
 // the training instantiation a plain launch (no dropout, no constrained-Poisson pass) takes, as
 // rocprofv3 prints it (bench.py matches its HIP-event timing against the kernel trace by name)
-int decoder_fused3_train_kernel_name(int kind, int H, bool u16, char* out, size_t n) {
+int decoder_fused3_train_kernel_name(int kind, int H, int rows, bool u16, char* out, size_t n) {
   const int P = likelihood_heads(kind);
-  if (d3_schedule(P, H) == 4) {
+  if (d3_schedule(P, H, rows) == 4) {
     const D4Config c = d4_config(P, H);
     return snprintf(out, n, "decoder_head4_kernel<%d, %d, %s, %d, %d, %s, %s>", kind, c.ks1,
                     u16 ? "true" : "false", c.npw, c.bn == d3_bn(P) ? 0 : c.bn,
@@ -1667,7 +1669,7 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
       case LK_BERNOULLI: SCVAE_D3(LK_BERNOULLI, true, true); break;
       default: set_error("decoder_head3_kernel: likelihood kind %d", kind); return -1;
     }
-  } else if (train && d3_schedule(P, H) == 4) {
+  } else if (train && d3_schedule(P, H, rows) == 4) {
     const D4Config c = d4_config(P, H);
     D4Launch a{s, dA, dT, rows, Rpad, H, hp, F, t, B, gw, inline_lgamma, ll_part, dd_part,
                dd_mode ? 1 : 0, (F + c.bn - 1) / c.bn, c.lds};

@@ -303,13 +303,13 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
 bool decoder_fused3_supported(int P, int H);
 size_t decoder_fused3_lds_bytes(int P, int H);
 int decoder_fused3_strip_genes(int P);   // genes per workgroup (= per slab of ll_part / dd_part)
-int decoder_fused3_train_kernel_name(int kind, int H, bool u16, char* out, size_t n);
+int decoder_fused3_train_kernel_name(int kind, int H, int rows, bool u16, char* out, size_t n);
 size_t decoder_fused3_workspace_floats(int rows, int H);
 // the producer / consumer training kernel (decoder_head4_kernel): any H up to 256 for one and two
 // heads, up to 159 for three (LDS), odd H included; plain training launches only
 bool decoder_fused4_supported(int P, int H);
 // genes per workgroup (= per slab of ll_part / dd_part) of a TRAINING launch
-int decoder_fused3_train_strip_genes(int P, int H, bool drop, int cp_pass);
+int decoder_fused3_train_strip_genes(int P, int H, int rows, bool drop, int cp_pass);
 // (train = false: the forward half alone, one- and two-head likelihoods; gw / dd_part unused)
 // drop (training only): dropout of the heads' input connections inside the kernel
 int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, int rows, int H,
@@ -320,7 +320,7 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
 // dd_mode 1: the per-strip partials of dd are not written as slabs but added (fp32 atomics, not
 // bit-repeatable) into eight XCD-local [H][rows] accumulators at dd_part; only where
 // decoder_fused3_dd_atomics says so (the producer / consumer training kernel)
-bool decoder_fused3_dd_atomics(int kind, int H, bool drop, int cp_pass, int dd_mode);
+bool decoder_fused3_dd_atomics(int kind, int H, int rows, bool drop, int cp_pass, int dd_mode);
 // Constrained Poisson (du:218-228) through the bf16x9 head kernel in three passes over the strip
 // grid (row maximum / sum of exponentials | log-likelihood and S | gradients): ll[rows] and, with
 // train, dW / db (in hp) and dd[rows, H].  workspace: decoder_fused_workspace_floats(.., true).

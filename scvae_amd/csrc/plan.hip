@@ -1701,15 +1701,15 @@ int32_t scvae_decoder_fused_variant(int32_t kind, int64_t H) {
   return scvae::decoder_fused_variant(scvae::likelihood_heads(kind), (int)H);
 }
 int32_t scvae_default_head_arith(void) { return scvae::default_head_arith(); }
-int scvae_decoder_train_kernel_name(int32_t kind, int64_t H, int32_t arith, int32_t u16, char* out,
-                                    int64_t n) {
+int scvae_decoder_train_kernel_name(int32_t kind, int64_t H, int64_t rows, int32_t arith,
+                                    int32_t u16, char* out, int64_t n) {
   SCVAE_ARG(out && n > 0);
   out[0] = 0;
   const int which = scvae_decoder_train_kernel(kind, H, arith);
   SCVAE_ARG(which > 0);
   const int P = scvae::likelihood_heads(kind);
   if (which == 3) {
-    scvae::decoder_fused3_train_kernel_name(kind, (int)H, u16 != 0, out, (size_t)n);
+    scvae::decoder_fused3_train_kernel_name(kind, (int)H, (int)rows, u16 != 0, out, (size_t)n);
   } else if (which == 2) {
     snprintf(out, (size_t)n, "decoder_head2_kernel<%d, true, %s>", kind,
              (P <= 2 && H > 96 && H <= 111) ? "true|false" : "false");

@@ -3,6 +3,9 @@ fp64 torch reference: row / gene counts around the 64-wide tiles, hidden sizes
 around the 32-wide MFMA tiles (incl. multiples of 32, where the ones-column of
 db lands in a tile of its own), queue overflow on dense counts, all kinds."""
 import ctypes
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -251,3 +254,19 @@ def test_dd_through_xcd_local_atomics(cuda_device, name, head_arith):
         assert torch.equal(a[2][j], c[2][j]) and torch.equal(a[3][j], c[3][j])
     err = (a[1] - c[1]).abs().max().item()
     assert err <= 2e-6 * a[1].abs().max().item(), err
+
+
+@pytest.mark.skipif(os.environ.get("SCVAE_FUSED_TEST_CHILD") == "1", reason="child process")
+@pytest.mark.parametrize("schedule", ["3", "4"])
+def test_edge_shapes_on_the_other_schedule(cuda_device, schedule):
+    """Up to 128 rows a training launch takes the all-in-one-phase kernel,
+    beyond them the producer / consumer one (bf16x9): the tile-edge and
+    hidden-size cases again with each schedule forced for every row count
+    (``SCVAE_D3_SCHEDULE``, read once per process)."""
+    env = dict(os.environ, SCVAE_D3_SCHEDULE=schedule, SCVAE_FUSED_TEST_CHILD="1")
+    out = subprocess.run(
+        [sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu",
+         "-k", "bf16x9 and (tile_edges or test_hidden_sizes or many_row_tiles or repeated)"],
+        env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+        capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
