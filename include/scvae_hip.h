@@ -137,7 +137,10 @@ int scvae_plan_set_sync(scvae_plan* plan, scvae_sync_fn fn, void* user);
  * evaluate-time statistics, which need the materialised pre-activations) */
 int scvae_plan_set_fused(scvae_plan* plan, int32_t enabled);
 /* Arithmetic of this plan's fused head kernels (see scvae_default_head_arith below): 0 fp32
- * matrix cores, 1 the exact nine-term bf16 split.  Affects which kernels the step launches and
+ * matrix cores, 1 the exact nine-term bf16 split, 2 the six-term split (the nine terms without
+ * a2 b3, a3 b2, a3 b3, together <= 2^-23 of a product: fp32-class, not exact; only the
+ * producer / consumer training kernel has it -- H <= 126, more than 128 rows, no head dropout --
+ * every other launch runs as under 1).  Affects which kernels the step launches and
  * what scvae_plan_accepts_counts_u16 answers; call it before the first step. */
 int scvae_plan_set_head_arith(scvae_plan* plan, int32_t mode);
 int32_t scvae_plan_head_arith(const scvae_plan* plan);
@@ -378,8 +381,8 @@ int32_t scvae_decoder_fused_variant(int32_t kind, int64_t H);
  * matrix cores.
  * There is no process-wide switch: a plan carries its arithmetic (scvae_plan_set_head_arith,
  * below), the stand-alone entry takes it per call in `train`.  scvae_default_head_arith: what a
- * new plan and a call without an arithmetic flag start from -- 1, or SCVAE_HEAD_ARITH=fp32|bf16x9
- * of the environment, read once.
+ * new plan and a call without an arithmetic flag start from -- 1, or
+ * SCVAE_HEAD_ARITH=fp32|bf16x9|bf16x6 of the environment, read once.
  * scvae_decoder_train_kernel: which kernel a training launch takes under `arith`:
  * 1 / 2 = scvae_decoder_fused_variant's fp32 schedules, 3 = decoder_fused3.hip (bf16x9),
  * 0 = unsupported H. */
@@ -393,6 +396,7 @@ int scvae_decoder_train_kernel_name(int32_t kind, int64_t H, int64_t rows, int32
 /* flags of scvae_decoder_fused's / scvae_decoder_fused_u16's `train` (or'ed to 0 / 1 / 3) */
 #define SCVAE_HEADS_FP32 0x100
 #define SCVAE_HEADS_BF16X9 0x200
+#define SCVAE_HEADS_BF16X6 0x800
 /* dd = sum over the gene strips of G W^T: with this flag the producer / consumer training kernel
  * adds each strip's part into eight XCD-local [H][rows] accumulators with fp32 atomics (L2
  * resident) instead of writing per-strip slabs to HBM (0.84 GB at 4096 x 32 738) -- the sums

@@ -20,8 +20,8 @@ NAME_MAX = 96
 
 POISSON, NB, ZIP, ZINB, CONSTRAINED_POISSON, BERNOULLI = 0, 1, 2, 3, 4, 5
 #: flags of scvae_decoder_fused's ``train`` argument: the arithmetic of that call
-HEADS_FP32, HEADS_BF16X9, HEADS_DD_ATOMICS = 0x100, 0x200, 0x400
-HEAD_ARITH_FLAGS = {"fp32": HEADS_FP32, "bf16x9": HEADS_BF16X9}
+HEADS_FP32, HEADS_BF16X9, HEADS_DD_ATOMICS, HEADS_BF16X6 = 0x100, 0x200, 0x400, 0x800
+HEAD_ARITH_FLAGS = {"fp32": HEADS_FP32, "bf16x9": HEADS_BF16X9, "bf16x6": HEADS_BF16X6}
 MODEL_VAE, MODEL_GMVAE = 0, 1
 
 #: registry name -> (kind, head parameter names in registry order)

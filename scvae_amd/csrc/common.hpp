@@ -134,19 +134,24 @@ __device__ __forceinline__ float sigmoidf(float a) {
   return a >= 0.f ? s : e * s;
 }
 
-// Stirling tail s(y) = 1/(12y) - 1/(360y^3) + 1/(1260y^5), y >= 8 (iy = 1/y)
+// Stirling tail s(y) = 1/(12y) - 1/(360y^3) + 1/(1260y^5) - 1/(1680y^7), y >= 4 (iy = 1/y):
+// the first term left out is 1/(1188 y^9) <= 3.2e-9
 __device__ __forceinline__ float stirling_tail_r(float iy) {
   const float iy2 = iy * iy;
-  return iy * (8.3333333333e-2f + iy2 * (-2.7777777778e-3f + iy2 * 7.9365079365e-4f));
+  return iy * (8.3333333333e-2f +
+               iy2 * (-2.7777777778e-3f + iy2 * (7.9365079365e-4f + iy2 * -5.9523809524e-4f)));
 }
-// digamma tail u(y) = 1/(2y) + 1/(12y^2) - 1/(120y^4) + 1/(252y^6), psi(y) = log y - u(y)
+// digamma tail u(y) = 1/(2y) + 1/(12y^2) - 1/(120y^4) + 1/(252y^6) - 1/(240y^8), psi(y) = log y
+// - u(y), y >= 4 (left out: 1/(132 y^10) <= 7.3e-9)
 __device__ __forceinline__ float digamma_tail_r(float iy) {
   const float iy2 = iy * iy;
-  return 0.5f * iy + iy2 * (8.3333333333e-2f + iy2 * (-8.3333333333e-3f + iy2 * 3.9682539683e-3f));
+  return 0.5f * iy +
+         iy2 * (8.3333333333e-2f +
+                iy2 * (-8.3333333333e-3f + iy2 * (3.9682539683e-3f + iy2 * -4.1666666667e-3f)));
 }
 
 // A = lgamma(r+t) - lgamma(r) and D = digamma(r+t) - digamma(r) for r > 0,
-// t >= 0 (t need not be an integer).  Both arguments are shifted up by 8 with
+// t >= 0 (t need not be an integer).  Both arguments are shifted up by 4 with
 // the recurrence, and the shifted difference is taken analytically
 //   lgamma(b+t)-lgamma(b) = t*log(b+t) + (b-1/2)*log1p(t/b) - t + s(b+t)-s(b)
 // so there is no cancellation of two large lgamma values.  Exactly 0 at t == 0.
@@ -187,35 +192,28 @@ __device__ __forceinline__ void lgamma_digamma_diff_small_wave(float r, float t,
   D = WITH_D ? Q * fast_rcp(P) : 0.f;
 }
 
+// (round 4: a shift by 4 with one more term in each tail instead of a shift by 8 -- half the
+//  product work and 8 transcendentals instead of 11; against scipy in fp32 emulation over
+//  r in [e^-10, e^10], t in [1, 65535]: |A - A*| <= 2.1e-7 (t log(r + t) + |log r| + 1),
+//  |D - D*| <= 1.2e-6 D*, both a little below the shift by 8.)  The four shift factors as
+//  y (y + 3) = u and (y + 1)(y + 2) = u + 2: product u (u + 2), derivative (2 y + 3)(2 u + 2).
 template <bool WITH_D>
 __device__ __forceinline__ void lgamma_digamma_diff_general(float r, float t, float& A, float& D) {
   const float x = r + t;
-  const float b = r + 8.f, a = x + 8.f;
+  const float b = r + 4.f, a = x + 4.f;
   const float ib = fast_rcp(b), ia = fast_rcp(a);
   const float l1 = fast_log1p(t * ib);
-  const float A8 = t * fast_log(a) + (b - 0.5f) * l1 - t + (stirling_tail_r(ia) - stirling_tail_r(ib));
-  // products of the 8 shift factors, in two groups of 4 (no overflow for t < 1e7)
-  float n1 = x, n2 = x + 4.f, d1 = r, d2 = r + 4.f;
-  float n1p = 1.f, n2p = 1.f, d1p = 1.f, d2p = 1.f;  // derivatives of the products
-#pragma unroll
-  for (int i = 1; i < 4; ++i) {
-    const float fx1 = x + (float)i, fx2 = x + (float)(4 + i);
-    const float fr1 = r + (float)i, fr2 = r + (float)(4 + i);
-    if (WITH_D) {
-      n1p = fmaf(n1p, fx1, n1); n2p = fmaf(n2p, fx2, n2);
-      d1p = fmaf(d1p, fr1, d1); d2p = fmaf(d2p, fr2, d2);
-    }
-    n1 *= fx1; n2 *= fx2; d1 *= fr1; d2 *= fr2;
-  }
-  const float in1 = fast_rcp(n1), in2 = fast_rcp(n2), id1 = fast_rcp(d1), id2 = fast_rcp(d2);
-  // log(n1*n2/(d1*d2)) as log(n1/d1) + log(n2/d2): each ratio is >= 1 and finite
-  A = A8 - (fast_log(n1 * id1) + fast_log(n2 * id2));
+  const float A4 = t * fast_log(a) + (b - 0.5f) * l1 - t + (stirling_tail_r(ia) - stirling_tail_r(ib));
+  const float ux = x * (x + 3.f), ur = r * (r + 3.f);
+  const float n = ux * (ux + 2.f), d = ur * (ur + 2.f);      // no overflow for t < 1e7
+  const float in = fast_rcp(n), id = fast_rcp(d);
+  A = A4 - fast_log(n * id);              // the ratio is >= 1 and finite
   if (WITH_D) {
-    const float D8 = l1 - (digamma_tail_r(ia) - digamma_tail_r(ib));
-    // sum_{i<8} 1/(r+i) - 1/(x+i)
-    const float sr = d1p * id1 + d2p * id2;
-    const float sx = n1p * in1 + n2p * in2;
-    D = D8 + (sr - sx);
+    const float D4 = l1 - (digamma_tail_r(ia) - digamma_tail_r(ib));
+    const float np = fmaf(2.f, x, 3.f) * fmaf(2.f, ux, 2.f);
+    const float dp = fmaf(2.f, r, 3.f) * fmaf(2.f, ur, 2.f);
+    // sum_{i<4} 1/(r+i) - 1/(x+i)
+    D = D4 + (dp * id - np * in);
   } else {
     D = 0.f;
   }

@@ -27,6 +27,7 @@
 // (the H dimension of GEMM2/GEMM3 is padded to the 32-wide MFMA tile).
 // decoder_fused2.hip holds a second schedule of the same phases (two pipelined half workgroups),
 // which the dispatcher below prefers where it fits.
+#include <cstring>
 #include <type_traits>
 
 #include "common.hpp"
@@ -626,7 +627,7 @@ static size_t dd_part_floats(size_t strips, int rows, int H) {
 }
 
 bool decoder_fused_train_supported(int P, int H, int arith) {
-  return decoder_fused_supported(H) || (arith == 1 && decoder_fused4_supported(P, H));
+  return decoder_fused_supported(H) || (arith >= 1 && decoder_fused4_supported(P, H));
 }
 
 size_t decoder_fused_workspace_floats(int rows, int H, int F, bool train) {
@@ -660,18 +661,25 @@ int decoder_fused_variant(int P, int H) {
 
 // Arithmetic of the three products of the fused head kernels (`arith` of every entry below):
 // 0 = fp32 MFMA (decoder_fused.hip / decoder_fused2.hip), 1 = the exact nine-term bf16 split
-// (decoder_fused3.hip) where that kernel applies (its LDS budget).  A plan carries its own
-// (scvae_plan_set_head_arith); the default of a new plan and of the stand-alone entry is bf16x9,
-// or what SCVAE_HEAD_ARITH=fp32 says -- read once, never written again: no mutable process state.
+// (decoder_fused3.hip) where that kernel applies (its LDS budget), 2 = the same kernels with the
+// three smallest of the nine terms (a2 b3, a3 b2, a3 b3: <= 2^-23 of a product) left out in the
+// producer / consumer training kernel -- six matrix instructions per product instead of nine;
+// every other launch under 2 runs as under 1.  A plan carries its own
+// (scvae_plan_set_head_arith); the default of a new plan and of the stand-alone entry is 2 (with
+// the terms cut by rounding its error is that of 1 to the digits tests/test_gpu_as_benched.py
+// prints, a third of the matrix instructions gone), or what SCVAE_HEAD_ARITH=fp32 / bf16x9 says
+// -- read once, never written again: no mutable process state.
 int default_head_arith() {
   static const int v = [] {
     const char* e = getenv("SCVAE_HEAD_ARITH");
-    return (e && (e[0] == 'f' || e[0] == '0')) ? 0 : 1;   // default: bf16x9
+    if (e && (e[0] == 'f' || e[0] == '0')) return 0;
+    if (e && (strstr(e, "x9") || e[0] == '1')) return 1;
+    return 2;   // default: bf16x6 (bf16x9 wherever a kernel has no six-term form)
   }();
   return v;
 }
 int decoder_train_kernel(int P, int H, int arith) {
-  if (arith == 1 && (decoder_fused3_supported(P, H) || decoder_fused4_supported(P, H))) return 3;
+  if (arith >= 1 && (decoder_fused3_supported(P, H) || decoder_fused4_supported(P, H))) return 3;
   return decoder_fused_supported(H) ? decoder_fused_variant(P, H) : 0;
 }
 
@@ -714,7 +722,7 @@ static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int
     static const int dbg = [] { const char* e = getenv("SCVAE_D3_DEBUG"); return e ? atoi(e) : 0; }();
     return decoder_fused3_launch(s, true, kind, d, rows, H, hp, F, t, B, gw,
                                  inline_lgamma | (dbg << 8), ll_part, dd_part, planes, drop, 0,
-                                 nullptr, dd_mode);
+                                 nullptr, (dd_mode ? 1 : 0) | (arith == 2 ? 2 : 0));
   }
   if (drop) {
     set_error("head dropout inside the fused kernel needs the bf16x9 head kernel");
@@ -773,7 +781,7 @@ int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int
   }();
   const int heads = likelihood_heads(kind);
   int which = decoder_forward_supported(heads, H) ? 1 : 0;
-  if (arith == 1 && heads <= 2 && decoder_fused3_supported(heads, H)) which = 3;
+  if (arith >= 1 && heads <= 2 && decoder_fused3_supported(heads, H)) which = 3;
   if (forced == 0) which = 0;
   if (forced == 1 && decoder_forward_supported(heads, H)) which = 1;
   int rc;
@@ -829,7 +837,7 @@ __global__ __launch_bounds__(256) void lse_reduce_kernel(const float* __restrict
 }
 
 bool decoder_fused_cpoisson_supported(int H, int arith) {
-  return decoder_fused_supported(H) && arith == 1 && decoder_fused3_supported(1, H);
+  return decoder_fused_supported(H) && arith >= 1 && decoder_fused3_supported(1, H);
 }
 
 // Constrained Poisson through the bf16x9 head kernel: three passes over the strip grid (an

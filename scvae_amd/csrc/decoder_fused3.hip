@@ -51,6 +51,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 // A/B switch (tools/ab_variants.sh): 1 = the global fragment loads of d stay where the source
@@ -105,16 +106,39 @@ size_t decoder_fused3_workspace_floats(int rows, int H) {
   return 3 * d3_set_elems((int)rpad) * sizeof(uint16_t) / sizeof(float) + 3 * rpad * 4 + 64;
 }
 
-// x = b1 + b2 + b3 exactly, each term's upper 16 bits a bf16 value (lower 16 bits zero)
-__device__ __forceinline__ void split3_trunc(float x, unsigned& b1, unsigned& b2, unsigned& b3) {
-  b1 = __float_as_uint(x) & 0xFFFF0000u;
+// x = b1 + b2 + b3 exactly, each term's upper 16 bits a bf16 value (lower 16 bits zero).
+// The terms are cut by ROUNDING to nearest (v_cvt_pk_bf16_f32), not by truncation: x - bf16(x)
+// has at most 16 significant bits and is exact in fp32, the next residual at most 8 -- the
+// three terms still add up to x exactly (the nine-term products stay exact), but they are
+// smaller, |b2| <= 2^-9 |x| and |b3| <= 2^-18 |x|, and of either sign: the three products the
+// six-term arithmetic leaves out (b2 c3, b3 c2, b3 c3) are then <= 2^-26 |x c| together and
+// unbiased -- below the rounding of an fp32 multiply-add -- where truncated terms (all of the
+// sign of x, up to 2^-8 and 2^-16) left a one-sided 2^-22 (measured against fp64 at 4096 rows:
+// 8e-6 of the largest element of dd, ten times the fp32 matrix cores' error).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {   // RN, lo in bits 0-15
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{lo, hi}, bf16x2));
+}
+__device__ __forceinline__ void split3_rn(float x, unsigned& b1, unsigned& b2, unsigned& b3) {
+  b1 = cvt_pk_bf16(0.f, x) & 0xFFFF0000u;
   const float r1 = x - __uint_as_float(b1);
-  b2 = __float_as_uint(r1) & 0xFFFF0000u;
+  b2 = cvt_pk_bf16(0.f, r1) & 0xFFFF0000u;
   b3 = __float_as_uint(r1 - __uint_as_float(b2));
 }
 // (upper half of hi) << 16 | upper half of lo
 __device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) {
   return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+// the same for two values at once, packed as the planes hold them (x0 in bits 0-15)
+__device__ __forceinline__ void split3_rn_pair(float x0, float x1, unsigned& p1, unsigned& p2,
+                                               unsigned& p3) {
+  p1 = cvt_pk_bf16(x0, x1);
+  float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xFFFF0000u);
+  p2 = cvt_pk_bf16(r0, r1);
+  r0 -= __uint_as_float(p2 << 16);
+  r1 -= __uint_as_float(p2 & 0xFFFF0000u);
+  p3 = pack_hi16(__float_as_uint(r0), __float_as_uint(r1));      // (8 bits each: exact)
 }
 
 // d [R, H] fp32 -> the bf16 planes of [d | 1 | 0...] (column H = 1: bias / db; zero beyond and
@@ -143,12 +167,12 @@ __global__ __launch_bounds__(256) void split3_hidden_kernel(const float* __restr
     const int rb = frag / ksp, ks = frag % ksp;
     const int row = 16 * rb + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) split3_trunc(value(row, k0 + e), t1[e], t2[e], t3[e]);
+    for (int e = 0; e < 8; ++e) split3_rn(value(row, k0 + e), t1[e], t2[e], t3[e]);
   } else {
     const int ht = frag / nb, kg = frag % nb;
     const int h = 32 * ht + (lane & 31), r0 = 16 * kg + 8 * (lane >> 5);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) split3_trunc(value(r0 + e, h), t1[e], t2[e], t3[e]);
+    for (int e = 0; e < 8; ++e) split3_rn(value(r0 + e, h), t1[e], t2[e], t3[e]);
   }
   auto pack = [](const unsigned* t) {
     u32x4 v;
@@ -296,7 +320,7 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
         const int h = h0 + u * HSTEP;
         if (h <= H) {
           unsigned b1, b2, b3;
-          split3_trunc(col_ok ? v[j][u] : 0.f, b1, b2, b3);
+          split3_rn(col_ok ? v[j][u] : 0.f, b1, b2, b3);
           char* dst = Wl + (size_t)(j * 3) * WPLANE + h * ROWB + 2 * g;
           *reinterpret_cast<uint16_t*>(dst) = (uint16_t)(b1 >> 16);
           *reinterpret_cast<uint16_t*>(dst + WPLANE) = (uint16_t)(b2 >> 16);
@@ -636,15 +660,14 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     for (int j = 0; j < P; ++j)
 #pragma unroll
       for (int sb = 0; sb < NSB; ++sb) {
-        unsigned b1[4], b2[4], b3[4];
+        unsigned p1[2], p2[2], p3[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) split3_trunc(G[j][4 * sb + e], b1[e], b2[e], b3[e]);
+        for (int e = 0; e < 2; ++e)
+          split3_rn_pair(G[j][4 * sb + 2 * e], G[j][4 * sb + 2 * e + 1], p1[e], p2[e], p3[e]);
         char* dst = Gl + (size_t)(j * 3) * GPLANE + gst + 32 * sb;
-        *reinterpret_cast<u32x2*>(dst) = u32x2{pack_hi16(b1[0], b1[1]), pack_hi16(b1[2], b1[3])};
-        *reinterpret_cast<u32x2*>(dst + GPLANE) =
-            u32x2{pack_hi16(b2[0], b2[1]), pack_hi16(b2[2], b2[3])};
-        *reinterpret_cast<u32x2*>(dst + 2 * GPLANE) =
-            u32x2{pack_hi16(b3[0], b3[1]), pack_hi16(b3[2], b3[3])};
+        *reinterpret_cast<u32x2*>(dst) = u32x2{p1[0], p1[1]};
+        *reinterpret_cast<u32x2*>(dst + GPLANE) = u32x2{p2[0], p2[1]};
+        *reinterpret_cast<u32x2*>(dst + 2 * GPLANE) = u32x2{p3[0], p3[1]};
       }
     }
     lds_barrier();
@@ -850,12 +873,20 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
 // interchangeable launch by launch (SCVAE_D3_SCHEDULE=3 selects the old one; A/B + tests).
 constexpr int D4_BM = 32;           // rows per tile
 
+#ifndef D4_COMPACT
+#define D4_COMPACT 1
+#endif
+// the non-zeros' corrections through a dense queue (below) up to four contraction steps
+// (H <= 126); the wide geometries, whose weight planes leave no LDS for the queues, keep the
+// per-lane walk
+__host__ __device__ constexpr bool d4_compact(int ks1) { return D4_COMPACT && ks1 <= 4; }
 // NPW producer waves (4 or 8) + four consumers per workgroup
 __host__ __device__ constexpr int d4_threads(int npw) { return (npw + 4) * 64; }
 size_t decoder_fused4_lds_bytes(int P, int H, int npw, int bn = 0) {
   const int rowb = 2 * (bn ? bn : d3_bn(P)) + 16;
   return (size_t)P * 3 * d3_hp1(H) * rowb + (size_t)2 * P * 3 * D4_BM * rowb +
-         (size_t)2 * (npw / 2) * 4 * D4_BM * sizeof(float);
+         (size_t)2 * (npw / 2) * 4 * D4_BM * sizeof(float) +
+         (d4_compact((H + 1 + 31) / 32) ? npw * 512 : 0);   // (the producers' queues)
 }
 
 #ifndef D4_PROF
@@ -891,11 +922,18 @@ __device__ unsigned long long d4_prof[12 * 8];
 #define D4_PROF_END do {} while (0)
 #endif
 
-// G1LAST: where the producers' GEMM1 sits relative to the workgroup barrier -- true: at the END
-// of an iteration (for the tile after the one whose likelihood the iteration evaluates), false:
-// at its start.  Measured (4096 x 32 738, kernel + reduces, dd atomics): with four producer
-// waves the end is better (ZINB 2.35 -> 2.23 ms, Poisson 0.82 -> 0.81), with eight the start
-// (NB 1.42 against 1.50).
+// G1: where the producers' GEMM1 sits relative to the workgroup barrier -- 1: at the END of an
+// iteration (for the tile after the one whose likelihood the iteration evaluates), 0: at its
+// start, 2 (eight producers): the first producer wave of every SIMD at the start, the second at
+// the end.  Measured (4096 x 32 738, kernel + reduces, dd atomics): with four producer waves the
+// end is better than the start (ZINB 2.35 -> 2.23 ms, Poisson 0.82 -> 0.81); with eight the start
+// beats the end (NB 1.42 against 1.50) and the staggered order beats both: with both GEMM1s at
+// the start they and the consumer's GEMM2 all want the matrix pipe in the first half of a tile
+// (the section probes: GEMM2 6.0 k cycles for 2.3 k of pipe work) and leave it to GEMM3 alone
+// and then idle under the atomic adds in the second.
+#ifndef D4_G1_EIGHT
+#define D4_G1_EIGHT 0
+#endif
 // KS1 = ceil((H + 1) / 32) contraction steps of GEMM1 = 32-wide h tiles of GEMM2, up to 9
 // (H <= 256): beyond four, a consumer wave owns (KS1 + 3) / 4 h tiles (ht, ht + 4, ht + 8) and the
 // producers refill their four fragment slots of d inside the loop.  BN_: genes per strip (0: the
@@ -905,7 +943,7 @@ __device__ unsigned long long d4_prof[12 * 8];
 // instead of falling out of GEMM2's ones row -- which at these widths would be an h tile of its
 // own (the fifth at H = 128, the ninth at 256) holding nothing but that row.
 template <int KIND, int KS1, bool U16, int NPW, int BN_ = 0, bool DBP = false,
-          bool G1LAST = (NPW == 4)>
+          int G1 = (NPW == 4 ? 1 : D4_G1_EIGHT), int TERMS = 9>
 __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
     const uint16_t* __restrict__ dA, const uint16_t* __restrict__ dT, int R, int Rpad, int H,
     HeadParams hp, int F, Targets tg, int B, const float* __restrict__ gw, int inline_lgamma,
@@ -974,7 +1012,7 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
         const int h = h0 + u * HSTEP;
         if (h <= H) {
           unsigned b1, b2, b3;
-          split3_trunc(col_ok ? v[j][u] : 0.f, b1, b2, b3);
+          split3_rn(col_ok ? v[j][u] : 0.f, b1, b2, b3);
           char* dst = Wl + (size_t)(j * 3) * WPLANE + h * ROWB + 2 * g;
           *reinterpret_cast<uint16_t*>(dst) = (uint16_t)(b1 >> 16);
           *reinterpret_cast<uint16_t*>(dst + WPLANE) = (uint16_t)(b2 >> 16);
@@ -1074,7 +1112,7 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
             for (int j = 0; j < P; ++j)
 #pragma unroll
               for (int sb = 0; sb < NSB; ++sb)
-                acc1[j][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                if (TERMS == 9 || a + b < 3) acc1[j][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     afr[ks & 1][j][sb][a], dfr[ks % DF][b], acc1[j][sb], 0, 0, 0);
         if (ks + DF < KS1) {        // this step's slot is free: step ks + DF of the same tile
           load_dk(mt, ks + DF, dfr[ks % DF]);
@@ -1082,7 +1120,7 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
         }
       }
     };
-    // (G1LAST) the barrier sits between GEMM1 of a tile and its likelihood: when it releases, the
+    // (g1last) the barrier sits between GEMM1 of a tile and its likelihood: when it releases, the
     // producers are in their VALU stretch and the consumers' GEMM2 finds the matrix pipe free;
     // the producers' GEMM1 of the NEXT tile runs at the end of the iteration, under the
     // consumers' stores (or atomic adds) of dd, which issue no matrix instructions.
@@ -1093,7 +1131,8 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
       for (int e = 0; e < NE; ++e) dbacc[j][e] = 0.f;
     TileIn nxt = load_t(0);
     load_d(0);
-    if (G1LAST) {
+    const bool g1last = G1 == 1 || (G1 == 2 && w >= NPW / 2);    // (wave-uniform)
+    if (g1last) {
       gemm1(0);
       load_d(min(D4_BM, Rpad - D4_BM));
       d3_pin_loads();
@@ -1106,13 +1145,13 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
       const float up = cur.up0;
       char* Gb = Gl + (tile & 1) * GBUF;
       float* lb = llbuf + (tile & 1) * LLN;
-      if (!G1LAST) gemm1(m0);
+      if (!g1last) gemm1(m0);
       {
         // the next tile's targets (and, GEMM1 first, its fragments of d): under the likelihood.
         // Unconditional (the last tile requests a valid tile again): under a branch the compiler
         // waits for the loads where the arms meet
         nxt = load_t(min(m0 + D4_BM, Rpad - D4_BM));
-        if (!G1LAST) load_d(min(m0 + D4_BM, Rpad - D4_BM));
+        if (!g1last) load_d(min(m0 + D4_BM, Rpad - D4_BM));
         d3_pin_loads();
       }
       // ---- likelihood of this lane's NSB x 4 elements: row 16 rq + i16, genes
@@ -1144,6 +1183,75 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
         }
       }
       D4_STAMP(1);
+      if constexpr (d4_compact(KS1)) {
+      // ---- t > 0: + lgamma(r+t) - lgamma(r) [- lgamma(1+t)], and the digamma term of dlog r.
+      //      5 % of the elements: instead of a per-lane walk (as many passes as the fullest lane
+      //      holds non-zeros -- 1.6 on average with a fifth of the lanes busy, and the VALU
+      //      instructions of these waves are what the tile time is made of), the wave's non-zeros
+      //      are queued densely -- (t, log r) at position [elements e' < e of all lanes][lanes
+      //      below] from one ballot per element slot -- corrected in ONE pass of full lanes, and
+      //      read back by their owners.  The queue is 512 bytes of LDS of the wave's own (64
+      //      entries: one pass per 64 non-zeros).  (Kept in the wave's corner of the G buffer
+      //      the tile is about to fill, the kernels whose GEMM1 sits at the end of the
+      //      iteration were not repeatable from run to run -- 26-40 of 40 launches differed,
+      //      in sporadic elements whose log r came out of GEMM1 wrong -- although no other
+      //      wave touches that corner between the two barriers; with the queue in LDS of
+      //      its own: 0 of 40.  Not understood; tools/time_head.py TIME_HEAD_STRESS.) ----
+      if ((Traits::HAS_R || inline_lgamma) && !(dbg & 4)) {
+        int pos[NE];
+        int total = 0;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const unsigned long long bal = __builtin_amdgcn_ballot_w64(((nz >> e) & 1u) != 0u);
+          pos[e] = total + (int)__builtin_amdgcn_mbcnt_hi(
+                               (unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+          total += __builtin_popcountll(bal);
+        }
+        char* qb = reinterpret_cast<char*>(llbuf + 2 * LLN) + w * 512;
+        auto qaddr = [&](int k) { return qb + 8 * k; };
+        for (int q0 = 0; q0 < total; q0 += 64) {
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            const int k = pos[e] - q0;
+            if (((nz >> e) & 1u) && (unsigned)k < 64u) {
+              const float lrv = Traits::HAS_R ? acc1[P - 1][e >> 2][e & 3] : 0.f;
+              *reinterpret_cast<f32x2*>(qaddr(k)) = f32x2{tval[e], lrv};
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          const bool on = lane < total - q0;
+          f32x2 in = *reinterpret_cast<const f32x2*>(qaddr(lane));
+          const float tt = on ? in.x : 1.f;
+          float corr = 0.f, rd = 0.f;
+          if (Traits::HAS_R) {
+            const float lrv = on ? in.y : 0.f;
+            const float r = __expf(fminf(fmaxf(lrv, -10.f), 10.f));
+            const float rgate = (lrv >= -10.f && lrv <= 10.f) ? 1.f : 0.f;
+            const bool small = tt <= 8.f && (U16 || tt == __builtin_rintf(tt));
+            float A, D;
+            if (__builtin_amdgcn_ballot_w64(!small) == 0)
+              lgamma_digamma_diff_small_wave<true>(r, tt, A, D);
+            else
+              lgamma_digamma_diff_general<true>(r, tt, A, D);
+            corr = A;
+            rd = rgate * r * D;
+          }
+          if (inline_lgamma) corr -= lgamma1p(tt);
+          if (on) *reinterpret_cast<f32x2*>(qaddr(lane)) = f32x2{corr, rd};
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            const int k = pos[e] - q0;
+            if (((nz >> e) & 1u) && (unsigned)k < 64u) {
+              const f32x2 o = *reinterpret_cast<const f32x2*>(qaddr(k));
+              lsum += o.x;
+              if (Traits::HAS_R) G[P - 1][e] = fmaf(up, o.y, G[P - 1][e]);
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      } else {
       // ---- t > 0: + lgamma(r+t) - lgamma(r) [- lgamma(1+t)], and the digamma term of dlog r:
       //      a per-lane walk over the lane's non-zero elements ----
       if ((Traits::HAS_R || inline_lgamma) && !(dbg & 4)) {
@@ -1178,6 +1286,7 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
           lsum += on ? corr : 0.f;
         }
       }
+      }
       D4_STAMP(2);
       if (DBP) {
 #pragma unroll
@@ -1192,20 +1301,19 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
       for (int j = 0; j < P; ++j)
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb) {
-          unsigned b1[4], b2[4], b3[4];
+          unsigned p1[2], p2[2], p3[2];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) split3_trunc(G[j][4 * sb + e], b1[e], b2[e], b3[e]);
+          for (int e = 0; e < 2; ++e)
+            split3_rn_pair(G[j][4 * sb + 2 * e], G[j][4 * sb + 2 * e + 1], p1[e], p2[e], p3[e]);
           char* dst = Gb + (size_t)(j * 3) * GPLANE + gst + 32 * sb;
-          *reinterpret_cast<u32x2*>(dst) = u32x2{pack_hi16(b1[0], b1[1]), pack_hi16(b1[2], b1[3])};
-          *reinterpret_cast<u32x2*>(dst + GPLANE) =
-              u32x2{pack_hi16(b2[0], b2[1]), pack_hi16(b2[2], b2[3])};
-          *reinterpret_cast<u32x2*>(dst + 2 * GPLANE) =
-              u32x2{pack_hi16(b3[0], b3[1]), pack_hi16(b3[2], b3[3])};
+          *reinterpret_cast<u32x2*>(dst) = u32x2{p1[0], p1[1]};
+          *reinterpret_cast<u32x2*>(dst + GPLANE) = u32x2{p2[0], p2[1]};
+          *reinterpret_cast<u32x2*>(dst + 2 * GPLANE) = u32x2{p3[0], p3[1]};
         }
       D4_STAMP(3);
       // GEMM1 of the next tile (the last iteration: a valid tile again, unused), then the request
       // for the fragments of the tile after it
-      if (G1LAST) {
+      if (g1last) {
         gemm1(min(m0 + D4_BM, Rpad - D4_BM));
         load_d(min(m0 + 2 * D4_BM, Rpad - D4_BM));
         d3_pin_loads();
@@ -1341,7 +1449,7 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
           for (int a = 2; a >= 0; --a)
 #pragma unroll
             for (int b = 2; b >= 0; --b)
-              accW[t][j][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2t[ks][a], bf[st & 1][b],
+              if (TERMS == 9 || a + b < 3) accW[t][j][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2t[ks][a], bf[st & 1][b],
                                                                        accW[t][j][gt], 0, 0, 0);
         }
       }
@@ -1378,7 +1486,7 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
           for (int a = 2; a >= 0; --a)
 #pragma unroll
             for (int b = 2; b >= 0; --b)
-              acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[st & 1][b], af[st & 1][a], acc3,
+              if (TERMS == 9 || a + b < 3) acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[st & 1][b], af[st & 1][a], acc3,
                                                              0, 0, 0);
         }
         D4_STAMP(1);
@@ -1518,13 +1626,15 @@ bool decoder_fused3_dd_atomics(int kind, int H, int rows, bool drop, int cp_pass
 
 // the training instantiation a plain launch (no dropout, no constrained-Poisson pass) takes, as
 // rocprofv3 prints it (bench.py matches its HIP-event timing against the kernel trace by name)
-int decoder_fused3_train_kernel_name(int kind, int H, int rows, bool u16, char* out, size_t n) {
+int decoder_fused3_train_kernel_name(int kind, int H, int rows, bool u16, char* out, size_t n,
+                                     int terms) {
   const int P = likelihood_heads(kind);
   if (d3_schedule(P, H, rows) == 4) {
     const D4Config c = d4_config(P, H);
-    return snprintf(out, n, "decoder_head4_kernel<%d, %d, %s, %d, %d, %s, %s>", kind, c.ks1,
+    const bool six = terms == 6 && c.ks1 <= 4 && c.bn == d3_bn(P) && !c.dbp;
+    return snprintf(out, n, "decoder_head4_kernel<%d, %d, %s, %d, %d, %s, %d, %d>", kind, c.ks1,
                     u16 ? "true" : "false", c.npw, c.bn == d3_bn(P) ? 0 : c.bn,
-                    c.dbp ? "true" : "false", c.npw == 4 ? "true" : "false");
+                    c.dbp ? "true" : "false", c.npw == 4 ? 1 : D4_G1_EIGHT, six ? 6 : 9);
   }
   return snprintf(out, n, "decoder_head3_kernel<%d, %d, %s, true, false, 0>", kind,
                   (d3_hp1(H) + 31) / 32, u16 ? "true" : "false");
@@ -1534,12 +1644,18 @@ int decoder_fused3_train_kernel_name(int kind, int H, int rows, bool u16, char* 
 struct D4Launch {
   hipStream_t s; const uint16_t* dA; const uint16_t* dT; int rows, Rpad, H; HeadParams hp; int F;
   Targets t; int B; const float* gw; int inline_lgamma; float* ll_part; float* dd_part;
-  int dd_atomic; int strips; size_t lds;
+  int dd_atomic; int strips; size_t lds; int terms;
 };
-template <int KIND, int KS1, int NPW, int BN_, bool DBP = false>
+template <int KIND, int KS1, int NPW, int BN_, bool DBP = false, int TERMS = 9>
 static int d4_launch_one(const D4Launch& a) {
-  auto kfn = a.t.u16 ? decoder_head4_kernel<KIND, KS1, true, NPW, BN_, DBP>
-                     : decoder_head4_kernel<KIND, KS1, false, NPW, BN_, DBP>;
+  constexpr int G1 = NPW == 4 ? 1 : D4_G1_EIGHT;
+  // (six-term products: instantiated for the default strips up to four contraction steps, i.e.
+  //  H <= 126; the wider geometries keep all nine terms)
+  if constexpr (TERMS == 9 && KS1 <= 4 && BN_ == 0 && !DBP) {
+    if (a.terms == 6) return d4_launch_one<KIND, KS1, NPW, BN_, DBP, 6>(a);
+  }
+  auto kfn = a.t.u16 ? decoder_head4_kernel<KIND, KS1, true, NPW, BN_, DBP, G1, TERMS>
+                     : decoder_head4_kernel<KIND, KS1, false, NPW, BN_, DBP, G1, TERMS>;
   SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)a.lds));
   hipLaunchKernelGGL(kfn, dim3(a.strips), dim3(d4_threads(NPW)), a.lds, a.s, a.dA, a.dT, a.rows,
                      a.Rpad, a.H, a.hp, a.F, a.t, a.B, a.gw, a.inline_lgamma, a.ll_part,
@@ -1672,7 +1788,7 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
   } else if (train && d3_schedule(P, H, rows) == 4) {
     const D4Config c = d4_config(P, H);
     D4Launch a{s, dA, dT, rows, Rpad, H, hp, F, t, B, gw, inline_lgamma, ll_part, dd_part,
-               dd_mode ? 1 : 0, (F + c.bn - 1) / c.bn, c.lds};
+               (dd_mode & 1) ? 1 : 0, (F + c.bn - 1) / c.bn, c.lds, (dd_mode & 2) ? 6 : 9};
     if (a.dd_atomic)    // eight XCD-local accumulators [8][H][rows], cleared for this launch
       SCVAE_HIP(hipMemsetAsync(dd_part, 0, (size_t)8 * H * rows * sizeof(float), s));
     int rc;

@@ -288,7 +288,8 @@ size_t decoder_fused2_lds_bytes(int P, int H);
 int decoder_fused2_launch(hipStream_t s, bool train, int kind, const float* d, int rows, int H,
                           HeadParams hp, int F, Targets t, int B, const float* gw,
                           int inline_lgamma, float* ll_part, float* dd_part);
-// arith: 0 fp32 MFMA, 1 the exact nine-term bf16 split where decoder_fused3 applies
+// arith: 0 fp32 MFMA, 1 the exact nine-term bf16 split where decoder_fused3 applies, 2 = 1 with
+// six-term products in the producer / consumer training kernel
 int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                           int F, Targets t, int B, const float* row_const, float* ll,
                           float* workspace, int arith);
@@ -303,7 +304,8 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
 bool decoder_fused3_supported(int P, int H);
 size_t decoder_fused3_lds_bytes(int P, int H);
 int decoder_fused3_strip_genes(int P);   // genes per workgroup (= per slab of ll_part / dd_part)
-int decoder_fused3_train_kernel_name(int kind, int H, int rows, bool u16, char* out, size_t n);
+int decoder_fused3_train_kernel_name(int kind, int H, int rows, bool u16, char* out, size_t n,
+                                     int terms = 9);
 size_t decoder_fused3_workspace_floats(int rows, int H);
 // the producer / consumer training kernel (decoder_head4_kernel): any H up to 256 for one and two
 // heads, up to 159 for three (LDS), odd H included; plain training launches only
@@ -345,7 +347,7 @@ void stage_probe(int stage, int which, hipStream_t s);
 void decoder_fused_set_probe(hipEvent_t before, hipEvent_t after);   // (nullptr, nullptr): off
 hipEvent_t decoder_fused_probe(int which);
 bool decoder_fused_probe_recorded();   // both events of the pair went into a stream
-int default_head_arith();   // SCVAE_HEAD_ARITH, read once: 0 fp32 MFMA, 1 (default) bf16x9
+int default_head_arith();   // SCVAE_HEAD_ARITH, read once: 0 fp32 MFMA, 1 (default) bf16x9, 2 bf16x6
 int decoder_train_kernel(int P, int H, int arith);   // 1 / 2: the fp32 schedules, 3: decoder_fused3.hip
 
 // forward-only variant with the pre-activations in registers (decoder_forward.hip)

@@ -1315,7 +1315,7 @@ int scvae_plan_set_fused(scvae_plan* p, int32_t enabled) {
   return 0;
 }
 int scvae_plan_set_head_arith(scvae_plan* p, int32_t mode) {
-  SCVAE_ARG(p && (mode == 0 || mode == 1));
+  SCVAE_ARG(p && mode >= 0 && mode <= 2);
   p->head_arith = mode;
   return 0;
 }
@@ -1709,7 +1709,8 @@ int scvae_decoder_train_kernel_name(int32_t kind, int64_t H, int64_t rows, int32
   SCVAE_ARG(which > 0);
   const int P = scvae::likelihood_heads(kind);
   if (which == 3) {
-    scvae::decoder_fused3_train_kernel_name(kind, (int)H, (int)rows, u16 != 0, out, (size_t)n);
+    scvae::decoder_fused3_train_kernel_name(kind, (int)H, (int)rows, u16 != 0, out, (size_t)n,
+                                            arith == 2 ? 6 : 9);
   } else if (which == 2) {
     snprintf(out, (size_t)n, "decoder_head2_kernel<%d, true, %s>", kind,
              (P <= 2 && H > 96 && H <= 111) ? "true|false" : "false");
@@ -1719,7 +1720,7 @@ int scvae_decoder_train_kernel_name(int32_t kind, int64_t H, int64_t rows, int32
   return 0;
 }
 int32_t scvae_decoder_train_kernel(int32_t kind, int64_t H, int32_t arith) {
-  if (kind < 0 || (kind > 3 && kind != scvae::LK_BERNOULLI) || (arith != 0 && arith != 1) ||
+  if (kind < 0 || (kind > 3 && kind != scvae::LK_BERNOULLI) || (arith < 0 || arith > 2) ||
       !scvae::decoder_fused_train_supported(scvae::likelihood_heads(kind), (int)H, arith))
     return 0;
   return scvae::decoder_train_kernel(scvae::likelihood_heads(kind), (int)H, arith);
@@ -1730,11 +1731,13 @@ static int decoder_fused_entry(int32_t kind, int32_t train, const float* d, int6
                                const float* gw, const float* row_const, float* ll, float* dd,
                                void* workspace, void* stream) {
   SCVAE_ARG(((kind >= 0 && kind <= 3) || kind == scvae::LK_BERNOULLI) && W && b);
-  // bits 8-9 of `train`: the arithmetic of this call (neither: the process default)
-  SCVAE_ARG((train & ~0x703) == 0 && (train & 0x300) != 0x300);
+  // bits 8, 9, 11 of `train`: the arithmetic of this call (none: the process default)
+  const int arith_bits = train & (SCVAE_HEADS_FP32 | SCVAE_HEADS_BF16X9 | SCVAE_HEADS_BF16X6);
+  SCVAE_ARG((train & ~0xF03) == 0 && (arith_bits & (arith_bits - 1)) == 0);
   const int dd_mode = (train & SCVAE_HEADS_DD_ATOMICS) ? 1 : 0;
   const int arith = (train & SCVAE_HEADS_FP32) ? 0
-                    : (train & SCVAE_HEADS_BF16X9) ? 1 : scvae::default_head_arith();
+                    : (train & SCVAE_HEADS_BF16X9) ? 1
+                    : (train & SCVAE_HEADS_BF16X6) ? 2 : scvae::default_head_arith();
   train &= 3;
   // (forward-only calls: even widths up to 126; training also the bf16x9 kernel's wider range)
   SCVAE_ARG(train ? scvae::decoder_fused_train_supported(scvae::likelihood_heads(kind), (int)H, arith)

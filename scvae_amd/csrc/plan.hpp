@@ -144,7 +144,7 @@ struct scvae_plan {
   int use_fused = 1;          // fused decoder head kernel (0 = unfused GEMM + likelihood path)
   int dd_atomics = 0;         // 1: the head kernel adds its part of dd into XCD-local accumulators
                               // (fp32 atomics: not bit-repeatable) instead of per-strip slabs
-  int head_arith = 1;         // arithmetic of the fused head kernels: 0 fp32 MFMA, 1 bf16x9
+  int head_arith = 2;         // arithmetic of the fused head kernels: 0 fp32 MFMA, 1 bf16x9, 2 bf16x6
                               // (scvae_plan_set_head_arith; a new plan: default_head_arith())
   int use_count_gemm = 1;     // exact bf16-split kernels for products with a count matrix x:
                               // 0 never, 1 where they pay (plan_gemm), 2 always

@@ -297,9 +297,12 @@ class Engine:
 
     def set_head_arith(self, arith):
         """Arithmetic of this engine's fused head kernels: ``"bf16x9"`` (the
-        exact nine-term bf16 split, default) or ``"fp32"`` (fp32 matrix
-        cores).  A plan attribute: engines of one process can differ."""
-        mode = {"fp32": 0, "bf16x9": 1, 0: 0, 1: 1}[arith]
+        exact nine-term bf16 split, default), ``"bf16x6"`` (the nine terms
+        without the three smallest, <= 2^-23 of a product: fp32-class, a
+        third fewer matrix instructions in the producer / consumer training
+        kernel) or ``"fp32"`` (fp32 matrix cores).  A plan attribute: engines
+        of one process can differ."""
+        mode = {"fp32": 0, "bf16x9": 1, "bf16x6": 2, 0: 0, 1: 1, 2: 2}[arith]
         _lib.check(self.lib.scvae_plan_set_head_arith(self.handle, mode),
                    "scvae_plan_set_head_arith")
 
@@ -312,7 +315,8 @@ class Engine:
 
     @property
     def head_arith(self):
-        return ("fp32", "bf16x9")[self.lib.scvae_plan_head_arith(self.handle)]
+        return ("fp32", "bf16x9", "bf16x6")[
+            self.lib.scvae_plan_head_arith(self.handle)]
 
     def set_count_gemm(self, enabled, always=False):
         """The exact bf16-split kernels for the products with a count matrix

@@ -239,15 +239,21 @@ def test_u16_training_step_is_the_fp32_step_at_benchmark_size(benchmark_step):
         assert torch.equal(a, b), i
 
 
+@pytest.mark.parametrize("arith", ["bf16x9", "bf16x6"])
 def test_u16_training_step_against_the_oracle_at_benchmark_size(
-        benchmark_step):
+        benchmark_step, arith):
     """One training step of the benchmark (B = 4096, uint16 minibatch, the
-    dealt head-kernel schedule, the count kernels reading two genes per lane)
-    against the fp64 oracle with autograd on the host."""
+    producer / consumer head kernel with the decoder gradient through atomics,
+    the count kernels reading two genes per lane) against the fp64 oracle with
+    autograd on the host -- under the head arithmetic `bench.py` times (the
+    exact nine-term split) and under the six-term option, same tolerances."""
     engine, x32, x16, rc, eps = benchmark_step
     B, F = x32.shape
     L = eps.shape[-1]
     eng = engine()
+    eng.set_head_arith(arith)
+    eng.set_dd_atomics(True)
+    assert eng.head_arith == arith
     cfg = om.ModelConfig(feature_size=F, latent_size=L, hidden_sizes=H,
                          likelihood="negative binomial")
     params = {k: v.detach().cpu().double()
@@ -280,3 +286,61 @@ def test_u16_training_step_against_the_oracle_at_benchmark_size(
             assert g.abs().max().item() == 0.0, name
             continue
         close_maxnorm(g, grads[name], rtol=2e-4, what="grad " + name)
+
+
+def test_six_term_heads_are_fp32_class(cuda_device):
+    """``SCVAE_HEADS_BF16X6`` (nine terms without a2 b3, a3 b2, a3 b3) against
+    the fp64 products at 4096 rows: its error next to the exact split's and
+    next to the fp32 matrix cores' on the same operands -- the option may not
+    be worse than twice the plain fp32 kernel (both round every accumulation
+    to fp32; the six-term product adds <= 2^-23 of |a||b| per term)."""
+    from scvae_amd import _lib
+    lib = _lib.load()
+    rows, F, Hd = 4096, 1500, 100
+    kind, heads = _lib.LIKELIHOOD_KINDS["negative binomial"]
+    P = len(heads)
+    g = torch.Generator(device=cuda_device).manual_seed(11)
+    d = torch.relu(torch.randn(rows, Hd, generator=g, device=cuda_device))
+    W = [torch.randn(Hd, F, generator=g, device=cuda_device) * 0.1 for _ in range(P)]
+    b = [torch.randn(F, generator=g, device=cuda_device) * 0.1 for _ in range(P)]
+    t = torch.poisson(torch.full((rows, F), 3.0, device=cuda_device), generator=g)
+    t = t * (torch.rand(rows, F, device=cuda_device, generator=g) < 0.1)
+    gw = -torch.rand(rows, generator=g, device=cuda_device) / rows
+    rc = torch.lgamma(t + 1).sum(dim=1)
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[x.data_ptr() for x in ts])
+    ws = torch.empty(lib.scvae_decoder_fused_workspace_bytes(rows, Hd, F),
+                     dtype=torch.uint8, device=cuda_device)
+    # fp64: pre-activations, likelihood and gradients through torch autograd
+    d64 = d.double().requires_grad_(True)
+    W64 = [w.double().requires_grad_(True) for w in W]
+    b64 = [v.double().requires_grad_(True) for v in b]
+    a0 = d64 @ W64[0] + b64[0]
+    a1 = d64 @ W64[1] + b64[1]
+    eps_ = torch.finfo(torch.float32).tiny
+    p = torch.sigmoid(a0).clamp(eps_, 1 - eps_)
+    r = torch.exp(a1.clamp(-10, 10))
+    t64 = t.double()
+    lp = (torch.lgamma(r + t64) - torch.lgamma(r) - torch.lgamma(t64 + 1)
+          + t64 * torch.log(p) + r * torch.log1p(-p))
+    ll64 = lp.sum(dim=1)
+    (ll64 * gw.double()).sum().backward()
+    ref = {"ll": ll64.detach(), "dd": d64.grad, "dW0": W64[0].grad,
+           "dW1": W64[1].grad, "db1": b64[1].grad}
+    errs = {}
+    for arith in ("fp32", "bf16x9", "bf16x6"):
+        dW = [torch.zeros_like(w) for w in W]
+        db = [torch.zeros_like(v) for v in b]
+        ll = torch.zeros(rows, device=cuda_device)
+        dd = torch.zeros(rows, Hd, device=cuda_device)
+        _lib.check(lib.scvae_decoder_fused(
+            kind, 1 | _lib.HEAD_ARITH_FLAGS[arith], _p(d), rows, Hd, arr(W), arr(b),
+            arr(dW), arr(db), F, _p(t), rows, _p(gw), _p(rc), _p(ll), _p(dd), _p(ws),
+            _stream()), "scvae_decoder_fused")
+        torch.cuda.synchronize()
+        got = {"ll": ll, "dd": dd, "dW0": dW[0], "dW1": dW[1], "db1": db[1]}
+        errs[arith] = {k: ((got[k].double() - ref[k]).abs().max()
+                           / ref[k].abs().max()).item() for k in ref}
+    for k in ref:
+        assert errs["bf16x6"][k] <= max(2.0 * errs["fp32"][k], 2e-7), (k, errs)
+        assert errs["bf16x9"][k] <= max(2.0 * errs["fp32"][k], 2e-7), (k, errs)
+    print("max-norm relative errors against fp64:", errs)

@@ -19,11 +19,13 @@ pytestmark = pytest.mark.gpu
 ARITH = {"flag": 0}
 
 
-@pytest.fixture(params=["fp32", "bf16x9"], autouse=True)
+@pytest.fixture(params=["fp32", "bf16x9", "bf16x6"], autouse=True)
 def head_arith(request):
-    """Every case on both training kernels: the fp32 matrix cores and the exact
-    nine-term bf16 split (decoder_fused3.hip, where it applies) -- the
-    arithmetic travels with each call (``train | SCVAE_HEADS_*``)."""
+    """Every case on the three arithmetics of the training kernels: the fp32
+    matrix cores, the exact nine-term bf16 split (decoder_fused3.hip, where it
+    applies) and its six-term form (the producer / consumer kernel beyond 128
+    rows; everything else then runs as bf16x9) -- the arithmetic travels with
+    each call (``train | SCVAE_HEADS_*``), the tolerances are the same."""
     from scvae_amd import _lib
     ARITH["flag"] = _lib.HEAD_ARITH_FLAGS[request.param]
     yield request.param
@@ -115,7 +117,7 @@ def test_wide_and_odd_hidden_sizes(cuda_device, H, head_arith):
     stay on the unfused kernels (the plan's business), so: training only."""
     from scvae_amd import _lib
     lib = _lib.load()
-    if head_arith != "bf16x9":
+    if head_arith == "fp32":
         assert H > 126 or H % 2 == 0 or lib.scvae_decoder_train_kernel(1, H, 0) == 0
         pytest.skip("the fp32 kernels stop at even H <= 126")
     assert lib.scvae_decoder_train_kernel(1, H, 1) == 3
@@ -217,7 +219,7 @@ def test_dd_through_xcd_local_atomics(cuda_device, name, head_arith):
          extra_flags=_lib.HEADS_DD_ATOMICS)
     _run(cuda_device, name, 70, 35, 130, 20, 0.3,
          extra_flags=_lib.HEADS_DD_ATOMICS)
-    if head_arith != "bf16x9":
+    if head_arith == "fp32":
         return          # (the fp32 kernels have no such store: the flag is ignored)
     lib = _lib.load()
     kind, heads = _lib.LIKELIHOOD_KINDS[name]

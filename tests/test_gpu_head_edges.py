@@ -224,7 +224,7 @@ NAMES = list(lk.ELEMENTWISE_LIKELIHOODS)
 
 
 @pytest.mark.parametrize("u16", [False, True], ids=["f32", "u16"])
-@pytest.mark.parametrize("arith", ["fp32", "bf16x9"])
+@pytest.mark.parametrize("arith", ["fp32", "bf16x9", "bf16x6"])
 @pytest.mark.parametrize("name", NAMES)
 def test_clip_and_saturation_regime(cuda_device, name, arith, u16):
     # 200 rows: four 64-row / seven 32-row tiles; 196 genes: every (pre, target)

@@ -77,3 +77,21 @@ for train in (3, 1):
 print("{} rows {}: kernel {:.3f} ms, kernel + reduces {:.3f} ms; checksum ll {:.6e} dd {:.6e} dW {:.6e}".format(
     name, rows, res[0], res[1], ll.double().sum().item(), dd.double().abs().sum().item(),
     dW[0].double().abs().sum().item()))
+if os.environ.get("TIME_HEAD_SAVE"):
+    launch(1)
+    torch.cuda.synchronize()
+    torch.save({"ll": ll.cpu(), "dd": dd.cpu(), "dW": [x.cpu() for x in dW], "db": [x.cpu() for x in db]},
+               os.environ["TIME_HEAD_SAVE"])
+if os.environ.get("TIME_HEAD_STRESS"):
+    # run-to-run repeatability of the per-row log-likelihood (deterministic by construction)
+    n = int(os.environ["TIME_HEAD_STRESS"])
+    launch(1)
+    torch.cuda.synchronize()
+    ref_ll, ref_db = ll.clone(), [x.clone() for x in db]
+    bad = 0
+    for _ in range(n):
+        launch(1)
+        torch.cuda.synchronize()
+        if not torch.equal(ll, ref_ll) or any(not torch.equal(x, y) for x, y in zip(db, ref_db)):
+            bad += 1
+    print("stress: {} of {} launches differ from the first (ll / db bitwise)".format(bad, n))
