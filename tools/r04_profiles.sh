@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# Round-4 profiles of the final build, on the GPU box (writes gpurun_out/r04_*; the summaries are
+# Round-4 profiles of the final build (six-term head arithmetic, dense-queue corrections), on the GPU box (writes gpurun_out/r04_*; the summaries are
 # copied to profiles/ by hand afterwards):
 #   kernel stats (rocprofv3 --kernel-trace --stats) of the benchmark step for the headline NB VAE,
 #   the Poisson VAE, cfg3 (ZINB VAE, latent 100), cfg4 (NB GMVAE K = 20), cfg5 (ZINB GMVAE K = 20,
