@@ -272,3 +272,16 @@ def test_edge_shapes_on_the_other_schedule(cuda_device, schedule):
         env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
         capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+
+
+@pytest.mark.parametrize("density", [0.3, 0.7, 1.0])
+@pytest.mark.parametrize("name", ["negative binomial", "zero-inflated negative binomial"])
+def test_dense_counts_through_the_queue(cuda_device, name, density):
+    """The producer / consumer kernel queues the non-zeros of a wave densely and
+    corrects them in passes of 64 (``lgamma(r + t) - lgamma(r)`` and the digamma
+    term of dlog r, du:230-262): 5 % non-zeros fill a fraction of one pass --
+    here 77, 180 and all 256 of a wave's elements per tile are non-zero (two to
+    four passes, ragged last pass), row-replicated targets included; without
+    the per-row constant the queue also carries ``lgamma(1 + t)``."""
+    _run(cuda_device, name, 300, 300, 200, 100, density, seed=5)
+    _run(cuda_device, name, 320, 160, 130, 36, density, seed=6, row_const=False)
