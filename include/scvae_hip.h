@@ -175,12 +175,17 @@ int scvae_plan_probe_heads_ms(scvae_plan* plan, float* out, int32_t n);
 #define SCVAE_PROBE_STAGES 5
 int scvae_plan_probe_stages(scvae_plan* plan, int32_t n);
 int scvae_plan_probe_stages_us(scvae_plan* plan, float* out, int32_t n);
-/* Large VAE training minibatches (more than 128 rows, batch norm, no dropout, no data-parallel
- * hook): 1 (default) = every hidden layer and the posterior heads as ONE launch per layer and
- * direction -- a workgroup owns a 64-row tile, merges the batch-norm chunk statistics of the layer
- * below, normalises its rows of it, multiplies (mu:38-76), and leaves the chunk statistics of its
- * own output (tilechain.hip); 0 = the chain of GEMM / statistics / merge / normalise launches. */
+/* Large VAE training minibatches (more than 128 rows, batch norm, no dropout): 1 (default) =
+ * every hidden layer and the posterior heads as ONE launch per layer and direction -- a
+ * workgroup owns a 64-row tile, merges the batch-norm chunk statistics of the layer below,
+ * normalises its rows of it, multiplies (mu:38-76), and leaves the chunk statistics of its own
+ * output (tilechain.hip); 0 = the chain of GEMM / statistics / merge / normalise launches.
+ * With a data-parallel hook (scvae_plan_set_sync) the rank's chunk statistics are merged by a
+ * small kernel, handed to the hook (kinds 1 and 0, as from the launch chain) and taken as given by
+ * the consuming tile kernel.  scvae_plan_uses_tile_chain: whether a training step of `cells`
+ * cells x `samples` samples of this plan, as configured now, takes that path (VAE plans). */
 int scvae_plan_set_tile_chain(scvae_plan* plan, int32_t enabled);
+int32_t scvae_plan_uses_tile_chain(const scvae_plan* plan, int64_t cells, int32_t samples);
 /* Small VAE minibatches (cells x samples <= 128, widths <= 128, batch norm, analytic KL, no
  * dropout / decoder extras, single process): the hidden layers, posterior heads and latent stage
  * of a step run as TWO cooperative launches (forwards, backwards: sixteen workgroups with a grid

@@ -155,6 +155,7 @@ SIGNATURES = {
     "scvae_plan_set_bn_one_launch": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_set_mid_chain": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_set_tile_chain": (c_int32, [c_void_p, c_int32]),
+    "scvae_plan_uses_tile_chain": (c_int32, [c_void_p, c_int64, c_int32]),
     "scvae_plan_probe_heads": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_probe_heads_ms": (c_int32, [c_void_p, c_void_p, c_int32]),
     "scvae_count_gemm": (c_int32, [

@@ -242,6 +242,13 @@ int tile_forward(hipStream_t s, const TileFwdArgs& q);
 int tile_backward(hipStream_t s, const TileBwdArgs& q);
 int tile_backward_stats(hipStream_t s, const float* dh, const TileBN& bn, int rows, int N);
 int tile_slab_reduce(hipStream_t s, const SlabJobs& q);
+// data-parallel steps: a layer's chunk statistics (forward) / chunk sums (backward) of this rank
+// merged into the layer's buffers, for the caller's hook to merge over the ranks; the tile kernels
+// take them as given where TileBN::part == nullptr
+int tile_stats_merge(hipStream_t s, const float* part, int chunks, int chunk, int rows, int N,
+                     float* mean, float* var);
+int tile_sums_merge(hipStream_t s, const float* part, int chunks, int N, const TileBN& bn,
+                    float bessel);
 
 struct HeadDropout;   // (below, with dropout_apply)
 // per-row inputs / second output of the constrained Poisson passes of decoder_head3_kernel

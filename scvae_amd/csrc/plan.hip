@@ -538,7 +538,7 @@ HeadParams head_params(scvae_plan* p) {
 static bool tile_chain_ok(const scvae_plan* p, int B, int S, bool training) {
   const scvae_model_config& c = p->cfg;
   static const bool env_on = [] { const char* e = getenv("SCVAE_TILE_CHAIN"); return !(e && e[0] == '0'); }();
-  if (!env_on || !p->use_tile_chain || p->sync || !training) return false;
+  if (!env_on || !p->use_tile_chain || !training) return false;
   if (!c.batch_norm || p->enc.empty() || p->dec.empty()) return false;
   if (c.latent_mode != 0 || c.decoder_extra != 0 || c.latent_size > 128) return false;
   if ((int64_t)B * S <= 128) return false;      // (the mid-chain kernels' regime)
@@ -559,6 +559,46 @@ static TileBN tile_bn(scvae_plan* p, Dense& d, const float* part, int chunks, in
   t.dbeta = p->grads ? p->grads + d.beta : nullptr;
   t.mov_mean = p->moving + d.mov_mean; t.mov_var = p->moving + d.mov_var;
   return t;
+}
+
+// Data-parallel steps (scvae_plan_set_sync): the statistics of layer d over the GLOBAL minibatch
+// before the tile kernel that consumes them -- this rank's chunks merged into d.stats, the hook
+// (kind 1: all-gather + Chan merge over the ranks), and a TileBN that hands them over as given
+// (part == nullptr).  Without a hook: the chunks themselves, merged by the consuming kernel.
+static int tile_bn_forward(scvae_plan* p, hipStream_t s, Dense& d, const float* part, int chunks,
+                           int chunk, int rows, TileBN* out) {
+  if (!p->sync) {
+    *out = tile_bn(p, d, part, chunks, chunk, nullptr);
+    return 0;
+  }
+  const int N = d.n_out;
+  int rc = tile_stats_merge(s, part, chunks, chunk, rows, N, d.stats, d.stats + N);
+  if (rc) return rc;
+  if (p->sync(p->sync_user, d.stats, 2 * (int64_t)N, 1, rows)) {
+    set_error("batch-norm sync hook failed");
+    return -2;
+  }
+  *out = tile_bn(p, d, nullptr, 0, 0, nullptr);
+  return 0;
+}
+// ... and the sums of the backward pass (kind 0: all-reduce); dbeta (this rank's rows) and the
+// moving averages are written by the merge
+static int tile_bn_backward(scvae_plan* p, hipStream_t s, Dense& d, const float* part, int chunks,
+                            float bessel, TileBN* out) {
+  if (!p->sync) {
+    *out = tile_bn(p, d, part, chunks, 64, nullptr);
+    return 0;
+  }
+  const int N = d.n_out;
+  TileBN t = tile_bn(p, d, nullptr, 0, 0, nullptr);
+  int rc = tile_sums_merge(s, part, chunks, N, t, bessel);
+  if (rc) return rc;
+  if (p->sync(p->sync_user, t.s1, 2 * (int64_t)N, 0, 0)) {
+    set_error("batch-norm backward sync hook failed");
+    return -2;
+  }
+  *out = t;
+  return 0;
 }
 
 // ---- small minibatches: the chain between the input layer and the likelihood heads in one
@@ -780,7 +820,8 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       Dense& d = p->enc[i];
       TileFwdArgs q;
       q.rows = B; q.K = d.n_in;
-      q.bn = tile_bn(p, p->enc[i - 1], p->tc_part[cur], chunks, chunk, nullptr);
+      if ((rc = tile_bn_forward(p, s, p->enc[i - 1], p->tc_part[cur], chunks, chunk, B, &q.bn)))
+        return rc;
       q.n_out = 1;
       q.o[0].W = p->params + d.w; q.o[0].b = p->params + d.b; q.o[0].out = d.a;
       q.o[0].part = p->tc_part[cur ^ 1]; q.o[0].N = d.n_out;
@@ -791,7 +832,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       Dense& last = p->enc.back();
       TileFwdArgs q;
       q.rows = B; q.K = last.n_out;
-      q.bn = tile_bn(p, last, p->tc_part[cur], chunks, chunk, nullptr);
+      if ((rc = tile_bn_forward(p, s, last, p->tc_part[cur], chunks, chunk, B, &q.bn))) return rc;
       q.n_out = 2;
       q.o[0].W = p->params + p->mu.w; q.o[0].b = p->params + p->mu.b; q.o[0].out = p->mu_pre;
       q.o[0].N = L;
@@ -858,7 +899,9 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       if (i == 0) { q.x = dec_in; q.ldx = L; q.K = L; }
       else {
         q.K = p->dec[i - 1].n_out;
-        q.bn = tile_bn(p, p->dec[i - 1], p->tc_part[cur], (R + 63) / 64, 64, nullptr);
+        if ((rc = tile_bn_forward(p, s, p->dec[i - 1], p->tc_part[cur], (R + 63) / 64, 64, R,
+                                  &q.bn)))
+          return rc;
       }
       if (i < p->dec.size()) {
         Dense& d = p->dec[i];
@@ -1067,7 +1110,10 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       float* slab = p->tc_slab[pending.n_jobs % TC_MAX_JOBS];
       q.up[0].g = dh_in; q.up[0].W = p->params + d.w; q.up[0].N = d.n_out;
       q.up[0].dW_slab = slab; q.up[0].dA_out = dA_out;
-      q.bn = tile_bn(p, d, p->tc_spart[sp], G, 64, nullptr);
+      {
+        const int r = tile_bn_backward(p, s, d, p->tc_spart[sp], G, q.bessel, &q.bn);
+        if (r) return r;
+      }
       q.in = in; q.K = in ? d.n_in : 0; q.d_in = d_in;
       if (below) q.below = tile_bn(p, *below, nullptr, 0, 0, p->tc_spart[sp ^ 1]);
       int r = tile_backward(s, q);
@@ -1125,6 +1171,15 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     Dense& d0 = p->enc[0];
     if ((rc = layer_backward(d0, nullptr, nullptr, B, GB, dh, nullptr, p->dbuf[2]))) return rc;
     if ((rc = flush())) return rc;
+    if (p->sync && p->early_reduce_layer == &d0) {
+      // (data parallel: everything between ENCODER/1 and the likelihood heads is final -- its
+      //  all-reduce runs under x^T dA, as in dense_backward)
+      if (p->sync(p->sync_user, p->grads + p->early_reduce_start,
+                  (int64_t)(p->heads_start - p->early_reduce_start), 2, 0)) {
+        set_error("gradient all-reduce hook failed");
+        return -2;
+      }
+    }
     if ((rc = plan_side_fork(p, s, 2))) return rc;
     return plan_gemm(p, s, true, false, p->step_x, p->dbuf[2], nullptr, p->grads + d0.w, d0.n_in,
                      d0.n_out, B, F, d0.n_out, d0.n_out, ACT_NONE, false);
@@ -1383,6 +1438,10 @@ int scvae_plan_set_tile_chain(scvae_plan* p, int32_t enabled) {
   SCVAE_ARG(p);
   p->use_tile_chain = enabled ? 1 : 0;
   return 0;
+}
+int32_t scvae_plan_uses_tile_chain(const scvae_plan* p, int64_t cells, int32_t samples) {
+  if (!p || cells <= 0 || samples <= 0 || p->cfg.model_type != SCVAE_MODEL_VAE) return 0;
+  return tile_chain_ok(p, (int)cells, samples, true) ? 1 : 0;
 }
 int scvae_plan_set_mid_chain(scvae_plan* p, int32_t enabled) {
   SCVAE_ARG(p);

@@ -19,8 +19,12 @@
 // One launch per layer and direction (+ one fixed-order reduce of the dW slabs), kernel
 // boundaries where the statistics need all rows, no atomics, no grid barrier.  The posterior heads
 // (two weight matrices on the same input) ride in the same kernels.  Used by the VAE plan for
-// training minibatches of more than 128 rows without dropout or a data-parallel hook; everything
-// else keeps the launch chain (plan.hip) or the two mid-chain kernels (midchain.hip).
+// training minibatches of more than 128 rows without dropout; everything else keeps the launch
+// chain (plan.hip) or the two mid-chain kernels (midchain.hip).  Under a data-parallel hook
+// (scvae_plan_set_sync) the statistics of a layer are those of the global minibatch: the rank's
+// chunks are merged by a one-workgroup kernel, the hook merges the ranks, and the consuming tile
+// kernel takes the result as given (TileBN::part == nullptr) -- two small launches and a
+// collective per layer boundary instead of the launch chain's four and a collective.
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -145,7 +149,15 @@ __global__ __launch_bounds__(TC_THREADS) void tile_fwd_kernel(TileFwdArgs q) {
   pw.load(q.n_out > 0 ? q.o[0].W : q.x, n_w0, tid, q.n_out > 0 ? q.o[0].N : 1);
   const float* src_a = q.bn.a ? q.bn.a + (size_t)r0 * K : q.x + (size_t)r0 * q.ldx;
   pa.load(src_a, nr * K, tid, K);
-  if (q.bn.a) {
+  if (q.bn.a && !q.bn.part) {
+    // the statistics are given (merged over this rank's chunks by tile_stats_merge and over the
+    // ranks by the caller's hook: data-parallel steps, scvae_plan_set_sync)
+    if (tid < K) {
+      st[tid] = q.bn.mean[tid];
+      st[TC_MAXN + tid] = rsqrtf(q.bn.var[tid] + BN_EPSILON);
+      st[2 * TC_MAXN + tid] = q.bn.beta[tid];
+    }
+  } else if (q.bn.a) {
     // (the chunk statistics pass through LDS, 64 chunks at a time: a thread walking its column's
     //  chunks in global memory pays a round trip per chunk.  Two passes -- mean, then M2 about it
     //  -- in chunk order: fixed, so every workgroup of the launch arrives at the same bits)
@@ -335,7 +347,18 @@ __global__ __launch_bounds__(TC_THREADS) void tile_bwd_kernel(TileBwdArgs q) {
   // (groups: see TileBN -- this tile's group, its first chunk, the chunks merged here)
   const int gt_bn = q.bn.group_tiles;
   const int grp = gt_bn ? g / gt_bn : (q.below.group_tiles ? g / q.below.group_tiles : 0);
-  if (bn) {
+  if (bn && !q.bn.part) {
+    // the sums are given (tile_sums_merge + the caller's all-reduce, as in the forward kernel;
+    // dbeta and the moving averages were written there)
+    const int N = q.up[0].N;
+    if (tid < N) {
+      st[tid] = q.bn.mean[tid];
+      st[TC_MAXN + tid] = rsqrtf(q.bn.var[tid] + BN_EPSILON);
+      st[2 * TC_MAXN + tid] = q.bn.s1[tid];
+      st[3 * TC_MAXN + tid] = q.bn.s2[tid];
+    }
+    lds_barrier();
+  } else if (bn) {
     const int N = q.up[0].N;
     const int zfirst = gt_bn ? grp * gt_bn : 0;
     const int nchunks = gt_bn ? gt_bn : q.bn.chunks;
@@ -633,6 +656,64 @@ int tile_backward_stats(hipStream_t s, const float* dh, const TileBN& bn, int ro
   hipLaunchKernelGGL(tile_bwd_stats_kernel, dim3((rows + TC_ROWS - 1) / TC_ROWS), dim3(256),
                      0, s, dh, bn, rows, N);
   SCVAE_LAUNCH_CHECK("tile_bwd_stats_kernel");
+  return 0;
+}
+
+// ---- data-parallel steps (a sync hook between a layer's statistics and their use): this rank's
+//      chunk statistics / chunk sums merged by ONE workgroup into the layer's buffers, which the
+//      caller's hook then merges over the ranks; the consuming tile kernel takes them as given
+//      (TileBN::part == nullptr).  One thread per column, the chunks in order. ----
+__global__ __launch_bounds__(TC_MAXN) void tile_stats_merge_kernel(const float* __restrict__ part,
+                                                                   int chunks, int chunk, int rows,
+                                                                   int N, float* __restrict__ mean,
+                                                                   float* __restrict__ var) {
+  const int c = threadIdx.x;
+  if (c >= N) return;
+  const float n_last = (float)(rows - (chunks - 1) * chunk);
+  float sum = 0.f;
+  for (int z = 0; z < chunks; ++z)
+    sum = bn_merge_mean(sum, z == chunks - 1 ? n_last : (float)chunk, part[(size_t)z * 2 * N + c]);
+  const float mu = sum / (float)rows;
+  float m2 = 0.f;
+  for (int z = 0; z < chunks; ++z)
+    m2 = bn_merge_m2(m2, z == chunks - 1 ? n_last : (float)chunk, part[(size_t)z * 2 * N + c],
+                     part[((size_t)z * 2 + 1) * N + c], mu);
+  mean[c] = mu;
+  var[c] = m2 / (float)rows;
+}
+__global__ __launch_bounds__(TC_MAXN) void tile_sums_merge_kernel(const float* __restrict__ part,
+                                                                  int chunks, int N, TileBN bn,
+                                                                  float bessel) {
+  const int c = threadIdx.x;
+  if (c >= N) return;
+  float t1 = 0.f, t2 = 0.f;
+  for (int z = 0; z < chunks; ++z) {
+    t1 += part[(size_t)z * 2 * N + c];
+    t2 += part[((size_t)z * 2 + 1) * N + c];
+  }
+  bn.s1[c] = t1;
+  bn.s2[c] = t2;
+  // dbeta: this rank's rows (the gradient all-reduce sums the ranks); the moving averages from the
+  // batch statistics of the forward pass, which are those of the global minibatch
+  bn.dbeta[c] = t1;
+  bn.mov_mean[c] = bn_moving_update(bn.mov_mean[c], bn.mean[c]);
+  bn.mov_var[c] = bn_moving_update(bn.mov_var[c], bn.var[c] * bessel);
+}
+int tile_stats_merge(hipStream_t s, const float* part, int chunks, int chunk, int rows, int N,
+                     float* mean, float* var) {
+  SCVAE_ARG(part && chunks > 0 && chunk > 0 && N > 0 && N <= TC_MAXN && mean && var);
+  hipLaunchKernelGGL(tile_stats_merge_kernel, dim3(1), dim3(TC_MAXN), 0, s, part, chunks, chunk,
+                     rows, N, mean, var);
+  SCVAE_LAUNCH_CHECK("tile_stats_merge_kernel");
+  return 0;
+}
+int tile_sums_merge(hipStream_t s, const float* part, int chunks, int N, const TileBN& bn,
+                    float bessel) {
+  SCVAE_ARG(part && chunks > 0 && N > 0 && N <= TC_MAXN && bn.s1 && bn.s2 && bn.dbeta &&
+            bn.mov_mean && bn.mov_var && bn.mean && bn.var);
+  hipLaunchKernelGGL(tile_sums_merge_kernel, dim3(1), dim3(TC_MAXN), 0, s, part, chunks, N, bn,
+                     bessel);
+  SCVAE_LAUNCH_CHECK("tile_sums_merge_kernel");
   return 0;
 }
 

@@ -332,6 +332,12 @@ class Engine:
         _lib.check(self.lib.scvae_plan_set_mid_chain(
             self.handle, 1 if enabled else 0), "scvae_plan_set_mid_chain")
 
+    def uses_tile_chain(self, cells, samples=1):
+        """Whether a training step of ``cells`` x ``samples`` rows runs its
+        hidden layers on the tile chain (one launch per layer and direction)."""
+        return bool(self.lib.scvae_plan_uses_tile_chain(
+            self.handle, int(cells), int(samples)))
+
     def set_tile_chain(self, enabled):
         """Large VAE training minibatches: one launch per hidden layer and
         direction (default) or the chain of GEMM / batch-norm launches."""
