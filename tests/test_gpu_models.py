@@ -12,6 +12,18 @@ from oracle import models as om
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _seeded_minibatch_order():
+    """The training loop shuffles with the global NumPy generator, as the
+    reference does (va:981-983): unseeded, a learning curve -- and an assertion
+    about its trend -- differs from run to run (one full-suite run in three
+    saw epoch 3 below epoch 1 at learning rate 1e-2).  Fixed here."""
+    state = np.random.get_state()
+    np.random.seed(20260929)
+    yield
+    np.random.set_state(state)
+
+
 def _data(n=96, F=60, seed=3, labels=True):
     from scvae_amd.data import DataSet
     rng = np.random.default_rng(seed)
