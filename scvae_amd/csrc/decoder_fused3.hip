@@ -1196,7 +1196,9 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
       //      iteration were not repeatable from run to run -- 26-40 of 40 launches differed,
       //      in sporadic elements whose log r came out of GEMM1 wrong -- although no other
       //      wave touches that corner between the two barriers; with the queue in LDS of
-      //      its own: 0 of 40.  Not understood; tools/time_head.py TIME_HEAD_STRESS.) ----
+      //      its own: 0 of 40.  Not strict aliasing (-fno-strict-aliasing: the same), rarer
+      //      with dd through slabs (0-2 of 30), and gone with the queue in the buffer's LAST
+      //      plane instead of its first.  Not understood; tools/time_head.py TIME_HEAD_STRESS.) ----
       if ((Traits::HAS_R || inline_lgamma) && !(dbg & 4)) {
         int pos[NE];
         int total = 0;
