@@ -665,16 +665,17 @@ int decoder_fused_variant(int P, int H) {
 // three smallest of the nine terms (a2 b3, a3 b2, a3 b3: <= 2^-23 of a product) left out in the
 // producer / consumer training kernel -- six matrix instructions per product instead of nine;
 // every other launch under 2 runs as under 1.  A plan carries its own
-// (scvae_plan_set_head_arith); the default of a new plan and of the stand-alone entry is 2 (with
-// the terms cut by rounding its error is that of 1 to the digits tests/test_gpu_as_benched.py
-// prints, a third of the matrix instructions gone), or what SCVAE_HEAD_ARITH=fp32 / bf16x9 says
-// -- read once, never written again: no mutable process state.
+// (scvae_plan_set_head_arith); the default of a new plan and of the stand-alone entry is 1, the
+// exact form (every bf16 product exact, fp32 accumulation: an fp32 sum of exact products), or
+// what SCVAE_HEAD_ARITH=fp32 / bf16x6 says -- read once, never written again: no mutable process
+// state.  2 is an opt-in (its error is that of 1 to the digits tests/test_gpu_as_benched.py
+// prints, a third of the matrix instructions gone); bench.py reports it beside the headline.
 int default_head_arith() {
   static const int v = [] {
     const char* e = getenv("SCVAE_HEAD_ARITH");
     if (e && (e[0] == 'f' || e[0] == '0')) return 0;
-    if (e && (strstr(e, "x9") || e[0] == '1')) return 1;
-    return 2;   // default: bf16x6 (bf16x9 wherever a kernel has no six-term form)
+    if (e && (strstr(e, "x6") || e[0] == '2')) return 2;
+    return 1;   // default: bf16x9, exact
   }();
   return v;
 }
