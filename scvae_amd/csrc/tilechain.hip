@@ -131,6 +131,13 @@ struct LinePre {
     }
   }
 };
+#ifdef SCVAE_TC_PROBE
+__device__ unsigned long long g_tc_probe[2][16];
+#define TCP(i) do { if (tid == 0 && blockIdx.x == 1) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+  atomicAdd(&g_tc_probe[q.bn.a && q.bn.part ? 1 : 0][i], t_ - tlast); tlast = t_; } } while (0)
+#else
+#define TCP(i) do {} while (0)
+#endif
 __global__ __launch_bounds__(TC_THREADS) void tile_fwd_kernel(TileFwdArgs q) {
   extern __shared__ __attribute__((aligned(16))) float tsm[];
   float* As = tsm;                               // [64][TC_LD]
@@ -141,8 +148,22 @@ __global__ __launch_bounds__(TC_THREADS) void tile_fwd_kernel(TileFwdArgs q) {
   const int g = blockIdx.x, r0 = g * TC_ROWS;
   const int nr = min(TC_ROWS, q.rows - r0);
   const int K = q.K, K2 = (K + 1) & ~1;
+#ifdef SCVAE_TC_PROBE
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+  if (tid == 0 && blockIdx.x == 1) atomicAdd(&g_tc_probe[q.bn.a && q.bn.part ? 1 : 0][15], 1ull);
+#endif
   // ---- every input of the kernel is requested up front: the first weight matrix, the input
   //      tile, the chunk statistics of the layer below ----
+  // (the chunk statistics of the layer below first: they are needed first, and a wave's loads
+  //  return in order -- behind the 48 scalar loads of the two tiles they arrived 3 us later)
+  const bool merge_here = q.bn.a && q.bn.part;
+  LinePre<8> pp_first;
+  if (merge_here) {
+    const int gt0 = q.bn.group_tiles;
+    const int zfirst0 = gt0 ? (g / gt0) * gt0 : 0;
+    const int zn0 = min(64, gt0 ? gt0 : q.bn.chunks);
+    pp_first.load(q.bn.part + (size_t)zfirst0 * 2 * K, zn0 * 2 * K, tid);
+  }
   TilePre<128 / TC_RG> pw;              // [K, N] weights (<= 128 x 128)
   TilePre<TC_ROWS / TC_RG> pa;          // [64, K] input tile
   const int n_w0 = q.n_out > 0 ? K * q.o[0].N : 0;
@@ -172,10 +193,12 @@ __global__ __launch_bounds__(TC_THREADS) void tile_fwd_kernel(TileFwdArgs q) {
         const int zn = min(64, chunks - z0);
         if (pass == 0 || chunks > 64) {     // (a single block stays in LDS for the second pass)
           LinePre<8> pp;
-          pp.load(q.bn.part + (size_t)(zfirst + z0) * 2 * K, zn * 2 * K, tid);
+          if (pass == 0 && z0 == 0) pp = pp_first;
+          else pp.load(q.bn.part + (size_t)(zfirst + z0) * 2 * K, zn * 2 * K, tid);
           lds_barrier();
           pp.store_linear(Bs, zn * 2 * K, tid);
           lds_barrier();
+          TCP(pass);          // 0/1: chunk statistics arrived in LDS
         }
         {
           // thread (column c, group zg) takes the chunks z = zg mod TC_RG; the groups' partial
@@ -222,6 +245,7 @@ __global__ __launch_bounds__(TC_THREADS) void tile_fwd_kernel(TileFwdArgs q) {
     }
   }
   lds_barrier();        // (As zeroed, statistics in st, Bs free)
+  TCP(2);               // merge done
   pa.store(As, (K + 31) & ~31, TC_ROWS, tid);
   if (q.bn.a) {
     lds_barrier();
@@ -236,6 +260,7 @@ __global__ __launch_bounds__(TC_THREADS) void tile_fwd_kernel(TileFwdArgs q) {
       }
     }
   }
+  TCP(3);               // input tile landed, normalised, h written
   // ---- products ----
   for (int o = 0; o < q.n_out; ++o) {
     const TileFwdArgs::Out& out = q.o[o];
@@ -244,11 +269,13 @@ __global__ __launch_bounds__(TC_THREADS) void tile_fwd_kernel(TileFwdArgs q) {
     lds_barrier();     // (As written / the previous output tile consumed)
     pw.store(Bs, (N + 31) & ~31, K2, tid);
     lds_barrier();
+    TCP(4);             // weights in LDS
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     tile_mma(As, Bs, K2, N, w, lane, acc);
     lds_barrier();     // (all waves done with Bs)
+    TCP(5);            // product
     tile_store(Bs, N, w, lane, acc);
     lds_barrier();
     // bias, store, chunk statistics of the tile (two-pass, as bn_stats_partial_kernel)
@@ -262,6 +289,7 @@ __global__ __launch_bounds__(TC_THREADS) void tile_fwd_kernel(TileFwdArgs q) {
           out.out[(size_t)(r0 + r) * N + c] = v;
         }
     }
+    TCP(6);            // bias + output stored
     if (out.part) {
       // chunk statistics of the tile, two-pass (mean, then M2 about it); two threads per column
       lds_barrier();
@@ -295,9 +323,15 @@ __global__ __launch_bounds__(TC_THREADS) void tile_fwd_kernel(TileFwdArgs q) {
         out.part[((size_t)g * 2) * N + c] = mu;
         out.part[((size_t)g * 2 + 1) * N + c] = t2;
       }
+      TCP(7);          // tile statistics
     }
   }
 }
+#ifdef SCVAE_TC_PROBE
+extern "C" int scvae_debug_tc_probe(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tc_probe), sizeof(g_tc_probe));
+}
+#endif
 
 static constexpr size_t TC_FWD_LDS =
     (size_t)(TC_ROWS * TC_LD + TC_MAXN * TC_LD + (1 + TC_RG) * TC_MAXN) * 4;
@@ -327,7 +361,15 @@ __global__ __launch_bounds__(TC_THREADS) void tile_bwd_kernel(TileBwdArgs q) {
   const int nr = min(TC_ROWS, q.rows - r0);
   const int K = q.K;
   const bool bn = q.bn.a != nullptr;
-  // ---- every input tile is requested up front ----
+  // ---- every input tile is requested up front (the chunk sums of this layer's batch norm
+  //      first: they are needed first and loads return in order) ----
+  LinePre<8> pp_first;
+  if (bn && q.bn.part) {
+    const int gt0 = q.bn.group_tiles;
+    const int zfirst0 = gt0 ? (g / gt0) * gt0 : 0;
+    const int zn0 = min(64, gt0 ? gt0 : q.bn.chunks);
+    pp_first.load(q.bn.part + (size_t)zfirst0 * 2 * q.up[0].N, zn0 * 2 * q.up[0].N, tid);
+  }
   TilePre<TC_ROWS / TC_RG> pg[2], ph, pa, pin, pw0;
 #pragma unroll
   for (int u = 0; u < 2; ++u)
@@ -367,7 +409,8 @@ __global__ __launch_bounds__(TC_THREADS) void tile_bwd_kernel(TileBwdArgs q) {
       const int zn = min(64, nchunks - z0);
       {
         LinePre<8> pp;
-        pp.load(q.bn.part + (size_t)(zfirst + z0) * 2 * N, zn * 2 * N, tid);
+        if (z0 == 0) pp = pp_first;
+        else pp.load(q.bn.part + (size_t)(zfirst + z0) * 2 * N, zn * 2 * N, tid);
         lds_barrier();
         pp.store_linear(Ds, zn * 2 * N, tid);
         lds_barrier();
