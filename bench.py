@@ -64,8 +64,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dd-slabs", action="store_true",
                     help="accumulate the decoder gradient dd through per-strip slabs and a "
-                         "fixed-order reduce (bit-repeatable; the library's default) instead "
-                         "of XCD-local fp32 atomics")
+                         "fixed-order reduce (bit-repeatable; `scvae train --deterministic`) "
+                         "instead of XCD-local fp32 atomics, the library's default")
     ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--head-arith", default=None, choices=["fp32", "bf16x9", "bf16x6"],
                     help="arithmetic of the fused head kernels (default: the library's, "
@@ -210,7 +210,8 @@ def cpu_baseline(matrix, batch):
 # ----------------------------------------------------------------------------
 # roofline of the dominant kernel
 # ----------------------------------------------------------------------------
-DD_ATOMICS = True      # (main() clears it for --dd-slabs)
+DD_ATOMICS = True      # the library's default (scvae_default_dd_atomics: what `scvae train`
+                       # runs); main() clears it for --dd-slabs and reads the default back
 
 
 def _measured_traffic(rows, F, H, kernel, targets="f32"):
@@ -409,9 +410,12 @@ class Workload:
                              model_type="GMVAE" if self.gm else "VAE",
                              n_clusters=self.K, device=device, seed=0)
         self.engine.reserve(batch, 1)
-        # dd = sum over the gene strips: XCD-local fp32 atomics (a plan option; run-to-run the
-        # sums differ in their last bits) unless --dd-slabs asks for the bit-repeatable path
-        self.engine.set_dd_atomics(DD_ATOMICS)
+        # dd = sum over the gene strips: the plan's default (XCD-local fp32 atomics, what
+        # `scvae train` runs; run-to-run the sums differ in their last bits) unless --dd-slabs
+        # asks for the bit-repeatable path (`scvae train --deterministic`)
+        if not DD_ATOMICS:
+            self.engine.set_dd_atomics(False)
+        assert self.engine.dd_atomics == DD_ATOMICS
         if head_arith is not None:
             self.engine.set_head_arith(head_arith)
         if os.environ.get("SCVAE_BENCH_COUNT_ALWAYS"):
@@ -630,7 +634,8 @@ def other_workloads(matrix, device, barrier):
 def main():
     global DD_ATOMICS
     args = parse_args()
-    DD_ATOMICS = not args.dd_slabs
+    from scvae_amd import _lib as _l0
+    DD_ATOMICS = bool(_l0.load().scvae_default_dd_atomics()) and not args.dd_slabs
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(respawn_one_rank_per_gpu(args))
 
@@ -740,8 +745,10 @@ def main():
             # readers (integer counts: uint16, exact; the arithmetic stays fp32)
             "minibatch_storage": "u16" if work.u16 else "f32",
             # the decoder gradient dd = sum over the gene strips of G W^T
-            "dd_accumulation": ("xcd-local fp32 atomics (plan option; not bit-repeatable)"
-                                if DD_ATOMICS else "per-strip slabs + fixed-order reduce"),
+            "dd_accumulation": ("xcd-local fp32 atomics (the library default, what `scvae "
+                                "train` runs; not bit-repeatable)"
+                                if DD_ATOMICS else "per-strip slabs + fixed-order reduce "
+                                "(`scvae train --deterministic`)"),
             "data": "synthetic",
             "config": {
                 "workload": describe(args.cells, F, args.likelihood, gm, K, L),

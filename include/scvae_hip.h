@@ -138,16 +138,23 @@ int scvae_plan_set_sync(scvae_plan* plan, scvae_sync_fn fn, void* user);
 int scvae_plan_set_fused(scvae_plan* plan, int32_t enabled);
 /* Arithmetic of this plan's fused head kernels (see scvae_default_head_arith below): 0 fp32
  * matrix cores, 1 the exact nine-term bf16 split, 2 the six-term split (the nine terms without
- * a2 b3, a3 b2, a3 b3, together <= 2^-23 of a product: fp32-class, not exact; only the
+ * a2 b3, a3 b2, a3 b3, together <= 2^-26 of a product on the rounded split: fp32-class, not exact; only the
  * producer / consumer training kernel has it -- H <= 126, more than 128 rows, no head dropout --
  * every other launch runs as under 1).  Affects which kernels the step launches and
  * what scvae_plan_accepts_counts_u16 answers; call it before the first step. */
 int scvae_plan_set_head_arith(scvae_plan* plan, int32_t mode);
 int32_t scvae_plan_head_arith(const scvae_plan* plan);
-/* 1: this plan's training steps accumulate the decoder gradient dd with XCD-local fp32 atomics
- * where the head kernel has that store (SCVAE_HEADS_DD_ATOMICS below); 0 (default): per-strip
- * slabs and a fixed-order reduce, bit-repeatable */
+/* 1 (the default of a new plan, scvae_default_dd_atomics): this plan's training steps accumulate
+ * the decoder gradient dd with XCD-local fp32 atomics where the head kernel has that store
+ * (SCVAE_HEADS_DD_ATOMICS below; the producer / consumer kernel, more than 128 rows) -- the order
+ * of the additions, hence the last bits of dd, differ from run to run, as the reference's
+ * multi-threaded TensorFlow reductions do; 0: per-strip slabs and a fixed-order reduce,
+ * bit-repeatable (+ 0.1 ms per 4096-row step).  SCVAE_DD_ACCUMULATION=slabs in the environment
+ * (read once) makes 0 the default; `scvae train --deterministic` / `train(deterministic=True)`
+ * set it per model. */
 int scvae_plan_set_dd_atomics(scvae_plan* plan, int32_t enabled);
+int32_t scvae_plan_dd_atomics(const scvae_plan* plan);
+int32_t scvae_default_dd_atomics(void);
 /* The exact bf16-split kernels for products with a count matrix: 1 (default) where they pay
  * (minibatches from a few hundred cells upwards, see plan_gemm), 2 always, 0 never -- those
  * products then take the fp32 MFMA kernels even when scvae_step_args.x_counts is set (A/B

@@ -151,6 +151,8 @@ SIGNATURES = {
     "scvae_plan_set_head_arith": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_head_arith": (c_int32, [c_void_p]),
     "scvae_plan_set_dd_atomics": (c_int32, [c_void_p, c_int32]),
+    "scvae_plan_dd_atomics": (c_int32, [c_void_p]),
+    "scvae_default_dd_atomics": (c_int32, []),
     "scvae_plan_set_count_gemm": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_set_bn_one_launch": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_set_mid_chain": (c_int32, [c_void_p, c_int32]),

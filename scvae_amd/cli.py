@@ -139,8 +139,9 @@ def train(data_set_file_or_name, data_format=None, data_directory=None,
           number_of_epochs=None, minibatch_size=None, learning_rate=None,
           run_id=None, new_run=False, reset_training=None,
           models_directory=None, caches_directory=None,
-          analyses_directory=None, **keyword_arguments):
-    """Train model on data set (``cli.py:111-264``)."""
+          analyses_directory=None, deterministic=False, **keyword_arguments):
+    """Train model on data set (``cli.py:111-264``).  ``deterministic`` (not in
+    the reference): bit-repeatable accumulation of the decoder gradient."""
     if split_data_set is None:
         split_data_set = defaults["data"]["split_data_set"]
     if splitting_method is None:
@@ -191,7 +192,8 @@ def train(data_set_file_or_name, data_format=None, data_directory=None,
         minibatch_size=minibatch_size, learning_rate=learning_rate,
         intermediate_analyser=None, run_id=run_id, new_run=new_run,
         reset_training=reset_training,
-        temporary_log_directory=model_caches_directory)
+        temporary_log_directory=model_caches_directory,
+        deterministic=deterministic)
     return 0
 
 
@@ -561,6 +563,11 @@ def main(arguments=None):
     parser_train.add_argument(
         "--caches-directory", "-C", metavar="DIRECTORY",
         help="directory for temporary storage")
+    parser_train.add_argument(
+        "--deterministic", action="store_true", default=False,
+        help="(this build) bit-repeatable training steps: sum the decoder "
+             "gradient over the gene strips in a fixed order instead of with "
+             "fp32 atomics (about 5 %% slower at large minibatches)")
 
     parser_evaluate.add_argument(
         "--evaluation-set-kind", metavar="KIND",

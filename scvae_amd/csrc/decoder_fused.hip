@@ -662,7 +662,7 @@ int decoder_fused_variant(int P, int H) {
 // Arithmetic of the three products of the fused head kernels (`arith` of every entry below):
 // 0 = fp32 MFMA (decoder_fused.hip / decoder_fused2.hip), 1 = the exact nine-term bf16 split
 // (decoder_fused3.hip) where that kernel applies (its LDS budget), 2 = the same kernels with the
-// three smallest of the nine terms (a2 b3, a3 b2, a3 b3: <= 2^-23 of a product) left out in the
+// three smallest of the nine terms (a2 b3, a3 b2, a3 b3: <= 2^-26 of a product on the rounded split) left out in the
 // producer / consumer training kernel -- six matrix instructions per product instead of nine;
 // every other launch under 2 runs as under 1.  A plan carries its own
 // (scvae_plan_set_head_arith); the default of a new plan and of the stand-alone entry is 1, the
@@ -676,6 +676,16 @@ int default_head_arith() {
     if (e && (e[0] == 'f' || e[0] == '0')) return 0;
     if (e && (strstr(e, "x6") || e[0] == '2')) return 2;
     return 1;   // default: bf16x9, exact
+  }();
+  return v;
+}
+// Accumulation of the decoder gradient dd over the gene strips in the producer / consumer kernel:
+// 1 (default) XCD-local fp32 atomics, 0 per-strip slabs + fixed-order reduce (bit-repeatable).
+// SCVAE_DD_ACCUMULATION=slabs, read once; a plan carries its own (scvae_plan_set_dd_atomics).
+int default_dd_atomics() {
+  static const int v = [] {
+    const char* e = getenv("SCVAE_DD_ACCUMULATION");
+    return (e && (e[0] == 's' || e[0] == '0')) ? 0 : 1;
   }();
   return v;
 }

@@ -354,6 +354,7 @@ void stage_probe(int stage, int which, hipStream_t s);
 void decoder_fused_set_probe(hipEvent_t before, hipEvent_t after);   // (nullptr, nullptr): off
 hipEvent_t decoder_fused_probe(int which);
 bool decoder_fused_probe_recorded();   // both events of the pair went into a stream
+int default_dd_atomics();   // SCVAE_DD_ACCUMULATION, read once: 1 (default) atomics, 0 slabs
 int default_head_arith();   // SCVAE_HEAD_ARITH, read once: 0 fp32 MFMA, 1 (default) bf16x9, 2 bf16x6
 int decoder_train_kernel(int P, int H, int arith);   // 1 / 2: the fp32 schedules, 3: decoder_fused3.hip
 

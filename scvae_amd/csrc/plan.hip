@@ -584,7 +584,7 @@ static int tile_bn_forward(scvae_plan* p, hipStream_t s, Dense& d, const float* 
 // ... and the sums of the backward pass (kind 0: all-reduce); dbeta (this rank's rows) and the
 // moving averages are written by the merge
 static int tile_bn_backward(scvae_plan* p, hipStream_t s, Dense& d, const float* part, int chunks,
-                            float bessel, TileBN* out) {
+                            int rows, float bessel, TileBN* out) {
   if (!p->sync) {
     *out = tile_bn(p, d, part, chunks, 64, nullptr);
     return 0;
@@ -593,7 +593,7 @@ static int tile_bn_backward(scvae_plan* p, hipStream_t s, Dense& d, const float*
   TileBN t = tile_bn(p, d, nullptr, 0, 0, nullptr);
   int rc = tile_sums_merge(s, part, chunks, N, t, bessel);
   if (rc) return rc;
-  if (p->sync(p->sync_user, t.s1, 2 * (int64_t)N, 0, 0)) {
+  if (p->sync(p->sync_user, t.s1, 2 * (int64_t)N, 0, rows)) {   // (rows as the launch chain passes them)
     set_error("batch-norm backward sync hook failed");
     return -2;
   }
@@ -1111,7 +1111,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       q.up[0].g = dh_in; q.up[0].W = p->params + d.w; q.up[0].N = d.n_out;
       q.up[0].dW_slab = slab; q.up[0].dA_out = dA_out;
       {
-        const int r = tile_bn_backward(p, s, d, p->tc_spart[sp], G, q.bessel, &q.bn);
+        const int r = tile_bn_backward(p, s, d, p->tc_spart[sp], G, rows, q.bessel, &q.bn);
         if (r) return r;
       }
       q.in = in; q.K = in ? d.n_in : 0; q.d_in = d_in;
@@ -1283,6 +1283,7 @@ int scvae_plan_create(const scvae_model_config* cfg, scvae_plan** out) {
   for (int i = 0; i < 4; ++i) SCVAE_ARG(cfg->dropout_keep[i] >= 0.f && cfg->dropout_keep[i] <= 1.f);
   scvae_plan* p = new scvae_plan();
   p->head_arith = scvae::default_head_arith();
+  p->dd_atomics = scvae::default_dd_atomics();
   p->cfg = *cfg;
   p->P = scvae::likelihood_heads(cfg->likelihood);
   if (cfg->model_type == SCVAE_MODEL_GMVAE) scvae::build_gmvae(p);
@@ -1409,13 +1410,19 @@ int scvae_plan_probe_stages(scvae_plan* p, int32_t n) {
   SCVAE_ARG(p && n >= 0 && n <= 4096);
   for (hipEvent_t e : p->stage_events) (void)hipEventDestroy(e);
   p->stage_events.clear();
-  p->stage_recorded.assign((size_t)n, 0u);
+  p->stage_recorded.clear();   // (armed per step by its size: set only once every event exists)
   p->stage_next = 0;
   for (int i = 0; i < 2 * scvae::PS_COUNT * n; ++i) {
     hipEvent_t e = nullptr;
-    SCVAE_HIP(hipEventCreate(&e));
+    const hipError_t err = hipEventCreate(&e);
+    if (err != hipSuccess) {
+      for (hipEvent_t made : p->stage_events) (void)hipEventDestroy(made);
+      p->stage_events.clear();
+      return ::scvae::check_hip(err, "hipEventCreate (scvae_plan_probe_stages)");
+    }
     p->stage_events.push_back(e);
   }
+  p->stage_recorded.assign((size_t)n, 0u);
   return 0;
 }
 int scvae_plan_probe_stages_us(scvae_plan* p, float* out, int32_t n) {
@@ -1650,13 +1657,18 @@ int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
     }
     if (w->noise_out) {
       SCVAE_ARG(w->noise_blocks >= 0 && w->noise_block_rows >= 0 && w->noise_cols > 0);
+      // the output is a contiguous [blocks, block_rows, cols] tensor (noise_block_stride is the
+      // row stride of the Philox FIELD, not of the output); the step reads one eps row per
+      // (sample, cell), times the K passes of a GMVAE
+      const size_t blocks = (size_t)(w->noise_blocks > 0 ? w->noise_blocks : 1);
+      const size_t out_bytes =
+          blocks * (size_t)w->noise_block_rows * (size_t)w->noise_cols * sizeof(float);
       const size_t samples = (size_t)(a->n_iw > 0 ? a->n_iw : 1) * (size_t)(a->n_mc > 0 ? a->n_mc : 1);
-      SCVAE_ARG(!overlaps(w->noise_out,
-                          ((size_t)(w->noise_blocks > 0 ? w->noise_blocks - 1 : 0) *
-                               (size_t)w->noise_block_stride +
-                           (size_t)w->noise_block_rows * (size_t)w->noise_cols) * sizeof(float),
-                          a->eps, samples * (size_t)a->cells * (size_t)p->cfg.latent_size *
-                                      sizeof(float)));
+      const size_t passes =
+          p->cfg.model_type == SCVAE_MODEL_GMVAE ? (size_t)(p->cfg.n_clusters > 0 ? p->cfg.n_clusters : 1) : 1;
+      SCVAE_ARG(!overlaps(w->noise_out, out_bytes, a->eps,
+                          passes * samples * (size_t)a->cells * (size_t)p->cfg.latent_size *
+                              sizeof(float)));
     }
     p->side = w;
   }
@@ -1760,6 +1772,8 @@ int32_t scvae_decoder_fused_variant(int32_t kind, int64_t H) {
   return scvae::decoder_fused_variant(scvae::likelihood_heads(kind), (int)H);
 }
 int32_t scvae_default_head_arith(void) { return scvae::default_head_arith(); }
+int32_t scvae_default_dd_atomics(void) { return scvae::default_dd_atomics(); }
+int32_t scvae_plan_dd_atomics(const scvae_plan* p) { return p ? p->dd_atomics : -1; }
 int scvae_decoder_train_kernel_name(int32_t kind, int64_t H, int64_t rows, int32_t arith,
                                     int32_t u16, char* out, int64_t n) {
   SCVAE_ARG(out && n > 0);

@@ -142,9 +142,10 @@ struct scvae_plan {
   size_t gw_rows = 0;         //  the constant -1/(MC*B) is only rewritten when it changes)
   float *zcat = nullptr, *dzcat = nullptr;  // [rows, L + E]: decoder input [z | extra] and its gradient
   int use_fused = 1;          // fused decoder head kernel (0 = unfused GEMM + likelihood path)
-  int dd_atomics = 0;         // 1: the head kernel adds its part of dd into XCD-local accumulators
-                              // (fp32 atomics: not bit-repeatable) instead of per-strip slabs
-  int head_arith = 2;         // arithmetic of the fused head kernels: 0 fp32 MFMA, 1 bf16x9, 2 bf16x6
+  int dd_atomics = 1;         // 1 (default, default_dd_atomics()): the head kernel adds its part of dd
+                              // into XCD-local accumulators (fp32 atomics: sums not bit-repeatable
+                              // from run to run); 0: per-strip slabs + a fixed-order reduce
+  int head_arith = 1;         // arithmetic of the fused head kernels: 0 fp32 MFMA, 1 bf16x9, 2 bf16x6
                               // (scvae_plan_set_head_arith; a new plan: default_head_arith())
   int use_count_gemm = 1;     // exact bf16-split kernels for products with a count matrix x:
                               // 0 never, 1 where they pay (plan_gemm), 2 always

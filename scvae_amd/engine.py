@@ -298,7 +298,7 @@ class Engine:
     def set_head_arith(self, arith):
         """Arithmetic of this engine's fused head kernels: ``"bf16x9"`` (the
         exact nine-term bf16 split, default), ``"bf16x6"`` (the nine terms
-        without the three smallest, <= 2^-23 of a product: fp32-class, a
+        without the three smallest, <= 2^-26 of a product: fp32-class, a
         third fewer matrix instructions in the producer / consumer training
         kernel) or ``"fp32"`` (fp32 matrix cores).  A plan attribute: engines
         of one process can differ."""
@@ -308,10 +308,16 @@ class Engine:
 
     def set_dd_atomics(self, enabled):
         """Accumulate the decoder gradient ``dd`` of a training step with
-        XCD-local fp32 atomics instead of per-strip slabs (faster where the
-        head kernel has that store; the sums are not bit-repeatable)."""
+        XCD-local fp32 atomics (the default of a plan: faster where the head
+        kernel has that store; the last bits of the sums differ from run to
+        run) or through per-strip slabs and a fixed-order reduce
+        (``False``: bit-repeatable)."""
         _lib.check(self.lib.scvae_plan_set_dd_atomics(
             self.handle, 1 if enabled else 0), "scvae_plan_set_dd_atomics")
+
+    @property
+    def dd_atomics(self):
+        return bool(self.lib.scvae_plan_dd_atomics(self.handle))
 
     @property
     def head_arith(self):

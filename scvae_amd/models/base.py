@@ -371,6 +371,11 @@ class ModelBase:
         say("Preparing data.")
         preparing_data_time_start = time()
         engine = self.engine
+        if kwargs.get("deterministic") is not None:
+            # (not in the reference) True: the decoder gradient is summed over
+            # the gene strips in a fixed order (bit-repeatable steps) instead
+            # of with fp32 atomics, the plan's default
+            engine.set_dd_atomics(not kwargs["deterministic"])
         x_train, t_train = self._device_matrices(training_set)
         n_examples_train = training_set.number_of_examples
         if validation_set:

@@ -2,6 +2,7 @@
 row sharding, batch-norm statistic merging, the backward sum exchange and the
 gradient all-reduce give the single-process result.  The compute stand-in is
 plain fp64 torch (the product's kernels need a GPU)."""
+import datetime
 import os
 import socket
 
@@ -49,10 +50,18 @@ def _single_process(x, W, b, beta, v):
     return loss.detach(), W.grad, b.grad, beta.grad, mean.detach(), var.detach()
 
 
+RENDEZVOUS_FAILED = "rendezvous failed"
+
+
 def _worker(rank, world, port, x, W, b, beta, v, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=60))
+    except Exception as error:   # the port was taken between pick and bind
+        out.put((RENDEZVOUS_FAILED, rank, repr(error)))
+        return
     try:
         lo, hi = shard_bounds(x.shape[0], world, rank)
         xs = x[lo:hi]
@@ -80,7 +89,9 @@ def _worker(rank, world, port, x, W, b, beta, v, out):
                            loss.reshape(1)])
         dist.all_reduce(grads)                      # gradient all-reduce
         if rank == 0:
-            out.put((grads.clone(), mean.clone(), var.clone()))
+            # (plain lists: a tensor on a queue travels as a shared-memory handle that dies
+            #  with this process -- the consumer then fails with ConnectionResetError)
+            out.put((grads.tolist(), mean.tolist(), var.tolist()))
     finally:
         dist.destroy_process_group()
 
@@ -102,8 +113,9 @@ def test_two_rank_step_equals_single_process():
     loss, gW, gb, gbeta, mean, var = _single_process(x, W, b, beta, v)
     ctx = mp.get_context("spawn")
     # (the port is picked, released and bound again by rank 0: another process can take it in
-    #  between -- seen once in a few hundred runs -- so a failed rendezvous is retried on a fresh
-    #  port; a wrong RESULT is never retried)
+    #  between -- seen once in a few hundred runs.  ONLY a rendezvous failure, reported by the
+    #  worker itself, is retried on a fresh port; a crashed or hanging rank, a non-zero exit
+    #  code or a wrong result fail the test at once)
     result = None
     for attempt in range(3):
         out = ctx.Queue()
@@ -113,20 +125,20 @@ def test_two_rank_step_equals_single_process():
                  for r in range(2)]
         for p in procs:
             p.start()
-        try:
-            result = out.get(timeout=120)
-        except Exception:       # queue.Empty: a rank died before the result
-            result = None
+        result = out.get(timeout=180)     # queue.Empty (a rank died or hangs) fails the test
         for p in procs:
             p.join(timeout=60)
             if p.is_alive():
                 p.terminate()
                 p.join()
-        if result is not None and all(p.exitcode == 0 for p in procs):
-            break
-        result = None
-    assert result is not None, "two-rank gloo step failed three times"
-    grads, dmean, dvar = result
+                raise AssertionError("a rank did not exit")
+        if isinstance(result[0], str) and result[0] == RENDEZVOUS_FAILED:
+            result = None
+            continue
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        break
+    assert result is not None, "the gloo rendezvous failed three times"
+    grads, dmean, dvar = (torch.tensor(r, dtype=torch.float64) for r in result)
     want = torch.cat([gW.reshape(-1), gb, gbeta, loss.reshape(1)])
     assert torch.allclose(grads, want, rtol=1e-10, atol=1e-12)
     assert torch.allclose(dmean, mean) and torch.allclose(dvar, var)
