@@ -559,6 +559,104 @@ def describe(cells, F, likelihood, gm, K, L):
                 cells, F, likelihood, "GMVAE K={}".format(K) if gm else "VAE", L))
 
 
+def evaluation_step(matrix, device, batch, steps=60):
+    """cells/s of the evaluation step (is_training = False: the epoch-end passes of
+    model.train, va:1092-1150 / 1251-1304, and model.evaluate, va:1969-2055) of the headline
+    model: minibatch fetch + one graph execution per step, HIP events around the loop."""
+    import torch
+    from scvae_amd.engine import Engine
+    F = matrix.shape[1]
+    eng = Engine(F, LATENT, HIDDEN, LIKELIHOOD, batch_norm=True, device=device, seed=0)
+    eng.reserve(batch, 1)
+    u16 = bool(matrix.integer_counts and eng.accepts_counts_u16(batch, False))
+    x = (torch.empty(batch, matrix.u16_pitch, dtype=torch.uint16, device=device) if u16
+         else torch.empty(batch, F, device=device))
+    rc = torch.empty(batch, device=device)
+    eps = torch.randn(1, batch, LATENT, device=device)
+    n = matrix.number_of_rows
+    rows = torch.arange(n, device=device)
+
+    def step(i):
+        r = rows[(i * batch) % (n - batch + 1):][:batch]
+        matrix.request(r, x, rc).issue()
+        eng.step(x, x, eps=eps, row_const=rc, training=False, x_counts=matrix.integer_counts)
+    for i in range(10):
+        step(i)
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(steps):
+        step(i)
+    e1.record()
+    torch.cuda.synchronize(device)
+    ms = e0.elapsed_time(e1) / steps
+    del eng
+    torch.cuda.empty_cache()
+    return {"workload": "evaluation step (is_training = False) of the headline model: fetch + "
+                        "forward + likelihood + ELBO, " + describe(n, F, LIKELIHOOD, False, 1,
+                                                                 LATENT),
+            "cells_per_step": batch, "steps": steps, "ms_per_step": ms,
+            "minibatch_storage": "u16" if u16 else "f32",
+            "value": batch / ms * 1e3, "unit": "cells/s"}
+
+
+def model_train_epoch(matrix, device, batch, epochs):
+    """The drop-in's own entry point: ``VariationalAutoencoder.train`` (the Python epoch loop of
+    va:958-1599 -- shuffled minibatches, one step call each, the printed lines, BOTH epoch-end
+    evaluation passes over the training and the validation set, early-stopping bookkeeping, the
+    checkpoint written in the background) on the benchmark's matrix as a DataSet; wall-clock
+    between the ends of consecutive epochs (the first epoch -- allocations, warm-up -- is not
+    counted), cells of the training set per second."""
+    import contextlib
+    import tempfile
+    import numpy
+    import scipy.sparse
+    import torch
+    from scvae_amd.data import DataSet
+    from scvae_amd.models import VariationalAutoencoder
+    n, F = matrix.shape
+    host = scipy.sparse.csr_matrix(
+        (matrix.values.cpu().numpy(), matrix.indices.cpu().numpy(),
+         matrix.indptr.cpu().numpy()), shape=(n, F))
+    n_valid = n // 10
+    feature_names = numpy.array(["g%d" % j for j in range(F)])
+
+    def data_set(values, kind, first):
+        return DataSet("bench_shaped", values=values, kind=kind, feature_names=feature_names,
+                       example_names=numpy.array(
+                           ["c%d" % i for i in range(first, first + values.shape[0])]))
+    training = data_set(host[:n - n_valid], "training", 0)
+    validation = data_set(host[n - n_valid:], "validation", n - n_valid)
+    ends = []
+
+    def epoch_done(**kwargs):
+        torch.cuda.synchronize(device)
+        ends.append(time.perf_counter())
+    with tempfile.TemporaryDirectory() as directory:
+        model = VariationalAutoencoder(
+            feature_size=F, latent_size=LATENT, hidden_sizes=list(HIDDEN),
+            reconstruction_distribution=LIKELIHOOD, log_directory=directory,
+            device=str(device))
+        with open(os.devnull, "w") as sink, contextlib.redirect_stdout(sink):
+            model.train(training, validation, number_of_epochs=epochs, minibatch_size=batch,
+                        learning_rate=1e-4, intermediate_analyser=epoch_done)
+        dd_atomics = model.engine.dd_atomics
+        del model
+    torch.cuda.empty_cache()
+    spans = [b - a for a, b in zip(ends[:-1], ends[1:])]
+    sec = statistics.median(spans)
+    n_train = n - n_valid
+    steps = -(-n_train // batch)
+    return {"workload": "VariationalAutoencoder.train, one epoch: {} training steps of {} cells "
+                        "+ evaluation of the training set ({} cells) and of the validation set "
+                        "({} cells) + checkpoint; ".format(steps, batch, n_train, n_valid)
+                        + describe(n, F, LIKELIHOOD, False, 1, LATENT),
+            "cells_per_step": batch, "epochs_timed": len(spans), "seconds_per_epoch": sec,
+            "value": n_train / sec, "unit": "training cells/s (epoch wall-clock, evaluations "
+                                            "and checkpoint included)",
+            "dd_accumulation": "atomics" if dd_atomics else "slabs"}
+
+
 def other_workloads(matrix, device, barrier):
     """The other BASELINE.json configurations' models, measured in the same
     run (rank 0, N = 1): cells/s of the same step sequence."""
@@ -608,6 +706,9 @@ def other_workloads(matrix, device, barrier):
              "zero-inflated negative binomial GMVAE K=20 hidden 100-100 latent 100")
     measure("cfg5_zinb_gmvae_k20_latent_100_f27998", note5,
             m5, 512, "zero-inflated negative binomial", 100, "gmvae", 10)
+    out["evaluation_step"] = evaluation_step(matrix, device, 4096)
+    for b, epochs in ((4096, 4), (100, 3)):
+        out["model_train_epoch_b{}".format(b)] = model_train_epoch(matrix, device, b, epochs)
     # Opt-in arithmetic, NOT the headline: the same steps with the heads' products as six of the
     # nine bf16 terms (Engine.set_head_arith('bf16x6'): the three smallest products, together
     # <= 2^-26 of a product with the rounded split, left out -- fp32-class, not exact;
@@ -634,8 +735,7 @@ def other_workloads(matrix, device, barrier):
 def main():
     global DD_ATOMICS
     args = parse_args()
-    from scvae_amd import _lib as _l0
-    DD_ATOMICS = bool(_l0.load().scvae_default_dd_atomics()) and not args.dd_slabs
+    DD_ATOMICS = not args.dd_slabs
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(respawn_one_rank_per_gpu(args))
 
@@ -672,6 +772,9 @@ def main():
         ranks_seen = int(ones.item())
 
     from scvae_amd.minibatch import synthetic_count_matrix
+    # (the library is loaded after torch: both must share torch's HIP runtime)
+    from scvae_amd import _lib as _l0
+    DD_ATOMICS = bool(_l0.load().scvae_default_dd_atomics()) and not args.dd_slabs
 
     matrix, _ = synthetic_count_matrix(
         args.cells, args.features, density=0.05, seed=60, device=device)

@@ -190,7 +190,8 @@ int scvae_plan_probe_stages_us(scvae_plan* plan, float* out, int32_t n);
  * With a data-parallel hook (scvae_plan_set_sync) the rank's chunk statistics are merged by a
  * small kernel, handed to the hook (kinds 1 and 0, as from the launch chain) and taken as given by
  * the consuming tile kernel.  scvae_plan_uses_tile_chain: whether a training step of `cells`
- * cells x `samples` samples of this plan, as configured now, takes that path (VAE plans). */
+ * cells x `samples` samples of this plan, as configured now, takes that path (VAE plans; GMVAE
+ * plans: the K stacked passes as tile-chain groups, whole 64-row tiles per pass). */
 int scvae_plan_set_tile_chain(scvae_plan* plan, int32_t enabled);
 int32_t scvae_plan_uses_tile_chain(const scvae_plan* plan, int64_t cells, int32_t samples);
 /* Small VAE minibatches (cells x samples <= 128, widths <= 128, batch norm, analytic KL, no

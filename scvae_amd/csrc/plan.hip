@@ -1447,7 +1447,9 @@ int scvae_plan_set_tile_chain(scvae_plan* p, int32_t enabled) {
   return 0;
 }
 int32_t scvae_plan_uses_tile_chain(const scvae_plan* p, int64_t cells, int32_t samples) {
-  if (!p || cells <= 0 || samples <= 0 || p->cfg.model_type != SCVAE_MODEL_VAE) return 0;
+  if (!p || cells <= 0 || samples <= 0) return 0;
+  if (p->cfg.model_type == SCVAE_MODEL_GMVAE)   // (the K stacked passes as tile-chain groups)
+    return scvae::gm_tile_chain_ok(p, (int)cells, samples, true) ? 1 : 0;
   return tile_chain_ok(p, (int)cells, samples, true) ? 1 : 0;
 }
 int scvae_plan_set_mid_chain(scvae_plan* p, int32_t enabled) {

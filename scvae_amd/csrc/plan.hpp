@@ -242,6 +242,7 @@ int copy(hipStream_t s, const float* src, float* dst, size_t n);
 int build_gmvae(scvae_plan* p);
 size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t samples, bool dry);
 int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s);
+bool gm_tile_chain_ok(const scvae_plan* p, int B, int S, bool training);   // plan_gmvae.hip
 int plan_side_fork(scvae_plan* p, hipStream_t s, int point);   // scvae_step_args.side (plan.hip)
 int plan_side_finish(scvae_plan* p, hipStream_t s);
 }  // namespace scvae

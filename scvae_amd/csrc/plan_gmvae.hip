@@ -214,7 +214,7 @@ size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t
 //      direction (tilechain.hip with groups: the rows of pass k are a range of 64-row tiles with
 //      their own batch statistics).  Training steps with batch normalisation, no dropout, no
 //      data-parallel hook, whole tiles per pass, layers and latent at most 128 wide. ----
-static bool gm_tile_chain_ok(const scvae_plan* p, int B, int S, bool training) {
+bool gm_tile_chain_ok(const scvae_plan* p, int B, int S, bool training) {
   const scvae_model_config& c = p->cfg;
   static const bool env_on = [] { const char* e = getenv("SCVAE_TILE_CHAIN"); return !(e && e[0] == '0'); }();
   if (!env_on || !p->use_tile_chain || p->sync || !training || !c.batch_norm) return false;

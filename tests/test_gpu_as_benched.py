@@ -220,6 +220,9 @@ def test_u16_training_step_is_the_fp32_step_at_benchmark_size(benchmark_step):
     results = []
     for x in (x32, x16):
         eng = engine()
+        # (bit-for-bit: the decoder gradient through the fixed-order slabs; the plan's default
+        #  -- fp32 atomics -- is what the oracle tests below run)
+        eng.set_dd_atomics(False)
         if x.dtype == torch.uint16:
             assert eng.accepts_counts_u16(B, True)
             assert eng.accepts_counts_u16(B, False)
@@ -252,7 +255,7 @@ def test_u16_training_step_against_the_oracle_at_benchmark_size(
     L = eps.shape[-1]
     eng = engine()
     eng.set_head_arith(arith)
-    eng.set_dd_atomics(True)
+    assert eng.dd_atomics          # the plan's default, as bench.py and `scvae train` run it
     assert eng.head_arith == arith
     cfg = om.ModelConfig(feature_size=F, latent_size=L, hidden_sizes=H,
                          likelihood="negative binomial")
@@ -286,6 +289,91 @@ def test_u16_training_step_against_the_oracle_at_benchmark_size(
             assert g.abs().max().item() == 0.0, name
             continue
         close_maxnorm(g, grads[name], rtol=2e-4, what="grad " + name)
+
+
+@pytest.mark.parametrize("config,likelihood,features", [
+    ("cfg4", "negative binomial", 32738),
+    ("cfg5", "zero-inflated negative binomial", 27998),
+])
+def test_gmvae_training_step_against_the_oracle_as_benched(
+        cuda_device, config, likelihood, features):
+    """The GMVAE steps `bench.py` times (`other_workloads.cfg4_* / cfg5_*`):
+    K = 20 passes x 512 cells = 10 240 stacked rows through the producer /
+    consumer head kernel (decoder gradient through atomics, the plan's
+    default), the hidden layers on the tile-chain groups, the minibatch in the
+    encoding the bench's ``Workload`` picks -- against the fp64 oracle with
+    autograd on the host (gm:3223-3434): ELBO terms, per-cell and per-cluster
+    log-likelihood per element, q(y|x) logits, every gradient."""
+    from scvae_amd.engine import Engine
+    from scvae_amd.minibatch import philox_normal_blocks
+    B, F, L, K = 512, features, 100, 20
+    matrix, x32, x16, rc = _minibatches(cuda_device, B, F, seed=64)
+    eng = Engine(F, L, H, likelihood, batch_norm=True, model_type="GMVAE",
+                 n_clusters=K, device=cuda_device, seed=0)
+    g = torch.Generator().manual_seed(3)
+    for name, p in eng.named_parameters().items():
+        if not name.endswith("weights"):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    for name, m in eng.named_moving_statistics().items():
+        if name.endswith("moving_mean"):
+            m.copy_(torch.randn(m.shape, generator=g) * 0.2)
+        else:
+            m.copy_(torch.rand(m.shape, generator=g) + 0.5)
+    eng.reserve(B, 1)
+    assert eng.dd_atomics
+    assert eng.head_arith == "bf16x9"
+    assert eng.uses_tile_chain(B, 1)
+    # exactly bench.py's choice (Workload.__init__)
+    u16 = bool(matrix.integer_counts and eng.accepts_counts_u16(B, True))
+    x = x16 if u16 else x32
+    eps = torch.empty(K, B, L, device=cuda_device)
+    philox_normal_blocks(eps, block_stride=B, row_offset=0, seed=1, stream_id=7)
+    cfg = om.ModelConfig(feature_size=F, latent_size=L, hidden_sizes=H,
+                         likelihood=likelihood, n_clusters=K)
+    params = {k: v.detach().cpu().double()
+              for k, v in eng.named_parameters().items()}
+    moving = {k: v.detach().cpu().double()
+              for k, v in eng.named_moving_statistics().items()}
+    ll = torch.zeros(K * B, device=cuda_device)
+    logits = torch.zeros(B, K, device=cuda_device)
+    zmean = torch.zeros(B, L, device=cuda_device)
+    sc = eng.step(x, x, eps=eps, row_const=rc, training=True, x_counts=True,
+                  outputs={"log_p_x_given_z": ll, "q_y_logits": logits,
+                           "q_z_mean": zmean}).cpu().numpy()
+    dev_grads = {k: v.detach().cpu().double()
+                 for k, v in eng.named_gradients().items()}
+    torch.cuda.synchronize()
+    assert np.isfinite(sc[:5]).all()
+    xh = x32.cpu().double()
+    out, grads = om.gradients(
+        lambda p: om.gmvae_forward(
+            cfg, p, moving, xh, xh, eps.cpu().double().reshape(K, 1, B, L),
+            True, 1.0, {}), params)
+    close_scalar(sc[0], out["lower_bound"], what="lower_bound")
+    close_scalar(sc[2], out["reconstruction_error"],
+                 what="reconstruction_error")
+    close_scalar(sc[3], out["kl_divergence_z"], what="kl_divergence_z")
+    close_scalar(sc[4], out["kl_divergence_y"], rtol=2e-4, atol=1e-6,
+                 what="kl_divergence_y")
+    close_elementwise(ll, out["log_p_x_given_z"].reshape(-1), rtol=LL_RTOL,
+                      atol=LL_ATOL, what="per-cell log-likelihood")
+    close_elementwise(logits, out["q_y_logits"], rtol=1e-4, atol=1e-5,
+                      what="q_y_logits")
+    close_elementwise(zmean, out["z_mean"], rtol=1e-4, atol=1e-5,
+                      what="z_mean")
+    for name, gr in dev_grads.items():
+        if name.endswith("DENSE/biases") and "/LAYER_" in name:
+            assert gr.abs().max().item() == 0.0, name   # cancelled by batch norm
+            continue
+        got, want = gr, grads[name]
+        if name == "Z/Q/ENCODER/LAYER_1/DENSE/weights":
+            # the one-hot rows W[F+k] are cancelled by the per-pass batch norm
+            assert got[F:].abs().max().item() < 1e-5
+            got, want = got[:F], want[:F]
+        # (Y/: differences of per-cluster log-likelihoods of order 2e4, see
+        #  tests/test_gpu_baseline_configs.py)
+        rtol = 2e-3 if name.startswith("Y/") else 5e-4
+        close_maxnorm(got, want, rtol=rtol, what="grad " + name)
 
 
 def test_six_term_heads_are_fp32_class(cuda_device):

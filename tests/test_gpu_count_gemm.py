@@ -179,6 +179,7 @@ def test_count_precondition_check(cuda_device):
     assert not DeviceCSR.from_scipy(logged, cuda_device).integer_counts
 
 
+@pytest.mark.usefixtures("bit_repeatable")
 @pytest.mark.parametrize("model_type", ["VAE", "GMVAE"])
 def test_training_step_with_and_without_the_count_kernels(cuda_device,
                                                           model_type):
@@ -224,6 +225,7 @@ def test_training_step_with_and_without_the_count_kernels(cuda_device,
     assert np.array_equal(plain.cpu().numpy()[:5], s_f[:5])
 
 
+@pytest.mark.usefixtures("bit_repeatable")
 @pytest.mark.parametrize("likelihood", ["negative binomial",
                                         "zero-inflated negative binomial",
                                         "poisson"])
@@ -346,6 +348,7 @@ def test_uint16_minibatch_is_refused_where_it_does_not_apply(cuda_device):
     assert drop.accepts_counts_u16(B, False)
 
 
+@pytest.mark.usefixtures("bit_repeatable")
 def test_tail_minibatch_fits_the_reserved_count_workspace(cuda_device):
     """A plan bound for 1300 cells runs every smaller minibatch on the uint16
     path: the forward count kernel takes MORE split-K slabs for fewer row
@@ -381,6 +384,7 @@ def test_tail_minibatch_fits_the_reserved_count_workspace(cuda_device):
         assert torch.equal(s16, s32) and torch.equal(g16, eng.grads)
 
 
+@pytest.mark.usefixtures("bit_repeatable")
 @pytest.mark.parametrize("likelihood", ["negative binomial",
                                         "zero-inflated negative binomial"])
 def test_uint16_minibatch_gmvae_is_the_fp32_step_bit_for_bit(cuda_device,

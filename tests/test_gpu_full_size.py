@@ -61,10 +61,12 @@ def test_fused_and_unfused_paths_agree(full_size):
     assert eng.lib.scvae_decoder_fused_variant(_lib.LIKELIHOOD_KINDS[
         "negative binomial"][0], H[0]) in (1, 2)
     eng.set_fused(True)
+    eng.set_dd_atomics(False)    # (`scvae train --deterministic`: the fixed-order slabs)
     s_f, ll_f, g_f = _training_step(eng, x, row_const, eps)
     again = _training_step(eng, x, row_const, eps)
     assert np.array_equal(s_f, again[0]) and torch.equal(g_f, again[2]), \
         "a repeated step must be bitwise reproducible"
+    eng.set_dd_atomics(True)     # (the plan's default for everything below)
     eng.set_fused(False)
     s_u, ll_u, g_u = _training_step(eng, x, row_const, eps)
     eng.set_fused(True)

@@ -78,6 +78,7 @@ def _loop(device, matrix, B, L, H, likelihood, model, u16, carried, steps=4):
                 adam_t=eng.adam_t)
 
 
+@pytest.mark.usefixtures("bit_repeatable")
 @pytest.mark.parametrize("B,H,L,likelihood,model,u16", [
     (100, (64, 48), 10, "negative binomial", "VAE", False),       # mid-chain kernels
     (1024, (100, 100), 25, "negative binomial", "VAE", True),      # tile chain, count kernels
