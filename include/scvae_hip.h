@@ -193,6 +193,17 @@ int scvae_plan_probe_stages_us(scvae_plan* plan, float* out, int32_t n);
  * cells x `samples` samples of this plan, as configured now, takes that path (VAE plans; GMVAE
  * plans: the K stacked passes as tile-chain groups, whole 64-row tiles per pass). */
 int scvae_plan_set_tile_chain(scvae_plan* plan, int32_t enabled);
+/* Single process (no scvae_plan_set_sync hook), VAE plans: 1 = the tile chain's
+ * stages of a pass -- hidden layers, posterior heads, the latent stage, the dW slab sums -- in
+ * ONE resident launch per direction, grid barriers where a stage needs every tile's batch-norm
+ * statistics (same tile code, same bits as the per-layer launches; minibatches whose tiles fit
+ * half the device's CUs); 0 (default) = one launch per layer and direction.  Measured on
+ * MI355X at 4096 rows the resident launches are SLOWER (112 + 144 us against 79 + 128 us of
+ * kernel time: the stages are bound by their memory-instruction issue, not by launch gaps, and
+ * the resident kernel's first stage pays a longer cold start), so the option is off by default;
+ * DESIGN.md section 8. */
+int scvae_plan_set_tile_resident(scvae_plan* plan, int32_t enabled);
+int32_t scvae_plan_uses_tile_resident(const scvae_plan* plan, int64_t cells, int32_t samples);
 int32_t scvae_plan_uses_tile_chain(const scvae_plan* plan, int64_t cells, int32_t samples);
 /* Small VAE minibatches (cells x samples <= 128, widths <= 128, batch norm, analytic KL, no
  * dropout / decoder extras, single process): the hidden layers, posterior heads and latent stage

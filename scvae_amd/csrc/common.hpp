@@ -252,6 +252,19 @@ __device__ __forceinline__ float bn_input_gradient(float g, float xh, float s1, 
   return istd * (t - (xh * s2) * inv_count);
 }
 // moving <- moving - (moving - batch) * rate
+// The analytic Gaussian KL term and its gradients (va:2624-2656), shared by gauss_latent_*
+// (elementwise.hip) and the tile chain's latent stage (tilechain.hip); the fused multiply-adds
+// are spelled out so that every caller rounds alike (the compiler's own contraction differs from
+// one kernel to the next).
+__device__ __forceinline__ float gauss_kl_elem(float mu, float sigma, float ls) {
+  return fmaf(0.5f, fmaf(mu, mu, fmaf(sigma, sigma, -1.f)), -ls);
+}
+__device__ __forceinline__ float gauss_kl_dmu(float gz, float kl_coeff, float mu) {
+  return fmaf(kl_coeff, mu, gz);
+}
+__device__ __forceinline__ float gauss_kl_dls(float gze, float sigma, float kl_coeff) {
+  return fmaf(gze, sigma, kl_coeff * fmaf(sigma, sigma, -1.f));
+}
 __device__ __forceinline__ float bn_moving_update(float moving, float batch) {
   const float d = moving - batch;
   return moving - d * BN_UPDATE_RATE;

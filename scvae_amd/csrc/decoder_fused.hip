@@ -640,6 +640,7 @@ size_t decoder_fused_workspace_floats(int rows, int H, int F, bool train) {
   if (train) n += decoder_fused3_workspace_floats(rows, H) + 64;   // bf16 planes of d (bf16x9 kernel)
   // (constrained Poisson passes: a second [strips][rows] array, lse[rows], S[rows])
   if (train) n += strips * (size_t)rows + 2 * (size_t)rows + 192;
+  if (train) n += decoder_fused3_rg_slab_floats(H, F) + 64;       // row groups' dW / db slabs
   return n + 64;
 }
 
@@ -727,13 +728,14 @@ template <bool TRAIN>
 static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                           int F, Targets t, int B, const float* gw, int inline_lgamma,
                           float* ll_part, float* dd_part, int arith, float* planes = nullptr,
-                          const HeadDropout* drop = nullptr, int dd_mode = 0) {
+                          const HeadDropout* drop = nullptr, int dd_mode = 0,
+                          float* rg_slab = nullptr) {
   const int P = likelihood_heads(kind);
   if (TRAIN && planes && decoder_train_kernel(P, H, arith) == 3) {
     static const int dbg = [] { const char* e = getenv("SCVAE_D3_DEBUG"); return e ? atoi(e) : 0; }();
     return decoder_fused3_launch(s, true, kind, d, rows, H, hp, F, t, B, gw,
                                  inline_lgamma | (dbg << 8), ll_part, dd_part, planes, drop, 0,
-                                 nullptr, (dd_mode ? 1 : 0) | (arith == 2 ? 2 : 0));
+                                 nullptr, (dd_mode ? 1 : 0) | (arith == 2 ? 2 : 0), rg_slab);
   }
   if (drop) {
     set_error("head dropout inside the fused kernel needs the bf16x9 head kernel");
@@ -771,7 +773,11 @@ static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int
 int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int H, HeadParams hp,
                           int F, Targets t, int B, const float* row_const, float* ll,
                           float* workspace, int arith) {
-  SCVAE_ARG(d && t.p && ll && workspace && decoder_fused_supported(H));
+  const int heads = likelihood_heads(kind);
+  // (odd widths and widths beyond 126: the forward half of the producer / consumer kernel)
+  const bool wide = !decoder_fused_supported(H);
+  SCVAE_ARG(d && t.p && ll && workspace &&
+            (!wide || (arith >= 1 && decoder_fused4_supported(heads, H))));
   if (rows == 0) return 0;
   int strips = (F + DF_BN - 1) / DF_BN;
   float* ll_part = workspace;
@@ -783,20 +789,27 @@ int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int
   //      for one- and two-head likelihoods under the bf16x9 head arithmetic;
   //   1  the register-resident fp32 forward kernel (decoder_forward.hip) -- default otherwise,
   //      where its LDS budget allows;
-  //   0  the forward instantiation of the fp32 training kernels.
+  //   0  the forward instantiation of the fp32 training kernels;
+  //   4  (odd widths, widths beyond 126, bf16x9 arithmetic) decoder_head4_kernel<.., FWD = true>.
   // The workspace is the one decoder_fused_workspace_floats(.., train = true) sizes (the plans
   // and the C ABI size no other): the bf16 planes of d go behind ll_part.
   static const int forced = [] {
     const char* e = getenv("SCVAE_DECODER_FORWARD");
     return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : -1;
   }();
-  const int heads = likelihood_heads(kind);
   int which = decoder_forward_supported(heads, H) ? 1 : 0;
   if (arith >= 1 && heads <= 2 && decoder_fused3_supported(heads, H)) which = 3;
   if (forced == 0) which = 0;
   if (forced == 1 && decoder_forward_supported(heads, H)) which = 1;
+  if (wide) which = 4;
   int rc;
-  if (which == 3) {
+  if (which == 4) {
+    const int bn = decoder_fused3_train_strip_genes(heads, H, rows, false, 0);
+    strips = (F + bn - 1) / bn;
+    float* planes = workspace + ((size_t)strips * rows + 63) / 64 * 64;
+    rc = decoder_fused3_launch(s, false, kind, d, rows, H, hp, F, t, B, nullptr, inline_lgamma,
+                               ll_part, nullptr, planes);
+  } else if (which == 3) {
     const int bn = decoder_fused3_strip_genes(heads);
     strips = (F + bn - 1) / bn;
     float* planes = workspace + ((size_t)strips * rows + 63) / 64 * 64;
@@ -930,9 +943,12 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
   size_t off = ((size_t)strips * rows + 63) / 64 * 64;
   float* dd_part = workspace + off;
   float* planes = dd_part + (dd_part_floats(strips, rows, H) + 63) / 64 * 64;
+  // (the last region of the workspace: behind everything the constrained-Poisson passes carve)
+  float* rg_slab = workspace + decoder_fused_workspace_floats(rows, H, F, true) -
+                   (decoder_fused3_rg_slab_floats(H, F) + 64);
   int rc = launch_decoder<true>(s, kind, d, rows, H, hp, F, t, B, gw,
                                 (row_const || kind == LK_BERNOULLI) ? 0 : 1, ll_part, dd_part,
-                                arith, planes, drop, dd_mode);
+                                arith, planes, drop, dd_mode, rg_slab);
   if (rc) return rc;
   if (kernel_only) return 0;  // profiling aid: leave the per-strip partials unreduced
   hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 15) / 16), dim3(1024), 0, s, ll_part,

@@ -942,12 +942,17 @@ __device__ unsigned long long d4_prof[12 * 8];
 // the PRODUCERS on their registers (one add per element and tile, a cross-lane reduce at the end)
 // instead of falling out of GEMM2's ones row -- which at these widths would be an h tile of its
 // own (the fifth at H = 128, the ninth at 256) holding nothing but that row.
+// FWD: the forward half alone (is_training = False, the first pass of an importance-weighted
+// step) for the decoder widths only this kernel takes -- odd ones and everything beyond 126: the
+// producers' GEMM1 + likelihood + row sums; the gradient planes are not formed (nothing reads G:
+// the compiler drops its arithmetic), the consumers only add up the row sums.
 template <int KIND, int KS1, bool U16, int NPW, int BN_ = 0, bool DBP = false,
-          int G1 = (NPW == 4 ? 1 : D4_G1_EIGHT), int TERMS = 9>
+          int G1 = (NPW == 4 ? 1 : D4_G1_EIGHT), int TERMS = 9, bool FWD = false>
 __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
     const uint16_t* __restrict__ dA, const uint16_t* __restrict__ dT, int R, int Rpad, int H,
     HeadParams hp, int F, Targets tg, int B, const float* __restrict__ gw, int inline_lgamma,
-    float* __restrict__ ll_part, float* __restrict__ dd_part, int dd_atomic) {
+    float* __restrict__ ll_part, float* __restrict__ dd_part, int dd_atomic, int rg_tiles,
+    float* __restrict__ rg_slab) {
   using Traits = LikelihoodTraits<KIND>;
   constexpr int P = Traits::P;
   constexpr int NT = d4_threads(NPW);
@@ -1022,7 +1027,17 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
   }
   __syncthreads();
 
-  const int n_tiles = (R + D4_BM - 1) / D4_BM;
+  // (strip x ROW GROUP: workgroup (x, y) takes the 32-row tiles y * rg_tiles .. of strip x, so
+  //  that the launch fills whole rounds of the CUs whatever the gene count -- d4_row_groups.  ll
+  //  and dd are per row; the strip's dW / db of row group 0 go to the gradient buffers, those of
+  //  the groups behind it to rg_slab [group - 1][P][H + 1][F], summed by d4_rg_combine_kernel)
+  const int tile0 = blockIdx.y * rg_tiles;
+  const int n_tiles = min((R + D4_BM - 1) / D4_BM, tile0 + rg_tiles);
+  const int mfirst = tile0 * D4_BM;
+  auto grad_row = [&](int j, int h) -> float* {       // dW_j[h, :] (h < H) or db_j (h == H)
+    if (blockIdx.y == 0) return h < H ? hp.dW[j] + (size_t)h * F : hp.db[j];
+    return rg_slab + (((size_t)(blockIdx.y - 1) * P + j) * (H + 1) + h) * F;
+  };
   const int KP = d3_kp(H), ksp = KP / 32;   // padded width of the planes of d, in elements / steps
   const size_t dplane = (size_t)Rpad * KP;
   const int nb16 = Rpad / 16;
@@ -1041,7 +1056,7 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
       TileIn in;
       const int row = m0 + 16 * rq + i16;
       const bool rok = row < R;
-      in.up0 = rok ? gw[row] : 0.f;
+      in.up0 = (rok && !FWD) ? gw[row] : 0.f;
       const int rc = rok ? row : R - 1;
       const int cell = R == B ? rc : rc % B;
       const size_t trow = (size_t)cell * tg.ld;
@@ -1129,22 +1144,22 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
     for (int j = 0; j < P; ++j)
 #pragma unroll
       for (int e = 0; e < NE; ++e) dbacc[j][e] = 0.f;
-    TileIn nxt = load_t(0);
-    load_d(0);
+    TileIn nxt = load_t(mfirst);
+    load_d(mfirst);
     const bool g1last = G1 == 1 || (G1 == 2 && w >= NPW / 2);    // (wave-uniform)
     if (g1last) {
-      gemm1(0);
-      load_d(min(D4_BM, Rpad - D4_BM));
+      gemm1(mfirst);
+      load_d(min(mfirst + D4_BM, Rpad - D4_BM));
       d3_pin_loads();
     }
     D4_PROF_BEGIN;
-    for (int tile = 0; tile < n_tiles; ++tile) {
+    for (int tile = tile0; tile < n_tiles; ++tile) {
       const int m0 = tile * D4_BM;
       if (dbg & 2) { lds_barrier(); continue; }
       const TileIn cur = nxt;
       const float up = cur.up0;
-      char* Gb = Gl + (tile & 1) * GBUF;
-      float* lb = llbuf + (tile & 1) * LLN;
+      char* Gb = Gl + ((tile - tile0) & 1) * GBUF;
+      float* lb = llbuf + ((tile - tile0) & 1) * LLN;
       if (!g1last) gemm1(m0);
       {
         // the next tile's targets (and, GEMM1 first, its fragments of d): under the likelihood.
@@ -1290,7 +1305,7 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
       }
       }
       D4_STAMP(2);
-      if (DBP) {
+      if (DBP && !FWD) {
 #pragma unroll
         for (int j = 0; j < P; ++j)
 #pragma unroll
@@ -1299,6 +1314,7 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
       // ---- this lane's part of the row sum -> lb[gp][q][row]: the consumers add the parts ----
       lb[(gp * 4 + q) * D4_BM + 16 * rq + i16] = lsum;
       // ---- G_j -> three bf16 planes, row-major [row][gene], 8 bytes (4 genes) per store ----
+      if constexpr (!FWD)
 #pragma unroll
       for (int j = 0; j < P; ++j)
 #pragma unroll
@@ -1326,7 +1342,7 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
     }
     lds_barrier();     // (the consumers' pass over the last tile)
     D4_PROF_END;
-    if (DBP) {
+    if (DBP && !FWD) {
       // db_j[gene] = sum over the rows: over the 16 lanes of a q group (the tile's rows of this
       // wave), then over the row blocks rq through LDS (the G tiles are free now), fixed order
 #pragma unroll
@@ -1352,7 +1368,7 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
 #pragma unroll
           for (int e = 0; e < NE; ++e) {
             const int c = c0 + gbase + 16 * (e >> 2) + 4 * q + (e & 3);
-            if (c < F) hp.db[j][c] = dbacc[j][e] + park[((gp * P + j) * NE + e) * 4 + q];
+            if (c < F) grad_row(j, H)[c] = dbacc[j][e] + park[((gp * P + j) * NE + e) * 4 + q];
           }
       }
     }
@@ -1361,6 +1377,22 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
 
   // =========================== consumers: GEMM3 (dd) and GEMM2 (dW) ===========================
   __builtin_amdgcn_s_setprio(D4_PRIO_CONSUMER);
+  if constexpr (FWD) {
+    // forward only: the strip's per-row log-likelihood, the producers' parts in a fixed order
+    lds_barrier();       // (the producers' first tile)
+    for (int tile = tile0; tile < n_tiles; ++tile) {
+      const int m0 = tile * D4_BM;
+      const float* lb = llbuf + ((tile - tile0) & 1) * LLN;
+      if (w == NPW && lane < D4_BM && m0 + lane < R) {
+        float sm = 0.f;
+#pragma unroll
+        for (int u = 0; u < NGP * 4; ++u) sm += lb[u * D4_BM + lane];
+        ll_part[(size_t)blockIdx.x * R + m0 + lane] = sm;
+      }
+      lds_barrier();
+    }
+    return;
+  }
   const int ht = w - NPW;                         // h tile of this wave
   // (dd_atomic) the accumulator copy of the XCD this workgroup actually runs on: its adds are
   // then performed in that XCD's own L2, the only L2 that ever holds lines of that copy --
@@ -1403,13 +1435,13 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
   // (across the barrier -- and across GEMM3, where the wave's register need peaks -- only the
   //  first k-step of the next row tile travels; the second is requested when its GEMM2 starts,
   //  half a GEMM2 ahead of its use)
-  if (ht < n_ht2) load_a2k(0, 0, 0, a2[0][0]);
+  if (ht < n_ht2) load_a2k(mfirst, 0, 0, a2[0][0]);
   lds_barrier();       // (the producers' first tile)
   D4_PROF_BEGIN;
-  for (int tile = 0; tile < n_tiles; ++tile) {
+  for (int tile = tile0; tile < n_tiles; ++tile) {
     const int m0 = tile * D4_BM;
-    const char* Gb = Gl + (tile & 1) * GBUF;
-    const float* lb = llbuf + (tile & 1) * LLN;
+    const char* Gb = Gl + ((tile - tile0) & 1) * GBUF;
+    const float* lb = llbuf + ((tile - tile0) & 1) * LLN;
     // per-row log-likelihood of the strip: the producers' parts summed in a fixed order
     if (w == NPW && lane < D4_BM && m0 + lane < R) {
       float sm = 0.f;
@@ -1542,8 +1574,7 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
               const int h = 32 * htt + (i & 3) + 8 * (i >> 2) + 4 * kh;
-              if (h < H) hp.dW[j][(size_t)h * F + c] = accW[t][j][gt][i];
-              else if (h == H) hp.db[j][c] = accW[t][j][gt][i];
+              if (h <= H) grad_row(j, h)[c] = accW[t][j][gt][i];
             }
         }
       }
@@ -1642,11 +1673,71 @@ int decoder_fused3_train_kernel_name(int kind, int H, int rows, bool u16, char* 
                   (d3_hp1(H) + 31) / 32, u16 ? "true" : "false");
 }
 
+// ---- row groups of the producer / consumer kernel ----
+// One workgroup per CU (its LDS), so a launch of `strips` workgroups runs in ceil(strips / CUs)
+// rounds and the last round may be nearly empty (27 998 genes on 32-gene strips: 875 workgroups
+// on 256 CUs, the fourth round on 107 of them -- a seventh of the launch).  Cutting the rows of
+// every strip into n groups multiplies the workgroups; n is chosen for the fullest rounds, a
+// group keeps at least 256 rows, and every group beyond the first costs a pass over
+// [P][H + 1][F] floats (its dW / db slab), so one more group has to buy at least four percent.
+constexpr int D4_MAX_ROW_GROUPS = 4;
+size_t decoder_fused3_rg_slab_floats(int H, int F) {
+  return (size_t)(D4_MAX_ROW_GROUPS - 1) * 3 * (size_t)(H + 1) * F + 64;
+}
+static int d4_cu_count() {
+  static thread_local int cached_device = -1, cached = 0;
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return 256;
+  if (device != cached_device) {
+    hipDeviceProp_t prop;
+    cached = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
+    cached_device = device;
+  }
+  return cached > 0 ? cached : 256;
+}
+static int d4_row_groups(int strips, int rows) {
+  static const int forced = [] {
+    const char* e = getenv("SCVAE_D4_ROW_GROUPS");
+    return e ? atoi(e) : 0;
+  }();
+  const int tiles = (rows + D4_BM - 1) / D4_BM;
+  int most = tiles / 8;                            // >= 256 rows per group
+  if (most > D4_MAX_ROW_GROUPS) most = D4_MAX_ROW_GROUPS;
+  if (most < 1) most = 1;
+  if (forced >= 1) return forced < most ? forced : most;
+  const int cus = d4_cu_count();
+  int best = 1;
+  double best_score = 0.0;
+  for (int n = 1; n <= most; ++n) {
+    const long wgs = (long)strips * n;
+    const long rounds = (wgs + cus - 1) / cus;
+    const double score = (double)wgs / (double)(rounds * cus) - 0.04 * (n - 1);
+    if (score > best_score + 1e-9) { best = n; best_score = score; }
+  }
+  return best;
+}
+// gradient rows (dW_j[h, :], h < H; db_j, h == H) += the row groups' slabs, in group order
+__global__ __launch_bounds__(256) void d4_rg_combine_kernel(HeadParams hp, int P, int H, int F,
+                                                            const float* __restrict__ slab,
+                                                            int groups) {
+  const int jh = blockIdx.y;                       // (head, row)
+  const int j = jh / (H + 1), h = jh % (H + 1);
+  float* dst = h < H ? hp.dW[j] + (size_t)h * F : hp.db[j];
+  const size_t gstride = (size_t)P * (H + 1) * F;
+  const float* src = slab + ((size_t)j * (H + 1) + h) * F;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < F; c += gridDim.x * blockDim.x) {
+    float v = dst[c];
+    for (int g = 0; g < groups; ++g) v += src[(size_t)g * gstride + c];
+    dst[c] = v;
+  }
+}
+
 // ---- launch of the producer / consumer kernel: the instantiation for (kind, steps, strip, waves) ----
 struct D4Launch {
   hipStream_t s; const uint16_t* dA; const uint16_t* dT; int rows, Rpad, H; HeadParams hp; int F;
   Targets t; int B; const float* gw; int inline_lgamma; float* ll_part; float* dd_part;
-  int dd_atomic; int strips; size_t lds; int terms;
+  int dd_atomic; int strips; size_t lds; int terms; int row_groups; float* rg_slab;
+  bool fwd = false;      // the forward half alone (decoder_head4_kernel<..., FWD = true>)
 };
 template <int KIND, int KS1, int NPW, int BN_, bool DBP = false, int TERMS = 9>
 static int d4_launch_one(const D4Launch& a) {
@@ -1656,12 +1747,31 @@ static int d4_launch_one(const D4Launch& a) {
   if constexpr (TERMS == 9 && KS1 <= 4 && BN_ == 0 && !DBP) {
     if (a.terms == 6) return d4_launch_one<KIND, KS1, NPW, BN_, DBP, 6>(a);
   }
+  const int tiles = (a.rows + D4_BM - 1) / D4_BM;
+  const int rg_tiles = (tiles + a.row_groups - 1) / a.row_groups;
+  const int groups = (tiles + rg_tiles - 1) / rg_tiles;     // (no empty group)
+  if constexpr (TERMS == 9) {
+    if (a.fwd) {
+      auto ffn = a.t.u16 ? decoder_head4_kernel<KIND, KS1, true, NPW, BN_, DBP, G1, 9, true>
+                         : decoder_head4_kernel<KIND, KS1, false, NPW, BN_, DBP, G1, 9, true>;
+      SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(ffn), (int)a.lds));
+      hipLaunchKernelGGL(ffn, dim3(a.strips, groups), dim3(d4_threads(NPW)), a.lds, a.s, a.dA,
+                         a.dT, a.rows, a.Rpad, a.H, a.hp, a.F, a.t, a.B, a.gw, a.inline_lgamma,
+                         a.ll_part, a.dd_part, 0, rg_tiles, nullptr);
+      return 0;
+    }
+  }
   auto kfn = a.t.u16 ? decoder_head4_kernel<KIND, KS1, true, NPW, BN_, DBP, G1, TERMS>
                      : decoder_head4_kernel<KIND, KS1, false, NPW, BN_, DBP, G1, TERMS>;
   SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)a.lds));
-  hipLaunchKernelGGL(kfn, dim3(a.strips), dim3(d4_threads(NPW)), a.lds, a.s, a.dA, a.dT, a.rows,
-                     a.Rpad, a.H, a.hp, a.F, a.t, a.B, a.gw, a.inline_lgamma, a.ll_part,
-                     a.dd_part, a.dd_atomic);
+  hipLaunchKernelGGL(kfn, dim3(a.strips, groups), dim3(d4_threads(NPW)), a.lds, a.s, a.dA, a.dT,
+                     a.rows, a.Rpad, a.H, a.hp, a.F, a.t, a.B, a.gw, a.inline_lgamma, a.ll_part,
+                     a.dd_part, a.dd_atomic, rg_tiles, a.rg_slab);
+  if (groups > 1) {
+    constexpr int P = likelihood_heads(KIND);
+    hipLaunchKernelGGL(d4_rg_combine_kernel, dim3((a.F + 1023) / 1024, P * (a.H + 1)), dim3(256), 0,
+                       a.s, a.hp, P, a.H, a.F, a.rg_slab, groups - 1);
+  }
   return 0;
 }
 template <int KIND, int KS1>
@@ -1714,11 +1824,15 @@ static int d4_launch_kind(const D4Launch& a, const D4Config& c) {
 int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, int rows, int H,
                           HeadParams hp, int F, Targets t, int B, const float* gw,
                           int inline_lgamma, float* ll_part, float* dd_part, float* planes,
-                          const HeadDropout* drop, int cp_pass, const CpRows* cp, int dd_mode) {
+                          const HeadDropout* drop, int cp_pass, const CpRows* cp, int dd_mode,
+                          float* rg_slab) {
   const int P = likelihood_heads(kind);
-  const bool wide = !decoder_fused3_supported(P, H);     // (beyond H = 126: head4, training only)
-  SCVAE_ARG(planes && (!wide || (train && !drop && cp_pass == 0 && decoder_fused4_supported(P, H))));
-  SCVAE_ARG(train || P <= 2);
+  // (head4 alone: beyond the all-in-one-phase kernel's LDS budget; forward-only calls also the
+  //  widths and head counts that kernel's forward instantiation does not take -- odd widths, three
+  //  heads: decoder_fused_forward sends it exactly those)
+  const bool wide = !decoder_fused3_supported(P, H) ||
+                    (!train && cp_pass == 0 && (P > 2 || !decoder_fused_supported(H)));
+  SCVAE_ARG(planes && (!wide || (!drop && cp_pass == 0 && decoder_fused4_supported(P, H))));
   SCVAE_ARG(train || !drop);
   SCVAE_ARG((kind == LK_CPOISSON) == (cp_pass >= 1 && cp_pass <= 3 && cp && cp->count_sum));
   SCVAE_ARG(cp_pass == 0 || ((cp_pass == 3) == train && !drop));
@@ -1787,10 +1901,16 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
       case LK_BERNOULLI: SCVAE_D3(LK_BERNOULLI, true, true); break;
       default: set_error("decoder_head3_kernel: likelihood kind %d", kind); return -1;
     }
-  } else if (train && d3_schedule(P, H, rows) == 4) {
+  } else if ((train && d3_schedule(P, H, rows) == 4) || (!train && wide)) {
     const D4Config c = d4_config(P, H);
     D4Launch a{s, dA, dT, rows, Rpad, H, hp, F, t, B, gw, inline_lgamma, ll_part, dd_part,
-               (dd_mode & 1) ? 1 : 0, (F + c.bn - 1) / c.bn, c.lds, (dd_mode & 2) ? 6 : 9};
+               (dd_mode & 1) ? 1 : 0, (F + c.bn - 1) / c.bn, c.lds, (dd_mode & 2) ? 6 : 9, 1,
+               rg_slab};
+    a.fwd = !train;
+    if (a.fwd) { a.dd_atomic = 0; a.terms = 9; }
+    // (no slab from the caller: one group -- the stand-alone forward-only / probe entries; the
+    //  forward half leaves no dW and needs none)
+    if (rg_slab || a.fwd) a.row_groups = d4_row_groups(a.strips, rows);
     if (a.dd_atomic)    // eight XCD-local accumulators [8][H][rows], cleared for this launch
       SCVAE_HIP(hipMemsetAsync(dd_part, 0, (size_t)8 * H * rows * sizeof(float), s));
     int rc;

@@ -527,7 +527,7 @@ __global__ void gauss_latent_fwd_kernel(const float* __restrict__ mu_pre,
           z[o] = fmaf(sigma, eps[o], mu);
         }
       }
-      kl = 0.5f * (mu * mu + sigma * sigma - 1.f) - ls;
+      kl = gauss_kl_elem(mu, sigma, ls);
       kl_elem[i] = kl;
     }
     // block reduction over L (blockDim.x is a multiple of 64, <= 1024)
@@ -609,15 +609,15 @@ __global__ void gauss_latent_bwd_kernel(const float* __restrict__ mu_pre,
         csum += c;
       }
       gz += d;
-      gze += d * e;
+      gze = fmaf(d, e, gze);
     }
     float gmu, gls;
     if (kl_gw) {
       gmu = gz;
       gls = gze * sigma - csum;
     } else {
-      gmu = gz + kl_coeff * mu;
-      gls = gze * sigma + kl_coeff * (sigma * sigma - 1.f);
+      gmu = gauss_kl_dmu(gz, kl_coeff, mu);
+      gls = gauss_kl_dls(gze, sigma, kl_coeff);
     }
     dmu_pre[i] = (mp >= -F32_MAX_HALF && mp <= F32_MAX_HALF) ? gmu : 0.f;
     if (dls_pre) dls_pre[i] = (lp >= -3.f && lp <= 3.f) ? gls : 0.f;

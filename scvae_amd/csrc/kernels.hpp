@@ -231,7 +231,7 @@ struct TileBwdArgs {
 // out[i] = sum_g slabs[g][i] (g < G), fixed order; up to eight (slabs, n, G, out) jobs in one
 // launch: the weight-gradient slabs of a backward pass are independent of the chain of layers, so
 // they are summed together at its end
-constexpr int TC_MAX_JOBS = 8;
+constexpr int TC_MAX_JOBS = 10;
 struct SlabJobs {
   int n_jobs = 0;
   struct Job { const float* slabs; float* out; int n; int G; } job[TC_MAX_JOBS];
@@ -245,10 +245,59 @@ int tile_slab_reduce(hipStream_t s, const SlabJobs& q);
 // data-parallel steps: a layer's chunk statistics (forward) / chunk sums (backward) of this rank
 // merged into the layer's buffers, for the caller's hook to merge over the ranks; the tile kernels
 // take them as given where TileBN::part == nullptr
+// (groups > 1: `chunks` chunks and `rows` rows PER GROUP, statistics [groups][N] -- the GMVAE's
+//  K passes)
 int tile_stats_merge(hipStream_t s, const float* part, int chunks, int chunk, int rows, int N,
-                     float* mean, float* var);
+                     float* mean, float* var, int groups = 1);
 int tile_sums_merge(hipStream_t s, const float* part, int chunks, int N, const TileBN& bn,
-                    float bessel);
+                    float bessel, int groups = 1);
+
+// ---- the resident chain (tilechain.hip): the stages of a whole pass in one launch ----
+constexpr int TCR_MAX_STAGES = 12;   // stages of a launch
+constexpr int TCR_MAX_TILES = 7;     // tile stages (TileFwdArgs / TileBwdArgs) among them
+enum { TCS_TILE = 0, TCS_LATENT = 1, TCS_STATS = 2, TCS_REDUCE = 3 };
+struct TileLatent {            // the latent stage between the posterior heads and the decoder
+  const float* mu_pre = nullptr;
+  const float* ls_pre = nullptr;
+  const float* eps = nullptr;  // [S, B, L]
+  float* z = nullptr;          // forward: [S, B, L]
+  float* kl_elem = nullptr;    // [B, L]
+  float* kl_cell = nullptr;    // [B]
+  const float* dz = nullptr;   // backward: [S, B, L]
+  float* dmu = nullptr;
+  float* dls = nullptr;
+  float kl_coeff = 0.f;
+  int S = 1, B = 0, L = 0;
+};
+struct TileChainFwdArgs {
+  unsigned* bar = nullptr;     // grid-barrier counter and its value when this launch starts
+  unsigned bar_base = 0;
+  int n = 0;                   // stages
+  int kind[TCR_MAX_STAGES] = {};   // TCS_TILE (f[idx]) or TCS_LATENT
+  int idx[TCR_MAX_STAGES] = {};
+  int sync[TCR_MAX_STAGES] = {};   // after stage i: 1 workgroup barrier, 2 grid barrier (chunk
+                                   // statistics cross), 3 grid barrier with release / acquire
+  TileFwdArgs f[TCR_MAX_TILES];
+  TileLatent lat;
+};
+struct TileChainBwdArgs {
+  unsigned* bar = nullptr;
+  unsigned bar_base = 0;
+  int n = 0;
+  int kind[TCR_MAX_STAGES] = {};   // TCS_TILE (b[idx]), TCS_LATENT, TCS_STATS, TCS_REDUCE
+  int idx[TCR_MAX_STAGES] = {};
+  int sync[TCR_MAX_STAGES] = {};
+  TileBwdArgs b[TCR_MAX_TILES];
+  const float* stats_dh = nullptr;   // TCS_STATS: tile_backward_stats(stats_dh, stats_bn, ...)
+  TileBN stats_bn;
+  int stats_rows = 0, stats_N = 0;
+  TileLatent lat;
+  SlabJobs jobs;                     // TCS_REDUCE
+};
+int tile_chain_resident_capacity();   // workgroups the device holds at once (0: unknown)
+// one launch; *advance: what the barrier counter has gained once it has run
+int tile_chain_forward(hipStream_t s, const TileChainFwdArgs& q, int tiles, unsigned* advance);
+int tile_chain_backward(hipStream_t s, const TileChainBwdArgs& q, int tiles, unsigned* advance);
 
 struct HeadDropout;   // (below, with dropout_apply)
 // per-row inputs / second output of the constrained Poisson passes of decoder_head3_kernel
@@ -325,7 +374,11 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
                           HeadParams hp, int F, Targets t, int B, const float* gw,
                           int inline_lgamma, float* ll_part, float* dd_part, float* planes,
                           const HeadDropout* drop = nullptr, int cp_pass = 0,
-                          const CpRows* cp = nullptr, int dd_mode = 0);
+                          const CpRows* cp = nullptr, int dd_mode = 0, float* rg_slab = nullptr);
+// rg_slab (decoder_fused3_rg_slab_floats(H, F) floats, or nullptr: one row group): where the
+// producer / consumer kernel's row groups behind the first leave their dW / db (decoder_fused3.hip,
+// "row groups")
+size_t decoder_fused3_rg_slab_floats(int H, int F);
 // dd_mode 1: the per-strip partials of dd are not written as slabs but added (fp32 atomics, not
 // bit-repeatable) into eight XCD-local [H][rows] accumulators at dd_part; only where
 // decoder_fused3_dd_atomics says so (the producer / consumer training kernel)

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(MC_THREADS) void vae_mid_forward_kernel(MidChainArg
             q.z[o] = fmaf(sigma, q.eps[o], mu);
           }
         }
-        q.kl_elem[i] = 0.5f * (mu * mu + sigma * sigma - 1.f) - ls;
+        q.kl_elem[i] = gauss_kl_elem(mu, sigma, ls);
       }
     }
   }
@@ -617,8 +617,8 @@ __global__ __launch_bounds__(MC_THREADS) void vae_mid_backward_kernel(MidChainAr
           gz += dzv;
           gze += dzv * q.eps[(size_t)s * B * L + i];
         }
-        const float gmu = gz + q.kl_coeff * mu;
-        const float gls = gze * sigma + q.kl_coeff * (sigma * sigma - 1.f);
+        const float gmu = gauss_kl_dmu(gz, q.kl_coeff, mu);
+        const float gls = gauss_kl_dls(gze, sigma, q.kl_coeff);
         dm[j] = (mp[j] >= -F32_MAX_HALF && mp[j] <= F32_MAX_HALF) ? gmu : 0.f;
         dl[j] = (lp[j] >= -3.f && lp[j] <= 3.f) ? gls : 0.f;
         if (MC_MINE(j)) { q.dmu[i] = dm[j]; q.dls[i] = dl[j]; }

@@ -547,6 +547,21 @@ static bool tile_chain_ok(const scvae_plan* p, int B, int S, bool training) {
   for (int i = 0; i < 3; ++i) if (dropout_keep(c, i) > 0.f) return false;
   return p->tc_part[0] != nullptr;
 }
+// ... and its layers as ONE resident launch per direction (tilechain.hip): single process (a hook
+// needs the host between the stages), every workgroup of the launch co-resident with room to
+// spare for the step's second stream, stage and slab-job tables large enough
+static bool tile_resident_ok(const scvae_plan* p, int R) {
+  static const bool env_on = [] { const char* e = getenv("SCVAE_TILE_RESIDENT"); return !(e && e[0] == '0'); }();
+  if (!env_on || !p->use_tile_resident || p->sync || !p->mid_bar) return false;
+  const int tiles = (R + 63) / 64;
+  const int cap = tile_chain_resident_capacity();
+  if (tiles > cap / 2) return false;
+  const int n_enc = (int)p->enc.size(), n_dec = (int)p->dec.size();
+  if ((n_enc - 1) + 1 + n_dec + 1 > TCR_MAX_TILES) return false;            // forward tile stages
+  if (n_dec + 1 + n_enc > TCR_MAX_TILES) return false;                      // backward tile stages
+  if (n_dec + 4 + (n_enc - 1) > TC_MAX_JOBS) return false;                  // dW / db slab jobs
+  return true;
+}
 // the batch norm of layer d as the tile kernels see it
 static TileBN tile_bn(scvae_plan* p, Dense& d, const float* part, int chunks, int chunk,
                       float* part_out) {
@@ -793,6 +808,18 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   // ---------------- forward ----------------
   const bool mid = mid_chain_ok(p, B, S, training);
   const bool tile = !mid && tile_chain_ok(p, B, S, training);
+  // the tile stages of the pass: launched one by one, or collected for ONE resident launch
+  const bool resident = tile && tile_resident_ok(p, R);
+  TileChainFwdArgs cf;
+  int cf_tiles = 0;
+  auto fwd_stage = [&](const TileFwdArgs& q, int sync_after) -> int {
+    if (!resident) return tile_forward(s, q);
+    SCVAE_ARG(cf.n < TCR_MAX_STAGES && cf_tiles < TCR_MAX_TILES);
+    cf.f[cf_tiles] = q;
+    cf.kind[cf.n] = TCS_TILE; cf.idx[cf.n] = cf_tiles++; cf.sync[cf.n] = sync_after;
+    ++cf.n;
+    return 0;
+  };
   const float* h = p->step_x;   // (the fp32 batch, or the token of the uint16 one: plan_gemm)
   int ld = F;
   if (mid) {
@@ -825,7 +852,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       q.n_out = 1;
       q.o[0].W = p->params + d.w; q.o[0].b = p->params + d.b; q.o[0].out = d.a;
       q.o[0].part = p->tc_part[cur ^ 1]; q.o[0].N = d.n_out;
-      if ((rc = tile_forward(s, q))) return rc;
+      if ((rc = fwd_stage(q, 2))) return rc;
       cur ^= 1; chunk = 64; chunks = (B + 63) / 64;
     }
     {   // the two posterior heads on the normalised output of the last encoder layer
@@ -838,7 +865,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       q.o[0].N = L;
       q.o[1].W = p->params + p->ls.w; q.o[1].b = p->params + p->ls.b; q.o[1].out = p->ls_pre;
       q.o[1].N = L;
-      if ((rc = tile_forward(s, q))) return rc;
+      if ((rc = fwd_stage(q, 1))) return rc;     // (the latent stage needs the tile's own rows)
     }
     h = p->enc.back().h; ld = p->enc.back().n_out;
   } else {
@@ -856,7 +883,15 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const bool mc_kl = (c.latent_mode & 1) != 0;      // va:2633-2640
   const bool unit_var = (c.latent_mode & 2) != 0;   // du:323-337
   const float* ls_pre = unit_var ? nullptr : p->ls_pre;
-  if (tile) {
+  if (resident) {
+    // (tile_chain_ok: analytic KL, a log_sigma head, training: the stage restates that case)
+    SCVAE_ARG(cf.n < TCR_MAX_STAGES && !mc_kl && !unit_var && !a->deterministic_z && a->eps);
+    TileLatent& t = cf.lat;
+    t.mu_pre = p->mu_pre; t.ls_pre = p->ls_pre; t.eps = a->eps; t.z = p->z;
+    t.kl_elem = p->kl_elem; t.kl_cell = p->kl_cell; t.S = S; t.B = B; t.L = L;
+    cf.kind[cf.n] = TCS_LATENT; cf.sync[cf.n] = S == 1 ? 1 : 3;   // (decoder tile = its own cells)
+    ++cf.n;
+  } else if (tile) {
     if ((rc = gauss_latent_fwd(s, p->mu_pre, ls_pre, a->eps, p->z, p->kl_elem, p->kl_cell,
                                mc_kl ? p->kl_cell : nullptr, S, B, L, a->deterministic_z)))
       return rc;
@@ -875,10 +910,16 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                              mc_kl ? p->kl_cell : nullptr, S, B, L, a->deterministic_z)))
     return rc;
   }
-  if (a->kl_neurons)
-    if ((rc = col_sum(s, p->kl_elem, L, B, L, a->kl_neurons, 1.f / (float)GB, 0, p->partial))) return rc;
-  if (a->q_z_mean)
-    if ((rc = copy(s, p->mu_pre, a->q_z_mean, (size_t)B * L))) return rc;
+  // (under the resident chain the latent stage has not run yet: these follow its launch)
+  auto latent_outputs = [&]() -> int {
+    if (a->kl_neurons)
+      if (int r = col_sum(s, p->kl_elem, L, B, L, a->kl_neurons, 1.f / (float)GB, 0, p->partial)) return r;
+    if (a->q_z_mean)
+      if (int r = copy(s, p->mu_pre, a->q_z_mean, (size_t)B * L)) return r;
+    return 0;
+  };
+  if (!resident)
+    if ((rc = latent_outputs())) return rc;
 
   const int E = c.decoder_extra;
   const float* dec_in = p->z;   // decoder input: z, or [z | extra] (va:2407-2441)
@@ -909,8 +950,15 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
         q.o[0].W = p->params + d.w; q.o[0].b = p->params + d.b; q.o[0].out = d.a;
         q.o[0].part = p->tc_part[i == 0 ? cur : cur ^ 1]; q.o[0].N = d.n_out;
       }   // (i == size: the last layer's normalisation alone -> its h feeds the likelihood heads)
-      if ((rc = tile_forward(s, q))) return rc;
+      if ((rc = fwd_stage(q, 2))) return rc;
       if (i > 0) cur ^= 1;
+    }
+    if (resident) {
+      cf.bar = p->mid_bar; cf.bar_base = p->mid_bar_count;
+      unsigned advance = 0;
+      if ((rc = tile_chain_forward(s, cf, (R + 63) / 64, &advance))) return rc;
+      p->mid_bar_count += advance;
+      if ((rc = latent_outputs())) return rc;
     }
     dch = p->dec.back().h; ld = p->dec.back().n_out;
   } else {
@@ -935,12 +983,12 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     set_error("the constrained Poisson likelihood needs scvae_step_args.count_sum");
     return -1;
   }
-  // (every fused kernel takes even widths up to 126; a training step of one likelihood pass also
-  //  the bf16x9 producer / consumer kernel's wider range -- forward-only passes stay unfused there)
+  // (every fused kernel takes even widths up to 126; the bf16x9 producer / consumer kernel a wider
+  //  range -- odd widths, up to 256 -- for training steps and, its forward half, for evaluation
+  //  and the first pass of an importance-weighted step)
   const bool fused_width =
       decoder_fused_supported(h1) ||
-      (training && n_iw == 1 && !head_drop && !cpoisson &&
-       decoder_fused_train_supported(p->P, h1, p->head_arith));
+      (!head_drop && !cpoisson && decoder_fused_train_supported(p->P, h1, p->head_arith));
   const bool fused = p->use_fused && p->fused_ws && fused_width && ld == h1 &&
                      !a->p_x_mean && KM == 0 &&
                      (!head_drop || (heads_fused_dropout_ok(p, n_iw) && !cpoisson)) &&
@@ -1088,17 +1136,35 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     // the dW / db slabs of the layers wait for ONE fixed-order reduce at the end of the pass (they
     // are not on the chain's critical path: four launches fewer); slab buffer i <-> pending job i
     SlabJobs pending;
+    TileChainBwdArgs cb;          // (resident: the stages of the pass, launched once at its end)
+    int cb_tiles = 0;
+    auto bwd_stage = [&](const TileBwdArgs& q, int sync_after) -> int {
+      if (!resident) return tile_backward(s, q);
+      SCVAE_ARG(cb.n < TCR_MAX_STAGES && cb_tiles < TCR_MAX_TILES);
+      cb.b[cb_tiles] = q;
+      cb.kind[cb.n] = TCS_TILE; cb.idx[cb.n] = cb_tiles++; cb.sync[cb.n] = sync_after;
+      ++cb.n;
+      return 0;
+    };
     auto flush = [&]() -> int {
       if (pending.n_jobs == 0) return 0;
+      if (resident) {             // (tile_resident_ok: one table holds the jobs of the pass)
+        set_error("resident tile chain: slab job table overflow");
+        return -1;
+      }
       const int r = tile_slab_reduce(s, pending);
       pending.n_jobs = 0;
       return r;
     };
     {
       Dense& top = p->dec.back();
-      if ((rc = tile_backward_stats(s, dcur, tile_bn(p, top, nullptr, 0, 0, p->tc_spart[sp]), R,
-                                    top.n_out)))
+      const TileBN tb = tile_bn(p, top, nullptr, 0, 0, p->tc_spart[sp]);
+      if (resident) {
+        cb.stats_dh = dcur; cb.stats_bn = tb; cb.stats_rows = R; cb.stats_N = top.n_out;
+        cb.kind[cb.n] = TCS_STATS; cb.sync[cb.n] = 3; ++cb.n;
+      } else if ((rc = tile_backward_stats(s, dcur, tb, R, top.n_out))) {
         return rc;
+      }
     }
     auto layer_backward = [&](Dense& d, Dense* below, const float* in, int rows, int64_t grows,
                               const float* dh_in, float* d_in, float* dA_out) -> int {
@@ -1116,7 +1182,9 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       }
       q.in = in; q.K = in ? d.n_in : 0; q.d_in = d_in;
       if (below) q.below = tile_bn(p, *below, nullptr, 0, 0, p->tc_spart[sp ^ 1]);
-      int r = tile_backward(s, q);
+      // what follows needs every tile's chunk sums (a layer below), every slab (the last stage)
+      // or -- the first decoder layer, then the latent stage -- the rows of this tile's cells
+      int r = bwd_stage(q, (below || !in) ? 3 : (S == 1 ? 1 : 3));
       if (r || !in) return r;
       pending.job[pending.n_jobs++] = {slab, p->grads + d.w, d.n_in * d.n_out, G};
       sp ^= 1;
@@ -1130,9 +1198,16 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
         return rc;
       if (i > 0) { float* t = dcur; dcur = dalt; dalt = t; }
     }
-    if ((rc = gauss_latent_bwd(s, p->mu_pre, ls_pre, a->eps, p->dz, w / (float)GB, nullptr, p->dmu,
-                               p->dls, S, B, L)))
+    if (resident) {
+      SCVAE_ARG(cb.n < TCR_MAX_STAGES);
+      TileLatent& t = cb.lat;
+      t.mu_pre = p->mu_pre; t.ls_pre = p->ls_pre; t.eps = a->eps; t.dz = p->dz;
+      t.dmu = p->dmu; t.dls = p->dls; t.kl_coeff = w / (float)GB; t.S = S; t.B = B; t.L = L;
+      cb.kind[cb.n] = TCS_LATENT; cb.sync[cb.n] = 1; ++cb.n;   // (the heads' tile: the same cells)
+    } else if ((rc = gauss_latent_bwd(s, p->mu_pre, ls_pre, a->eps, p->dz, w / (float)GB, nullptr,
+                                      p->dmu, p->dls, S, B, L))) {
       return rc;
+    }
     float* dh = p->dbuf[0];
     float* dh_alt = p->dbuf[1];
     {   // the two posterior heads: dW, db of both, dh of the last encoder layer and its chunk sums
@@ -1151,7 +1226,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       }
       q.in = last.h; q.K = K; q.d_in = dh;
       q.below = tile_bn(p, last, nullptr, 0, 0, p->tc_spart[sp]);
-      if ((rc = tile_backward(s, q))) return rc;
+      if ((rc = bwd_stage(q, 3))) return rc;
       // (jobs i and i + 1 own slab buffers i and i + 1; the two bias jobs ride in the same
       //  buffers and only take job slots)
       const int j0 = pending.n_jobs;
@@ -1170,6 +1245,17 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     // the layer that sees x: its dA here, its weight gradient x^T dA on the count kernels
     Dense& d0 = p->enc[0];
     if ((rc = layer_backward(d0, nullptr, nullptr, B, GB, dh, nullptr, p->dbuf[2]))) return rc;
+    if (resident) {
+      // (the slab sums stay a launch of their own: every tile's slabs would have to cross the
+      //  XCDs' L2s behind a full release / acquire barrier)
+      cb.bar = p->mid_bar; cb.bar_base = p->mid_bar_count;
+      unsigned advance = 0;
+      if ((rc = tile_chain_backward(s, cb, (R + 63) / 64, &advance))) return rc;
+      p->mid_bar_count += advance;
+      const int r = tile_slab_reduce(s, pending);
+      pending.n_jobs = 0;
+      if (r) return r;
+    }
     if ((rc = flush())) return rc;
     if (p->sync && p->early_reduce_layer == &d0) {
       // (data parallel: everything between ENCODER/1 and the likelihood heads is final -- its
@@ -1451,6 +1537,17 @@ int32_t scvae_plan_uses_tile_chain(const scvae_plan* p, int64_t cells, int32_t s
   if (p->cfg.model_type == SCVAE_MODEL_GMVAE)   // (the K stacked passes as tile-chain groups)
     return scvae::gm_tile_chain_ok(p, (int)cells, samples, true) ? 1 : 0;
   return tile_chain_ok(p, (int)cells, samples, true) ? 1 : 0;
+}
+int scvae_plan_set_tile_resident(scvae_plan* p, int32_t enabled) {
+  SCVAE_ARG(p);
+  p->use_tile_resident = enabled ? 1 : 0;
+  return 0;
+}
+int32_t scvae_plan_uses_tile_resident(const scvae_plan* p, int64_t cells, int32_t samples) {
+  if (!p || cells <= 0 || samples <= 0 || p->cfg.model_type != SCVAE_MODEL_VAE) return 0;
+  return tile_chain_ok(p, (int)cells, samples, true) &&
+                 tile_resident_ok(p, (int)(cells * samples))
+             ? 1 : 0;
 }
 int scvae_plan_set_mid_chain(scvae_plan* p, int32_t enabled) {
   SCVAE_ARG(p);
@@ -1814,9 +1911,9 @@ static int decoder_fused_entry(int32_t kind, int32_t train, const float* d, int6
                     : (train & SCVAE_HEADS_BF16X9) ? 1
                     : (train & SCVAE_HEADS_BF16X6) ? 2 : scvae::default_head_arith();
   train &= 3;
-  // (forward-only calls: even widths up to 126; training also the bf16x9 kernel's wider range)
-  SCVAE_ARG(train ? scvae::decoder_fused_train_supported(scvae::likelihood_heads(kind), (int)H, arith)
-                  : scvae::decoder_fused_supported((int)H));
+  // (even widths up to 126: every arithmetic; the bf16x9 kernel's wider range -- odd widths, up
+  //  to 256 -- for training and, its forward half, forward-only calls)
+  SCVAE_ARG(scvae::decoder_fused_train_supported(scvae::likelihood_heads(kind), (int)H, arith));
   scvae::HeadParams hp;
   for (int j = 0; j < 3; ++j) {
     const bool on = j < scvae::likelihood_heads(kind);

@@ -175,6 +175,9 @@ struct scvae_plan {
   ~scvae_plan();
   int use_mid_chain = 1;      // small VAE steps: hidden layers + heads + latent in two launches
   int use_tile_chain = 1;     // large VAE training steps: one launch per hidden layer and direction
+  int use_tile_resident = 0;  // ... and, single process, the layers of a pass in ONE resident launch
+                              // (tilechain.hip: grid barriers instead of kernel boundaries).  Off
+                              // by default: measured slower than the per-layer launches
   float* tc_part[2] = {nullptr, nullptr};    // tilechain.hip: chunk statistics (forward), ping-pong
   float* tc_spart[2] = {nullptr, nullptr};   // ... chunk sums of the batch-norm backward
   float* tc_slab[TC_MAX_JOBS] = {};          // ... dW / db slabs of the layers of a backward pass

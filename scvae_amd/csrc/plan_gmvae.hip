@@ -212,12 +212,17 @@ size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t
 
 // ---- the K stacked passes through q(z|x,y) and p(x|z,y) with one launch per hidden layer and
 //      direction (tilechain.hip with groups: the rows of pass k are a range of 64-row tiles with
-//      their own batch statistics).  Training steps with batch normalisation, no dropout, no
-//      data-parallel hook, whole tiles per pass, layers and latent at most 128 wide. ----
+//      their own batch statistics).  Training steps with batch normalisation, no dropout, whole
+//      tiles per pass, layers and latent at most 128 wide.  Under a data-parallel hook
+//      (scvae_plan_set_sync) the statistics of a layer are those of the global minibatch: the
+//      rank's chunks are merged per pass by a small kernel, the hook merges the ranks (the K
+//      passes' statistics in ONE collective, as the launch chain issues it), and the consuming
+//      tile kernel takes them as given -- gm_tile_bn_forward / gm_tile_bn_backward, the VAE's
+//      tile_bn_forward / tile_bn_backward (plan.hip) with groups. ----
 bool gm_tile_chain_ok(const scvae_plan* p, int B, int S, bool training) {
   const scvae_model_config& c = p->cfg;
   static const bool env_on = [] { const char* e = getenv("SCVAE_TILE_CHAIN"); return !(e && e[0] == '0'); }();
-  if (!env_on || !p->use_tile_chain || p->sync || !training || !c.batch_norm) return false;
+  if (!env_on || !p->use_tile_chain || !training || !c.batch_norm) return false;
   if (p->zenc.empty() || p->xdec.empty() || c.decoder_extra != 0 || c.latent_size > 128) return false;
   if (B % 64 != 0 || ((int64_t)B * S) % 64 != 0) return false;
   for (const auto& d : p->zenc) if (d.n_out > 128 || !d.bn) return false;
@@ -238,6 +243,45 @@ static TileBN gm_tile_bn(scvae_plan* p, Dense& d, int K, int group_rows, const f
   t.dbeta = p->grads ? p->grads + d.beta : nullptr;
   t.mov_mean = p->moving + d.mov_mean; t.mov_var = p->moving + d.mov_var;
   return t;
+}
+
+// the batch norm of layer d for the tile kernel that CONSUMES its forward statistics: merged by
+// that kernel from the chunk statistics `part` (single process), or -- data parallel -- merged
+// here per pass, over the ranks by the hook, and handed over as given
+static int gm_tile_bn_forward(scvae_plan* p, hipStream_t s, Dense& d, int K, int group_rows,
+                              const float* part, TileBN* out) {
+  if (!p->sync) {
+    *out = gm_tile_bn(p, d, K, group_rows, part, nullptr);
+    return 0;
+  }
+  const int N = d.n_out;
+  TileBN t = gm_tile_bn(p, d, K, group_rows, nullptr, nullptr);
+  int rc = tile_stats_merge(s, part, group_rows / 64, 64, group_rows, N, t.mean, t.var, K);
+  if (rc) return rc;
+  if (p->sync(p->sync_user, d.stats, 2 * (int64_t)K * N, 1, group_rows)) {
+    set_error("batch-norm sync hook failed");
+    return -2;
+  }
+  *out = t;
+  return 0;
+}
+// ... and for the tile kernel that consumes its backward sums (s1, s2: [K][N] behind mean / var)
+static int gm_tile_bn_backward(scvae_plan* p, hipStream_t s, Dense& d, int K, int group_rows,
+                               const float* part, float bessel, TileBN* out) {
+  if (!p->sync) {
+    *out = gm_tile_bn(p, d, K, group_rows, part, nullptr);
+    return 0;
+  }
+  const int N = d.n_out;
+  TileBN t = gm_tile_bn(p, d, K, group_rows, nullptr, nullptr);
+  int rc = tile_sums_merge(s, part, group_rows / 64, N, t, bessel, K);
+  if (rc) return rc;
+  if (p->sync(p->sync_user, t.s1, 2 * (int64_t)K * N, 0, group_rows)) {
+    set_error("batch-norm backward sync hook failed");
+    return -2;
+  }
+  *out = t;
+  return 0;
 }
 
 int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
@@ -323,7 +367,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       TileFwdArgs q;
       q.rows = KB; q.K = d.n_in;
       if (i == 1) { q.x = p->zenc[0].h; q.ldx = d.n_in; }
-      else q.bn = gm_tile_bn(p, p->zenc[i - 1], K, B, p->tc_part[tcur], nullptr);
+      else TRY(gm_tile_bn_forward(p, s, p->zenc[i - 1], K, B, p->tc_part[tcur], &q.bn));
       q.n_out = 1;
       q.o[0].W = p->params + d.w; q.o[0].b = p->params + d.b; q.o[0].out = d.a;
       q.o[0].part = p->tc_part[i == 1 ? tcur : tcur ^ 1]; q.o[0].N = d.n_out;
@@ -346,7 +390,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     TileFwdArgs q;
     q.rows = KB; q.K = p->zenc.back().n_out;
     if (p->zenc.size() == 1) { q.x = p->zenc[0].h; q.ldx = q.K; }
-    else q.bn = gm_tile_bn(p, p->zenc.back(), K, B, p->tc_part[tcur], nullptr);
+    else TRY(gm_tile_bn_forward(p, s, p->zenc.back(), K, B, p->tc_part[tcur], &q.bn));
     q.n_out = 2;
     q.o[0].W = p->params + p->qmean.w; q.o[0].b = p->params + p->qmean.b; q.o[0].out = p->qm;
     q.o[0].N = L;
@@ -406,7 +450,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       if (i == 0) { q.x = dec_in; q.ldx = L; q.K = L; }
       else {
         q.K = p->xdec[i - 1].n_out;
-        q.bn = gm_tile_bn(p, p->xdec[i - 1], K, SB, p->tc_part[cur], nullptr);
+        TRY(gm_tile_bn_forward(p, s, p->xdec[i - 1], K, SB, p->tc_part[cur], &q.bn));
       }
       if (i < p->xdec.size()) {
         Dense& d = p->xdec[i];
@@ -440,8 +484,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   const bool fused_width =
       decoder_fused_supported(h1) ||
-      (training && !head_drop && !cpoisson &&
-       decoder_fused_train_supported(p->P, h1, p->head_arith));
+      (!head_drop && !cpoisson && decoder_fused_train_supported(p->P, h1, p->head_arith));
   const bool fused = p->use_fused && p->fused_ws && fused_width && ld == h1 &&
                      !a->p_x_mean && KM == 0 &&
                      (!head_drop || (heads_fused_dropout_ok(p, 1) && !cpoisson)) &&
@@ -579,7 +622,10 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     float* slab = p->tc_slab[pending.n_jobs % TC_MAX_JOBS];
     q.up[0].g = dh_in; q.up[0].W = p->params + d.w; q.up[0].N = d.n_out;
     q.up[0].dW_slab = slab;
-    q.bn = gm_tile_bn(p, d, K, group_rows, p->tc_spart[sp], nullptr);
+    {
+      const int r = gm_tile_bn_backward(p, s, d, K, group_rows, p->tc_spart[sp], q.bessel, &q.bn);
+      if (r) return r;
+    }
     q.in = in; q.K = d.n_in; q.d_in = d_in;
     if (below) q.below = gm_tile_bn(p, *below, K, group_rows, nullptr, p->tc_spart[sp ^ 1]);
     const int r = tile_backward(s, q);

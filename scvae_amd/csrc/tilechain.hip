@@ -131,207 +131,247 @@ struct LinePre {
     }
   }
 };
+// What crosses workgroups INSIDE a launch of the resident chain (below) -- the chunk statistics
+// and chunk sums of the batch norms, a few hundred bytes per tile -- is written and read with
+// agent-scope accesses (global_store / global_load ... sc1: performed at the memory side, past
+// the XCD's own L2), so that the grid barrier between two stages needs no L2 write-back and no
+// invalidate.  The per-layer launches use the same accessors (same code, same bits).
+__device__ __forceinline__ float ld_agent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #ifdef SCVAE_TC_PROBE
-__device__ unsigned long long g_tc_probe[2][16];
-#define TCP(i) do { if (tid == 0 && blockIdx.x == 1) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-  atomicAdd(&g_tc_probe[q.bn.a && q.bn.part ? 1 : 0][i], t_ - tlast); tlast = t_; } } while (0)
+// phase probe of the resident kernels (workgroup 1, thread 0): s_memtime ticks per (stage, phase),
+// summed over the launches; slot 5 * stage + {0 run, 1 stores done, 2 issue, 3 wait, 4 partials},
+// slot 63: launches
+__device__ unsigned long long g_tc_probe[2][64];
+extern "C" int scvae_debug_tc_probe(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tc_probe), sizeof(g_tc_probe));
+}
+#define TCP_RUN(slot) do { if (threadIdx.x == 0 && blockIdx.x == 1) { \
+  const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+  atomicAdd(&g_tc_probe[0][slot], t_ - trun); trun = t_; } } while (0)
+#define TCP_RUN_BEGIN unsigned long long trun = __builtin_amdgcn_s_memtime()
+#define TCP_BEGIN(dir) unsigned long long tlast = __builtin_amdgcn_s_memtime(); const int tdir = dir; \
+  if (threadIdx.x == 0 && blockIdx.x == 1) atomicAdd(&g_tc_probe[tdir][63], 1ull)
+#define TCP(slot) do { if (threadIdx.x == 0 && blockIdx.x == 1) { \
+  const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+  atomicAdd(&g_tc_probe[tdir][slot], t_ - tlast); tlast = t_; } } while (0)
 #else
-#define TCP(i) do {} while (0)
+#define TCP_RUN(slot) do {} while (0)
+#define TCP_RUN_BEGIN do {} while (0)
+#define TCP_BEGIN(dir) do {} while (0)
+#define TCP(slot) do {} while (0)
 #endif
-__global__ __launch_bounds__(TC_THREADS) void tile_fwd_kernel(TileFwdArgs q) {
-  extern __shared__ __attribute__((aligned(16))) float tsm[];
-  float* As = tsm;                               // [64][TC_LD]
-  float* Bs = As + TC_ROWS * TC_LD;              // [K2][TC_LD], then the output tile
-  float* st = Bs + TC_MAXN * TC_LD;              // [3][128]: mean, istd, beta
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = blockIdx.x, r0 = g * TC_ROWS;
-  const int nr = min(TC_ROWS, q.rows - r0);
-  const int K = q.K, K2 = (K + 1) & ~1;
-#ifdef SCVAE_TC_PROBE
-  unsigned long long tlast = __builtin_amdgcn_s_memtime();
-  if (tid == 0 && blockIdx.x == 1) atomicAdd(&g_tc_probe[q.bn.a && q.bn.part ? 1 : 0][15], 1ull);
-#endif
-  // ---- every input of the kernel is requested up front: the first weight matrix, the input
-  //      tile, the chunk statistics of the layer below ----
-  // (the chunk statistics of the layer below first: they are needed first, and a wave's loads
-  //  return in order -- behind the 48 scalar loads of the two tiles they arrived 3 us later)
-  const bool merge_here = q.bn.a && q.bn.part;
-  LinePre<8> pp_first;
-  if (merge_here) {
-    const int gt0 = q.bn.group_tiles;
-    const int zfirst0 = gt0 ? (g / gt0) * gt0 : 0;
-    const int zn0 = min(64, gt0 ? gt0 : q.bn.chunks);
-    pp_first.load(q.bn.part + (size_t)zfirst0 * 2 * K, zn0 * 2 * K, tid);
-  }
+constexpr int TC_ZPT = 64 / TC_RG;    // chunks per thread in a block of 64 chunks
+
+// One tile (workgroup g) of one forward stage, in three steps so that the resident chain can put
+// its grid barrier between them: tile_fwd_issue requests what does not depend on other tiles (the
+// first weight matrix, the tile's own input rows), tile_fwd_partials requests the first 64 chunk
+// statistics of the layer below (every tile's: after the barrier), tile_fwd_run does the work.
+// Thread (c = tid & 127, rl = tid >> 7) owns column c of rows rl, rl + 4, ... of the tile -- of
+// the input tile (TilePre), through the normalisation, and of the output tile in the epilogue:
+// normalisation, bias, the tile's statistics run on registers.
+struct TileFwdRegs {
   TilePre<128 / TC_RG> pw;              // [K, N] weights (<= 128 x 128)
   TilePre<TC_ROWS / TC_RG> pa;          // [64, K] input tile
+};
+struct TileFwdPart {
+  float pm[TC_ZPT], pv[TC_ZPT];         // chunk (mean, M2) of chunks rl, rl + 4, ... of a block
+};
+__device__ __forceinline__ void tile_fwd_issue(const TileFwdArgs& q, TileFwdRegs& R, const int g) {
+  const int tid = threadIdx.x;
+  const int r0 = g * TC_ROWS;
+  const int nr = min(TC_ROWS, q.rows - r0);
+  const int K = q.K;
   const int n_w0 = q.n_out > 0 ? K * q.o[0].N : 0;
-  pw.load(q.n_out > 0 ? q.o[0].W : q.x, n_w0, tid, q.n_out > 0 ? q.o[0].N : 1);
+  R.pw.load(q.n_out > 0 ? q.o[0].W : q.x, n_w0, tid, q.n_out > 0 ? q.o[0].N : 1);
   const float* src_a = q.bn.a ? q.bn.a + (size_t)r0 * K : q.x + (size_t)r0 * q.ldx;
-  pa.load(src_a, nr * K, tid, K);
+  R.pa.load(src_a, nr * K, tid, K);
+}
+// chunks z0 + rl, z0 + rl + 4, ... (those below zn) of column c
+__device__ __forceinline__ void tile_part_load(const float* __restrict__ part, int K, int zbase,
+                                               int zn, float* pm, float* pv) {
+  const int c = threadIdx.x & 127, rl = threadIdx.x >> 7;
+#pragma unroll
+  for (int j = 0; j < TC_ZPT; ++j) {
+    const int z = rl + TC_RG * j;
+    const bool on = z < zn && c < K;
+    const float* pz = part + (size_t)(zbase + (on ? z : 0)) * 2 * K + (on ? c : 0);
+    pm[j] = on ? ld_agent(pz) : 0.f;
+    pv[j] = on ? ld_agent(pz + K) : 0.f;
+  }
+}
+__device__ __forceinline__ void tile_fwd_partials(const TileFwdArgs& q, TileFwdPart& P, const int g) {
+  if (!(q.bn.a && q.bn.part)) return;
+  const int gt = q.bn.group_tiles;
+  const int zfirst = gt ? (g / gt) * gt : 0;
+  tile_part_load(q.bn.part, q.K, zfirst, min(64, gt ? gt : q.bn.chunks), P.pm, P.pv);
+}
+__device__ __forceinline__ void tile_fwd_run(const TileFwdArgs& q, TileFwdRegs& R, TileFwdPart& P,
+                                             float* tsm, const int g) {
+  float* As = tsm;                               // [64][TC_LD]
+  float* Bs = As + TC_ROWS * TC_LD;              // [K2][TC_LD], then the output tile
+  float* X = Bs + TC_MAXN * TC_LD;               // [TC_RG][128]: the row groups' partial sums
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = tid & 127, rl = tid >> 7;
+  const int r0 = g * TC_ROWS;
+  const int nr = min(TC_ROWS, q.rows - r0);
+  const int K = q.K, K2 = (K + 1) & ~1;
+  // the second weight matrix (the posterior heads) travels under the first product
+  TCP_RUN_BEGIN;
+  TilePre<128 / TC_RG> pw2;
+  if (q.n_out > 1) pw2.load(q.o[1].W, K * q.o[1].N, tid, q.o[1].N);
+  float bias[2];
+#pragma unroll
+  for (int o = 0; o < 2; ++o) bias[o] = (o < q.n_out && c < q.o[o].N) ? q.o[o].b[c] : 0.f;
+  // ---- the batch statistics of the layer below, column c ----
+  float mean_c = 0.f, istd_c = 0.f, beta_c = 0.f;
   if (q.bn.a && !q.bn.part) {
-    // the statistics are given (merged over this rank's chunks by tile_stats_merge and over the
-    // ranks by the caller's hook: data-parallel steps, scvae_plan_set_sync)
-    if (tid < K) {
-      st[tid] = q.bn.mean[tid];
-      st[TC_MAXN + tid] = rsqrtf(q.bn.var[tid] + BN_EPSILON);
-      st[2 * TC_MAXN + tid] = q.bn.beta[tid];
+    // given (merged over this rank's chunks by tile_stats_merge and over the ranks by the
+    // caller's hook: data-parallel steps, scvae_plan_set_sync)
+    if (c < K) {
+      const int grp = q.bn.group_tiles ? g / q.bn.group_tiles : 0;    // (its group's: [groups][K])
+      mean_c = q.bn.mean[grp * K + c];
+      istd_c = rsqrtf(q.bn.var[grp * K + c] + BN_EPSILON);
+      beta_c = q.bn.beta[c];
     }
   } else if (q.bn.a) {
-    // (the chunk statistics pass through LDS, 64 chunks at a time: a thread walking its column's
-    //  chunks in global memory pays a round trip per chunk.  Two passes -- mean, then M2 about it
-    //  -- in chunk order: fixed, so every workgroup of the launch arrives at the same bits)
+    // merged here, by every workgroup alike: two passes -- mean, then M2 about it -- over the
+    // chunks in a fixed order (thread (c, rl): chunks rl, rl + 4, ... of each block of 64, the
+    // four row groups' sums added in group order), so every workgroup arrives at the same bits.
     // (groups: the statistics of this tile's group alone -- its group_tiles chunks of 64 rows)
     const int gt = q.bn.group_tiles;
     const int grp = gt ? g / gt : 0, zfirst = grp * gt;
     const int chunks = gt ? gt : q.bn.chunks, chunk = q.bn.chunk;
     const int rows_g = gt ? gt * TC_ROWS : q.rows;
+    const float n_full = (float)chunk;
+    const float n_last = (float)(rows_g - (chunks - 1) * chunk);
+    if (c < K) beta_c = q.bn.beta[c];
     float mean = 0.f, m2 = 0.f;
     for (int pass = 0; pass < 2; ++pass) {
       for (int z0 = 0; z0 < chunks; z0 += 64) {
         const int zn = min(64, chunks - z0);
-        if (pass == 0 || chunks > 64) {     // (a single block stays in LDS for the second pass)
-          LinePre<8> pp;
-          if (pass == 0 && z0 == 0) pp = pp_first;
-          else pp.load(q.bn.part + (size_t)(zfirst + z0) * 2 * K, zn * 2 * K, tid);
-          lds_barrier();
-          pp.store_linear(Bs, zn * 2 * K, tid);
-          lds_barrier();
-          TCP(pass);          // 0/1: chunk statistics arrived in LDS
-        }
-        {
-          // thread (column c, group zg) takes the chunks z = zg mod TC_RG; the groups' partial
-          // sums are combined in group order: a fixed order, the same bits in every workgroup
-          const int c = tid & 127, zg = tid >> 7;
-          const float n_full = (float)chunk;
-          const float n_last = (float)(rows_g - (chunks - 1) * chunk);
-          float part_sum = 0.f;
-          if (c < K) {
-#pragma unroll 4
-            for (int z = zg; z < 64; z += TC_RG) {
-              const bool on = z < zn;
-              const float n = on ? (z0 + z == chunks - 1 ? n_last : n_full) : 0.f;
-              const float* pz = Bs + (on ? z : 0) * 2 * K;
-              if (pass == 0) part_sum = bn_merge_mean(part_sum, n, pz[c]);
-              else part_sum = on ? bn_merge_m2(part_sum, n, pz[c], pz[K + c], st[c]) : part_sum;
-            }
-          }
-          lds_barrier();
-          st[(1 + zg) * TC_MAXN + c] = part_sum;
-          lds_barrier();
-          if (tid < K) {
-            float total = st[TC_MAXN + tid];
+        // (block 0 arrived with P; a single block stays in registers for the second pass)
+        if (chunks > 64 && !(pass == 0 && z0 == 0))
+          tile_part_load(q.bn.part, K, zfirst + z0, zn, P.pm, P.pv);
+        float part_sum = 0.f;
 #pragma unroll
-            for (int j = 1; j < TC_RG; ++j) total += st[(1 + j) * TC_MAXN + tid];
-            if (pass == 0) mean += total; else m2 += total;
+        for (int j = 0; j < TC_ZPT; ++j) {
+          const int z = rl + TC_RG * j;
+          if (z < zn) {
+            const float n = z0 + z == chunks - 1 ? n_last : n_full;
+            part_sum = pass == 0 ? bn_merge_mean(part_sum, n, P.pm[j])
+                                 : bn_merge_m2(part_sum, n, P.pm[j], P.pv[j], mean);
           }
         }
-      }
-      if (pass == 0) {
-        // (the mean of the whole minibatch, broadcast to the column's other threads through st)
-        mean /= (float)rows_g;
         lds_barrier();
-        if (tid < K) st[tid] = mean;
+        X[rl * TC_MAXN + c] = part_sum;
         lds_barrier();
+        float total = X[c];
+#pragma unroll
+        for (int j = 1; j < TC_RG; ++j) total += X[j * TC_MAXN + c];
+        if (pass == 0) mean += total; else m2 += total;
       }
+      if (pass == 0) mean /= (float)rows_g;
     }
-    if (tid < K) {
-      const float var = m2 / (float)rows_g;
-      st[tid] = mean;
-      st[TC_MAXN + tid] = rsqrtf(var + BN_EPSILON);
-      st[2 * TC_MAXN + tid] = q.bn.beta[tid];
-      if (g == zfirst) { q.bn.mean[grp * K + tid] = mean; q.bn.var[grp * K + tid] = var; }
-    }
+    const float var = m2 / (float)rows_g;
+    mean_c = mean;
+    istd_c = rsqrtf(var + BN_EPSILON);
+    if (g == zfirst && rl == 0 && c < K) { q.bn.mean[grp * K + c] = mean; q.bn.var[grp * K + c] = var; }
   }
-  lds_barrier();        // (As zeroed, statistics in st, Bs free)
-  TCP(2);               // merge done
-  pa.store(As, (K + 31) & ~31, TC_ROWS, tid);
-  if (q.bn.a) {
-    lds_barrier();
-    const int c = tid & 127, rl = tid >> 7;
-    if (c < K) {
-#pragma unroll 4
-      for (int r = rl; r < nr; r += TC_RG) {
-        float v = bn_normalise(As[r * TC_LD + c], st[c], st[TC_MAXN + c], st[2 * TC_MAXN + c]);
-        v = fmaxf(v, 0.f);
-        As[r * TC_LD + c] = v;
+  TCP_RUN(40);    // statistics merged
+  // ---- the input tile: normalise + relu in registers, h written out once ----
+  if (q.bn.a && c < K) {
+#pragma unroll
+    for (int u = 0; u < TC_ROWS / TC_RG; ++u) {
+      const int r = rl + TC_RG * u;
+      if (r < nr) {
+        const float v = fmaxf(bn_normalise(R.pa.v[u], mean_c, istd_c, beta_c), 0.f);
+        R.pa.v[u] = v;
         q.bn.h[(size_t)(r0 + r) * K + c] = v;
       }
     }
   }
-  TCP(3);               // input tile landed, normalised, h written
+  if (q.n_out > 0) {
+    lds_barrier();        // (As / Bs free: an earlier stage of a resident launch is done with them)
+    R.pa.store(As, (K + 31) & ~31, TC_ROWS, tid);
+  }
+  TCP_RUN(41);    // normalised, h stored, tile -> LDS
   // ---- products ----
   for (int o = 0; o < q.n_out; ++o) {
     const TileFwdArgs::Out& out = q.o[o];
     const int N = out.N;
-    if (o > 0) pw.load(out.W, K * N, tid, N);
-    lds_barrier();     // (As written / the previous output tile consumed)
-    pw.store(Bs, (N + 31) & ~31, K2, tid);
+    if (o > 0) lds_barrier();     // (the previous output tile consumed)
+    if (o == 0) R.pw.store(Bs, (N + 31) & ~31, K2, tid);
+    else pw2.store(Bs, (N + 31) & ~31, K2, tid);
     lds_barrier();
-    TCP(4);             // weights in LDS
+    TCP_RUN(42);    // weights -> LDS
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     tile_mma(As, Bs, K2, N, w, lane, acc);
     lds_barrier();     // (all waves done with Bs)
-    TCP(5);            // product
+    TCP_RUN(43);    // product
     tile_store(Bs, N, w, lane, acc);
     lds_barrier();
-    // bias, store, chunk statistics of the tile (two-pass, as bn_stats_partial_kernel)
-    {
-      const int c = tid & 127, rl = tid >> 7;
-      const float bv = c < N ? out.b[c] : 0.f;
-      for (int r = rl; r < nr; r += TC_RG)
-        if (c < N) {
-          const float v = Bs[r * TC_LD + c] + bv;
-          Bs[r * TC_LD + c] = v;
-          out.out[(size_t)(r0 + r) * N + c] = v;
-        }
-    }
-    TCP(6);            // bias + output stored
-    if (out.part) {
-      // chunk statistics of the tile, two-pass (mean, then M2 about it); two threads per column
-      lds_barrier();
-      const int c = tid & 127, rl = tid >> 7;
-      float sum = 0.f;
-      if (c < N) {
-#pragma unroll 8
-        for (int r = rl; r < TC_ROWS; r += TC_RG) sum += (r < nr) ? Bs[r * TC_LD + c] : 0.f;
-      }
-      st[rl * TC_MAXN + c] = sum;
-      lds_barrier();
-      float tot = st[c];
+    TCP_RUN(44);    // accumulators -> LDS
+    // bias, store, chunk statistics of the tile (two-pass, as bn_stats_partial_kernel) on the
+    // thread's sixteen values of column c
+    const float bv = o == 0 ? bias[0] : bias[1];
+    float v[TC_ROWS / TC_RG];
+    float sum = 0.f;
 #pragma unroll
-      for (int j = 1; j < TC_RG; ++j) tot += st[j * TC_MAXN + c];
+    for (int u = 0; u < TC_ROWS / TC_RG; ++u) {
+      const int r = rl + TC_RG * u;
+      const bool live = c < N && r < nr;
+      v[u] = live ? Bs[r * TC_LD + c] + bv : 0.f;
+      if (live) out.out[(size_t)(r0 + r) * N + c] = v[u];
+      sum += v[u];
+    }
+    TCP_RUN(45);    // bias + output stored
+    if (out.part) {
+      lds_barrier();
+      X[rl * TC_MAXN + c] = sum;
+      lds_barrier();
+      float tot = X[c];
+#pragma unroll
+      for (int j = 1; j < TC_RG; ++j) tot += X[j * TC_MAXN + c];
       const float mu = tot / (float)nr;
       float m2 = 0.f;
-      if (c < N) {
-#pragma unroll 8
-        for (int r = rl; r < TC_ROWS; r += TC_RG) {
-          const float d = Bs[r * TC_LD + c] - mu;
-          m2 = fmaf(d, (r < nr) ? d : 0.f, m2);
-        }
+#pragma unroll
+      for (int u = 0; u < TC_ROWS / TC_RG; ++u) {
+        const float d = v[u] - mu;
+        m2 = fmaf(d, (rl + TC_RG * u < nr) ? d : 0.f, m2);
       }
       lds_barrier();
-      st[rl * TC_MAXN + c] = m2;
+      X[rl * TC_MAXN + c] = m2;
       lds_barrier();
       if (rl == 0 && c < N) {
-        float t2 = st[c];
+        float t2 = X[c];
 #pragma unroll
-        for (int j = 1; j < TC_RG; ++j) t2 += st[j * TC_MAXN + c];
-        out.part[((size_t)g * 2) * N + c] = mu;
-        out.part[((size_t)g * 2 + 1) * N + c] = t2;
+        for (int j = 1; j < TC_RG; ++j) t2 += X[j * TC_MAXN + c];
+        st_agent(out.part + ((size_t)g * 2) * N + c, mu);
+        st_agent(out.part + ((size_t)g * 2 + 1) * N + c, t2);
       }
-      TCP(7);          // tile statistics
+      TCP_RUN(46);  // tile statistics
     }
   }
 }
-#ifdef SCVAE_TC_PROBE
-extern "C" int scvae_debug_tc_probe(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tc_probe), sizeof(g_tc_probe));
+__global__ __launch_bounds__(TC_THREADS) void tile_fwd_kernel(TileFwdArgs q) {
+  extern __shared__ __attribute__((aligned(16))) float tsm[];
+  TileFwdRegs R;
+  TileFwdPart P;
+  // (the chunk statistics of the layer below first: they are needed first, and a wave's loads
+  //  return in order)
+  tile_fwd_partials(q, P, blockIdx.x);
+  tile_fwd_issue(q, R, blockIdx.x);
+  tile_fwd_run(q, R, P, tsm, blockIdx.x);
 }
-#endif
 
 static constexpr size_t TC_FWD_LDS =
     (size_t)(TC_ROWS * TC_LD + TC_MAXN * TC_LD + (1 + TC_RG) * TC_MAXN) * 4;
@@ -348,8 +388,7 @@ int tile_forward(hipStream_t s, const TileFwdArgs& q) {
 }
 
 // ------------------------------- backward ---------------------------------------------------
-__global__ __launch_bounds__(TC_THREADS) void tile_bwd_kernel(TileBwdArgs q) {
-  extern __shared__ __attribute__((aligned(16))) float tsm[];
+__device__ __forceinline__ void tile_bwd_body(const TileBwdArgs& q, float* tsm, const int g) {
   float* As = tsm;                               // h tile, then the input tile, then d_in [64][TC_LD]
   float* Ds = As + TC_ROWS * TC_LD;              // dA tiles [n_up][64][TC_LD]
   float* Ws = Ds + 2 * TC_ROWS * TC_LD;          // a tile, then half of W: [64][TC_LD]
@@ -357,7 +396,7 @@ __global__ __launch_bounds__(TC_THREADS) void tile_bwd_kernel(TileBwdArgs q) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, kh = lane >> 5;
-  const int g = blockIdx.x, r0 = g * TC_ROWS;
+  const int r0 = g * TC_ROWS;
   const int nr = min(TC_ROWS, q.rows - r0);
   const int K = q.K;
   const bool bn = q.bn.a != nullptr;
@@ -394,10 +433,10 @@ __global__ __launch_bounds__(TC_THREADS) void tile_bwd_kernel(TileBwdArgs q) {
     // dbeta and the moving averages were written there)
     const int N = q.up[0].N;
     if (tid < N) {
-      st[tid] = q.bn.mean[tid];
-      st[TC_MAXN + tid] = rsqrtf(q.bn.var[tid] + BN_EPSILON);
-      st[2 * TC_MAXN + tid] = q.bn.s1[tid];
-      st[3 * TC_MAXN + tid] = q.bn.s2[tid];
+      st[tid] = q.bn.mean[grp * N + tid];
+      st[TC_MAXN + tid] = rsqrtf(q.bn.var[grp * N + tid] + BN_EPSILON);
+      st[2 * TC_MAXN + tid] = q.bn.s1[grp * N + tid];
+      st[3 * TC_MAXN + tid] = q.bn.s2[grp * N + tid];
     }
     lds_barrier();
   } else if (bn) {
@@ -638,6 +677,10 @@ __global__ __launch_bounds__(TC_THREADS) void tile_bwd_kernel(TileBwdArgs q) {
     }
   }
 }
+__global__ __launch_bounds__(TC_THREADS) void tile_bwd_kernel(TileBwdArgs q) {
+  extern __shared__ __attribute__((aligned(16))) float tsm[];
+  tile_bwd_body(q, tsm, blockIdx.x);
+}
 
 static constexpr size_t TC_BWD_LDS =
     (size_t)(4 * TC_ROWS * TC_LD + 2 * TC_RG * TC_MAXN) * 4;
@@ -653,15 +696,15 @@ int tile_backward(hipStream_t s, const TileBwdArgs& q) {
   return 0;
 }
 
-// chunk sums of the TOP batch-normalised layer of a chain from its output gradient dh
-__global__ __launch_bounds__(256) void tile_bwd_stats_kernel(const float* __restrict__ dh,
-                                                                    TileBN bn, int rows, int N) {
-  __shared__ float red[2][256];
-  const int g = blockIdx.x, r0 = g * TC_ROWS;
+// chunk sums of the TOP batch-normalised layer of a chain from its output gradient dh (the first
+// 256 threads of the workgroup work; red: 512 floats of LDS)
+__device__ __forceinline__ void tile_bwd_stats_body(const float* __restrict__ dh, const TileBN& bn,
+                                                    int rows, int N, float* red, const int g) {
+  const int r0 = g * TC_ROWS;
   const int nr = min(TC_ROWS, rows - r0);
-  const int c = threadIdx.x & 127, rl = threadIdx.x >> 7;
+  const int c = threadIdx.x & 127, rl = (threadIdx.x >> 7) & 1;
   float a1 = 0.f, a2 = 0.f;
-  if (c < N) {
+  if (c < N && threadIdx.x < 256) {
     const int gb = bn.group_tiles ? g / bn.group_tiles : 0;
     const float mu = bn.mean[gb * N + c];
     const float istd = rsqrtf(bn.var[gb * N + c] + BN_EPSILON);
@@ -685,13 +728,20 @@ __global__ __launch_bounds__(256) void tile_bwd_stats_kernel(const float* __rest
       }
     }
   }
-  red[0][threadIdx.x] = a1;
-  red[1][threadIdx.x] = a2;
-  lds_barrier();
-  if (rl == 0 && c < N) {
-    bn.part_out[((size_t)g * 2) * N + c] = red[0][c] + red[0][128 + c];
-    bn.part_out[((size_t)g * 2 + 1) * N + c] = red[1][c] + red[1][128 + c];
+  if (threadIdx.x < 256) {
+    red[threadIdx.x] = a1;
+    red[256 + threadIdx.x] = a2;
   }
+  lds_barrier();
+  if (threadIdx.x < 128 && c < N) {
+    bn.part_out[((size_t)g * 2) * N + c] = red[c] + red[128 + c];
+    bn.part_out[((size_t)g * 2 + 1) * N + c] = red[256 + c] + red[256 + 128 + c];
+  }
+}
+__global__ __launch_bounds__(256) void tile_bwd_stats_kernel(const float* __restrict__ dh,
+                                                                    TileBN bn, int rows, int N) {
+  __shared__ float red[512];
+  tile_bwd_stats_body(dh, bn, rows, N, red, blockIdx.x);
 }
 
 int tile_backward_stats(hipStream_t s, const float* dh, const TileBN& bn, int rows, int N) {
@@ -706,12 +756,15 @@ int tile_backward_stats(hipStream_t s, const float* dh, const TileBN& bn, int ro
 //      chunk statistics / chunk sums merged by ONE workgroup into the layer's buffers, which the
 //      caller's hook then merges over the ranks; the consuming tile kernel takes them as given
 //      (TileBN::part == nullptr).  One thread per column, the chunks in order. ----
+// (groups: block k merges the chunks of group k alone -- its group_tiles tiles of 64 rows -- into
+//  mean[k][N], var[k][N]: the GMVAE's K passes, gm:2859-2922)
 __global__ __launch_bounds__(TC_MAXN) void tile_stats_merge_kernel(const float* __restrict__ part,
                                                                    int chunks, int chunk, int rows,
                                                                    int N, float* __restrict__ mean,
                                                                    float* __restrict__ var) {
-  const int c = threadIdx.x;
+  const int c = threadIdx.x, k = blockIdx.x;
   if (c >= N) return;
+  part += (size_t)k * chunks * 2 * N;
   const float n_last = (float)(rows - (chunks - 1) * chunk);
   float sum = 0.f;
   for (int z = 0; z < chunks; ++z)
@@ -721,48 +774,60 @@ __global__ __launch_bounds__(TC_MAXN) void tile_stats_merge_kernel(const float* 
   for (int z = 0; z < chunks; ++z)
     m2 = bn_merge_m2(m2, z == chunks - 1 ? n_last : (float)chunk, part[(size_t)z * 2 * N + c],
                      part[((size_t)z * 2 + 1) * N + c], mu);
-  mean[c] = mu;
-  var[c] = m2 / (float)rows;
+  mean[k * N + c] = mu;
+  var[k * N + c] = m2 / (float)rows;
 }
 __global__ __launch_bounds__(TC_MAXN) void tile_sums_merge_kernel(const float* __restrict__ part,
                                                                   int chunks, int N, TileBN bn,
-                                                                  float bessel) {
+                                                                  float bessel, int groups) {
   const int c = threadIdx.x;
   if (c >= N) return;
-  float t1 = 0.f, t2 = 0.f;
-  for (int z = 0; z < chunks; ++z) {
-    t1 += part[(size_t)z * 2 * N + c];
-    t2 += part[((size_t)z * 2 + 1) * N + c];
+  // this rank's sums per group (s1, s2: [groups][N]); dbeta: all the rank's chunks in chunk order
+  // (the gradient all-reduce sums the ranks); the moving averages from the batch statistics of
+  // the forward pass -- those of the global minibatch -- group after group (K executions of the
+  // UPDATE_OPS in pass order)
+  float tall = 0.f;
+  float mm = bn.mov_mean[c], mv = bn.mov_var[c];
+  for (int k = 0; k < groups; ++k) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int z = k * chunks; z < (k + 1) * chunks; ++z) {
+      const float p1 = part[(size_t)z * 2 * N + c];
+      t1 += p1;
+      t2 += part[((size_t)z * 2 + 1) * N + c];
+      tall += p1;
+    }
+    bn.s1[k * N + c] = t1;
+    bn.s2[k * N + c] = t2;
+    mm = bn_moving_update(mm, bn.mean[k * N + c]);
+    mv = bn_moving_update(mv, bn.var[k * N + c] * bessel);
   }
-  bn.s1[c] = t1;
-  bn.s2[c] = t2;
-  // dbeta: this rank's rows (the gradient all-reduce sums the ranks); the moving averages from the
-  // batch statistics of the forward pass, which are those of the global minibatch
-  bn.dbeta[c] = t1;
-  bn.mov_mean[c] = bn_moving_update(bn.mov_mean[c], bn.mean[c]);
-  bn.mov_var[c] = bn_moving_update(bn.mov_var[c], bn.var[c] * bessel);
+  bn.dbeta[c] = tall;
+  bn.mov_mean[c] = mm;
+  bn.mov_var[c] = mv;
 }
+// chunks: per group; rows: per group
 int tile_stats_merge(hipStream_t s, const float* part, int chunks, int chunk, int rows, int N,
-                     float* mean, float* var) {
-  SCVAE_ARG(part && chunks > 0 && chunk > 0 && N > 0 && N <= TC_MAXN && mean && var);
-  hipLaunchKernelGGL(tile_stats_merge_kernel, dim3(1), dim3(TC_MAXN), 0, s, part, chunks, chunk,
-                     rows, N, mean, var);
+                     float* mean, float* var, int groups) {
+  SCVAE_ARG(part && chunks > 0 && chunk > 0 && N > 0 && N <= TC_MAXN && mean && var && groups >= 1);
+  hipLaunchKernelGGL(tile_stats_merge_kernel, dim3(groups), dim3(TC_MAXN), 0, s, part, chunks,
+                     chunk, rows, N, mean, var);
   SCVAE_LAUNCH_CHECK("tile_stats_merge_kernel");
   return 0;
 }
 int tile_sums_merge(hipStream_t s, const float* part, int chunks, int N, const TileBN& bn,
-                    float bessel) {
+                    float bessel, int groups) {
   SCVAE_ARG(part && chunks > 0 && N > 0 && N <= TC_MAXN && bn.s1 && bn.s2 && bn.dbeta &&
-            bn.mov_mean && bn.mov_var && bn.mean && bn.var);
+            bn.mov_mean && bn.mov_var && bn.mean && bn.var && groups >= 1);
   hipLaunchKernelGGL(tile_sums_merge_kernel, dim3(1), dim3(TC_MAXN), 0, s, part, chunks, N, bn,
-                     bessel);
+                     bessel, groups);
   SCVAE_LAUNCH_CHECK("tile_sums_merge_kernel");
   return 0;
 }
 
-__global__ __launch_bounds__(256) void tile_slab_reduce_kernel(SlabJobs q) {
-  const SlabJobs::Job jb = q.job[blockIdx.y];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += gridDim.x * blockDim.x) {
+// one job: out[i] = sum_g slabs[g][i], elements first, first + stride, ...
+__device__ __forceinline__ void tile_slab_reduce_job(const SlabJobs::Job& jb, int first,
+                                                     int stride) {
+  for (int i = first; i < jb.n; i += stride) {
     float s0 = 0.f;
     int g = 0;
     for (; g + 8 <= jb.G; g += 8) {
@@ -776,6 +841,10 @@ __global__ __launch_bounds__(256) void tile_slab_reduce_kernel(SlabJobs q) {
     jb.out[i] = s0;
   }
 }
+__global__ __launch_bounds__(256) void tile_slab_reduce_kernel(SlabJobs q) {
+  tile_slab_reduce_job(q.job[blockIdx.y], blockIdx.x * blockDim.x + threadIdx.x,
+                       gridDim.x * blockDim.x);
+}
 int tile_slab_reduce(hipStream_t s, const SlabJobs& q) {
   SCVAE_ARG(q.n_jobs >= 1 && q.n_jobs <= TC_MAX_JOBS);
   int n_max = 0;
@@ -786,6 +855,232 @@ int tile_slab_reduce(hipStream_t s, const SlabJobs& q) {
   hipLaunchKernelGGL(tile_slab_reduce_kernel, dim3((n_max + 255) / 256, q.n_jobs), dim3(256), 0, s,
                      q);
   SCVAE_LAUNCH_CHECK("tile_slab_reduce_kernel");
+  return 0;
+}
+
+// ------------------------------- the resident chain -----------------------------------------
+// The stages of a whole forward (backward) pass of the hidden layers in ONE launch: the same tile
+// bodies as above -- the same arithmetic in the same order, hence the same bits as the chain of
+// per-layer launches -- run by workgroups that stay resident, with a grid barrier (common.hpp)
+// where the next stage needs every tile's chunk statistics and a workgroup barrier where it only
+// needs the tile's own rows (posterior heads -> latent stage -> first decoder layer, one sample
+// per cell).  What goes away: nine of ten launches, their cold starts (instruction cache, the
+// first round trip of each kernel) and the gaps between them.  Single process only: a data-
+// parallel hook needs the host between the stages.
+//
+// The latent stage (va:2266-2289, 2346-2369, 2624-2656: clip, z = mu + sigma eps, analytic KL)
+// is gauss_latent_fwd_kernel / gauss_latent_bwd_kernel of elementwise.hip restated per tile:
+// a wave per cell, the lanes over the latent units, the same wave sum.
+__device__ __forceinline__ void tile_latent_fwd_body(const TileLatent& q, const int g) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r0 = g * TC_ROWS;
+  const int nr = min(TC_ROWS, q.B - r0);
+  const int nw = (q.L + 63) >> 6;
+  for (int r = w; r < nr; r += TC_THREADS / 64) {
+    const int b = r0 + r;
+    float total = 0.f;
+    for (int part = 0; part < nw; ++part) {
+      const int l = 64 * part + lane;
+      const bool live = l < q.L;
+      const size_t i = (size_t)b * q.L + (live ? l : 0);
+      const float mu = fminf(fmaxf(q.mu_pre[i], -F32_MAX_HALF), F32_MAX_HALF);
+      const float ls = fminf(fmaxf(q.ls_pre[i], -3.f), 3.f);
+      const float sigma = __expf(ls);
+      float kl = 0.f;
+      if (live) {
+        for (int s = 0; s < q.S; ++s) {
+          const size_t o = ((size_t)s * q.B + b) * q.L + l;
+          q.z[o] = fmaf(sigma, q.eps[o], mu);
+        }
+        kl = gauss_kl_elem(mu, sigma, ls);
+        q.kl_elem[i] = kl;
+      }
+      total += wave_sum(kl);
+    }
+    if (lane == 0) q.kl_cell[b] = total;
+  }
+}
+__device__ __forceinline__ void tile_latent_bwd_body(const TileLatent& q, const int g) {
+  const int r0 = g * TC_ROWS;
+  const int nr = min(TC_ROWS, q.B - r0);
+  const size_t n = (size_t)q.B * q.L;
+  for (int e = threadIdx.x; e < nr * q.L; e += TC_THREADS) {
+    const size_t i = (size_t)r0 * q.L + e;
+    const float mp = q.mu_pre[i], lp = q.ls_pre[i];
+    const float mu = fminf(fmaxf(mp, -F32_MAX_HALF), F32_MAX_HALF);
+    const float ls = fminf(fmaxf(lp, -3.f), 3.f);
+    const float sigma = __expf(ls);
+    float gz = 0.f, gze = 0.f;
+    for (int s = 0; s < q.S; ++s) {
+      const size_t o = (size_t)s * n + i;
+      const float ev = q.eps[o];
+      const float d = q.dz[o];
+      gz += d;
+      gze = fmaf(d, ev, gze);
+    }
+    const float gmu = gauss_kl_dmu(gz, q.kl_coeff, mu);
+    const float gls = gauss_kl_dls(gze, sigma, q.kl_coeff);
+    q.dmu[i] = (mp >= -F32_MAX_HALF && mp <= F32_MAX_HALF) ? gmu : 0.f;
+    q.dls[i] = (lp >= -3.f && lp <= 3.f) ? gls : 0.f;
+  }
+}
+
+// Between two stages.  sync 1: this workgroup alone (the tile's own rows went through global
+// memory: stores complete, then the barrier).  2: every workgroup of the launch, for stages that
+// only exchange chunk statistics / chunk sums (ld_agent / st_agent, above): arrival and wait on the
+// counter with relaxed agent-scope atomics, no L2 write-back, no invalidate.  3: every workgroup,
+// full release / acquire (grid_barrier, common.hpp): whole rows or slabs of other tiles are read
+// next.  The barrier is cut in two so that a stage's own inputs travel while the workgroup waits.
+__device__ __forceinline__ void tile_chain_stores_done() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+__device__ __forceinline__ void tile_chain_wait(int how, unsigned* bar, unsigned& target) {
+  if (how == 3) {
+    grid_barrier(bar, target += gridDim.x);
+  } else if (how == 2) {
+    target += gridDim.x;
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins == (1u << 28)) __builtin_trap();
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(TC_THREADS) void tile_chain_fwd_kernel(TileChainFwdArgs q) {
+  extern __shared__ __attribute__((aligned(16))) float tsm[];
+  const int g = blockIdx.x;
+  unsigned target = q.bar_base;
+  TileFwdRegs R;
+  TileFwdPart P;
+  TCP_BEGIN(0);
+  // (stage i as an index into q.f, -1: not a tile stage or no tile g in it; the arguments are
+  //  read in place, in the kernel-argument segment: a pointer to one of them would send the whole
+  //  table to scratch memory)
+  auto tile_of = [&](int i) -> int {
+    if (q.kind[i] != TCS_TILE) return -1;
+    return g * TC_ROWS < q.f[q.idx[i]].rows ? q.idx[i] : -1;
+  };
+  int cur = tile_of(0);
+  if (cur >= 0) {
+    tile_fwd_partials(q.f[cur], P, g);
+    tile_fwd_issue(q.f[cur], R, g);
+  }
+  for (int i = 0; i < q.n; ++i) {
+    if (q.kind[i] == TCS_LATENT) {
+      if (g * TC_ROWS < q.lat.B) tile_latent_fwd_body(q.lat, g);
+    } else if (cur >= 0) {
+      tile_fwd_run(q.f[cur], R, P, tsm, g);
+    }
+    TCP(5 * i);
+    if (i + 1 == q.n) break;
+    // the next stage: its own rows and weights are requested before the wait for the other
+    // workgroups, the chunk statistics of all tiles after it
+    tile_chain_stores_done();
+    TCP(5 * i + 1);
+    cur = tile_of(i + 1);
+    if (q.sync[i] == 3) tile_chain_wait(3, q.bar, target);
+    if (cur >= 0) tile_fwd_issue(q.f[cur], R, g);
+    TCP(5 * i + 2);
+    if (q.sync[i] == 2) tile_chain_wait(2, q.bar, target);
+    TCP(5 * i + 3);
+    if (cur >= 0) tile_fwd_partials(q.f[cur], P, g);
+    TCP(5 * i + 4);
+  }
+}
+
+__global__ __launch_bounds__(TC_THREADS) void tile_chain_bwd_kernel(TileChainBwdArgs q) {
+  extern __shared__ __attribute__((aligned(16))) float tsm[];
+  const int g = blockIdx.x;
+  unsigned target = q.bar_base;
+  for (int i = 0; i < q.n; ++i) {
+    const int kind = q.kind[i];
+    if (kind == TCS_LATENT) {
+      if (g * TC_ROWS < q.lat.B) tile_latent_bwd_body(q.lat, g);
+    } else if (kind == TCS_STATS) {
+      if (g * TC_ROWS < q.stats_rows)
+        tile_bwd_stats_body(q.stats_dh, q.stats_bn, q.stats_rows, q.stats_N, tsm, g);
+    } else if (kind == TCS_REDUCE) {
+      // the dW / db slabs of the pass, summed in slab order: all workgroups, job after job
+      for (int j = 0; j < q.jobs.n_jobs; ++j)
+        tile_slab_reduce_job(q.jobs.job[j], g * TC_THREADS + (int)threadIdx.x,
+                             (int)gridDim.x * TC_THREADS);
+    } else {
+      const TileBwdArgs& b = q.b[q.idx[i]];
+      if (g * TC_ROWS < b.rows) tile_bwd_body(b, tsm, g);
+    }
+    if (i + 1 == q.n) break;
+    tile_chain_stores_done();
+    tile_chain_wait(q.sync[i], q.bar, target);
+  }
+}
+
+static int tile_chain_setup() {
+  SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(tile_chain_fwd_kernel), (int)TC_FWD_LDS));
+  SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(tile_chain_bwd_kernel), (int)TC_BWD_LDS));
+  return 0;
+}
+// how many workgroups of the resident kernels the current device holds at once (0: unknown);
+// the hand-rolled grid barrier needs the whole launch co-resident (cached per device)
+int tile_chain_resident_capacity() {
+  static thread_local int cached_device = -1;
+  static thread_local int cached = 0;
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return 0;
+  if (device == cached_device) return cached;
+  int cap = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && tile_chain_setup() == 0) {
+    int fwd = 0, bwd = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fwd, tile_chain_fwd_kernel, TC_THREADS,
+                                                     TC_FWD_LDS) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&bwd, tile_chain_bwd_kernel, TC_THREADS,
+                                                     TC_BWD_LDS) == hipSuccess)
+      cap = (fwd < bwd ? fwd : bwd) * prop.multiProcessorCount;
+  }
+  cached_device = device;
+  cached = cap;
+  return cap;
+}
+static int tile_chain_check(int n, const int* kind, const int* idx, const int* sync, int n_items) {
+  SCVAE_ARG(n >= 1 && n <= TCR_MAX_STAGES);
+  for (int i = 0; i < n; ++i) {
+    SCVAE_ARG(kind[i] >= TCS_TILE && kind[i] <= TCS_REDUCE);
+    SCVAE_ARG(kind[i] != TCS_TILE || (idx[i] >= 0 && idx[i] < n_items));
+    SCVAE_ARG(i + 1 == n || (sync[i] >= 1 && sync[i] <= 3));
+  }
+  return 0;
+}
+// grid barriers of a launch (the host advances the counter's base by barriers * workgroups)
+static int tile_chain_barriers(int n, const int* sync) {
+  int b = 0;
+  for (int i = 0; i + 1 < n; ++i) b += sync[i] >= 2 ? 1 : 0;
+  return b;
+}
+int tile_chain_forward(hipStream_t s, const TileChainFwdArgs& q, int tiles, unsigned* advance) {
+  SCVAE_ARG(q.bar && tiles >= 1 && advance);
+  if (int rc = tile_chain_check(q.n, q.kind, q.idx, q.sync, TCR_MAX_TILES)) return rc;
+  for (int i = 0; i < q.n; ++i) SCVAE_ARG(q.kind[i] == TCS_TILE || q.kind[i] == TCS_LATENT);
+  SCVAE_ARG(tiles <= tile_chain_resident_capacity());
+  if (int rc = tile_chain_setup()) return rc;
+  hipLaunchKernelGGL(tile_chain_fwd_kernel, dim3(tiles), dim3(TC_THREADS), TC_FWD_LDS, s, q);
+  SCVAE_LAUNCH_CHECK("tile_chain_fwd_kernel");
+  *advance = (unsigned)(tile_chain_barriers(q.n, q.sync) * tiles);
+  return 0;
+}
+int tile_chain_backward(hipStream_t s, const TileChainBwdArgs& q, int tiles, unsigned* advance) {
+  SCVAE_ARG(q.bar && tiles >= 1 && advance);
+  if (int rc = tile_chain_check(q.n, q.kind, q.idx, q.sync, TCR_MAX_TILES)) return rc;
+  SCVAE_ARG(tiles <= tile_chain_resident_capacity());
+  if (int rc = tile_chain_setup()) return rc;
+  hipLaunchKernelGGL(tile_chain_bwd_kernel, dim3(tiles), dim3(TC_THREADS), TC_BWD_LDS, s, q);
+  SCVAE_LAUNCH_CHECK("tile_chain_bwd_kernel");
+  *advance = (unsigned)(tile_chain_barriers(q.n, q.sync) * tiles);
   return 0;
 }
 

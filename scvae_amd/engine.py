@@ -344,6 +344,17 @@ class Engine:
         return bool(self.lib.scvae_plan_uses_tile_chain(
             self.handle, int(cells), int(samples)))
 
+    def set_tile_resident(self, enabled):
+        """The tile chain's stages of a pass in ONE resident launch per
+        direction (single process; measured slower on MI355X, hence off by
+        default) or one launch per layer."""
+        _lib.check(self.lib.scvae_plan_set_tile_resident(
+            self.handle, 1 if enabled else 0), "scvae_plan_set_tile_resident")
+
+    def uses_tile_resident(self, cells, samples=1):
+        return bool(self.lib.scvae_plan_uses_tile_resident(
+            self.handle, int(cells), int(samples)))
+
     def set_tile_chain(self, enabled):
         """Large VAE training minibatches: one launch per hidden layer and
         direction (default) or the chain of GEMM / batch-norm launches."""

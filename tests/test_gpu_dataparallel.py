@@ -26,12 +26,15 @@ def single_rank_group(cuda_device):
 
 
 @pytest.mark.parametrize("model_type,B", [("VAE", 48), ("GMVAE", 48),
-                                          ("VAE", 300), ("VAE", 1000)])
+                                          ("VAE", 300), ("VAE", 1000),
+                                          ("GMVAE", 128), ("GMVAE", 512)])
 def test_step_with_sync_hook_equals_plain_step(cuda_device, single_rank_group,
                                                model_type, B):
     """(B > 128: the hidden layers on the tile chain -- under the hook with a
     layer's statistics merged per rank, handed to the hook and taken as given by
-    the consuming kernel; 300 and 1000 rows: ragged last tiles, 5 / 16 chunks.)"""
+    the consuming kernel; 300 and 1000 rows: ragged last tiles, 5 / 16 chunks.
+    GMVAE at 128 / 512 cells: the K passes as tile-chain groups of 2 / 8 tiles,
+    every pass's statistics in one collective per layer.)"""
     from scvae_amd.dataparallel import GradientSynchroniser
     from scvae_amd.engine import Engine
     F, L, H, K = 130, 5, (20, 16), 3
@@ -51,7 +54,8 @@ def test_step_with_sync_hook_equals_plain_step(cuda_device, single_rank_group,
         if with_sync:
             sync = GradientSynchroniser(eng)
             sync.broadcast_state(0)
-        assert eng.uses_tile_chain(B) == (model_type == "VAE" and B > 128)
+        assert eng.uses_tile_chain(B) == (
+            B > 128 if model_type == "VAE" else B % 64 == 0)
         scalars = eng.step(x, x, eps=eps, training=True).clone()
         if with_sync:
             sync.all_reduce_gradients()
@@ -83,7 +87,9 @@ def _two_rank_worker(rank, port, model_type, result_path):
         dropout = model_type.endswith("-dropout")
         large = model_type.endswith("-large")     # (the tile chain under the hook: 203 / 203 rows)
         model_type = model_type.split("-")[0]
-        F, L, H, B, K = 130, 5, (20, 16), (406 if large else 48), 3
+        # (GMVAE: whole 64-row tiles per pass and rank)
+        F, L, H, K = 130, 5, (20, 16), 3
+        B = (406 if model_type == "VAE" else 256) if large else 48
         n_iw = 2 if options else 1
         rng = np.random.default_rng(0)
         x = torch.from_numpy(
@@ -167,7 +173,7 @@ def _two_rank_worker(rank, port, model_type, result_path):
 
 
 CASES = ["VAE", "GMVAE", "VAE-options", "GMVAE-options", "VAE-dropout",
-         "GMVAE-dropout", "VAE-large"]
+         "GMVAE-dropout", "VAE-large", "GMVAE-large"]
 
 
 @pytest.mark.parametrize("model_type", CASES)
@@ -181,7 +187,8 @@ def test_two_ranks_equal_single_process(cuda_device, tmp_path, model_type):
     mp.spawn(_two_rank_worker, args=(port, model_type, str(result)),
              nprocs=2, join=True)
     worst = float(result.read_text())
-    assert worst <= (2e-5 if model_type in ("VAE", "GMVAE", "VAE-large") else 1e-4), worst
+    assert worst <= (2e-5 if model_type in ("VAE", "GMVAE", "VAE-large",
+                                            "GMVAE-large") else 1e-4), worst
 
 
 def _model_train_worker(rank, port, directory, result_path):

@@ -113,21 +113,21 @@ def test_wide_and_odd_hidden_sizes(cuda_device, H, head_arith):
     size): training launches of the bf16x9 producer / consumer kernel up to
     H = 255 -- 32-gene strips for two heads from H = 111, five to eight
     contraction steps and two h tiles per consumer wave from H = 127, odd widths
-    included (three heads: up to H = 159).  Forward-only calls of those widths
-    stay on the unfused kernels (the plan's business), so: training only."""
+    included (three heads: up to H = 159) -- and the forward half of the same
+    kernel (``FWD``: evaluation passes, the first pass of an importance-weighted
+    step; mode 0 of ``_run``)."""
     from scvae_amd import _lib
     lib = _lib.load()
     if head_arith == "fp32":
         assert H > 126 or H % 2 == 0 or lib.scvae_decoder_train_kernel(1, H, 0) == 0
         pytest.skip("the fp32 kernels stop at even H <= 126")
     assert lib.scvae_decoder_train_kernel(1, H, 1) == 3
-    _run(cuda_device, "negative binomial", 200, 200, 150, H, 0.2, modes=(1,))
-    _run(cuda_device, "poisson", 70, 70, 130, H, 0.2, modes=(1,))
-    _run(cuda_device, "negative binomial", 96, 48, 100, H, 0.3, modes=(1,),
+    _run(cuda_device, "negative binomial", 200, 200, 150, H, 0.2)
+    _run(cuda_device, "poisson", 70, 70, 130, H, 0.2)
+    _run(cuda_device, "negative binomial", 96, 48, 100, H, 0.3,
          extra_flags=_lib.HEADS_DD_ATOMICS)
     if H <= 159:
-        _run(cuda_device, "zero-inflated negative binomial", 100, 100, 90, H, 0.2,
-             modes=(1,))
+        _run(cuda_device, "zero-inflated negative binomial", 100, 100, 90, H, 0.2)
     else:
         assert lib.scvae_decoder_train_kernel(3, H, 1) == 0
 

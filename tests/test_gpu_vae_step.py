@@ -113,7 +113,7 @@ def test_wide_decoder_trains_on_the_fused_kernel(cuda_device, likelihood, H, B):
     """``-H`` beyond 126 (mu:81-126 takes any size): a training step of one
     likelihood pass runs the heads on the bf16x9 producer / consumer kernel
     (``scvae_decoder_train_kernel`` == 3), evaluation steps of the same model on
-    the unfused kernels -- both against the oracle."""
+    its forward half (``FWD``) -- both against the oracle."""
     from scvae_amd import _lib
     lib = _lib.load()
     kind, _ = _lib.LIKELIHOOD_KINDS[likelihood]
@@ -139,7 +139,7 @@ def test_wide_decoder_trains_on_the_fused_kernel(cuda_device, likelihood, H, B):
                 and "POSTERIOR" not in name:
             continue
         _close(g.cpu(), grads[name], rtol=2e-4, what="grad " + name)
-    # evaluation (forward only): the unfused kernels at this width
+    # evaluation (forward only): the forward half of the same kernel at this width
     moving_now = {k: v.detach().cpu().double()
                   for k, v in eng.named_moving_statistics().items()}
     sc = eng.step(xd, xd, eps=epsd, training=False,
@@ -354,6 +354,62 @@ def test_mid_chain_matches_the_launch_chain(cuda_device, B, H, L, n_iw):
     for a, b in zip(*results):
         scale = b.abs().max().item()
         assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-9
+
+
+@pytest.mark.parametrize("B,H,L,n_iw,n_mc", [(4096, (100, 100), 25, 1, 1),
+                                              (300, (100, 100), 25, 1, 1),
+                                              (129, (24, 20), 7, 1, 1),
+                                              (1000, (128,), 128, 1, 1),
+                                              (333, (16, 12, 8), 5, 1, 1),
+                                              (200, (50, 30), 10, 2, 1),
+                                              (150, (64, 64), 9, 1, 3)])
+def test_resident_tile_chain_is_the_tile_chain_bit_for_bit(cuda_device, B, H, L,
+                                                           n_iw, n_mc):
+    """The stages of a pass in ONE resident launch per direction (grid barriers
+    between the layers, ``scvae_plan_set_tile_resident``) against one launch per
+    layer: the same tile code on the same tiles, so every output, gradient and
+    moving statistic carries identical bits -- over two steps with the
+    optimiser in between (the barrier counter carries over)."""
+    from scvae_amd.engine import Engine
+    F = 400
+    S = n_iw * n_mc
+    rng = np.random.default_rng(B + L)
+    x = torch.from_numpy(_counts(rng, B, F)).float().to(cuda_device)
+    eps = torch.from_numpy(rng.standard_normal((S, B, L))).float().to(
+        cuda_device)
+    results = []
+    for resident in (True, False):
+        eng = Engine(F, L, H, "negative binomial", batch_norm=True,
+                     device=cuda_device, seed=4)
+        eng.set_dd_atomics(False)
+        g = torch.Generator().manual_seed(9)
+        for name, p in eng.named_parameters().items():
+            if not name.endswith("weights"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+        for name, m in eng.named_moving_statistics().items():
+            m.copy_(torch.rand(m.shape, generator=g) + 0.5)
+        eng.set_tile_resident(resident)
+        eng.reserve(B, S)
+        assert eng.uses_tile_chain(B, S)
+        assert eng.uses_tile_resident(B, S) == resident
+        out = []
+        for step in range(2):
+            ll = torch.zeros(S * B, device=cuda_device)
+            qz = torch.zeros(B, L, device=cuda_device)
+            klz = torch.zeros(L, device=cuda_device)
+            scalars = eng.step(
+                x, x, eps=eps, training=True, n_iw=n_iw, n_mc=n_mc,
+                warm_up_weight=0.7, outputs={
+                    "log_p_x_given_z": ll, "q_z_mean": qz,
+                    "kl_neurons": klz}).clone()
+            torch.cuda.synchronize()
+            out += [scalars.cpu(), ll.cpu(), qz.cpu(), klz.cpu(),
+                    eng.grads.clone().cpu(), eng.moving.clone().cpu()]
+            eng.adam_step(1e-3)
+        out.append(eng.params.clone().cpu())
+        results.append(out)
+    for i, (a, b) in enumerate(zip(*results)):
+        assert torch.equal(a, b), i
 
 
 @pytest.mark.parametrize("B,H,L,n_iw,n_mc", [(4096, (100, 100), 25, 1, 1),

@@ -19,6 +19,11 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--latent", type=int, default=25)
     ap.add_argument("--likelihood", default="negative binomial")
+    ap.add_argument("--unfused", action="store_true",
+                    help="heads as GEMM + element-wise likelihood kernels (A/B)")
+    ap.add_argument("--hidden", type=int, nargs="+", default=[100, 100],
+                    help="hidden layer sizes (encoder order; the decoder's last layer -- the "
+                         "heads' input -- is the first)")
     args = ap.parse_args()
     from scvae_amd.engine import Engine
     from scvae_amd.minibatch import synthetic_count_matrix
@@ -26,9 +31,11 @@ def main():
     matrix, _ = synthetic_count_matrix(args.cells, args.features, density=0.05, seed=60,
                                        device=dev)
     B = args.batch
-    eng = Engine(args.features, args.latent, (100, 100), args.likelihood, batch_norm=True,
+    eng = Engine(args.features, args.latent, tuple(args.hidden), args.likelihood, batch_norm=True,
                  device=dev, seed=0)
     eng.reserve(B, 1)
+    if args.unfused:
+        eng.set_fused(False)
     u16 = matrix.integer_counts and eng.accepts_counts_u16(B, False)
     x = (torch.empty(B, matrix.u16_pitch, dtype=torch.uint16, device=dev) if u16
          else torch.empty(B, args.features, device=dev))
@@ -51,8 +58,9 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.steps
-    print("evaluation step, {} cells x {} genes, {} ({} minibatch): {:.3f} ms = {:.0f} cells/s"
-          .format(B, args.features, args.likelihood, "uint16" if u16 else "fp32", ms,
+    print("evaluation step, {} cells x {} genes, {} H = {} ({} minibatch{}): {:.3f} ms = {:.0f} cells/s"
+          .format(B, args.features, args.likelihood, args.hidden, "uint16" if u16 else "fp32",
+                  ", unfused heads" if args.unfused else "", ms,
                   B / ms * 1e3))
 
 

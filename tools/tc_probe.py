@@ -1,30 +1,37 @@
-"""Phase probe of tile_fwd_kernel (a -DSCVAE_TC_PROBE build of tilechain.hip loaded through
-SCVAE_HIP_LIBRARY): s_memtime ticks per phase of workgroup 1, summed over the launches of a few
-benchmark steps, split into launches with / without a batch-norm merge."""
-import ctypes
-import os
-import sys
-
+"""Phase probe of the resident tile-chain kernels (a -DSCVAE_TC_PROBE build of tilechain.hip
+loaded through SCVAE_HIP_LIBRARY): s_memtime ticks of workgroup 1 per (stage, phase), mean per launch.
+    SCVAE_HIP_LIBRARY=$PWD/scvae_amd/csrc/libscvae_hip_tcprobe.so python tools/tc_probe.py"""
+import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
-from scvae_amd import _lib
 from scvae_amd.minibatch import synthetic_count_matrix
-
+from scvae_amd import _lib
 dev = torch.device("cuda:0")
-matrix, _ = synthetic_count_matrix(16384, bench.N_FEATURES, density=0.05, seed=60, device=dev)
+matrix, _ = synthetic_count_matrix(16384, 32738, density=0.05, seed=60, device=dev)
 w = bench.Workload(matrix, dev, 4096, bench.LIKELIHOOD, bench.LATENT)
-w.run(20, 3, lambda: torch.cuda.synchronize(dev), min_warm_seconds=0.1)
-torch.cuda.synchronize(dev)
-lib = ctypes.CDLL(os.environ["SCVAE_HIP_LIBRARY"])
-buf = (ctypes.c_ulonglong * 32)()
+for _ in range(60):
+    w.one_step()
+torch.cuda.synchronize()
+lib = _lib.load()
+buf = (ctypes.c_ulonglong * 128)()
 assert lib.scvae_debug_tc_probe(buf) == 0
-names = ["stats0 in LDS", "stats1 in LDS", "merge done", "tile normalised", "weights in LDS",
-         "product", "bias+store", "tile stats"]
-for kind in (0, 1):
-    row = buf[16 * kind:16 * kind + 16]
-    n = max(1, row[15])
-    print("bn-merge launches" if kind else "plain launches", "n =", row[15])
-    for i, name in enumerate(names):
-        print("   {:18s} {:9.0f} ticks per launch".format(name, row[i] / n))
-    print("   total              {:9.0f}".format(sum(row[:8]) / n))
+names = ["run", "stores done", "issue", "wait", "partials"]
+for d, label in ((0, "forward"), (1, "backward")):
+    n = buf[d * 64 + 63]
+    if not n:
+        continue
+    print(label, "launches", n)
+    tot = 0
+    for st in range(12):
+        vals = [buf[d * 64 + 5 * st + k] / n for k in range(5)]
+        if any(vals):
+            tot += sum(vals)
+            print("  stage {:2d}: ".format(st) + "  ".join(
+                "{} {:7.0f}".format(nm, v) for nm, v in zip(names, vals)))
+    print("  total ticks", round(tot))
+    if d == 0:
+        inner = ["merge", "normalise + tile -> LDS", "weights -> LDS", "product", "acc -> LDS",
+                 "bias + store", "tile statistics"]
+        print("  inside run, all tile stages: " + "  ".join(
+            "{} {:.0f}".format(nm, buf[40 + k] / n) for k, nm in enumerate(inner)))
