@@ -550,6 +550,14 @@ static bool tile_chain_ok(const scvae_plan* p, int B, int S, bool training) {
 // ... and its layers as ONE resident launch per direction (tilechain.hip): single process (a hook
 // needs the host between the stages), every workgroup of the launch co-resident with room to
 // spare for the step's second stream, stage and slab-job tables large enough
+// SCVAE_TILE_SEGMENTS=1 (A/B runs; a resident plan records as well): stages that only need their
+// own tile's rows share a launch.  Off by default: measured SLOWER than one launch per stage
+// (2.02-2.03 against 1.99-2.00 ms per 4096-cell step) -- the chain kernels pay more for their
+// size (registers, cold start) than two launch boundaries cost.
+static bool tile_segments_on() {
+  static const bool on = [] { const char* e = getenv("SCVAE_TILE_SEGMENTS"); return e && e[0] == '1'; }();
+  return on;
+}
 static bool tile_resident_ok(const scvae_plan* p, int R) {
   static const bool env_on = [] { const char* e = getenv("SCVAE_TILE_RESIDENT"); return !(e && e[0] == '0'); }();
   if (!env_on || !p->use_tile_resident || p->sync || !p->mid_bar) return false;
@@ -808,17 +816,43 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   // ---------------- forward ----------------
   const bool mid = mid_chain_ok(p, B, S, training);
   const bool tile = !mid && tile_chain_ok(p, B, S, training);
-  // the tile stages of the pass: launched one by one, or collected for ONE resident launch
+  // The tile stages of the pass: one launch each (default), or -- single process: a
+  // data-parallel hook needs the host between them -- RECORDED and launched together, both
+  // measured slower and off by default: in SEGMENTS (SCVAE_TILE_SEGMENTS=1: stages that only
+  // need their own tile's rows of the stage before -- posterior heads -> latent stage -> first
+  // decoder layer, one sample per cell -- in one launch behind a workgroup barrier,
+  // tile_chain_fwd_kernel; a stage that needs every tile's batch-norm statistics starts a new
+  // launch) or `resident` (scvae_plan_set_tile_resident: the whole pass in ONE launch, grid
+  // barriers where the segments end).
   const bool resident = tile && tile_resident_ok(p, R);
+  const bool record = resident || (tile && !p->sync && p->mid_bar && tile_segments_on());
   TileChainFwdArgs cf;
   int cf_tiles = 0;
+  auto fwd_flush = [&]() -> int {
+    if (cf.n == 0) return 0;
+    int r;
+    if (cf.n == 1 && cf.kind[0] == TCS_TILE) {
+      r = tile_forward(s, cf.f[0]);
+    } else if (cf.n == 1) {
+      const TileLatent& t = cf.lat;
+      r = gauss_latent_fwd(s, t.mu_pre, t.ls_pre, t.eps, t.z, t.kl_elem, t.kl_cell, nullptr, t.S,
+                           t.B, t.L, 0);
+    } else {
+      cf.bar = p->mid_bar; cf.bar_base = p->mid_bar_count;
+      unsigned advance = 0;
+      r = tile_chain_forward(s, cf, (R + 63) / 64, &advance);
+      p->mid_bar_count += advance;
+    }
+    cf.n = 0; cf_tiles = 0;
+    return r;
+  };
   auto fwd_stage = [&](const TileFwdArgs& q, int sync_after) -> int {
-    if (!resident) return tile_forward(s, q);
+    if (!record) return tile_forward(s, q);
     SCVAE_ARG(cf.n < TCR_MAX_STAGES && cf_tiles < TCR_MAX_TILES);
     cf.f[cf_tiles] = q;
     cf.kind[cf.n] = TCS_TILE; cf.idx[cf.n] = cf_tiles++; cf.sync[cf.n] = sync_after;
     ++cf.n;
-    return 0;
+    return (!resident && sync_after >= 2) ? fwd_flush() : 0;
   };
   const float* h = p->step_x;   // (the fp32 batch, or the token of the uint16 one: plan_gemm)
   int ld = F;
@@ -883,7 +917,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const bool mc_kl = (c.latent_mode & 1) != 0;      // va:2633-2640
   const bool unit_var = (c.latent_mode & 2) != 0;   // du:323-337
   const float* ls_pre = unit_var ? nullptr : p->ls_pre;
-  if (resident) {
+  if (record) {
     // (tile_chain_ok: analytic KL, a log_sigma head, training: the stage restates that case)
     SCVAE_ARG(cf.n < TCR_MAX_STAGES && !mc_kl && !unit_var && !a->deterministic_z && a->eps);
     TileLatent& t = cf.lat;
@@ -891,6 +925,8 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     t.kl_elem = p->kl_elem; t.kl_cell = p->kl_cell; t.S = S; t.B = B; t.L = L;
     cf.kind[cf.n] = TCS_LATENT; cf.sync[cf.n] = S == 1 ? 1 : 3;   // (decoder tile = its own cells)
     ++cf.n;
+    if (!resident && S != 1)
+      if ((rc = fwd_flush())) return rc;
   } else if (tile) {
     if ((rc = gauss_latent_fwd(s, p->mu_pre, ls_pre, a->eps, p->z, p->kl_elem, p->kl_cell,
                                mc_kl ? p->kl_cell : nullptr, S, B, L, a->deterministic_z)))
@@ -910,7 +946,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                              mc_kl ? p->kl_cell : nullptr, S, B, L, a->deterministic_z)))
     return rc;
   }
-  // (under the resident chain the latent stage has not run yet: these follow its launch)
+  // (recorded stages: the latent stage has not run yet -- these follow its launch)
   auto latent_outputs = [&]() -> int {
     if (a->kl_neurons)
       if (int r = col_sum(s, p->kl_elem, L, B, L, a->kl_neurons, 1.f / (float)GB, 0, p->partial)) return r;
@@ -918,7 +954,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       if (int r = copy(s, p->mu_pre, a->q_z_mean, (size_t)B * L)) return r;
     return 0;
   };
-  if (!resident)
+  if (!record)
     if ((rc = latent_outputs())) return rc;
 
   const int E = c.decoder_extra;
@@ -953,11 +989,8 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       if ((rc = fwd_stage(q, 2))) return rc;
       if (i > 0) cur ^= 1;
     }
-    if (resident) {
-      cf.bar = p->mid_bar; cf.bar_base = p->mid_bar_count;
-      unsigned advance = 0;
-      if ((rc = tile_chain_forward(s, cf, (R + 63) / 64, &advance))) return rc;
-      p->mid_bar_count += advance;
+    if (record) {
+      if ((rc = fwd_flush())) return rc;
       if ((rc = latent_outputs())) return rc;
     }
     dch = p->dec.back().h; ld = p->dec.back().n_out;
@@ -1136,21 +1169,41 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     // the dW / db slabs of the layers wait for ONE fixed-order reduce at the end of the pass (they
     // are not on the chain's critical path: four launches fewer); slab buffer i <-> pending job i
     SlabJobs pending;
-    TileChainBwdArgs cb;          // (resident: the stages of the pass, launched once at its end)
+    TileChainBwdArgs cb;          // (the recorded stages: launched in segments, as going forward)
     int cb_tiles = 0;
+    auto bwd_flush = [&]() -> int {
+      if (cb.n == 0) return 0;
+      int r;
+      if (cb.n == 1 && cb.kind[0] == TCS_TILE) {
+        r = tile_backward(s, cb.b[0]);
+      } else if (cb.n == 1 && cb.kind[0] == TCS_STATS) {
+        r = tile_backward_stats(s, cb.stats_dh, cb.stats_bn, cb.stats_rows, cb.stats_N);
+      } else if (cb.n == 1) {
+        const TileLatent& t = cb.lat;
+        r = gauss_latent_bwd(s, t.mu_pre, t.ls_pre, t.eps, t.dz, t.kl_coeff, nullptr, t.dmu, t.dls,
+                             t.S, t.B, t.L);
+      } else {
+        cb.bar = p->mid_bar; cb.bar_base = p->mid_bar_count;
+        unsigned advance = 0;
+        r = tile_chain_backward(s, cb, (R + 63) / 64, &advance);
+        p->mid_bar_count += advance;
+      }
+      cb.n = 0; cb_tiles = 0;
+      return r;
+    };
     auto bwd_stage = [&](const TileBwdArgs& q, int sync_after) -> int {
-      if (!resident) return tile_backward(s, q);
+      if (!record) return tile_backward(s, q);
       SCVAE_ARG(cb.n < TCR_MAX_STAGES && cb_tiles < TCR_MAX_TILES);
       cb.b[cb_tiles] = q;
       cb.kind[cb.n] = TCS_TILE; cb.idx[cb.n] = cb_tiles++; cb.sync[cb.n] = sync_after;
       ++cb.n;
-      return 0;
+      return (!resident && sync_after >= 2) ? bwd_flush() : 0;
     };
     auto flush = [&]() -> int {
       if (pending.n_jobs == 0) return 0;
-      if (resident) {             // (tile_resident_ok: one table holds the jobs of the pass)
-        set_error("resident tile chain: slab job table overflow");
-        return -1;
+      if (cb.n != 0) {            // (a segment in flight still writes slabs of this table)
+        const int rf = bwd_flush();
+        if (rf) return rf;
       }
       const int r = tile_slab_reduce(s, pending);
       pending.n_jobs = 0;
@@ -1159,9 +1212,11 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     {
       Dense& top = p->dec.back();
       const TileBN tb = tile_bn(p, top, nullptr, 0, 0, p->tc_spart[sp]);
-      if (resident) {
+      if (record) {
         cb.stats_dh = dcur; cb.stats_bn = tb; cb.stats_rows = R; cb.stats_N = top.n_out;
         cb.kind[cb.n] = TCS_STATS; cb.sync[cb.n] = 3; ++cb.n;
+        if (!resident)
+          if ((rc = bwd_flush())) return rc;
       } else if ((rc = tile_backward_stats(s, dcur, tb, R, top.n_out))) {
         return rc;
       }
@@ -1198,7 +1253,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
         return rc;
       if (i > 0) { float* t = dcur; dcur = dalt; dalt = t; }
     }
-    if (resident) {
+    if (record) {
       SCVAE_ARG(cb.n < TCR_MAX_STAGES);
       TileLatent& t = cb.lat;
       t.mu_pre = p->mu_pre; t.ls_pre = p->ls_pre; t.eps = a->eps; t.dz = p->dz;
@@ -1245,17 +1300,10 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     // the layer that sees x: its dA here, its weight gradient x^T dA on the count kernels
     Dense& d0 = p->enc[0];
     if ((rc = layer_backward(d0, nullptr, nullptr, B, GB, dh, nullptr, p->dbuf[2]))) return rc;
-    if (resident) {
-      // (the slab sums stay a launch of their own: every tile's slabs would have to cross the
-      //  XCDs' L2s behind a full release / acquire barrier)
-      cb.bar = p->mid_bar; cb.bar_base = p->mid_bar_count;
-      unsigned advance = 0;
-      if ((rc = tile_chain_backward(s, cb, (R + 63) / 64, &advance))) return rc;
-      p->mid_bar_count += advance;
-      const int r = tile_slab_reduce(s, pending);
-      pending.n_jobs = 0;
-      if (r) return r;
-    }
+    // (the slab sums stay a launch of their own: every tile's slabs would have to cross the
+    //  XCDs' L2s behind a full release / acquire barrier)
+    if (record)
+      if ((rc = bwd_flush())) return rc;
     if ((rc = flush())) return rc;
     if (p->sync && p->early_reduce_layer == &d0) {
       // (data parallel: everything between ENCODER/1 and the likelihood heads is final -- its

@@ -1066,7 +1066,8 @@ int tile_chain_forward(hipStream_t s, const TileChainFwdArgs& q, int tiles, unsi
   SCVAE_ARG(q.bar && tiles >= 1 && advance);
   if (int rc = tile_chain_check(q.n, q.kind, q.idx, q.sync, TCR_MAX_TILES)) return rc;
   for (int i = 0; i < q.n; ++i) SCVAE_ARG(q.kind[i] == TCS_TILE || q.kind[i] == TCS_LATENT);
-  SCVAE_ARG(tiles <= tile_chain_resident_capacity());
+  // (a launch with grid barriers needs all its workgroups resident at once)
+  SCVAE_ARG(tile_chain_barriers(q.n, q.sync) == 0 || tiles <= tile_chain_resident_capacity());
   if (int rc = tile_chain_setup()) return rc;
   hipLaunchKernelGGL(tile_chain_fwd_kernel, dim3(tiles), dim3(TC_THREADS), TC_FWD_LDS, s, q);
   SCVAE_LAUNCH_CHECK("tile_chain_fwd_kernel");
@@ -1076,7 +1077,7 @@ int tile_chain_forward(hipStream_t s, const TileChainFwdArgs& q, int tiles, unsi
 int tile_chain_backward(hipStream_t s, const TileChainBwdArgs& q, int tiles, unsigned* advance) {
   SCVAE_ARG(q.bar && tiles >= 1 && advance);
   if (int rc = tile_chain_check(q.n, q.kind, q.idx, q.sync, TCR_MAX_TILES)) return rc;
-  SCVAE_ARG(tiles <= tile_chain_resident_capacity());
+  SCVAE_ARG(tile_chain_barriers(q.n, q.sync) == 0 || tiles <= tile_chain_resident_capacity());
   if (int rc = tile_chain_setup()) return rc;
   hipLaunchKernelGGL(tile_chain_bwd_kernel, dim3(tiles), dim3(TC_THREADS), TC_BWD_LDS, s, q);
   SCVAE_LAUNCH_CHECK("tile_chain_bwd_kernel");

@@ -681,13 +681,12 @@ class ModelBase:
                             "Saving model parameters for previous epoch.")
                         saving_time_start = time()
                         lower_bound_valid_early_stopping = lower_bound_valid
-                        checkpoint_writer.wait()
-                        current_checkpoint = mu.get_checkpoint_state(
-                            log_directory)
-                        if master and current_checkpoint:
-                            mu.copy_model_directory(
-                                current_checkpoint,
-                                early_stopping_log_directory)
+                        # (queued behind the previous epoch's save and ahead of
+                        #  this epoch's: the latest checkpoint then IS the
+                        #  previous epoch's)
+                        if master:
+                            checkpoint_writer.copy_latest(
+                                log_directory, early_stopping_log_directory)
                         say("        "
                             "Previous model parameters saved ({})."
                             .format(format_duration(
@@ -704,9 +703,9 @@ class ModelBase:
                             "Validation loss improved.")
                     epochs_with_no_improvement = 0
                     lower_bound_valid_early_stopping = lower_bound_valid
-                    if master and os.path.exists(
-                            early_stopping_log_directory):
-                        shutil.rmtree(early_stopping_log_directory)
+                    if master:
+                        checkpoint_writer.remove_tree(
+                            early_stopping_log_directory)
                 if epochs_with_no_improvement >= self.early_stopping_rounds:
                     say("    Early stopping in effect:",
                         "Previously saved model parameters is available.")
@@ -728,12 +727,9 @@ class ModelBase:
                     "Saving model parameters as best model parameters.")
                 saving_time_start = time()
                 lower_bound_valid_maximum = lower_bound_valid
-                checkpoint_writer.wait()
-                current_checkpoint = mu.get_checkpoint_state(log_directory)
-                if master and current_checkpoint:
-                    mu.copy_model_directory(
-                        current_checkpoint, best_model_log_directory)
-                    mu.remove_old_checkpoints(best_model_log_directory)
+                if master:   # (behind this epoch's save, see CheckpointWriter)
+                    checkpoint_writer.copy_latest(
+                        log_directory, best_model_log_directory, prune=True)
                 say("    Best model parameters saved ({}).".format(
                     format_duration(time() - saving_time_start)))
             say()
@@ -751,7 +747,7 @@ class ModelBase:
                     run_id=run_id, analyses_directory=analyses_directory)
                 say()
 
-        checkpoint_writer.wait()
+        checkpoint_writer.close()
         training_duration = time() - training_time_start
         say("{} trained for {} epochs ({}).".format(
             capitalise_string(model_string), number_of_epochs,

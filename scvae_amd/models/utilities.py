@@ -164,34 +164,95 @@ def save_checkpoint(state, log_directory, epoch):
 
 
 class CheckpointWriter:
-    """Writes checkpoints on a background thread: the training loop only pays
-    for the device-to-host copy of the state (``engine.state_dict()``), the
-    serialisation and the file system work overlap the next epoch.  Whoever
-    reads the checkpoint files calls ``wait()`` first."""
+    """The file-system side of an epoch on a background thread, in order: the
+    training loop only pays for the device-to-host copy of the state
+    (``engine.state_dict()``); serialising it, the copies into
+    ``early_stopping/`` and ``best/`` (va:1385-1441, 1470-1492) and the pruning
+    of old files overlap the next epoch.  Jobs run strictly in the order they
+    were queued, so "the latest checkpoint of a directory" means what it means
+    in the reference's sequential loop.  Whoever reads the files calls
+    ``wait()`` first; at most two states wait in memory."""
+
+    MAX_PENDING_SAVES = 2
 
     def __init__(self):
+        import atexit
+        import queue
+        atexit.register(self.close)   # (an aborted run still finishes its queued saves)
+        self._jobs = queue.Queue()
         self._thread = None
         self._error = None
+        self._pending_saves = 0
+        import threading
+        self._lock = threading.Lock()
+
+    def _worker(self):
+        while True:
+            job = self._jobs.get()
+            try:
+                if job is None:
+                    return
+                if self._error is None:   # (after a failure: drain without working)
+                    job()
+            except BaseException as error:   # surfaced by the next wait()
+                self._error = error
+            finally:
+                self._jobs.task_done()
+
+    def _submit(self, job):
+        import threading
+        if self._thread is None or not self._thread.is_alive():
+            self._thread = threading.Thread(target=self._worker, daemon=True)
+            self._thread.start()
+        self._jobs.put(job)
 
     def save(self, state, log_directory, epoch):
-        import threading
-        self.wait()
+        while self._pending_saves >= self.MAX_PENDING_SAVES:
+            self.wait()
 
         def work():
             try:
                 save_checkpoint(state, log_directory, epoch)
-            except BaseException as error:   # surfaced by the next wait()
-                self._error = error
-        self._thread = threading.Thread(target=work, daemon=False)
-        self._thread.start()
+            finally:
+                with self._lock:
+                    self._pending_saves -= 1
+        with self._lock:
+            self._pending_saves += 1
+        self._submit(work)
+
+    def copy_latest(self, log_directory, output_directory, prune=False):
+        """``copy_model_directory`` of the checkpoint that is the latest of
+        ``log_directory`` when the job runs (no checkpoint: nothing), with the
+        logs as they are NOW."""
+        logs = snapshot_logs(log_directory)
+
+        def work():
+            latest = get_checkpoint_state(log_directory)
+            if latest:
+                copy_model_directory(latest, output_directory, logs=logs)
+                if prune:
+                    remove_old_checkpoints(output_directory)
+        self._submit(work)
+
+    def remove_tree(self, directory):
+        def work():
+            if os.path.exists(directory):
+                shutil.rmtree(directory)
+        self._submit(work)
 
     def wait(self):
         if self._thread is not None:
-            self._thread.join()
-            self._thread = None
+            self._jobs.join()
         if self._error is not None:
             error, self._error = self._error, None
             raise error
+
+    def close(self):
+        self.wait()
+        if self._thread is not None:
+            self._jobs.put(None)
+            self._thread.join()
+            self._thread = None
 
 
 def load_checkpoint(checkpoint_path):
@@ -202,22 +263,52 @@ def load_checkpoint(checkpoint_path):
                       weights_only=True)
 
 
-def copy_model_directory(checkpoint_path, output_directory):
+def snapshot_logs(source):
+    """The small text files that travel with a checkpoint -- ``*.log`` and the
+    scalar stores under ``training/`` and ``validation/`` -- as {relative path:
+    bytes}, read NOW (the background copy of the checkpoint must not see the
+    records later epochs append)."""
+    files = {}
+    if not os.path.isdir(source):
+        return files
+    for entry in os.listdir(source):
+        path = os.path.join(source, entry)
+        if os.path.isfile(path) and entry.endswith(".log"):
+            with open(path, "rb") as f:
+                files[entry] = f.read()
+        elif os.path.isdir(path) and entry in ("training", "validation"):
+            for root, _, names in os.walk(path):
+                for name in names:
+                    full = os.path.join(root, name)
+                    with open(full, "rb") as f:
+                        files[os.path.relpath(full, source)] = f.read()
+    return files
+
+
+def copy_model_directory(checkpoint_path, output_directory, logs=None):
     """Copy the checkpoint and the scalar logs next to it into
-    ``output_directory`` (``early_stopping/`` and ``best/`` are such copies)."""
+    ``output_directory`` (``early_stopping/`` and ``best/`` are such copies).
+    ``logs``: a ``snapshot_logs`` of the source taken earlier (default: now)."""
     source = os.path.dirname(checkpoint_path)
+    if logs is None:
+        logs = snapshot_logs(source)
     if os.path.exists(output_directory):
         shutil.rmtree(output_directory)
     os.makedirs(output_directory)
-    for entry in os.listdir(source):
-        path = os.path.join(source, entry)
-        if os.path.isfile(path):
-            if (entry == CHECKPOINT_INDEX
-                    or entry == os.path.basename(checkpoint_path)
-                    or entry.endswith(".log")):
-                shutil.copy2(path, os.path.join(output_directory, entry))
-        elif entry in ("training", "validation"):
-            shutil.copytree(path, os.path.join(output_directory, entry))
+    name = os.path.basename(checkpoint_path)
+    # (a state file is written once and renamed into place, never modified: a
+    #  hard link is a copy; across file systems: copy)
+    try:
+        os.link(checkpoint_path, os.path.join(output_directory, name))
+    except OSError:
+        shutil.copy2(checkpoint_path, os.path.join(output_directory, name))
+    with open(os.path.join(output_directory, CHECKPOINT_INDEX), "w") as f:
+        json.dump({"model_checkpoint_path": name}, f)
+    for relative, data in logs.items():
+        target = os.path.join(output_directory, relative)
+        os.makedirs(os.path.dirname(target), exist_ok=True)
+        with open(target, "wb") as f:
+            f.write(data)
 
 
 def remove_old_checkpoints(log_directory):
@@ -273,7 +364,10 @@ def _read_scalars(directory):
         for line in f:
             line = line.strip()
             if line:
-                records.append(json.loads(line))
+                try:
+                    records.append(json.loads(line))
+                except ValueError:   # a torn last line (interrupted append)
+                    continue
     # later records for the same step win (resumed / repeated epochs)
     by_step = {}
     for record in records:
