@@ -1665,7 +1665,7 @@ int decoder_fused3_train_kernel_name(int kind, int H, int rows, bool u16, char* 
   if (d3_schedule(P, H, rows) == 4) {
     const D4Config c = d4_config(P, H);
     const bool six = terms == 6 && c.ks1 <= 4 && c.bn == d3_bn(P) && !c.dbp;
-    return snprintf(out, n, "decoder_head4_kernel<%d, %d, %s, %d, %d, %s, %d, %d>", kind, c.ks1,
+    return snprintf(out, n, "decoder_head4_kernel<%d, %d, %s, %d, %d, %s, %d, %d, false>", kind, c.ks1,
                     u16 ? "true" : "false", c.npw, c.bn == d3_bn(P) ? 0 : c.bn,
                     c.dbp ? "true" : "false", c.npw == 4 ? 1 : D4_G1_EIGHT, six ? 6 : 9);
   }

@@ -1,9 +1,9 @@
 #!/usr/bin/env bash
-# Round-4 profiles of the final build, on the GPU box (writes gpurun_out/<prefix>_*; the summaries
+# Per-round profiles of the final build, on the GPU box (writes gpurun_out/<prefix>_*; the summaries
 # are copied to profiles/ by hand afterwards).
-#   tools/r04_profiles.sh                      prefix r04e: the library's default arithmetic, the
+#   tools/round_profiles.sh                      prefix r04e: the library's default arithmetic, the
 #                                              exact nine-term heads (what bench.py's headline runs)
-#   tools/r04_profiles.sh r04 --head-arith bf16x6   the opt-in six-term heads (profiles/r04_*)
+#   tools/round_profiles.sh r04 --head-arith bf16x6   the opt-in six-term heads (profiles/r04_*)
 #   QUICK=1: headline only.
 #   kernel stats (rocprofv3 --kernel-trace --stats) of the benchmark step for the headline NB VAE,
 #   the Poisson VAE, cfg3 (ZINB VAE, latent 100), cfg4 (NB GMVAE K = 20), cfg5 (ZINB GMVAE K = 20,
