@@ -600,6 +600,49 @@ def evaluation_step(matrix, device, batch, steps=60):
             "value": batch / ms * 1e3, "unit": "cells/s"}
 
 
+def categorised_step(matrix, device, batch, k, steps=12):
+    """The headline model with the piecewise categorical likelihood `-k` (distributions/
+    categorised.py:255-263, va:2507-2532): a training step (fp32 minibatch, forward + backward +
+    clip + Adam; the fetch is not part of it) on the fused kernels -- two launches of the bf16x9
+    head kernel -- and, beside it, on the unfused ones (GEMM + element-wise kernels)."""
+    import torch
+    from scvae_amd.engine import Engine
+    F = matrix.shape[1]
+    rows = torch.arange(batch, device=device)
+    rc = torch.empty(batch, device=device)
+    x = matrix.gather_dense(rows, row_const_out=rc)
+    eps = torch.randn(1, batch, LATENT, device=device)
+    out = {}
+    for fused in (True, False):
+        eng = Engine(F, LATENT, HIDDEN, LIKELIHOOD, batch_norm=True, device=device, seed=0,
+                     k_max=k)
+        eng.set_fused(fused)
+        eng.reserve(batch, 1)
+        assert eng.fused_categorised == fused
+        for _ in range(3):
+            eng.step(x, x, eps=eps, row_const=rc, training=True, x_counts=True)
+            eng.adam_step(1e-4)
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            eng.step(x, x, eps=eps, row_const=rc, training=True, x_counts=True)
+            eng.adam_step(1e-4)
+        e1.record()
+        torch.cuda.synchronize(device)
+        out["fused" if fused else "unfused"] = e0.elapsed_time(e1) / steps
+        del eng
+        torch.cuda.empty_cache()
+    del x
+    torch.cuda.empty_cache()
+    return {"workload": "headline model with -k {} (piecewise categorical likelihood), training "
+                        "step without the fetch, {} cells: ".format(k, batch)
+                        + describe(matrix.shape[0], F, LIKELIHOOD, False, 1, LATENT),
+            "cells_per_step": batch, "steps": steps, "ms_per_step": out["fused"],
+            "ms_per_step_unfused_kernels": out["unfused"],
+            "value": batch / out["fused"] * 1e3, "unit": "cells/s"}
+
+
 def model_train_epoch(matrix, device, batch, epochs):
     """The drop-in's own entry point: ``VariationalAutoencoder.train`` (the Python epoch loop of
     va:958-1599 -- shuffled minibatches, one step call each, the printed lines, BOTH epoch-end
@@ -707,6 +750,7 @@ def other_workloads(matrix, device, barrier):
     measure("cfg5_zinb_gmvae_k20_latent_100_f27998", note5,
             m5, 512, "zero-inflated negative binomial", 100, "gmvae", 10)
     out["evaluation_step"] = evaluation_step(matrix, device, 4096)
+    out["headline_model_k1_categorised"] = categorised_step(matrix, device, 4096, 1)
     for b, epochs in ((4096, 4), (100, 3)):
         out["model_train_epoch_b{}".format(b)] = model_train_epoch(matrix, device, b, epochs)
     # Opt-in arithmetic, NOT the headline: the same steps with the heads' products as six of the

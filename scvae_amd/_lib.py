@@ -150,6 +150,7 @@ SIGNATURES = {
     "scvae_plan_set_fused": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_set_head_arith": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_head_arith": (c_int32, [c_void_p]),
+    "scvae_plan_fused_categorised": (c_int32, [c_void_p]),
     "scvae_plan_set_tile_resident": (c_int32, [c_void_p, c_int32]),
     "scvae_plan_uses_tile_resident": (c_int32, [c_void_p, c_int64, c_int32]),
     "scvae_plan_set_dd_atomics": (c_int32, [c_void_p, c_int32]),

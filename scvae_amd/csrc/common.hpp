@@ -52,12 +52,17 @@ enum Likelihood : int {
   LK_ZINB = 3,     // heads: pi, p, log_r
   LK_CPOISSON = 4, // constrained Poisson (du:218-228): head lambda = softmax over the genes,
                    // rate = lambda * N with N the count sum of the cell; unfused path only
-  LK_BERNOULLI = 5 // heads: logits (du:194-204; binarised targets); unfused path only
+  LK_BERNOULLI = 5, // heads: logits (du:194-204; binarised targets); unfused path only
+  // (internal to the fused kernels, never a model's likelihood) the categorical part of the
+  // piecewise categorical likelihood `-k` (distributions/categorised.py:255-263, va:2507-2532):
+  // k + 1 classes of one gene as k + 1 "heads", log softmax(logits)[min(t, k)]
+  LK_CAT2 = 6,      // k = 1: classes 0, >= 1
+  LK_CAT3 = 7       // k = 2: classes 0, 1, >= 2
 };
 __host__ __device__ constexpr int likelihood_heads(int kind) {
   return (kind == LK_POISSON || kind == LK_CPOISSON || kind == LK_BERNOULLI)
              ? 1
-             : (kind == LK_ZINB ? 3 : 2);
+             : ((kind == LK_ZINB || kind == LK_CAT3) ? 3 : 2);
 }
 
 #ifdef __HIPCC__

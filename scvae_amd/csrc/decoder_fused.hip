@@ -735,7 +735,8 @@ static int launch_decoder(hipStream_t s, int kind, const float* d, int rows, int
     static const int dbg = [] { const char* e = getenv("SCVAE_D3_DEBUG"); return e ? atoi(e) : 0; }();
     return decoder_fused3_launch(s, true, kind, d, rows, H, hp, F, t, B, gw,
                                  inline_lgamma | (dbg << 8), ll_part, dd_part, planes, drop, 0,
-                                 nullptr, (dd_mode ? 1 : 0) | (arith == 2 ? 2 : 0), rg_slab);
+                                 nullptr, (dd_mode & 1) | (arith == 2 ? 2 : 0) | (dd_mode & 4),
+                                 rg_slab);
   }
   if (drop) {
     set_error("head dropout inside the fused kernel needs the bf16x9 head kernel");
@@ -935,7 +936,11 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
             decoder_fused_train_supported(heads, H, arith));
   SCVAE_ARG(!drop || decoder_fused3_supported(heads, H));
   if (rows == 0) return 0;
-  const int bn = decoder_train_kernel(heads, H, arith) == 3
+  const bool head3 = (dd_mode & 4) != 0;     // (forced: decoder_fused_train_cat)
+  SCVAE_ARG(!head3 || (decoder_train_kernel(heads, H, arith) == 3 && decoder_fused_supported(H)));
+  if (head3) dd_mode &= ~1;                   // (only the producer / consumer kernel has the atomics)
+  const int bn = head3 ? decoder_fused3_strip_genes(heads)
+                 : decoder_train_kernel(heads, H, arith) == 3
                      ? decoder_fused3_train_strip_genes(heads, H, rows, drop != nullptr, 0)
                      : DF_BN;
   const int strips = (F + bn - 1) / bn;
@@ -946,8 +951,11 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
   // (the last region of the workspace: behind everything the constrained-Poisson passes carve)
   float* rg_slab = workspace + decoder_fused_workspace_floats(rows, H, F, true) -
                    (decoder_fused3_rg_slab_floats(H, F) + 64);
+  // (the data-only term lgamma(1 + t): the caller's row constant, or inline; the Bernoulli and
+  //  the categorical kinds have none)
+  const bool no_lgamma = kind == LK_BERNOULLI || kind == LK_CAT2 || kind == LK_CAT3;
   int rc = launch_decoder<true>(s, kind, d, rows, H, hp, F, t, B, gw,
-                                (row_const || kind == LK_BERNOULLI) ? 0 : 1, ll_part, dd_part,
+                                (row_const || no_lgamma) ? 0 : 1, ll_part, dd_part,
                                 arith, planes, drop, dd_mode, rg_slab);
   if (rc) return rc;
   if (kernel_only) return 0;  // profiling aid: leave the per-strip partials unreduced
@@ -994,6 +1002,60 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
                        strips, n, dd);
   }
   SCVAE_LAUNCH_CHECK("dd_reduce_kernel");
+  return 0;
+}
+
+// ---- the piecewise categorical likelihood `-k` on the fused kernels ----
+// log p(t) = log softmax(logits)[min(t, k)] + [t >= k] log p_count(t - k)
+// (distributions/categorised.py:255-263, va:2507-2532) is a SUM, so the step is two launches of
+// decoder_head3_kernel over the same d and the same gw: the count distribution's heads on shifted,
+// masked targets (Targets::shift), and the k + 1 class logits of every gene -- columns c,
+// c + (k + 1), ... of the P_K head's [H, F (k + 1)] matrix -- as k + 1 heads of a categorical
+// kind (LK_CAT2 / LK_CAT3: k = 1, 2; more classes than the kernels have heads stay unfused).
+// ll and dd of the two are added.  Nothing [rows, (P + k + 1) F]-sized touches HBM.
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a,
+                                                          const float* __restrict__ b, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    a[i] += b[i];
+}
+bool decoder_fused_cat_supported(int kind, int k_max, int H, int arith) {
+  return (kind == LK_POISSON || kind == LK_NB) && (k_max == 1 || k_max == 2) && arith >= 1 &&
+         decoder_fused_supported(H) && decoder_fused3_supported(3, H);
+}
+int decoder_fused_train_cat(hipStream_t s, int kind, int k_max, const float* d, int rows, int H,
+                            HeadParams hp, const float* Wk, const float* bk, float* dWk,
+                            float* dbk, int F, const float* t, int B, const float* gw, float* ll,
+                            float* dd, float* workspace, int arith, float* scratch) {
+  SCVAE_ARG(decoder_fused_cat_supported(kind, k_max, H, arith) && Wk && bk && dWk && dbk && scratch);
+  if (rows == 0) return 0;
+  Targets shifted = targets_f32(t, F);
+  shifted.shift = (float)k_max;
+  int rc = decoder_fused_train(s, kind, d, rows, H, hp, F, shifted, B, gw, nullptr, ll, dd,
+                               workspace, arith, false, nullptr, 4);
+  if (rc) return rc;
+  HeadParams hc;
+  for (int c = 0; c < 3; ++c) {
+    const bool on = c <= k_max;
+    hc.W[c] = on ? Wk + c : nullptr;
+    hc.b[c] = on ? bk + c : nullptr;
+    hc.dW[c] = on ? dWk + c : nullptr;
+    hc.db[c] = on ? dbk + c : nullptr;
+  }
+  hc.gene_stride = k_max + 1;
+  hc.row_pitch = F * (k_max + 1);
+  float* ll2 = scratch;
+  float* dd2 = scratch + ((size_t)rows + 63) / 64 * 64;
+  rc = decoder_fused_train(s, k_max == 1 ? LK_CAT2 : LK_CAT3, d, rows, H, hc, F,
+                           targets_f32(t, F), B, gw, nullptr, ll2, dd2, workspace, arith, false,
+                           nullptr, 4);
+  if (rc) return rc;
+  const size_t n = (size_t)rows * H;
+  hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, ll,
+                     ll2, (size_t)rows);
+  hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)),
+                     dim3(256), 0, s, dd, dd2, n);
+  SCVAE_LAUNCH_CHECK("add_inplace_kernel");
   return 0;
 }
 

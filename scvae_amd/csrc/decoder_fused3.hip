@@ -296,14 +296,18 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
     const bool col_ok = c0 + g < F;
     const int gc = min(c0 + g, F - 1);
     float v[P][NV];
+    // (the plain [H, F] layout, or -- the class logits of the P_K head -- genes gene_stride apart
+    //  in rows of row_pitch elements)
+    const size_t gs = hp.gene_stride ? hp.gene_stride : 1;
+    const size_t rp = hp.row_pitch ? hp.row_pitch : F;
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-      const float* wj = hp.W[j] + gc;
-      const float* bj = hp.b[j] + gc;
+      const float* wj = hp.W[j] + gc * gs;
+      const float* bj = hp.b[j] + gc * gs;
 #pragma unroll
       for (int u = 0; u < NV; ++u) {
         const int h = h0 + u * HSTEP;
-        const float* src = h < H ? wj + (size_t)h * F : bj;
+        const float* src = h < H ? wj + (size_t)h * rp : bj;
         v[j][u] = *src;
       }
     }
@@ -583,12 +587,16 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
         float a[P], g[P], lp, r, rgate;
 #pragma unroll
         for (int j = 0; j < P; ++j) a[j] = acc1[j][sb][e];
+        // (tg.shift > 0 -- the count part of the piecewise categorical likelihood: the
+        //  distribution sees t - shift where t >= shift, nothing elsewhere; 0: every element)
+        const bool live = tval[4 * sb + e] >= tg.shift;
+        tval[4 * sb + e] = live ? tval[4 * sb + e] - tg.shift : 0.f;
         lik_dense<KIND, TRAIN>(tval[4 * sb + e], a, lp, g, r, rgate);
-        const bool ok = c0 + gbase + 16 * sb + 4 * q + e < F;
+        const bool ok = live && c0 + gbase + 16 * sb + 4 * q + e < F;
         lsum += ok ? lp : 0.f;
         if (TRAIN) {
 #pragma unroll
-          for (int j = 0; j < P; ++j) G[j][4 * sb + e] = up * g[j];
+          for (int j = 0; j < P; ++j) G[j][4 * sb + e] = live ? up * g[j] : 0.f;
         }
         nz |= (ok && tval[4 * sb + e] > 0.f) ? (1u << (4 * sb + e)) : 0u;
       }
@@ -836,13 +844,15 @@ __global__ __launch_bounds__(D3_THREADS) void decoder_head3_kernel(
   if (ht < n_ht2 && (!KSPLIT || hi2 == 0)) {
     const int c = c0 + (KSPLIT ? 0 : 32 * hi2) + li;
     if (c < F) {
+      const size_t gs_out = hp.gene_stride ? hp.gene_stride : 1;
+      const size_t rp_out = hp.row_pitch ? hp.row_pitch : F;
 #pragma unroll
       for (int j = 0; j < P; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int h = 32 * ht + (i & 3) + 8 * (i >> 2) + 4 * kh;
-          if (h < H) hp.dW[j][(size_t)h * F + c] = accW[j][i];
-          else if (h == H) hp.db[j][c] = accW[j][i];
+          if (h < H) hp.dW[j][(size_t)h * rp_out + c * gs_out] = accW[j][i];
+          else if (h == H) hp.db[j][c * gs_out] = accW[j][i];
         }
     }
   }
@@ -1654,7 +1664,7 @@ int decoder_fused3_train_strip_genes(int P, int H, int rows, bool drop, int cp_p
 // consumer kernel has that store
 bool decoder_fused3_dd_atomics(int kind, int H, int rows, bool drop, int cp_pass, int dd_mode) {
   const int P = likelihood_heads(kind);
-  return dd_mode && !drop && cp_pass == 0 && d3_schedule(P, H, rows) == 4;
+  return (dd_mode & 1) && !(dd_mode & 4) && !drop && cp_pass == 0 && d3_schedule(P, H, rows) == 4;
 }
 
 // the training instantiation a plain launch (no dropout, no constrained-Poisson pass) takes, as
@@ -1832,6 +1842,10 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
   //  heads: decoder_fused_forward sends it exactly those)
   const bool wide = !decoder_fused3_supported(P, H) ||
                     (!train && cp_pass == 0 && (P > 2 || !decoder_fused_supported(H)));
+  // (dd_mode & 4: the all-in-one-phase kernel whatever the row count -- the two launches of the
+  //  piecewise categorical likelihood, whose strided heads and shifted targets only it takes)
+  SCVAE_ARG(!(dd_mode & 4) || (train && !wide && !drop && cp_pass == 0));
+  SCVAE_ARG((hp.gene_stride == 0 && t.shift == 0.f) || (dd_mode & 4));
   SCVAE_ARG(planes && (!wide || (!drop && cp_pass == 0 && decoder_fused4_supported(P, H))));
   SCVAE_ARG(train || !drop);
   SCVAE_ARG((kind == LK_CPOISSON) == (cp_pass >= 1 && cp_pass <= 3 && cp && cp->count_sum));
@@ -1901,7 +1915,7 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
       case LK_BERNOULLI: SCVAE_D3(LK_BERNOULLI, true, true); break;
       default: set_error("decoder_head3_kernel: likelihood kind %d", kind); return -1;
     }
-  } else if ((train && d3_schedule(P, H, rows) == 4) || (!train && wide)) {
+  } else if ((train && !(dd_mode & 4) && d3_schedule(P, H, rows) == 4) || (!train && wide)) {
     const D4Config c = d4_config(P, H);
     D4Launch a{s, dA, dT, rows, Rpad, H, hp, F, t, B, gw, inline_lgamma, ll_part, dd_part,
                (dd_mode & 1) ? 1 : 0, (F + c.bn - 1) / c.bn, c.lds, (dd_mode & 2) ? 6 : 9, 1,
@@ -1930,6 +1944,8 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
       case LK_ZIP: SCVAE_D3(LK_ZIP, true, false); break;
       case LK_ZINB: SCVAE_D3(LK_ZINB, true, false); break;
       case LK_BERNOULLI: SCVAE_D3(LK_BERNOULLI, true, false); break;   // du:194-204; targets binarised by the caller
+      case LK_CAT2: SCVAE_D3(LK_CAT2, true, false); break;   // the class logits of -k (decoder_fused_train_cat)
+      case LK_CAT3: SCVAE_D3(LK_CAT3, true, false); break;
       default: set_error("decoder_head3_kernel: likelihood kind %d", kind); return -1;
     }
   } else {

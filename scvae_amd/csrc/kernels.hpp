@@ -314,9 +314,12 @@ struct Targets {
   const void* p;
   int ld;
   int u16;
+  // (the count part of the piecewise categorical likelihood, decoder_head3_kernel only) the count
+  // distribution sees t - shift where t >= shift and nothing -- no term, no gradient -- elsewhere
+  float shift;
 };
-inline Targets targets_f32(const float* t, int F) { return Targets{t, F, 0}; }
-inline Targets targets_u16(const uint16_t* t, int ld) { return Targets{t, ld, 1}; }
+inline Targets targets_f32(const float* t, int F) { return Targets{t, F, 0, 0.f}; }
+inline Targets targets_u16(const uint16_t* t, int ld) { return Targets{t, ld, 1, 0.f}; }
 #ifdef __HIPCC__
 // a target as loaded (kept raw while the load is in flight: no instruction touches it) and as
 // the fp32 value the likelihood uses
@@ -331,12 +334,25 @@ struct HeadParams {
   const float* b[3];
   float* dW[3];
   float* db[3];
+  // (decoder_head3_kernel only; 0: the plain [H, F] / [F] layout) element stride between the
+  // genes of a head and pitch of its weight rows: the k + 1 class logits of the P_K head are
+  // columns c, c + (k + 1), ... of one [H, F (k + 1)] matrix (va:2507-2518)
+  int gene_stride = 0;
+  int row_pitch = 0;
 };
 bool decoder_fused_supported(int H);                       // every fused kernel: even H <= 126
 // a TRAINING launch of the fused heads: the above, or (bf16x9) the producer / consumer kernel's
 // wider range -- H <= 256 (one / two heads), <= 159 (three), odd H included
 bool decoder_fused_train_supported(int P, int H, int arith);
 size_t decoder_fused_workspace_floats(int rows, int H, int F, bool train);
+// the piecewise categorical likelihood -k (k_max = 1, 2; Poisson / negative-binomial counts) as
+// two launches of the bf16x9 all-in-one-phase kernel: Wk / bk / dWk / dbk the P_K head
+// [H, F (k_max + 1)] / [F (k_max + 1)]; t fp32 [B, F]; scratch: rows * (H + 1) + 64 floats
+bool decoder_fused_cat_supported(int kind, int k_max, int H, int arith);
+int decoder_fused_train_cat(hipStream_t s, int kind, int k_max, const float* d, int rows, int H,
+                            HeadParams hp, const float* Wk, const float* bk, float* dWk,
+                            float* dbk, int F, const float* t, int B, const float* gw, float* ll,
+                            float* dd, float* workspace, int arith, float* scratch);
 size_t decoder_fused_lds_bytes(int P, int H, bool train);
 int decoder_fused_variant(int P, int H);   // 1: decoder_head_kernel, 2: decoder_head2_kernel
 bool decoder_fused2_supported(int P, int H);

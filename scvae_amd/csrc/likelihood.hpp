@@ -33,7 +33,27 @@ struct LikelihoodTraits {
 template <int KIND, bool GRAD>
 __device__ __forceinline__ void lik_dense(float t, const float* a, float& lp, float* g, float& r,
                                           float& rgate) {
-  if constexpr (KIND == LK_BERNOULLI) {
+  if constexpr (KIND == LK_CAT2 || KIND == LK_CAT3) {
+    // tfp.distributions.Categorical(logits).log_prob(min(t, k)), k + 1 = P classes
+    // (categorised.py:255-259): log softmax, gradient one-hot minus softmax
+    constexpr int PC = likelihood_heads(KIND);
+    float m = a[0];
+#pragma unroll
+    for (int j = 1; j < PC; ++j) m = fmaxf(m, a[j]);
+    float e[PC], se = 0.f;
+#pragma unroll
+    for (int j = 0; j < PC; ++j) { e[j] = __expf(a[j] - m); se += e[j]; }
+    const float lse = m + fast_log(se);
+    const float inv = fast_rcp(se);
+    lp = 0.f;
+#pragma unroll
+    for (int j = 0; j < PC; ++j) {
+      const bool mine = j + 1 < PC ? t == (float)j : t >= (float)j;
+      lp += mine ? a[j] - lse : 0.f;
+      if (GRAD) g[j] = (mine ? 1.f : 0.f) - e[j] * inv;
+    }
+    r = 0.f; rgate = 0.f;
+  } else if constexpr (KIND == LK_BERNOULLI) {
     // tfp.distributions.Bernoulli(logits): t log sigmoid(a) + (1 - t) log sigmoid(-a)
     float ls_pos, ls_neg, sig, sig_neg;
     log_sigmoid_pair(a[0], ls_pos, ls_neg, sig, sig_neg);

@@ -1034,8 +1034,13 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   const Targets tg = p->x_u16 ? targets_u16(p->step_u16, p->step_u16_ld) : targets_f32(a->t, F);
   const HeadParams hp = head_params(p);
+  // -k (k = 1, 2) in a training step of one likelihood pass: two launches of the bf16x9 head
+  // kernel (decoder_fused_train_cat) instead of materialised pre-activations and logits
+  const bool fused_cat = training && n_iw == 1 && KM > 0 && p->use_fused && p->fused_ws &&
+                         p->pre_k && ld == h1 && !head_drop && !p->x_u16 && !a->p_x_mean &&
+                         decoder_fused_cat_supported(c.likelihood, KM, h1, p->head_arith);
   const float* head_in[4] = {dch, dch, dch, dch};   // [3]: the P_K head
-  if (!fused)
+  if (!fused && !fused_cat)
     if ((rc = heads_forward(p, s, dch, ld, R, training, head_in))) return rc;
   // per-row log-likelihood, forward only
   auto loglik_forward = [&]() -> int {
@@ -1120,6 +1125,13 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
                                p->ll, dcur, p->fused_ws, p->head_arith, false,
                                head_drop ? &hdrop : nullptr, p->dd_atomics);
     if (rc) return rc;
+  } else if (fused_cat) {
+    // (pre_k -- the logits' buffer of the unfused path -- is free: ll / dd of the second launch)
+    Dense& hk = p->head_k;
+    if ((rc = decoder_fused_train_cat(s, c.likelihood, KM, dch, R, h1, hp, p->params + hk.w,
+                                      p->params + hk.b, p->grads + hk.w, p->grads + hk.b, F, a->t,
+                                      B, p->gw, p->ll, dcur, p->fused_ws, p->head_arith, p->pre_k)))
+      return rc;
   } else {
     if (KM > 0)
       rc = loglik_cat_bwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->gw,
@@ -1596,6 +1608,13 @@ int32_t scvae_plan_uses_tile_resident(const scvae_plan* p, int64_t cells, int32_
   return tile_chain_ok(p, (int)cells, samples, true) &&
                  tile_resident_ok(p, (int)(cells * samples))
              ? 1 : 0;
+}
+int32_t scvae_plan_fused_categorised(const scvae_plan* p) {
+  // (what vae_step / gmvae_step test per step, without the step's own arguments)
+  if (!p || p->cfg.k_max <= 0 || !p->use_fused || !p->fused_ws || !p->pre_k) return 0;
+  if (p->heads[0].keep > 0.f) return 0;
+  return scvae::decoder_fused_cat_supported(p->cfg.likelihood, p->cfg.k_max, p->heads[0].n_in,
+                                            p->head_arith) ? 1 : 0;
 }
 int scvae_plan_set_mid_chain(scvae_plan* p, int32_t enabled) {
   SCVAE_ARG(p);

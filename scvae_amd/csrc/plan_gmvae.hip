@@ -499,8 +499,13 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   // the bytes of every pass
   const Targets tg = p->x_u16 ? targets_u16(p->step_u16, p->step_u16_ld) : targets_f32(a->t, F);
   const HeadParams hp = head_params(p);
+  // -k (k = 1, 2) in a training step: two launches of the bf16x9 head kernel over the K stacked
+  // passes (decoder_fused_train_cat, see plan.hip)
+  const bool fused_cat = training && KM > 0 && p->use_fused && p->fused_ws && p->pre_k &&
+                         ld == h1 && !head_drop && !p->x_u16 && !a->p_x_mean &&
+                         decoder_fused_cat_supported(c.likelihood, KM, h1, p->head_arith);
   const float* head_in[4] = {dch, dch, dch, dch};   // [3]: the P_K head
-  if (!fused) TRY(heads_forward(p, s, dch, ld, R, training, head_in));
+  if (!fused && !fused_cat) TRY(heads_forward(p, s, dch, ld, R, training, head_in));
   bool ll_done = false;
   if (a->p_x_mean) {
     if (!(a->p_x_stddev && a->stddev_of_p_x_given_z_mean)) {
@@ -573,6 +578,11 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       TRY(decoder_fused_train(s, c.likelihood, dch, R, h1, hp, F, tg, B, p->gw, a->row_const,
                               p->ll, dcur, p->fused_ws, p->head_arith, false,
                               head_drop ? &hdrop : nullptr, p->dd_atomics));
+  } else if (fused_cat) {
+    Dense& hk = p->head_k;
+    TRY(decoder_fused_train_cat(s, c.likelihood, KM, dch, R, h1, hp, p->params + hk.w,
+                                p->params + hk.b, p->grads + hk.w, p->grads + hk.b, F, a->t, B,
+                                p->gw, p->ll, dcur, p->fused_ws, p->head_arith, p->pre_k));
   } else if (KM > 0) {
     TRY(loglik_cat_bwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->gw, p->ll, R, B, F));
   } else if (cpoisson) {
@@ -596,7 +606,7 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   if (a->log_p_x_given_z) TRY(copy(s, p->ll, a->log_p_x_given_z, (size_t)R));
 
   // ---------------- backward: heads + decoder ----------------
-  if (!fused) TRY(heads_backward(p, s, head_in, R, head_drop, dcur, dalt));
+  if (!fused && !fused_cat) TRY(heads_backward(p, s, head_in, R, head_drop, dcur, dalt));
   // the next minibatch and its noise (scvae_step_args.side) under the rest of the backward pass
   TRY(plan_side_fork(p, s, 1));
   const int64_t GSB = GB * S;  // global rows per group (pass) in the decoder

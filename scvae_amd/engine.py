@@ -295,6 +295,12 @@ class Engine:
         _lib.check(self.lib.scvae_plan_set_fused(
             self.handle, 1 if enabled else 0), "scvae_plan_set_fused")
 
+    @property
+    def fused_categorised(self):
+        """Whether training steps run ``-k`` on the fused head kernels (k = 1, 2;
+        bound plan)."""
+        return bool(self.lib.scvae_plan_fused_categorised(self.handle))
+
     def set_head_arith(self, arith):
         """Arithmetic of this engine's fused head kernels: ``"bf16x9"`` (the
         exact nine-term bf16 split, default), ``"bf16x6"`` (the nine terms

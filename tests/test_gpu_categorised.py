@@ -96,6 +96,78 @@ def test_step_with_categorised_likelihood(cuda_device, model_type, likelihood,
            "decode")
 
 
+@pytest.mark.parametrize("model_type", ["VAE", "GMVAE"])
+@pytest.mark.parametrize("likelihood", ["negative binomial", "poisson"])
+@pytest.mark.parametrize("KM", [1, 2])
+def test_fused_categorised_training_step(cuda_device, model_type, likelihood,
+                                         KM):
+    """-k with k = 1, 2 in a training step: two launches of the bf16x9 head
+    kernel (``decoder_fused_train_cat``: the count distribution on shifted,
+    masked targets + the k + 1 class logits of every gene as heads of a
+    categorical kind, read with a stride from the P_K matrix) -- against the
+    fp64 oracle and against the unfused kernels of the same build.  Several
+    row tiles, a ragged last gene strip, counts on both sides of k."""
+    from scvae_amd.engine import Engine
+    F, L, H, B, K = 150, 5, (30, 20), 100, 3
+    gm = model_type == "GMVAE"
+    rng = np.random.default_rng(5 + KM)
+    x = rng.poisson(1.5, (B, F)) * (rng.random((B, F)) > 0.4)
+    x[0, :7] = [0, 1, 2, 3, 4, 40, 300]
+    x = torch.from_numpy(x.astype(np.float64))
+    eps = torch.from_numpy(rng.standard_normal((K, 1, B, L) if gm else (1, B, L)))
+    xd, epsd = x.float().to(cuda_device), eps.float().to(cuda_device)
+    rows = (K if gm else 1) * B
+    results = {}
+    for fused in (True, False):
+        eng = Engine(F, L, H, likelihood, batch_norm=True,
+                     model_type=model_type, n_clusters=K, device=cuda_device,
+                     seed=2, k_max=KM)
+        g = torch.Generator().manual_seed(7)
+        for name, p in eng.named_parameters().items():
+            if not name.endswith("weights"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+        eng.set_fused(fused)
+        eng.reserve(B, 1)
+        assert eng.fused_categorised == fused
+        ll = torch.zeros(rows, device=cuda_device)
+        sc = eng.step(xd, xd, eps=epsd, training=True,
+                      outputs={"log_p_x_given_z": ll}).cpu().numpy()
+        torch.cuda.synchronize()
+        results[fused] = (sc, ll.cpu(), {k: v.clone().cpu() for k, v in
+                                         eng.named_gradients().items()})
+        if fused:
+            params = {k: v.detach().cpu().double()
+                      for k, v in eng.named_parameters().items()}
+            moving = {k: v.detach().cpu().double()
+                      for k, v in eng.named_moving_statistics().items()}
+    cfg = om.ModelConfig(feature_size=F, latent_size=L, hidden_sizes=H,
+                         likelihood=likelihood, n_clusters=K, k_max=KM)
+    # (the moving statistics were read before the step updated them? no: after;
+    #  a training step normalises with batch statistics, they do not enter)
+    forward = om.gmvae_forward if gm else om.vae_forward
+    out, grads = om.gradients(
+        lambda p: forward(cfg, p, moving, x, x, eps, True), params)
+    sc, ll, dev = results[True]
+    _close(sc[0], out["lower_bound"], 1e-4, "lower_bound")
+    close_elementwise(ll, out["log_p_x_given_z"].reshape(-1), rtol=LL_RTOL,
+                      atol=LL_ATOL, what="per-cell ll")
+    for name, g in dev.items():
+        if name.endswith("DENSE/biases") and (
+                "LAYER_" in name or "ENCODER/" in name or "DECODER/" in name):
+            continue   # bias under batch norm: zero gradient
+        want = grads[name]
+        if gm and name == "Z/Q/ENCODER/LAYER_1/DENSE/weights":
+            g, want = g[:F], want[:F]
+        _close(g, want, 3e-4, "grad " + name)
+        # ... and the unfused kernels agree with the fused ones
+        u = results[False][2][name]
+        if gm and name == "Z/Q/ENCODER/LAYER_1/DENSE/weights":
+            u = u[:F]
+        _close(g, u, 3e-4, "fused vs unfused grad " + name)
+    close_elementwise(ll, results[False][1], rtol=LL_RTOL, atol=LL_ATOL,
+                      what="fused vs unfused per-cell ll")
+
+
 def test_categorised_model_trains_and_evaluates(tmp_path, cuda_device, capsys):
     from scvae_amd.data import DataSet
     from scvae_amd.models import VariationalAutoencoder
