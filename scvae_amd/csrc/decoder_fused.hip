@@ -796,20 +796,21 @@ int decoder_fused_forward(hipStream_t s, int kind, const float* d, int rows, int
   // and the C ABI size no other): the bf16 planes of d go behind ll_part.
   static const int forced = [] {
     const char* e = getenv("SCVAE_DECODER_FORWARD");
-    return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : -1;
+    return (e && e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : -1;
   }();
   int which = decoder_forward_supported(heads, H) ? 1 : 0;
   if (arith >= 1 && heads <= 2 && decoder_fused3_supported(heads, H)) which = 3;
   if (forced == 0) which = 0;
   if (forced == 1 && decoder_forward_supported(heads, H)) which = 1;
   if (wide) which = 4;
+  if (forced == 4 && arith >= 1 && decoder_fused4_supported(heads, H)) which = 4;
   int rc;
   if (which == 4) {
-    const int bn = decoder_fused3_train_strip_genes(heads, H, rows, false, 0);
+    const int bn = d4_strip_genes(heads, H);
     strips = (F + bn - 1) / bn;
     float* planes = workspace + ((size_t)strips * rows + 63) / 64 * 64;
     rc = decoder_fused3_launch(s, false, kind, d, rows, H, hp, F, t, B, nullptr, inline_lgamma,
-                               ll_part, nullptr, planes);
+                               ll_part, nullptr, planes, nullptr, 0, nullptr, 8);
   } else if (which == 3) {
     const int bn = decoder_fused3_strip_genes(heads);
     strips = (F + bn - 1) / bn;

@@ -1653,6 +1653,7 @@ static int d3_schedule(int P, int H, int rows) {
   if (!decoder_fused4_supported(P, H)) return 3;
   return d3_schedule_env() ? d3_schedule_env() : (rows <= 128 ? 3 : 4);
 }
+int d4_strip_genes(int P, int H) { return d4_config(P, H).bn; }   // the producer / consumer kernel's
 // genes per workgroup (= per slab of ll_part / dd_part) of a TRAINING launch
 int decoder_fused3_train_strip_genes(int P, int H, int rows, bool drop, int cp_pass) {
   if (!drop && cp_pass == 0 && d3_schedule(P, H, rows) == 4) return d4_config(P, H).bn;
@@ -1840,8 +1841,11 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
   // (head4 alone: beyond the all-in-one-phase kernel's LDS budget; forward-only calls also the
   //  widths and head counts that kernel's forward instantiation does not take -- odd widths, three
   //  heads: decoder_fused_forward sends it exactly those)
+  // (dd_mode & 8: a forward-only call asks for the producer / consumer kernel's forward half at a
+  //  width the all-in-one-phase kernel would take too)
   const bool wide = !decoder_fused3_supported(P, H) ||
-                    (!train && cp_pass == 0 && (P > 2 || !decoder_fused_supported(H)));
+                    (!train && cp_pass == 0 &&
+                     (P > 2 || !decoder_fused_supported(H) || (dd_mode & 8)));
   // (dd_mode & 4: the all-in-one-phase kernel whatever the row count -- the two launches of the
   //  piecewise categorical likelihood, whose strided heads and shifted targets only it takes)
   SCVAE_ARG(!(dd_mode & 4) || (train && !wide && !drop && cp_pass == 0));

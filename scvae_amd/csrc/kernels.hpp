@@ -375,6 +375,7 @@ int decoder_fused_train(hipStream_t s, int kind, const float* d, int rows, int H
 // training kernel on the bf16 matrix cores, exact nine-term split (decoder_fused3.hip)
 bool decoder_fused3_supported(int P, int H);
 size_t decoder_fused3_lds_bytes(int P, int H);
+int d4_strip_genes(int P, int H);      // ... of the producer / consumer kernel (any row count)
 int decoder_fused3_strip_genes(int P);   // genes per workgroup (= per slab of ll_part / dd_part)
 int decoder_fused3_train_kernel_name(int kind, int H, int rows, bool u16, char* out, size_t n,
                                      int terms = 9);
