@@ -402,12 +402,11 @@ __device__ __forceinline__ void tile_bwd_body(const TileBwdArgs& q, float* tsm, 
   const bool bn = q.bn.a != nullptr;
   // ---- every input tile is requested up front (the chunk sums of this layer's batch norm
   //      first: they are needed first and loads return in order) ----
-  LinePre<8> pp_first;
+  float pm[TC_ZPT], pv[TC_ZPT];     // chunk (sum dxh, sum dxh xh) of chunks rl, rl + 4, ... of a block
   if (bn && q.bn.part) {
     const int gt0 = q.bn.group_tiles;
     const int zfirst0 = gt0 ? (g / gt0) * gt0 : 0;
-    const int zn0 = min(64, gt0 ? gt0 : q.bn.chunks);
-    pp_first.load(q.bn.part + (size_t)zfirst0 * 2 * q.up[0].N, zn0 * 2 * q.up[0].N, tid);
+    tile_part_load(q.bn.part, q.up[0].N, zfirst0, min(64, gt0 ? gt0 : q.bn.chunks), pm, pv);
   }
   TilePre<TC_ROWS / TC_RG> pg[2], ph, pa, pin, pw0;
 #pragma unroll
@@ -444,28 +443,18 @@ __device__ __forceinline__ void tile_bwd_body(const TileBwdArgs& q, float* tsm, 
     const int zfirst = gt_bn ? grp * gt_bn : 0;
     const int nchunks = gt_bn ? gt_bn : q.bn.chunks;
     float t1 = 0.f, t2 = 0.f;
-    for (int z0 = 0; z0 < nchunks; z0 += 64) {     // (through LDS, as in the forward kernel)
+    for (int z0 = 0; z0 < nchunks; z0 += 64) {     // (from registers, as in the forward kernel)
       const int zn = min(64, nchunks - z0);
-      {
-        LinePre<8> pp;
-        if (z0 == 0) pp = pp_first;
-        else pp.load(q.bn.part + (size_t)(zfirst + z0) * 2 * N, zn * 2 * N, tid);
-        lds_barrier();
-        pp.store_linear(Ds, zn * 2 * N, tid);
-        lds_barrier();
-      }
+      if (z0 > 0) tile_part_load(q.bn.part, N, zfirst + z0, zn, pm, pv);
       {
         // thread (column c, group zg): chunks z = zg mod TC_RG; groups combined in a fixed order
         const int c = tid & 127, zg = tid >> 7;
         float p1 = 0.f, p2 = 0.f;
-        if (c < N) {
-#pragma unroll 4
-          for (int z = zg; z < 64; z += TC_RG) {
-            const bool on = z < zn;
-            const int zz = on ? z : 0;
-            p1 += on ? Ds[zz * 2 * N + c] : 0.f;
-            p2 += on ? Ds[(zz * 2 + 1) * N + c] : 0.f;
-          }
+#pragma unroll
+        for (int j = 0; j < TC_ZPT; ++j) {
+          const bool on = zg + TC_RG * j < zn && c < N;
+          p1 += on ? pm[j] : 0.f;
+          p2 += on ? pv[j] : 0.f;
         }
         lds_barrier();
         st[zg * TC_MAXN + c] = p1;
@@ -538,38 +527,41 @@ __device__ __forceinline__ void tile_bwd_body(const TileBwdArgs& q, float* tsm, 
       lds_barrier();
     }
   }
-  // ---- dA tiles ----
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-    if (u < q.n_up) pg[u].store(Ds + u * TC_ROWS * TC_LD, (q.up[u].N + 31) & ~31, TC_ROWS, tid);
-  if (bn) {
-    const int N = q.up[0].N;
-    ph.store(As, N, TC_ROWS, tid);
-    pa.store(Ws, N, TC_ROWS, tid);
-  }
-  lds_barrier();
-  for (int u = 0; u < q.n_up; ++u) {
-    const TileBwdArgs::Up& up = q.up[u];
-    const int N = up.N;
-    float* D = Ds + u * TC_ROWS * TC_LD;
+  // ---- dA tiles: formed on registers (thread (c, rl) holds rows rl, rl + 4, ... of column c of
+  //      the gradient, the normalised output and the pre-normalisation tile alike), parked once ----
+  {
     const int c = tid & 127, rl = tid >> 7;
-    if (c < N && (bn || up.dA_out)) {
-#pragma unroll 4
-      for (int r = rl; r < nr; r += TC_RG) {
-        float v = D[r * TC_LD + c];
-        if (bn) {
-          if (!(As[r * TC_LD + c] > 0.f)) v = 0.f;
-          const float xh = (Ws[r * TC_LD + c] - st[c]) * st[TC_MAXN + c];
-          v = bn_input_gradient(v, xh, st[2 * TC_MAXN + c], st[3 * TC_MAXN + c], q.inv_count,
-                                st[TC_MAXN + c]);
-          D[r * TC_LD + c] = v;
+    if (bn) {
+      const int N = q.up[0].N;
+      if (c < N) {        // (st: behind the barrier that closes the merge above)
+        const float mean_c = st[c], istd_c = st[TC_MAXN + c];
+        const float s1_c = st[2 * TC_MAXN + c], s2_c = st[3 * TC_MAXN + c];
+#pragma unroll
+        for (int u = 0; u < TC_ROWS / TC_RG; ++u) {
+          if (rl + TC_RG * u < nr) {
+            float v = pg[0].v[u];
+            if (!(ph.v[u] > 0.f)) v = 0.f;
+            const float xh = (pa.v[u] - mean_c) * istd_c;
+            pg[0].v[u] = bn_input_gradient(v, xh, s1_c, s2_c, q.inv_count, istd_c);
+          }
         }
-        if (up.dA_out) up.dA_out[(size_t)(r0 + r) * N + c] = v;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u < q.n_up) {
+        const int N = q.up[u].N;
+        if (q.up[u].dA_out && c < N) {
+#pragma unroll
+          for (int uu = 0; uu < TC_ROWS / TC_RG; ++uu)
+            if (rl + TC_RG * uu < nr)
+              q.up[u].dA_out[(size_t)(r0 + rl + TC_RG * uu) * N + c] = pg[u].v[uu];
+        }
+        pg[u].store(Ds + u * TC_ROWS * TC_LD, (N + 31) & ~31, TC_ROWS, tid);
       }
     }
   }
   if (!q.in) return;      // (uniform: the layer that sees x stops here)
-  lds_barrier();        // (the dA transform is done with As and Ws)
   pin.store(As, (K + 31) & ~31, TC_ROWS, tid);
   lds_barrier();
   // ---- dW slabs: dW_u[k, n] (this tile) = sum_row in[row, k] dA_u[row, n]; bias: column sums ----
