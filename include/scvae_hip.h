@@ -242,8 +242,9 @@ int scvae_plan_set_mid_chain(scvae_plan* plan, int32_t enabled);
  * those of calling scvae_adam_clip_step, scvae_csr_minibatch and scvae_philox_normal_blocks right
  * after the step.  The buffers written here must not be inputs of the step that carries them
  * (double-buffer the minibatch and the noise): the library may run this work on a second stream
- * of its own beside the step's backward pass (off by default -- measured on MI355X it does not
- * pay, see plan.hip -- SCVAE_SIDE_STREAM=1). */
+ * of its own beside the step's backward pass (VAE steps whose next minibatch has 1024 cells or
+ * more, since round 5: a steady 10 us of a 2.0 ms step, see plan.hip; SCVAE_SIDE_STREAM=1 / 0:
+ * always / never). */
 typedef struct scvae_side_work {
   /* clip + Adam (scvae_adam_clip_step on the plan's whole parameter buffer with this step's
    * gradients); adam_m == NULL: none.  Training steps only; refused while a data-parallel hook is

@@ -747,15 +747,24 @@ static int side_adam(scvae_plan* p, hipStream_t st, size_t begin, size_t end) {
 static int side_adam_point() {
   static const int at = [] {
     const char* e = getenv("SCVAE_SIDE_ADAM_AT");
-    return e ? atoi(e) : 2;
+    return e ? atoi(e) : 1;
   }();
   return at;
 }
 int plan_side_fork(scvae_plan* p, hipStream_t s, int point) {
   const scvae_side_work* w = p->side;
   if (!w) return 0;
-  static const bool env_on = [] { const char* e = getenv("SCVAE_SIDE_STREAM"); return e && e[0] == '1'; }();
-  if (!env_on) return 0;
+  // SCVAE_SIDE_STREAM=1 / 0: always / never.  Default (round 5): for minibatches of 1024 cells
+  // and more -- the next fetch, its noise and the likelihood heads' share of clip + Adam under the
+  // backward pass of the hidden layers (64 workgroups on 256 CUs).  The kernels do overlap (kernel
+  // trace: the step's span shrinks by the 100 us moved) but each side slows the other, and what is
+  // left without the profiler is a steady 10 us of a 2.0 ms step (300-step A/B, three
+  // alternations: 634 -> 624 us outside the head kernel); smaller minibatches: not measured, off.
+  static const int env = [] { const char* e = getenv("SCVAE_SIDE_STREAM"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+  const bool on = env >= 0 ? env == 1
+                           : (p->cfg.model_type == SCVAE_MODEL_VAE && !p->sync && w->fetch_out &&
+                              w->fetch_n >= 1024);   // (single process: never run beside RCCL's kernels)
+  if (!on) return 0;
   const bool jobs = !p->side_jobs_done && (w->fetch_out || w->noise_out);
   // (VAE plans: the likelihood heads are the tail of the parameter buffer)
   const bool adam = w->adam_m && p->side_adam_from == p->layout.n_params &&
