@@ -149,11 +149,18 @@ __device__ __forceinline__ void split3_rn_pair(float x0, float x1, unsigned& p1,
 //   dT[pl][ht][kg][lane][8]   GEMM2's A operand (32x32x16): h = 32 ht + (lane & 31),
 //                             row 16 kg + 8 (lane >> 5) + e                  (kg < Rpad / 16)
 // One thread = one lane slot of a fragment, all three planes.  blockIdx.y: 0 = dA, 1 = dT.
+// (zero, zero16: the XCD-local accumulators of dd the training kernel is about to add into, as
+//  16-byte pieces -- cleared by this launch's threads instead of a memset launch of its own)
 __global__ __launch_bounds__(256) void split3_hidden_kernel(const float* __restrict__ d, int R,
                                                             int H, int Rpad, int KP,
                                                             uint16_t* __restrict__ dA,
-                                                            uint16_t* __restrict__ dT) {
+                                                            uint16_t* __restrict__ dT,
+                                                            u32x4* __restrict__ zero,
+                                                            size_t zero16) {
   const int slot = blockIdx.x * 256 + threadIdx.x;       // < Rpad * KP / 8
+  for (size_t i = (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero16;
+       i += (size_t)gridDim.x * gridDim.y * 256)
+    zero[i] = u32x4{0u, 0u, 0u, 0u};
   if (slot >= Rpad * (KP / 8)) return;
   const int ksp = KP / 32;                               // contraction steps per 16-row block
   const int lane = slot & 63, frag = slot >> 6;
@@ -1864,10 +1871,19 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
   // (head dropout: one plane set per head, cut from that head's dropped-out copy of d, and the
   //  heads' masks as bits behind the three sets)
   uint32_t* bits = reinterpret_cast<uint32_t*>(dA + 3 * d3_set_elems(Rpad));
+  // (the producer / consumer kernel with dd through atomics: its eight accumulators [8][H][rows]
+  //  are cleared by the plane-cutting launch)
+  const bool head4_train = train && !(dd_mode & 4) && !drop && cp_pass == 0 &&
+                           d3_schedule(P, H, rows) == 4;
+  const size_t acc_bytes = (size_t)8 * H * rows * sizeof(float);
+  const bool clear_here = head4_train && (dd_mode & 1) && (acc_bytes & 15) == 0 &&
+                          (reinterpret_cast<uintptr_t>(dd_part) & 15) == 0;
   for (int j = 0; j < (drop ? P : 1); ++j) {
     hipLaunchKernelGGL(split3_hidden_kernel, dim3((Rpad * (KP / 8) + 255) / 256, train ? 2 : 1),
                        dim3(256), 0, s, drop ? drop->d[j] : d, rows, H, Rpad, KP,
-                       dA + j * d3_set_elems(Rpad), dT + j * d3_set_elems(Rpad));
+                       dA + j * d3_set_elems(Rpad), dT + j * d3_set_elems(Rpad),
+                       clear_here ? reinterpret_cast<u32x4*>(dd_part) : nullptr,
+                       clear_here ? acc_bytes / 16 : (size_t)0);
     SCVAE_LAUNCH_CHECK("split3_hidden_kernel");
     if (drop) {
       const int rc = dropout_mask_words(s, bits + (size_t)j * Rpad * 4, rows, Rpad, H, drop->keep,
@@ -1929,7 +1945,7 @@ int decoder_fused3_launch(hipStream_t s, bool train, int kind, const float* d, i
     // (no slab from the caller: one group -- the stand-alone forward-only / probe entries; the
     //  forward half leaves no dW and needs none)
     if (rg_slab || a.fwd) a.row_groups = d4_row_groups(a.strips, rows);
-    if (a.dd_atomic)    // eight XCD-local accumulators [8][H][rows], cleared for this launch
+    if (a.dd_atomic && !clear_here)   // eight XCD-local accumulators [8][H][rows], cleared for this launch
       SCVAE_HIP(hipMemsetAsync(dd_part, 0, (size_t)8 * H * rows * sizeof(float), s));
     int rc;
     switch (kind) {
