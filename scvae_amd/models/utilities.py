@@ -248,11 +248,15 @@ class CheckpointWriter:
             raise error
 
     def close(self):
-        self.wait()
-        if self._thread is not None:
-            self._jobs.put(None)
-            self._thread.join()
-            self._thread = None
+        import atexit
+        atexit.unregister(self.close)
+        try:
+            self.wait()
+        finally:
+            if self._thread is not None:
+                self._jobs.put(None)
+                self._thread.join()
+                self._thread = None
 
 
 def load_checkpoint(checkpoint_path):
