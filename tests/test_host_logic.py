@@ -180,6 +180,55 @@ def test_scalar_store_and_checkpoints(tmp_path):
     assert not mu.better_model_exists(model)
 
 
+def test_checkpoint_queue_keeps_the_sequential_meaning(tmp_path):
+    """``CheckpointWriter``: saves, copies into ``early_stopping/`` / ``best/``
+    and prunes run on a background thread in the order they were queued, so a
+    copy queued BEFORE an epoch's save gets the previous epoch's checkpoint and
+    one queued AFTER it this epoch's -- as in the reference's sequential loop
+    (va:1385-1441, 1470-1492); the logs travel as they were when the copy was
+    queued; the state file of a copy is a hard link."""
+    import torch
+    from scvae_amd.models import utilities as mu
+    log = str(tmp_path / "log")
+    early = str(tmp_path / "log" / "early_stopping")
+    best = str(tmp_path / "log" / "best")
+    scalars = mu.ScalarWriter(os.path.join(log, "training"))
+    writer = mu.CheckpointWriter()
+
+    def state(epoch):
+        return {"params": torch.full((1000,), float(epoch)), "adam_t": epoch}
+    scalars.add_summary({"lower_bound": -3.0}, 1)
+    writer.save(state(1), log, 1)
+    writer.copy_latest(log, best, prune=True)          # epoch 1 is the best so far
+    scalars.add_summary({"lower_bound": -4.0}, 2)      # (worse: early stopping starts)
+    writer.copy_latest(log, early)                     # "previous epoch's parameters"
+    writer.save(state(2), log, 2)
+    scalars.add_summary({"lower_bound": -2.0}, 3)
+    writer.save(state(3), log, 3)
+    writer.copy_latest(log, best, prune=True)
+    scalars.add_summary({"lower_bound": -9.0}, 4)      # (after the copy was queued)
+    writer.close()
+    assert mu.checkpoint_epoch(mu.get_checkpoint_state(log)) == 3
+    assert mu.checkpoint_epoch(mu.get_checkpoint_state(early)) == 1
+    assert mu.checkpoint_epoch(mu.get_checkpoint_state(best)) == 3
+    loaded = mu.load_checkpoint(mu.get_checkpoint_state(best))
+    assert float(loaded["params"][0]) == 3.0 and loaded["adam_t"] == 3
+    # one state file per directory (Saver(max_to_keep=1)), the copy a hard link
+    for d in (log, early, best):
+        assert len([f for f in os.listdir(d) if f.endswith(".pt")]) == 1
+    assert os.stat(mu.get_checkpoint_state(best)).st_ino == os.stat(
+        mu.get_checkpoint_state(log)).st_ino
+    # the logs of a copy: as they were when it was queued
+    steps = lambda d: [r["step"] for r in mu._read_scalars(os.path.join(d, "training"))]
+    assert steps(early) == [1, 2] and steps(best) == [1, 2, 3] and steps(log) == [1, 2, 3, 4]
+    # a failure on the worker surfaces at the next wait
+    writer = mu.CheckpointWriter()
+    writer.save({"bad": lambda: None}, str(tmp_path / "x"), 1)   # (not picklable)
+    with pytest.raises(Exception):
+        writer.wait()
+    writer.close()
+
+
 def test_data_set_and_split():
     from scvae_amd.data import DataSet, SparseRowMatrix
     data_set = DataSet("synthetic_1k")
