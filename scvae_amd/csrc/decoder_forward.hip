@@ -103,12 +103,16 @@ __global__ __launch_bounds__(512) void decoder_forward_kernel(
     const int cc = min(c0 + c, F - 1);
     constexpr int NV = HK / NW;                        // rows p0 + NW u < HK of this thread
     float v[P][NV];
+    // (the plain [H, F] layout, or -- the class logits of the P_K head of `-k` -- genes
+    //  gene_stride apart in rows of row_pitch elements: kernels.hpp, HeadParams)
+    const size_t gs = hp.gene_stride ? hp.gene_stride : 1;
+    const size_t rp = hp.row_pitch ? hp.row_pitch : F;
 #pragma unroll
     for (int j = 0; j < P; ++j)
 #pragma unroll
       for (int u = 0; u < NV; ++u) {
         const int pos = p0 + u * NW;
-        v[j][u] = pos < H ? hp.W[j][(size_t)pos * F + cc] : hp.b[j][cc];
+        v[j][u] = pos < H ? hp.W[j][(size_t)pos * rp + cc * gs] : hp.b[j][cc * gs];
       }
 #pragma unroll
     for (int j = 0; j < P; ++j)
@@ -211,10 +215,14 @@ __global__ __launch_bounds__(512) void decoder_forward_kernel(
         float a[P], lp, g[P], r, rgate;
 #pragma unroll
         for (int j = 0; j < P; ++j) a[j] = acc[j][i];
+        // (tg.shift > 0 -- the count part of the piecewise categorical likelihood: the
+        //  distribution sees t - shift where t >= shift, nothing elsewhere; 0: every element)
+        const bool live = tv[i] >= tg.shift;
+        tv[i] = live ? tv[i] - tg.shift : 0.f;
         lik_dense<KIND, false>(tv[i], a, lp, g, r, rgate);
         const int c = cbase + 8 * (i >> 2) + (i & 3);
-        lane_sum += (c < F) ? lp : 0.f;
-        nz |= (tv[i] > 0.f) ? (1u << i) : 0u;    // (t of a gene beyond F was loaded as 0)
+        lane_sum += (live && c < F) ? lp : 0.f;
+        nz |= (live && tv[i] > 0.f) ? (1u << i) : 0u;    // (t of a gene beyond F was loaded as 0)
         // four elements at a time: the 16 are independent, interleaving all of them only
         // costs registers
         if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -283,6 +291,8 @@ int decoder_forward_launch(hipStream_t s, int kind, const float* d, int rows, in
     case LK_ZIP: SCVAE_FWK(LK_ZIP); break;
     case LK_ZINB: SCVAE_FWK(LK_ZINB); break;
     case LK_BERNOULLI: SCVAE_FWK(LK_BERNOULLI); break;   // du:194-204; targets binarised by the caller
+    case LK_CAT2: SCVAE_FWK(LK_CAT2); break;   // the class logits of -k (decoder_fused_forward_cat)
+    case LK_CAT3: SCVAE_FWK(LK_CAT3); break;
     default: set_error("unknown likelihood kind %d", kind); return -1;
   }
 #undef SCVAE_FWK

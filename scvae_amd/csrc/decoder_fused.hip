@@ -1060,4 +1060,45 @@ int decoder_fused_train_cat(hipStream_t s, int kind, int k_max, const float* d, 
   return 0;
 }
 
+// ... and its forward half (evaluation passes, the first pass of an importance-weighted step):
+// two launches of decoder_forward_kernel (fp32 matrix cores, any head count up to three) -- the
+// count heads on shifted, masked targets, the class logits as strided heads -- ll added.
+bool decoder_fused_forward_cat_supported(int kind, int k_max, int H) {
+  return (kind == LK_POISSON || kind == LK_NB) && (k_max == 1 || k_max == 2) &&
+         decoder_forward_supported(3, H);
+}
+int decoder_fused_forward_cat(hipStream_t s, int kind, int k_max, const float* d, int rows, int H,
+                              HeadParams hp, const float* Wk, const float* bk, int F,
+                              const float* t, int B, float* ll, float* workspace, float* scratch) {
+  SCVAE_ARG(decoder_fused_forward_cat_supported(kind, k_max, H) && Wk && bk && scratch);
+  if (rows == 0) return 0;
+  const int strips = (F + DF_BN - 1) / DF_BN;
+  float* ll_part = workspace;
+  Targets shifted = targets_f32(t, F);
+  shifted.shift = (float)k_max;
+  int rc = decoder_forward_launch(s, kind, d, rows, H, hp, F, shifted, B, 1, ll_part);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 15) / 16), dim3(1024), 0, s, ll_part, strips,
+                     rows, nullptr, B, ll);
+  HeadParams hc;
+  for (int c = 0; c < 3; ++c) {
+    const bool on = c <= k_max;
+    hc.W[c] = on ? Wk + c : nullptr;
+    hc.b[c] = on ? bk + c : nullptr;
+    hc.dW[c] = nullptr;
+    hc.db[c] = nullptr;
+  }
+  hc.gene_stride = k_max + 1;
+  hc.row_pitch = F * (k_max + 1);
+  rc = decoder_forward_launch(s, k_max == 1 ? LK_CAT2 : LK_CAT3, d, rows, H, hc, F,
+                              targets_f32(t, F), B, 0, ll_part);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ll_reduce_kernel, dim3((rows + 15) / 16), dim3(1024), 0, s, ll_part, strips,
+                     rows, nullptr, B, scratch);
+  hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, ll,
+                     scratch, (size_t)rows);
+  SCVAE_LAUNCH_CHECK("decoder_fused_forward_cat");
+  return 0;
+}
+
 }  // namespace scvae

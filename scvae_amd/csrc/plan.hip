@@ -1048,8 +1048,12 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const bool fused_cat = training && n_iw == 1 && KM > 0 && p->use_fused && p->fused_ws &&
                          p->pre_k && ld == h1 && !head_drop && !p->x_u16 && !a->p_x_mean &&
                          decoder_fused_cat_supported(c.likelihood, KM, h1, p->head_arith);
+  // ... and its forward half in evaluation passes (two launches of decoder_forward_kernel)
+  const bool cat_forward = !training && KM > 0 && p->use_fused && p->fused_ws && p->pre_k &&
+                           ld == h1 && !p->x_u16 && !a->p_x_mean &&
+                           decoder_fused_forward_cat_supported(c.likelihood, KM, h1);
   const float* head_in[4] = {dch, dch, dch, dch};   // [3]: the P_K head
-  if (!fused && !fused_cat)
+  if (!fused && !fused_cat && !cat_forward)
     if ((rc = heads_forward(p, s, dch, ld, R, training, head_in))) return rc;
   // per-row log-likelihood, forward only
   auto loglik_forward = [&]() -> int {
@@ -1059,6 +1063,10 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     if (fused)
       return decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, tg, B, a->row_const, p->ll,
                                    p->fused_ws, p->head_arith);
+    if (cat_forward)
+      return decoder_fused_forward_cat(s, c.likelihood, KM, dch, R, h1, hp,
+                                       p->params + p->head_k.w, p->params + p->head_k.b, F, a->t,
+                                       B, p->ll, p->fused_ws, p->pre_k);
     if (KM > 0)
       return loglik_cat_fwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->ll, R, B, F);
     if (cpoisson)

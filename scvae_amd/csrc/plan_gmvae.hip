@@ -504,8 +504,12 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   const bool fused_cat = training && KM > 0 && p->use_fused && p->fused_ws && p->pre_k &&
                          ld == h1 && !head_drop && !p->x_u16 && !a->p_x_mean &&
                          decoder_fused_cat_supported(c.likelihood, KM, h1, p->head_arith);
+  const bool cat_forward = !training && KM > 0 && p->use_fused && p->fused_ws && p->pre_k &&
+                           ld == h1 && !p->x_u16 && !a->p_x_mean &&
+                           decoder_fused_forward_cat_supported(c.likelihood, KM, h1);
   const float* head_in[4] = {dch, dch, dch, dch};   // [3]: the P_K head
-  if (!fused && !fused_cat) TRY(heads_forward(p, s, dch, ld, R, training, head_in));
+  if (!fused && !fused_cat && !cat_forward)
+    TRY(heads_forward(p, s, dch, ld, R, training, head_in));
   bool ll_done = false;
   if (a->p_x_mean) {
     if (!(a->p_x_stddev && a->stddev_of_p_x_given_z_mean)) {
@@ -549,6 +553,10 @@ int gmvae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     else if (fused)
       TRY(decoder_fused_forward(s, c.likelihood, dch, R, h1, hp, F, tg, B, a->row_const, p->ll,
                                 p->fused_ws, p->head_arith));
+    else if (cat_forward)
+      TRY(decoder_fused_forward_cat(s, c.likelihood, KM, dch, R, h1, hp, p->params + p->head_k.w,
+                                    p->params + p->head_k.b, F, a->t, B, p->ll, p->fused_ws,
+                                    p->pre_k));
     else if (KM > 0)
       TRY(loglik_cat_fwd(s, c.likelihood, a->t, F, pre, F, p->pre_k, KM, p->ll, R, B, F));
     else if (cpoisson) {

@@ -133,8 +133,15 @@ def test_fused_categorised_training_step(cuda_device, model_type, likelihood,
         sc = eng.step(xd, xd, eps=epsd, training=True,
                       outputs={"log_p_x_given_z": ll}).cpu().numpy()
         torch.cuda.synchronize()
+        # ... and an evaluation step (the forward half: two launches of the fp32
+        # forward kernel) with the moving statistics the training step left
+        ll_e = torch.zeros(rows, device=cuda_device)
+        sc_e = eng.step(xd, xd, eps=epsd, training=False,
+                        outputs={"log_p_x_given_z": ll_e}).cpu().numpy()
+        torch.cuda.synchronize()
         results[fused] = (sc, ll.cpu(), {k: v.clone().cpu() for k, v in
-                                         eng.named_gradients().items()})
+                                         eng.named_gradients().items()},
+                          sc_e, ll_e.cpu())
         if fused:
             params = {k: v.detach().cpu().double()
                       for k, v in eng.named_parameters().items()}
@@ -147,7 +154,13 @@ def test_fused_categorised_training_step(cuda_device, model_type, likelihood,
     forward = om.gmvae_forward if gm else om.vae_forward
     out, grads = om.gradients(
         lambda p: forward(cfg, p, moving, x, x, eps, True), params)
-    sc, ll, dev = results[True]
+    sc, ll, dev, sc_e, ll_e = results[True]
+    out_e = forward(cfg, params, moving, x, x, eps, False)
+    _close(sc_e[0], out_e["lower_bound"], 1e-4, "lower_bound (evaluation)")
+    close_elementwise(ll_e, out_e["log_p_x_given_z"].reshape(-1), rtol=LL_RTOL,
+                      atol=LL_ATOL, what="per-cell ll (evaluation)")
+    close_elementwise(ll_e, results[False][4], rtol=LL_RTOL, atol=LL_ATOL,
+                      what="fused vs unfused per-cell ll (evaluation)")
     _close(sc[0], out["lower_bound"], 1e-4, "lower_bound")
     close_elementwise(ll, out["log_p_x_given_z"].reshape(-1), rtol=LL_RTOL,
                       atol=LL_ATOL, what="per-cell ll")

@@ -44,6 +44,15 @@ def main():
               "(fused_categorised = {})".format(args.k, B, args.features,
                                                "fused" if fused else "unfused", ms,
                                                B / ms * 1e3, eng.fused_categorised))
+        for _ in range(3):
+            eng.step(x, x, eps=eps, row_const=rc, training=False, x_counts=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.steps):
+            eng.step(x, x, eps=eps, row_const=rc, training=False, x_counts=True)
+        e1.record()
+        torch.cuda.synchronize()
+        print("   evaluation step: {:.3f} ms".format(e0.elapsed_time(e1) / args.steps))
         del eng
         torch.cuda.empty_cache()
 
