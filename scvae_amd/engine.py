@@ -297,8 +297,8 @@ class Engine:
 
     @property
     def fused_categorised(self):
-        """Whether training steps run ``-k`` on the fused head kernels (k = 1, 2;
-        bound plan)."""
+        """Whether training and evaluation steps run ``-k`` on the fused head
+        kernels (k = 1, 2; bound plan)."""
         return bool(self.lib.scvae_plan_fused_categorised(self.handle))
 
     def set_head_arith(self, arith):
