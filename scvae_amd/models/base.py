@@ -384,7 +384,8 @@ class ModelBase:
         sync = None
         if world > 1:
             from scvae_amd.dataparallel import GradientSynchroniser
-            engine.reserve(minibatch_size, n_iw * n_mc)
+            engine.reserve(max(minibatch_size, self._evaluation_largest_step(
+                n_examples_train, minibatch_size, n_iw * n_mc)), n_iw * n_mc)
             sync = GradientSynchroniser(engine)
         say("Data prepared ({}).".format(
             format_duration(time() - preparing_data_time_start)))
@@ -475,7 +476,10 @@ class ModelBase:
             int(numpy.prod(self._eps_shape(samples, max(local_batch, 1)))),
             device=device) for _ in range(2)]
         step = int(epoch_start * steps_per_epoch)
-        engine.reserve(max(local_batch, 1), samples)
+        # (the epoch-end passes run steps of several minibatches: bound once,
+        #  ahead of the first training step)
+        engine.reserve(max(local_batch, 1, self._evaluation_largest_step(
+            n_examples_train, minibatch_size, samples)), samples)
         # an integer count matrix that is both input and target: the minibatch
         # is densified as uint16 where the plan takes it (half the bytes for the
         # three kernels that stream it; the step is bit-identical)
@@ -814,36 +818,41 @@ class ModelBase:
         n = data_set.number_of_examples
         F, L = self.feature_size, self.latent_size
         samples = 1 if deterministic_z else n_iw * n_mc
-        starts = list(range(0, n, minibatch_size))
+        # whole minibatches share a step where nothing but the averages is
+        # asked for (the epoch-end passes of train, a plain evaluate)
+        chunks = mu.evaluation_chunks(
+            n, minibatch_size,
+            0 if outputs else self._evaluation_step_cells(samples))
+        starts = [start for start, _, _ in chunks]
+        largest = max((cells for _, cells, _ in chunks), default=0)
+        weights = torch.tensor([w for _, _, w in chunks], device=device)
         scalars = torch.zeros(len(starts), 8, device=device)
         kl_neurons = torch.zeros(len(starts), L, device=device)
         latent = torch.zeros(n, L, device=device)
         extra = self._allocate_evaluation_outputs(n, len(starts), device)
-        x_buffer = torch.empty(min(minibatch_size, n), F, device=device)
+        x_buffer = torch.empty(largest, F, device=device)
         t_buffer = x_buffer if x is t else torch.empty_like(x_buffer)
-        row_const = torch.empty(min(minibatch_size, n), device=device)
+        row_const = torch.empty(largest, device=device)
         eps_buffer = None
         if not deterministic_z:
             eps_buffer = torch.empty(
-                int(numpy.prod(self._eps_shape(
-                    samples, min(minibatch_size, n)))), device=device)
+                int(numpy.prod(self._eps_shape(samples, largest))),
+                device=device)
         all_rows = torch.arange(n, device=device, dtype=torch.int64)
         # plain passes (no reconstruction statistics requested) over an integer
         # count matrix take the uint16 minibatch where the plan allows it
         u16_buffer = None
         if (not outputs and x is t and getattr(x, "integer_counts", False)
                 and hasattr(x, "gather_counts_u16")
-                and engine.accepts_counts_u16(min(minibatch_size, n), False)):
+                and engine.accepts_counts_u16(largest, False)):
             u16_buffer = torch.empty(
-                min(minibatch_size, n), x.u16_pitch, dtype=torch.uint16,
-                device=device)
+                largest, x.u16_pitch, dtype=torch.uint16, device=device)
         self._evaluation_counter = getattr(
             self, "_evaluation_counter", 0) + 1
-        for j, i in enumerate(starts):
+        for j, (i, cells, _) in enumerate(chunks):
             if world > 1 and j % world != rank:
                 continue
-            rows = all_rows[i:i + minibatch_size]
-            cells = int(rows.numel())
+            rows = all_rows[i:i + cells]
             xb, tb, rc = x_buffer[:cells], t_buffer[:cells], row_const[:cells]
             if (u16_buffer is not None
                     and engine.accepts_counts_u16(cells, False)):
@@ -857,9 +866,12 @@ class ModelBase:
             if not deterministic_z:
                 eps = eps_buffer[:int(numpy.prod(
                     self._eps_shape(samples, cells)))]
+                # (keyed by the cell's row in the set, not by the step: a
+                #  cell draws the same noise however the pass is cut into
+                #  steps or dealt to ranks)
                 self._draw_noise(
-                    eps, samples, cells, cells, 0,
-                    (1 << 40) + self._evaluation_counter * (1 << 20) + j)
+                    eps, samples, cells, n, i,
+                    (1 << 40) + self._evaluation_counter * (1 << 20))
             out = {"q_z_mean": latent[i:i + cells],
                    "kl_neurons": kl_neurons[j]}
             out.update(self._evaluation_step_outputs(
@@ -872,6 +884,10 @@ class ModelBase:
                         n_iw=n_iw, n_mc=n_mc, deterministic_z=deterministic_z,
                         outputs=out, scalars=scalars[j], decoder_extra=de,
                         count_sum=cs, x_counts=x.integer_counts)
+        # a step's means count once per minibatch it holds
+        scalars *= weights[:, None]
+        kl_neurons *= weights[:, None]
+        self._weight_evaluation_outputs(extra, weights)
         if sync is not None:
             for tensor in [scalars, kl_neurons, latent] + [
                     v for v in extra.values() if torch.is_tensor(v)]:
@@ -887,8 +903,27 @@ class ModelBase:
         self._finish_evaluation(result, extra, data_set, denominator)
         return result
 
+    # cells per evaluation step where whole minibatches may share one (0: one
+    # step per minibatch, as the reference runs them); the stacked passes of a
+    # step stay within what the training workloads run
+    evaluation_chunk_cells = 4096
+    evaluation_chunk_stacked_rows = 16384
+
+    def _evaluation_step_cells(self, samples):
+        passes = int(numpy.prod(self._eps_shape(samples, 1)[:-2]))
+        return min(int(self.evaluation_chunk_cells),
+                   int(self.evaluation_chunk_stacked_rows) // max(passes, 1))
+
+    def _evaluation_largest_step(self, n, minibatch_size, samples):
+        return max((cells for _, cells, _ in mu.evaluation_chunks(
+            n, minibatch_size, self._evaluation_step_cells(samples))),
+            default=0)
+
     def _allocate_evaluation_outputs(self, n, n_batches, device):
         return {}
+
+    def _weight_evaluation_outputs(self, extra, weights):
+        pass
 
     def _evaluation_step_outputs(self, extra, outputs, i, j, cells):
         out = {}

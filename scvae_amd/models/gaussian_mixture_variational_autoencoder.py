@@ -461,6 +461,9 @@ class GaussianMixtureVariationalAutoencoder(ModelBase):
         out["cluster_stats"] = extra["cluster_stats"][j]
         return out
 
+    def _weight_evaluation_outputs(self, extra, weights):
+        extra["cluster_stats"] *= weights[:, None, None, None]
+
     def _finish_evaluation(self, result, extra, data_set, denominator):
         result["kl_divergence"] = (result["kl_divergence_z"]
                                    + result["kl_divergence_y"])

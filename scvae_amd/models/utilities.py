@@ -608,6 +608,29 @@ def validate_model_parameters(reconstruction_distribution=None,
                         model_type, latent_distribution))
 
 
+def evaluation_chunks(number_of_examples, minibatch_size, max_cells=0):
+    """The steps of an evaluation pass as ``(start, cells, weight)``.
+
+    The reference runs one step per minibatch and reports ``sum(minibatch
+    means) / (N / B)`` (va:1092-1150, 1969-2055).  With batch normalisation in
+    evaluation mode a cell's terms do not depend on its minibatch, so ``c``
+    whole minibatches evaluated in one step of ``c B`` cells contribute ``c``
+    times that step's mean -- the sum of their ``c`` means.  The ragged last
+    minibatch keeps a step of its own (its mean is over fewer cells).
+    ``max_cells`` < 2 B: one step per minibatch, as the reference."""
+    n, B = int(number_of_examples), int(minibatch_size)
+    per_step = max(1, int(max_cells) // B)
+    chunks, start, full = [], 0, n // B
+    while full > 0:
+        c = min(per_step, full)
+        chunks.append((start, c * B, float(c)))
+        start += c * B
+        full -= c
+    if start < n:
+        chunks.append((start, n - start, 1.0))
+    return chunks
+
+
 def batch_indices_for_subset(subset):
     if subset.batch_indices is None:
         raise TypeError(

@@ -172,8 +172,8 @@ def test_training_loop_matches_oracle(tmp_path, cuda_device):
     for j, i in enumerate(range(0, n, B)):
         rows = slice(i, min(i + B, n))
         cells = rows.stop - rows.start
-        eps = _philox(cuda_device, cells, L, 0, 1,
-                      (1 << 40) + 1 * (1 << 20) + j).unsqueeze(0)
+        eps = _philox(cuda_device, cells, L, i, 1,
+                      (1 << 40) + 1 * (1 << 20)).unsqueeze(0)
         out = om.vae_forward(cfg, params, moving, x[rows], x[rows], eps,
                              False)
         total += float(out["lower_bound"])
@@ -429,3 +429,82 @@ def test_initial_values_are_the_tf_contrib_defaults(cuda_device):
                        device=cuda_device, seed=8)
         assert torch.equal(again.params, eng.params)
         assert not torch.equal(other.params, eng.params)
+
+
+def _same_evaluation(one, two):
+    assert set(one) == set(two)
+    for key, a in one.items():
+        b = two[key]
+        if a is None or isinstance(a, str):
+            assert a == b, key
+        elif np.asarray(a).dtype.kind in "fc":
+            np.testing.assert_allclose(b, a, rtol=2e-5, atol=1e-6,
+                                       err_msg=key)
+        else:
+            assert np.array_equal(np.asarray(a), np.asarray(b)), key
+
+
+@pytest.mark.parametrize("model_type", ["VAE", "GMVAE"])
+def test_evaluation_pass_in_steps_of_several_minibatches(tmp_path, cuda_device,
+                                                         model_type):
+    """Whole minibatches sharing an evaluation step (``evaluation_chunks``):
+    the epoch averages ``sum(minibatch means) / (N / B)`` of a pass in steps
+    of two minibatches equal those of the pass the reference runs, one step per
+    minibatch -- ragged tail included; a cell draws the same noise in both --
+    and the oracle's on the same steps."""
+    from scvae_amd.models import (GaussianMixtureVariationalAutoencoder,
+                                  VariationalAutoencoder)
+    from scvae_amd.models.utilities import evaluation_chunks
+    n, F, L, B = 3 * 24 + 24 + 7, 36, 3, 24
+    data = _data(n, F, labels=True)
+    kw = dict(feature_size=F, latent_size=L, hidden_sizes=[10],
+              reconstruction_distribution="negative binomial",
+              log_directory=str(tmp_path), device=cuda_device)
+    if model_type == "VAE":
+        model = VariationalAutoencoder(**kw)
+    else:
+        model = GaussianMixtureVariationalAutoencoder(
+            number_of_latent_clusters=3, **kw)
+    g = torch.Generator().manual_seed(9)
+    for name, p in model.engine.named_parameters().items():
+        p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+    for name, m in model.engine.named_moving_statistics().items():
+        m.copy_(torch.rand(m.shape, generator=g) + 0.5)
+    x, t = model._device_matrices(data)
+
+    def run(cells, **kwargs):
+        model.evaluation_chunk_cells = cells
+        return model._evaluation_pass(x, t, data, B, 1, 1, **kwargs)
+
+    assert [c for _, c, _ in evaluation_chunks(n, B, 2 * B)] == [48, 48, 7]
+    # (the noise of a cell is keyed by its row in the set: both passes draw
+    #  the same; the VAE also without any)
+    variants = [{}] + ([dict(deterministic_z=True)] if model_type == "VAE"
+                       else [])
+    for kwargs in variants:
+        model._evaluation_counter = 0
+        one = run(0, **kwargs)
+        model._evaluation_counter = 0
+        two = run(2 * B, **kwargs)
+        _same_evaluation(one, two)
+    if model_type == "GMVAE":
+        return
+    # with noise: the oracle on the same steps and draws
+    model._evaluation_counter = 0
+    got = run(2 * B)["lower_bound"]
+    cfg = om.ModelConfig(feature_size=F, latent_size=L, hidden_sizes=(10,),
+                         likelihood="negative binomial")
+    params = {k: v.detach().cpu().double()
+              for k, v in model.engine.named_parameters().items()}
+    moving = {k: v.detach().cpu().double()
+              for k, v in model.engine.named_moving_statistics().items()}
+    xd = torch.from_numpy(np.asarray(data.values, dtype=np.float64))
+    total = 0.0
+    for j, (i, cells, weight) in enumerate(evaluation_chunks(n, B, 2 * B)):
+        eps = _philox(cuda_device, cells, L, i, 1,
+                      (1 << 40) + 1 * (1 << 20)).unsqueeze(0)
+        out = om.vae_forward(cfg, params, moving, xd[i:i + cells],
+                             xd[i:i + cells], eps, False)
+        total += weight * float(out["lower_bound"])
+    expected = total / (n / B)
+    assert abs(got - expected) <= 1e-4 * abs(expected)

@@ -504,3 +504,35 @@ def test_minibatch_request_checks_and_fills_the_side_work_struct():
     Matrix.integer_counts = False
     with pytest.raises(ValueError):      # uint16 needs an integer count matrix
         MinibatchRequest(Matrix, rows, out)
+
+
+def test_evaluation_chunks_keep_the_reference_average():
+    """``evaluation_chunks``: contiguous steps over all cells, every step but a
+    ragged last one a whole number of minibatches weighted by that number, so
+    that sum(weight x step mean) is the reference's sum of minibatch means."""
+    from scvae_amd.models.utilities import evaluation_chunks
+    for n, B, limit in [(61722, 100, 4096), (6857, 100, 4096), (250, 100, 4096),
+                        (99, 100, 4096), (300, 100, 150), (4096, 4096, 4096),
+                        (5000, 4096, 4096), (1000, 7, 50), (0, 100, 4096),
+                        (250, 100, 0)]:
+        chunks = evaluation_chunks(n, B, limit)
+        position = 0
+        for index, (start, cells, weight) in enumerate(chunks):
+            assert start == position and cells > 0
+            position += cells
+            if cells % B == 0:
+                assert weight == cells // B
+                assert cells <= max(limit, B)
+            else:
+                assert index == len(chunks) - 1 and cells < B and weight == 1
+        assert position == n
+        assert sum(w for _, _, w in chunks) == -(-n // B)
+    assert evaluation_chunks(250, 100, 0) == [(0, 100, 1.0), (100, 100, 1.0),
+                                              (200, 50, 1.0)]
+    # a mean of c B cells times c is the sum of the c minibatch means
+    import numpy
+    values = numpy.random.default_rng(0).normal(size=61722)
+    reference = sum(values[i:i + 100].mean() for i in range(0, 61722, 100))
+    chunked = sum(w * values[s:s + c].mean()
+                  for s, c, w in evaluation_chunks(61722, 100, 4096))
+    assert abs(reference - chunked) < 1e-9 * abs(reference)
