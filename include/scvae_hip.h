@@ -141,7 +141,8 @@ int scvae_plan_set_fused(scvae_plan* plan, int32_t enabled);
  * va:2507-2532) on the fused kernels: two launches of the bf16x9 head kernel -- the count heads on
  * shifted, masked targets and the k + 1 class logits of every gene as the heads of a categorical
  * kind -- instead of materialised [rows, (P + k + 1) F] pre-activations; evaluation passes the
- * same two terms on the forward kernel.  Larger k, importance weighting, head dropout,
+ * same two terms on the forward kernel (also the first pass of an importance-weighted
+ * training step).  Larger k, head dropout,
  * evaluate-time statistics: the unfused kernels, as before. */
 int32_t scvae_plan_fused_categorised(const scvae_plan* plan);
 /* Arithmetic of this plan's fused head kernels (see scvae_default_head_arith below): 0 fp32

@@ -1021,8 +1021,10 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a,
     a[i] += b[i];
 }
 bool decoder_fused_cat_supported(int kind, int k_max, int H, int arith) {
+  // (the forward half as well: the first pass of an importance-weighted step)
   return (kind == LK_POISSON || kind == LK_NB) && (k_max == 1 || k_max == 2) && arith >= 1 &&
-         decoder_fused_supported(H) && decoder_fused3_supported(3, H);
+         decoder_fused_supported(H) && decoder_fused3_supported(3, H) &&
+         decoder_forward_supported(3, H);
 }
 int decoder_fused_train_cat(hipStream_t s, int kind, int k_max, const float* d, int rows, int H,
                             HeadParams hp, const float* Wk, const float* bk, float* dWk,

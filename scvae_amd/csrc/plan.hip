@@ -1043,14 +1043,15 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   }
   const Targets tg = p->x_u16 ? targets_u16(p->step_u16, p->step_u16_ld) : targets_f32(a->t, F);
   const HeadParams hp = head_params(p);
-  // -k (k = 1, 2) in a training step of one likelihood pass: two launches of the bf16x9 head
-  // kernel (decoder_fused_train_cat) instead of materialised pre-activations and logits
-  const bool fused_cat = training && n_iw == 1 && KM > 0 && p->use_fused && p->fused_ws &&
+  // -k (k = 1, 2) in a training step: two launches of the bf16x9 head kernel
+  // (decoder_fused_train_cat) instead of materialised pre-activations and logits
+  const bool fused_cat = training && KM > 0 && p->use_fused && p->fused_ws &&
                          p->pre_k && ld == h1 && !head_drop && !p->x_u16 && !a->p_x_mean &&
                          decoder_fused_cat_supported(c.likelihood, KM, h1, p->head_arith);
-  // ... and its forward half in evaluation passes (two launches of decoder_forward_kernel)
-  const bool cat_forward = !training && KM > 0 && p->use_fused && p->fused_ws && p->pre_k &&
-                           ld == h1 && !p->x_u16 && !a->p_x_mean &&
+  // ... and its forward half (two launches of decoder_forward_kernel) in evaluation passes and
+  // in the first pass of an importance-weighted training step
+  const bool cat_forward = (!training || (fused_cat && n_iw > 1)) && KM > 0 && p->use_fused &&
+                           p->fused_ws && p->pre_k && ld == h1 && !p->x_u16 && !a->p_x_mean &&
                            decoder_fused_forward_cat_supported(c.likelihood, KM, h1);
   const float* head_in[4] = {dch, dch, dch, dch};   // [3]: the P_K head
   if (!fused && !fused_cat && !cat_forward)
