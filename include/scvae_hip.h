@@ -136,14 +136,14 @@ int scvae_plan_set_sync(scvae_plan* plan, scvae_sync_fn fn, void* user);
  * 0: separate GEMM and likelihood kernels (same results; kept for A/B tests and for the
  * evaluate-time statistics, which need the materialised pre-activations) */
 int scvae_plan_set_fused(scvae_plan* plan, int32_t enabled);
-/* 1 if a step of one likelihood pass of this (bound) plan runs the piecewise categorical
+/* 1 if the steps of this (bound) plan run the piecewise categorical
  * likelihood `-k` (cfg.k_max = 1 or 2, Poisson / negative-binomial counts; categorised.py:255-263,
  * va:2507-2532) on the fused kernels: two launches of the bf16x9 head kernel -- the count heads on
  * shifted, masked targets and the k + 1 class logits of every gene as the heads of a categorical
  * kind -- instead of materialised [rows, (P + k + 1) F] pre-activations; evaluation passes the
  * same two terms on the forward kernel (also the first pass of an importance-weighted
- * training step).  Larger k, head dropout,
- * evaluate-time statistics: the unfused kernels, as before. */
+ * training step).  Larger k, head dropout, evaluate-time statistics: the unfused kernels, as
+ * before. */
 int32_t scvae_plan_fused_categorised(const scvae_plan* plan);
 /* Arithmetic of this plan's fused head kernels (see scvae_default_head_arith below): 0 fp32
  * matrix cores, 1 the exact nine-term bf16 split, 2 the six-term split (the nine terms without
