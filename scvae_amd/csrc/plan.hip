@@ -765,7 +765,11 @@ int plan_side_fork(scvae_plan* p, hipStream_t s, int point) {
                            : (p->cfg.model_type == SCVAE_MODEL_VAE && !p->sync && w->fetch_out &&
                               w->fetch_n >= 1024);   // (single process: never run beside RCCL's kernels)
   if (!on) return 0;
-  const bool jobs = !p->side_jobs_done && (w->fetch_out || w->noise_out);
+  // (SCVAE_SIDE_JOBS_AT: where the next fetch and its noise leave the step's stream -- 0 at the
+  //  start of the step, beside the input layer; 1 (default) after the head kernel, beside the
+  //  backward pass of the hidden layers)
+  static const int jobs_at = [] { const char* e = getenv("SCVAE_SIDE_JOBS_AT"); return e ? atoi(e) : 1; }();
+  const bool jobs = !p->side_jobs_done && (w->fetch_out || w->noise_out) && point >= jobs_at;
   // (VAE plans: the likelihood heads are the tail of the parameter buffer)
   const bool adam = w->adam_m && p->side_adam_from == p->layout.n_params &&
                     p->cfg.model_type == SCVAE_MODEL_VAE &&
@@ -823,6 +827,8 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   p->drop_seed = a->dropout_seed;
 
   // ---------------- forward ----------------
+  if (training)
+    if ((rc = plan_side_fork(p, s, 0))) return rc;
   const bool mid = mid_chain_ok(p, B, S, training);
   const bool tile = !mid && tile_chain_ok(p, B, S, training);
   // The tile stages of the pass: one launch each (default), or -- single process: a

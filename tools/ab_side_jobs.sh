@@ -1,0 +1,13 @@
+#!/usr/bin/env bash
+# A/B on one box: where the carried fetch + noise leave the step's stream (SCVAE_SIDE_JOBS_AT:
+# 0 at the start of the step, beside the input layer; 1 after the head kernel, beside the
+# backward pass of the hidden layers)
+run() {
+  python bench.py --no-other-workloads --no-cpu-baseline --steps 300 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('  ms/step', round(d['ms_per_step'],4), 'median', round(d['step_ms_median'],4), 'head us', round(d['roofline']['launch_us'],1), 'rest', round(d['ms_per_step']*1e3-d['roofline']['launch_us'],1))"
+}
+for r in 1 2 3; do
+  echo "SCVAE_SIDE_JOBS_AT=1"; SCVAE_SIDE_JOBS_AT=1 run
+  echo "SCVAE_SIDE_JOBS_AT=0"; SCVAE_SIDE_JOBS_AT=0 run
+done
