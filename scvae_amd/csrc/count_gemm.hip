@@ -227,10 +227,20 @@ __global__ __launch_bounds__(256, 2) void count_gemm_dw_kernel(
         alo[t] = u32x4{l[0], l[1], l[2], l[3]};
       }
     }
-    // ---- requests: x two chunks ahead (the slot just converted), dA one chunk ahead ----
-    if (STEADY || kc + 2 * CD_BK < k_end) load_x(kc + 2 * CD_BK, buf_tag);
+    // ---- requests: dA one chunk ahead, x two chunks ahead (the slot just converted).  dA first:
+    //      in the unconditional loop (STEADY) the wait for dA at the end of the chunk (store_b)
+    //      is then vmcnt(8) and leaves the eight younger x loads in flight across the barrier;
+    //      with x first it was vmcnt(0) -- the counter retires in issue order -- and in the
+    //      conditional loop it still is (the compiler cannot count loads under a branch): every
+    //      x request lands within the chunk that issued it.  Measured (round 5, SCVAE_CD_STEADY,
+    //      tools/ab_cd_steady.sh): with the x requests really in flight the kernel is SLOWER,
+    //      138.8-142.2 against 134.7-137.2 us stand-alone, + 7 us in the step -- as round 2
+    //      found with the other order; the default stays the conditional loop ----
     const bool has_next = STEADY || kc + CD_BK < k_end;
     if (has_next) load_b(kc + CD_BK);
+    __builtin_amdgcn_sched_barrier(0);
+    if (STEADY || kc + 2 * CD_BK < k_end) load_x(kc + 2 * CD_BK, buf_tag);
+    __builtin_amdgcn_sched_barrier(0);
 
     const unsigned char* bcur = Bs[BUF] + frag_off;
 #pragma unroll
@@ -562,6 +572,12 @@ __global__ __launch_bounds__(256) void count_gemm_reduce_kernel(
   }
 }
 
+// (A/B: SCVAE_CD_STEADY=0 / 1 -- the weight-gradient kernel's unconditional main loop)
+static bool cd_steady() {
+  static const bool on = [] { const char* e = getenv("SCVAE_CD_STEADY"); return e ? e[0] == '1' : false; }();
+  return on;
+}
+
 static int cg_splits(int mode, int M, int K) {
   const int bm = mode == 0 ? CF_BM : CD_BM;
   const long blocks = (M + bm - 1) / bm;
@@ -644,8 +660,12 @@ static int count_gemm_impl(hipStream_t stream, int mode, const XT* x, int ldx, i
   do {                                                                                            \
     if constexpr (sizeof(XT) == 2) {                                                              \
       if ((M & 1) == 0) {   /* gene pairs per lane (4-byte loads) */                               \
-        hipLaunchKernelGGL((count_gemm_dw_kernel<NT_, XT, true>), grid, dim3(256), 0, stream, x,  \
-                           ldx, M, k_main, T, Kpad, N, k_chunk, dst, ldo);                        \
+        if (cd_steady())                                                                          \
+          hipLaunchKernelGGL((count_gemm_dw_kernel<NT_, XT, true, true>), grid, dim3(256), 0,     \
+                             stream, x, ldx, M, k_main, T, Kpad, N, k_chunk, dst, ldo);           \
+        else                                                                                      \
+          hipLaunchKernelGGL((count_gemm_dw_kernel<NT_, XT, true>), grid, dim3(256), 0, stream,   \
+                             x, ldx, M, k_main, T, Kpad, N, k_chunk, dst, ldo);                   \
         break;                                                                                    \
       }                                                                                           \
     }                                                                                             \
