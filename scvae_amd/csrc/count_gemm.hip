@@ -104,17 +104,19 @@ __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast
 // slots), the split dA operand through LDS (48-byte rows: conflict-free ds_read_b128).
 constexpr int CD_BK = 16;
 constexpr int CD_ROW = 48;            // LDS bytes per (term, column) row: 32 + 16 pad
-constexpr int CD_BM = 256;            // genes per workgroup
 
-template <int NT, typename XT, bool PAIR = false, bool USE_STEADY = false>
-__global__ __launch_bounds__(256, 2) void count_gemm_dw_kernel(
+// NW: waves per workgroup -- 4 (256 genes, two workgroups per CU) or 8 (512 genes, one per CU: the
+// dA planes of a chunk are fetched and parked once for twice the genes)
+template <int NT, typename XT, bool PAIR = false, bool USE_STEADY = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void count_gemm_dw_kernel(
     const XT* __restrict__ X, int ldx, int M, int K, const uint16_t* __restrict__ T, int Kpad,
     int N, int k_chunk, float* __restrict__ out, int ldo) {
   __shared__ __attribute__((aligned(16))) unsigned char Bs[2][3 * CG_NP * CD_ROW];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, kg = lane >> 5;
-  const int m_w = blockIdx.x * CD_BM + w * CG_TM;       // first gene of this wave
+  constexpr int NTHR = 64 * NW, NPC = (768 + NTHR - 1) / NTHR;   // pieces of dA per thread
+  const int m_w = blockIdx.x * (NW * CG_TM) + w * CG_TM;       // first gene of this wave
   const int k_begin = blockIdx.y * k_chunk;
   const int k_end = min(K, k_begin + k_chunk);
 
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void count_gemm_dw_kernel(
     if constexpr (PAIR) return (float)(t == 0 ? (rawp[SLOT][j] & 0xFFFFu) : (rawp[SLOT][j] >> 16));
     else return count_to_f32(raw[SLOT][t][j]);
   };
-  u32x4 breg[3];
+  u32x4 breg[USE_STEADY ? 2 : 1][NPC];
   auto load_x = [&](int kc, auto slot_tag) {
     constexpr int SLOT = decltype(slot_tag)::value;
 #pragma unroll
@@ -160,30 +162,40 @@ __global__ __launch_bounds__(256, 2) void count_gemm_dw_kernel(
       }
     }
   };
-  auto load_b = [&](int kc) {
+  auto load_b = [&](int kc, int slot = 0) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int p = tid + 256 * i;                 // 768 pieces: (term, column, half)
+    for (int i = 0; i < NPC; ++i) {
+      const int p = tid + NTHR * i;                // 768 pieces: (term, column, half)
       const int row = p >> 1, part = p & 1;        // row = term * 128 + column
-      if ((row & (CG_NP - 1)) < NT * 32)
-        breg[i] = *reinterpret_cast<const u32x4*>(T + (size_t)row * Kpad + kc + part * 8);
+      // (columns beyond N: the last live column's piece again -- a line this wave requests
+      //  anyway, no branch around the load; what they multiply into is never stored)
+      const int col = row & (CG_NP - 1), rowl = col < N ? row : row - col + (N - 1);
+      if (p < 768 && col < NT * 32)
+        breg[slot][i] = *reinterpret_cast<const u32x4*>(T + (size_t)rowl * Kpad + kc + part * 8);
     }
   };
-  auto store_b = [&](int buf) {
+  auto store_b = [&](int buf, int slot = 0) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int p = tid + 256 * i;
+    for (int i = 0; i < NPC; ++i) {
+      const int p = tid + NTHR * i;
       const int row = p >> 1, part = p & 1;
-      if ((row & (CG_NP - 1)) < NT * 32)
-        *reinterpret_cast<u32x4*>(&Bs[buf][row * CD_ROW + part * 16]) = breg[i];
+      if (p < 768 && (row & (CG_NP - 1)) < NT * 32)
+        *reinterpret_cast<u32x4*>(&Bs[buf][row * CD_ROW + part * 16]) = breg[slot][i];
     }
   };
+  // (USE_STEADY: every request of the loop is unconditional -- a chunk index beyond the split's
+  //  last chunk is clamped to it, its data never used -- so that the compiler can count the
+  //  loads in flight; dA travels TWO chunks ahead, like x)
+  const int k_last = k_end - CD_BK;
+  auto clampk = [&](int k) { return min(k, k_last); };
 
   if (k_begin < k_end) {
     load_x(k_begin, std::integral_constant<int, 0>{});
-    if (k_begin + CD_BK < k_end) load_x(k_begin + CD_BK, std::integral_constant<int, 1>{});
+    if (USE_STEADY) load_x(clampk(k_begin + CD_BK), std::integral_constant<int, 1>{});
+    else if (k_begin + CD_BK < k_end) load_x(k_begin + CD_BK, std::integral_constant<int, 1>{});
     load_b(k_begin);
     store_b(0);
+    if (USE_STEADY) load_b(clampk(k_begin + CD_BK), 1);
   }
   __syncthreads();
 
@@ -237,9 +249,15 @@ __global__ __launch_bounds__(256, 2) void count_gemm_dw_kernel(
     //      138.8-142.2 against 134.7-137.2 us stand-alone, + 7 us in the step -- as round 2
     //      found with the other order; the default stays the conditional loop ----
     const bool has_next = STEADY || kc + CD_BK < k_end;
-    if (has_next) load_b(kc + CD_BK);
-    __builtin_amdgcn_sched_barrier(0);
-    if (STEADY || kc + 2 * CD_BK < k_end) load_x(kc + 2 * CD_BK, buf_tag);
+    if (STEADY) {
+      load_b(clampk(kc + 2 * CD_BK), BUF);
+      __builtin_amdgcn_sched_barrier(0);
+      load_x(clampk(kc + 2 * CD_BK), buf_tag);
+    } else {
+      if (has_next) load_b(kc + CD_BK);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kc + 2 * CD_BK < k_end) load_x(kc + 2 * CD_BK, buf_tag);
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     const unsigned char* bcur = Bs[BUF] + frag_off;
@@ -267,19 +285,22 @@ __global__ __launch_bounds__(256, 2) void count_gemm_dw_kernel(
                                                             0, 0);
       }
     }
-    if (has_next) store_b(BUF ^ 1);
+    if (STEADY) store_b(BUF ^ 1, BUF ^ 1);     // (dA of chunk kc + 1: requested a chunk ago)
+    else if (has_next) store_b(BUF ^ 1);
     lds_barrier();       // (LDS only: the x requests stay in flight across it)
   };
   {
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
     int kc = k_begin;
-    if (USE_STEADY)
-    for (; kc + 3 * CD_BK < k_end; kc += 2 * CD_BK) {   // chunks j, j + 1 with j + 3 in range
-      chunk(kc, B0{}, std::true_type{});
-      chunk(kc + CD_BK, B1{}, std::true_type{});
-    }
-    for (; kc < k_end; kc += 2 * CD_BK) {               // the last one to three chunks
+    if (USE_STEADY) {
+      for (; kc + CD_BK < k_end; kc += 2 * CD_BK) {     // pairs of chunks
+        chunk(kc, B0{}, std::true_type{});
+        chunk(kc + CD_BK, B1{}, std::true_type{});
+      }
+      if (kc < k_end) chunk(kc, B0{}, std::true_type{});   // an odd last one
+    } else
+    for (; kc < k_end; kc += 2 * CD_BK) {
       chunk(kc, B0{}, std::false_type{});
       if (kc + CD_BK < k_end) chunk(kc + CD_BK, B1{}, std::false_type{});
     }
@@ -377,8 +398,10 @@ __global__ __launch_bounds__(512) void count_gemm_fwd_kernel(
     for (int i = 0; i < 3; ++i) {
       const int p = tid + 512 * i;                      // (term, column, quarter)
       const int row = p >> 2, prt = p & 3;              // row = term * 128 + column
-      if ((row & (CG_NP - 1)) < NCOL)
-        breg[slot][i] = *reinterpret_cast<const u32x4*>(T + (size_t)row * Kpad + kc + prt * 8);
+      // (columns beyond N: the last live column's piece again, as in count_gemm_dw_kernel)
+      const int col = row & (CG_NP - 1), rowl = col < N ? row : row - col + (N - 1);
+      if (col < NCOL)
+        breg[slot][i] = *reinterpret_cast<const u32x4*>(T + (size_t)rowl * Kpad + kc + prt * 8);
     }
   };
   bool dirty0 = false, dirty1 = false;                  // this wave's lo rows of buffer b are set
@@ -578,10 +601,25 @@ static bool cd_steady() {
   return on;
 }
 
+// Waves per workgroup of the weight-gradient kernel (uint16 gene pairs): 8 -- 512 genes, one
+// workgroup per CU, the dA planes of a chunk fetched and parked once for twice the genes -- where
+// such workgroups still fill the chip, else 4 (256 genes, two per CU).  The kernel is bound by
+// what it moves through the L2s, x + one copy of the dA planes per workgroup: 268 + 403 MB at
+// 4096 x 32 738 with 512 workgroups, 268 + 201 MB with 256 (round 5: 146-155 -> 131-136 us
+// stand-alone, -17 to -25 us in the step; tools/ab_cd_waves.sh, SCVAE_CD_WAVES=4 / 8 forces one).
+static int cd_waves(int M, int K) {
+  static const int forced = [] { const char* e = getenv("SCVAE_CD_WAVES"); return e ? atoi(e) : 0; }();
+  if (forced == 4 || forced == 8) return forced;
+  const long blocks = (M + 8 * CG_TM - 1) / (8 * CG_TM);
+  const long want = (256 + blocks - 1) / blocks, max_by_k = K / 256 > 0 ? K / 256 : 1;
+  return blocks * (want < max_by_k ? want : max_by_k) >= 224 ? 8 : 4;
+}
+
 static int cg_splits(int mode, int M, int K) {
-  const int bm = mode == 0 ? CF_BM : CD_BM;
+  const int nw = mode == 0 ? 0 : cd_waves(M, K);
+  const int bm = mode == 0 ? CF_BM : nw * CG_TM;
   const long blocks = (M + bm - 1) / bm;
-  const long target = mode == 0 ? 256 : 512;         // workgroups per CU: forward 1, dW 2
+  const long target = mode == 0 || nw == 8 ? 256 : 512;   // workgroups per CU: forward 1, dW 2 (or 1)
   long want = (target + blocks - 1) / blocks;
   const long max_by_k = K / 256 > 0 ? K / 256 : 1;   // at least 8 chunks per split
   long s = want < max_by_k ? want : max_by_k;
@@ -655,12 +693,16 @@ static int count_gemm_impl(hipStream_t stream, int mode, const XT* x, int ldx, i
       if (NQ == 2) SCVAE_CF(2); else SCVAE_CF(1);
 #undef SCVAE_CF
     } else {
-      const dim3 grid((M + CD_BM - 1) / CD_BM, splits);
+      const int nw = (sizeof(XT) == 2 && (M & 1) == 0) ? cd_waves(M, k_main) : 4;   // (8: the pair kernel)
+      const dim3 grid((M + nw * CG_TM - 1) / (nw * CG_TM), splits);
 #define SCVAE_CD(NT_)                                                                             \
   do {                                                                                            \
     if constexpr (sizeof(XT) == 2) {                                                              \
       if ((M & 1) == 0) {   /* gene pairs per lane (4-byte loads) */                               \
-        if (cd_steady())                                                                          \
+        if (nw == 8)                                                                              \
+          hipLaunchKernelGGL((count_gemm_dw_kernel<NT_, XT, true, false, 8>), grid, dim3(512), 0, \
+                             stream, x, ldx, M, k_main, T, Kpad, N, k_chunk, dst, ldo);           \
+        else if (cd_steady())                                                                     \
           hipLaunchKernelGGL((count_gemm_dw_kernel<NT_, XT, true, true>), grid, dim3(256), 0,     \
                              stream, x, ldx, M, k_main, T, Kpad, N, k_chunk, dst, ldo);           \
         else                                                                                      \
