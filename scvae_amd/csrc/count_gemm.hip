@@ -50,6 +50,17 @@ constexpr int CG_KPAD = 64;           // the split operand is zero-padded to a m
 // is the same arithmetic on the same fp32 value.
 template <typename XT> __device__ __forceinline__ float count_to_f32(XT v) { return (float)v; }
 
+// A/B switch (tools/ab_cg_nt.sh, round 5: refuted): the requests for x marked non-temporal (bit 0:
+// forward product, bit 1: weight gradient).  Forward: + 15 us stand-alone, + 30 us in the step (x
+// no longer waits in the infinity cache for its later readers); weight gradient: +- 0.
+#ifndef SCVAE_CG_NT
+#define SCVAE_CG_NT 0
+#endif
+template <bool NT, typename T> __device__ __forceinline__ T cg_load(const T* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+
 static inline int cg_kpad(int K) { return (K + CG_KPAD - 1) / CG_KPAD * CG_KPAD; }
 static inline int cg_bk(int mode) { return mode == 0 ? 32 : 16; }   // chunk of the mode's kernel
 
@@ -155,10 +166,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void count_gemm_dw_kernel
     for (int j = 0; j < 8; ++j) {
       const XT* srow = X + (size_t)(kc + j) * ldx;               // uniform: scalar base
       if constexpr (PAIR) {
-        rawp[SLOT][j] = *reinterpret_cast<const unsigned*>(srow + xoff[0]);
+        rawp[SLOT][j] = cg_load<(SCVAE_CG_NT & 2) != 0>(
+            reinterpret_cast<const unsigned*>(srow + xoff[0]));
       } else {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) raw[SLOT][t][j] = srow[xoff[t]];
+        for (int t = 0; t < 2; ++t)
+          raw[SLOT][t][j] = cg_load<(SCVAE_CG_NT & 2) != 0>(srow + xoff[t]);
       }
     }
   };
@@ -393,7 +406,11 @@ __global__ __launch_bounds__(512) void count_gemm_fwd_kernel(
   u32x4 breg[2][3];
   auto load_tiles = [&](int kc, int slot) {
 #pragma unroll
-    for (int i = 0; i < PCS; ++i) raw[slot][i] = *reinterpret_cast<const f32x4u*>(xsrc[i] + kc);
+    for (int i = 0; i < PCS; ++i) {
+      const f32x4u* src = reinterpret_cast<const f32x4u*>(xsrc[i] + kc);
+      if constexpr ((SCVAE_CG_NT & 1) != 0) raw[slot][i] = __builtin_nontemporal_load(src);
+      else raw[slot][i] = *src;
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int p = tid + 512 * i;                      // (term, column, quarter)
