@@ -32,6 +32,18 @@ def current_stream_handle(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+class PendingState(dict):
+    """A state dictionary whose tensors are still on their way to the host
+    (``Engine.state_dict(non_blocking=True)``): complete after ``wait()``."""
+    ready = None
+
+    def wait(self):
+        if self.ready is not None:
+            self.ready.synchronize()
+            self.ready = None
+        return self
+
+
 class Engine:
     """Flat-buffer model state + kernel plan on one GPU."""
 
@@ -134,6 +146,7 @@ class Engine:
         self.adam_v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.moving = torch.zeros(max(nm, 1), dtype=torch.float32, device=dev)
         self.adam_t = 0
+        self._copy_stream = None   # (state_dict(non_blocking=True))
         self.workspace = None
         self.max_cells = 0
         self.max_samples = 0
@@ -250,14 +263,35 @@ class Engine:
                 self.moving_statistic(k).copy_(
                     torch.as_tensor(v).to(torch.float32))
 
-    def state_dict(self):
-        return {
-            "params": self.params.detach().cpu(),
-            "adam_m": self.adam_m.detach().cpu(),
-            "adam_v": self.adam_v.detach().cpu(),
-            "moving": self.moving.detach().cpu(),
-            "adam_t": self.adam_t,
-        }
+    def state_dict(self, non_blocking=False):
+        """Parameters, Adam moments, moving statistics and the step count on the
+        host.  ``non_blocking``: the state is snapshotted on the device now (a
+        copy in HBM on the caller's stream, microseconds) and travels to pinned
+        host memory on a second stream while the caller carries on; the
+        returned ``PendingState`` is the finished dictionary once its ``wait()``
+        has returned (the checkpoint queue calls it, models/utilities.py)."""
+        tensors = {"params": self.params, "adam_m": self.adam_m,
+                   "adam_v": self.adam_v, "moving": self.moving}
+        if not non_blocking or self.device.type != "cuda":
+            state = {k: v.detach().cpu() for k, v in tensors.items()}
+            state["adam_t"] = self.adam_t
+            return state
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        side = self._copy_stream
+        snapshot = {k: v.detach().clone() for k, v in tensors.items()}
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        state = PendingState()
+        with torch.cuda.stream(side):
+            for k, v in snapshot.items():
+                v.record_stream(side)
+                state[k] = torch.empty(v.shape, dtype=v.dtype,
+                                       pin_memory=True).copy_(
+                                           v, non_blocking=True)
+            state.ready = torch.cuda.Event()
+            state.ready.record(side)
+        state["adam_t"] = self.adam_t
+        return state
 
     def load_state_dict(self, state):
         self.params.copy_(state["params"])

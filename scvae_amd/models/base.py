@@ -720,8 +720,11 @@ class ModelBase:
             say("    Saving model parameters.")
             saving_time_start = time()
             if master:   # (written in the background, see CheckpointWriter)
-                checkpoint_writer.save(engine.state_dict(), log_directory,
-                                       epoch + 1)
+                checkpoint_writer.save(
+                    engine.state_dict(
+                        non_blocking=self.checkpoint_non_blocking),
+                    log_directory,
+                    epoch + 1)
             say("    Model parameters saved ({}).".format(
                 format_duration(time() - saving_time_start)))
 
@@ -907,6 +910,9 @@ class ModelBase:
     # step per minibatch, as the reference runs them); the stacked passes of a
     # step stay within what the training workloads run
     evaluation_chunk_cells = 4096
+    # the state of an epoch's checkpoint leaves the device on a second stream
+    # (Engine.state_dict(non_blocking=True)); False: the blocking copy
+    checkpoint_non_blocking = True
     evaluation_chunk_stacked_rows = 16384
 
     def _evaluation_step_cells(self, samples):

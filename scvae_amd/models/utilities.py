@@ -165,10 +165,11 @@ def save_checkpoint(state, log_directory, epoch):
 
 class CheckpointWriter:
     """The file-system side of an epoch on a background thread, in order: the
-    training loop only pays for the device-to-host copy of the state
-    (``engine.state_dict()``); serialising it, the copies into
-    ``early_stopping/`` and ``best/`` (va:1385-1441, 1470-1492) and the pruning
-    of old files overlap the next epoch.  Jobs run strictly in the order they
+    training loop only pays for a snapshot of the state in device memory
+    (``engine.state_dict(non_blocking=True)``: the copy to pinned host memory
+    runs on a second stream and is waited for by the queue); serialising it,
+    the copies into ``early_stopping/`` and ``best/`` (va:1385-1441, 1470-1492)
+    and the pruning of old files overlap the next epoch.  Jobs run strictly in the order they
     were queued, so "the latest checkpoint of a directory" means what it means
     in the reference's sequential loop.  Whoever reads the files calls
     ``wait()`` first; at most two states wait in memory."""
@@ -212,7 +213,12 @@ class CheckpointWriter:
 
         def work():
             try:
-                save_checkpoint(state, log_directory, epoch)
+                # (a state still travelling to the host -- Engine.state_dict(
+                #  non_blocking=True) -- is waited for here, off the training
+                #  loop, and written as the plain dictionary it then is)
+                ready = (dict(state.wait()) if hasattr(state, "wait")
+                         else state)
+                save_checkpoint(ready, log_directory, epoch)
             finally:
                 with self._lock:
                     self._pending_saves -= 1

@@ -508,3 +508,32 @@ def test_evaluation_pass_in_steps_of_several_minibatches(tmp_path, cuda_device,
         total += weight * float(out["lower_bound"])
     expected = total / (n / B)
     assert abs(got - expected) <= 1e-4 * abs(expected)
+
+
+def test_non_blocking_state_is_a_snapshot(cuda_device):
+    """``Engine.state_dict(non_blocking=True)`` (what the training loop hands
+    the checkpoint queue): the state as it was when asked for -- whatever the
+    next steps do to the parameters while it travels -- equal to the blocking
+    copy, in pinned host memory, a plain dictionary after ``wait()``."""
+    from scvae_amd.engine import Engine
+    engine = Engine(300, 8, (32, 32), "negative binomial", batch_norm=True,
+                    device=cuda_device, seed=1)
+    engine.adam_m.normal_()
+    engine.adam_v.uniform_()
+    engine.moving.normal_()
+    engine.adam_t = 5
+    want = engine.state_dict()
+    pending = engine.state_dict(non_blocking=True)
+    # the "next epoch" overwrites everything while the copy may be in flight
+    engine.params.zero_()
+    engine.adam_m.zero_()
+    engine.adam_v.zero_()
+    engine.moving.zero_()
+    engine.adam_t = 6
+    got = dict(pending.wait())
+    assert set(got) == set(want) and got["adam_t"] == 5
+    for key in ("params", "adam_m", "adam_v", "moving"):
+        assert got[key].is_pinned() and torch.equal(got[key], want[key])
+    engine.load_state_dict(got)
+    assert torch.equal(engine.params.cpu(), want["params"])
+    assert engine.adam_t == 5

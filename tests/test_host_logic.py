@@ -221,6 +221,23 @@ def test_checkpoint_queue_keeps_the_sequential_meaning(tmp_path):
     # the logs of a copy: as they were when it was queued
     steps = lambda d: [r["step"] for r in mu._read_scalars(os.path.join(d, "training"))]
     assert steps(early) == [1, 2] and steps(best) == [1, 2, 3] and steps(log) == [1, 2, 3, 4]
+    # a state still on its way to the host (Engine.state_dict(non_blocking=True)) is waited
+    # for on the worker and written as a plain dictionary (weights-only loadable)
+    from scvae_amd.engine import PendingState
+
+    class Travelling(PendingState):
+        waited = 0
+
+        def wait(self):
+            Travelling.waited += 1
+            return super().wait()
+    pending = Travelling(state(7))
+    writer = mu.CheckpointWriter()
+    writer.save(pending, str(tmp_path / "p"), 7)
+    writer.close()
+    assert Travelling.waited == 1
+    loaded = mu.load_checkpoint(mu.get_checkpoint_state(str(tmp_path / "p")))
+    assert type(loaded) is dict and float(loaded["params"][0]) == 7.0 and loaded["adam_t"] == 7
     # a failure on the worker surfaces at the next wait
     writer = mu.CheckpointWriter()
     writer.save({"bad": lambda: None}, str(tmp_path / "x"), 1)   # (not picklable)
