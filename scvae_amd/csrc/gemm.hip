@@ -10,6 +10,8 @@
 // (lane l: A[i=l&31][k=l>>5]) are bank-conflict free.  Optional split-K writes
 // fp32 partial slabs that a second kernel reduces in a fixed order
 // (deterministic; no atomics).
+#include <cstdlib>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -473,7 +475,11 @@ size_t gemm_workspace_bytes(int M, int N, int K) {
 
 int gemm_choose_splits(int M, int N, int K) {
   const long tiles = (long)((M + GT - 1) / GT) * ((N + GT - 1) / GT);
-  if (tiles >= 256 || K < 1024) return 1;
+  // (the k loop is a chain of dependent global round trips, ~0.9 us per 16-k step on one
+  //  workgroup: K = 512 on a 2 x 2 grid took 28 us, the weight gradients of the GMVAE's q(y|x)
+  //  layers; split from K = 256 on -- SCVAE_GEMM_SPLIT_MIN_K=1024 restores the old threshold)
+  static const int min_k = [] { const char* e = getenv("SCVAE_GEMM_SPLIT_MIN_K"); return e ? atoi(e) : 256; }();
+  if (tiles >= 256 || K < min_k) return 1;
   long want = (512 + tiles - 1) / tiles;          // aim for ~2 workgroups per CU
   long max_by_k = K / 64;                         // keep >= 64 of K (4 k-steps) per split
   long s = want < max_by_k ? want : max_by_k;
