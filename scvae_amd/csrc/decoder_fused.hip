@@ -1026,6 +1026,9 @@ bool decoder_fused_cat_supported(int kind, int k_max, int H, int arith) {
          decoder_fused_supported(H) && decoder_fused3_supported(3, H) &&
          decoder_forward_supported(3, H);
 }
+size_t decoder_fused_cat_scratch_floats(int rows, int H) {
+  return ((size_t)rows + 63) / 64 * 64 + (size_t)rows * H;
+}
 int decoder_fused_train_cat(hipStream_t s, int kind, int k_max, const float* d, int rows, int H,
                             HeadParams hp, const float* Wk, const float* bk, float* dWk,
                             float* dbk, int F, const float* t, int B, const float* gw, float* ll,

@@ -349,6 +349,9 @@ size_t decoder_fused_workspace_floats(int rows, int H, int F, bool train);
 // two launches of the bf16x9 all-in-one-phase kernel: Wk / bk / dWk / dbk the P_K head
 // [H, F (k_max + 1)] / [F (k_max + 1)]; t fp32 [B, F]; scratch: rows * (H + 1) + 64 floats
 bool decoder_fused_cat_supported(int kind, int k_max, int H, int arith);
+// floats of the `scratch` argument of decoder_fused_train_cat / decoder_fused_forward_cat (ll and dd
+// of the second launch: the plans lend the unfused path's logits buffer and size it for both)
+size_t decoder_fused_cat_scratch_floats(int rows, int H);
 // (forward only: two launches of decoder_forward_kernel; scratch: rows floats)
 bool decoder_fused_forward_cat_supported(int kind, int k_max, int H);
 int decoder_fused_forward_cat(hipStream_t s, int kind, int k_max, const float* d, int rows, int H,

@@ -177,7 +177,12 @@ size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t
   const size_t E = (size_t)c.decoder_extra;
   float* zcat = E ? b.floats(R * (Lz + E)) : nullptr;
   float* dzcat = E ? b.floats(R * (Lz + E)) : nullptr;
-  float* pre_k = c.k_max > 0 ? b.floats(R * F * (size_t)(c.k_max + 1)) : nullptr;
+  // (the class logits of the unfused path; the fused -k launches keep the second launch's ll and
+  //  dd there -- more than the logits when there are fewer genes than hidden units)
+  size_t pre_k_floats = R * F * (size_t)(c.k_max + 1);
+  if (pre_k_floats < decoder_fused_cat_scratch_floats((int)R, p->heads[0].n_in))
+    pre_k_floats = decoder_fused_cat_scratch_floats((int)R, p->heads[0].n_in);
+  float* pre_k = c.k_max > 0 ? b.floats(pre_k_floats) : nullptr;
   // dropped-out layer inputs of the training pass (kept for the weight gradients); the p(z|y)
   // layers keep their effective (row-scaled) weights [K, L] there
   auto drop_ws = [&](Dense& d, size_t rows) {

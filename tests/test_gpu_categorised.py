@@ -185,6 +185,46 @@ def test_fused_categorised_training_step(cuda_device, model_type, likelihood,
                       what="fused vs unfused per-cell ll")
 
 
+@pytest.mark.parametrize("model_type", ["VAE", "GMVAE"])
+def test_fused_categorised_step_with_fewer_genes_than_hidden_units(
+        cuda_device, model_type):
+    """The fused -k launches keep the second launch's ll and dd in the plan's
+    buffer of the unfused path's class logits, [rows, F (k + 1)]: with fewer
+    genes than hidden units that is LESS than rows + rows x H, and what follows
+    it in the workspace are the dropped-out layer inputs the weight gradients
+    read (found by tools/fuzz_options.py, seed 5041: wrong dW of the layers
+    with dropout, everything else right).  Same step, same dropout seed, on the
+    fused and on the unfused kernels."""
+    from scvae_amd.engine import Engine
+    F, L, H, B, K, KM = 10, 2, (20, 28), 13, 3, 1
+    gm = model_type == "GMVAE"
+    keeps = (0.0, 0.0, 0.9, 0.9) if gm else (0.0, 0.0, 0.9)
+    rng = np.random.default_rng(11)
+    x = rng.poisson(2.0, (B, F)) * (rng.random((B, F)) < 0.5)
+    xd = torch.from_numpy(x.astype(np.float32)).to(cuda_device)
+    eps = torch.from_numpy(rng.standard_normal(
+        (K, 1, B, L) if gm else (1, B, L)).astype(np.float32)).to(cuda_device)
+    results = {}
+    for fused in (True, False):
+        eng = Engine(F, L, H, "poisson", batch_norm=True, model_type=model_type,
+                     n_clusters=K, device=cuda_device, seed=4, k_max=KM,
+                     dropout_keep_probabilities=keeps)
+        eng.set_fused(fused)
+        eng.reserve(B, 1)
+        assert eng.fused_categorised == fused
+        sc = eng.step(xd, xd, eps=eps, training=True, dropout_seed=99).cpu().numpy()
+        torch.cuda.synchronize()
+        results[fused] = (sc, {k: v.clone().cpu()
+                               for k, v in eng.named_gradients().items()})
+    _close(results[True][0][0], results[False][0][0], 1e-5, "lower_bound")
+    for name, g in results[True][1].items():
+        u = results[False][1][name]
+        if float(u.abs().max()) == 0.0:
+            assert float(g.abs().max()) == 0.0, name
+            continue
+        _close(g, u, 3e-4, "fused vs unfused grad " + name)
+
+
 def test_categorised_model_trains_and_evaluates(tmp_path, cuda_device, capsys):
     from scvae_amd.data import DataSet
     from scvae_amd.models import VariationalAutoencoder
