@@ -335,6 +335,11 @@ typedef struct scvae_step_args {
   /* optional: optimiser update of this step / fetch and noise of the next one (see above) */
   const scvae_side_work* side;
 } scvae_step_args;
+/* Debugging aid: with SCVAE_WS_GUARD=1 in the environment (read once per process) every buffer
+ * carved out of a plan's workspace is followed by a guard region (scvae_plan_workspace_bytes
+ * grows accordingly), filled when the plan is bound; scvae_plan_step then synchronises the stream
+ * after the step, checks the regions and fails (-3, scvae_last_error names the buffer's offset)
+ * if a kernel wrote past its buffer. */
 int scvae_plan_step(scvae_plan* plan, const scvae_step_args* args, void* stream);
 /* 1 if a step of `cells` cells of this plan can take its minibatch as uint16 counts
  * (training: 0 = evaluation step, 1 = training step, 2 = training step without importance

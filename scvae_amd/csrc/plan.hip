@@ -95,11 +95,58 @@ static int build_vae(scvae_plan* p) {
   return 0;
 }
 
+bool workspace_guard_on() {
+  static const bool on = [] { const char* e = getenv("SCVAE_WS_GUARD"); return e && e[0] == '1'; }();
+  return on;
+}
+// one workgroup per guard region: the first region (lowest index) holding a byte that is not the
+// pattern
+__global__ __launch_bounds__(256) void ws_guard_check_kernel(const unsigned char* __restrict__ base,
+                                                             const size_t* __restrict__ regions,
+                                                             int* __restrict__ first_bad) {
+  const size_t off = regions[2 * blockIdx.x], len = regions[2 * blockIdx.x + 1];
+  bool bad = false;
+  for (size_t i = threadIdx.x; i < len; i += blockDim.x) bad |= base[off + i] != WS_GUARD_BYTE;
+  if (bad) atomicMin(first_bad, (int)blockIdx.x);
+}
+static int ws_guard_arm(scvae_plan* p) {
+  if (p->ws_guards_dev) { (void)hipFree(p->ws_guards_dev); p->ws_guards_dev = nullptr; }
+  if (p->ws_guards.empty()) return 0;
+  std::vector<size_t> flat;
+  for (auto& g : p->ws_guards) {
+    flat.push_back(g.first); flat.push_back(g.second);
+    SCVAE_HIP(hipMemset((char*)p->ws + g.first, WS_GUARD_BYTE, g.second));
+  }
+  SCVAE_HIP(hipMalloc((void**)&p->ws_guards_dev, flat.size() * sizeof(size_t)));
+  SCVAE_HIP(hipMemcpy(p->ws_guards_dev, flat.data(), flat.size() * sizeof(size_t),
+                      hipMemcpyHostToDevice));
+  if (!p->ws_guard_flag) SCVAE_HIP(hipMalloc((void**)&p->ws_guard_flag, sizeof(int)));
+  return 0;
+}
+static int ws_guard_check(scvae_plan* p, hipStream_t s) {
+  if (!p->ws_guards_dev) return 0;
+  const int none = 0x7fffffff;
+  int first = none;
+  SCVAE_HIP(hipMemcpyAsync(p->ws_guard_flag, &first, sizeof(int), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(ws_guard_check_kernel, dim3((unsigned)p->ws_guards.size()), dim3(256), 0, s,
+                     (const unsigned char*)p->ws, p->ws_guards_dev, p->ws_guard_flag);
+  SCVAE_LAUNCH_CHECK("ws_guard_check_kernel");
+  SCVAE_HIP(hipMemcpyAsync(&first, p->ws_guard_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  SCVAE_HIP(hipStreamSynchronize(s));
+  if (first != none) {
+    set_error("SCVAE_WS_GUARD: a kernel wrote past workspace buffer %d of this plan (the buffer "
+              "ending at byte offset %zu)", first, p->ws_guards[(size_t)first].first);
+    return -3;
+  }
+  return 0;
+}
+
 // carve (or measure) the workspace
 static size_t carve(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t samples,
                     bool dry) {
   const scvae_model_config& c = p->cfg;
   Bump b(base, cap, dry);
+  if (!dry && workspace_guard_on()) { p->ws_guards.clear(); b.guards = &p->ws_guards; }
   const size_t B = (size_t)cells, R = (size_t)cells * samples;
   const size_t Lz = c.latent_size, F = c.feature_size;
   size_t hmax = Lz;
@@ -1429,6 +1476,8 @@ scvae_plan::~scvae_plan() {
   }
   if (side_fork) (void)hipEventDestroy(side_fork);
   if (side_join) (void)hipEventDestroy(side_join);
+  if (ws_guards_dev) (void)hipFree(ws_guards_dev);
+  if (ws_guard_flag) (void)hipFree(ws_guard_flag);
 }
 
 extern "C" {
@@ -1525,6 +1574,10 @@ int scvae_plan_bind(scvae_plan* p, float* params, float* grads, float* moving, v
   p->max_cells = max_cells; p->max_samples = max_samples;
   if (gm) scvae::carve_gmvae(p, workspace, (size_t)workspace_bytes, max_cells, max_samples, false);
   else scvae::carve(p, workspace, (size_t)workspace_bytes, max_cells, max_samples, false);
+  if (scvae::workspace_guard_on()) {
+    const int rc = scvae::ws_guard_arm(p);
+    if (rc) return rc;
+  }
   if (p->mid_bar) {
     SCVAE_HIP(hipMemset(p->mid_bar, 0, 64 * sizeof(float)));
     p->mid_bar_count = 0;
@@ -1899,6 +1952,7 @@ int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
     scvae::stage_probe_arm(nullptr, nullptr);
     ++p->stage_next;
   }
+  if (!rc && p->ws_guards_dev) rc = scvae::ws_guard_check(p, (hipStream_t)stream);
   return rc;
 }
 

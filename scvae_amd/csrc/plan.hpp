@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/scvae_hip.h"
@@ -96,13 +97,26 @@ static const char* head_names(int kind, int j) {
   }
 }
 
+// SCVAE_WS_GUARD=1 (a debugging aid, read once per process): every buffer carved out of a plan's
+// workspace is followed by a guard region -- the rest of its 256-byte line and one more line --
+// filled with a byte pattern when the plan is bound and checked after every step
+// (scvae_plan_step then synchronises the stream and fails with the buffer's offset).  Found the
+// overrun of the fused -k scratch in round 5 the second time round; GPU suite: tests/conftest.py.
+bool workspace_guard_on();
+constexpr unsigned char WS_GUARD_BYTE = 0xA5;
+
 struct Bump {
   char* base;
   size_t used = 0, cap;
   bool dry;  // dry run: only measure
+  std::vector<std::pair<size_t, size_t>>* guards = nullptr;   // (offset, bytes), real runs
   Bump(void* b, size_t c, bool d) : base((char*)b), cap(c), dry(d) {}
   float* floats(size_t n) {
-    const size_t bytes = (n * sizeof(float) + 255) / 256 * 256;
+    size_t bytes = (n * sizeof(float) + 255) / 256 * 256;
+    if (workspace_guard_on()) {
+      bytes += 256;
+      if (guards) guards->push_back({used + n * sizeof(float), bytes - n * sizeof(float)});
+    }
     char* p = dry ? nullptr : base + used;
     used += bytes;
     return (float*)p;
@@ -159,6 +173,10 @@ struct scvae_plan {
   // are final and joined before the step ends
   const scvae_side_work* side = nullptr;
   hipStream_t side_stream = nullptr;
+  // SCVAE_WS_GUARD: the guard regions of the bound workspace, host and device copy, and the flag
+  std::vector<std::pair<size_t, size_t>> ws_guards;
+  size_t* ws_guards_dev = nullptr;
+  int* ws_guard_flag = nullptr;
   hipEvent_t side_fork = nullptr, side_join = nullptr;
   bool side_forked = false;
   bool side_jobs_done = false;  // fetch + noise issued

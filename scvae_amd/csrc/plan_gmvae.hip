@@ -86,6 +86,7 @@ size_t carve_gmvae(scvae_plan* p, void* base, size_t cap, int64_t cells, int64_t
                    bool dry) {
   const scvae_model_config& c = p->cfg;
   Bump b(base, cap, dry);
+  if (!dry && workspace_guard_on()) { p->ws_guards.clear(); b.guards = &p->ws_guards; }
   const size_t K = c.n_clusters, B = (size_t)cells, KB = K * B, R = K * B * samples;
   const size_t Lz = c.latent_size, F = c.feature_size;
   size_t hmax = Lz > K ? Lz : K;

@@ -315,3 +315,40 @@ def test_gemm_small_shape_sweep(cuda_device):
                 err = np.abs(Cd.cpu().double().numpy() - want).max()
                 assert err <= 1e-5 * max(1.0, np.abs(want).max()) * max(
                     1.0, np.sqrt(K)), (ta, tb, M, N, K, acc, err)
+
+
+def test_workspace_guard_mode_catches_a_write_past_a_buffer(cuda_device):
+    """``SCVAE_WS_GUARD=1`` (a debugging aid of the library, read once per
+    process): every buffer carved out of a plan's workspace is followed by a
+    guard region that ``scvae_plan_step`` checks after the step.  A clean step
+    passes; a byte changed in the last buffer's guard makes the next step fail
+    and name the mode."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import torch
+from scvae_amd import _lib
+from scvae_amd.engine import Engine
+dev = torch.device("cuda:0")
+eng = Engine(40, 3, (16, 12), "negative binomial", batch_norm=True, device=dev, seed=0, k_max=1,
+             dropout_keep_probabilities=(0.9, 0.9, 0.9))
+eng.reserve(24, 2)
+x = torch.poisson(torch.full((24, 40), 2.0, device=dev))
+eps = torch.randn(2, 24, 3, device=dev)
+for training in (True, False):
+    eng.step(x, x, eps=eps, training=training, n_iw=2, n_mc=1, dropout_seed=5)
+torch.cuda.synchronize()
+nbytes = eng.lib.scvae_plan_workspace_bytes(eng.handle, 24, 2)
+eng.workspace[nbytes - 1] = 0        # the last buffer's guard
+try:
+    eng.step(x, x, eps=eps, training=True, n_iw=2, n_mc=1, dropout_seed=5)
+except _lib.HipLibraryError as error:
+    assert "SCVAE_WS_GUARD" in str(error), str(error)
+    print("CAUGHT")
+"""
+    env = dict(os.environ, SCVAE_WS_GUARD="1",
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "CAUGHT" in out.stdout, out.stdout + out.stderr[-2000:]
