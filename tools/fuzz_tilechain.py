@@ -40,6 +40,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
             if not name.endswith("weights"):
                 p.copy_(torch.randn(p.shape, generator=g) * 0.1)
         eng.set_tile_chain(tile)
+        eng.set_dd_atomics(False)   # (the repeatability check below needs the fixed-order slabs)
         ll = torch.zeros(S * B, device=dev); qz = torch.zeros(B, L, device=dev)
         outs = {"log_p_x_given_z": ll, "q_z_mean": qz}
         m0 = eng.moving.clone()
@@ -64,4 +65,17 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
         if not np.isfinite(err) or err > 5e-5 * scale + 1e-9:
             bad += 1
             print("MISMATCH", name, err, scale, "B", B, "H", H, "L", L, "F", F, lk, n_iw, n_mc)
+            if name == "grads":
+                # which hidden units disagree: a ReLU kink shows as ONE unit of one layer (its beta)
+                # plus whatever lies below it; anything broader is a defect
+                units = []
+                for pname, (off, shape) in eng.param_table.items():
+                    k = int(np.prod(shape))
+                    if pname.endswith("BATCH_NORM/beta"):
+                        da = (a[off:off + k] - b[off:off + k]).abs()
+                        lim = 5e-5 * b[off:off + k].abs().max().item() + 1e-9
+                        hit = torch.nonzero(da > lim).flatten().tolist()
+                        if hit:
+                            units.append((pname.rsplit("/", 2)[0], hit))
+                print("    units whose beta gradient differs:", units)
 print("fuzz_tilechain: {} configurations, {} failures".format(n, bad))
