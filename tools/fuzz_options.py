@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Random sweep over the graph options against the fp64 oracle (not part of the test suite: run
-on a GPU box to hunt for option interactions).  Usage: python tools/fuzz_options.py [cases] [seed0]"""
+on a GPU box to hunt for option interactions).  Usage: python tools/fuzz_options.py [cases] [seed0]
+(FUZZ_B_RANGE="lo,hi": cells per step, default 3,30)"""
 import importlib.util
 import os
 import sys
@@ -18,6 +19,10 @@ spec = importlib.util.spec_from_file_location(
 helpers = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(helpers)
 
+# cells per step: FUZZ_B_RANGE="130,700" moves the sweep onto the kernels of large minibatches (the
+# producer / consumer head kernel, the tile chain)
+B_RANGE = tuple(int(v) for v in os.environ.get("FUZZ_B_RANGE", "3,30").split(","))
+
 COUNT = ["poisson", "negative binomial", "zero-inflated poisson",
          "zero-inflated negative binomial"]
 
@@ -34,7 +39,7 @@ def case(seed):
         gm=gm, likelihood=likelihood, k_max=k_max,
         F=int(rng.integers(4, 120)), L=int(rng.integers(1, 7)),
         H=tuple(int(2 * rng.integers(2, 16)) for _ in range(n_hidden)),
-        B=int(rng.integers(3, 30)), K=int(rng.integers(2, 4)) if gm else 1,
+        B=int(rng.integers(*B_RANGE)), K=int(rng.integers(2, 4)) if gm else 1,
         n_iw=int(rng.integers(1, 3)), n_mc=int(rng.integers(1, 3)),
         bn=bool(rng.integers(0, 2)), warm_up=float(rng.choice([1.0, 0.4])),
         extra=int(rng.choice([0, 0, 2])),
