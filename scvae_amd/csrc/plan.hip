@@ -818,9 +818,14 @@ int plan_side_fork(scvae_plan* p, hipStream_t s, int point) {
                               w->fetch_n >= 1024);   // (single process: never run beside RCCL's kernels)
   if (!on) return 0;
   // (SCVAE_SIDE_JOBS_AT: where the next fetch and its noise leave the step's stream -- 0 at the
-  //  start of the step, beside the input layer; 1 (default) after the head kernel, beside the
-  //  backward pass of the hidden layers)
-  static const int jobs_at = [] { const char* e = getenv("SCVAE_SIDE_JOBS_AT"); return e ? atoi(e) : 1; }();
+  //  start of the step, beside the input layer; 1 after the head kernel, beside the backward pass
+  //  of the hidden layers; 2 beside the input layer's weight gradient; 3 never (in line at the end).
+  //  Default: 2 from 4096 cells on, 1 below -- three alternations per minibatch size on one box
+  //  (tools/ab_side_jobs2.sh), 2 against 1: 1024 cells + 16 us, 2048 + 15-20 us, 4096 -13 / -13 /
+  //  + 15 us (a second run: -13 / -11 / -9), ZINB 4096 -31 / -11 / -6, Poisson 4096 -7 / -17 / -4,
+  //  16384 cells -64 / -190 / -170 us of 7.3 ms)
+  static const int jobs_env = [] { const char* e = getenv("SCVAE_SIDE_JOBS_AT"); return e ? atoi(e) : -1; }();
+  const int jobs_at = jobs_env >= 0 ? jobs_env : (w->fetch_n >= 4096 ? 2 : 1);
   const bool jobs = !p->side_jobs_done && (w->fetch_out || w->noise_out) && point >= jobs_at;
   // (VAE plans: the likelihood heads are the tail of the parameter buffer)
   const bool adam = w->adam_m && p->side_adam_from == p->layout.n_params &&
