@@ -82,6 +82,7 @@ def _loop(device, matrix, B, L, H, likelihood, model, u16, carried, steps=4):
 @pytest.mark.parametrize("B,H,L,likelihood,model,u16", [
     (100, (64, 48), 10, "negative binomial", "VAE", False),       # mid-chain kernels
     (1024, (100, 100), 25, "negative binomial", "VAE", True),      # tile chain, count kernels
+    (4096, (100, 100), 25, "negative binomial", "VAE", True),      # ... the fetch forks beside x^T dA
     (300, (32,), 8, "zero-inflated negative binomial", "VAE", False),
     (256, (48, 32), 6, "poisson", "VAE", True),
     (192, (40, 40), 8, "negative binomial", "GMVAE", True),
