@@ -384,6 +384,17 @@ def hbm_rooflines(work, matrix, rows):
                     "launches_timed": len(us), "achieved": nbytes / med * 1e-6,
                     "unit": "TB/s", "peak": PEAK_HBM_TBPS,
                     "frac": nbytes / med * 1e-6 / PEAK_HBM_TBPS, "bytes_counted": note})
+        # single-process VAE steps of 4096 cells and more run the carried fetch on the plan's
+        # second stream BESIDE the input layer's weight gradient (plan.hip, plan_side_fork): the
+        # step is shorter for it, each of the two lasts longer than it does alone
+        if (key in ("fetch", "count_gemm_dw") and rows >= 4096 and not work.gm
+                and work.world == 1 and os.environ.get("SCVAE_SIDE_STREAM", "") != "0"
+                and os.environ.get("SCVAE_SIDE_JOBS_AT", "2") == "2"):
+            out[-1]["co_runs_with"] = (
+                "count_gemm_dw_kernel" if key == "fetch" else "csr_densify_u16_kernel")
+            out[-1]["note"] = ("the two share the chip's bandwidth while they overlap: launch_us "
+                               "includes the other's traffic (alone: fetch 75-80 us, weight "
+                               "gradient 120 us with split + reduce)")
     return out
 
 
