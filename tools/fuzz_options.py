@@ -146,7 +146,13 @@ def run(c, seed, device):
         scale = max(np.abs(want).max(), 1e-30)
         err = np.abs(got - want).max() / scale
         if not err <= rtol and np.abs(got - want).max() > 1e-9:
-            problems.append("{}: {:.2e} of {:.2e}".format(what, err, scale))
+            where = ""
+            if what.endswith("BATCH_NORM/beta"):
+                # (a ReLU kink -- fp32 and fp64 put a normalised activation within an ulp of zero on
+                #  different sides -- shows as ONE unit of the topmost affected layer)
+                units = np.nonzero(np.abs(got - want) > rtol * scale)[0].tolist()
+                where = "  units " + str(units[:8]) + (" ..." if len(units) > 8 else "")
+            problems.append("{}: {:.2e} of {:.2e}{}".format(what, err, scale, where))
     if gm and c["free_nats"]:
         # the free-nats gate is a comparison: near the threshold fp32 and fp64 may disagree
         thr = c["free_nats"] * float(np.log(K))
