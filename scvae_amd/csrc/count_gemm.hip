@@ -51,8 +51,9 @@ constexpr int CG_KPAD = 64;           // the split operand is zero-padded to a m
 template <typename XT> __device__ __forceinline__ float count_to_f32(XT v) { return (float)v; }
 
 // A/B switch (tools/ab_cg_nt.sh, round 5: refuted): the requests for x marked non-temporal (bit 0:
-// forward product, bit 1: weight gradient).  Forward: + 15 us stand-alone, + 30 us in the step (x
-// no longer waits in the infinity cache for its later readers); weight gradient: +- 0.
+// forward product, bit 1: weight gradient).  Forward: + 15 us stand-alone, + 30 us in the step (a
+// chunk's request takes half of a 128-byte line, the next chunk the other half: the line no longer
+// waits in the L2 for it); weight gradient: +- 0.
 #ifndef SCVAE_CG_NT
 #define SCVAE_CG_NT 0
 #endif
