@@ -450,6 +450,14 @@ class Workload:
         else:
             self.x = [torch.empty(batch, F, device=device) for _ in range(2)]
         self.row_const = [torch.empty(batch, device=device) for _ in range(2)]
+        # ... and, opt-in (SCVAE_BENCH_COUNT_TILES=1), next to the uint16 batch its
+        # non-zeros in tile-indexed form (scvae_count_tiles): the input layer's two
+        # products read those instead of the dense batch -- same arithmetic, a
+        # tenth of the bytes; measured in round 6: no faster
+        self.use_tiles = bool(self.u16 and matrix.count_tiles_supported
+                              and os.environ.get("SCVAE_BENCH_COUNT_TILES") == "1")
+        self.tiles = [matrix.count_tiles(batch) if self.use_tiles else None
+                      for _ in range(2)]
         self.eps = [torch.empty(self.K, batch, latent, device=device)
                     for _ in range(2)]
         self.generator = torch.Generator(device=device).manual_seed(2)
@@ -487,14 +495,14 @@ class Workload:
         cur = self.slot
         if not self.primed:
             self.matrix.request(self._next_rows(), self.x[cur],
-                                self.row_const[cur]).issue()
+                                self.row_const[cur], tiles=self.tiles[cur]).issue()
             philox_normal_blocks(self.eps[cur], block_stride=GB,
                                  row_offset=rank * B, seed=1,
                                  stream_id=self.step_counter)
             self.primed = True
         nxt = cur ^ 1
         request = self.matrix.request(self._next_rows(), self.x[nxt],
-                                      self.row_const[nxt])
+                                      self.row_const[nxt], tiles=self.tiles[nxt])
         self.step_counter += 1
         self.engine.step(self.x[cur], self.x[cur], eps=self.eps[cur],
                          row_const=self.row_const[cur], training=True,
@@ -502,7 +510,8 @@ class Workload:
                          x_counts=self.matrix.integer_counts,
                          learning_rate=1e-4 if self.sync is None else None,
                          next_minibatch=request,
-                         next_noise=self._noise(nxt, self.step_counter))
+                         next_noise=self._noise(nxt, self.step_counter),
+                         count_tiles=self.tiles[cur])
         if self.sync is not None:
             self.sync.all_reduce_gradients(events=comm_events)
             self.engine.adam_step(1e-4)

@@ -236,6 +236,30 @@ int scvae_plan_set_mid_chain(scvae_plan* plan, int32_t enabled);
  * finite: a caller that keeps passing the same buffer gets a sticky counter of non-finite
  * steps.  (The reference tests the loss at the steps it prints, va:1034-1044; with the counter
  * the same test at the same steps also catches a non-finite loss of any step in between.) */
+/* ---- the minibatch as tile-indexed non-zeros (optional: scvae_step_args.count_tiles) ----
+ * A count minibatch is ~5 % non-zeros (x_train[idx].toarray() of va:997-998 is 95 % zeros): next
+ * to its uint16 form the fetch can leave the list of its non-zeros, grouped so that the two
+ * products of the input layer (mu:53-59: x W + b and its weight gradient x^T dA) build their
+ * operand tiles in LDS from (position, value) pairs instead of streaming the dense batch.
+ * Group g holds minibatch rows 16 g .. 16 g + 15; the genes are cut into tiles of 32, 16 tiles
+ * make a block of 512.  T = scvae_count_tiles_padded(F) tiles per group (a multiple of 16).
+ *   entries[tile_ptr[g][t] & 0x7FFFFFFF .. tile_ptr[g][t + 1] & 0x7FFFFFFF)  bucket (g, t),
+ *     tiles ascending, so block b of group g is the run block_ptr[g][b] .. block_ptr[g][b + 1];
+ *   entry = value << 16 | lo << 13 | (tile & 15) << 9 | (row & 15) << 5 | (gene & 31);
+ *   a count of up to 8 significant bits is one entry (lo = 0); a larger one is two: its upper 8
+ *   significant bits (lo = 0) and the remainder (lo = 1) -- the exact bf16 cut of the dense
+ *   kernels; bit 31 of a pointer: that bucket / block holds lo entries.
+ * Group g owns entries[g * capacity .. (g + 1) * capacity); capacity >= 16 x the largest
+ * scvae_csr_row_entries value of the matrix never overflows (status, optional device word: bit 0
+ * is set if a group did -- that group is then left empty).  groups * capacity < 2^31. */
+typedef struct scvae_count_tiles {
+  uint32_t* entries;   /* [groups][capacity] */
+  uint32_t* tile_ptr;  /* [groups][T + 1] */
+  uint32_t* block_ptr; /* [groups][T / 16 + 1] */
+  int64_t capacity;    /* entries per group of 16 rows */
+  int32_t* status;     /* optional */
+} scvae_count_tiles;
+
 /* ---- work a step carries along (optional: scvae_step_args.side) ----
  * The reference's loop is fetch -> session.run(optimiser) -> fetch -> ... (va:985-1013): four
  * calls per step through this ABI (minibatch, noise, step, optimiser).  A step may carry its own
@@ -270,6 +294,9 @@ typedef struct scvae_side_work {
   int64_t fetch_ld;
   const float* fetch_row_values;
   float* fetch_row_values_out;
+  /* optional: the same rows also as tile-indexed non-zeros (scvae_csr_count_tiles); integer
+   * count matrices only */
+  const scvae_count_tiles* fetch_tiles;
   /* the next step's noise: the arguments of scvae_philox_normal_blocks; noise_out == NULL: none */
   float* noise_out;
   int64_t noise_blocks;
@@ -332,6 +359,11 @@ typedef struct scvae_step_args {
    * anything else is refused with an error. */
   const uint16_t* counts_u16;
   int64_t counts_ld;
+  /* Optional, with counts_u16: the same minibatch as tile-indexed non-zeros
+   * (scvae_csr_count_tiles of the same rows).  The input layer's two products then read it
+   * instead of the dense batch -- same MFMAs on the same operand tiles in the same order:
+   * bit-identical to the step without it, a tenth of the bytes through the fabric. */
+  const scvae_count_tiles* count_tiles;
   /* optional: optimiser update of this step / fetch and noise of the next one (see above) */
   const scvae_side_work* side;
 } scvae_step_args;
@@ -493,6 +525,24 @@ int scvae_csr_densify_u16(const int64_t* indptr, const int32_t* indices, const f
                           void* stream);
 int scvae_csr_row_lgamma1p(const int64_t* indptr, const float* values, int64_t n_rows, float* out,
                            void* stream);
+/* tiles per group of a scvae_count_tiles over F genes: ceil(F / 512) * 16 (F <= 65 536) */
+int64_t scvae_count_tiles_padded(int64_t F);
+/* out[r] = entries row r contributes to a scvae_count_tiles: its non-zeros, plus one for every
+ * count of more than 8 significant bits with a non-zero remainder (int32 per row) */
+int scvae_csr_row_entries(const int64_t* indptr, const float* values, int64_t n_rows, int32_t* out,
+                          void* stream);
+/* the minibatch `rows` of an integer count matrix (values in [0, 65536): scvae_check_counts) as
+ * tile-indexed non-zeros; one launch, a workgroup per group of 16 rows */
+int scvae_csr_count_tiles(const int64_t* indptr, const int32_t* indices, const float* values,
+                          const int64_t* rows, int64_t n, int64_t F,
+                          const scvae_count_tiles* tiles, void* stream);
+/* scvae_count_gemm_u16 with the contraction read from `tiles` (the same rows); x, the uint16
+ * batch, is read only for the leftover terms of the contraction (cols % 32 genes in mode 0,
+ * rows % 16 cells in mode 1) and may be NULL when there are none.  Bit-identical results. */
+int scvae_count_gemm_tiles(int32_t mode, const scvae_count_tiles* tiles, const uint16_t* x,
+                           int64_t ldx, int64_t rows, int64_t cols, const float* other,
+                           int64_t ld_other, int64_t N, const float* bias, int32_t relu, float* C,
+                           int64_t ldc, void* workspace, int64_t workspace_bytes, void* stream);
 int scvae_gather_rows(const float* src, const int64_t* rows, int64_t n, float* out, void* stream);
 /* q.sample() noise: Philox4x32-10 + Box-Muller keyed by (seed, stream_id, row_offset+row, col):
  * key = (seed_lo, seed_hi ^ stream_id_hi), counter = (row_lo, row_hi, col / 4, stream_id_lo) */

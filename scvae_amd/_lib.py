@@ -85,7 +85,19 @@ class StepArgs(Structure):
         ("x_counts", c_int32),
         ("counts_u16", c_void_p),
         ("counts_ld", c_int64),
+        ("count_tiles", c_void_p),
         ("side", c_void_p),
+    ]
+
+
+class CountTilesStruct(Structure):
+    """``scvae_count_tiles``: a minibatch as tile-indexed non-zeros."""
+    _fields_ = [
+        ("entries", c_void_p),
+        ("tile_ptr", c_void_p),
+        ("block_ptr", c_void_p),
+        ("capacity", c_int64),
+        ("status", c_void_p),
     ]
 
 
@@ -111,6 +123,7 @@ class SideWork(Structure):
         ("fetch_ld", c_int64),
         ("fetch_row_values", c_void_p),
         ("fetch_row_values_out", c_void_p),
+        ("fetch_tiles", c_void_p),
         ("noise_out", c_void_p),
         ("noise_blocks", c_int64),
         ("noise_block_rows", c_int64),
@@ -225,6 +238,16 @@ SIGNATURES = {
     "scvae_csr_densify": (c_int32, [
         c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
         c_void_p]),
+    "scvae_count_tiles_padded": (c_int64, [c_int64]),
+    "scvae_csr_row_entries": (c_int32, [
+        c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "scvae_csr_count_tiles": (c_int32, [
+        c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+        POINTER(CountTilesStruct), c_void_p]),
+    "scvae_count_gemm_tiles": (c_int32, [
+        c_int32, POINTER(CountTilesStruct), c_void_p, c_int64, c_int64,
+        c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int32, c_void_p,
+        c_int64, c_void_p, c_int64, c_void_p]),
     "scvae_csr_row_lgamma1p": (c_int32, [
         c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "scvae_gather_rows": (c_int32, [

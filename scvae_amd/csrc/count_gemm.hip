@@ -762,6 +762,730 @@ int count_gemm_u16(hipStream_t stream, int mode, const uint16_t* x, int ldx, int
                                    C, ldc, workspace, workspace_bytes);
 }
 
+// ====================== the minibatch as tile-indexed non-zeros ======================
+// A count minibatch is ~5 % non-zeros; densified to uint16 it is 268 MB at 4096 x 32 738 of which
+// the two products above use 27 MB.  CountTiles is the same minibatch as a list of its non-zeros
+// grouped by (16 cells, 32 genes): for group g of 16 consecutive minibatch rows the entries of
+// gene tile t are entries[tile_ptr[g][t] .. tile_ptr[g][t + 1]) -- in no particular order within
+// the bucket --, tiles ascending, so that 16 tiles (a block of 512 genes) are one contiguous run
+// block_ptr[g][b] .. block_ptr[g][b + 1].  An entry is
+//     value << 16 | lo << 13 | (tile & 15) << 9 | row << 5 | gene & 31
+// with value the count cut as the dense kernels cut it: a count of up to 8 significant bits is
+// one entry; a larger one is two, its upper 8 significant bits (lo = 0) and the remainder
+// (lo = 1), both exact in bf16.  Bit 31 of a pointer says that the bucket (the block) holds lo
+// entries.  The sparse kernels below scatter a bucket into the zeroed LDS tile the dense kernels
+// fill from the uint16 batch and run the same MFMAs on it in the same order: bit-identical
+// results, a tenth of the bytes.
+constexpr int CT_ROWS = 16, CT_GENES = 32, CT_BLOCK = 16;
+constexpr unsigned CT_LO = 0x80000000u, CT_MASK = 0x7FFFFFFFu;
+constexpr int CT_MAX_TILES = 2048;            // F <= 65 536
+
+int count_tiles_padded(int F) { return (F + 511) / 512 * CT_BLOCK; }
+bool count_tiles_supported(int F) { return F > 0 && F <= CT_MAX_TILES * CT_GENES; }
+
+// hi / lo cut of an integer count below 65 536 (the fp32 bit pattern truncated to 16 bits)
+__device__ __forceinline__ void ct_cut(unsigned v, unsigned& hi, unsigned& lo) {
+  const int nb = 32 - __builtin_clz(v | 1u);
+  const int sh = nb > 8 ? nb - 8 : 0;
+  hi = (v >> sh) << sh;
+  lo = v - hi;
+}
+
+// One workgroup per group of 16 rows (a wave per row): count the entries of every tile, scan,
+// place.  Rows of one group land in the group's own region [g * cap, (g + 1) * cap) of `ent`, so
+// no workgroup waits for another.
+__global__ __launch_bounds__(1024) void csr_count_tiles_kernel(
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const float* __restrict__ values, const int64_t* __restrict__ rows, int n, int F, int ntp,
+    uint32_t* __restrict__ ent, long cap, uint32_t* __restrict__ tptr, uint32_t* __restrict__ gptr,
+    int* __restrict__ status) {
+  __shared__ unsigned cnt[CT_MAX_TILES], flag[CT_MAX_TILES], off[CT_MAX_TILES + 1], wtot[16];
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int i = tid; i < ntp; i += 1024) { cnt[i] = 0u; flag[i] = 0u; }
+  __syncthreads();
+  const int b = g * CT_ROWS + w;
+  int64_t lo_j = 0, hi_j = 0;
+  if (b < n) { const int64_t r = rows[b]; lo_j = indptr[r]; hi_j = indptr[r + 1]; }
+  // (four strides of the row per trip: eight loads in flight per lane)
+  for (int64_t j0 = lo_j + lane; j0 < hi_j; j0 += 256) {
+    int c[4]; float fv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t j = j0 + 64 * u;
+      c[u] = j < hi_j ? indices[j] : -1;
+      fv[u] = j < hi_j ? values[j] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned v = (unsigned)(int)fv[u];
+      if (c[u] < 0 || c[u] >= F || v == 0u) continue;
+      unsigned h, l;
+      ct_cut(v & 0xFFFFu, h, l);
+      atomicAdd(&cnt[c[u] >> 5], l ? 2u : 1u);
+      if (l) flag[c[u] >> 5] = 1u;
+    }
+  }
+  __syncthreads();
+  {   // exclusive scan of cnt[0 .. ntp): two tiles per thread
+    const unsigned a = 2 * tid < ntp ? cnt[2 * tid] : 0u;
+    const unsigned c2 = 2 * tid + 1 < ntp ? cnt[2 * tid + 1] : 0u;
+    unsigned s = a + c2, incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wtot[w] = incl;
+    __syncthreads();
+    unsigned base = 0u;
+    for (int i = 0; i < w; ++i) base += wtot[i];
+    const unsigned ex = base + incl - s;
+    if (2 * tid < ntp) off[2 * tid] = ex;
+    if (2 * tid + 1 < ntp) off[2 * tid + 1] = ex + a;
+    if (tid == 1023) off[ntp] = base + incl;      // (tiles beyond ntp count zero)
+  }
+  __syncthreads();
+  const unsigned total = off[ntp];
+  const bool fits = (long)total <= cap;
+  if (!fits && tid == 0 && status) atomicOr(status, 1);
+  const unsigned gbase = (unsigned)((long)g * cap);
+  const int ngb = ntp / CT_BLOCK;
+  for (int i = tid; i <= ntp; i += 1024) {
+    const unsigned o = fits ? off[i] : 0u;       // (an overflowing group: empty, flagged)
+    tptr[(size_t)g * (ntp + 1) + i] = (gbase + o) | ((i < ntp && fits && flag[i]) ? CT_LO : 0u);
+  }
+  for (int i = tid; i <= ngb; i += 1024) {
+    unsigned f = 0u;
+    if (i < ngb && fits)
+      for (int k = 0; k < CT_BLOCK; ++k) f |= flag[i * CT_BLOCK + k];
+    gptr[(size_t)g * (ngb + 1) + i] = (gbase + (fits ? off[i * CT_BLOCK] : 0u)) | (f ? CT_LO : 0u);
+  }
+  if (!fits) return;
+  __syncthreads();
+  for (int i = tid; i < ntp; i += 1024) cnt[i] = 0u;
+  __syncthreads();
+  for (int64_t j0 = lo_j + lane; j0 < hi_j; j0 += 256) {
+    int c[4]; float fv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t j = j0 + 64 * u;
+      c[u] = j < hi_j ? indices[j] : -1;
+      fv[u] = j < hi_j ? values[j] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned v = (unsigned)(int)fv[u];
+      if (c[u] < 0 || c[u] >= F || v == 0u) continue;
+      unsigned h, l;
+      ct_cut(v & 0xFFFFu, h, l);
+      const int t = c[u] >> 5;
+      const unsigned slot = atomicAdd(&cnt[t], l ? 2u : 1u);
+      const unsigned key = ((unsigned)(t & 15) << 9) | ((unsigned)w << 5) | (unsigned)(c[u] & 31);
+      uint32_t* dst = ent + gbase + off[t] + slot;
+      dst[0] = (h << 16) | key;
+      if (l) dst[1] = (l << 16) | (1u << 13) | key;
+    }
+  }
+}
+
+// per row: entries it contributes (non-zeros + one more per count above 8 significant bits whose
+// remainder is not zero) -- the caller sizes CountTiles.cap as 16 x the maximum over the matrix
+__global__ __launch_bounds__(256) void csr_row_entries_kernel(const int64_t* __restrict__ indptr,
+                                                             const float* __restrict__ values,
+                                                             int64_t n_rows,
+                                                             int32_t* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const int lane = threadIdx.x & 63;
+  int s = 0;
+  for (int64_t j = indptr[r] + lane; j < indptr[r + 1]; j += 64) {
+    const unsigned v = (unsigned)(int)values[j] & 0xFFFFu;
+    unsigned h, l;
+    ct_cut(v, h, l);
+    s += v ? (l ? 2 : 1) : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) out[r] = s;
+}
+
+int csr_row_entries(hipStream_t stream, const int64_t* indptr, const float* values, int64_t n_rows,
+                    int32_t* out) {
+  SCVAE_ARG(indptr && values && out);
+  if (n_rows == 0) return 0;
+  hipLaunchKernelGGL(csr_row_entries_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0,
+                     stream, indptr, values, n_rows, out);
+  SCVAE_LAUNCH_CHECK("csr_row_entries_kernel");
+  return 0;
+}
+
+int csr_count_tiles(hipStream_t stream, const int64_t* indptr, const int32_t* indices,
+                    const float* values, const int64_t* rows, int B, int F, CountTiles t) {
+  SCVAE_ARG(indptr && indices && values && rows && t.ent && t.tptr && t.gptr);
+  SCVAE_ARG(count_tiles_supported(F) && t.cap > 0 && B >= 0);
+  const long groups = (B + CT_ROWS - 1) / CT_ROWS;
+  SCVAE_ARG(groups * t.cap < (1L << 31));
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(csr_count_tiles_kernel, dim3((unsigned)groups), dim3(1024), 0, stream, indptr,
+                     indices, values, rows, B, F, count_tiles_padded(F), t.ent, (long)t.cap,
+                     t.tptr, t.gptr, t.status);
+  SCVAE_LAUNCH_CHECK("csr_count_tiles_kernel");
+  return 0;
+}
+
+// entry -> bf16 bits of its value (at most 8 significant bits: the conversion is exact)
+__device__ __forceinline__ unsigned ct_bf16(unsigned e) {
+  return __float_as_uint((float)(e >> 16)) >> 16;
+}
+
+// ---- forward from tiles: count_gemm_fwd_kernel with the [256, 32] tile of x scattered into LDS
+// from its non-zeros (16 buckets: one per group of 16 rows, 32 lanes each) instead of copied from
+// the dense batch.  With the bytes gone the dense kernel's rhythm -- every wave stages, then every
+// wave multiplies -- leaves the matrix pipe idle while the tile is built (measured: 122 us for 50
+// us of MFMA at 4096 x 32 738).  Here the hi plane has THREE buffers -- chunk j is multiplied
+// from buffer j % 3 while chunk j + 1 is scattered into the next (zeroed one iteration earlier)
+// and the third is zeroed -- so one barrier per chunk suffices, and the two waves of a SIMD run
+// the iteration in opposite order: waves 0-3 stage first and multiply second, waves 4-7 multiply
+// first.  The lo plane (counts above 8 significant bits: 0.02 % of the entries, 8 % of the
+// chunks) has one buffer, filled at the start of its chunk's own iteration behind an extra
+// barrier.  Entries travel two chunks ahead (three loads per lane: 96 entries per bucket, more
+// take a direct loop), pointers three.  Same MFMAs on the same operands in the same order as the
+// dense kernel: bit-identical.
+constexpr int CTF_NE = 3;
+
+static size_t ctf_lds_bytes(int NQ) {
+  return 4 * (size_t)CF_A_BYTES + 2 * (size_t)(3 * 64 * NQ * CG_ROW) + 3 * 8 * sizeof(int);
+}
+
+template <int NQ>
+__global__ __launch_bounds__(512) void count_tiles_fwd_kernel(
+    const uint32_t* __restrict__ ent, const uint32_t* __restrict__ tptr, int ntp, int n_groups,
+    int M, int K, const uint16_t* __restrict__ T, int Kpad, int N, int k_chunk,
+    float* __restrict__ out, int ldo, const float* __restrict__ bias, int act, int direct,
+    int dbg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cf_smem[];
+  constexpr int NCOL = 64 * NQ;
+  constexpr int B_BYTES = 3 * NCOL * CG_ROW;
+  unsigned char* Ahi = cf_smem;                         // [3][256][80]
+  unsigned char* Alo = Ahi + 3 * CF_A_BYTES;            // [256][80]
+  unsigned char* Bsm = Alo + CF_A_BYTES;                // [2][3][NCOL][80]
+  int* lo_flag = reinterpret_cast<int*>(Bsm + 2 * B_BYTES);   // [3][8]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kg = lane >> 5;
+  const int rg = w & 3, q0 = (w >> 2) * NQ;
+  const int m0 = blockIdx.x * CF_BM;
+  const int k_begin = blockIdx.y * k_chunk;
+  const int k_end = min(K, k_begin + k_chunk);
+  const int k_last = k_end - CG_BK;
+
+  f32x16 acc[2][NQ];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][q][i] = 0.f;
+
+  // this thread's bucket: group grp of the block's 16, lane gl of its 32
+  const int grp = tid >> 5, gl = tid & 31;
+  const int cc = blockIdx.x * (CF_BM / CT_ROWS) + grp;
+  const bool live = cc < n_groups;
+  const uint32_t* tp = tptr + (size_t)(live ? cc : 0) * (ntp + 1);
+  const int a_row = (CT_ROWS * grp) * CG_ROW;
+
+  auto zero_plane = [&](unsigned char* plane) {
+    u32x4* z = reinterpret_cast<u32x4*>(plane);
+    z[tid] = u32x4{0u, 0u, 0u, 0u};
+    z[tid + 512] = u32x4{0u, 0u, 0u, 0u};
+    if (tid < CF_A_BYTES / 16 - 1024) z[tid + 1024] = u32x4{0u, 0u, 0u, 0u};
+  };
+  for (int i = tid; i < 4 * CF_A_BYTES / 16; i += 512)
+    reinterpret_cast<u32x4*>(Ahi)[i] = u32x4{0u, 0u, 0u, 0u};
+
+  // pointers of a chunk (clamped to the split's last: unconditional loads)
+  struct Ptr { unsigned s, e; };
+  auto load_ptr = [&](int kc) {
+    const int t = min(kc, k_last) / CG_BK;
+    Ptr p; p.s = tp[t]; p.e = tp[t + 1];
+    return p;
+  };
+  unsigned E[2][CTF_NE];
+  unsigned Es[2], En[2];           // first entry / number of entries (| CT_LO) of the slot's bucket
+  u32x4 breg[2][3];
+  auto load_chunk = [&](int kc, Ptr p, auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    const unsigned s = p.s & CT_MASK, e = p.e & CT_MASK;
+    const unsigned n = (live && kc < k_end) ? e - s : 0u;
+    Es[SLOT] = s; En[SLOT] = n | (((p.s & CT_LO) && n) ? CT_LO : 0u);
+#pragma unroll
+    for (int k = 0; k < CTF_NE; ++k) {
+      const unsigned i = gl + 32 * k;
+      E[SLOT][k] = ent[i < n ? s + i : 0u];
+    }
+    const int kb = min(kc, k_last);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int p2 = tid + 512 * i;                     // (term, column, quarter)
+      const int row = p2 >> 2, prt = p2 & 3;
+      const int col = row & (CG_NP - 1), rowl = col < N ? row : row - col + (N - 1);
+      if (col < NCOL)
+        breg[SLOT][i] = *reinterpret_cast<const u32x4*>(T + (size_t)rowl * Kpad + kb + prt * 8);
+    }
+  };
+  auto put = [&](unsigned e, unsigned char* plane) {
+    *reinterpret_cast<uint16_t*>(plane + a_row + ((e >> 5) & 15u) * CG_ROW + (e & 31u) * 2) =
+        (uint16_t)ct_bf16(e);
+  };
+  // scatter the hi (LO = false) or lo entries of the slot's bucket into `plane`
+  auto scatter = [&](unsigned char* plane, auto slot_tag, bool want_lo) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    const unsigned n = En[SLOT] & CT_MASK;
+#pragma unroll
+    for (int k = 0; k < CTF_NE; ++k)
+      if (gl + 32u * k < n && (((E[SLOT][k] >> 13) & 1u) != 0u) == want_lo) put(E[SLOT][k], plane);
+    if (n > 32u * CTF_NE)
+      for (unsigned i = gl + 32u * CTF_NE; i < n; i += 32u) {
+        const unsigned e = ent[Es[SLOT] + i];
+        if ((((e >> 13) & 1u) != 0u) == want_lo) put(e, plane);
+      }
+  };
+  auto store_b = [&](int buf, auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int p2 = tid + 512 * i;
+      const int row = p2 >> 2, prt = p2 & 3;
+      const int term = row >> 7, col = row & (CG_NP - 1);
+      if (col < NCOL)
+        *reinterpret_cast<u32x4*>(Bsm + buf * B_BYTES + (term * NCOL + col) * CG_ROW + prt * 16) =
+            breg[SLOT][i];
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  Ptr pn = Ptr{0u, 0u};
+  __syncthreads();                                      // planes zeroed
+  if (k_begin < k_end) {
+    load_chunk(k_begin, load_ptr(k_begin), S0{});
+    load_chunk(k_begin + CG_BK, load_ptr(k_begin + CG_BK), S1{});
+    pn = load_ptr(k_begin + 2 * CG_BK);
+    scatter(Ahi, S0{}, false);
+    {
+      const bool need = __builtin_amdgcn_readfirstlane(__any((int)((En[0] & CT_LO) != 0u)));
+      if (lane == 0) lo_flag[w] = need ? 1 : 0;
+    }
+    store_b(0, S0{});
+  }
+  __syncthreads();
+
+  const int a_frag = (64 * rg + li) * CG_ROW + 32 * kg;      // + 32 rows * t, + 16 s
+  const int b_frag = (q0 * 32 + li) * CG_ROW + 32 * kg;      // + term * NCOL rows, + 32 rows * q
+  bool lo_dirty = false;                                // the lo plane holds entries
+  int ab = 0;                                           // hi buffer of the current chunk (j % 3)
+  auto chunk = [&](int kc, auto buf_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;       // B buffer / register slot of chunk j
+    using Other = std::integral_constant<int, BUF ^ 1>;
+    const int ab1 = ab == 2 ? 0 : ab + 1, ab2 = ab1 == 2 ? 0 : ab1 + 1;
+    const bool need_lo =
+        __builtin_amdgcn_readfirstlane(__any(lo_flag[ab * 8 + (lane & 7)]));
+    // ---- counts above 8 significant bits in this chunk (rare): the lo plane, behind barriers of
+    //      its own -- the entries of chunk j are still in slot BUF ----
+    if (lo_dirty || need_lo) {
+      if (lo_dirty) { zero_plane(Alo); lds_barrier(); }
+      if (need_lo) { scatter(Alo, buf_tag, true); lds_barrier(); }
+      lo_dirty = need_lo;
+    }
+    auto stage = [&]() {
+      // buffer j + 2 (chunk j - 1, multiplied before the last barrier): zeroed for chunk j + 2
+      if (!(dbg & 8)) zero_plane(Ahi + ab2 * CF_A_BYTES);
+      // chunk j + 2 -> slot BUF (chunk j has left it); pointers of j + 3
+      {
+        const Ptr p = pn;
+        pn = load_ptr(kc + 3 * CG_BK);
+        load_chunk(kc + 2 * CG_BK, p, buf_tag);
+      }
+      // chunk j + 1 (slot BUF ^ 1, requested an iteration ago) -> buffer j + 1, zeroed an
+      // iteration ago; its dA / W planes -> B buffer BUF ^ 1 (read by chunk j - 1)
+      if (!(dbg & 4)) scatter(Ahi + ab1 * CF_A_BYTES, Other{}, false);
+      {
+        const bool need =
+            __builtin_amdgcn_readfirstlane(__any((int)((En[BUF ^ 1] & CT_LO) != 0u)));
+        if (lane == 0) lo_flag[ab1 * 8 + w] = need ? 1 : 0;
+      }
+      store_b(BUF ^ 1, Other{});
+    };
+    auto multiply = [&]() {
+      if (dbg & 2) return;
+      const unsigned char* ah = Ahi + ab * CF_A_BYTES + a_frag;
+      const unsigned char* al = Alo + a_frag;
+      const unsigned char* bb = Bsm + BUF * B_BYTES + b_frag;
+      // every fragment of the chunk requested up front (16 ds_read_b128 in flight, counted
+      // waits): with the reads issued next to their MFMAs the pipe drained at every pair
+      // (measured: 41 % of the wave cycles parked at s_waitcnt for 44 % matrix-pipe time)
+      bf16x8 fh[2][2], fl[2][2], fb[2][3][NQ];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          fh[s][t] = as_bf16x8(*reinterpret_cast<const u32x4*>(ah + t * 32 * CG_ROW + 16 * s));
+#pragma unroll
+        for (int term = 2; term >= 0; --term)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            fb[s][term][q] = as_bf16x8(*reinterpret_cast<const u32x4*>(
+                bb + (term * NCOL + q * 32) * CG_ROW + 16 * s));
+      }
+      if (need_lo) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            fl[s][t] = as_bf16x8(*reinterpret_cast<const u32x4*>(al + t * 32 * CG_ROW + 16 * s));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int term = 2; term >= 0; --term) {           // smallest term first
+          if (need_lo) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+              acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s][0], fb[s][term][q], acc[0][q], 0, 0, 0);
+              acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s][1], fb[s][term][q], acc[1][q], 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s][0], fb[s][term][q], acc[0][q], 0, 0, 0);
+            acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s][1], fb[s][term][q], acc[1][q], 0, 0, 0);
+          }
+        }
+      }
+    };
+    stage();
+    __builtin_amdgcn_sched_barrier(0);
+    multiply();
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+    ab = ab1;
+  };
+  for (int kc = k_begin; kc < k_end; kc += 2 * CG_BK) {
+    chunk(kc, S0{});
+    if (kc + CG_BK < k_end) chunk(kc + CG_BK, S1{});
+  }
+
+  float* dst = direct ? out : out + (size_t)blockIdx.y * M * ldo;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int col = (q0 + q) * 32 + li;
+      if (col >= N) continue;
+      const float bv = (direct && bias != nullptr) ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 64 * rg + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (m < M) {
+          float v = acc[t][q][r] + bv;
+          if (direct && act == ACT_RELU) v = fmaxf(v, 0.f);
+          dst[(size_t)m * ldo + col] = v;
+        }
+      }
+    }
+}
+
+// ---- weight gradient from tiles: the [512 genes, 16 cells] operand of a chunk scattered into
+// LDS from one contiguous run of entries (the 16 buckets of gene block x group), eight waves of
+// 64 genes; dA planes as in count_gemm_dw_kernel.  Three hi buffers, one lo buffer, one barrier
+// per chunk, the two waves of a SIMD in opposite order -- as in the forward kernel above.
+constexpr int CTD_NE = 2;
+constexpr int CTD_A_BYTES = 512 * CD_ROW;
+
+template <int NT>
+__global__ __launch_bounds__(512, 1) void count_tiles_dw_kernel(
+    const uint32_t* __restrict__ ent, const uint32_t* __restrict__ gptr, int ngb, int M, int K,
+    const uint16_t* __restrict__ T, int Kpad, int N, int k_chunk, float* __restrict__ out,
+    int ldo, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cd_smem[];
+  constexpr int B_BYTES = 3 * CG_NP * CD_ROW;
+  unsigned char* Ahi = cd_smem;                         // [3][512][48]
+  unsigned char* Alo = Ahi + 3 * CTD_A_BYTES;           // [512][48]
+  unsigned char* Bs = Alo + CTD_A_BYTES;                // [2][3][128][48]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kg = lane >> 5;
+  const int gb = blockIdx.x;
+  const int m_w = gb * 512 + w * CG_TM;
+  const int k_begin = blockIdx.y * k_chunk;
+  const int k_end = min(K, k_begin + k_chunk);
+  const int k_last = k_end - CD_BK;
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][q][i] = 0.f;
+
+  for (int i = tid; i < 4 * CTD_A_BYTES / 16; i += 512)
+    reinterpret_cast<u32x4*>(Ahi)[i] = u32x4{0u, 0u, 0u, 0u};
+  auto zero_plane = [&](unsigned char* plane) {
+    u32x4* z = reinterpret_cast<u32x4*>(plane);
+#pragma unroll
+    for (int i = 0; i < CTD_A_BYTES / 16 / 512; ++i) z[tid + 512 * i] = u32x4{0u, 0u, 0u, 0u};
+  };
+  struct Ptr { unsigned s, e; };
+  auto load_ptr = [&](int kc) {
+    const uint32_t* gp = gptr + (size_t)(min(kc, k_last) / CD_BK) * (ngb + 1) + gb;   // uniform
+    Ptr p; p.s = gp[0]; p.e = gp[1];
+    return p;
+  };
+  constexpr int NPC = 2;                                // 768 pieces of dA over 512 threads
+  unsigned E[2][CTD_NE];
+  unsigned Es[2], En[2];
+  u32x4 breg[2][NPC];
+  auto load_chunk = [&](int kc, Ptr p, auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    const unsigned s = p.s & CT_MASK, e = p.e & CT_MASK;
+    const unsigned n = kc < k_end ? e - s : 0u;
+    Es[SLOT] = s; En[SLOT] = n | (((p.s & CT_LO) && n) ? CT_LO : 0u);
+#pragma unroll
+    for (int k = 0; k < CTD_NE; ++k) {
+      const unsigned i = tid + 512 * k;
+      E[SLOT][k] = ent[i < n ? s + i : 0u];
+    }
+    const int kb = min(kc, k_last);
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int p2 = tid + 512 * i;                // 768 pieces: (term, column, half)
+      const int row = p2 >> 1, part = p2 & 1;
+      const int col = row & (CG_NP - 1), rowl = col < N ? row : row - col + (N - 1);
+      if (p2 < 768 && col < NT * 32)
+        breg[SLOT][i] = *reinterpret_cast<const u32x4*>(T + (size_t)rowl * Kpad + kb + part * 8);
+    }
+  };
+  auto put = [&](unsigned e, unsigned char* plane) {
+    const unsigned gene = ((e >> 9) & 15u) * 32u + (e & 31u);
+    *reinterpret_cast<uint16_t*>(plane + gene * CD_ROW + ((e >> 5) & 15u) * 2) =
+        (uint16_t)ct_bf16(e);
+  };
+  auto scatter = [&](unsigned char* plane, auto slot_tag, bool want_lo) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    const unsigned n = En[SLOT] & CT_MASK;
+#pragma unroll
+    for (int k = 0; k < CTD_NE; ++k)
+      if (tid + 512u * k < n && (((E[SLOT][k] >> 13) & 1u) != 0u) == want_lo)
+        put(E[SLOT][k], plane);
+    if (n > 512u * CTD_NE)
+      for (unsigned i = tid + 512u * CTD_NE; i < n; i += 512u) {
+        const unsigned e = ent[Es[SLOT] + i];
+        if ((((e >> 13) & 1u) != 0u) == want_lo) put(e, plane);
+      }
+  };
+  auto store_b = [&](int buf, auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int p2 = tid + 512 * i;
+      const int row = p2 >> 1, part = p2 & 1;
+      if (p2 < 768 && (row & (CG_NP - 1)) < NT * 32)
+        *reinterpret_cast<u32x4*>(&Bs[buf * B_BYTES + row * CD_ROW + part * 16]) = breg[SLOT][i];
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  Ptr pn = Ptr{0u, 0u};
+  __syncthreads();
+  if (k_begin < k_end) {
+    load_chunk(k_begin, load_ptr(k_begin), S0{});
+    load_chunk(k_begin + CD_BK, load_ptr(k_begin + CD_BK), S1{});
+    pn = load_ptr(k_begin + 2 * CD_BK);
+    scatter(Ahi, S0{}, false);
+    store_b(0, S0{});
+  }
+  __syncthreads();
+
+  const int a_frag = (64 * w + li) * CD_ROW + 16 * kg;       // + 32 genes * t
+  const int b_frag = li * CD_ROW + 16 * kg;
+  bool lo_dirty = false;
+  int ab = 0;
+  auto chunk = [&](int kc, auto buf_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    using Other = std::integral_constant<int, BUF ^ 1>;
+    const int ab1 = ab == 2 ? 0 : ab + 1, ab2 = ab1 == 2 ? 0 : ab1 + 1;
+    const bool need_lo = (En[BUF] & CT_LO) != 0u;        // (uniform: the block pointer's flag)
+    if (lo_dirty || need_lo) {
+      if (lo_dirty) { zero_plane(Alo); lds_barrier(); }
+      if (need_lo) { scatter(Alo, buf_tag, true); lds_barrier(); }
+      lo_dirty = need_lo;
+    }
+    auto stage = [&]() {
+      if (!(dbg & 8)) zero_plane(Ahi + ab2 * CTD_A_BYTES);
+      {
+        const Ptr p = pn;
+        pn = load_ptr(kc + 3 * CD_BK);
+        load_chunk(kc + 2 * CD_BK, p, buf_tag);
+      }
+      if (!(dbg & 4)) scatter(Ahi + ab1 * CTD_A_BYTES, Other{}, false);
+      store_b(BUF ^ 1, Other{});
+    };
+    auto multiply = [&]() {
+      if (dbg & 2) return;
+      const unsigned char* ah = Ahi + ab * CTD_A_BYTES + a_frag;
+      const unsigned char* al = Alo + a_frag;
+      const unsigned char* bcur = Bs + BUF * B_BYTES + b_frag;
+      // (every fragment of the chunk requested up front: see the forward kernel)
+      bf16x8 fh[2], fl[2], fr[3][NT];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        fh[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(ah + t * 32 * CD_ROW));
+#pragma unroll
+      for (int term = 2; term >= 0; --term)
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+          fr[term][q] = as_bf16x8(*reinterpret_cast<const u32x4*>(
+              bcur + (term * CG_NP + q * 32) * CD_ROW));
+      if (need_lo) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          fl[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(al + t * 32 * CD_ROW));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int term = 2; term >= 0; --term) {              // smallest term first
+        if (need_lo) {
+#pragma unroll
+          for (int q = 0; q < NT; ++q) {
+            acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[0], fr[term][q], acc[0][q], 0, 0, 0);
+            acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[1], fr[term][q], acc[1][q], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+          acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[0], fr[term][q], acc[0][q], 0, 0, 0);
+          acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[1], fr[term][q], acc[1][q], 0, 0, 0);
+        }
+      }
+    };
+    // (the lo test above read En[BUF] before stage() reloads the slot)
+    stage();
+    __builtin_amdgcn_sched_barrier(0);
+    multiply();
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+    ab = ab1;
+  };
+  for (int kc = k_begin; kc < k_end; kc += 2 * CD_BK) {
+    chunk(kc, S0{});
+    if (kc + CD_BK < k_end) chunk(kc + CD_BK, S1{});
+  }
+
+  float* dst = out + (size_t)blockIdx.y * M * ldo;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const int col = q * 32 + li;
+      if (col >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m_w + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (m < M) dst[(size_t)m * ldo + col] = acc[t][q][r];
+      }
+    }
+}
+
+static int ct_dbg() {   // (ablation flags of the tile kernels, measurements only: SCVAE_CT_DBG)
+  static const int v = [] { const char* e = getenv("SCVAE_CT_DBG"); return e ? atoi(e) : 0; }();
+  return v;
+}
+static size_t ctd_lds_bytes() { return 4 * (size_t)CTD_A_BYTES + 2 * (size_t)(3 * CG_NP * CD_ROW); }
+
+// count_gemm_u16 with the large part of the contraction read from `tiles` (the same minibatch:
+// csr_count_tiles of the rows x was densified from).  x (the uint16 batch) is only read for the
+// K % chunk leftover terms of the reduce kernel; the split, the k ranges of the slabs and their
+// fixed-order sum are those of count_gemm_u16: bit-identical results.
+int count_gemm_tiles(hipStream_t stream, int mode, CountTiles tiles, const uint16_t* x, int ldx,
+                     int rows, int cols, const float* other, int ld_other, int N,
+                     const float* bias, int act, float* C, int ldc, void* workspace,
+                     size_t workspace_bytes) {
+  SCVAE_ARG(tiles.ent && tiles.tptr && tiles.gptr && other && C && workspace);
+  SCVAE_ARG(mode == 0 || mode == 1);
+  SCVAE_ARG(count_gemm_supported(N) && ld_other >= N && ldc >= N && count_tiles_supported(cols));
+  if (rows == 0 || cols == 0) return 0;
+  SCVAE_ARG(workspace_bytes >= count_gemm_workspace_bytes(mode, rows, cols, N));
+  SCVAE_ARG(((uintptr_t)workspace & 15) == 0);
+  const int M = mode == 0 ? rows : cols, K = mode == 0 ? cols : rows;
+  const int bk = cg_bk(mode);
+  const int k_main = K / bk * bk;
+  SCVAE_ARG(k_main == K || (x && ldx >= cols));      // the leftover terms come from the dense batch
+  const int Kpad = cg_kpad(K);
+  uint16_t* T = reinterpret_cast<uint16_t*>(workspace);
+  const size_t t_bytes = ((size_t)3 * CG_NP * Kpad * sizeof(uint16_t) + 255) / 256 * 256;
+  float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + t_bytes);
+  const int ntp = count_tiles_padded(cols), ngb = ntp / CT_BLOCK;
+  const int n_groups = (rows + CT_ROWS - 1) / CT_ROWS;
+  int splits = 0;
+  if (k_main > 0) {
+    hipLaunchKernelGGL(split3_transpose_kernel, dim3((Kpad / 8 + 1) / 2), dim3(256), 0, stream,
+                       other, K, N, ld_other, T, Kpad);
+    SCVAE_LAUNCH_CHECK("split3_transpose_kernel");
+    splits = cg_splits(mode, M, k_main);
+    int k_chunk = k_main;
+    if (splits > 1) {
+      k_chunk = (k_main + splits - 1) / splits;
+      k_chunk = (k_chunk + bk - 1) / bk * bk;
+      splits = (k_main + k_chunk - 1) / k_chunk;
+    }
+    const bool direct = mode == 0 && splits == 1 && k_main == K;
+    float* dst = direct ? C : slabs;
+    const int ldo = direct ? ldc : N;
+    const int NT = (N + 31) / 32;
+    const float* kbias = direct ? bias : nullptr;
+    const int kact = direct ? act : (int)ACT_NONE, kdirect = direct ? 1 : 0;
+    if (mode == 0) {
+      const dim3 grid((M + CF_BM - 1) / CF_BM, splits);
+      const int NQ = NT > 2 ? 2 : 1;
+      const size_t lds = ctf_lds_bytes(NQ);
+#define SCVAE_CTF(NQ_)                                                                           \
+  do {                                                                                           \
+    auto kfn = count_tiles_fwd_kernel<NQ_>;                                                      \
+    SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)lds));                    \
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, stream, tiles.ent, tiles.tptr, ntp, n_groups,  \
+                       M, k_main, T, Kpad, N, k_chunk, dst, ldo, kbias, kact, kdirect, ct_dbg()); \
+  } while (0)
+      if (NQ == 2) SCVAE_CTF(2); else SCVAE_CTF(1);
+#undef SCVAE_CTF
+    } else {
+      const dim3 grid((M + 511) / 512, splits);
+      const size_t lds = ctd_lds_bytes();
+#define SCVAE_CTD(NT_)                                                                           \
+  do {                                                                                           \
+    auto kfn = count_tiles_dw_kernel<NT_>;                                                       \
+    SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)lds));                    \
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, stream, tiles.ent, tiles.gptr, ngb, M, k_main, \
+                       T, Kpad, N, k_chunk, dst, ldo, ct_dbg());                                 \
+  } while (0)
+      switch (NT) { case 1: SCVAE_CTD(1); break; case 2: SCVAE_CTD(2); break;
+                    case 3: SCVAE_CTD(3); break; default: SCVAE_CTD(4); }
+#undef SCVAE_CTD
+    }
+    SCVAE_LAUNCH_CHECK("count_tiles_kernel");
+    if (direct) return 0;
+  }
+  const size_t total = (size_t)M * N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(count_gemm_reduce_kernel<uint16_t>, dim3(blocks), dim3(256), 0, stream, slabs,
+                     bias, C, M, N, ldc, splits, act, mode, x, ldx, other, ld_other, k_main, K);
+  SCVAE_LAUNCH_CHECK("count_gemm_reduce_kernel");
+  return 0;
+}
+
 // ---- precondition check: every value an integer in [0, 65536) ----
 __global__ __launch_bounds__(256) void check_counts_kernel(const float* __restrict__ v, size_t n,
                                                            int* __restrict__ bad) {

@@ -30,6 +30,25 @@ int count_gemm(hipStream_t stream, int mode, const float* x, int ldx, int rows, 
 int count_gemm_u16(hipStream_t stream, int mode, const uint16_t* x, int ldx, int rows, int cols,
                const float* other, int ld_other, int N, const float* bias, int act, float* C,
                int ldc, void* workspace, size_t workspace_bytes);
+// The same minibatch as a list of its non-zeros grouped by (16 rows, 32 genes) -- count_gemm.hip
+// describes the format -- and the two products read from it (bit-identical to count_gemm_u16).
+struct CountTiles {
+  uint32_t* ent = nullptr;    // [groups][cap]
+  uint32_t* tptr = nullptr;   // [groups][count_tiles_padded(F) + 1]
+  uint32_t* gptr = nullptr;   // [groups][count_tiles_padded(F) / 16 + 1]
+  int64_t cap = 0;            // entries per group of 16 rows
+  int* status = nullptr;      // optional device word: bit 0 set when a group overflowed cap
+};
+int count_tiles_padded(int F);
+bool count_tiles_supported(int F);
+int csr_row_entries(hipStream_t stream, const int64_t* indptr, const float* values, int64_t n_rows,
+                    int32_t* out);
+int csr_count_tiles(hipStream_t stream, const int64_t* indptr, const int32_t* indices,
+                    const float* values, const int64_t* rows, int B, int F, CountTiles tiles);
+int count_gemm_tiles(hipStream_t stream, int mode, CountTiles tiles, const uint16_t* x, int ldx,
+                     int rows, int cols, const float* other, int ld_other, int N,
+                     const float* bias, int act, float* C, int ldc, void* workspace,
+                     size_t workspace_bytes);
 // *bad = 1 unless every value is an integer in [0, 65536) (the precondition of count_gemm)
 int check_counts(hipStream_t stream, const float* values, size_t n, int* bad);
 

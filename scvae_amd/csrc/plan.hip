@@ -95,6 +95,10 @@ static int build_vae(scvae_plan* p) {
   return 0;
 }
 
+bool count_tiles_enabled() {
+  static const bool on = [] { const char* e = getenv("SCVAE_COUNT_TILES"); return !(e && e[0] == '0'); }();
+  return on;
+}
 bool workspace_guard_on() {
   static const bool on = [] { const char* e = getenv("SCVAE_WS_GUARD"); return e && e[0] == '1'; }();
   return on;
@@ -285,8 +289,13 @@ int plan_gemm(scvae_plan* p, hipStream_t s, bool ta, bool tb, const float* A, co
       return -1;
     }
     stage_probe(mode ? PS_COUNT_DW : PS_COUNT_FWD, 0, s);
-    const int rc = count_gemm_u16(s, mode, p->step_u16, p->step_u16_ld, rows, cols, B, ldb, N,
-                                  bias, act, C, ldc, p->gemm_ws, p->gemm_ws_bytes);
+    // (the same minibatch as tile-indexed non-zeros, when the caller left it: same MFMAs on the
+    //  same operand tiles, a tenth of the bytes)
+    const int rc = p->step_tiles.ent
+        ? count_gemm_tiles(s, mode, p->step_tiles, p->step_u16, p->step_u16_ld, rows, cols, B, ldb,
+                           N, bias, act, C, ldc, p->gemm_ws, p->gemm_ws_bytes)
+        : count_gemm_u16(s, mode, p->step_u16, p->step_u16_ld, rows, cols, B, ldb, N,
+                         bias, act, C, ldc, p->gemm_ws, p->gemm_ws_bytes);
     stage_probe(mode ? PS_COUNT_DW : PS_COUNT_FWD, 1, s);
     return rc;
   }
@@ -778,6 +787,9 @@ static int side_jobs(const scvae_side_work* w, hipStream_t st) {
       rc = csr_densify(st, w->fetch_indptr, w->fetch_indices, w->fetch_values, w->fetch_rows,
                        (int)w->fetch_n, (int)w->fetch_features, static_cast<float*>(w->fetch_out),
                        (int)w->fetch_ld, w->fetch_row_values, w->fetch_row_values_out, &nr);
+    if (!rc && w->fetch_tiles)
+      rc = csr_count_tiles(st, w->fetch_indptr, w->fetch_indices, w->fetch_values, w->fetch_rows,
+                           (int)w->fetch_n, (int)w->fetch_features, count_tiles_of(w->fetch_tiles));
     return rc;
   }
   if (w->noise_out)
@@ -1858,6 +1870,13 @@ int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
   p->x_u16 = u16;
   p->step_u16 = a->counts_u16;
   p->step_u16_ld = (int)a->counts_ld;
+  p->step_tiles = scvae::CountTiles();
+  if (a->count_tiles) {
+    SCVAE_ARG(u16 && a->count_tiles->entries && a->count_tiles->tile_ptr &&
+              a->count_tiles->block_ptr && a->count_tiles->capacity > 0 &&
+              scvae::count_tiles_supported(p->cfg.feature_size));
+    if (scvae::count_tiles_enabled()) p->step_tiles = scvae::count_tiles_of(a->count_tiles);
+  }
   // (the uint16 batch travels through the layers as an opaque token; only plan_gemm, which
   //  hands it to the count kernels, and the fused likelihood launch look behind it)
   p->step_x = u16 ? reinterpret_cast<const float*>(a->counts_u16) : a->x;
@@ -1898,6 +1917,11 @@ int scvae_plan_step(scvae_plan* p, const scvae_step_args* a, void* stream) {
                 w->fetch_n > 0 && w->fetch_features > 0 && w->fetch_ld >= w->fetch_features &&
                 (w->fetch_as_u16 == 0 || w->fetch_as_u16 == 1) &&
                 (w->fetch_row_values_out == nullptr || w->fetch_row_values));
+      SCVAE_ARG(!w->fetch_tiles ||
+                (w->fetch_as_u16 && w->fetch_tiles->entries && w->fetch_tiles->tile_ptr &&
+                 w->fetch_tiles->block_ptr && w->fetch_tiles->capacity > 0 &&
+                 w->fetch_features <= 65536 &&
+                 (!a->count_tiles || a->count_tiles->entries != w->fetch_tiles->entries)));
       const size_t out_bytes =
           (size_t)w->fetch_n * (size_t)w->fetch_ld * (w->fetch_as_u16 ? 2 : 4);
       const size_t x_bytes = (size_t)a->cells * Fsz * sizeof(float);
@@ -2155,6 +2179,31 @@ int scvae_count_gemm_u16(int32_t mode, const uint16_t* x, int64_t ldx, int64_t r
                                (int)ld_other, (int)N, bias,
                                relu ? scvae::ACT_RELU : scvae::ACT_NONE, C, (int)ldc, workspace,
                                (size_t)workspace_bytes);
+}
+
+int64_t scvae_count_tiles_padded(int64_t F) {
+  return scvae::count_tiles_supported((int)F) && F > 0 && F <= 65536 ? scvae::count_tiles_padded((int)F) : -1;
+}
+int scvae_csr_row_entries(const int64_t* indptr, const float* values, int64_t n_rows, int32_t* out,
+                          void* stream) {
+  return scvae::csr_row_entries((hipStream_t)stream, indptr, values, n_rows, out);
+}
+int scvae_csr_count_tiles(const int64_t* indptr, const int32_t* indices, const float* values,
+                          const int64_t* rows, int64_t n, int64_t F,
+                          const scvae_count_tiles* tiles, void* stream) {
+  SCVAE_ARG(tiles && n >= 0 && n <= INT32_MAX && F > 0 && F <= 65536);
+  return scvae::csr_count_tiles((hipStream_t)stream, indptr, indices, values, rows, (int)n, (int)F,
+                                scvae::count_tiles_of(tiles));
+}
+int scvae_count_gemm_tiles(int32_t mode, const scvae_count_tiles* tiles, const uint16_t* x,
+                           int64_t ldx, int64_t rows, int64_t cols, const float* other,
+                           int64_t ld_other, int64_t N, const float* bias, int32_t relu, float* C,
+                           int64_t ldc, void* workspace, int64_t workspace_bytes, void* stream) {
+  SCVAE_ARG(tiles && workspace_bytes >= 0);
+  return scvae::count_gemm_tiles((hipStream_t)stream, mode, scvae::count_tiles_of(tiles), x, (int)ldx,
+                                 (int)rows, (int)cols, other, (int)ld_other, (int)N, bias,
+                                 relu ? scvae::ACT_RELU : scvae::ACT_NONE, C, (int)ldc, workspace,
+                                 (size_t)workspace_bytes);
 }
 
 int scvae_csr_densify(const int64_t* indptr, const int32_t* indices, const float* values,

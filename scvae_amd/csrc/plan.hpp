@@ -167,6 +167,7 @@ struct scvae_plan {
   unsigned* mid_bar = nullptr;   // midchain.hip's grid-barrier counter (workspace, zeroed at bind)
   unsigned mid_bar_count = 0;    // its value once every launch enqueued so far has run
   bool x_u16 = false;            // this step's minibatch is the uint16 count matrix below
+  scvae::CountTiles step_tiles;  // ... and, when ent != nullptr, the same rows as tile-indexed non-zeros
   const uint16_t* step_u16 = nullptr;
   int step_u16_ld = 0;
   // scvae_step_args.side: the plan's second stream, forked where the likelihood heads' gradients
@@ -224,6 +225,14 @@ struct scvae_plan {
 };
 
 namespace scvae {
+inline CountTiles count_tiles_of(const scvae_count_tiles* t) {
+  CountTiles c;
+  if (t) { c.ent = t->entries; c.tptr = t->tile_ptr; c.gptr = t->block_ptr; c.cap = t->capacity;
+           c.status = t->status; }
+  return c;
+}
+// SCVAE_COUNT_TILES=0: steps ignore scvae_step_args.count_tiles (A/B against the dense batch)
+bool count_tiles_enabled();
 const char* last_error();
 int dense_forward(scvae_plan* p, hipStream_t s, Dense& d, const float* in, int ld_in, int rows,
                   int groups, bool relu, bool training);

@@ -471,7 +471,8 @@ class Engine:
              global_cells=None, outputs=None, scalars=None,
              decoder_extra=None, dropout_seed=None, count_sum=None,
              row_offset=0, x_counts=False, learning_rate=None,
-             grad_scale=1.0, next_minibatch=None, next_noise=None):
+             grad_scale=1.0, next_minibatch=None, next_noise=None,
+             count_tiles=None):
         """One graph execution (no host synchronisation).  ``outputs`` maps
         optional output names of ``scvae_step_args`` to preallocated tensors.
         ``dropout_seed``: seed of this training step's dropout masks (default:
@@ -485,7 +486,9 @@ class Engine:
         process only); ``next_minibatch`` -- a ``DeviceCSR.request(...)`` for
         the following step's minibatch (into buffers this step does not read);
         ``next_noise`` -- ``dict(out=, block_stride=, row_offset=, seed=,
-        stream_id=)`` for its noise (``philox_normal_blocks`` arguments)."""
+        stream_id=)`` for its noise (``philox_normal_blocks`` arguments).
+        ``count_tiles``: this step's uint16 minibatch also as a
+        ``minibatch.CountTiles`` (same rows)."""
         cells = x.shape[0]
         samples = 1 if deterministic_z else n_iw * n_mc
         self.reserve(cells, samples)
@@ -497,6 +500,10 @@ class Engine:
                 raise ValueError("a uint16 minibatch is both x and t")
             a.counts_u16 = x.data_ptr()
             a.counts_ld = x.stride(0)
+            # the same rows as tile-indexed non-zeros (minibatch.CountTiles):
+            # the input layer's two products read them instead of the batch
+            if count_tiles is not None:
+                a.count_tiles = count_tiles.address
         else:
             a.x = x.data_ptr()
             a.t = t.data_ptr()

@@ -56,6 +56,53 @@ class DeviceCSR:
                 _ptr(self.row_lgamma1p),
                 current_stream_handle(self.device)), "scvae_csr_row_lgamma1p")
 
+        self._max_row_entries = None
+
+    @property
+    def max_row_entries(self):
+        """Most entries a row contributes to a ``CountTiles`` (its non-zeros,
+        plus one for every count of more than 8 significant bits): sizes the
+        per-group capacity.  Computed on first use (integer count matrices)."""
+        if self._max_row_entries is None:
+            if not self.integer_counts or not self.shape[0]:
+                self._max_row_entries = 0
+            else:
+                per_row = torch.empty(self.shape[0], dtype=torch.int32,
+                                      device=self.device)
+                _lib.check(self.lib.scvae_csr_row_entries(
+                    _ptr(self.indptr), _ptr(self.values), self.shape[0],
+                    _ptr(per_row), current_stream_handle(self.device)),
+                    "scvae_csr_row_entries")
+                self._max_row_entries = int(per_row.max().item())
+        return self._max_row_entries
+
+    @property
+    def count_tiles_supported(self):
+        """Whether minibatches of this matrix can also be kept as tile-indexed
+        non-zeros (``count_tiles``): integer counts, at most 65 536 genes."""
+        return bool(self.integer_counts and 0 < self.shape[1] <= 65536
+                    and self.max_row_entries > 0)
+
+    def count_tiles(self, n_rows):
+        """Buffers for a minibatch of up to ``n_rows`` rows as tile-indexed
+        non-zeros (``CountTiles``); fill with ``gather_count_tiles`` or let the
+        previous step carry it (``request(..., tiles=)``)."""
+        if not self.count_tiles_supported:
+            raise ValueError("count tiles: an integer count matrix of at most "
+                             "65 536 genes expected")
+        return CountTiles(self, int(n_rows))
+
+    def gather_count_tiles(self, rows, tiles):
+        """``tiles`` <- the minibatch ``rows`` as tile-indexed non-zeros."""
+        n = int(rows.numel())
+        if n > tiles.max_rows:
+            raise ValueError("more rows than the tiles were sized for")
+        _lib.check(self.lib.scvae_csr_count_tiles(
+            _ptr(self.indptr), _ptr(self.indices), _ptr(self.values),
+            _ptr(rows), n, self.shape[1], ctypes.byref(tiles.struct),
+            current_stream_handle(self.device)), "scvae_csr_count_tiles")
+        return tiles
+
     @classmethod
     def from_scipy(cls, matrix, device):
         matrix = matrix.tocsr()
@@ -93,10 +140,11 @@ class DeviceCSR:
         return out
 
 
-    def request(self, rows, out, row_const_out=None):
+    def request(self, rows, out, row_const_out=None, tiles=None):
         """A fetch of ``rows`` into ``out`` (fp32 ``[n, F]`` or uint16
-        ``[n, u16_pitch]``) to hand to ``Engine.step(next_minibatch=...)``."""
-        return MinibatchRequest(self, rows, out, row_const_out)
+        ``[n, u16_pitch]``) to hand to ``Engine.step(next_minibatch=...)``;
+        ``tiles``: a ``CountTiles`` to fill with the same rows (uint16 only)."""
+        return MinibatchRequest(self, rows, out, row_const_out, tiles)
 
     @property
     def u16_pitch(self):
@@ -122,13 +170,53 @@ class DeviceCSR:
         return out
 
 
+class CountTiles:
+    """A count minibatch as the list of its non-zeros grouped by (16 rows, 32
+    genes) -- ``scvae_count_tiles`` (include/scvae_hip.h).  Handed to
+    ``Engine.step(count_tiles=)`` next to the uint16 batch of the same rows,
+    the input layer's two products (mu:53-59) read it instead of the dense
+    batch: same arithmetic, a tenth of the bytes."""
+
+    def __init__(self, matrix, max_rows):
+        lib = matrix.lib
+        device = matrix.device
+        self.max_rows = max_rows
+        groups = (max_rows + 15) // 16
+        tiles = int(lib.scvae_count_tiles_padded(matrix.shape[1]))
+        self.capacity = 16 * matrix.max_row_entries
+        if groups * self.capacity >= 2 ** 31:
+            raise ValueError("count tiles: minibatch too large")
+        self.entries = torch.zeros(max(groups * self.capacity, 1),
+                                   dtype=torch.int32, device=device)
+        self.tile_ptr = torch.zeros(groups * (tiles + 1), dtype=torch.int32,
+                                    device=device)
+        self.block_ptr = torch.zeros(groups * (tiles // 16 + 1),
+                                     dtype=torch.int32, device=device)
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+        self.struct = _lib.CountTilesStruct()
+        self.struct.entries = self.entries.data_ptr()
+        self.struct.tile_ptr = self.tile_ptr.data_ptr()
+        self.struct.block_ptr = self.block_ptr.data_ptr()
+        self.struct.capacity = self.capacity
+        self.struct.status = self.status.data_ptr()
+
+    @property
+    def address(self):
+        return ctypes.addressof(self.struct)
+
+
 class MinibatchRequest:
     """The arguments of one minibatch fetch (``scvae_csr_minibatch``), to be
     carried by the step before it (``Engine.step(next_minibatch=...)``: the
     densify then runs under that step's backward pass) or issued directly
     (``issue()``).  Holds references to every tensor involved."""
 
-    def __init__(self, matrix, rows, out, row_const_out=None):
+    def __init__(self, matrix, rows, out, row_const_out=None, tiles=None):
+        if tiles is not None and (out.dtype != torch.uint16
+                                  or rows.numel() > tiles.max_rows):
+            raise ValueError("count tiles go with a uint16 minibatch of at "
+                             "most the rows they were sized for")
+        self.tiles = tiles
         if out.dtype not in (torch.uint16, torch.float32):
             raise ValueError("uint16 or float32 minibatch buffer expected")
         if out.dtype == torch.uint16 and not matrix.integer_counts:
@@ -153,11 +241,15 @@ class MinibatchRequest:
         side.fetch_row_values_out = (
             self.row_const_out.data_ptr()
             if self.row_const_out is not None else None)
+        side.fetch_tiles = (self.tiles.address if self.tiles is not None
+                            else None)
 
     def issue(self):
         if self.out.dtype == torch.uint16:
             self.matrix.gather_counts_u16(self.rows, out=self.out,
                                           row_const_out=self.row_const_out)
+            if self.tiles is not None:
+                self.matrix.gather_count_tiles(self.rows, self.tiles)
         else:
             self.matrix.gather_dense(self.rows, out=self.out,
                                      row_const_out=self.row_const_out)
