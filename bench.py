@@ -113,6 +113,46 @@ def train_flops_per_cell(F, hidden, latent, heads):
 # ----------------------------------------------------------------------------
 # CPU baseline (rank 0, N = 1): the torch-CPU fp32 port of the step
 # ----------------------------------------------------------------------------
+class GpuClocks:
+    """Engine / memory clocks as rocm-smi reports them WHILE the warm-up steps run (the
+    pool's boxes come in two speeds: without the clocks a reader cannot tell a regression
+    from a slow box).  Started before the warm-up (seconds of real steps), read after the
+    timed region; never fails the run."""
+
+    def __init__(self):
+        import shutil
+        import subprocess
+        self.out = {"source": "rocm-smi --showclocks --json -d 0, sampled ~1 s into the "
+                              "warm-up steps (GPU busy with the benchmark's own steps)"}
+        self.process = None
+        tool = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+        try:
+            self.process = subprocess.Popen(
+                ["/bin/sh", "-c", "sleep 1; exec {} --showclocks --json -d 0".format(tool)],
+                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        except Exception as error:   # noqa: BLE001 (a report, not a dependency)
+            self.out["error"] = repr(error)[:200]
+
+    def read(self):
+        if self.process is not None:
+            try:
+                text, _ = self.process.communicate(timeout=30)
+                card = next(iter(json.loads(text).values()))
+                for key, value in card.items():
+                    low = key.lower()
+                    for name in ("sclk", "mclk", "fclk", "socclk"):
+                        if low.startswith(name):
+                            self.out[name] = value.strip("()")
+            except Exception as error:   # noqa: BLE001
+                self.out["error"] = repr(error)[:200]
+                try:
+                    self.process.kill()
+                except Exception:   # noqa: BLE001
+                    pass
+            self.process = None
+        return self.out
+
+
 def _cpu_model_string():
     try:
         with open("/proc/cpuinfo") as f:
@@ -860,7 +900,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    clock_probe = GpuClocks() if rank == 0 else None
     elapsed, per_step, warm_steps = work.run(args.steps, args.warmup, barrier)
+    clocks = clock_probe.read() if clock_probe else None
     if world > 1:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -939,6 +981,7 @@ def main():
             "step_mfma_frac": value / world * flops_cell / 1e12
             / PEAK_FP32_MFMA_TFLOPS,
             "last_lower_bound": lower_bound,
+            "gpu_clocks": clocks,
         }
         if gm:   # informational run: per-cell flops of the VAE formula do not apply
             result["train_flop_per_cell"] = None

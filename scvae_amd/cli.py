@@ -10,6 +10,7 @@ flags that only feed them are accepted and ignored with a notice.
 """
 
 import argparse
+import contextlib
 import os
 
 from scvae_amd import __version__
@@ -595,5 +596,61 @@ def main(arguments=None):
              "early-stopping")
 
     parsed = parser.parse_args(arguments)
-    status = parsed.func(**vars(parsed))
+    started = _start_data_parallel()
+    try:
+        import torch.distributed as dist
+        quiet = (dist.is_available() and dist.is_initialized()
+                 and dist.get_rank() != 0)
+        if quiet:   # one voice: rank 0 prints, writes logs and checkpoints
+            with open(os.devnull, "w") as sink, \
+                    contextlib.redirect_stdout(sink):
+                status = parsed.func(**vars(parsed))
+        else:
+            status = parsed.func(**vars(parsed))
+    finally:
+        if started:
+            _stop_data_parallel()
     return status
+
+
+def _start_data_parallel():
+    """One process per GPU: when the command was started by
+    ``python -m torch.distributed.run --nproc-per-node N -m scvae_amd train ...``
+    (``WORLD_SIZE`` / ``RANK`` / ``LOCAL_RANK`` / ``MASTER_*`` in the
+    environment), join the process group before any model is built -- the
+    model classes shard every minibatch over the group (``models/base.py``,
+    ``dataparallel.py``: contiguous row shards, gradient all-reduce over RCCL,
+    synchronised batch norm) -- and leave it afterwards.  The reference is a
+    single process (va:887); nothing here changes a run without that
+    environment.  ``SCVAE_DIST_BACKEND=gloo`` moves the bytes over the host
+    (tests on a box with fewer GPUs than ranks).  Returns whether this call
+    created the group."""
+    world = int(os.environ.get("WORLD_SIZE", "1") or 1)
+    if world <= 1:
+        return False
+    import torch
+    import torch.distributed as dist
+    if not dist.is_available() or dist.is_initialized():
+        return False
+    backend = os.environ.get("SCVAE_DIST_BACKEND", "nccl")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    keyword_arguments = {}
+    if torch.cuda.is_available():
+        device = torch.device("cuda", local_rank % torch.cuda.device_count())
+        torch.cuda.set_device(device)
+        if backend == "nccl":
+            keyword_arguments["device_id"] = device
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend, rank=rank, world_size=world,
+                            **keyword_arguments)
+    return True
+
+
+def _stop_data_parallel():
+    import torch.distributed as dist
+    if dist.is_initialized():
+        try:
+            dist.barrier()
+        finally:
+            dist.destroy_process_group()

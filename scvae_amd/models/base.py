@@ -81,8 +81,11 @@ class ModelBase:
             from scvae_amd.engine import Engine
             device = self._device
             if device is None:
+                # one process per GPU; more ranks than GPUs (tests) share them
+                import torch
                 local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-                device = "cuda:{}".format(local_rank)
+                device = "cuda:{}".format(
+                    local_rank % max(torch.cuda.device_count(), 1))
             self._engine = Engine(device=device, seed=self.initial_seed,
                                   **self._engine_arguments())
         return self._engine
