@@ -122,13 +122,13 @@ class GpuClocks:
     def __init__(self):
         import shutil
         import subprocess
-        self.out = {"source": "rocm-smi --showclocks --json -d 0, sampled ~1 s into the "
+        self.out = {"source": "rocm-smi --showclocks --json -d 0, sampled ~0.5 s into the "
                               "warm-up steps (GPU busy with the benchmark's own steps)"}
         self.process = None
         tool = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
         try:
             self.process = subprocess.Popen(
-                ["/bin/sh", "-c", "sleep 1; exec {} --showclocks --json -d 0".format(tool)],
+                ["/bin/sh", "-c", "sleep 0.3; exec {} --showclocks --json -d 0".format(tool)],
                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
         except Exception as error:   # noqa: BLE001 (a report, not a dependency)
             self.out["error"] = repr(error)[:200]

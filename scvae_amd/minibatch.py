@@ -104,8 +104,18 @@ class DeviceCSR:
         return tiles
 
     @classmethod
-    def from_scipy(cls, matrix, device):
+    def from_scipy(cls, matrix, device, rows=None):
+        """Upload a scipy matrix -- all of it, or (``rows=(lo, hi)``) only the
+        contiguous row shard ``lo .. hi - 1``, whose local row ``i`` is row
+        ``lo + i`` of the matrix: a data-parallel rank that draws its cells
+        from its own 1 / W of a matrix too large to replicate (SURVEY section
+        8e: the 1.3 M-cell matrix is ~20 GB of CSR)."""
         matrix = matrix.tocsr()
+        if rows is not None:
+            lo, hi = int(rows[0]), int(rows[1])
+            if not 0 <= lo <= hi <= matrix.shape[0]:
+                raise ValueError("row shard outside the matrix")
+            matrix = matrix[lo:hi]
         if not matrix.has_canonical_format:
             # duplicate (row, column) entries are summed, as ``.toarray()`` of
             # the reference's minibatch fetch does (va:997-998); the densify
@@ -116,6 +126,19 @@ class DeviceCSR:
         return cls(matrix.indptr.astype(numpy.int64),
                    matrix.indices.astype(numpy.int32),
                    matrix.data.astype(numpy.float32), matrix.shape, device)
+
+    def row_shard(self, lo, hi):
+        """The rows ``lo .. hi - 1`` as a matrix of their own (device-side
+        copy of the three arrays; local row ``i`` = row ``lo + i``)."""
+        lo, hi = int(lo), int(hi)
+        if not 0 <= lo <= hi <= self.shape[0]:
+            raise ValueError("row shard outside the matrix")
+        first = int(self.indptr[lo].item())
+        last = int(self.indptr[hi].item())
+        return DeviceCSR(self.indptr[lo:hi + 1] - first,
+                         self.indices[first:last].clone(),
+                         self.values[first:last].clone(),
+                         (hi - lo, self.shape[1]), self.device)
 
     @property
     def number_of_rows(self):
