@@ -374,11 +374,12 @@ class ModelBase:
         say("Preparing data.")
         preparing_data_time_start = time()
         engine = self.engine
-        if kwargs.get("deterministic") is not None:
-            # (not in the reference) True: the decoder gradient is summed over
-            # the gene strips in a fixed order (bit-repeatable steps) instead
-            # of with fp32 atomics, the plan's default
-            engine.set_dd_atomics(not kwargs["deterministic"])
+        if kwargs.get("deterministic"):
+            # (not in the reference) the decoder gradient is summed over the
+            # gene strips in a fixed order (bit-repeatable steps) instead of
+            # with fp32 atomics.  Absent / False leaves the plan's default --
+            # scvae_default_dd_atomics, SCVAE_DD_ACCUMULATION -- alone.
+            engine.set_dd_atomics(False)
         x_train, t_train = self._device_matrices(training_set)
         n_examples_train = training_set.number_of_examples
         if validation_set:
@@ -387,8 +388,15 @@ class ModelBase:
         sync = None
         if world > 1:
             from scvae_amd.dataparallel import GradientSynchroniser
-            engine.reserve(max(minibatch_size, self._evaluation_largest_step(
-                n_examples_train, minibatch_size, n_iw * n_mc)), n_iw * n_mc)
+            # (bound once, for the largest step of EITHER epoch-end pass: a
+            #  later re-bind would replace the buffers the synchroniser holds)
+            engine.reserve(max(
+                minibatch_size,
+                self._evaluation_largest_step(
+                    n_examples_train, minibatch_size, n_iw * n_mc),
+                self._evaluation_largest_step(
+                    n_examples_valid, minibatch_size, n_iw * n_mc)
+                if validation_set else 0), n_iw * n_mc)
             sync = GradientSynchroniser(engine)
         say("Data prepared ({}).".format(
             format_duration(time() - preparing_data_time_start)))
@@ -481,8 +489,13 @@ class ModelBase:
         step = int(epoch_start * steps_per_epoch)
         # (the epoch-end passes run steps of several minibatches: bound once,
         #  ahead of the first training step)
-        engine.reserve(max(local_batch, 1, self._evaluation_largest_step(
-            n_examples_train, minibatch_size, samples)), samples)
+        engine.reserve(max(
+            local_batch, 1,
+            self._evaluation_largest_step(
+                n_examples_train, minibatch_size, samples),
+            self._evaluation_largest_step(
+                n_examples_valid, minibatch_size, samples)
+            if validation_set else 0), samples)
         # an integer count matrix that is both input and target: the minibatch
         # is densified as uint16 where the plan takes it (half the bytes for the
         # three kernels that stream it; the step is bit-identical)
@@ -920,8 +933,22 @@ class ModelBase:
 
     def _evaluation_step_cells(self, samples):
         passes = int(numpy.prod(self._eps_shape(samples, 1)[:-2]))
-        return min(int(self.evaluation_chunk_cells),
-                   int(self.evaluation_chunk_stacked_rows) // max(passes, 1))
+        cells = min(int(self.evaluation_chunk_cells),
+                    int(self.evaluation_chunk_stacked_rows) // max(passes, 1))
+        # plans off the fused likelihood kernels (-k > 2, head dropout, ...)
+        # keep [rows, F] buffers per head: a step of 4096 cells is then GBs of
+        # workspace a step of one minibatch never needed.  Halve the step
+        # until its workspace fits half of what is free (below 2 B cells
+        # evaluation_chunks runs one step per minibatch, as the reference).
+        engine = self._engine
+        if engine is not None and cells > 0 and engine.device.type == "cuda":
+            free, _ = torch.cuda.mem_get_info(engine.device)
+            held = engine.workspace.numel() if engine.workspace is not None else 0
+            budget = held + free // 2
+            while cells > 1 and engine.lib.scvae_plan_workspace_bytes(
+                    engine.handle, cells, max(int(samples), 1)) > budget:
+                cells //= 2
+        return cells
 
     def _evaluation_largest_step(self, n, minibatch_size, samples):
         return max((cells for _, cells, _ in mu.evaluation_chunks(

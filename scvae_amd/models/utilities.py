@@ -183,6 +183,7 @@ class CheckpointWriter:
         self._jobs = queue.Queue()
         self._thread = None
         self._error = None
+        self._delivered = False
         self._pending_saves = 0
         import threading
         self._lock = threading.Lock()
@@ -193,21 +194,39 @@ class CheckpointWriter:
             try:
                 if job is None:
                     return
-                if self._error is None:   # (after a failure: drain without working)
+                if self._error is None:
                     job()
-            except BaseException as error:   # surfaced by the next wait()
-                self._error = error
+                else:
+                    # after a failure the queue is drained without working --
+                    # but a skipped save still gives its slot back, or save()
+                    # would wait for it for ever
+                    skipped = getattr(job, "on_skip", None)
+                    if skipped is not None:
+                        skipped()
+            except BaseException as error:   # raised by the next call from the loop
+                if self._error is None:
+                    self._error = error
             finally:
                 self._jobs.task_done()
 
+    def _raise_if_failed(self):
+        """The first failure of a queued job, raised from every later call (it
+        stays: nothing queued after it has run, so the files on disk are those of
+        before the failure and the run must not carry on as if they were not)."""
+        if self._error is not None:
+            self._delivered = True
+            raise self._error
+
     def _submit(self, job):
         import threading
+        self._raise_if_failed()
         if self._thread is None or not self._thread.is_alive():
             self._thread = threading.Thread(target=self._worker, daemon=True)
             self._thread.start()
         self._jobs.put(job)
 
     def save(self, state, log_directory, epoch):
+        self._raise_if_failed()
         while self._pending_saves >= self.MAX_PENDING_SAVES:
             self.wait()
 
@@ -220,11 +239,19 @@ class CheckpointWriter:
                          else state)
                 save_checkpoint(ready, log_directory, epoch)
             finally:
-                with self._lock:
-                    self._pending_saves -= 1
+                release()
+
+        def release():
+            with self._lock:
+                self._pending_saves -= 1
+        work.on_skip = release
         with self._lock:
             self._pending_saves += 1
-        self._submit(work)
+        try:
+            self._submit(work)
+        except BaseException:
+            release()
+            raise
 
     def copy_latest(self, log_directory, output_directory, prune=False):
         """``copy_model_directory`` of the checkpoint that is the latest of
@@ -249,15 +276,17 @@ class CheckpointWriter:
     def wait(self):
         if self._thread is not None:
             self._jobs.join()
-        if self._error is not None:
-            error, self._error = self._error, None
-            raise error
+        self._raise_if_failed()
 
     def close(self):
         import atexit
         atexit.unregister(self.close)
         try:
-            self.wait()
+            if self._thread is not None:
+                self._jobs.join()
+            error, self._error = self._error, None
+            if error is not None and not self._delivered:   # (nobody has seen it yet)
+                raise error
         finally:
             if self._thread is not None:
                 self._jobs.put(None)
@@ -273,6 +302,9 @@ def load_checkpoint(checkpoint_path):
                       weights_only=True)
 
 
+SMALL_LOG_FILE_BYTES = 1 << 20
+
+
 def snapshot_logs(source):
     """The small text files that travel with a checkpoint -- ``*.log`` and the
     scalar stores under ``training/`` and ``validation/`` -- as {relative path:
@@ -283,7 +315,12 @@ def snapshot_logs(source):
         return files
     for entry in os.listdir(source):
         path = os.path.join(source, entry)
-        if os.path.isfile(path) and entry.endswith(".log"):
+        # (every small top-level file travels -- the reference copies the whole
+        #  directory, va:1385-1441 --, except the checkpoints themselves and
+        #  their index, which copy_model_directory places)
+        if (os.path.isfile(path) and entry != CHECKPOINT_INDEX
+                and not entry.endswith((".pt", ".tmp"))
+                and os.path.getsize(path) <= SMALL_LOG_FILE_BYTES):
             with open(path, "rb") as f:
                 files[entry] = f.read()
         elif os.path.isdir(path) and entry in ("training", "validation"):
@@ -306,8 +343,11 @@ def copy_model_directory(checkpoint_path, output_directory, logs=None):
         shutil.rmtree(output_directory)
     os.makedirs(output_directory)
     name = os.path.basename(checkpoint_path)
-    # (a state file is written once and renamed into place, never modified: a
-    #  hard link is a copy; across file systems: copy)
+    # INVARIANT: a state file is immutable -- save_checkpoint writes a temporary
+    # file and renames it into place, nothing ever rewrites one in place -- so a
+    # hard link is a copy that cannot change under `best/` or `early_stopping/`.
+    # Anything that edits checkpoints in place (an external tool) must break
+    # the link first.  Across file systems: a real copy.
     try:
         os.link(checkpoint_path, os.path.join(output_directory, name))
     except OSError:

@@ -553,3 +553,59 @@ def test_evaluation_chunks_keep_the_reference_average():
     chunked = sum(w * values[s:s + c].mean()
                   for s, c, w in evaluation_chunks(61722, 100, 4096))
     assert abs(reference - chunked) < 1e-9 * abs(reference)
+
+
+def test_checkpoint_writer_failure_is_sticky_and_never_hangs(tmp_path, monkeypatch):
+    """A failed job (disk full, ...) must surface at the very next call from the
+    loop and must not strand the queue: jobs queued behind it are skipped, a
+    skipped save gives its slot back (it used to stay counted, and the next
+    save() then waited for ever), later calls raise the same error."""
+    import threading
+    from scvae_amd.models import utilities as mu
+    gate = threading.Event()
+
+    def failing(state, log_directory, epoch):
+        gate.wait(10)
+        raise OSError("No space left on device")
+    monkeypatch.setattr(mu, "save_checkpoint", failing)
+    writer = mu.CheckpointWriter()
+    log = str(tmp_path / "log")
+    writer.save({"a": 1}, log, 1)          # fails once the gate opens
+    writer.save({"a": 2}, log, 2)          # queued behind it: skipped
+    writer.copy_latest(log, str(tmp_path / "best"))
+    gate.set()
+    with pytest.raises(OSError):
+        writer.wait()
+    assert writer._pending_saves == 0
+    finished = []
+
+    def later():
+        try:
+            writer.save({"a": 3}, log, 3)
+        except OSError:
+            finished.append("raised")
+    worker = threading.Thread(target=later, daemon=True)
+    worker.start()
+    worker.join(10)
+    assert finished == ["raised"]          # (not hanging, not silently accepted)
+    with pytest.raises(OSError):
+        writer.copy_latest(log, str(tmp_path / "best"))
+    writer.close()                         # (the error has been delivered: a quiet end)
+    unseen = mu.CheckpointWriter()
+    unseen.save({"a": 1}, log, 1)
+    with pytest.raises(OSError):           # nobody waited: close() is the last chance
+        unseen.close()
+
+
+def test_snapshot_logs_takes_every_small_file_but_the_checkpoints(tmp_path):
+    from scvae_amd.models import utilities as mu
+    source = tmp_path / "log"
+    (source / "training").mkdir(parents=True)
+    (source / "training" / "scalars.jsonl").write_text("{}\n")
+    (source / "run.log").write_text("x")
+    (source / "notes.txt").write_text("kept as before")
+    (source / "model.ckpt-3.pt").write_bytes(b"state")
+    (source / mu.CHECKPOINT_INDEX).write_text("{}")
+    files = mu.snapshot_logs(str(source))
+    assert set(files) == {"run.log", "notes.txt",
+                          os.path.join("training", "scalars.jsonl")}
