@@ -544,6 +544,70 @@ int scvae_count_gemm_tiles(int32_t mode, const scvae_count_tiles* tiles, const u
                            int64_t ld_other, int64_t N, const float* bias, int32_t relu, float* C,
                            int64_t ldc, void* workspace, int64_t workspace_bytes, void* stream);
 int scvae_gather_rows(const float* src, const int64_t* rows, int64_t n, float* out, void* stream);
+/* ---- the small ops of the graph, stand-alone (the kernels scvae_plan_step launches; SURVEY.md
+ *      section 8b).  Row-major contiguous fp32 unless a pitch is given. ---- */
+/* tf.contrib.layers.batch_norm(center=True, scale=False, is_training=True) inside dense_layer
+ * (scvae/models/utilities.py:60-70): batch mean and biased variance of the columns of
+ * a[rows, N] (row pitch lda).  workspace: scvae_bn_workspace_floats(N) floats. */
+int64_t scvae_bn_workspace_floats(int64_t N);
+int scvae_bn_stats(const float* a, int64_t lda, int64_t rows, int64_t N, float* mean, float* var,
+                   float* workspace, void* stream);
+/* h = [relu]((a - mean) / sqrt(var + 1e-3) + beta)   (mu:60-76; the moving statistics in
+ * evaluation mode, the batch statistics of scvae_bn_stats while training) */
+int scvae_bn_apply_relu_fwd(const float* a, int64_t lda, const float* mean, const float* var,
+                            const float* beta, float* h, int64_t ldh, int64_t rows, int64_t N,
+                            int32_t relu, void* stream);
+/* its backward through the batch statistics: da[rows, N] and dbeta[N] from dh (the gradient
+ * w.r.t. h), the forward's h, a, mean, var.  workspace: scvae_bn_workspace_floats(N) + 2 N */
+int scvae_bn_apply_relu_bwd(const float* dh, int64_t lddh, const float* h, int64_t ldh,
+                            const float* a, int64_t lda, const float* mean, const float* var,
+                            int64_t rows, int64_t N, int32_t relu, float* da, int64_t ldda,
+                            float* dbeta, float* workspace, void* stream);
+/* The GMVAE's "softplus gaussian" pair (du:52-73; gm:2936-3048, 3272-3292): posterior
+ * q(z|x,y=k) = N(qm, sqrt(softplus(qs))) with qm, qs [K*B, L]; prior p(z|y=k) = row k of the
+ * Z/P dense layers (Wpm, Wps [K, L]; bpm, bps [L]).  z[k,s,b,:] = mean + sigma eps[k,s,b,:];
+ * klz[k,s,b] = sum_l log q(z) - log p(z|y=k); qvar (optional) [K*B, L] = sigma^2. */
+int scvae_softplus_gaussian_logprob_pair_fwd(const float* qm, const float* qs, const float* Wpm,
+                                             const float* bpm, const float* Wps,
+                                             const float* bps, const float* eps, float* z,
+                                             float* klz, float* qvar, int64_t K, int64_t S,
+                                             int64_t B, int64_t L, void* stream);
+/* backward: dz [K,S,B,L] (from the decoder) and gklz [K,S,B] (d loss / d klz) -> dqm, dqs
+ * [K*B, L] and the per-element prior gradients dprior [K*B, 2 L] = (d mean | d scale
+ * pre-activation), to be summed over b for the Z/P layers */
+int scvae_softplus_gaussian_logprob_pair_bwd(const float* qm, const float* qs, const float* Wpm,
+                                             const float* bpm, const float* Wps,
+                                             const float* bps, const float* eps, const float* dz,
+                                             const float* gklz, float* dqm, float* dqs,
+                                             float* dprior, int64_t K, int64_t S, int64_t B,
+                                             int64_t L, void* stream);
+/* q(y|x) = Categorical(logits) (gm:3050-3092): y = softmax(logits) [B, K] and
+ * kl_y_cell[b] = KL(q(y|x_b) || p(y)): log K - H[q] for the uniform prior (prior_logits NULL,
+ * gm:3242-3254), tfp kl_divergence against softmax(prior_logits) otherwise (gm:3256-3258) */
+int scvae_categorical_entropy_kl_fwd(const float* logits, float* y, float* kl_y_cell, int64_t B,
+                                     int64_t K, const float* prior_logits, void* stream);
+/* backward: dlogits = softmax-backward(dy) + c * gate[0] * d kl_y_cell / d logits, with gate a
+ * device float (the free-nats switch of gm:3391-3398: 1 when the KL term is above its
+ * threshold) */
+int scvae_categorical_entropy_kl_bwd(const float* y, const float* dy, const float* gate, float c,
+                                     float* dlogits, int64_t B, int64_t K,
+                                     const float* prior_logits, void* stream);
+/* Importance-weighted bound (va:2717-2734 with log_reduce_exp, mu:129-137):
+ * lower_bound = mean_{MC,B} log mean_IW exp(ll - KL), its KL-weighted twin, ENRE and KL into
+ * scalars[0..3], and the backward in the same launch: gw[s*B + b] = d(-lower_bound_weighted) /
+ * d ll (the softmax weights over the importance samples, scaled by row_scale = 1 / (MC * B)).
+ * ll [n_iw*n_mc*B]; kl_cell [B] (analytic) or [n_iw*n_mc*B] (kl_per_sample != 0). */
+int scvae_iw_logmeanexp(const float* ll, const float* kl_cell, int32_t kl_per_sample,
+                        int32_t n_iw, int32_t n_mc, int64_t B, float kl_weight, float row_scale,
+                        float* scalars, float* gw, void* stream);
+/* Evaluate-time statistics over the S samples of a cell (va:2665-2713): from the heads'
+ * pre-activations pre_j [S*B, F] the mean of p(x|z) averaged over the samples (p_x_mean), the
+ * sample mean of its variance (mean_of_var) and the variance of its mean over the samples
+ * (var_of_mean), each [B, F].  weight (optional, [B] with stride ldw) and accumulate != 0 form
+ * the GMVAE's mixture sums over the clusters (gm:3311-3386). */
+int scvae_pxmean_stats(int32_t kind, const float* const* pre, int64_t S, int64_t B, int64_t F,
+                       const float* weight, int64_t ldw, int32_t accumulate, float* p_x_mean,
+                       float* mean_of_var, float* var_of_mean, void* stream);
 /* q.sample() noise: Philox4x32-10 + Box-Muller keyed by (seed, stream_id, row_offset+row, col):
  * key = (seed_lo, seed_hi ^ stream_id_hi), counter = (row_lo, row_hi, col / 4, stream_id_lo) */
 int scvae_philox_normal(float* out, int64_t rows, int64_t cols, int64_t row_offset, uint64_t seed,

@@ -260,6 +260,32 @@ SIGNATURES = {
     "scvae_dropout_apply": (c_int32, [
         c_void_p, c_void_p, c_int64, c_int64, c_float, c_uint64, c_int32,
         c_int32, c_void_p]),
+    "scvae_bn_workspace_floats": (c_int64, [c_int64]),
+    "scvae_bn_stats": (c_int32, [
+        c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+        c_void_p]),
+    "scvae_bn_apply_relu_fwd": (c_int32, [
+        c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+        c_int64, c_int64, c_int32, c_void_p]),
+    "scvae_bn_apply_relu_bwd": (c_int32, [
+        c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+        c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64, c_void_p,
+        c_void_p, c_void_p]),
+    "scvae_softplus_gaussian_logprob_pair_fwd": (c_int32, [
+        c_void_p] * 10 + [c_int64] * 4 + [c_void_p]),
+    "scvae_softplus_gaussian_logprob_pair_bwd": (c_int32, [
+        c_void_p] * 12 + [c_int64] * 4 + [c_void_p]),
+    "scvae_categorical_entropy_kl_fwd": (c_int32, [
+        c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "scvae_categorical_entropy_kl_bwd": (c_int32, [
+        c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64,
+        c_void_p, c_void_p]),
+    "scvae_iw_logmeanexp": (c_int32, [
+        c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_float,
+        c_float, c_void_p, c_void_p, c_void_p]),
+    "scvae_pxmean_stats": (c_int32, [
+        c_int32, POINTER(c_void_p), c_int64, c_int64, c_int64, c_void_p,
+        c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "scvae_bn_merge": (c_int32, [
         c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
 }

@@ -2222,6 +2222,89 @@ int scvae_bn_merge(const float* gathered, const int64_t* counts, int64_t ranks, 
                    float* out, void* stream) {
   return scvae::bn_merge((hipStream_t)stream, gathered, counts, (int)ranks, (int)n, out);
 }
+int64_t scvae_bn_workspace_floats(int64_t N) {
+  return N > 0 ? (int64_t)scvae::bn_partial_floats(1, (int)N) : -1;
+}
+int scvae_bn_stats(const float* a, int64_t lda, int64_t rows, int64_t N, float* mean, float* var,
+                   float* workspace, void* stream) {
+  SCVAE_ARG(rows > 0 && rows <= INT32_MAX && N > 0 && lda >= N);
+  return scvae::bn_stats((hipStream_t)stream, a, (int)lda, (int)rows, 1, (int)N, mean, var,
+                         workspace);
+}
+int scvae_bn_apply_relu_fwd(const float* a, int64_t lda, const float* mean, const float* var,
+                            const float* beta, float* h, int64_t ldh, int64_t rows, int64_t N,
+                            int32_t relu, void* stream) {
+  SCVAE_ARG(a && mean && var && beta && h && rows >= 0 && N > 0 && lda >= N && ldh >= N);
+  if (rows == 0) return 0;
+  return scvae::bn_apply((hipStream_t)stream, a, (int)lda, mean, var, (int)N, beta, h, (int)ldh,
+                         (int)rows, 1, (int)N, relu ? 1 : 0);
+}
+int scvae_bn_apply_relu_bwd(const float* dh, int64_t lddh, const float* h, int64_t ldh,
+                            const float* a, int64_t lda, const float* mean, const float* var,
+                            int64_t rows, int64_t N, int32_t relu, float* da, int64_t ldda,
+                            float* dbeta, float* workspace, void* stream) {
+  SCVAE_ARG(dh && h && a && mean && var && da && dbeta && workspace && rows > 0 && N > 0);
+  SCVAE_ARG(lddh >= N && ldh >= N && lda >= N && ldda >= N && rows <= INT32_MAX);
+  float* s1 = workspace;
+  float* s2 = workspace + N;
+  float* partial = workspace + 2 * N;
+  int rc = scvae::bn_bwd_stats((hipStream_t)stream, dh, (int)lddh, h, (int)ldh, a, (int)lda, mean,
+                               var, (int)rows, 1, (int)N, relu ? 1 : 0, s1, s2, partial, dbeta,
+                               nullptr, nullptr, rows);
+  if (rc) return rc;
+  return scvae::bn_bwd_apply((hipStream_t)stream, dh, (int)lddh, h, (int)ldh, a, (int)lda, mean,
+                             var, s1, s2, (int)rows, 1, (int)N, relu ? 1 : 0, 1.f / (float)rows,
+                             da, (int)ldda);
+}
+int scvae_softplus_gaussian_logprob_pair_fwd(const float* qm, const float* qs, const float* Wpm,
+                                             const float* bpm, const float* Wps,
+                                             const float* bps, const float* eps, float* z,
+                                             float* klz, float* qvar, int64_t K, int64_t S,
+                                             int64_t B, int64_t L, void* stream) {
+  SCVAE_ARG(K > 0 && S > 0 && B >= 0 && K <= 65535 && B <= INT32_MAX);
+  return scvae::softplus_gaussian_fwd((hipStream_t)stream, qm, qs, Wpm, bpm, Wps, bps, eps, z,
+                                      klz, qvar, (int)K, (int)S, (int)B, (int)L);
+}
+int scvae_softplus_gaussian_logprob_pair_bwd(const float* qm, const float* qs, const float* Wpm,
+                                             const float* bpm, const float* Wps,
+                                             const float* bps, const float* eps, const float* dz,
+                                             const float* gklz, float* dqm, float* dqs,
+                                             float* dprior, int64_t K, int64_t S, int64_t B,
+                                             int64_t L, void* stream) {
+  SCVAE_ARG(Wpm && bpm && Wps && bps && K > 0 && S > 0 && B >= 0 && L > 0);
+  return scvae::softplus_gaussian_bwd((hipStream_t)stream, qm, qs, Wpm, bpm, Wps, bps, eps, dz,
+                                      gklz, dqm, dqs, dprior, (int)K, (int)S, (int)B, (int)L);
+}
+int scvae_categorical_entropy_kl_fwd(const float* logits, float* y, float* kl_y_cell, int64_t B,
+                                     int64_t K, const float* prior_logits, void* stream) {
+  SCVAE_ARG(logits && y && kl_y_cell && B >= 0 && K > 0 && B <= INT32_MAX);
+  return scvae::categorical_fwd((hipStream_t)stream, logits, y, kl_y_cell, (int)B, (int)K,
+                                prior_logits);
+}
+int scvae_categorical_entropy_kl_bwd(const float* y, const float* dy, const float* gate, float c,
+                                     float* dlogits, int64_t B, int64_t K,
+                                     const float* prior_logits, void* stream) {
+  SCVAE_ARG(y && dy && gate && dlogits && B >= 0 && K > 0 && B <= INT32_MAX);
+  return scvae::categorical_bwd_gated((hipStream_t)stream, y, dy, gate, c, dlogits, (int)B,
+                                      (int)K, prior_logits);
+}
+int scvae_iw_logmeanexp(const float* ll, const float* kl_cell, int32_t kl_per_sample,
+                        int32_t n_iw, int32_t n_mc, int64_t B, float kl_weight, float row_scale,
+                        float* scalars, float* gw, void* stream) {
+  SCVAE_ARG(ll && kl_cell && scalars && n_iw > 0 && n_mc > 0 && B > 0 && B <= INT32_MAX);
+  return scvae::vae_elbo((hipStream_t)stream, ll, kl_cell, kl_per_sample ? 1 : 0, n_iw, n_mc,
+                         (int)B, kl_weight, row_scale, scalars, gw);
+}
+int scvae_pxmean_stats(int32_t kind, const float* const* pre, int64_t S, int64_t B, int64_t F,
+                       const float* weight, int64_t ldw, int32_t accumulate, float* p_x_mean,
+                       float* mean_of_var, float* var_of_mean, void* stream) {
+  SCVAE_ARG(pre && ((kind >= 0 && kind <= 3) || kind == LK_BERNOULLI) && S > 0 && B >= 0 && F > 0);
+  scvae::HeadPtrs hp = {{nullptr, nullptr, nullptr}};
+  for (int j = 0; j < scvae::likelihood_heads(kind); ++j) hp.p[j] = const_cast<float*>(pre[j]);
+  return scvae::px_statistics((hipStream_t)stream, kind, hp, (int)F, (int)S, (int)B, (int)F,
+                              weight, (int)ldw, accumulate ? 1 : 0, p_x_mean, mean_of_var,
+                              var_of_mean);
+}
 int scvae_philox_normal(float* out, int64_t rows, int64_t cols, int64_t row_offset, uint64_t seed,
                         uint64_t stream_id, void* stream) {
   return scvae::philox_normal((hipStream_t)stream, out, rows, (int)cols, row_offset, seed,
