@@ -1,11 +1,13 @@
 """Minimal ``DataSet`` container: the attributes and methods of
 ``scvae/data/data_set.py:50`` that the model classes and the CLI consume
-(SURVEY.md section 8b).  Loading of external file formats, preprocessing and
-plotting metadata are outside the hot path and are not provided here; the
-built-in sources are synthetic count matrices (``scvae_amd/data/synthetic.py``).
+(SURVEY.md section 8b).  Sources: local files (``loaders.py``: 10x ``.h5`` and
+``.tar.gz``, sparse ``.h5``, text matrices) with the reference's ``.sparse.h5``
+cache of a parsed file (``internal_io.py``), and built-in synthetic count
+matrices (``synthetic.py``); downloads and plotting metadata are not provided.
 """
 
 import os
+from time import time
 
 import numpy
 import scipy.sparse
@@ -13,6 +15,11 @@ import scipy.sparse
 from scvae_amd.data.sparse import SparseRowMatrix
 from scvae_amd.defaults import defaults
 from scvae_amd.utilities import normalise_string
+
+# (data_set.py:31-35)
+PREPROCESS_SUFFIX = "preprocessed"
+PREPROCESSED_EXTENSION = ".sparse.h5"
+MINIMUM_NUMBER_OF_SECONDS_BEFORE_SAVING = 30
 
 
 class DataSet:
@@ -220,12 +227,39 @@ class DataSet:
                     "is outside the scope of this build."
                     .format(self.name, ", ".join(sorted(SYNTHETIC_DATA_SETS))))
             self._generator = SYNTHETIC_DATA_SETS[key]
-        dictionary = self._generator()
+        # the `.sparse.h5` cache of a parsed file (data_set.py:749-790): loaded
+        # when it exists, written when parsing took long enough to be worth it
+        sparse_path = self._sparse_cache_path() if self.path else None
+        if sparse_path and os.path.isfile(sparse_path):
+            from scvae_amd.data import internal_io
+            print("Loading data set.")
+            dictionary = internal_io.load_data_dictionary(sparse_path)
+            dictionary["values"] = scipy.sparse.csr_matrix(
+                dictionary["values"], dtype=numpy.float32)
+        else:
+            loading_time_start = time()
+            dictionary = self._generator()
+            loading_duration = time() - loading_time_start
+            if sparse_path and loading_duration > float(os.environ.get(
+                    "SCVAE_CACHE_AFTER_SECONDS",
+                    MINIMUM_NUMBER_OF_SECONDS_BEFORE_SAVING)):
+                from scvae_amd.data import internal_io
+                print("Saving data set.")
+                internal_io.save_data_dictionary(
+                    {key: dictionary.get(key) for key in (
+                        "values", "labels", "example names", "feature names")},
+                    sparse_path)
         self.update(values=dictionary["values"],
                     labels=dictionary.get("labels"),
                     example_names=dictionary.get("example names"),
                     feature_names=dictionary.get("feature names"))
         self.preprocess()
+
+    def _sparse_cache_path(self):
+        """``<directory>/<name>/preprocessed/<name>.sparse.h5``
+        (data_set.py:146-149, 1278-1315 without processing parts)."""
+        return os.path.join(self.directory, self.name, PREPROCESS_SUFFIX,
+                            self.name + PREPROCESSED_EXTENSION)
 
     def preprocess(self):
         """``preprocessing_methods`` applied to the values once

@@ -1,10 +1,16 @@
 """File loaders for local count matrices (``scvae/data/loaders.py``): the
 formats that need nothing but NumPy / SciPy.
 
-* ``10x``        -- a CellRanger ``*.tar.gz`` with ``matrix.mtx``,
+* ``10x``        -- a CellRanger ``*.h5`` (one genome group holding ``data``,
+                    ``indices``, ``indptr``, ``shape``, ``barcodes``,
+                    ``gene_names``) or ``*.tar.gz`` with ``matrix.mtx``,
                     ``barcodes.tsv`` and ``genes.tsv`` in one directory
-                    (loaders.py:651-721); the ``.h5`` variant needs PyTables,
-                    which this image does not have.
+                    (loaders.py:93-121, 651-721).  The reference opens the
+                    ``.h5`` with PyTables; here ``scvae_amd/data/hdf5.py``
+                    reads the format itself.
+* ``h5``         -- any HDF5 file with one sparse matrix (``data``,
+                    ``indices``, ``indptr``, ``shape``) and name lists found
+                    by the reference's guesses (loaders.py:37-47, 725-798).
 * ``matrix_ebf`` / ``matrix_fbe`` -- a (gzipped) tab-separated text matrix,
                     examples-by-features or features-by-examples, optionally
                     with a header row and a first column of names
@@ -54,12 +60,119 @@ def data_set_name_from_path(path):
     return os.path.splitext(name)[0]
 
 
+# (normalised list names, in the reference's order -- including its missing
+#  comma, which makes one guess of "cell_ids" and "samples")
+LIST_NAME_GUESSES = {
+    "example": [
+        "barcodes", "cells", "cell_names", "cell_ids" "samples",
+        "sample_names", "sample_ids", "examples", "example_names",
+        "example_ids"],
+    "feature": [
+        "genes", "gene_names", "gene_ids", "features", "feature_names",
+        "feature_ids"],
+}
+
+
+def _arrays_of_one_directory(path, what):
+    """{node name: array} of every array in the file, which must all live in
+    one group (loaders.py:658-669, 730-741)."""
+    from scvae_amd.data import hdf5
+    table, parents = {}, set()
+    with hdf5.File(path) as hdf5_file:
+        for node in hdf5_file.root.walk():
+            if not isinstance(node, hdf5.Dataset):
+                continue
+            parent, name = node.name.rsplit("/", 1)
+            parents.add(parent or "/")
+            if len(parents) > 1:
+                raise NotImplementedError(
+                    "Cannot handle {} with multiple directories.".format(what))
+            table[name] = node.read()
+    return table, (parents.pop() if parents else "/")
+
+
+def _sparse_matrix_of(table, path):
+    missing = [k for k in ("data", "indices", "indptr", "shape")
+               if k not in table]
+    if missing:
+        raise ValueError("`{}` holds no sparse matrix ({} missing).".format(
+            path, ", ".join(missing)))
+    return scipy.sparse.csc_matrix(
+        (table["data"], table["indices"], table["indptr"]),
+        shape=tuple(int(n) for n in table["shape"]))
+
+
+def _names(array):
+    array = numpy.asarray(array)
+    if array.dtype.kind == "S":
+        return numpy.char.decode(array, "utf-8").astype("U")
+    return array.astype("U")
+
+
+def load_10x_h5(path):
+    table, parent = _arrays_of_one_directory(path, "10x data sets")
+    values = _sparse_matrix_of(table, path)
+    if "barcodes" not in table or "gene_names" not in table:
+        raise ValueError(
+            "`{}` does not hold `barcodes` and `gene_names`.".format(path))
+    # the matrix is stored genes x cells
+    return {
+        "values": scipy.sparse.csr_matrix(values.T, dtype=numpy.float32),
+        "labels": None,
+        "example names": _names(table["barcodes"]),
+        "feature names": _names(table["gene_names"]),
+        "genome name": os.path.basename(parent),
+    }
+
+
+@_register_loader("h5")
+def load_h5_data_set(path):
+    """loaders.py:725-798: the orientation is decided by which axis the name
+    lists fit; missing lists are numbered."""
+    from scvae_amd.utilities import normalise_string
+    table, _ = _arrays_of_one_directory(path, "HDF5 data sets")
+    values = _sparse_matrix_of(table, path)
+    for key in ("data", "indices", "indptr", "shape"):
+        table.pop(key)
+
+    def find(kind):
+        for guess in LIST_NAME_GUESSES[kind]:
+            found = None
+            for key in table:
+                if guess == normalise_string(key):
+                    found = table[key]
+            if found is not None:
+                return found
+        return None
+    example_names, feature_names = find("example"), find("feature")
+    n_rows, n_columns = values.shape
+    examples_fit_columns = (example_names is not None
+                            and len(example_names) == n_columns)
+    features_fit_rows = (feature_names is not None
+                         and len(feature_names) == n_rows)
+    if (examples_fit_columns and features_fit_rows
+            or examples_fit_columns and feature_names is None
+            or features_fit_rows and example_names is None):
+        values = values.T
+        n_rows, n_columns = n_columns, n_rows
+    if example_names is None:
+        example_names = numpy.array(
+            ["example {}".format(i + 1) for i in range(n_rows)])
+    if feature_names is None:
+        feature_names = numpy.array(
+            ["feature {}".format(j + 1) for j in range(n_columns)])
+    return {
+        "values": scipy.sparse.csr_matrix(values, dtype=numpy.float32),
+        "labels": None,
+        "example names": _names(example_names),
+        "feature names": _names(feature_names),
+    }
+
+
 @_register_loader("10x")
 def load_10x_data_set(path):
     if path.endswith(".h5"):
-        raise NotImplementedError(
-            "10x HDF5 files need PyTables, which is not available here; use "
-            "the matrix.mtx tarball (loaders.py:658-676).")
+        return load_10x_h5(path)
     multiple_directories_error = NotImplementedError(
         "Cannot handle 10x data sets with multiple directories.")
     parent_paths = set()
