@@ -629,23 +629,29 @@ def evaluation_step(matrix, device, batch, steps=60):
     eng = Engine(F, LATENT, HIDDEN, LIKELIHOOD, batch_norm=True, device=device, seed=0)
     eng.reserve(batch, 1)
     u16 = bool(matrix.integer_counts and eng.accepts_counts_u16(batch, False))
-    x = (torch.empty(batch, matrix.u16_pitch, dtype=torch.uint16, device=device) if u16
-         else torch.empty(batch, F, device=device))
-    rc = torch.empty(batch, device=device)
+    # (as the model classes run their evaluation passes: two sets of buffers, a step
+    #  carries the fetch of the next one -- scvae_side_work, forked after the input layer)
+    x = [(torch.empty(batch, matrix.u16_pitch, dtype=torch.uint16, device=device) if u16
+          else torch.empty(batch, F, device=device)) for _ in range(2)]
+    rc = [torch.empty(batch, device=device) for _ in range(2)]
     eps = torch.randn(1, batch, LATENT, device=device)
     n = matrix.number_of_rows
     rows = torch.arange(n, device=device)
 
-    def step(i):
+    def request(i):
         r = rows[(i * batch) % (n - batch + 1):][:batch]
-        matrix.request(r, x, rc).issue()
-        eng.step(x, x, eps=eps, row_const=rc, training=False, x_counts=matrix.integer_counts)
+        return matrix.request(r, x[i & 1], rc[i & 1])
+    request(0).issue()
+
+    def step(i):
+        eng.step(x[i & 1], x[i & 1], eps=eps, row_const=rc[i & 1], training=False,
+                 x_counts=matrix.integer_counts, next_minibatch=request(i + 1))
     for i in range(10):
         step(i)
     torch.cuda.synchronize(device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for i in range(steps):
+    for i in range(10, 10 + steps):
         step(i)
     e1.record()
     torch.cuda.synchronize(device)

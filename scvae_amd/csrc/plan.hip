@@ -838,7 +838,11 @@ int plan_side_fork(scvae_plan* p, hipStream_t s, int point) {
   //  16384 cells -64 / -190 / -170 us of 7.3 ms)
   static const int jobs_env = [] { const char* e = getenv("SCVAE_SIDE_JOBS_AT"); return e ? atoi(e) : -1; }();
   const int jobs_at = jobs_env >= 0 ? jobs_env : (w->fetch_n >= 4096 ? 2 : 1);
-  const bool jobs = !p->side_jobs_done && (w->fetch_out || w->noise_out) && point >= jobs_at;
+  // (point 4: an EVALUATION step, right after the input layer's product -- the next fetch runs
+  //  beside the hidden layers' small launches, ahead of the head kernel, which does not tolerate
+  //  a neighbour)
+  const bool jobs = !p->side_jobs_done && (w->fetch_out || w->noise_out) &&
+                    (point == 4 || (point < 4 && point >= jobs_at));
   // (VAE plans: the likelihood heads are the tail of the parameter buffer)
   const bool adam = w->adam_m && p->side_adam_from == p->layout.n_params &&
                     p->cfg.model_type == SCVAE_MODEL_VAE &&
@@ -987,9 +991,14 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     }
     h = p->enc.back().h; ld = p->enc.back().n_out;
   } else {
+  bool first = true;
   for (auto& d : p->enc) {
     if ((rc = dense_forward(p, s, d, h, ld, B, 1, true, training))) return rc;
     h = d.h; ld = d.n_out;
+    // (evaluation steps: the fetch / noise of the next step leave the stream here)
+    if (first && !training)
+      if ((rc = plan_side_fork(p, s, 4))) return rc;
+    first = false;
   }
   }
   Dense& mu = p->mu;

@@ -868,12 +868,54 @@ class ModelBase:
                 largest, x.u16_pitch, dtype=torch.uint16, device=device)
         self._evaluation_counter = getattr(
             self, "_evaluation_counter", 0) + 1
-        for j, (i, cells, _) in enumerate(chunks):
-            if world > 1 and j % world != rank:
-                continue
+        noise_stream = (1 << 40) + self._evaluation_counter * (1 << 20)
+        mine = [(j, i, cells) for j, (i, cells, _) in enumerate(chunks)
+                if not (world > 1 and j % world != rank)]
+        # uint16 steps carry the fetch and the noise of the NEXT step
+        # (scvae_side_work: they leave the stream after the input layer's
+        # product and run beside the hidden layers); two sets of buffers
+        carried = (u16_buffer is not None and len(mine) > 1 and all(
+            engine.accepts_counts_u16(cells, False) for _, _, cells in mine))
+        if carried:
+            u16_sets = [u16_buffer, torch.empty_like(u16_buffer)]
+            rc_sets = [row_const, torch.empty_like(row_const)]
+            eps_sets = [eps_buffer, torch.empty_like(eps_buffer)
+                        if eps_buffer is not None else None]
+
+            def carried_request(position):
+                _, first, count = mine[position]
+                slot = position & 1
+                request = x.request(all_rows[first:first + count],
+                                    u16_sets[slot][:count],
+                                    rc_sets[slot][:count])
+                noise = None
+                if not deterministic_z:
+                    noise = self._noise_request(
+                        eps_sets[slot][:int(numpy.prod(
+                            self._eps_shape(samples, count)))],
+                        samples, count, n, first, noise_stream)
+                return request, noise
+        for position, (j, i, cells) in enumerate(mine):
             rows = all_rows[i:i + cells]
             xb, tb, rc = x_buffer[:cells], t_buffer[:cells], row_const[:cells]
-            if (u16_buffer is not None
+            eps = None
+            next_request = next_noise = None
+            if carried:
+                slot = position & 1
+                if position == 0:
+                    request, noise = carried_request(0)
+                    request.issue()
+                    if noise is not None:
+                        from scvae_amd.minibatch import philox_normal_blocks
+                        philox_normal_blocks(**noise)
+                xb = tb = u16_sets[slot][:cells]
+                rc = rc_sets[slot][:cells]
+                if not deterministic_z:
+                    eps = eps_sets[slot][:int(numpy.prod(
+                        self._eps_shape(samples, cells)))]
+                if position + 1 < len(mine):
+                    next_request, next_noise = carried_request(position + 1)
+            elif (u16_buffer is not None
                     and engine.accepts_counts_u16(cells, False)):
                 xb = tb = x.gather_counts_u16(
                     rows, out=u16_buffer[:cells], row_const_out=rc)
@@ -881,16 +923,13 @@ class ModelBase:
                 t.gather_dense(rows, out=tb, row_const_out=rc)
                 if x is not t:
                     x.gather_dense(rows, out=xb)
-            eps = None
-            if not deterministic_z:
+            if not deterministic_z and not carried:
                 eps = eps_buffer[:int(numpy.prod(
                     self._eps_shape(samples, cells)))]
                 # (keyed by the cell's row in the set, not by the step: a
                 #  cell draws the same noise however the pass is cut into
                 #  steps or dealt to ranks)
-                self._draw_noise(
-                    eps, samples, cells, n, i,
-                    (1 << 40) + self._evaluation_counter * (1 << 20))
+                self._draw_noise(eps, samples, cells, n, i, noise_stream)
             out = {"q_z_mean": latent[i:i + cells],
                    "kl_neurons": kl_neurons[j]}
             out.update(self._evaluation_step_outputs(
@@ -902,7 +941,8 @@ class ModelBase:
             engine.step(xb, tb, eps=eps, row_const=rc, training=False,
                         n_iw=n_iw, n_mc=n_mc, deterministic_z=deterministic_z,
                         outputs=out, scalars=scalars[j], decoder_extra=de,
-                        count_sum=cs, x_counts=x.integer_counts)
+                        count_sum=cs, x_counts=x.integer_counts,
+                        next_minibatch=next_request, next_noise=next_noise)
         # a step's means count once per minibatch it holds
         scalars *= weights[:, None]
         kl_neurons *= weights[:, None]

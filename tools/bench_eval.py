@@ -37,17 +37,25 @@ def main():
     if args.unfused:
         eng.set_fused(False)
     u16 = matrix.integer_counts and eng.accepts_counts_u16(B, False)
-    x = (torch.empty(B, matrix.u16_pitch, dtype=torch.uint16, device=dev) if u16
-         else torch.empty(B, args.features, device=dev))
-    rc = torch.empty(B, device=dev)
+    carry = os.environ.get("BENCH_EVAL_CARRY", "1") != "0"
+    x = [(torch.empty(B, matrix.u16_pitch, dtype=torch.uint16, device=dev) if u16
+          else torch.empty(B, args.features, device=dev)) for _ in range(2)]
+    rc = [torch.empty(B, device=dev) for _ in range(2)]
     eps = torch.randn(1, B, args.latent, device=dev)
     rows = torch.arange(args.cells, device=dev)
 
-    def step(i):
+    def request(i):
         r = rows[(i * B) % (args.cells - B + 1):][:B]
-        matrix.request(r, x, rc).issue()
-        eng.step(x, x, eps=eps, row_const=rc, training=False,
-                 x_counts=matrix.integer_counts)
+        return matrix.request(r, x[i & 1], rc[i & 1])
+    request(0).issue()
+
+    def step(i):
+        # (BENCH_EVAL_CARRY=0: the fetch in line in front of the step, as before round 6)
+        if not carry and i > 0:
+            request(i).issue()
+        eng.step(x[i & 1], x[i & 1], eps=eps, row_const=rc[i & 1], training=False,
+                 x_counts=matrix.integer_counts,
+                 next_minibatch=request(i + 1) if carry else None)
     for i in range(10):
         step(i)
     torch.cuda.synchronize()
