@@ -138,11 +138,12 @@ class GpuClocks:
             try:
                 text, _ = self.process.communicate(timeout=30)
                 card = next(iter(json.loads(text).values()))
+                # (rocm-smi reports a level and a speed per clock: "sclk clock level:" "1",
+                #  "sclk clock speed:" "(2400Mhz)" -- keep what it says under its own key)
                 for key, value in card.items():
-                    low = key.lower()
-                    for name in ("sclk", "mclk", "fclk", "socclk"):
-                        if low.startswith(name):
-                            self.out[name] = value.strip("()")
+                    low = key.lower().rstrip(":")
+                    if low.split(" ")[0] in ("sclk", "mclk", "fclk", "socclk"):
+                        self.out[low.replace(" ", "_")] = str(value).strip("()")
             except Exception as error:   # noqa: BLE001
                 self.out["error"] = repr(error)[:200]
                 try:
