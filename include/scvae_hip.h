@@ -245,7 +245,8 @@ int scvae_plan_set_mid_chain(scvae_plan* plan, int32_t enabled);
  * make a block of 512.  T = scvae_count_tiles_padded(F) tiles per group (a multiple of 16).
  *   entries[tile_ptr[g][t] & 0x7FFFFFFF .. tile_ptr[g][t + 1] & 0x7FFFFFFF)  bucket (g, t),
  *     tiles ascending, so block b of group g is the run block_ptr[g][b] .. block_ptr[g][b + 1];
- *   entry = value << 16 | lo << 13 | (tile & 15) << 9 | (row & 15) << 5 | (gene & 31);
+ *   entry = bf16(value) << 16 | lo << 13 | (tile & 15) << 9 | (row & 15) << 5 | (gene & 31)
+ *     (the value as its bfloat16 bit pattern: the kernels store the upper half as it is);
  *   a count of up to 8 significant bits is one entry (lo = 0); a larger one is two: its upper 8
  *   significant bits (lo = 0) and the remainder (lo = 1) -- the exact bf16 cut of the dense
  *   kernels; bit 31 of a pointer: that bucket / block holds lo entries.

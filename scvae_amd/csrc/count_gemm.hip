@@ -769,8 +769,8 @@ int count_gemm_u16(hipStream_t stream, int mode, const uint16_t* x, int ldx, int
 // gene tile t are entries[tile_ptr[g][t] .. tile_ptr[g][t + 1]) -- in no particular order within
 // the bucket --, tiles ascending, so that 16 tiles (a block of 512 genes) are one contiguous run
 // block_ptr[g][b] .. block_ptr[g][b + 1].  An entry is
-//     value << 16 | lo << 13 | (tile & 15) << 9 | row << 5 | gene & 31
-// with value the count cut as the dense kernels cut it: a count of up to 8 significant bits is
+//     bf16(value) << 16 | lo << 13 | (tile & 15) << 9 | row << 5 | gene & 31
+// with value the count cut as the dense kernels cut it (and carried as its bf16 bit pattern): a count of up to 8 significant bits is
 // one entry; a larger one is two, its upper 8 significant bits (lo = 0) and the remainder
 // (lo = 1), both exact in bf16.  Bit 31 of a pointer says that the bucket (the block) holds lo
 // entries.  The sparse kernels below scatter a bucket into the zeroed LDS tile the dense kernels
@@ -790,6 +790,9 @@ __device__ __forceinline__ void ct_cut(unsigned v, unsigned& hi, unsigned& lo) {
   hi = (v >> sh) << sh;
   lo = v - hi;
 }
+
+// bf16 bits of an integer of at most 8 significant bits (exact)
+__device__ __forceinline__ unsigned ct_bits(unsigned v) { return __float_as_uint((float)v) >> 16; }
 
 // One workgroup per group of 16 rows (a wave per row): count the entries of every tile, scan,
 // place.  Rows of one group land in the group's own region [g * cap, (g + 1) * cap) of `ent`, so
@@ -882,8 +885,8 @@ __global__ __launch_bounds__(1024) void csr_count_tiles_kernel(
       const unsigned slot = atomicAdd(&cnt[t], l ? 2u : 1u);
       const unsigned key = ((unsigned)(t & 15) << 9) | ((unsigned)w << 5) | (unsigned)(c[u] & 31);
       uint32_t* dst = ent + gbase + off[t] + slot;
-      dst[0] = (h << 16) | key;
-      if (l) dst[1] = (l << 16) | (1u << 13) | key;
+      dst[0] = (ct_bits(h) << 16) | key;
+      if (l) dst[1] = (ct_bits(l) << 16) | (1u << 13) | key;
     }
   }
 }
@@ -933,43 +936,65 @@ int csr_count_tiles(hipStream_t stream, const int64_t* indptr, const int32_t* in
   return 0;
 }
 
-// entry -> bf16 bits of its value (at most 8 significant bits: the conversion is exact)
-__device__ __forceinline__ unsigned ct_bf16(unsigned e) {
-  return __float_as_uint((float)(e >> 16)) >> 16;
-}
+// Probe build (-DCT_PROF=1, scvae_amd/csrc/build_ctprof.sh): s_memtime sums per section of a chunk
+// for the eight waves of workgroup (0, 0) of count_tiles_fwd_kernel (scvae_ct_prof_dump,
+// tools/ct_prof.py).
+#ifndef CT_PROF
+#define CT_PROF 0
+#endif
+#if CT_PROF
+__device__ unsigned long long ct_prof[8 * 8];
+#define CT_STAMP(k)                                                         \
+  do {                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                      \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();           \
+    pacc[k] += now_ - plast; plast = now_;                                  \
+    __builtin_amdgcn_sched_barrier(0);                                      \
+  } while (0)
+#else
+#define CT_STAMP(k) do {} while (0)
+#endif
+#define CT_FENCE __builtin_amdgcn_sched_barrier(0)
 
 // ---- forward from tiles: count_gemm_fwd_kernel with the [256, 32] tile of x scattered into LDS
 // from its non-zeros (16 buckets: one per group of 16 rows, 32 lanes each) instead of copied from
-// the dense batch.  With the bytes gone the dense kernel's rhythm -- every wave stages, then every
-// wave multiplies -- leaves the matrix pipe idle while the tile is built (measured: 122 us for 50
-// us of MFMA at 4096 x 32 738).  Here the hi plane has THREE buffers -- chunk j is multiplied
-// from buffer j % 3 while chunk j + 1 is scattered into the next (zeroed one iteration earlier)
-// and the third is zeroed -- so one barrier per chunk suffices, and the two waves of a SIMD run
-// the iteration in opposite order: waves 0-3 stage first and multiply second, waves 4-7 multiply
-// first.  The lo plane (counts above 8 significant bits: 0.02 % of the entries, 8 % of the
-// chunks) has one buffer, filled at the start of its chunk's own iteration behind an extra
-// barrier.  Entries travel two chunks ahead (three loads per lane: 96 entries per bucket, more
-// take a direct loop), pointers three.  Same MFMAs on the same operands in the same order as the
-// dense kernel: bit-identical.
+// the dense batch.  Same MFMAs on the same operands in the same order: bit-identical.
+//
+// What bounds these kernels (round 6, s_memtime per section + the ISA): not bytes and not the
+// matrix pipe but the INSTRUCTIONS A WAVE ISSUES per chunk -- a wave issues one instruction every
+// ~4 cycles, in order; the first version spent ~500 of them per chunk beside its 24 MFMAs (64-bit
+// address arithmetic per load, exec-mask branches around every predicated entry, per-use
+// conversions): 3.8 k cycles per chunk for 1.5 k of matrix work, whatever the barriers, the
+// buffer count or the order of the pieces.  Hence this shape:
+//   * entries carry their bf16 value bits (the fetch converts once), so an entry becomes an LDS
+//     address (bit field extract x 2, one multiply-add) and a 16-bit store of its upper half;
+//   * no branches in the common path: a lane without an entry -- or with a lo entry in the hi
+//     pass -- stores to a dummy slot of its own;
+//   * every global address is a uniform base (SGPR) + a per-thread 32-bit offset computed once;
+//   * three hi buffers (chunk j multiplied from buffer j % 3, chunk j + 1 scattered into the
+//     next, the third zeroed): one barrier per chunk; the lo plane (counts above 8 significant
+//     bits: 0.02 % of the entries, 8 % of the chunks) has one buffer, filled behind barriers of
+//     its own at the start of its chunk's iteration;
+//   * the chunk's MFMAs in six groups with the staging pieces between them.
 constexpr int CTF_NE = 3;
+constexpr int CTF_DUMMY = 512 * 2;      // bytes: a 2-byte slot per thread for masked stores
 
 static size_t ctf_lds_bytes(int NQ) {
-  return 4 * (size_t)CF_A_BYTES + 2 * (size_t)(3 * 64 * NQ * CG_ROW) + 3 * 8 * sizeof(int);
+  return 4 * (size_t)CF_A_BYTES + 2 * (size_t)(3 * 64 * NQ * CG_ROW) + 3 * 8 * sizeof(int) +
+         CTF_DUMMY;
 }
 
 template <int NQ>
 __global__ __launch_bounds__(512) void count_tiles_fwd_kernel(
     const uint32_t* __restrict__ ent, const uint32_t* __restrict__ tptr, int ntp, int n_groups,
     int M, int K, const uint16_t* __restrict__ T, int Kpad, int N, int k_chunk,
-    float* __restrict__ out, int ldo, const float* __restrict__ bias, int act, int direct,
-    int dbg) {
+    float* __restrict__ out, int ldo, const float* __restrict__ bias, int act, int direct) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cf_smem[];
   constexpr int NCOL = 64 * NQ;
   constexpr int B_BYTES = 3 * NCOL * CG_ROW;
-  unsigned char* Ahi = cf_smem;                         // [3][256][80]
-  unsigned char* Alo = Ahi + 3 * CF_A_BYTES;            // [256][80]
-  unsigned char* Bsm = Alo + CF_A_BYTES;                // [2][3][NCOL][80]
-  int* lo_flag = reinterpret_cast<int*>(Bsm + 2 * B_BYTES);   // [3][8]
+  constexpr int AHI = 0, ALO = 3 * CF_A_BYTES, BSM = 4 * CF_A_BYTES, FLG = BSM + 2 * B_BYTES,
+                DUM = FLG + 3 * 8 * 4;
+  int* lo_flag = reinterpret_cast<int*>(cf_smem + FLG);   // [3][8]
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, kg = lane >> 5;
@@ -987,80 +1012,108 @@ __global__ __launch_bounds__(512) void count_tiles_fwd_kernel(
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][q][i] = 0.f;
 
-  // this thread's bucket: group grp of the block's 16, lane gl of its 32
-  const int grp = tid >> 5, gl = tid & 31;
+  // ---- per-thread constants: this thread's bucket (group grp of the block's 16, lane gl of its
+  //      32) and its pieces of the W planes, as 32-bit offsets from uniform bases ----
+  const int grp = tid >> 5;
+  const unsigned gl = tid & 31;
   const int cc = blockIdx.x * (CF_BM / CT_ROWS) + grp;
   const bool live = cc < n_groups;
-  const uint32_t* tp = tptr + (size_t)(live ? cc : 0) * (ntp + 1);
-  const int a_row = (CT_ROWS * grp) * CG_ROW;
+  const unsigned tp_off = (unsigned)(live ? cc : 0) * (unsigned)(ntp + 1);      // elements
+  const unsigned a_base = (unsigned)(CT_ROWS * grp) * CG_ROW;
+  const unsigned dummy = DUM + 2u * tid;
+  unsigned boff[3], bst[3];
+  bool bon[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int p2 = tid + 512 * i;                       // (term, column, quarter)
+    const int row = p2 >> 2, prt = p2 & 3;
+    const int term = row >> 7, col = row & (CG_NP - 1);
+    const int rowl = col < N ? row : row - col + (N - 1);
+    bon[i] = col < NCOL;
+    boff[i] = ((unsigned)rowl * (unsigned)Kpad + prt * 8) * 2u;                 // bytes
+    bst[i] = BSM + (term * NCOL + col) * CG_ROW + prt * 16;
+  }
+  for (int i = tid; i < (4 * CF_A_BYTES) / 16; i += 512)
+    reinterpret_cast<u32x4*>(cf_smem)[i] = u32x4{0u, 0u, 0u, 0u};
 
-  auto zero_plane = [&](unsigned char* plane) {
-    u32x4* z = reinterpret_cast<u32x4*>(plane);
-    z[tid] = u32x4{0u, 0u, 0u, 0u};
-    z[tid + 512] = u32x4{0u, 0u, 0u, 0u};
-    if (tid < CF_A_BYTES / 16 - 1024) z[tid + 1024] = u32x4{0u, 0u, 0u, 0u};
-  };
-  for (int i = tid; i < 4 * CF_A_BYTES / 16; i += 512)
-    reinterpret_cast<u32x4*>(Ahi)[i] = u32x4{0u, 0u, 0u, 0u};
-
-  // pointers of a chunk (clamped to the split's last: unconditional loads)
   struct Ptr { unsigned s, e; };
-  auto load_ptr = [&](int kc) {
-    const int t = min(kc, k_last) / CG_BK;
-    Ptr p; p.s = tp[t]; p.e = tp[t + 1];
+  auto load_ptr = [&](int kc) {     // (clamped to the split's last chunk: unconditional loads)
+    const uint32_t* base = tptr + min(kc, k_last) / CG_BK;                       // uniform
+    Ptr p; p.s = base[tp_off]; p.e = base[tp_off + 1];
     return p;
   };
-  unsigned E[2][CTF_NE];
-  unsigned Es[2], En[2];           // first entry / number of entries (| CT_LO) of the slot's bucket
+  unsigned E[2][CTF_NE], Es[2], En[2];     // entries / first index / count (| CT_LO) of a slot
   u32x4 breg[2][3];
   auto load_chunk = [&](int kc, Ptr p, auto slot_tag) {
     constexpr int SLOT = decltype(slot_tag)::value;
-    const unsigned s = p.s & CT_MASK, e = p.e & CT_MASK;
-    const unsigned n = (live && kc < k_end) ? e - s : 0u;
-    Es[SLOT] = s; En[SLOT] = n | (((p.s & CT_LO) && n) ? CT_LO : 0u);
+    const unsigned s0 = p.s & CT_MASK;
+    const unsigned n = (live && kc < k_end) ? (p.e & CT_MASK) - s0 : 0u;
+    Es[SLOT] = s0; En[SLOT] = n | (((p.s & CT_LO) && n) ? CT_LO : 0u);
 #pragma unroll
     for (int k = 0; k < CTF_NE; ++k) {
-      const unsigned i = gl + 32 * k;
-      E[SLOT][k] = ent[i < n ? s + i : 0u];
+      const unsigned i = gl + 32u * k;
+      E[SLOT][k] = ent[i < n ? s0 + i : 0u];
     }
-    const int kb = min(kc, k_last);
+    const unsigned char* tb = reinterpret_cast<const unsigned char*>(T) +
+                              (size_t)min(kc, k_last) * 2;                      // uniform
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int p2 = tid + 512 * i;                     // (term, column, quarter)
-      const int row = p2 >> 2, prt = p2 & 3;
-      const int col = row & (CG_NP - 1), rowl = col < N ? row : row - col + (N - 1);
-      if (col < NCOL)
-        breg[SLOT][i] = *reinterpret_cast<const u32x4*>(T + (size_t)rowl * Kpad + kb + prt * 8);
-    }
+    for (int i = 0; i < 3; ++i)
+      if (bon[i]) breg[SLOT][i] = *reinterpret_cast<const u32x4*>(tb + boff[i]);
   };
-  auto put = [&](unsigned e, unsigned char* plane) {
-    *reinterpret_cast<uint16_t*>(plane + a_row + ((e >> 5) & 15u) * CG_ROW + (e & 31u) * 2) =
-        (uint16_t)ct_bf16(e);
+  // entry -> LDS byte offset within a plane
+  auto where = [&](unsigned e) {
+    return a_base + __builtin_amdgcn_ubfe(e, 5, 4) * (unsigned)CG_ROW + ((e & 31u) << 1);
   };
-  // scatter the hi (LO = false) or lo entries of the slot's bucket into `plane`
-  auto scatter = [&](unsigned char* plane, auto slot_tag, bool want_lo) {
+  auto put16 = [&](unsigned addr, unsigned e) {
+    *reinterpret_cast<uint16_t*>(cf_smem + addr) = (uint16_t)(e >> 16);
+  };
+  // the hi entries of the slot's bucket -> plane at byte offset `plane` (branch-free: what a lane
+  // does not hold, or a lo entry, goes to the lane's dummy slot)
+  auto scatter_hi = [&](unsigned plane, auto slot_tag) {
     constexpr int SLOT = decltype(slot_tag)::value;
     const unsigned n = En[SLOT] & CT_MASK;
 #pragma unroll
-    for (int k = 0; k < CTF_NE; ++k)
-      if (gl + 32u * k < n && (((E[SLOT][k] >> 13) & 1u) != 0u) == want_lo) put(E[SLOT][k], plane);
+    for (int k = 0; k < CTF_NE; ++k) {
+      const unsigned e = E[SLOT][k];
+      const bool ok = (gl + 32u * k < n) && !(e & (1u << 13));
+      put16(ok ? plane + where(e) : dummy, e);
+    }
+    if (n > 32u * CTF_NE)        // (a bucket beyond the three loads: rare, a direct loop)
+      for (unsigned i = gl + 32u * CTF_NE; i < n; i += 32u) {
+        const unsigned e = ent[Es[SLOT] + i];
+        if (!(e & (1u << 13))) put16(plane + where(e), e);
+      }
+  };
+  auto scatter_lo = [&](auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    const unsigned n = En[SLOT] & CT_MASK;
+#pragma unroll
+    for (int k = 0; k < CTF_NE; ++k) {
+      const unsigned e = E[SLOT][k];
+      if ((gl + 32u * k < n) && (e & (1u << 13))) put16(ALO + where(e), e);
+    }
     if (n > 32u * CTF_NE)
       for (unsigned i = gl + 32u * CTF_NE; i < n; i += 32u) {
         const unsigned e = ent[Es[SLOT] + i];
-        if ((((e >> 13) & 1u) != 0u) == want_lo) put(e, plane);
+        if (e & (1u << 13)) put16(ALO + where(e), e);
       }
   };
   auto store_b = [&](int buf, auto slot_tag) {
     constexpr int SLOT = decltype(slot_tag)::value;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int p2 = tid + 512 * i;
-      const int row = p2 >> 2, prt = p2 & 3;
-      const int term = row >> 7, col = row & (CG_NP - 1);
-      if (col < NCOL)
-        *reinterpret_cast<u32x4*>(Bsm + buf * B_BYTES + (term * NCOL + col) * CG_ROW + prt * 16) =
-            breg[SLOT][i];
-    }
+    for (int i = 0; i < 3; ++i)
+      if (bon[i])
+        *reinterpret_cast<u32x4*>(cf_smem + bst[i] + buf * B_BYTES) = breg[SLOT][i];
+  };
+  auto zero_plane = [&](unsigned plane) {
+    u32x4* z = reinterpret_cast<u32x4*>(cf_smem + plane);
+    z[tid] = u32x4{0u, 0u, 0u, 0u};
+    z[tid + 512] = u32x4{0u, 0u, 0u, 0u};
+    if (tid < CF_A_BYTES / 16 - 1024) z[tid + 1024] = u32x4{0u, 0u, 0u, 0u};
+  };
+  auto flag_of = [&](auto slot_tag) {       // (wave-uniform) the slot's bucket holds lo entries
+    constexpr int SLOT = decltype(slot_tag)::value;
+    return (bool)__builtin_amdgcn_readfirstlane(__any((int)((En[SLOT] & CT_LO) != 0u)));
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
@@ -1071,11 +1124,9 @@ __global__ __launch_bounds__(512) void count_tiles_fwd_kernel(
     load_chunk(k_begin, load_ptr(k_begin), S0{});
     load_chunk(k_begin + CG_BK, load_ptr(k_begin + CG_BK), S1{});
     pn = load_ptr(k_begin + 2 * CG_BK);
-    scatter(Ahi, S0{}, false);
-    {
-      const bool need = __builtin_amdgcn_readfirstlane(__any((int)((En[0] & CT_LO) != 0u)));
-      if (lane == 0) lo_flag[w] = need ? 1 : 0;
-    }
+    scatter_hi(AHI, S0{});
+    const bool need = flag_of(S0{});
+    if (lane == 0) lo_flag[w] = need ? 1 : 0;
     store_b(0, S0{});
   }
   __syncthreads();
@@ -1084,6 +1135,9 @@ __global__ __launch_bounds__(512) void count_tiles_fwd_kernel(
   const int b_frag = (q0 * 32 + li) * CG_ROW + 32 * kg;      // + term * NCOL rows, + 32 rows * q
   bool lo_dirty = false;                                // the lo plane holds entries
   int ab = 0;                                           // hi buffer of the current chunk (j % 3)
+#if CT_PROF
+  unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = __builtin_amdgcn_s_memtime();
+#endif
   auto chunk = [&](int kc, auto buf_tag) {
     constexpr int BUF = decltype(buf_tag)::value;       // B buffer / register slot of chunk j
     using Other = std::integral_constant<int, BUF ^ 1>;
@@ -1093,88 +1147,87 @@ __global__ __launch_bounds__(512) void count_tiles_fwd_kernel(
     // ---- counts above 8 significant bits in this chunk (rare): the lo plane, behind barriers of
     //      its own -- the entries of chunk j are still in slot BUF ----
     if (lo_dirty || need_lo) {
-      if (lo_dirty) { zero_plane(Alo); lds_barrier(); }
-      if (need_lo) { scatter(Alo, buf_tag, true); lds_barrier(); }
+      if (lo_dirty) { zero_plane(ALO); lds_barrier(); }
+      if (need_lo) { scatter_lo(buf_tag); lds_barrier(); }
       lo_dirty = need_lo;
     }
-    auto stage = [&]() {
-      // buffer j + 2 (chunk j - 1, multiplied before the last barrier): zeroed for chunk j + 2
-      if (!(dbg & 8)) zero_plane(Ahi + ab2 * CF_A_BYTES);
-      // chunk j + 2 -> slot BUF (chunk j has left it); pointers of j + 3
-      {
-        const Ptr p = pn;
-        pn = load_ptr(kc + 3 * CG_BK);
-        load_chunk(kc + 2 * CG_BK, p, buf_tag);
-      }
-      // chunk j + 1 (slot BUF ^ 1, requested an iteration ago) -> buffer j + 1, zeroed an
-      // iteration ago; its dA / W planes -> B buffer BUF ^ 1 (read by chunk j - 1)
-      if (!(dbg & 4)) scatter(Ahi + ab1 * CF_A_BYTES, Other{}, false);
-      {
-        const bool need =
-            __builtin_amdgcn_readfirstlane(__any((int)((En[BUF ^ 1] & CT_LO) != 0u)));
-        if (lane == 0) lo_flag[ab1 * 8 + w] = need ? 1 : 0;
-      }
-      store_b(BUF ^ 1, Other{});
-    };
-    auto multiply = [&]() {
-      if (dbg & 2) return;
-      const unsigned char* ah = Ahi + ab * CF_A_BYTES + a_frag;
-      const unsigned char* al = Alo + a_frag;
-      const unsigned char* bb = Bsm + BUF * B_BYTES + b_frag;
-      // every fragment of the chunk requested up front (16 ds_read_b128 in flight, counted
-      // waits): with the reads issued next to their MFMAs the pipe drained at every pair
-      // (measured: 41 % of the wave cycles parked at s_waitcnt for 44 % matrix-pipe time)
-      bf16x8 fh[2][2], fl[2][2], fb[2][3][NQ];
+    CT_STAMP(0);
+    const unsigned char* ah = cf_smem + AHI + ab * CF_A_BYTES + a_frag;
+    const unsigned char* al = cf_smem + ALO + a_frag;
+    const unsigned char* bb = cf_smem + BSM + BUF * B_BYTES + b_frag;
+    bf16x8 fh[2][2], fl[2][2], fb[2][3][NQ];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        fh[s][t] = as_bf16x8(*reinterpret_cast<const u32x4*>(ah + t * 32 * CG_ROW + 16 * s));
+#pragma unroll
+      for (int term = 2; term >= 0; --term)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          fb[s][term][q] = as_bf16x8(*reinterpret_cast<const u32x4*>(
+              bb + (term * NCOL + q * 32) * CG_ROW + 16 * s));
+    }
+    if (need_lo) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          fh[s][t] = as_bf16x8(*reinterpret_cast<const u32x4*>(ah + t * 32 * CG_ROW + 16 * s));
-#pragma unroll
-        for (int term = 2; term >= 0; --term)
-#pragma unroll
-          for (int q = 0; q < NQ; ++q)
-            fb[s][term][q] = as_bf16x8(*reinterpret_cast<const u32x4*>(
-                bb + (term * NCOL + q * 32) * CG_ROW + 16 * s));
-      }
+          fl[s][t] = as_bf16x8(*reinterpret_cast<const u32x4*>(al + t * 32 * CG_ROW + 16 * s));
+    }
+    auto mm = [&](int s, int term) {
       if (need_lo) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-            fl[s][t] = as_bf16x8(*reinterpret_cast<const u32x4*>(al + t * 32 * CG_ROW + 16 * s));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-#pragma unroll
-        for (int term = 2; term >= 0; --term) {           // smallest term first
-          if (need_lo) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-              acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s][0], fb[s][term][q], acc[0][q], 0, 0, 0);
-              acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s][1], fb[s][term][q], acc[1][q], 0, 0, 0);
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s][0], fb[s][term][q], acc[0][q], 0, 0, 0);
-            acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s][1], fb[s][term][q], acc[1][q], 0, 0, 0);
-          }
+        for (int q = 0; q < NQ; ++q) {
+          acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s][0], fb[s][term][q], acc[0][q], 0, 0, 0);
+          acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s][1], fb[s][term][q], acc[1][q], 0, 0, 0);
         }
       }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s][0], fb[s][term][q], acc[0][q], 0, 0, 0);
+        acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s][1], fb[s][term][q], acc[1][q], 0, 0, 0);
+      }
     };
-    stage();
-    __builtin_amdgcn_sched_barrier(0);
-    multiply();
-    __builtin_amdgcn_sched_barrier(0);
+    // buffer j + 2 (chunk j - 1, multiplied before the last barrier): zeroed for chunk j + 2
+    zero_plane(AHI + ab2 * CF_A_BYTES);
+    CT_FENCE; CT_STAMP(1);
+    mm(0, 2); mm(0, 1);
+    CT_FENCE;
+    {   // chunk j + 2 -> slot BUF (chunk j has left it); pointers of j + 3
+      const Ptr p = pn;
+      pn = load_ptr(kc + 3 * CG_BK);
+      load_chunk(kc + 2 * CG_BK, p, buf_tag);
+    }
+    CT_FENCE; CT_STAMP(2);
+    mm(0, 0); mm(1, 2);
+    CT_FENCE;
+    // chunk j + 1 (slot BUF ^ 1, requested an iteration ago) -> buffer j + 1, zeroed an
+    // iteration ago
+    scatter_hi(AHI + ab1 * CF_A_BYTES, Other{});
+    {
+      const bool need = flag_of(Other{});
+      if (lane == 0) lo_flag[ab1 * 8 + w] = need ? 1 : 0;
+    }
+    CT_FENCE; CT_STAMP(3);
+    mm(1, 1);
+    CT_FENCE;
+    store_b(BUF ^ 1, Other{});      // its W planes -> B buffer BUF ^ 1 (read by chunk j - 1)
+    CT_FENCE; CT_STAMP(4);
+    mm(1, 0);
+    CT_FENCE; CT_STAMP(5);
     lds_barrier();
+    CT_STAMP(6);
     ab = ab1;
   };
   for (int kc = k_begin; kc < k_end; kc += 2 * CG_BK) {
     chunk(kc, S0{});
     if (kc + CG_BK < k_end) chunk(kc + CG_BK, S1{});
   }
+#if CT_PROF
+  if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)
+    for (int k_ = 0; k_ < 8; ++k_) ct_prof[w * 8 + k_] = pacc[k_];
+#endif
 
   float* dst = direct ? out : out + (size_t)blockIdx.y * M * ldo;
 #pragma unroll
@@ -1198,21 +1251,21 @@ __global__ __launch_bounds__(512) void count_tiles_fwd_kernel(
 
 // ---- weight gradient from tiles: the [512 genes, 16 cells] operand of a chunk scattered into
 // LDS from one contiguous run of entries (the 16 buckets of gene block x group), eight waves of
-// 64 genes; dA planes as in count_gemm_dw_kernel.  Three hi buffers, one lo buffer, one barrier
-// per chunk, the two waves of a SIMD in opposite order -- as in the forward kernel above.
+// 64 genes; dA planes as in count_gemm_dw_kernel.  Built like the forward kernel above: three hi
+// buffers, one lo buffer, one barrier per chunk, branch-free scatter, 32-bit offsets from uniform
+// bases, the MFMAs in groups with the staging between them.
 constexpr int CTD_NE = 2;
 constexpr int CTD_A_BYTES = 512 * CD_ROW;
+constexpr int CTD_DUMMY = 512 * 2;
 
 template <int NT>
 __global__ __launch_bounds__(512, 1) void count_tiles_dw_kernel(
     const uint32_t* __restrict__ ent, const uint32_t* __restrict__ gptr, int ngb, int M, int K,
     const uint16_t* __restrict__ T, int Kpad, int N, int k_chunk, float* __restrict__ out,
-    int ldo, int dbg) {
+    int ldo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cd_smem[];
   constexpr int B_BYTES = 3 * CG_NP * CD_ROW;
-  unsigned char* Ahi = cd_smem;                         // [3][512][48]
-  unsigned char* Alo = Ahi + 3 * CTD_A_BYTES;           // [512][48]
-  unsigned char* Bs = Alo + CTD_A_BYTES;                // [2][3][128][48]
+  constexpr int AHI = 0, ALO = 3 * CTD_A_BYTES, BSM = 4 * CTD_A_BYTES, DUM = BSM + 2 * B_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, kg = lane >> 5;
@@ -1231,69 +1284,92 @@ __global__ __launch_bounds__(512, 1) void count_tiles_dw_kernel(
       for (int i = 0; i < 16; ++i) acc[t][q][i] = 0.f;
 
   for (int i = tid; i < 4 * CTD_A_BYTES / 16; i += 512)
-    reinterpret_cast<u32x4*>(Ahi)[i] = u32x4{0u, 0u, 0u, 0u};
-  auto zero_plane = [&](unsigned char* plane) {
-    u32x4* z = reinterpret_cast<u32x4*>(plane);
+    reinterpret_cast<u32x4*>(cd_smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  auto zero_plane = [&](unsigned plane) {
+    u32x4* z = reinterpret_cast<u32x4*>(cd_smem + plane);
 #pragma unroll
     for (int i = 0; i < CTD_A_BYTES / 16 / 512; ++i) z[tid + 512 * i] = u32x4{0u, 0u, 0u, 0u};
   };
+  const unsigned dummy = DUM + 2u * tid;
+  constexpr int NPC = 2;                                // 768 pieces of dA over 512 threads
+  unsigned boff[NPC], bst[NPC];
+  bool bon[NPC];
+#pragma unroll
+  for (int i = 0; i < NPC; ++i) {
+    const int p2 = tid + 512 * i;                // 768 pieces: (term, column, half)
+    const int row = p2 >> 1, part = p2 & 1;
+    const int col = row & (CG_NP - 1), rowl = col < N ? row : row - col + (N - 1);
+    bon[i] = p2 < 768 && col < NT * 32;
+    boff[i] = ((unsigned)(bon[i] ? rowl : 0) * (unsigned)Kpad + part * 8) * 2u;
+    bst[i] = BSM + row * CD_ROW + part * 16;
+  }
   struct Ptr { unsigned s, e; };
   auto load_ptr = [&](int kc) {
     const uint32_t* gp = gptr + (size_t)(min(kc, k_last) / CD_BK) * (ngb + 1) + gb;   // uniform
     Ptr p; p.s = gp[0]; p.e = gp[1];
     return p;
   };
-  constexpr int NPC = 2;                                // 768 pieces of dA over 512 threads
-  unsigned E[2][CTD_NE];
-  unsigned Es[2], En[2];
+  unsigned E[2][CTD_NE], Es[2], En[2];
   u32x4 breg[2][NPC];
   auto load_chunk = [&](int kc, Ptr p, auto slot_tag) {
     constexpr int SLOT = decltype(slot_tag)::value;
-    const unsigned s = p.s & CT_MASK, e = p.e & CT_MASK;
-    const unsigned n = kc < k_end ? e - s : 0u;
-    Es[SLOT] = s; En[SLOT] = n | (((p.s & CT_LO) && n) ? CT_LO : 0u);
+    const unsigned s0 = p.s & CT_MASK;
+    const unsigned n = kc < k_end ? (p.e & CT_MASK) - s0 : 0u;
+    Es[SLOT] = s0; En[SLOT] = n | (((p.s & CT_LO) && n) ? CT_LO : 0u);
 #pragma unroll
     for (int k = 0; k < CTD_NE; ++k) {
-      const unsigned i = tid + 512 * k;
-      E[SLOT][k] = ent[i < n ? s + i : 0u];
+      const unsigned i = tid + 512u * k;
+      E[SLOT][k] = ent[i < n ? s0 + i : 0u];
     }
-    const int kb = min(kc, k_last);
+    const unsigned char* tb = reinterpret_cast<const unsigned char*>(T) +
+                              (size_t)min(kc, k_last) * 2;                      // uniform
 #pragma unroll
-    for (int i = 0; i < NPC; ++i) {
-      const int p2 = tid + 512 * i;                // 768 pieces: (term, column, half)
-      const int row = p2 >> 1, part = p2 & 1;
-      const int col = row & (CG_NP - 1), rowl = col < N ? row : row - col + (N - 1);
-      if (p2 < 768 && col < NT * 32)
-        breg[SLOT][i] = *reinterpret_cast<const u32x4*>(T + (size_t)rowl * Kpad + kb + part * 8);
-    }
+    for (int i = 0; i < NPC; ++i)
+      if (bon[i]) breg[SLOT][i] = *reinterpret_cast<const u32x4*>(tb + boff[i]);
   };
-  auto put = [&](unsigned e, unsigned char* plane) {
-    const unsigned gene = ((e >> 9) & 15u) * 32u + (e & 31u);
-    *reinterpret_cast<uint16_t*>(plane + gene * CD_ROW + ((e >> 5) & 15u) * 2) =
-        (uint16_t)ct_bf16(e);
+  // entry -> byte offset of (gene of the block, cell of the chunk) within a plane
+  auto where = [&](unsigned e) {
+    const unsigned gene = ((e >> 4) & 0x1E0u) | (e & 31u);          // (tile & 15) * 32 + gene
+    return gene * (unsigned)CD_ROW + ((e >> 4) & 0x1Eu);            // + 2 * row
   };
-  auto scatter = [&](unsigned char* plane, auto slot_tag, bool want_lo) {
+  auto put16 = [&](unsigned addr, unsigned e) {
+    *reinterpret_cast<uint16_t*>(cd_smem + addr) = (uint16_t)(e >> 16);
+  };
+  auto scatter_hi = [&](unsigned plane, auto slot_tag) {
     constexpr int SLOT = decltype(slot_tag)::value;
     const unsigned n = En[SLOT] & CT_MASK;
 #pragma unroll
-    for (int k = 0; k < CTD_NE; ++k)
-      if (tid + 512u * k < n && (((E[SLOT][k] >> 13) & 1u) != 0u) == want_lo)
-        put(E[SLOT][k], plane);
+    for (int k = 0; k < CTD_NE; ++k) {
+      const unsigned e = E[SLOT][k];
+      const bool ok = (tid + 512u * k < n) && !(e & (1u << 13));
+      put16(ok ? plane + where(e) : dummy, e);
+    }
     if (n > 512u * CTD_NE)
       for (unsigned i = tid + 512u * CTD_NE; i < n; i += 512u) {
         const unsigned e = ent[Es[SLOT] + i];
-        if ((((e >> 13) & 1u) != 0u) == want_lo) put(e, plane);
+        if (!(e & (1u << 13))) put16(plane + where(e), e);
+      }
+  };
+  auto scatter_lo = [&](auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    const unsigned n = En[SLOT] & CT_MASK;
+#pragma unroll
+    for (int k = 0; k < CTD_NE; ++k) {
+      const unsigned e = E[SLOT][k];
+      if ((tid + 512u * k < n) && (e & (1u << 13))) put16(ALO + where(e), e);
+    }
+    if (n > 512u * CTD_NE)
+      for (unsigned i = tid + 512u * CTD_NE; i < n; i += 512u) {
+        const unsigned e = ent[Es[SLOT] + i];
+        if (e & (1u << 13)) put16(ALO + where(e), e);
       }
   };
   auto store_b = [&](int buf, auto slot_tag) {
     constexpr int SLOT = decltype(slot_tag)::value;
 #pragma unroll
-    for (int i = 0; i < NPC; ++i) {
-      const int p2 = tid + 512 * i;
-      const int row = p2 >> 1, part = p2 & 1;
-      if (p2 < 768 && (row & (CG_NP - 1)) < NT * 32)
-        *reinterpret_cast<u32x4*>(&Bs[buf * B_BYTES + row * CD_ROW + part * 16]) = breg[SLOT][i];
-    }
+    for (int i = 0; i < NPC; ++i)
+      if (bon[i])
+        *reinterpret_cast<u32x4*>(cd_smem + bst[i] + buf * B_BYTES) = breg[SLOT][i];
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
@@ -1304,7 +1380,7 @@ __global__ __launch_bounds__(512, 1) void count_tiles_dw_kernel(
     load_chunk(k_begin, load_ptr(k_begin), S0{});
     load_chunk(k_begin + CD_BK, load_ptr(k_begin + CD_BK), S1{});
     pn = load_ptr(k_begin + 2 * CD_BK);
-    scatter(Ahi, S0{}, false);
+    scatter_hi(AHI, S0{});
     store_b(0, S0{});
   }
   __syncthreads();
@@ -1319,63 +1395,59 @@ __global__ __launch_bounds__(512, 1) void count_tiles_dw_kernel(
     const int ab1 = ab == 2 ? 0 : ab + 1, ab2 = ab1 == 2 ? 0 : ab1 + 1;
     const bool need_lo = (En[BUF] & CT_LO) != 0u;        // (uniform: the block pointer's flag)
     if (lo_dirty || need_lo) {
-      if (lo_dirty) { zero_plane(Alo); lds_barrier(); }
-      if (need_lo) { scatter(Alo, buf_tag, true); lds_barrier(); }
+      if (lo_dirty) { zero_plane(ALO); lds_barrier(); }
+      if (need_lo) { scatter_lo(buf_tag); lds_barrier(); }
       lo_dirty = need_lo;
     }
-    auto stage = [&]() {
-      if (!(dbg & 8)) zero_plane(Ahi + ab2 * CTD_A_BYTES);
-      {
-        const Ptr p = pn;
-        pn = load_ptr(kc + 3 * CD_BK);
-        load_chunk(kc + 2 * CD_BK, p, buf_tag);
-      }
-      if (!(dbg & 4)) scatter(Ahi + ab1 * CTD_A_BYTES, Other{}, false);
-      store_b(BUF ^ 1, Other{});
-    };
-    auto multiply = [&]() {
-      if (dbg & 2) return;
-      const unsigned char* ah = Ahi + ab * CTD_A_BYTES + a_frag;
-      const unsigned char* al = Alo + a_frag;
-      const unsigned char* bcur = Bs + BUF * B_BYTES + b_frag;
-      // (every fragment of the chunk requested up front: see the forward kernel)
-      bf16x8 fh[2], fl[2], fr[3][NT];
+    const unsigned char* ah = cd_smem + AHI + ab * CTD_A_BYTES + a_frag;
+    const unsigned char* al = cd_smem + ALO + a_frag;
+    const unsigned char* bcur = cd_smem + BSM + BUF * B_BYTES + b_frag;
+    bf16x8 fh[2], fl[2], fr[3][NT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      fh[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(ah + t * 32 * CD_ROW));
+#pragma unroll
+    for (int term = 2; term >= 0; --term)
+#pragma unroll
+      for (int q = 0; q < NT; ++q)
+        fr[term][q] = as_bf16x8(*reinterpret_cast<const u32x4*>(
+            bcur + (term * CG_NP + q * 32) * CD_ROW));
+    if (need_lo) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
-        fh[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(ah + t * 32 * CD_ROW));
-#pragma unroll
-      for (int term = 2; term >= 0; --term)
-#pragma unroll
-        for (int q = 0; q < NT; ++q)
-          fr[term][q] = as_bf16x8(*reinterpret_cast<const u32x4*>(
-              bcur + (term * CG_NP + q * 32) * CD_ROW));
+        fl[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(al + t * 32 * CD_ROW));
+    }
+    auto mm = [&](int term) {
       if (need_lo) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-          fl[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(al + t * 32 * CD_ROW));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int term = 2; term >= 0; --term) {              // smallest term first
-        if (need_lo) {
-#pragma unroll
-          for (int q = 0; q < NT; ++q) {
-            acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[0], fr[term][q], acc[0][q], 0, 0, 0);
-            acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[1], fr[term][q], acc[1][q], 0, 0, 0);
-          }
-        }
-#pragma unroll
         for (int q = 0; q < NT; ++q) {
-          acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[0], fr[term][q], acc[0][q], 0, 0, 0);
-          acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[1], fr[term][q], acc[1][q], 0, 0, 0);
+          acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[0], fr[term][q], acc[0][q], 0, 0, 0);
+          acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[1], fr[term][q], acc[1][q], 0, 0, 0);
         }
+      }
+#pragma unroll
+      for (int q = 0; q < NT; ++q) {
+        acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[0], fr[term][q], acc[0][q], 0, 0, 0);
+        acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[1], fr[term][q], acc[1][q], 0, 0, 0);
       }
     };
-    // (the lo test above read En[BUF] before stage() reloads the slot)
-    stage();
-    __builtin_amdgcn_sched_barrier(0);
-    multiply();
-    __builtin_amdgcn_sched_barrier(0);
+    zero_plane(AHI + ab2 * CTD_A_BYTES);
+    {
+      const Ptr p = pn;
+      pn = load_ptr(kc + 3 * CD_BK);
+      load_chunk(kc + 2 * CD_BK, p, buf_tag);      // (overwrites En[BUF]: need_lo was read above)
+    }
+    CT_FENCE;
+    mm(2);
+    CT_FENCE;
+    scatter_hi(AHI + ab1 * CTD_A_BYTES, Other{});
+    CT_FENCE;
+    mm(1);
+    CT_FENCE;
+    store_b(BUF ^ 1, Other{});
+    CT_FENCE;
+    mm(0);
+    CT_FENCE;
     lds_barrier();
     ab = ab1;
   };
@@ -1399,11 +1471,14 @@ __global__ __launch_bounds__(512, 1) void count_tiles_dw_kernel(
     }
 }
 
-static int ct_dbg() {   // (ablation flags of the tile kernels, measurements only: SCVAE_CT_DBG)
-  static const int v = [] { const char* e = getenv("SCVAE_CT_DBG"); return e ? atoi(e) : 0; }();
-  return v;
+#if CT_PROF
+extern "C" int scvae_ct_prof_dump(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ct_prof), sizeof(unsigned long long) * 64);
 }
-static size_t ctd_lds_bytes() { return 4 * (size_t)CTD_A_BYTES + 2 * (size_t)(3 * CG_NP * CD_ROW); }
+#endif
+static size_t ctd_lds_bytes() {
+  return 4 * (size_t)CTD_A_BYTES + 2 * (size_t)(3 * CG_NP * CD_ROW) + CTD_DUMMY;
+}
 
 // count_gemm_u16 with the large part of the contraction read from `tiles` (the same minibatch:
 // csr_count_tiles of the rows x was densified from).  x (the uint16 batch) is only read for the
@@ -1456,7 +1531,7 @@ int count_gemm_tiles(hipStream_t stream, int mode, CountTiles tiles, const uint1
     auto kfn = count_tiles_fwd_kernel<NQ_>;                                                      \
     SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)lds));                    \
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, stream, tiles.ent, tiles.tptr, ntp, n_groups,  \
-                       M, k_main, T, Kpad, N, k_chunk, dst, ldo, kbias, kact, kdirect, ct_dbg()); \
+                       M, k_main, T, Kpad, N, k_chunk, dst, ldo, kbias, kact, kdirect);          \
   } while (0)
       if (NQ == 2) SCVAE_CTF(2); else SCVAE_CTF(1);
 #undef SCVAE_CTF
@@ -1468,7 +1543,7 @@ int count_gemm_tiles(hipStream_t stream, int mode, CountTiles tiles, const uint1
     auto kfn = count_tiles_dw_kernel<NT_>;                                                       \
     SCVAE_HIP(max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)lds));                    \
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, stream, tiles.ent, tiles.gptr, ngb, M, k_main, \
-                       T, Kpad, N, k_chunk, dst, ldo, ct_dbg());                                 \
+                       T, Kpad, N, k_chunk, dst, ldo);                                           \
   } while (0)
       switch (NT) { case 1: SCVAE_CTD(1); break; case 2: SCVAE_CTD(2); break;
                     case 3: SCVAE_CTD(3); break; default: SCVAE_CTD(4); }

@@ -70,7 +70,10 @@ def _decode(tiles, n, F, lib):
         assert np.array_equal((e >> 9) & 15, tile_of & 15)
         row = (e >> 5) & 15
         gene = tile_of * 32 + (e & 31)
-        value = (e >> 16).astype(np.int64)
+        # the value travels as its bf16 bit pattern (exact: at most 8 significant bits)
+        as_float = ((e >> 16).astype(np.uint32) << 16).view(np.float32)
+        value = as_float.astype(np.int64)
+        assert np.array_equal(value.astype(np.float32), as_float)
         is_lo = ((e >> 13) & 1).astype(bool)
         assert (value > 0).all()
         # at most 8 significant bits per entry: exact in bf16
