@@ -5,7 +5,7 @@ set -euo pipefail
 cd "$(dirname "$0")"
 bash build.sh > /dev/null
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DCT_PROF=1 -c count_gemm.hip -o /tmp/count_gemm_ctprof.o
+$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DCT_PROF=1 ${CT_EXTRA:-} -c count_gemm.hip -o /tmp/count_gemm_ctprof.o
 objs=$(ls build/*.o | grep -v "count_gemm.o")
-$HIPCC --offload-arch=gfx950 -shared -fPIC $objs /tmp/count_gemm_ctprof.o -o libscvae_hip_ctprof.so
-echo "built $(pwd)/libscvae_hip_ctprof.so"
+$HIPCC --offload-arch=gfx950 -shared -fPIC $objs /tmp/count_gemm_ctprof.o -o ${CT_OUT:-libscvae_hip_ctprof.so}
+echo "built $(pwd)/${CT_OUT:-libscvae_hip_ctprof.so}"

@@ -71,13 +71,18 @@ __device__ __forceinline__ unsigned bf16_rne_bits(float v) {
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 
-// S[R][C] (row-major, pitch ld) -> T[3][CG_NP][Rpad] bf16 with T[t][c][r] = term t of S[r][c];
-// zero for c >= C or r >= R.  One thread: one column, 8 consecutive rows (one 16-byte store
+// S[R][C] (row-major, pitch ld) -> T[Rpad / BK][3][CG_NP][BK] bf16 with T[r / BK][t][c][r % BK] =
+// term t of S[r][c]; zero for c >= C or r >= R.  Chunk-major: the operand of one chunk of the
+// contraction (BK = 32 forward, 16 weight gradient) is ONE contiguous run of 3 * 128 * BK * 2
+// bytes, so the kernels stream it with coalesced 16-byte loads.  (Round 6: with the planes
+// [3][128][Rpad] a chunk was 384 pieces of 64 / 32 bytes, each Rpad * 2 bytes from the next --
+// 384 DRAM pages per chunk -- and every count kernel, dense or tiles, waited ~2 k cycles per
+// chunk on exactly those loads.)  One thread: one column, 8 consecutive rows (one 16-byte store
 // per term).
 __global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __restrict__ S, int R,
                                                                int C, int ld,
                                                                uint16_t* __restrict__ T,
-                                                               int Rpad) {
+                                                               int Rpad, int BK) {
   const int c = threadIdx.x & (CG_NP - 1);
   const int r0 = (blockIdx.x * 2 + (threadIdx.x >> 7)) * 8;
   if (r0 >= Rpad) return;
@@ -93,8 +98,8 @@ __global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __re
     const unsigned b3 = bf16_rne_bits(r2);
     t1[j] = b1; t2[j] = b2; t3[j] = b3;
   }
-  const size_t plane = (size_t)CG_NP * Rpad;
-  uint16_t* dst = T + (size_t)c * Rpad + r0;
+  const size_t plane = (size_t)CG_NP * BK;
+  uint16_t* dst = T + ((size_t)(r0 / BK) * 3 * CG_NP + c) * BK + r0 % BK;
   auto pack = [](const unsigned* t) {
     u32x4 v;
     v.x = t[0] | (t[1] << 16); v.y = t[2] | (t[3] << 16);
@@ -104,6 +109,11 @@ __global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __re
   *reinterpret_cast<u32x4*>(dst) = pack(t1);
   *reinterpret_cast<u32x4*>(dst + plane) = pack(t2);
   *reinterpret_cast<u32x4*>(dst + 2 * plane) = pack(t3);
+}
+
+// offset (elements) of the 8-element piece `part` of row (term * 128 + column) in chunk kc / BK
+template <int BK> __device__ __forceinline__ size_t cg_piece(int kc, int row, int part) {
+  return ((size_t)(kc / BK) * 3 * CG_NP + row) * BK + part * 8;
 }
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void count_gemm_dw_kernel
       //  anyway, no branch around the load; what they multiply into is never stored)
       const int col = row & (CG_NP - 1), rowl = col < N ? row : row - col + (N - 1);
       if (p < 768 && col < NT * 32)
-        breg[slot][i] = *reinterpret_cast<const u32x4*>(T + (size_t)rowl * Kpad + kc + part * 8);
+        breg[slot][i] = *reinterpret_cast<const u32x4*>(T + cg_piece<CD_BK>(kc, rowl, part));
     }
   };
   auto store_b = [&](int buf, int slot = 0) {
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(512) void count_gemm_fwd_kernel(
       // (columns beyond N: the last live column's piece again, as in count_gemm_dw_kernel)
       const int col = row & (CG_NP - 1), rowl = col < N ? row : row - col + (N - 1);
       if (col < NCOL)
-        breg[slot][i] = *reinterpret_cast<const u32x4*>(T + (size_t)rowl * Kpad + kc + prt * 8);
+        breg[slot][i] = *reinterpret_cast<const u32x4*>(T + cg_piece<CG_BK>(kc, rowl, prt));
     }
   };
   bool dirty0 = false, dirty1 = false;                  // this wave's lo rows of buffer b are set
@@ -680,7 +690,7 @@ static int count_gemm_impl(hipStream_t stream, int mode, const XT* x, int ldx, i
   int splits = 0;
   if (k_main > 0) {
     hipLaunchKernelGGL(split3_transpose_kernel, dim3((Kpad / 8 + 1) / 2), dim3(256), 0, stream,
-                       other, K, N, ld_other, T, Kpad);
+                       other, K, N, ld_other, T, Kpad, bk);
     SCVAE_LAUNCH_CHECK("split3_transpose_kernel");
     splits = cg_splits(mode, M, k_main);
     int k_chunk = k_main;
@@ -942,6 +952,13 @@ int csr_count_tiles(hipStream_t stream, const int64_t* indptr, const int32_t* in
 #ifndef CT_PROF
 #define CT_PROF 0
 #endif
+#ifndef CT_PRIO
+#define CT_PRIO 0
+#endif
+#ifndef CT_EXP
+#define CT_EXP 0      // probe experiments (wrong results): 2 = the entries of chunk 0 always;
+                      // 4 = no MFMAs, 5 = no staging, 6 = neither, 7 = 5 and no W planes in the multiplying waves
+#endif
 #if CT_PROF
 __device__ unsigned long long ct_prof[8 * 8];
 #define CT_STAMP(k)                                                         \
@@ -957,32 +974,45 @@ __device__ unsigned long long ct_prof[8 * 8];
 #define CT_FENCE __builtin_amdgcn_sched_barrier(0)
 
 // ---- forward from tiles: count_gemm_fwd_kernel with the [256, 32] tile of x scattered into LDS
-// from its non-zeros (16 buckets: one per group of 16 rows, 32 lanes each) instead of copied from
-// the dense batch.  Same MFMAs on the same operands in the same order: bit-identical.
+// from its non-zeros (16 buckets: one per group of 16 rows) instead of copied from the dense
+// batch.  Same MFMAs on the same operands in the same order per accumulator: bit-identical.
 //
-// What bounds these kernels (round 6, s_memtime per section + the ISA): not bytes and not the
-// matrix pipe but the INSTRUCTIONS A WAVE ISSUES per chunk -- a wave issues one instruction every
-// ~4 cycles, in order; the first version spent ~500 of them per chunk beside its 24 MFMAs (64-bit
-// address arithmetic per load, exec-mask branches around every predicated entry, per-use
-// conversions): 3.8 k cycles per chunk for 1.5 k of matrix work, whatever the barriers, the
-// buffer count or the order of the pieces.  Hence this shape:
-//   * entries carry their bf16 value bits (the fetch converts once), so an entry becomes an LDS
-//     address (bit field extract x 2, one multiply-add) and a 16-bit store of its upper half;
-//   * no branches in the common path: a lane without an entry -- or with a lo entry in the hi
-//     pass -- stores to a dummy slot of its own;
-//   * every global address is a uniform base (SGPR) + a per-thread 32-bit offset computed once;
-//   * three hi buffers (chunk j multiplied from buffer j % 3, chunk j + 1 scattered into the
-//     next, the third zeroed): one barrier per chunk; the lo plane (counts above 8 significant
-//     bits: 0.02 % of the entries, 8 % of the chunks) has one buffer, filled behind barriers of
-//     its own at the start of its chunk's iteration;
-//   * the chunk's MFMAs in six groups with the staging pieces between them.
-constexpr int CTF_NE = 3;
-constexpr int CTF_DUMMY = 512 * 2;      // bytes: a 2-byte slot per thread for masked stores
+// What bounds these kernels (round 6, s_memtime per section, tools/ct_prof.py): neither bytes nor
+// instruction count but what the two waves of a SIMD do beside each other.
+//   * With all eight waves running the same program -- stage, barrier, multiply -- both waves of
+//     a SIMD multiply at the same time (8 MFMAs: 250 cycles, the pipe's rate) and stage at the
+//     same time (the pipe idle): 3.8 k cycles per chunk for 1.5 k of matrix work, whatever the
+//     barriers, the buffer count, the order of the pieces or the instruction count.
+//   * With two roles (waves 0-3 multiply, waves 4-7 stage) the chunk still took 3.8 k: alone the
+//     multiplying waves need 2.1 k and the staging waves 2.0 k, together the SUM -- the staging
+//     wave's 14 global loads per chunk take ~140 cycles EACH to issue beside a wave that streams
+//     MFMAs (1.9 k of its 3.6 k; 0.6 k alone), whatever the priorities, and whichever of its
+//     streams is made cache-hot.
+// Hence: few vector-memory instructions per wave and chunk, spread over all eight waves.
+//   waves 0-3 (one per SIMD) multiply chunk j from buffers j & 1 (48 MFMAs each; a
+//     [128 rows, 64 columns] tile per wave at NQ = 2: 20 fragment reads per chunk);
+//   waves 4-7 stage the x side of chunk j + 1 into the other buffers meanwhile: a wave owns 64
+//     rows = four buckets, a quarter-wave per bucket; per chunk and wave ONE load (a bucket's
+//     first 64 entries: an aligned 16 bytes per lane), the tile pointers read 16 chunks at a time
+//     and handed around by ds_bpermute, and no zeroing pass: a lane stores zeros where it wrote
+//     two chunks ago before it scatters -- LDS operations of one wave complete in order;
+//   all eight waves move the W planes of chunk j + 1 (three 16-byte pieces per thread: loaded a
+//     chunk ahead, stored, the next requested);
+//   one barrier per chunk.
+// Entries carry their bf16 value bits (the fetch converts once): an entry becomes an LDS address
+// (bit field extract, multiply-add) and a 16-bit store of its upper half; no branches in the
+// common path (a lane without an entry -- or with a lo entry in the hi pass -- stores to a dummy
+// slot of its own).  The lo plane (counts above 8 significant bits: 0.02 % of the entries, 8 % of
+// the chunks) is zeroed by its owner only after it was written.
+constexpr int CTF_DUMMY = 256 * 2;      // bytes: a 2-byte slot per staging thread
+constexpr int CTF_WINDOW = 15;          // chunks served by one read of the tile pointers
 
 static size_t ctf_lds_bytes(int NQ) {
-  return 4 * (size_t)CF_A_BYTES + 2 * (size_t)(3 * 64 * NQ * CG_ROW) + 3 * 8 * sizeof(int) +
+  return 4 * (size_t)CF_A_BYTES + 2 * (size_t)(3 * 64 * NQ * CG_ROW) + 2 * 4 * sizeof(int) +
          CTF_DUMMY;
 }
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 template <int NQ>
 __global__ __launch_bounds__(512) void count_tiles_fwd_kernel(
@@ -992,261 +1022,317 @@ __global__ __launch_bounds__(512) void count_tiles_fwd_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char cf_smem[];
   constexpr int NCOL = 64 * NQ;
   constexpr int B_BYTES = 3 * NCOL * CG_ROW;
-  constexpr int AHI = 0, ALO = 3 * CF_A_BYTES, BSM = 4 * CF_A_BYTES, FLG = BSM + 2 * B_BYTES,
-                DUM = FLG + 3 * 8 * 4;
-  int* lo_flag = reinterpret_cast<int*>(cf_smem + FLG);   // [3][8]
+  constexpr int AHI = 0, ALO = 2 * CF_A_BYTES, BSM = 4 * CF_A_BYTES, FLG = BSM + 2 * B_BYTES,
+                DUM = FLG + 2 * 4 * 4;
+  int* lo_flag = reinterpret_cast<int*>(cf_smem + FLG);   // [2][4]: buffer, staging wave
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, kg = lane >> 5;
-  const int rg = w & 3, q0 = (w >> 2) * NQ;
   const int m0 = blockIdx.x * CF_BM;
   const int k_begin = blockIdx.y * k_chunk;
   const int k_end = min(K, k_begin + k_chunk);
   const int k_last = k_end - CG_BK;
+  const int nch = k_begin < k_end ? (k_end - k_begin + CG_BK - 1) / CG_BK : 0;
 
-  f32x16 acc[2][NQ];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][q][i] = 0.f;
-
-  // ---- per-thread constants: this thread's bucket (group grp of the block's 16, lane gl of its
-  //      32) and its pieces of the W planes, as 32-bit offsets from uniform bases ----
-  const int grp = tid >> 5;
-  const unsigned gl = tid & 31;
-  const int cc = blockIdx.x * (CF_BM / CT_ROWS) + grp;
-  const bool live = cc < n_groups;
-  const unsigned tp_off = (unsigned)(live ? cc : 0) * (unsigned)(ntp + 1);      // elements
-  const unsigned a_base = (unsigned)(CT_ROWS * grp) * CG_ROW;
-  const unsigned dummy = DUM + 2u * tid;
-  unsigned boff[3], bst[3];
-  bool bon[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int p2 = tid + 512 * i;                       // (term, column, quarter)
-    const int row = p2 >> 2, prt = p2 & 3;
-    const int term = row >> 7, col = row & (CG_NP - 1);
-    const int rowl = col < N ? row : row - col + (N - 1);
-    bon[i] = col < NCOL;
-    boff[i] = ((unsigned)rowl * (unsigned)Kpad + prt * 8) * 2u;                 // bytes
-    bst[i] = BSM + (term * NCOL + col) * CG_ROW + prt * 16;
-  }
+  // all four x planes start clean: a hi plane is kept clean by un-scattering, a lo plane is
+  // zeroed by its owners after use
   for (int i = tid; i < (4 * CF_A_BYTES) / 16; i += 512)
     reinterpret_cast<u32x4*>(cf_smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  if (tid < 8) lo_flag[tid] = 0;
 
-  struct Ptr { unsigned s, e; };
-  auto load_ptr = [&](int kc) {     // (clamped to the split's last chunk: unconditional loads)
-    const uint32_t* base = tptr + min(kc, k_last) / CG_BK;                       // uniform
-    Ptr p; p.s = base[tp_off]; p.e = base[tp_off + 1];
-    return p;
-  };
-  unsigned E[2][CTF_NE], Es[2], En[2];     // entries / first index / count (| CT_LO) of a slot
-  u32x4 breg[2][3];
-  auto load_chunk = [&](int kc, Ptr p, auto slot_tag) {
-    constexpr int SLOT = decltype(slot_tag)::value;
-    const unsigned s0 = p.s & CT_MASK;
-    const unsigned n = (live && kc < k_end) ? (p.e & CT_MASK) - s0 : 0u;
-    Es[SLOT] = s0; En[SLOT] = n | (((p.s & CT_LO) && n) ? CT_LO : 0u);
+  // ---- the W planes: every thread moves NPB 16-byte pieces per chunk ----
+  constexpr int NPIECE = 3 * NCOL * 4;
+  constexpr int NPB = (NPIECE + 511) / 512;
+  unsigned boff[NPB], bst[NPB];
+  bool bon[NPB];
 #pragma unroll
-    for (int k = 0; k < CTF_NE; ++k) {
-      const unsigned i = gl + 32u * k;
-      E[SLOT][k] = ent[i < n ? s0 + i : 0u];
-    }
+  for (int i = 0; i < NPB; ++i) {
+    const int p2 = tid + 512 * i;                       // (term, column, quarter)
+    bon[i] = p2 < NPIECE;
+    const int row = (bon[i] ? p2 : 0) >> 2, prt = p2 & 3;
+    const int term = row / NCOL, col = row % NCOL;
+    const int rowl = term * CG_NP + (col < N ? col : N - 1);
+    boff[i] = ((unsigned)rowl * CG_BK + prt * 8) * 2u;                          // bytes
+    bst[i] = BSM + (term * NCOL + col) * CG_ROW + prt * 16;
+  }
+  u32x4 breg[NPB];
+  auto load_b = [&](int kc) {     // (clamped to the split's last chunk: unconditional loads)
     const unsigned char* tb = reinterpret_cast<const unsigned char*>(T) +
-                              (size_t)min(kc, k_last) * 2;                      // uniform
+                              (size_t)(min(kc, k_last) / CG_BK) * (3 * CG_NP * CG_BK * 2);   // uniform
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-      if (bon[i]) breg[SLOT][i] = *reinterpret_cast<const u32x4*>(tb + boff[i]);
+    for (int i = 0; i < NPB; ++i)
+      if (NPIECE % 512 == 0 || bon[i]) breg[i] = *reinterpret_cast<const u32x4*>(tb + boff[i]);
   };
-  // entry -> LDS byte offset within a plane
-  auto where = [&](unsigned e) {
-    return a_base + __builtin_amdgcn_ubfe(e, 5, 4) * (unsigned)CG_ROW + ((e & 31u) << 1);
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NPB; ++i)
+      if (NPIECE % 512 == 0 || bon[i])
+        *reinterpret_cast<u32x4*>(cf_smem + bst[i] + buf * B_BYTES) = breg[i];
+  };
+  if (nch > 0) load_b(k_begin);
+  __syncthreads();                                      // planes zeroed
+  if (nch > 0) { store_b(0); load_b(k_begin + CG_BK); }
+#if CT_PROF
+  unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = __builtin_amdgcn_s_memtime();
+#endif
+
+  if (w < 4) {
+    // ================= the multiplying waves =================
+    constexpr int TT = 2 * NQ;                          // 32-row tiles of this wave
+    const int li = lane & 31, kg = lane >> 5;
+    const int row0 = NQ == 2 ? 128 * (w & 1) : 64 * w;
+    const int qb = NQ == 2 ? 2 * (w >> 1) : 0;          // first of its two 32-column tiles
+    f32x16 acc[TT][2];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][q][i] = 0.f;
+    const int a_frag = (row0 + li) * CG_ROW + 32 * kg;         // + 32 rows * t, + 16 s
+    const int b_frag = (qb * 32 + li) * CG_ROW + 32 * kg;      // + term * NCOL rows, + 32 rows * q
+    // The last eight MFMAs of a chunk (s = 1, term 0) wait in registers across the barrier and
+    // run behind the next chunk's first fragment reads: the pipe works through the reads'
+    // latency.  (Zero operands before the first chunk: acc + 0 * 0.)
+    bf16x8 th[TT], tb[2];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) th[t] = as_bf16x8(u32x4{0u, 0u, 0u, 0u});
+#pragma unroll
+    for (int q = 0; q < 2; ++q) tb[q] = as_bf16x8(u32x4{0u, 0u, 0u, 0u});
+    auto mma = [&](const bf16x8* a, const bf16x8* b2) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          acc[t][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b2[q], acc[t][q], 0, 0, 0);
+    };
+    lds_barrier();                                      // chunk 0 staged
+    for (int j = 0; j < nch; ++j) {
+      const int buf = j & 1;
+      const unsigned char* ah = cf_smem + AHI + buf * CF_A_BYTES + a_frag;
+      const unsigned char* al = cf_smem + ALO + buf * CF_A_BYTES + a_frag;
+      const unsigned char* bb = cf_smem + BSM + buf * B_BYTES + b_frag;
+      auto frags = [&](const unsigned char* a, bf16x8* f, int s_) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+          f[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(a + t * 32 * CG_ROW + 16 * s_));
+      };
+      auto frags_b = [&](bf16x8 (*f)[2], int s_) {
+#pragma unroll
+        for (int term = 2; term >= 0; --term)
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            f[term][q] = as_bf16x8(*reinterpret_cast<const u32x4*>(
+                bb + (term * NCOL + q * 32) * CG_ROW + 16 * s_));
+      };
+      bf16x8 fh0[TT], fb0[3][2], fh1[TT], fb1[3][2], fl[TT];
+      const int flag = lo_flag[buf * 4 + (lane & 3)];  // (first: its wait is the shortest)
+      CT_FENCE;
+      frags(ah, fh0, 0);
+      frags_b(fb0, 0);
+      CT_FENCE;
+#if CT_EXP == 4 || CT_EXP == 6
+      if (M < 0) {
+#endif
+      mma(th, tb);                                      // the previous chunk's last eight
+      CT_FENCE;
+      const bool need_lo = __builtin_amdgcn_readfirstlane(__any(flag));
+      if (need_lo) frags(al, fl, 0);
+      if (need_lo) mma(fl, fb0[2]);
+      mma(fh0, fb0[2]);
+      // its share of the W planes of chunk j + 1 (requested a chunk ago); chunk j + 2's
+#if CT_EXP != 7
+      store_b(buf ^ 1);
+      load_b(k_begin + (j + 2) * CG_BK);
+#endif
+      if (need_lo) mma(fl, fb0[1]);
+      mma(fh0, fb0[1]);
+      CT_FENCE;
+      frags(ah, fh1, 1);
+      frags_b(fb1, 1);
+      CT_FENCE;
+      if (need_lo) mma(fl, fb0[0]);
+      mma(fh0, fb0[0]);
+      if (need_lo) frags(al, fl, 1);
+      CT_FENCE;
+      if (need_lo) mma(fl, fb1[2]);
+      mma(fh1, fb1[2]);
+      if (need_lo) mma(fl, fb1[1]);
+      mma(fh1, fb1[1]);
+      if (need_lo) mma(fl, fb1[0]);
+#pragma unroll
+      for (int t = 0; t < TT; ++t) th[t] = fh1[t];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) tb[q] = fb1[0][q];
+#if CT_EXP == 4 || CT_EXP == 6
+      }
+#endif
+      CT_STAMP(0);
+      lds_barrier();
+      CT_STAMP(1);
+    }
+    mma(th, tb);
+#if CT_PROF
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)
+      for (int k_ = 0; k_ < 8; ++k_) ct_prof[w * 8 + k_] = pacc[k_];
+#endif
+    float* dst = direct ? out : out + (size_t)blockIdx.y * M * ldo;
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int col = (qb + q) * 32 + li;
+        if (col >= N) continue;
+        const float bv = (direct && bias != nullptr) ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + row0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kg;
+          if (m < M) {
+            float v = acc[t][q][r] + bv;
+            if (direct && act == ACT_RELU) v = fmaxf(v, 0.f);
+            dst[(size_t)m * ldo + col] = v;
+          }
+        }
+      }
+    return;
+  }
+
+  // ================= the staging waves =================
+  __builtin_amdgcn_s_setprio(CT_PRIO);
+  const int p = w - 4, pt = tid - 256;
+  const unsigned l16 = lane & 15, quarter = lane & 48;
+  // a quarter-wave per bucket
+  const int bucket = 4 * p + (lane >> 4);
+  const int cc = blockIdx.x * (CF_BM / CT_ROWS) + bucket;
+  const bool live = cc < n_groups;
+  const unsigned tp_off = (unsigned)(live ? cc : 0) * (unsigned)(ntp + 1);      // elements
+  const unsigned a_base = (unsigned)(CT_ROWS * bucket) * CG_ROW;
+  const unsigned dummy = DUM + 2u * pt;
+  // tile pointers: lane l of a quarter-wave holds pointer c0 + l of its bucket
+  int c0 = 0;
+  unsigned win = 0u;
+  auto load_window = [&](int tile) {
+    c0 = tile;
+    win = tptr[tp_off + (unsigned)min(tile + (int)l16, ntp)];
+  };
+  u32x4 E;                              // the lane's four of the chunk's entries
+  unsigned Es = 0u, En = 0u;            // the bucket's first entry, its count | CT_LO
+  // pointers of the chunk at kc -> (Es, En), its entries requested into E: an aligned 16 bytes
+  // per lane, entries 4 (Es / 4 + l16) .. + 3
+  auto load_entries = [&](int kc) {
+    const int tile = min(kc, k_last) / CG_BK;
+    if (tile - c0 >= CTF_WINDOW) load_window(tile);
+    const int at = (int)((quarter + (unsigned)(tile - c0)) * 4u);
+    const unsigned ps = (unsigned)__builtin_amdgcn_ds_bpermute(at, (int)win);
+    const unsigned pe = (unsigned)__builtin_amdgcn_ds_bpermute(at + 4, (int)win);
+    const unsigned s0 = ps & CT_MASK;
+    const unsigned n = (live && kc < k_end) ? (pe & CT_MASK) - s0 : 0u;
+    Es = s0; En = n | (((ps & CT_LO) && n) ? CT_LO : 0u);
+    const unsigned first = ((s0 >> 2) + l16) << 2;
+#if CT_EXP == 2
+    E = *reinterpret_cast<const u32x4*>(ent + 4 * l16);
+#else
+    E = *reinterpret_cast<const u32x4*>(ent + (first < s0 + n ? first : 0u));
+#endif
+  };
+  auto where = [&](unsigned e) {            // entry -> byte offset within its bucket's rows
+    return __builtin_amdgcn_ubfe(e, 5, 4) * (unsigned)CG_ROW + ((e & 31u) << 1);
   };
   auto put16 = [&](unsigned addr, unsigned e) {
     *reinterpret_cast<uint16_t*>(cf_smem + addr) = (uint16_t)(e >> 16);
   };
-  // the hi entries of the slot's bucket -> plane at byte offset `plane` (branch-free: what a lane
-  // does not hold, or a lo entry, goes to the lane's dummy slot)
-  auto scatter_hi = [&](unsigned plane, auto slot_tag) {
-    constexpr int SLOT = decltype(slot_tag)::value;
-    const unsigned n = En[SLOT] & CT_MASK;
+  auto zero_rows = [&](unsigned plane) {    // this wave's 64 rows of a plane
+    u32x4* z = reinterpret_cast<u32x4*>(cf_smem + plane + p * (64 * CG_ROW));
 #pragma unroll
-    for (int k = 0; k < CTF_NE; ++k) {
-      const unsigned e = E[SLOT][k];
-      const bool ok = (gl + 32u * k < n) && !(e & (1u << 13));
-      put16(ok ? plane + where(e) : dummy, e);
+    for (int i = 0; i < 64 * CG_ROW / 16 / 64; ++i) z[lane + 64 * i] = u32x4{0u, 0u, 0u, 0u};
+  };
+  // where this lane wrote in hi buffer 0 / 1 (to take it out again)
+  unsigned held[2][4];
+  bool spilled[2] = {false, false};         // ... and the wave wrote more than that
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) held[b][c] = dummy;
+  bool lo_dirty[2] = {false, false};        // this wave's rows of lo plane 0 / 1 hold entries
+  // the chunk in (E, Es, En) -> buffers BUF
+  auto fill = [&](auto buf_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    const unsigned hi = AHI + BUF * CF_A_BYTES, lo = ALO + BUF * CF_A_BYTES;
+    CT_STAMP(2);
+    if (spilled[BUF]) zero_rows(hi);
+    else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) put16(held[BUF][c], 0u);
     }
-    if (n > 32u * CTF_NE)        // (a bucket beyond the three loads: rare, a direct loop)
-      for (unsigned i = gl + 32u * CTF_NE; i < n; i += 32u) {
-        const unsigned e = ent[Es[SLOT] + i];
-        if (!(e & (1u << 13))) put16(plane + where(e), e);
-      }
-  };
-  auto scatter_lo = [&](auto slot_tag) {
-    constexpr int SLOT = decltype(slot_tag)::value;
-    const unsigned n = En[SLOT] & CT_MASK;
+    CT_STAMP(3);
+    const unsigned n = En & CT_MASK;
+    const unsigned d = (((Es >> 2) + l16) << 2) - Es;      // index of E.x in the bucket (may be < 0)
+    const unsigned base = hi + a_base;
 #pragma unroll
-    for (int k = 0; k < CTF_NE; ++k) {
-      const unsigned e = E[SLOT][k];
-      if ((gl + 32u * k < n) && (e & (1u << 13))) put16(ALO + where(e), e);
+    for (int c = 0; c < 4; ++c) {
+      const unsigned e = E[c];
+      const bool ok = (d + c) < n && !(e & (1u << 13));
+      const unsigned at = ok ? base + where(e) : dummy;
+      put16(at, e);
+      held[BUF][c] = at;
     }
-    if (n > 32u * CTF_NE)
-      for (unsigned i = gl + 32u * CTF_NE; i < n; i += 32u) {
-        const unsigned e = ent[Es[SLOT] + i];
-        if (e & (1u << 13)) put16(ALO + where(e), e);
+    const unsigned covered = 64u - (Es & 3u);
+    const bool more = n > covered;
+    if (more)                      // (a bucket beyond four per lane: rare, a direct loop)
+      for (unsigned idx = covered + l16; idx < n; idx += 16u) {
+        const unsigned e = ent[Es + idx];
+        if (!(e & (1u << 13))) put16(base + where(e), e);
       }
-  };
-  auto store_b = [&](int buf, auto slot_tag) {
-    constexpr int SLOT = decltype(slot_tag)::value;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      if (bon[i])
-        *reinterpret_cast<u32x4*>(cf_smem + bst[i] + buf * B_BYTES) = breg[SLOT][i];
-  };
-  auto zero_plane = [&](unsigned plane) {
-    u32x4* z = reinterpret_cast<u32x4*>(cf_smem + plane);
-    z[tid] = u32x4{0u, 0u, 0u, 0u};
-    z[tid + 512] = u32x4{0u, 0u, 0u, 0u};
-    if (tid < CF_A_BYTES / 16 - 1024) z[tid + 1024] = u32x4{0u, 0u, 0u, 0u};
-  };
-  auto flag_of = [&](auto slot_tag) {       // (wave-uniform) the slot's bucket holds lo entries
-    constexpr int SLOT = decltype(slot_tag)::value;
-    return (bool)__builtin_amdgcn_readfirstlane(__any((int)((En[SLOT] & CT_LO) != 0u)));
+    spilled[BUF] = (bool)__builtin_amdgcn_readfirstlane(__any((int)more));
+    CT_STAMP(4);
+    const bool need = (bool)__builtin_amdgcn_readfirstlane(__any((int)((En & CT_LO) != 0u)));
+    if (lo_dirty[BUF]) { zero_rows(lo); lo_dirty[BUF] = false; }
+    if (need) {
+      for (unsigned idx = l16; idx < n; idx += 16u) {
+        const unsigned e = ent[Es + idx];
+        if (e & (1u << 13)) put16(lo + a_base + where(e), e);
+      }
+      lo_dirty[BUF] = true;
+    }
+    if (lane == 0) lo_flag[BUF * 4 + p] = need ? 1 : 0;
+    CT_STAMP(5);
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
 
-  Ptr pn = Ptr{0u, 0u};
-  __syncthreads();                                      // planes zeroed
-  if (k_begin < k_end) {
-    load_chunk(k_begin, load_ptr(k_begin), S0{});
-    load_chunk(k_begin + CG_BK, load_ptr(k_begin + CG_BK), S1{});
-    pn = load_ptr(k_begin + 2 * CG_BK);
-    scatter_hi(AHI, S0{});
-    const bool need = flag_of(S0{});
-    if (lane == 0) lo_flag[w] = need ? 1 : 0;
-    store_b(0, S0{});
+  if (nch > 0) {
+    load_window(k_begin / CG_BK);
+    load_entries(k_begin);
+    fill(S0{});
+    load_entries(k_begin + CG_BK);
   }
-  __syncthreads();
-
-  const int a_frag = (64 * rg + li) * CG_ROW + 32 * kg;      // + 32 rows * t, + 16 s
-  const int b_frag = (q0 * 32 + li) * CG_ROW + 32 * kg;      // + term * NCOL rows, + 32 rows * q
-  bool lo_dirty = false;                                // the lo plane holds entries
-  int ab = 0;                                           // hi buffer of the current chunk (j % 3)
-#if CT_PROF
-  unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = __builtin_amdgcn_s_memtime();
+  lds_barrier();
+  // during chunk j: the x side of chunk j + 1 (requested a chunk ago) into the other buffers,
+  // chunk j + 2 requested; the same for this thread's pieces of the W planes
+  auto step = [&](int j, auto buf_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;       // buffers of chunk j + 1
+#if CT_EXP == 5 || CT_EXP == 6 || CT_EXP == 7
+    if (M < 0) {
 #endif
-  auto chunk = [&](int kc, auto buf_tag) {
-    constexpr int BUF = decltype(buf_tag)::value;       // B buffer / register slot of chunk j
-    using Other = std::integral_constant<int, BUF ^ 1>;
-    const int ab1 = ab == 2 ? 0 : ab + 1, ab2 = ab1 == 2 ? 0 : ab1 + 1;
-    const bool need_lo =
-        __builtin_amdgcn_readfirstlane(__any(lo_flag[ab * 8 + (lane & 7)]));
-    // ---- counts above 8 significant bits in this chunk (rare): the lo plane, behind barriers of
-    //      its own -- the entries of chunk j are still in slot BUF ----
-    if (lo_dirty || need_lo) {
-      if (lo_dirty) { zero_plane(ALO); lds_barrier(); }
-      if (need_lo) { scatter_lo(buf_tag); lds_barrier(); }
-      lo_dirty = need_lo;
-    }
-    CT_STAMP(0);
-    const unsigned char* ah = cf_smem + AHI + ab * CF_A_BYTES + a_frag;
-    const unsigned char* al = cf_smem + ALO + a_frag;
-    const unsigned char* bb = cf_smem + BSM + BUF * B_BYTES + b_frag;
-    bf16x8 fh[2][2], fl[2][2], fb[2][3][NQ];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-        fh[s][t] = as_bf16x8(*reinterpret_cast<const u32x4*>(ah + t * 32 * CG_ROW + 16 * s));
-#pragma unroll
-      for (int term = 2; term >= 0; --term)
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-          fb[s][term][q] = as_bf16x8(*reinterpret_cast<const u32x4*>(
-              bb + (term * NCOL + q * 32) * CG_ROW + 16 * s));
-    }
-    if (need_lo) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-          fl[s][t] = as_bf16x8(*reinterpret_cast<const u32x4*>(al + t * 32 * CG_ROW + 16 * s));
-    }
-    auto mm = [&](int s, int term) {
-      if (need_lo) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s][0], fb[s][term][q], acc[0][q], 0, 0, 0);
-          acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s][1], fb[s][term][q], acc[1][q], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s][0], fb[s][term][q], acc[0][q], 0, 0, 0);
-        acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s][1], fb[s][term][q], acc[1][q], 0, 0, 0);
-      }
-    };
-    // buffer j + 2 (chunk j - 1, multiplied before the last barrier): zeroed for chunk j + 2
-    zero_plane(AHI + ab2 * CF_A_BYTES);
-    CT_FENCE; CT_STAMP(1);
-    mm(0, 2); mm(0, 1);
-    CT_FENCE;
-    {   // chunk j + 2 -> slot BUF (chunk j has left it); pointers of j + 3
-      const Ptr p = pn;
-      pn = load_ptr(kc + 3 * CG_BK);
-      load_chunk(kc + 2 * CG_BK, p, buf_tag);
-    }
-    CT_FENCE; CT_STAMP(2);
-    mm(0, 0); mm(1, 2);
-    CT_FENCE;
-    // chunk j + 1 (slot BUF ^ 1, requested an iteration ago) -> buffer j + 1, zeroed an
-    // iteration ago
-    scatter_hi(AHI + ab1 * CF_A_BYTES, Other{});
-    {
-      const bool need = flag_of(Other{});
-      if (lane == 0) lo_flag[ab1 * 8 + w] = need ? 1 : 0;
-    }
-    CT_FENCE; CT_STAMP(3);
-    mm(1, 1);
-    CT_FENCE;
-    store_b(BUF ^ 1, Other{});      // its W planes -> B buffer BUF ^ 1 (read by chunk j - 1)
-    CT_FENCE; CT_STAMP(4);
-    mm(1, 0);
-    CT_FENCE; CT_STAMP(5);
-    lds_barrier();
+    fill(buf_tag);
+    load_entries(k_begin + (j + 2) * CG_BK);
     CT_STAMP(6);
-    ab = ab1;
+    store_b(BUF);
+    load_b(k_begin + (j + 2) * CG_BK);
+#if CT_EXP == 5 || CT_EXP == 6 || CT_EXP == 7
+    }
+#endif
+    CT_STAMP(0);
+    lds_barrier();
+    CT_STAMP(1);
   };
-  for (int kc = k_begin; kc < k_end; kc += 2 * CG_BK) {
-    chunk(kc, S0{});
-    if (kc + CG_BK < k_end) chunk(kc + CG_BK, S1{});
+  for (int j = 0; j < nch; j += 2) {
+    step(j, S1{});
+    if (j + 1 < nch) step(j + 1, S0{});
   }
 #if CT_PROF
   if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)
     for (int k_ = 0; k_ < 8; ++k_) ct_prof[w * 8 + k_] = pacc[k_];
 #endif
-
-  float* dst = direct ? out : out + (size_t)blockIdx.y * M * ldo;
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int col = (q0 + q) * 32 + li;
-      if (col >= N) continue;
-      const float bv = (direct && bias != nullptr) ? bias[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + 64 * rg + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kg;
-        if (m < M) {
-          float v = acc[t][q][r] + bv;
-          if (direct && act == ACT_RELU) v = fmaxf(v, 0.f);
-          dst[(size_t)m * ldo + col] = v;
-        }
-      }
-    }
 }
 
 // ---- weight gradient from tiles: the [512 genes, 16 cells] operand of a chunk scattered into
@@ -1300,7 +1386,7 @@ __global__ __launch_bounds__(512, 1) void count_tiles_dw_kernel(
     const int row = p2 >> 1, part = p2 & 1;
     const int col = row & (CG_NP - 1), rowl = col < N ? row : row - col + (N - 1);
     bon[i] = p2 < 768 && col < NT * 32;
-    boff[i] = ((unsigned)(bon[i] ? rowl : 0) * (unsigned)Kpad + part * 8) * 2u;
+    boff[i] = ((unsigned)(bon[i] ? rowl : 0) * CD_BK + part * 8) * 2u;
     bst[i] = BSM + row * CD_ROW + part * 16;
   }
   struct Ptr { unsigned s, e; };
@@ -1322,7 +1408,7 @@ __global__ __launch_bounds__(512, 1) void count_tiles_dw_kernel(
       E[SLOT][k] = ent[i < n ? s0 + i : 0u];
     }
     const unsigned char* tb = reinterpret_cast<const unsigned char*>(T) +
-                              (size_t)min(kc, k_last) * 2;                      // uniform
+                              (size_t)(min(kc, k_last) / CD_BK) * (3 * CG_NP * CD_BK * 2);   // uniform
 #pragma unroll
     for (int i = 0; i < NPC; ++i)
       if (bon[i]) breg[SLOT][i] = *reinterpret_cast<const u32x4*>(tb + boff[i]);
@@ -1507,7 +1593,7 @@ int count_gemm_tiles(hipStream_t stream, int mode, CountTiles tiles, const uint1
   int splits = 0;
   if (k_main > 0) {
     hipLaunchKernelGGL(split3_transpose_kernel, dim3((Kpad / 8 + 1) / 2), dim3(256), 0, stream,
-                       other, K, N, ld_other, T, Kpad);
+                       other, K, N, ld_other, T, Kpad, bk);
     SCVAE_LAUNCH_CHECK("split3_transpose_kernel");
     splits = cg_splits(mode, M, k_main);
     int k_chunk = k_main;

@@ -7,7 +7,7 @@ import sys
 
 here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, here)
-os.environ["SCVAE_HIP_LIBRARY"] = os.path.join(here, "scvae_amd", "csrc", "libscvae_hip_ctprof.so")
+os.environ["SCVAE_HIP_LIBRARY"] = os.path.join(here, "scvae_amd", "csrc", os.environ.get("CT_LIB", "libscvae_hip_ctprof.so"))
 import torch
 from scvae_amd import _lib
 from scvae_amd.minibatch import synthetic_count_matrix
@@ -36,7 +36,7 @@ raw = ctypes.CDLL(os.environ["SCVAE_HIP_LIBRARY"])
 buf = (ctypes.c_ulonglong * 64)()
 raw.scvae_ct_prof_dump(buf)
 chunks = (F // 32 + 15) // 16          # chunks of one k-split (16 splits at 4096 rows)
-names = ["lo+frags", "zero", "mm+requests", "mm+scatter", "mm+B store", "mm", "barrier"]
+names = ["work/W planes", "barrier", "wait", "unscatter", "scatter", "lo", "requests"]     # waves 0-3 multiply (work, barrier), waves 4-7 stage
 print("count_tiles_fwd_kernel, {} rows: cycles per chunk ({} chunks per workgroup), workgroup (0, 0)".format(rows, chunks))
 for w in range(8):
     v = [buf[w * 8 + k] / chunks for k in range(7)]
