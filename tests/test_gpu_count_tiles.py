@@ -265,3 +265,56 @@ def test_step_with_count_tiles_is_the_step_without(cuda_device, bit_repeatable,
     for i, (a, b) in enumerate(zip(*results)):
         assert torch.isfinite(a).all(), i
         assert torch.equal(a, b), i
+
+
+_TWO_ROLE_SNIPPET = r"""
+import ctypes, hashlib, sys
+import numpy as np, torch
+from scvae_amd import _lib
+lib = _lib.load()
+dev = torch.device("cuda:0")
+P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+digest = hashlib.sha256()
+for rows, F, N, density, epilogue in ((1024, 32738, 100, 0.05, False), (300, 1000, 100, 0.3, False),
+                                      (37, 203, 24, 0.3, True), (256, 64, 128, 0.5, True),
+                                      (100, 32738, 64, 0.05, False), (5, 96, 1, 0.5, True)):
+    rng = np.random.default_rng(rows + F)
+    x = rng.poisson(3.0, size=(rows, F)) * (rng.random((rows, F)) < density)
+    k = max(1, rows * F // 500)
+    x.flat[rng.integers(0, x.size, k)] = rng.integers(256, 65536, k)
+    x.flat[0] = 65535
+    ld = (F + 7) // 8 * 8
+    x16 = torch.zeros(rows, ld, dtype=torch.uint16, device=dev)
+    x16[:, :F] = torch.from_numpy(x.astype(np.uint16)).to(dev)
+    W = torch.from_numpy(rng.standard_normal((F, N)).astype(np.float32) * 0.05).to(dev)
+    b = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(dev) if epilogue else None
+    nb = lib.scvae_count_gemm_workspace_bytes(0, rows, F, N)
+    ws = torch.empty(nb + 16, dtype=torch.uint8, device=dev)
+    out = torch.full((rows, N), float("nan"), device=dev)
+    _lib.check(lib.scvae_count_gemm_u16(0, P(x16), ld, rows, F, P(W), N, N, P(b), 1 if epilogue else 0,
+                                        P(out), N, P(ws), nb, st), "scvae_count_gemm_u16")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    digest.update(out.cpu().numpy().tobytes())
+print("digest", digest.hexdigest())
+"""
+
+
+def test_two_role_forward_kernel_on_the_uint16_batch_is_bit_identical(cuda_device):
+    """``SCVAE_CG_FWD2=1`` -- count_fwd2_kernel with x staged from the dense
+    uint16 batch (four waves multiply, four stage) -- against the default
+    count_gemm_fwd_kernel: the same bits on every shape, counts that need the lo
+    plane, bias + ReLU written directly, ragged tails (mu:53-59)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for flag in ("0", "1"):
+        env = dict(os.environ, SCVAE_CG_FWD2=flag, PYTHONPATH=root)
+        done = subprocess.run([sys.executable, "-c", _TWO_ROLE_SNIPPET], env=env, cwd=root,
+                              capture_output=True, text=True, timeout=300)
+        assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-2000:]
+        digests.append(done.stdout.strip().splitlines()[-1])
+    assert digests[0] == digests[1] and digests[0].startswith("digest ")

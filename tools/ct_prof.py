@@ -13,6 +13,7 @@ from scvae_amd import _lib
 from scvae_amd.minibatch import synthetic_count_matrix
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+dense = len(sys.argv) > 2 and sys.argv[2] == "dense"      # the uint16 batch instead of the tiles
 F, N = 32738, 100
 lib = _lib.load()
 dev = torch.device("cuda:0")
@@ -29,15 +30,19 @@ ws = torch.empty(nb + 16, dtype=torch.uint8, device=dev)
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 for _ in range(3):
-    _lib.check(lib.scvae_count_gemm_tiles(0, ctypes.byref(tiles.struct), P(x16), x16.stride(0), rows, F,
-                                          P(W), N, N, None, 0, P(out), N, P(ws), nb, st), "tiles")
+    if dense:
+        _lib.check(lib.scvae_count_gemm_u16(0, P(x16), x16.stride(0), rows, F, P(W), N, N, None, 0,
+                                            P(out), N, P(ws), nb, st), "dense")
+    else:
+        _lib.check(lib.scvae_count_gemm_tiles(0, ctypes.byref(tiles.struct), P(x16), x16.stride(0), rows, F,
+                                              P(W), N, N, None, 0, P(out), N, P(ws), nb, st), "tiles")
 torch.cuda.synchronize()
 raw = ctypes.CDLL(os.environ["SCVAE_HIP_LIBRARY"])
 buf = (ctypes.c_ulonglong * 64)()
 raw.scvae_ct_prof_dump(buf)
 chunks = (F // 32 + 15) // 16          # chunks of one k-split (16 splits at 4096 rows)
-names = ["work/W planes", "barrier", "wait", "unscatter", "scatter", "lo", "requests"]     # waves 0-3 multiply (work, barrier), waves 4-7 stage
-print("count_tiles_fwd_kernel, {} rows: cycles per chunk ({} chunks per workgroup), workgroup (0, 0)".format(rows, chunks))
+names = ["work/W planes", "barrier", "wait", "unscatter | hi", "scatter", "lo", "requests"]     # waves 0-3 multiply (work, barrier), waves 4-7 stage
+print("count_fwd2_kernel ({}), {} rows: cycles per chunk ({} chunks per workgroup), workgroup (0, 0)".format("uint16 batch" if dense else "tiles", rows, chunks))
 for w in range(8):
     v = [buf[w * 8 + k] / chunks for k in range(7)]
     print("wave {}: ".format(w) + "  ".join("{} {:6.0f}".format(n, x) for n, x in zip(names, v)) +
