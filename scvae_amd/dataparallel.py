@@ -21,9 +21,12 @@ per optimiser step there is
 Tests: ``tests/test_dataparallel_cpu.py`` (gloo, world size 2, no GPU) covers
 ``shard_bounds``, ``merge_batch_norm_statistics`` and the same sequence of
 collectives with plain fp64 torch as the compute stand-in;
-``GradientSynchroniser`` itself is driven by ``tests/test_gpu_dataparallel.py``
-(two ranks on one GPU with the real kernels, gloo moving the bytes, and a
-single-rank RCCL group).  RCCL between several physical GPUs is only run by the
+``tests/test_dataparallel_sync_cpu.py`` (gloo, world size 2) drives
+``GradientSynchroniser`` on a stand-in engine: hook kinds 0 and 2, every
+gradient element summed exactly once around the ranges announced early, state
+broadcast, refused ranges; ``tests/test_gpu_dataparallel.py`` drives it with the
+real kernels (two ranks on one GPU, gloo moving the bytes, and a single-rank
+RCCL group).  RCCL between several physical GPUs is only run by the
 driver's scaling benchmark.
 """
 
