@@ -12,6 +12,7 @@ from time import time
 import numpy
 import scipy.sparse
 
+from scvae_amd.data.processing import build_preprocessor
 from scvae_amd.data.sparse import SparseRowMatrix
 from scvae_amd.defaults import defaults
 from scvae_amd.utilities import normalise_string
@@ -52,8 +53,12 @@ class DataSet:
         self.feature_selection = feature_selection or []
         self.example_filter = example_filter or []
         self.preprocessing_methods = preprocessing_methods or []
+        # (data_set.py:362-375: a preprocessor applied anew every epoch of
+        #  the training loop, va:960-976)
         self.noisy_preprocessing_methods = noisy_preprocessing_methods or []
-        self.noisy_preprocess = None
+        self.noisy_preprocess = (
+            build_preprocessor(self.noisy_preprocessing_methods, noisy=True)
+            if self.noisy_preprocessing_methods else None)
         self.kind = kind
         self.version = version
         self.split_indices = None
@@ -266,7 +271,6 @@ class DataSet:
         (data_set.py:817-905: the result is the models' input x, the counts
         stay the target t); ``binarise()`` for the Bernoulli likelihood."""
         if self.preprocessing_methods and not self.has_preprocessed_values:
-            from scvae_amd.data.processing import build_preprocessor
             print("Preprocessing values ({}).".format(
                 ", ".join(self.preprocessing_methods)))
             self.update(preprocessed_values=build_preprocessor(
@@ -275,7 +279,6 @@ class DataSet:
     def binarise(self):
         """data_set.py:984-1024: values > 0.5 as the Bernoulli targets."""
         if not self.has_binarised_values:
-            from scvae_amd.data.processing import build_preprocessor
             self.update(binarised_values=build_preprocessor(["binarise"])(
                 self.values))
 

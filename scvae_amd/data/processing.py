@@ -1,5 +1,5 @@
 """Value preprocessing of a data set (``scvae/data/processing.py:305-333,
-496-513``): the encoder input x may be a transformed copy of the counts, the
+496-522``): the encoder input x may be a transformed copy of the counts, the
 likelihood always sees the counts themselves (or, for the Bernoulli likelihood,
 their binarisation).  Element-wise NumPy / SciPy work on the host, once per
 data set; sparse matrices stay sparse (every method maps 0 to 0)."""
@@ -62,14 +62,29 @@ def _binarise(values):
     return _on_values(values, lambda v: (v > 0.5).astype(numpy.float32))
 
 
+@_register("bernoulli_sample")
+def _bernoulli_sample(values):
+    """A Bernoulli draw per value, the value its probability
+    (``scvae/data/processing.py:516-522``: what "binarise" means when the
+    preprocessing is noisy -- a new sample of the data set every epoch).
+    NumPy's global generator, as in the reference: the draws of a run follow
+    ``numpy.random.seed``."""
+    def draw(probabilities):
+        probabilities = numpy.asarray(probabilities, dtype=numpy.float64)
+        if probabilities.size and (probabilities.min() < 0
+                                   or probabilities.max() > 1):
+            raise ValueError(
+                "Bernoulli sampling needs values in [0, 1]; found [{:g}, {:g}]."
+                .format(probabilities.min(), probabilities.max()))
+        return numpy.random.binomial(1, probabilities)
+    return _on_values(values, draw)
+
+
 def build_preprocessor(preprocessing_methods, noisy=False):
-    if noisy:
-        raise NotImplementedError(
-            "Noisy preprocessing (a new Bernoulli sample every epoch, "
-            "scvae/data/processing.py:311-312, 516-522) is not part of this "
-            "build.")
     preprocessers = []
     for method in preprocessing_methods or []:
+        if noisy and method == "binarise":
+            method = "bernoulli_sample"
         if method not in PREPROCESSERS:
             raise ValueError(
                 "Preprocessing method `{}` not found.".format(method))

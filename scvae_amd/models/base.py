@@ -169,23 +169,28 @@ class ModelBase:
         raise NotImplementedError
 
     # -- data ------------------------------------------------------------------
-    def _device_matrices(self, data_set):
+    def _device_matrices(self, data_set, noisy=False):
+        """(input, target) of a data set on the device.  ``noisy``: the data
+        set's noisy preprocessor applied to its values -- a new draw at every
+        call -- as both input and target (va:960-976)."""
         from scvae_amd.minibatch import DeviceCSR
         import scipy.sparse
-        if data_set.noisy_preprocess or data_set.noisy_preprocessing_methods:
-            raise mu.not_in_this_build(
-                "Noisy preprocessing at every epoch", "va:960-976")
 
         def upload(values):
             if not scipy.sparse.issparse(values):
                 values = scipy.sparse.csr_matrix(
                     numpy.asarray(values, dtype=numpy.float32))
             return DeviceCSR.from_scipy(values, self.engine.device)
-        if self.reconstruction_distribution_name == "bernoulli":
+        transformed = None     # the host target where it is not data_set.values
+        if noisy:
+            transformed = data_set.noisy_preprocess(data_set.values)
+            x = t = upload(transformed)
+        elif self.reconstruction_distribution_name == "bernoulli":
             # the Bernoulli likelihood models the binarised values
             # (va:854-857; "binarise" = values > 0.5, data/processing.py:511-513)
             if data_set.has_binarised_values:
-                t = upload(data_set.binarised_values)
+                transformed = data_set.binarised_values
+                t = upload(transformed)
             else:
                 values = data_set.values
                 if scipy.sparse.issparse(values):
@@ -197,15 +202,19 @@ class ModelBase:
                 else:
                     binarised = (numpy.asarray(values) > 0.5).astype(
                         numpy.float32)
+                transformed = binarised
                 t = upload(binarised)
         else:
             t = upload(data_set.values)
-        if data_set.has_preprocessed_values:
+        if noisy:
+            pass
+        elif data_set.has_preprocessed_values:
             x = upload(data_set.preprocessed_values)
         elif self.reconstruction_distribution_name == "bernoulli":
             x = upload(data_set.values)
         else:
             x = t
+        t.transformed_values = transformed
         t.decoder_extra = self._decoder_extra_inputs(data_set)
         # N of the constrained Poisson: the count sums of the data set
         # (count_sum_parameter, va:823-826, 1017-1019)
@@ -380,10 +389,17 @@ class ModelBase:
             # with fp32 atomics.  Absent / False leaves the plan's default --
             # scvae_default_dd_atomics, SCVAE_DD_ACCUMULATION -- alone.
             engine.set_dd_atomics(False)
-        x_train, t_train = self._device_matrices(training_set)
+        # (va:840-860: with a noisy preprocessor the matrices are drawn anew at
+        #  the head of every epoch; the draw here sizes the buffers)
+        noisy_preprocess = training_set.noisy_preprocess is not None
+        x_train, t_train = self._device_matrices(
+            training_set, noisy=noisy_preprocess)
         n_examples_train = training_set.number_of_examples
         if validation_set:
-            x_valid, t_valid = self._device_matrices(validation_set)
+            x_valid, t_valid = self._device_matrices(
+                validation_set,
+                noisy=noisy_preprocess
+                and validation_set.noisy_preprocess is not None)
             n_examples_valid = validation_set.number_of_examples
         sync = None
         if world > 1:
@@ -527,7 +543,23 @@ class ModelBase:
         from scvae_amd.minibatch import philox_normal
 
         checkpoint_writer = mu.CheckpointWriter()
+        first_epoch = True
         for epoch in range(epoch_start, number_of_epochs):
+            if noisy_preprocess:
+                # (va:960-976; the first epoch uses the draw made above)
+                say("Noisily preprocess values.")
+                noisy_time_start = time()
+                if not first_epoch:
+                    x_train, t_train = self._device_matrices(
+                        training_set, noisy=True)
+                    if (validation_set
+                            and validation_set.noisy_preprocess is not None):
+                        x_valid, t_valid = self._device_matrices(
+                            validation_set, noisy=True)
+                say("Values noisily preprocessed ({}).".format(
+                    format_duration(time() - noisy_time_start)))
+                say()
+            first_epoch = False
             epoch_time_start = time()
             if self.number_of_warm_up_epochs:
                 warm_up_weight = float(
@@ -1104,7 +1136,17 @@ class ModelBase:
         engine = self.engine
         engine.load_state_dict(mu.load_checkpoint(checkpoint))
         epoch = mu.checkpoint_epoch(checkpoint)
-        x_eval, t_eval = self._device_matrices(evaluation_set)
+        # (va:1861-1885: a noisy preprocessor draws the evaluation set once)
+        noisy_preprocess = evaluation_set.noisy_preprocess is not None
+        if noisy_preprocess and master:
+            print("Noisily preprocess values.")
+        noisy_time_start = time()
+        x_eval, t_eval = self._device_matrices(
+            evaluation_set, noisy=noisy_preprocess)
+        if noisy_preprocess and master:
+            print("Values noisily preprocessed ({}).".format(
+                format_duration(time() - noisy_time_start)))
+            print()
 
         if log_results and master:
             eval_summary_directory = os.path.join(log_directory, "evaluation")
@@ -1174,7 +1216,11 @@ class ModelBase:
 
         output_sets = [None] * len(output_versions)
         if "transformed" in output_versions:
-            output_sets[output_versions.index("transformed")] = evaluation_set
+            # (va:2135-2158: the binarised / noisily preprocessed values the
+            #  likelihood saw, where those are not the set's own)
+            output_sets[output_versions.index("transformed")] = (
+                wrap(t_eval.transformed_values, "transformed")
+                if t_eval.transformed_values is not None else evaluation_set)
         if "reconstructed" in output_versions:
             import scipy.sparse
             p_x_mean_eval = outputs["p_x_mean"].cpu().numpy()

@@ -258,7 +258,11 @@ def test_cli_with_preprocessed_input(tmp_path, cuda_device, capsys):
     cli.main(["train"] + arguments + ["-e", "1"])
     results = cli.main(["evaluate"] + arguments)
     transformed, reconstructed, latent = results["end_of_training"]
-    assert transformed.has_binarised_values
+    # (va:2135-2158: the transformed set carries the binarised targets as its values)
+    assert transformed.version == "transformed"
+    binary = transformed.values
+    binary = np.asarray(binary.todense() if hasattr(binary, "todense") else binary)
+    assert set(np.unique(binary)) <= {0.0, 1.0} and binary.sum() > 0
     values = np.asarray(reconstructed.values)
     assert values.min() >= 0 and values.max() <= 1
 
@@ -537,3 +541,62 @@ def test_non_blocking_state_is_a_snapshot(cuda_device):
     engine.load_state_dict(got)
     assert torch.equal(engine.params.cpu(), want["params"])
     assert engine.adam_t == 5
+
+
+def test_noisy_preprocessing_draws_the_data_set_anew_every_epoch(tmp_path, cuda_device,
+                                                                capsys):
+    """``--noisy-preprocessing-methods binarise`` (va:840-860, 960-976,
+    1861-1885; processing.py:311-312, 516-522): input and target of every epoch
+    are one Bernoulli draw of the values (here probabilities in [0, 1]); the
+    evaluation draws once and returns what it drew as the transformed set."""
+    from scvae_amd.data import DataSet
+    from scvae_amd.models import VariationalAutoencoder
+    from scvae_amd.models.utilities import load_learning_curves
+    rng = np.random.default_rng(11)
+    n, F = 160, 30
+    probabilities = (rng.random((n, F)) * (rng.random((n, F)) > 0.4)).astype(np.float32)
+    full = DataSet("toy", values=probabilities,
+                   noisy_preprocessing_methods=["binarise"],
+                   example_names=np.arange(n).astype(str),
+                   feature_names=np.arange(F).astype(str))
+    training_set, validation_set, test_set = full.split()
+    assert training_set.noisy_preprocess is not None
+    model = VariationalAutoencoder(
+        feature_size=F, latent_size=3, hidden_sizes=[12],
+        reconstruction_distribution="bernoulli", log_directory=str(tmp_path))
+    seen = []
+    upload = model._device_matrices
+
+    def spy(data_set, noisy=False):
+        x, t = upload(data_set, noisy=noisy)
+        seen.append((data_set.kind, noisy, x is t, t.transformed_values))
+        return x, t
+    model._device_matrices = spy
+    assert model.train(training_set, validation_set, number_of_epochs=3,
+                       minibatch_size=32, learning_rate=1e-2) == 0
+    out = capsys.readouterr().out
+    assert out.count("Noisily preprocess values.") == 3
+    curves = load_learning_curves(model)
+    assert len(curves["training"]["lower_bound"]) == 3
+    assert np.all(np.isfinite(curves["training"]["lower_bound"]))
+    draws = [s for s in seen if s[0] == "training"]
+    assert len(draws) == 3 and all(noisy and same for _, noisy, same, _ in draws)
+    assert len([s for s in seen if s[0] == "validation"]) == 3
+    matrices = [np.asarray(d[3].todense() if hasattr(d[3], "todense") else d[3])
+                for d in draws]
+    for m in matrices:
+        assert set(np.unique(m)) <= {0.0, 1.0}
+        assert (m > 0).sum() > 0 and ((m > 0) <= (np.asarray(
+            training_set.values.todense() if hasattr(training_set.values, "todense")
+            else training_set.values) > 0)).all()
+    assert not np.array_equal(matrices[0], matrices[1])     # a new draw per epoch
+    assert not np.array_equal(matrices[1], matrices[2])
+
+    transformed, reconstructed, latent = model.evaluate(test_set, minibatch_size=16)
+    out = capsys.readouterr().out
+    assert "Values noisily preprocessed" in out
+    assert transformed is not test_set and transformed.version == "transformed"
+    values = transformed.values
+    values = np.asarray(values.todense() if hasattr(values, "todense") else values)
+    assert set(np.unique(values)) <= {0.0, 1.0}
+    assert reconstructed.values.shape == (test_set.number_of_examples, F)

@@ -466,8 +466,26 @@ def test_preprocessing_methods():
                        want, rtol=1e-5)
     with pytest.raises(ValueError, match="not found"):
         build_preprocessor(["square"])
-    with pytest.raises(NotImplementedError):
-        build_preprocessor(["binarise"], noisy=True)
+    # noisy: "binarise" is a Bernoulli draw per value (processing.py:311-312, 516-522)
+    probabilities = np.clip(dense / dense.max(), 0, 1).astype(np.float32)
+    np.random.seed(3)
+    want = np.random.binomial(1, probabilities.astype(np.float64)).astype(np.float32)
+    np.random.seed(3)
+    drawn = build_preprocessor(["binarise"], noisy=True)(probabilities)
+    assert np.array_equal(drawn, want) and set(np.unique(drawn)) <= {0.0, 1.0}
+    np.random.seed(4)
+    sparse_draw = build_preprocessor(["binarise"], noisy=True)(sp.csr_matrix(probabilities))
+    assert sp.issparse(sparse_draw) and sparse_draw.nnz == int(sparse_draw.sum())
+    assert ((sparse_draw.toarray() > 0) <= (probabilities > 0)).all()
+    with pytest.raises(ValueError, match=r"\[0, 1\]"):
+        build_preprocessor(["binarise"], noisy=True)(dense + 2)
+    noisy_set = DataSet("toy", values=sp.csr_matrix(probabilities),
+                        noisy_preprocessing_methods=["binarise"],
+                        example_names=np.arange(30).astype(str),
+                        feature_names=np.arange(12).astype(str))
+    assert noisy_set.noisy_preprocess is not None
+    assert DataSet("toy", values=sparse, example_names=np.arange(30).astype(str),
+                   feature_names=np.arange(12).astype(str)).noisy_preprocess is None
     data = DataSet("toy", values=sparse, preprocessing_methods=["log"],
                    example_names=np.arange(30).astype(str),
                    feature_names=np.arange(12).astype(str))
