@@ -534,6 +534,40 @@ int philox_normal(hipStream_t stream, float* out, int64_t rows, int cols, int64_
                   uint64_t seed, uint64_t stream_id, int64_t block_rows = 0,
                   int64_t block_stride = 0);
 // Local row -> row of the global minibatch (data parallel).  A buffer of `rows` rows stacks
+// Evaluation steps of the VAE: everything between the input layer's product and the likelihood
+// heads for 16 cells per workgroup, one launch (tilechain.hip: eval_mlp_kernel).  With
+// is_training = False a batch-normalised layer uses its moving statistics (mu:60-70), so a cell's
+// path through the hidden layers, the posterior heads, the reparameterised sample (one sample per
+// cell) and the decoder's layers needs no other cell.
+constexpr int EM_MAX_OPS = 10;
+enum { EM_HIDDEN = 0, EM_MU = 1, EM_LOG_SIGMA = 2 };
+struct EvalMlpArgs {
+  int rows = 0, n_ops = 0;
+  const float* a0 = nullptr;      // [rows, K0] pre-normalisation output of the input layer
+  float* h0 = nullptr;            // [rows, K0] its normalised output (written)
+  int K0 = 0;
+  const float* mean0 = nullptr;   // its moving statistics, its beta
+  const float* var0 = nullptr;
+  const float* beta0 = nullptr;
+  struct Op {
+    const float* W = nullptr;     // [K, N]
+    const float* b = nullptr;
+    const float* mean = nullptr;  // EM_HIDDEN: the layer's moving statistics, its beta
+    const float* var = nullptr;
+    const float* beta = nullptr;
+    float* pre = nullptr;         // [rows, N] x W + b (EM_HIDDEN: may be nullptr)
+    float* out = nullptr;         // EM_HIDDEN: [rows, N] normalised + relu
+    int K = 0, N = 0, kind = EM_HIDDEN;
+  } op[EM_MAX_OPS];
+  // the latent stage, behind the EM_LOG_SIGMA op (gauss_latent_fwd for one sample per cell)
+  const float* eps = nullptr;     // [rows, L]
+  float* z = nullptr;             // [rows, L]
+  float* kl_elem = nullptr;       // [rows, L]
+  float* kl_cell = nullptr;       // [rows]
+  int L = 0;
+};
+int eval_mlp(hipStream_t stream, const EvalMlpArgs& q);
+
 // rows / cells passes (samples, GMVAE clusters) of this rank's `cells` cells, which are cells
 // offset .. offset + cells - 1 of the global_cells cells of the step: local row p*cells + b is
 // global row p*global_cells + offset + b.  cells == 0: identity.

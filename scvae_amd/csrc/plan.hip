@@ -645,6 +645,59 @@ static TileBN tile_bn(scvae_plan* p, Dense& d, const float* part, int chunks, in
   return t;
 }
 
+// ---- evaluation steps: the hidden layers of the pass in ONE launch ----
+// With is_training = False a batch-normalised layer uses its moving statistics (mu:60-70): every
+// layer between the input layer's product and the likelihood heads then needs nothing but the
+// cell's own row of the layer below -- normalise + relu, product, bias, the posterior heads, the
+// reparameterised sample and the decoder's layers are one launch of eval_mlp_kernel
+// (tilechain.hip: 16 cells per workgroup, the activations stay in LDS) instead of five GEMM, four
+// normalisation and one latent launch (round 6: 120 of an 845 us evaluation step; the same
+// stages recorded into one tile_chain_fwd_kernel launch took as long as the launches).
+// One sample per cell, analytic KL, a drawn z.  SCVAE_EVAL_CHAIN=0: the launches.
+static bool eval_chain_ok(const scvae_plan* p, const scvae_step_args* a, int B, int S,
+                          bool training) {
+  const scvae_model_config& c = p->cfg;
+  static const bool env_on = [] { const char* e = getenv("SCVAE_EVAL_CHAIN"); return !(e && e[0] == '0'); }();
+  if (!env_on || training) return false;
+  if (!c.batch_norm || p->enc.empty() || p->dec.empty()) return false;
+  if (c.latent_mode != 0 || c.decoder_extra != 0 || c.latent_size > 128) return false;
+  if (S != 1 || a->deterministic_z || !a->eps) return false;
+  if (B <= 128) return false;                   // (the mid-chain kernels' regime)
+  for (const auto& d : p->enc) if (d.n_out > 128 || !d.bn) return false;
+  for (const auto& d : p->dec) if (d.n_out > 128 || !d.bn) return false;
+  return ((int)p->enc.size() - 1) + 2 + (int)p->dec.size() <= EM_MAX_OPS;
+}
+static int eval_chain(scvae_plan* p, const scvae_step_args* a, hipStream_t s, int B) {
+  EvalMlpArgs q;
+  Dense& d0 = p->enc[0];
+  q.rows = B;
+  q.a0 = d0.a; q.h0 = d0.h; q.K0 = d0.n_out;
+  q.mean0 = p->moving + d0.mov_mean; q.var0 = p->moving + d0.mov_var; q.beta0 = p->params + d0.beta;
+  int n = 0;
+  auto hidden = [&](Dense& d) {
+    EvalMlpArgs::Op& o = q.op[n++];
+    o.W = p->params + d.w; o.b = p->params + d.b;
+    o.mean = p->moving + d.mov_mean; o.var = p->moving + d.mov_var; o.beta = p->params + d.beta;
+    o.pre = d.a; o.out = d.h; o.K = d.n_in; o.N = d.n_out; o.kind = EM_HIDDEN;
+  };
+  for (size_t i = 1; i < p->enc.size(); ++i) hidden(p->enc[i]);
+  const int L = p->cfg.latent_size;
+  {
+    EvalMlpArgs::Op& o = q.op[n++];
+    o.W = p->params + p->mu.w; o.b = p->params + p->mu.b; o.pre = p->mu_pre;
+    o.K = p->mu.n_in; o.N = L; o.kind = EM_MU;
+  }
+  {
+    EvalMlpArgs::Op& o = q.op[n++];
+    o.W = p->params + p->ls.w; o.b = p->params + p->ls.b; o.pre = p->ls_pre;
+    o.K = p->ls.n_in; o.N = L; o.kind = EM_LOG_SIGMA;
+  }
+  for (auto& d : p->dec) hidden(d);
+  q.n_ops = n;
+  q.eps = a->eps; q.z = p->z; q.kl_elem = p->kl_elem; q.kl_cell = p->kl_cell; q.L = L;
+  return eval_mlp(s, q);
+}
+
 // Data-parallel steps (scvae_plan_set_sync): the statistics of layer d over the GLOBAL minibatch
 // before the tile kernel that consumes them -- this rank's chunks merged into d.stats, the hook
 // (kind 1: all-gather + Chan merge over the ranks), and a TileBN that hands them over as given
@@ -913,6 +966,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
   // launch) or `resident` (scvae_plan_set_tile_resident: the whole pass in ONE launch, grid
   // barriers where the segments end).
   const bool resident = tile && tile_resident_ok(p, R);
+  const bool evalc = !mid && !tile && eval_chain_ok(p, a, B, S, training);
   const bool record = resident || (tile && !p->sync && p->mid_bar && tile_segments_on());
   TileChainFwdArgs cf;
   int cf_tiles = 0;
@@ -990,6 +1044,16 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       if ((rc = fwd_stage(q, 1))) return rc;     // (the latent stage needs the tile's own rows)
     }
     h = p->enc.back().h; ld = p->enc.back().n_out;
+  } else if (evalc) {
+    // the input layer's product, then everything up to the decoder's output in one launch
+    Dense& d0 = p->enc[0];
+    if ((rc = plan_gemm(p, s, false, false, p->step_x, p->params + d0.w, p->params + d0.b, d0.a, B,
+                        d0.n_out, d0.n_in, F, d0.n_out, d0.n_out, ACT_NONE, false)))
+      return rc;
+    // (the fetch / noise of the next step leave the stream here, as in the launch chain)
+    if ((rc = plan_side_fork(p, s, 4))) return rc;
+    if ((rc = eval_chain(p, a, s, B))) return rc;
+    h = p->enc.back().h; ld = p->enc.back().n_out;
   } else {
   bool first = true;
   for (auto& d : p->enc) {
@@ -1024,7 +1088,7 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
     if ((rc = gauss_latent_fwd(s, p->mu_pre, ls_pre, a->eps, p->z, p->kl_elem, p->kl_cell,
                                mc_kl ? p->kl_cell : nullptr, S, B, L, a->deterministic_z)))
       return rc;
-  } else if (!mid) {
+  } else if (!mid && !evalc) {
   if ((rc = dense_input(p, s, mu, h, ld, B, training, &h_mu, &ld_mu))) return rc;
   if ((rc = plan_gemm(p, s, false, false, h_mu, p->params + mu.w, p->params + mu.b, p->mu_pre, B, L,
                       mu.n_in, ld_mu, L, L, ACT_NONE, false)))
@@ -1086,6 +1150,8 @@ static int vae_step(scvae_plan* p, const scvae_step_args* a, hipStream_t s) {
       if ((rc = fwd_flush())) return rc;
       if ((rc = latent_outputs())) return rc;
     }
+    dch = p->dec.back().h; ld = p->dec.back().n_out;
+  } else if (evalc) {
     dch = p->dec.back().h; ld = p->dec.back().n_out;
   } else {
   for (auto& d : p->dec) {

@@ -1077,4 +1077,167 @@ int tile_chain_backward(hipStream_t s, const TileChainBwdArgs& q, int tiles, uns
   return 0;
 }
 
+// ---- evaluation steps: the hidden stack in one launch (EvalMlpArgs, kernels.hpp) ----
+// A workgroup of eight waves owns 16 cells; wave w owns output columns 16 w .. 16 w + 15 of every
+// layer (widths <= 128).  The cells' activations never leave LDS between the layers ([16][130]
+// fp32: the MFMA's A operand without bank conflicts); a layer's weights come through registers
+// into LDS ([128][144]: the B operand likewise), requested while the layer before is multiplied;
+// v_mfma_f32_16x16x4_f32 (fp32 products, as gemm_kernel); bias, moving-statistics normalisation
+// and relu on the accumulators.  The two posterior heads multiply the same input; the latent
+// stage (gauss_latent_fwd's formulas, a wave per cell) writes z as the decoder's input.  What the
+// rest of the step reads -- the normalised layers, mu / log sigma, z, the KL terms -- goes to
+// memory as the launch chain leaves it.
+constexpr int EM_ROWS = 16;
+constexpr int EM_THREADS = 512;
+constexpr int EM_PA = 130;          // As pitch: 130 = 2 (mod 32): row i, k -> bank 2 i + k
+constexpr int EM_PW = 144;          // Ws pitch: 144 = 16 (mod 32): k, column j -> bank 16 k + j
+constexpr size_t EM_LDS = (size_t)(3 * EM_ROWS * EM_PA + 128 * EM_PW) * sizeof(float);
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(EM_THREADS) void eval_mlp_kernel(EvalMlpArgs q) {
+  extern __shared__ __attribute__((aligned(16))) float em[];
+  float* As = em;                                   // [16][EM_PA] the layer's input
+  float* Ws = As + EM_ROWS * EM_PA;                 // [128][EM_PW] the layer's weights
+  float* Mu = Ws + 128 * EM_PW;                     // [16][EM_PA] mu, log sigma pre-activations
+  float* Ls = Mu + EM_ROWS * EM_PA;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = tid & 127, rl = tid >> 7;           // staging: column c, rows / k rl, rl + 4, ...
+  const int r0 = blockIdx.x * EM_ROWS;
+  const int nr = min(EM_ROWS, q.rows - r0);
+  const int li = lane & 15, kq = lane >> 4;         // MFMA: row / column li, k (or row group) kq
+  const int col = 16 * w + li;                      // this lane's output column
+
+  // the weights of a layer: thread (c, rl) holds W[rl + 4 u][c], zero beyond [K, N]
+  float wreg[32];
+  auto load_w = [&](int o) {
+    const float* W = q.op[o].W;
+    const int K = q.op[o].K, N = q.op[o].N;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      const int k = rl + 4 * u;
+      wreg[u] = (c < N && k < K) ? W[(size_t)k * N + c] : 0.f;
+    }
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int u = 0; u < 32; ++u) Ws[(rl + 4 * u) * EM_PW + c] = wreg[u];
+  };
+  load_w(0);
+  // ---- the input layer's output: normalise + relu -> As (and h0) ----
+  {
+    const int K0 = q.K0;
+    const bool on = c < K0;
+    const float mean = on ? q.mean0[c] : 0.f;
+    const float istd = on ? rsqrtf(q.var0[c] + BN_EPSILON) : 0.f;
+    const float beta = on ? q.beta0[c] : 0.f;
+#pragma unroll
+    for (int u = 0; u < EM_ROWS / 4; ++u) {
+      const int r = rl + 4 * u;
+      float v = 0.f;
+      if (on && r < nr) {
+        v = fmaxf(bn_normalise(q.a0[(size_t)(r0 + r) * K0 + c], mean, istd, beta), 0.f);
+        q.h0[(size_t)(r0 + r) * K0 + c] = v;
+      }
+      As[r * EM_PA + c] = v;                          // (columns up to 127: zero beyond K0)
+    }
+  }
+  store_w();
+  __syncthreads();
+
+  for (int o = 0; o < q.n_ops; ++o) {
+    const int K = q.op[o].K, N = q.op[o].N, kind = q.op[o].kind;
+    // the next layer's weights travel under this layer's product
+    if (o + 1 < q.n_ops) load_w(o + 1);
+    const bool live = col < N;
+    const float bias = live ? q.op[o].b[col] : 0.f;
+    float mean = 0.f, istd = 0.f, beta = 0.f;
+    if (kind == EM_HIDDEN && live) {
+      mean = q.op[o].mean[col];
+      istd = rsqrtf(q.op[o].var[col] + BN_EPSILON);
+      beta = q.op[o].beta[col];
+    }
+    f32x4a acc = {0.f, 0.f, 0.f, 0.f};
+    if (16 * w < N) {
+      const float* ap = As + li * EM_PA + kq;
+      const float* bp = Ws + kq * EM_PW + 16 * w + li;
+      const int K4 = (K + 3) & ~3;
+#pragma unroll 4
+      for (int k = 0; k < K4; k += 4)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[k], bp[k * EM_PW], acc, 0, 0, 0);
+    }
+    __syncthreads();                                // (every wave done with As and Ws)
+    // accumulator element v: row 4 kq + v, column col
+    float* dst = kind == EM_HIDDEN ? As : kind == EM_MU ? Mu : Ls;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int r = 4 * kq + v;
+      const float pre = acc[v] + bias;
+      float val = 0.f;
+      if (live && r < nr) {
+        val = kind == EM_HIDDEN ? fmaxf(bn_normalise(pre, mean, istd, beta), 0.f) : pre;
+        if (q.op[o].pre) q.op[o].pre[(size_t)(r0 + r) * N + col] = pre;
+        if (kind == EM_HIDDEN && q.op[o].out) q.op[o].out[(size_t)(r0 + r) * N + col] = val;
+      }
+      dst[r * EM_PA + col] = val;                     // (columns up to 127: zero beyond N)
+    }
+    if (o + 1 < q.n_ops) store_w();
+    __syncthreads();
+    if (kind == EM_LOG_SIGMA) {
+      // ---- the latent stage: z = mu + sigma eps -> As; KL per unit and per cell ----
+      const int L = q.L;
+      for (int r = w; r < EM_ROWS; r += EM_THREADS / 64) {
+        float total = 0.f;
+        for (int part = 0; part < 2; ++part) {
+          const int l = 64 * part + lane;
+          const bool on = l < L && r < nr;
+          const float mu = fminf(fmaxf(Mu[r * EM_PA + l], -F32_MAX_HALF), F32_MAX_HALF);
+          const float ls = fminf(fmaxf(Ls[r * EM_PA + l], -3.f), 3.f);
+          const float sigma = __expf(ls);
+          float zv = 0.f, kl = 0.f;
+          if (on) {
+            const size_t i = (size_t)(r0 + r) * L + l;
+            zv = fmaf(sigma, q.eps[i], mu);
+            kl = gauss_kl_elem(mu, sigma, ls);
+            q.z[i] = zv;
+            q.kl_elem[i] = kl;
+          }
+          As[r * EM_PA + l] = zv;
+          total += wave_sum(kl);
+        }
+        if (lane == 0 && r < nr) q.kl_cell[r0 + r] = total;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+int eval_mlp(hipStream_t s, const EvalMlpArgs& q) {
+  SCVAE_ARG(q.rows > 0 && q.n_ops >= 1 && q.n_ops <= EM_MAX_OPS);
+  SCVAE_ARG(q.a0 && q.h0 && q.mean0 && q.var0 && q.beta0 && q.K0 >= 1 && q.K0 <= 128);
+  int K = q.K0, n_ls = 0;
+  for (int o = 0; o < q.n_ops; ++o) {
+    const EvalMlpArgs::Op& op = q.op[o];
+    SCVAE_ARG(op.W && op.b && op.N >= 1 && op.N <= 128 && op.K == K);
+    SCVAE_ARG(op.kind >= EM_HIDDEN && op.kind <= EM_LOG_SIGMA);
+    if (op.kind == EM_HIDDEN) { SCVAE_ARG(op.mean && op.var && op.beta); K = op.N; }
+    else SCVAE_ARG(op.pre);
+    if (op.kind == EM_MU) SCVAE_ARG(o + 1 < q.n_ops && q.op[o + 1].kind == EM_LOG_SIGMA);
+    if (op.kind == EM_LOG_SIGMA) {
+      SCVAE_ARG(o >= 1 && q.op[o - 1].kind == EM_MU && q.op[o - 1].N == op.N && op.N == q.L);
+      SCVAE_ARG(q.eps && q.z && q.kl_elem && q.kl_cell);
+      K = q.L; ++n_ls;
+    }
+  }
+  SCVAE_ARG(n_ls <= 1);
+  static const int prepared = [] {
+    return (int)max_dynamic_lds(reinterpret_cast<const void*>(eval_mlp_kernel), (int)EM_LDS);
+  }();
+  SCVAE_HIP((hipError_t)prepared);
+  hipLaunchKernelGGL(eval_mlp_kernel, dim3((q.rows + EM_ROWS - 1) / EM_ROWS), dim3(EM_THREADS),
+                     EM_LDS, s, q);
+  SCVAE_LAUNCH_CHECK("eval_mlp_kernel");
+  return 0;
+}
+
 }  // namespace scvae
