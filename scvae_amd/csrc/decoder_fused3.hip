@@ -1418,6 +1418,9 @@ __global__ __launch_bounds__(d4_threads(NPW)) void decoder_head4_kernel(
   if (dd_atomic) {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7u;
+    // (probe build, timing only -- the sums are wrong: the workgroups of an XCD spread over the
+    //  eight copies, a quarter of the adds per line at a time)
+    if (dbg & 16) xcc = (blockIdx.x >> 3) & 7u;
   }
   const int n_ht3 = (H + 31) / 32, n_ht2 = DBP ? H / 32 : (H + 1 + 31) / 32;
   // this wave's h tiles: ht, ht + 4, ... (NHT of them; one for H <= 126)
