@@ -560,7 +560,7 @@ struct EvalMlpArgs {
     int K = 0, N = 0, kind = EM_HIDDEN;
   } op[EM_MAX_OPS];
   // the latent stage, behind the EM_LOG_SIGMA op (gauss_latent_fwd for one sample per cell)
-  const float* eps = nullptr;     // [rows, L]
+  const float* eps = nullptr;     // [rows, L]; nullptr: z = mu (deterministic_z)
   float* z = nullptr;             // [rows, L]
   float* kl_elem = nullptr;       // [rows, L]
   float* kl_cell = nullptr;       // [rows]

@@ -653,7 +653,8 @@ static TileBN tile_bn(scvae_plan* p, Dense& d, const float* part, int chunks, in
 // (tilechain.hip: 16 cells per workgroup, the activations stay in LDS) instead of five GEMM, four
 // normalisation and one latent launch (round 6: 120 of an 845 us evaluation step; the same
 // stages recorded into one tile_chain_fwd_kernel launch took as long as the launches).
-// One sample per cell, analytic KL, a drawn z.  SCVAE_EVAL_CHAIN=0: the launches.
+// One sample per cell (drawn, or the deterministic z = mu), analytic KL.  SCVAE_EVAL_CHAIN=0:
+// the launches.
 static bool eval_chain_ok(const scvae_plan* p, const scvae_step_args* a, int B, int S,
                           bool training) {
   const scvae_model_config& c = p->cfg;
@@ -661,7 +662,7 @@ static bool eval_chain_ok(const scvae_plan* p, const scvae_step_args* a, int B, 
   if (!env_on || training) return false;
   if (!c.batch_norm || p->enc.empty() || p->dec.empty()) return false;
   if (c.latent_mode != 0 || c.decoder_extra != 0 || c.latent_size > 128) return false;
-  if (S != 1 || a->deterministic_z || !a->eps) return false;
+  if (S != 1 || (!a->deterministic_z && !a->eps)) return false;
   if (B <= 128) return false;                   // (the mid-chain kernels' regime)
   for (const auto& d : p->enc) if (d.n_out > 128 || !d.bn) return false;
   for (const auto& d : p->dec) if (d.n_out > 128 || !d.bn) return false;
@@ -694,7 +695,8 @@ static int eval_chain(scvae_plan* p, const scvae_step_args* a, hipStream_t s, in
   }
   for (auto& d : p->dec) hidden(d);
   q.n_ops = n;
-  q.eps = a->eps; q.z = p->z; q.kl_elem = p->kl_elem; q.kl_cell = p->kl_cell; q.L = L;
+  q.eps = a->deterministic_z ? nullptr : a->eps;
+  q.z = p->z; q.kl_elem = p->kl_elem; q.kl_cell = p->kl_cell; q.L = L;
   return eval_mlp(s, q);
 }
 

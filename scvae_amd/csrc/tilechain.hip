@@ -1197,7 +1197,7 @@ __global__ __launch_bounds__(EM_THREADS) void eval_mlp_kernel(EvalMlpArgs q) {
           float zv = 0.f, kl = 0.f;
           if (on) {
             const size_t i = (size_t)(r0 + r) * L + l;
-            zv = fmaf(sigma, q.eps[i], mu);
+            zv = q.eps ? fmaf(sigma, q.eps[i], mu) : mu;      // (no noise: the deterministic z)
             kl = gauss_kl_elem(mu, sigma, ls);
             q.z[i] = zv;
             q.kl_elem[i] = kl;
@@ -1225,7 +1225,7 @@ int eval_mlp(hipStream_t s, const EvalMlpArgs& q) {
     if (op.kind == EM_MU) SCVAE_ARG(o + 1 < q.n_ops && q.op[o + 1].kind == EM_LOG_SIGMA);
     if (op.kind == EM_LOG_SIGMA) {
       SCVAE_ARG(o >= 1 && q.op[o - 1].kind == EM_MU && q.op[o - 1].N == op.N && op.N == q.L);
-      SCVAE_ARG(q.eps && q.z && q.kl_elem && q.kl_cell);
+      SCVAE_ARG(q.z && q.kl_elem && q.kl_cell);
       K = q.L; ++n_ls;
     }
   }

@@ -24,15 +24,17 @@ import json, sys
 import numpy as np, torch
 from scvae_amd.engine import Engine
 dev = torch.device("cuda:0")
-cases = [  # cells, genes, hidden, latent, likelihood
+cases = [  # cells, genes, hidden, latent, likelihood (a sixth element: deterministic z)
     (300, 500, (100, 100), 25, "negative binomial"),
+    (500, 400, (100, 100), 25, "negative binomial", True),
     (4096, 2000, (100, 100), 25, "negative binomial"),
     (129, 300, (64,), 7, "poisson"),
     (1000, 700, (128, 96, 32), 100, "zero-inflated negative binomial"),
     (777, 640, (33, 17), 128, "negative binomial"),
 ]
 report = []
-for cells, F, hidden, L, likelihood in cases:
+for cells, F, hidden, L, likelihood, *more in cases:
+    deterministic = bool(more and more[0])
     rng = np.random.default_rng(cells + F)          # (host draws: the same in both processes)
     eng = Engine(F, L, hidden, likelihood, batch_norm=True, device=dev, seed=3)
     eng.reserve(cells, 1)
@@ -44,7 +46,8 @@ for cells, F, hidden, L, likelihood in cases:
     eps = torch.from_numpy(rng.standard_normal((1, cells, L)).astype(np.float32)).to(dev)
     out = {"q_z_mean": torch.empty(cells, L, device=dev),
            "kl_neurons": torch.empty(L, device=dev)}
-    scalars = eng.step(x, x, eps=eps, training=False, outputs=out, x_counts=True).clone()
+    scalars = eng.step(x, x, eps=eps, training=False, outputs=out, x_counts=True,
+                       deterministic_z=deterministic).clone()
     torch.cuda.synchronize()
     report.append({"scalars": scalars.cpu().double().tolist(),
                    "q_z_mean": out["q_z_mean"].cpu().double().numpy().ravel().tolist()[:4000],
@@ -64,7 +67,7 @@ def _run(flag):
 
 def test_evaluation_step_in_one_launch_equals_the_launch_chain(cuda_device):
     launches, one = _run("0"), _run("1")
-    assert len(launches) == len(one) == 5
+    assert len(launches) == len(one) == 6
     for a, b in zip(launches, one):
         sa, sb = np.array(a["scalars"]), np.array(b["scalars"])
         assert np.isfinite(sb).all()
