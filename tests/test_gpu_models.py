@@ -600,3 +600,50 @@ def test_noisy_preprocessing_draws_the_data_set_anew_every_epoch(tmp_path, cuda_
     values = np.asarray(values.todense() if hasattr(values, "todense") else values)
     assert set(np.unique(values)) <= {0.0, 1.0}
     assert reconstructed.values.shape == (test_set.number_of_examples, F)
+
+
+def test_resident_evaluation_set_is_the_fetched_one(tmp_path, cuda_device, capsys):
+    """The epoch-end passes over a count matrix keep the uint16 rows of the first
+    epoch on the device and read them as views in every later one
+    (``_evaluation_resident``; va:1092-1150 evaluates the same sequential
+    minibatches every epoch): the learning curves are those of passes that
+    fetch every minibatch again, bit for bit (deterministic steps)."""
+    from scvae_amd.data import DataSet
+    from scvae_amd.models import VariationalAutoencoder
+    from scvae_amd.models.utilities import load_learning_curves
+    import scipy.sparse
+    rng = np.random.default_rng(5)
+    n, n_valid, F = 3072, 1024, 32738
+    values = scipy.sparse.random(n + n_valid, F, density=0.02, format="csr", random_state=7,
+                                 data_rvs=lambda k: rng.integers(1, 9, k).astype(np.float32))
+    values = values.astype(np.float32)
+
+    def subset(rows, kind, first):
+        return DataSet("toy", values=rows, kind=kind,
+                       example_names=np.arange(first, first + rows.shape[0]).astype(str),
+                       feature_names=np.arange(F).astype(str))
+    curves = []
+    for name, resident_bytes in (("resident", VariationalAutoencoder.evaluation_resident_bytes),
+                                 ("fetched", 0)):
+        # three steps of 1024 cells per pass over the training set (each carries the next
+        # one's fetch), one over the validation set
+        training_set = subset(values[:n], "training", 0)
+        validation_set = subset(values[n:], "validation", n)
+        model = VariationalAutoencoder(
+            feature_size=F, latent_size=5, hidden_sizes=[32],
+            reconstruction_distribution="negative binomial",
+            log_directory=str(tmp_path / name))
+        model.evaluation_chunk_cells = 1024
+        model.evaluation_resident_bytes = resident_bytes
+        np.random.seed(77)
+        assert model.train(training_set, validation_set, number_of_epochs=3,
+                           minibatch_size=1024, learning_rate=1e-3, deterministic=True) == 0
+        got = load_learning_curves(model)
+        curves.append((got["training"]["lower_bound"], got["validation"]["lower_bound"]))
+        if name == "resident":
+            assert model._evaluation_resident_hits == 2 * (3 + 1)   # epochs 2 and 3: every step
+        else:
+            assert model._evaluation_resident_hits == 0
+    capsys.readouterr()
+    for a, b in zip(curves[0], curves[1]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
