@@ -657,6 +657,30 @@ def evaluation_step(matrix, device, batch, steps=60):
     e1.record()
     torch.cuda.synchronize(device)
     ms = e0.elapsed_time(e1) / steps
+    # ... and as the epoch-end passes of model.train run it from their second epoch on: the
+    # set's uint16 rows are resident (models/base.py: _evaluation_resident), a step reads a view
+    resident_ms = None
+    if u16:
+        blocks = min(n // batch, 4)
+        dense = torch.empty(blocks * batch, matrix.u16_pitch, dtype=torch.uint16, device=device)
+        constants = torch.empty(blocks * batch, device=device)
+        matrix.gather_counts_u16(rows[:blocks * batch], out=dense, row_const_out=constants)
+
+        def resident_step(i):
+            lo = (i % blocks) * batch
+            view = dense[lo:lo + batch]
+            eng.step(view, view, eps=eps, row_const=constants[lo:lo + batch], training=False,
+                     x_counts=True)
+        for i in range(10):
+            resident_step(i)
+        torch.cuda.synchronize(device)
+        e0.record()
+        for i in range(steps):
+            resident_step(i)
+        e1.record()
+        torch.cuda.synchronize(device)
+        resident_ms = e0.elapsed_time(e1) / steps
+        del dense, constants
     del eng
     torch.cuda.empty_cache()
     return {"workload": "evaluation step (is_training = False) of the headline model: fetch + "
@@ -664,7 +688,10 @@ def evaluation_step(matrix, device, batch, steps=60):
                                                                  LATENT),
             "cells_per_step": batch, "steps": steps, "ms_per_step": ms,
             "minibatch_storage": "u16" if u16 else "f32",
-            "value": batch / ms * 1e3, "unit": "cells/s"}
+            "value": batch / ms * 1e3, "unit": "cells/s",
+            "ms_per_step_resident_rows": resident_ms,
+            "resident_rows_note": "the same step on rows already dense on the device (what the "
+                                  "epoch-end passes of model.train read after the first epoch)"}
 
 
 def categorised_step(matrix, device, batch, k, steps=12):
